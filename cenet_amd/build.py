@@ -1,0 +1,55 @@
+"""Builds libcenet_hip.so (hipcc, gfx950) in-tree.  `python -m cenet_amd.build`."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcenet_hip.so")
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = True) -> str:
+    """hipcc --offload-arch=gfx950 -> cenet_amd/libcenet_hip.so (cross-compiles without a GPU)."""
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "cenet_hip.h")]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "csrc", "obj"), exist_ok=True)
+    for src in sources():
+        obj = os.path.join(HERE, "csrc", "obj", os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + deps[len(sources()):]):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
+                   "-Wno-unused-result"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    failed = [s for s, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed for {failed}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_hip(force="--force" in sys.argv)
+    print(LIB)

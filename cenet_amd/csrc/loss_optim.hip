@@ -1,0 +1,182 @@
+// loss_optim.hip — Dice + cross-entropy loss (forward/backward) and the fused SGD-momentum update.
+//   Criterion / DiceLoss / CrossEntropyLoss   utils/core.py:44-80,161-188
+//   SGD(momentum 0.9, weight decay)           utils/core.py:19-21 (torch.optim.SGD semantics)
+// The loss never leaves the device: per-class Dice sums (over the WHOLE batch, as the reference does) and the CE sum
+// are reduced with block partials + float atomics into a small accumulator that the backward kernel re-reads.
+#include "common.h"
+#include "../../include/cenet_hip.h"
+
+#define LOSS_MAXK 16
+
+// acc layout: [0..K) intersect, [K..2K) z_sum (p^2), [2K..3K) y_sum (t), [3K] ce_sum
+__global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                         float* __restrict__ acc, int K, int HW, long npix) {
+  __shared__ float red[16];
+  float part[3 * LOSS_MAXK + 1];
+#pragma unroll
+  for (int i = 0; i < 3 * LOSS_MAXK + 1; ++i) part[i] = 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
+    const long b = e / HW;
+    const int p = (int)(e - b * HW);
+    const float* lp = logits + b * (long)K * HW + p;
+    float v[LOSS_MAXK];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int c = 0; c < LOSS_MAXK; ++c)
+      if (c < K) {
+        v[c] = lp[(long)c * HW];
+        mx = fmaxf(mx, v[c]);
+      }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LOSS_MAXK; ++c)
+      if (c < K) {
+        v[c] = expf(v[c] - mx);
+        s += v[c];
+      }
+    const float inv = 1.f / s;
+    const int t = (int)labels[e];
+#pragma unroll
+    for (int c = 0; c < LOSS_MAXK; ++c)
+      if (c < K) {
+        const float pc = v[c] * inv;
+        part[LOSS_MAXK + c] += pc * pc;
+        if (c == t) {
+          part[c] += pc;
+          part[2 * LOSS_MAXK + c] += 1.f;
+          part[3 * LOSS_MAXK] -= logf(fmaxf(pc, 1e-37f));
+        }
+      }
+  }
+  for (int c = 0; c < K; ++c) {
+    float a0 = block_sum(part[c], red), a1 = block_sum(part[LOSS_MAXK + c], red), a2 = block_sum(part[2 * LOSS_MAXK + c], red);
+    if (threadIdx.x == 0) {
+      atomicAdd(&acc[c], a0);
+      atomicAdd(&acc[K + c], a1);
+      atomicAdd(&acc[2 * K + c], a2);
+    }
+  }
+  float ce = block_sum(part[3 * LOSS_MAXK], red);
+  if (threadIdx.x == 0) atomicAdd(&acc[3 * K], ce);
+}
+
+__global__ void dice_ce_finalize_kernel(const float* __restrict__ acc, float* __restrict__ loss, int K, float npix,
+                                        float w_dice, float w_ce) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float d = 0.f;
+    for (int c = 0; c < K; ++c) d += 1.f - (2.f * acc[c] + 1e-5f) / (acc[K + c] + acc[2 * K + c] + 1e-5f);
+    loss[0] = w_dice * d / K + w_ce * acc[3 * K] / npix;
+  }
+}
+
+__global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                         const float* __restrict__ acc, const float* __restrict__ gout,
+                                                         float* __restrict__ dlogits, int K, int HW, long npix, float w_dice,
+                                                         float w_ce) {
+  const float go = gout[0];
+  float A[LOSS_MAXK], Bc[LOSS_MAXK];  // dL/dp_c = A_c * t_c + Bc_c * p_c
+#pragma unroll
+  for (int c = 0; c < LOSS_MAXK; ++c)
+    if (c < K) {
+      const float D = acc[K + c] + acc[2 * K + c] + 1e-5f;
+      const float num = 2.f * acc[c] + 1e-5f;
+      A[c] = -w_dice / K * 2.f / D;
+      Bc[c] = w_dice / K * num * 2.f / (D * D);
+    }
+  const float cew = w_ce / (float)npix;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
+    const long b = e / HW;
+    const int p = (int)(e - b * HW);
+    const float* lp = logits + b * (long)K * HW + p;
+    float* dp = dlogits + b * (long)K * HW + p;
+    float v[LOSS_MAXK];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int c = 0; c < LOSS_MAXK; ++c)
+      if (c < K) {
+        v[c] = lp[(long)c * HW];
+        mx = fmaxf(mx, v[c]);
+      }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LOSS_MAXK; ++c)
+      if (c < K) {
+        v[c] = expf(v[c] - mx);
+        s += v[c];
+      }
+    const float inv = 1.f / s;
+    const int t = (int)labels[e];
+    float gp[LOSS_MAXK];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < LOSS_MAXK; ++c)
+      if (c < K) {
+        v[c] *= inv;
+        gp[c] = Bc[c] * v[c] + (c == t ? A[c] : 0.f);
+        dot += gp[c] * v[c];
+      }
+#pragma unroll
+    for (int c = 0; c < LOSS_MAXK; ++c)
+      if (c < K) dp[(long)c * HW] = go * (v[c] * (gp[c] - dot) + cew * (v[c] - (c == t ? 1.f : 0.f)));
+  }
+}
+
+// p -= lr * buf, buf = momentum*buf + (g*gscale + wd*p)   (first step: buf = g*gscale + wd*p)
+// hyper (device): [lr, momentum, weight_decay, gscale, first_step_flag]
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                 const float* __restrict__ hyper, long n) {
+  const float lr = hyper[0], mom = hyper[1], wd = hyper[2], gs = hyper[3];
+  const bool first = hyper[4] != 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pv = p[i];
+    const float d = g[i] * gs + wd * pv;
+    const float bv = first ? d : mom * buf[i] + d;
+    buf[i] = bv;
+    p[i] = pv - lr * bv;
+  }
+}
+
+extern "C" int cenet_dice_ce_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int HW,
+                                     float w_dice, float w_ce, hipStream_t stream) {
+  if (B <= 0 || K <= 0 || K > LOSS_MAXK || HW <= 0) return CENET_EINVAL;
+#ifdef CENET_HOSTSIM_BUILD
+  memset(acc, 0, sizeof(float) * (3 * K + 1));
+#else
+  if (hipMemsetAsync(acc, 0, sizeof(float) * (3 * K + 1), stream) != hipSuccess) return CENET_EINVAL;
+#endif
+  const long npix = (long)B * HW;
+  long blocks = (npix + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  CENET_LAUNCH(dice_ce_fwd_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix);
+  CENET_LAUNCH(dice_ce_finalize_kernel, dim3(1), dim3(64), stream, (const float*)acc, loss, K, (float)npix, w_dice, w_ce);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_dice_ce_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout,
+                                     float* dlogits, int B, int K, int HW, float w_dice, float w_ce, hipStream_t stream) {
+  if (B <= 0 || K <= 0 || K > LOSS_MAXK || HW <= 0) return CENET_EINVAL;
+  const long npix = (long)B * HW;
+  long blocks = (npix + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  CENET_LAUNCH(dice_ce_bwd_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix,
+               w_dice, w_ce);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, hipStream_t stream) {
+  if (n <= 0) return CENET_EINVAL;
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  CENET_LAUNCH(sgd_kernel, dim3((unsigned)blocks), dim3(256), stream, p, g, buf, hyper5, n);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_zero_f32(float* p, long n, hipStream_t stream) {
+  if (n <= 0) return CENET_EINVAL;
+#ifdef CENET_HOSTSIM_BUILD
+  memset(p, 0, sizeof(float) * n);
+#else
+  if (hipMemsetAsync(p, 0, sizeof(float) * n, stream) != hipSuccess) return CENET_EINVAL;
+#endif
+  return CENET_OK;
+}

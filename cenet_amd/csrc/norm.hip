@@ -1,0 +1,295 @@
+// norm.hip — LayerNorm (token layout) and train-mode BatchNorm (NCHW planes) forward/backward.
+//   LayerNorm : pvtv2.py:117,124,166,69,221-245 (eps 1e-6 in blocks, 1e-5 in patch-embed / sr norm)
+//   BatchNorm : cfam.py:22-32, blocks.py:151,161,212,307, nlb.py:81, unet.py:175-197, cfam.py:92,250
+// All statistics in fp32; BN batch statistics use per-channel shifted sums (shift = first element) so that
+// E[x^2]-E[x]^2 does not cancel; partial sums from several workgroups per channel meet in float atomics.
+#include "common.h"
+#include "../../include/cenet_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, 4 rows per 256-thread workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y,
+                                                           float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                           int C, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;  // wave-uniform
+  const float* xr = x + row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mu = wave_sum(s) / C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float d = xr[c] - mu;
+    v += d * d;
+  }
+  const float rs = rsqrtf(wave_sum(v) / C + eps);
+  float* yr = y + row * C;
+  for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+#define LN_MAXJ 8  // C <= 512
+#define LN_ROWS_PER_BLOCK 64
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ dx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int rows, int C) {
+  __shared__ float red[2][4][LN_MAXJ * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float dg[LN_MAXJ], db[LN_MAXJ], gm[LN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    dg[j] = 0.f;
+    db[j] = 0.f;
+    int c = lane + 64 * j;
+    gm[j] = c < C ? gamma[c] : 0.f;
+  }
+  const long r0 = (long)blockIdx.x * LN_ROWS_PER_BLOCK;
+  for (int i = wave; i < LN_ROWS_PER_BLOCK; i += 4) {
+    const long row = r0 + i;
+    if (row >= rows) break;  // wave-uniform
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + row * C;
+    const float* gr = dy + row * C;
+    float xh[LN_MAXJ], g[LN_MAXJ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      int c = lane + 64 * j;
+      if (c < C) {
+        xh[j] = (xr[c] - mu) * rs;
+        g[j] = gr[c];
+      } else {
+        xh[j] = 0.f;
+        g[j] = 0.f;
+      }
+      float gg = g[j] * gm[j];
+      s1 += gg;
+      s2 += gg * xh[j];
+      dg[j] += g[j] * xh[j];
+      db[j] += g[j];
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+    float* dxr = dx + row * C;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      int c = lane + 64 * j;
+      if (c < C) dxr[c] = rs * (g[j] * gm[j] - s1 - xh[j] * s2);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    red[0][wave][j * 64 + lane] = dg[j];
+    red[1][wave][j * 64 + lane] = db[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomicAdd(&dgamma[c], a);
+    atomicAdd(&dbeta[c], b);
+  }
+}
+
+extern "C" int cenet_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                       float* rstd, int rows, int C, float eps, hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+extern "C" int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                           const float* rstd, float* dx, float* dgamma_acc, float* dbeta_acc, int rows,
+                                           int C, hipStream_t stream) {
+  if (rows <= 0 || C <= 0) return CENET_EINVAL;
+  if (C > LN_MAXJ * 64) return CENET_EUNSUPPORTED;
+  CENET_LAUNCH(layernorm_bwd_kernel, dim3(cdiv(rows, LN_ROWS_PER_BLOCK)), dim3(256), stream, dy, x, gamma, mean, rstd, dx,
+               dgamma_acc, dbeta_acc, rows, C);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm (training): statistics over (B, HW) per channel of x[b*sb + c*HW + p].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, long sb, int B, int HW,
+                                                        float* __restrict__ ws) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const float* xc = x + (long)c * HW;
+  const float shift = xc[0];
+  const long total = (long)B * HW;
+  float s1 = 0.f, s2 = 0.f;
+  for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
+    int b = (int)(e / HW);
+    int p = (int)(e - (long)b * HW);
+    float v = xc[(long)b * sb + p] - shift;
+    s1 += v;
+    s2 += v * v;
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[2 * c], s1);
+    atomicAdd(&ws[2 * c + 1], s2);
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ x, int HW, const float* __restrict__ ws, int C, float n,
+                                   float* __restrict__ mean, float* __restrict__ var, float* running_mean,
+                                   float* running_var, float momentum, long* nbt) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float shift = x[(long)c * HW];
+    float m = ws[2 * c] / n;
+    float v = ws[2 * c + 1] / n - m * m;
+    if (v < 0.f) v = 0.f;
+    float mu = shift + m;
+    mean[c] = mu;
+    var[c] = v;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * v * (n / (n - 1.f));
+    }
+  }
+  if (c == 0 && nbt) nbt[0] += 1;
+}
+
+// y = act(gamma*(x-mean)*rsqrt(var+eps)+beta); grid (B*C, chunks)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long sxb, float* __restrict__ y, long syb,
+                                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                                      float eps, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int act, float slope, int C, int HW) {
+  const int bc = blockIdx.x;
+  const int b = bc / C, c = bc - b * C;
+  const float sc = gamma[c] * rsqrtf(var[c] + eps);
+  const float sh = beta[c] - mean[c] * sc;
+  const float* xp = x + (long)b * sxb + (long)c * HW;
+  float* yp = y + (long)b * syb + (long)c * HW;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) yp[p] = act_fwd(act, xp[p] * sc + sh, slope);
+}
+
+// partial sums of g' = dy*act'(pre) and g'*xhat per channel
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, long sgb,
+                                                            const float* __restrict__ x, long sxb,
+                                                            const float* __restrict__ mean, const float* __restrict__ var,
+                                                            float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int act, float slope, int B,
+                                                            int HW, float* __restrict__ ws) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
+  const long total = (long)B * HW;
+  float s1 = 0.f, s2 = 0.f;
+  for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
+    int b = (int)(e / HW);
+    int p = (int)(e - (long)b * HW);
+    float xh = (x[(long)b * sxb + (long)c * HW + p] - mu) * rs;
+    float g = dy[(long)b * sgb + (long)c * HW + p];
+    if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
+    s1 += g;
+    s2 += g * xh;
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[2 * c], s1);
+    atomicAdd(&ws[2 * c + 1], s2);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, long sgb, const float* __restrict__ x,
+                                                          long sxb, float* __restrict__ dx, long sdb,
+                                                          const float* __restrict__ mean, const float* __restrict__ var,
+                                                          float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int act, float slope, int C, int HW,
+                                                          float n, const float* __restrict__ ws, float* dgamma,
+                                                          float* dbeta) {
+  const int bc = blockIdx.x;
+  const int b = bc / C, c = bc - b * C;
+  const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
+  const float s1 = ws[2 * c], s2 = ws[2 * c + 1];
+  const float m1 = s1 / n, m2 = s2 / n;
+  const float* xp = x + (long)b * sxb + (long)c * HW;
+  const float* gp = dy + (long)b * sgb + (long)c * HW;
+  float* dp = dx + (long)b * sdb + (long)c * HW;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) {
+    float xh = (xp[p] - mu) * rs;
+    float g = gp[p];
+    if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
+    dp[p] = gm * rs * (g - m1 - xh * m2);
+  }
+  if (b == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    atomicAdd(&dgamma[c], s2);
+    atomicAdd(&dbeta[c], s1);
+  }
+}
+
+static inline int bn_splits(int C, long total) {
+  long want = 1024 / (C > 0 ? C : 1);
+  long maxs = (total + 2047) / 2048;
+  if (want < 1) want = 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  return (int)want;
+}
+
+extern "C" int cenet_bn_stats_f32(const float* x, long sb, int B, int C, int HW, float* ws, float* mean, float* var,
+                                  float* running_mean, float* running_var, float momentum, long* num_batches_tracked,
+                                  hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+#ifdef CENET_HOSTSIM_BUILD
+  memset(ws, 0, sizeof(float) * 2 * C);
+#else
+  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, stream) != hipSuccess) return CENET_EINVAL;
+#endif
+  const long total = (long)B * HW;
+  CENET_LAUNCH(bn_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, x, sb, B, HW, ws);
+  CENET_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), stream, x, HW, (const float*)ws, C, (float)total, mean, var,
+               running_mean, running_var, momentum, num_batches_tracked);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+extern "C" int cenet_bn_apply_f32(const float* x, long sxb, float* y, long syb, const float* mean, const float* var,
+                                  float eps, const float* gamma, const float* beta, int act, float slope, int B, int C,
+                                  int HW, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  int chunks = cdiv(HW, 1024);
+  if (chunks > 64) chunks = 64;
+  CENET_LAUNCH(bn_apply_kernel, dim3(B * C, chunks), dim3(256), stream, x, sxb, y, syb, mean, var, eps, gamma, beta, act,
+               slope, C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+extern "C" int cenet_bn_bwd_acc_f32(const float* dy, long sgb, const float* x, long sxb, float* dx, long sdb,
+                                    const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                                    int act, float slope, int B, int C, int HW, float* ws, float* dgamma_acc,
+                                    float* dbeta_acc, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+#ifdef CENET_HOSTSIM_BUILD
+  memset(ws, 0, sizeof(float) * 2 * C);
+#else
+  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, stream) != hipSuccess) return CENET_EINVAL;
+#endif
+  const long total = (long)B * HW;
+  CENET_LAUNCH(bn_bwd_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma,
+               beta, act, slope, B, HW, ws);
+  int chunks = cdiv(HW, 1024);
+  if (chunks > 64) chunks = 64;
+  CENET_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma,
+               beta, act, slope, C, HW, (float)total, (const float*)ws, dgamma_acc, dbeta_acc);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}

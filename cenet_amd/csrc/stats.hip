@@ -1,0 +1,375 @@
+// stats.hip — the two "style statistics" gates of the CFAM decoder (HBM-bound full-tensor reductions).
+//   CCU  : per-(b,c) plane [max, mean, std(biased)] -> grouped conv1d k3 -> ReLU -> k1 -> (BN1d) -> sigmoid gate
+//          cfam.py:251-264
+//   SRM  : per-pixel channel [max, mean, std(unbiased)] -> 1x1 + 3x3 conv (3->1) -> GELU -> BN(1) -> sigmoid gate
+//          cfam.py:93-101
+// The BN steps in the middle reuse the generic BatchNorm kernels of norm.hip; the kernels here do the
+// reductions, the tiny per-channel MLP / 3->1 conv, and the scatter of the statistic gradients back onto x.
+#include "common.h"
+#include "../../include/cenet_hip.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// CCU forward: grid (B*C); u[bc*3+{0,1,2}] = max, mean, std ; amax[bc] = argmax ; z[bc] = fc2(relu(fc1(u)))
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ccu_stats_fwd_kernel(const float* __restrict__ x, const float* __restrict__ fc1,
+                                                           const float* __restrict__ fc2, float* __restrict__ u,
+                                                           int* __restrict__ amax, float* __restrict__ z, int C, int HW) {
+  __shared__ float red[16];
+  __shared__ float rv[4];
+  __shared__ int ri[4];
+  const int bc = blockIdx.x, c = bc % C;
+  const float* xp = x + (long)bc * HW;
+  float s = 0.f, mx = -3.4e38f;
+  int mi = 0;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    float v = xp[p];
+    s += v;
+    if (v > mx) {
+      mx = v;
+      mi = p;
+    }
+  }
+  const float mean = block_sum(s, red) / HW;
+  float q = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    float d = xp[p] - mean;
+    q += d * d;
+  }
+  const float var = block_sum(q, red) / HW;
+  // arg-max: wave reduce (value, smallest index on ties), then across waves
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(mx, o);
+    int oi = __shfl_xor(mi, o);
+    if (ov > mx || (ov == mx && oi < mi)) {
+      mx = ov;
+      mi = oi;
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) {
+    rv[wave] = mx;
+    ri[wave] = mi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (rv[w] > mx || (rv[w] == mx && ri[w] < mi)) {
+        mx = rv[w];
+        mi = ri[w];
+      }
+    const float sd = sqrtf(var);
+    u[bc * 3 + 0] = mx;
+    u[bc * 3 + 1] = mean;
+    u[bc * 3 + 2] = sd;
+    amax[bc] = mi;
+    float zz = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float* w1 = fc1 + (c * 3 + j) * 3;
+      float hdn = w1[0] * mx + w1[1] * mean + w1[2] * sd;
+      if (hdn > 0.f) zz += fc2[c * 3 + j] * hdn;
+    }
+    z[bc] = zz;
+  }
+}
+
+// y = x * sigmoid(g[bc])
+__global__ __launch_bounds__(256) void gate_chan_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           float* __restrict__ y, int HW) {
+  const int bc = blockIdx.x;
+  const float s = sigmoid_f(g[bc]);
+  const float* xp = x + (long)bc * HW;
+  float* yp = y + (long)bc * HW;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) yp[p] = xp[p] * s;
+}
+
+// dg[bc] = sigmoid'(g) * sum_p dy*x    (grid B*C)
+__global__ __launch_bounds__(256) void gate_chan_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  const float* __restrict__ g, float* __restrict__ dg,
+                                                                  int HW) {
+  __shared__ float red[16];
+  const int bc = blockIdx.x;
+  const float* xp = x + (long)bc * HW;
+  const float* gp = dy + (long)bc * HW;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) s += xp[p] * gp[p];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    float sg = sigmoid_f(g[bc]);
+    dg[bc] = s * sg * (1.f - sg);
+  }
+}
+
+// CCU backward apply (grid B*C): from dz[bc] (grad of the pre-BN MLP output) rebuild du through the MLP, accumulate
+// fc1/fc2 gradients, and write dx = dy*sigmoid(g) + du_max*[p==amax] + du_mean/HW + du_std*(x-mean)/(HW*std)
+__global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ g, const float* __restrict__ dz,
+                                                           const float* __restrict__ u, const int* __restrict__ amax,
+                                                           const float* __restrict__ fc1, const float* __restrict__ fc2,
+                                                           float* __restrict__ dfc1, float* __restrict__ dfc2,
+                                                           float* __restrict__ dx, int C, int HW) {
+  __shared__ float du_s[3];
+  const int bc = blockIdx.x, c = bc % C;
+  if (threadIdx.x == 0) {
+    const float mx = u[bc * 3], mean = u[bc * 3 + 1], sd = u[bc * 3 + 2];
+    const float gz = dz[bc];
+    float du[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float* w1 = fc1 + (c * 3 + j) * 3;
+      const float hdn = w1[0] * mx + w1[1] * mean + w1[2] * sd;
+      const float w2 = fc2[c * 3 + j];
+      if (hdn > 0.f) {
+        atomicAdd(&dfc2[c * 3 + j], gz * hdn);
+        const float gh = gz * w2;
+        atomicAdd(&dfc1[(c * 3 + j) * 3 + 0], gh * mx);
+        atomicAdd(&dfc1[(c * 3 + j) * 3 + 1], gh * mean);
+        atomicAdd(&dfc1[(c * 3 + j) * 3 + 2], gh * sd);
+        du[0] += gh * w1[0];
+        du[1] += gh * w1[1];
+        du[2] += gh * w1[2];
+      }
+    }
+    du_s[0] = du[0];
+    du_s[1] = du[1];
+    du_s[2] = du[2];
+  }
+  __syncthreads();
+  const float sg = sigmoid_f(g[bc]);
+  const float mean = u[bc * 3 + 1], sd = u[bc * 3 + 2];
+  const int am = amax[bc];
+  const float dmax = du_s[0], dmean = du_s[1] / HW, dstd = du_s[2] / (HW * sd);
+  const float* xp = x + (long)bc * HW;
+  const float* gp = dy + (long)bc * HW;
+  float* dp = dx + (long)bc * HW;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    float v = gp[p] * sg + dmean + dstd * (xp[p] - mean);
+    if (p == am) v += dmax;
+    dp[p] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SRM: channel statistics per pixel. x [B, C, HW]; u [B, 3, HW]; amax [B, HW]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void srm_stats_fwd_kernel(const float* __restrict__ x, float* __restrict__ u,
+                                                           int* __restrict__ amax, int C, int HW) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float* xb = x + (long)b * C * HW + p;
+  float s = 0.f, mx = -3.4e38f;
+  int mi = 0;
+  for (int c = 0; c < C; ++c) {
+    float v = xb[(long)c * HW];
+    s += v;
+    if (v > mx) {
+      mx = v;
+      mi = c;
+    }
+  }
+  const float mean = s / C;
+  float q = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float d = xb[(long)c * HW] - mean;
+    q += d * d;
+  }
+  float* ub = u + (long)b * 3 * HW + p;
+  ub[0] = mx;
+  ub[HW] = mean;
+  ub[2 * HW] = sqrtf(q / (C - 1));
+  amax[(long)b * HW + p] = mi;
+}
+
+// f[b,p] = pwc(u) + dwc(u): 3->1 1x1 plus 3->1 3x3 (pad 1), no bias
+__global__ __launch_bounds__(256) void srm_conv_fwd_kernel(const float* __restrict__ u, const float* __restrict__ pwc,
+                                                          const float* __restrict__ dwc, float* __restrict__ f, int H, int W) {
+  const int b = blockIdx.y, HW = H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int py = p / W, px = p - py * W;
+  const float* ub = u + (long)b * 3 * HW;
+  float acc = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    acc += pwc[ch] * ub[ch * HW + p];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = py + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = px + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        acc += dwc[ch * 9 + ky * 3 + kx] * ub[ch * HW + iy * W + ix];
+      }
+    }
+  }
+  f[(long)b * HW + p] = acc;
+}
+
+// du[b,ch,p] from df[b,p]; weight grads (3 + 27) accumulated with block partial sums + atomics
+__global__ __launch_bounds__(256) void srm_conv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ df,
+                                                          const float* __restrict__ pwc, const float* __restrict__ dwc,
+                                                          float* __restrict__ du, float* __restrict__ dpwc,
+                                                          float* __restrict__ ddwc, int H, int W) {
+  __shared__ float red[16];
+  const int b = blockIdx.y, HW = H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = p < HW;
+  const int py = valid ? p / W : 0, px = valid ? p - py * W : 0;
+  const float* ub = u + (long)b * 3 * HW;
+  const float* gb = df + (long)b * HW;
+  const float g = valid ? gb[p] : 0.f;
+  for (int ch = 0; ch < 3; ++ch) {
+    // data gradient (correlation with flipped taps)
+    float acc = pwc[ch] * g;
+    float wg[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int t = ky * 3 + kx;
+        wg[t] = 0.f;
+        if (!valid) continue;
+        // du[p] += dwc[t] * df[p - off_t]  ;  ddwc[t] += df[p] * u[p + off_t]
+        const int qy = py - (ky - 1), qx = px - (kx - 1);
+        if (qy >= 0 && qy < H && qx >= 0 && qx < W) acc += dwc[ch * 9 + t] * gb[qy * W + qx];
+        const int iy = py + ky - 1, ix = px + kx - 1;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) wg[t] = g * ub[ch * HW + iy * W + ix];
+      }
+    if (valid) du[(long)b * 3 * HW + ch * HW + p] = acc;
+    float sp = block_sum(valid ? g * ub[ch * HW + p] : 0.f, red);
+    if (threadIdx.x == 0) atomicAdd(&dpwc[ch], sp);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float sw = block_sum(wg[t], red);
+      if (threadIdx.x == 0) atomicAdd(&ddwc[ch * 9 + t], sw);
+    }
+  }
+}
+
+// y[b,c,p] = x[b,c,p] * sigmoid(f[b,p])
+__global__ __launch_bounds__(256) void gate_pix_fwd_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                                          float* __restrict__ y, int C, int HW) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float s = sigmoid_f(f[(long)b * HW + p]);
+  const long base = (long)b * C * HW + p;
+  for (int c = 0; c < C; ++c) y[base + (long)c * HW] = x[base + (long)c * HW] * s;
+}
+
+// df[b,p] = sigmoid'(f) * sum_c dy*x
+__global__ __launch_bounds__(256) void gate_pix_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const float* __restrict__ f, float* __restrict__ df, int C,
+                                                                 int HW) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const long base = (long)b * C * HW + p;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += x[base + (long)c * HW] * dy[base + (long)c * HW];
+  const float sg = sigmoid_f(f[(long)b * HW + p]);
+  df[(long)b * HW + p] = s * sg * (1.f - sg);
+}
+
+// dx = dy*sigmoid(f) + du_max*[c==amax] + du_mean/C + du_std*(x-mean)/((C-1)*std)
+__global__ __launch_bounds__(256) void srm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ f, const float* __restrict__ u,
+                                                           const float* __restrict__ du, const int* __restrict__ amax,
+                                                           float* __restrict__ dx, int C, int HW) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const float sg = sigmoid_f(f[(long)b * HW + p]);
+  const float* ub = u + (long)b * 3 * HW + p;
+  const float* db = du + (long)b * 3 * HW + p;
+  const float mean = ub[HW], sd = ub[2 * HW];
+  const float dmax = db[0], dmean = db[HW] / C, dstd = db[2 * HW] / ((C - 1) * sd);
+  const int am = amax[(long)b * HW + p];
+  const long base = (long)b * C * HW + p;
+  for (int c = 0; c < C; ++c) {
+    float v = dy[base + (long)c * HW] * sg + dmean + dstd * (x[base + (long)c * HW] - mean);
+    if (c == am) v += dmax;
+    dx[base + (long)c * HW] = v;
+  }
+}
+
+static inline int chunks_for(int n) {
+  int ch = cdiv(n, 1024);
+  return ch > 64 ? 64 : (ch < 1 ? 1 : ch);
+}
+
+extern "C" int cenet_ccu_stats_fwd_f32(const float* x, const float* fc1, const float* fc2, float* u, int* amax, float* z,
+                                       int B, int C, int HW, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(ccu_stats_fwd_kernel, dim3(B * C), dim3(256), stream, x, fc1, fc2, u, amax, z, C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_gate_chan_fwd_f32(const float* x, const float* g, float* y, int BC, int HW, hipStream_t stream) {
+  if (BC <= 0 || HW <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(gate_chan_fwd_kernel, dim3(BC, chunks_for(HW)), dim3(256), stream, x, g, y, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_gate_chan_bwd_reduce_f32(const float* x, const float* dy, const float* g, float* dg, int BC, int HW,
+                                              hipStream_t stream) {
+  if (BC <= 0 || HW <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(gate_chan_bwd_reduce_kernel, dim3(BC), dim3(256), stream, x, dy, g, dg, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_ccu_bwd_apply_acc_f32(const float* x, const float* dy, const float* g, const float* dz, const float* u,
+                                           const int* amax, const float* fc1, const float* fc2, float* dfc1_acc,
+                                           float* dfc2_acc, float* dx, int B, int C, int HW, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(ccu_bwd_apply_kernel, dim3(B * C), dim3(256), stream, x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc, dx,
+               C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_srm_stats_fwd_f32(const float* x, float* u, int* amax, int B, int C, int HW, hipStream_t stream) {
+  if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(srm_stats_fwd_kernel, dim3(cdiv(HW, 256), B), dim3(256), stream, x, u, amax, C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_srm_conv_fwd_f32(const float* u, const float* pwc, const float* dwc, float* f, int B, int H, int W,
+                                      hipStream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(srm_conv_fwd_kernel, dim3(cdiv(H * W, 256), B), dim3(256), stream, u, pwc, dwc, f, H, W);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_srm_conv_bwd_acc_f32(const float* u, const float* df, const float* pwc, const float* dwc, float* du,
+                                          float* dpwc_acc, float* ddwc_acc, int B, int H, int W, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(srm_conv_bwd_kernel, dim3(cdiv(H * W, 256), B), dim3(256), stream, u, df, pwc, dwc, du, dpwc_acc, ddwc_acc, H,
+               W);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_gate_pix_fwd_f32(const float* x, const float* f, float* y, int B, int C, int HW, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(gate_pix_fwd_kernel, dim3(cdiv(HW, 256), B), dim3(256), stream, x, f, y, C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_gate_pix_bwd_reduce_f32(const float* x, const float* dy, const float* f, float* df, int B, int C,
+                                             int HW, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(gate_pix_bwd_reduce_kernel, dim3(cdiv(HW, 256), B), dim3(256), stream, x, dy, f, df, C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_srm_bwd_apply_f32(const float* x, const float* dy, const float* f, const float* u, const float* du,
+                                       const int* amax, float* dx, int B, int C, int HW, hipStream_t stream) {
+  if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(srm_bwd_apply_kernel, dim3(cdiv(HW, 256), B), dim3(256), stream, x, dy, f, u, du, amax, dx, C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}

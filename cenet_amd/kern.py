@@ -1,0 +1,425 @@
+"""Thin, autograd-free Python bindings over the C ABI in include/cenet_hip.h.
+
+Every function here launches hand-written HIP kernels on the current torch stream with raw data pointers.
+Tensors must be fp32 and live on the GPU (the only exception is the tests' host-side SIMT checker, which
+swaps the library handle — see cenet_amd/_lib.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import EpiT, MatT
+
+ACT = {"none": 0, "relu": 1, "lrelu": 2, "gelu": 3, "silu": 4, "sigmoid": 5}
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.int64:
+            raise TypeError(f"cenet_amd kernels are fp32; got {t.dtype}")
+        if not t.is_cuda and not _lib.is_hostsim():
+            raise RuntimeError("cenet_amd kernels run on the MI355X only: tensor is not on a CUDA/HIP device "
+                               "(there is no CPU fallback)")
+
+
+def P(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream():
+    if _lib.is_hostsim():
+        return C.c_void_p(0)
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM / implicit GEMM
+# ------------------------------------------------------------------------------------------------
+def mat_plain(t: torch.Tensor, sr: int, sc: int, sb: int = 0, skb: int = 0, kfast: int = 0, offset: int = 0,
+              sb2: int = 0, kinner: int = 0, sk_outer: int = 0) -> MatT:
+    m = MatT()
+    m.ptr = t.data_ptr() + 4 * offset
+    m.sb, m.sb2, m.skb, m.sr, m.sc = sb, sb2, skb, sr, sc
+    m.kinner, m.sk_outer = kinner, sk_outer
+    m.mode, m.kfast = 0, kfast
+    return m
+
+
+def mat_im2col(t: torch.Tensor, *, sb: int, skb: int, sci: int, sy: int, sx: int, KH: int, KW: int, Pw: int,
+               Hs: int, Ws: int, stride: int, pad: int, dil: int, patch_is_row: int, transposed: int,
+               kfast: int, offset: int = 0) -> MatT:
+    m = MatT()
+    m.ptr = t.data_ptr() + 4 * offset
+    m.sb, m.skb, m.sr, m.sc = sb, skb, 0, 0
+    m.mode, m.kfast = 1, kfast
+    m.patch_is_row, m.transposed = patch_is_row, transposed
+    m.KH, m.KW, m.Pw, m.Hs, m.Ws = KH, KW, Pw, Hs, Ws
+    m.stride, m.pad, m.dil = stride, pad, dil
+    m.sci, m.sy, m.sx = sci, sy, sx
+    return m
+
+
+def pick_splits(M: int, N: int, nbatch: int, iters: int, target_blocks: int = 1024) -> int:
+    blocks = ((M + 63) // 64) * ((N + 63) // 64) * nbatch
+    if blocks >= target_blocks or iters <= 4:
+        return 1
+    return max(1, min(iters // 2, (target_blocks + blocks - 1) // blocks, 256))
+
+
+def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: int, scc: int, scb: int = 0,
+         nbatch: int = 1, nkb: int = 1, splits: int = 1, bias: Optional[torch.Tensor] = None, bias_on_row: bool = False,
+         act: str = "none", slope: float = 0.0, bscale: Optional[torch.Tensor] = None,
+         R: Optional[torch.Tensor] = None, srb: int = 0, srr: int = 0, src: int = 0, atomic: bool = False,
+         alpha: float = 1.0, c_offset: int = 0, r_offset: int = 0, nb_inner: int = 1, scb2: int = 0, srb2: int = 0):
+    _chk(Cout, bias, bscale, R)
+    e = EpiT()
+    e.C = Cout.data_ptr() + 4 * c_offset
+    e.scb, e.scb2, e.scr, e.scc = scb, scb2, scr, scc
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.bias_on_row = int(bias_on_row)
+    e.act, e.slope = ACT[act], slope
+    e.bscale = bscale.data_ptr() if bscale is not None else None
+    e.R = (R.data_ptr() + 4 * r_offset) if R is not None else None
+    e.srb, e.srb2, e.srr, e.src = srb, srb2, srr, src
+    e.atomic, e.alpha = int(atomic), alpha
+    rc = _lib.lib().cenet_gemm_f32(C.byref(A), C.byref(B), C.byref(e), M, N, K, nbatch, nb_inner, nkb, splits, stream())
+    _lib.check(rc, "cenet_gemm_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# generic call helper
+# ------------------------------------------------------------------------------------------------
+def _call(name, *args):
+    cargs = []
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            cargs.append(C.c_void_p(a.data_ptr()))
+        elif a is None:
+            cargs.append(C.c_void_p(0))
+        elif isinstance(a, float):
+            cargs.append(C.c_float(a))
+        elif isinstance(a, bool):
+            cargs.append(C.c_int(int(a)))
+        elif isinstance(a, int):
+            cargs.append(C.c_long(a) if abs(a) > 0x7FFFFFFF else C.c_int(a))
+        else:
+            cargs.append(a)
+    rc = getattr(_lib.lib(), name)(*cargs, stream())
+    _lib.check(rc, name)
+
+
+def L(v: int):
+    """force a C long argument"""
+    return C.c_long(int(v))
+
+
+class AttnT(C.Structure):
+    """cenet_attn_t (include/cenet_hip.h)."""
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+                ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("delta", C.c_void_p)] + \
+               [(n, C.c_long) for n in ("qsb", "qsh", "qsi", "qsd", "ksb", "ksh", "ksi", "ksd", "vsb", "vsh", "vsi", "vsd",
+                                        "osb", "osh", "osi", "osd")] + \
+               [(n, C.c_int) for n in ("B", "H", "Nq", "Nk", "D", "Dv", "v_head_div")] + [("scale", C.c_float)]
+
+
+def flash_supported(D: int, Dv: int) -> bool:
+    return bool(_lib.lib().cenet_flash_attn_supported(int(D), int(Dv)))
+
+
+def flash_fwd(a: AttnT):
+    _lib.check(_lib.lib().cenet_flash_attn_fwd_f32(C.byref(a), stream()), "cenet_flash_attn_fwd_f32")
+
+
+def flash_bwd(a: AttnT):
+    _lib.check(_lib.lib().cenet_flash_attn_bwd_f32(C.byref(a), stream()), "cenet_flash_attn_bwd_f32")
+
+
+def softmax_rows_fwd(x, y, rows, n):
+    _chk(x, y)
+    _call("cenet_softmax_rows_fwd_f32", x, y, L(rows), n)
+
+
+def softmax_rows_bwd(y, dy, dx, rows, n):
+    _chk(y, dy, dx)
+    _call("cenet_softmax_rows_bwd_f32", y, dy, dx, L(rows), n)
+
+
+# ---- norms -----------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, Cn, eps):
+    _chk(x, gamma, beta, y, mean, rstd)
+    _call("cenet_layernorm_fwd_f32", x, gamma, beta, y, mean, rstd, rows, Cn, float(eps))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cn):
+    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta)
+    _call("cenet_layernorm_bwd_acc_f32", dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cn)
+
+
+def bn_stats(x, sb, B, Cn, HW, ws, mean, var, rmean, rvar, momentum, nbt):
+    _chk(x, ws, mean, var, rmean, rvar)
+    _call("cenet_bn_stats_f32", x, L(sb), B, Cn, HW, ws, mean, var, rmean, rvar, float(momentum), nbt)
+
+
+def bn_apply(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, Cn, HW):
+    _chk(x, y, mean, var, gamma, beta)
+    _call("cenet_bn_apply_f32", x, L(sxb), y, L(syb), mean, var, float(eps), gamma, beta, ACT[act], float(slope), B, Cn, HW)
+
+
+def bn_bwd(dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma, beta, act, slope, B, Cn, HW, ws, dgamma, dbeta):
+    _chk(dy, x, dx, mean, var, gamma, beta, ws, dgamma, dbeta)
+    _call("cenet_bn_bwd_acc_f32", dy, L(sgb), x, L(sxb), dx, L(sdb), mean, var, float(eps), gamma, beta, ACT[act],
+          float(slope), B, Cn, HW, ws, dgamma, dbeta)
+
+
+# ---- depthwise conv ------------------------------------------------------------------------------------
+def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0):
+    _chk(x, w, bias, y, a)
+    _call("cenet_dwconv3x3_nchw_f32", x, L(sxb), w, bias, y, L(syb), a, L(sab), B, Cn, H, W, dil, int(flip), ACT[act],
+          float(slope))
+
+
+def dw_tok(x, w, bias, y, a, B, Cn, H, W, flip, act="none", slope=0.0):
+    _chk(x, w, bias, y, a)
+    _call("cenet_dwconv3x3_tok_f32", x, w, bias, y, a, B, Cn, H, W, int(flip), ACT[act], float(slope))
+
+
+def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil):
+    _chk(x, dy, dw, dbias)
+    _call("cenet_dwconv3x3_wgrad_nchw_acc_f32", x, L(sxb), dy, L(sgb), dw, dbias, B, Cn, H, W, dil)
+
+
+def dw_wgrad_tok(x, dy, dw, dbias, B, Cn, H, W):
+    _chk(x, dy, dw, dbias)
+    _call("cenet_dwconv3x3_wgrad_tok_acc_f32", x, dy, dw, dbias, B, Cn, H, W)
+
+
+# ---- resampling ------------------------------------------------------------------------------------------
+def bilinear_fwd(x, sxb, y, syb, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align):
+    _chk(x, y)
+    _call("cenet_bilinear_fwd_f32", x, L(sxb), y, L(syb), B, Cn, Hi, Wi, Ho, Wo, float(sh), float(sw), int(align))
+
+
+def bilinear_bwd(dy, sgb, dx, sdb, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align):
+    _chk(dy, dx)
+    _call("cenet_bilinear_bwd_acc_f32", dy, L(sgb), dx, L(sdb), B, Cn, Hi, Wi, Ho, Wo, float(sh), float(sw), int(align))
+
+
+def nearest2x_fwd(x, sxb, y, syb, B, Cn, Hi, Wi):
+    _chk(x, y)
+    _call("cenet_nearest2x_fwd_f32", x, L(sxb), y, L(syb), B, Cn, Hi, Wi)
+
+
+def nearest2x_bwd(dy, sgb, dx, sdb, B, Cn, Hi, Wi):
+    _chk(dy, dx)
+    _call("cenet_nearest2x_bwd_f32", dy, L(sgb), dx, L(sdb), B, Cn, Hi, Wi)
+
+
+def avgpool_fwd(x, sxb, y, syb, B, Cn, Hi, Wi, Ho, Wo):
+    _chk(x, y)
+    _call("cenet_adaptive_avgpool_fwd_f32", x, L(sxb), y, L(syb), B, Cn, Hi, Wi, Ho, Wo)
+
+
+def avgpool_bwd(dy, sgb, dx, sdb, B, Cn, Hi, Wi, Ho, Wo):
+    _chk(dy, dx)
+    _call("cenet_adaptive_avgpool_bwd_f32", dy, L(sgb), dx, L(sdb), B, Cn, Hi, Wi, Ho, Wo)
+
+
+def maxpool2_fwd(x, y, syb, scale, B, Cn, Hi, Wi):
+    _chk(x, y, scale)
+    _call("cenet_maxpool2_fwd_f32", x, y, L(syb), scale, B, Cn, Hi, Wi)
+
+
+def maxpool2_bwd(x, dy, sgb, dx, scale, dscale, B, Cn, Hi, Wi):
+    _chk(x, dy, dx, scale, dscale)
+    _call("cenet_maxpool2_bwd_acc_f32", x, dy, L(sgb), dx, scale, dscale, B, Cn, Hi, Wi)
+
+
+# ---- CCU / SRM ---------------------------------------------------------------------------------------------
+def ccu_stats_fwd(x, fc1, fc2, u, amax, z, B, Cn, HW):
+    _chk(x, fc1, fc2, u, amax, z)
+    _call("cenet_ccu_stats_fwd_f32", x, fc1, fc2, u, amax, z, B, Cn, HW)
+
+
+def gate_chan_fwd(x, g, y, BC, HW):
+    _chk(x, g, y)
+    _call("cenet_gate_chan_fwd_f32", x, g, y, BC, HW)
+
+
+def gate_chan_bwd_reduce(x, dy, g, dg, BC, HW):
+    _chk(x, dy, g, dg)
+    _call("cenet_gate_chan_bwd_reduce_f32", x, dy, g, dg, BC, HW)
+
+
+def ccu_bwd_apply(x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx, B, Cn, HW):
+    _chk(x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx)
+    _call("cenet_ccu_bwd_apply_acc_f32", x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx, B, Cn, HW)
+
+
+def srm_stats_fwd(x, u, amax, B, Cn, HW):
+    _chk(x, u, amax)
+    _call("cenet_srm_stats_fwd_f32", x, u, amax, B, Cn, HW)
+
+
+def srm_conv_fwd(u, pwc, dwc, f, B, H, W):
+    _chk(u, pwc, dwc, f)
+    _call("cenet_srm_conv_fwd_f32", u, pwc, dwc, f, B, H, W)
+
+
+def srm_conv_bwd(u, df, pwc, dwc, du, dpwc, ddwc, B, H, W):
+    _chk(u, df, pwc, dwc, du, dpwc, ddwc)
+    _call("cenet_srm_conv_bwd_acc_f32", u, df, pwc, dwc, du, dpwc, ddwc, B, H, W)
+
+
+def gate_pix_fwd(x, f, y, B, Cn, HW):
+    _chk(x, f, y)
+    _call("cenet_gate_pix_fwd_f32", x, f, y, B, Cn, HW)
+
+
+def gate_pix_bwd_reduce(x, dy, f, df, B, Cn, HW):
+    _chk(x, dy, f, df)
+    _call("cenet_gate_pix_bwd_reduce_f32", x, dy, f, df, B, Cn, HW)
+
+
+def srm_bwd_apply(x, dy, f, u, du, amax, dx, B, Cn, HW):
+    _chk(x, dy, f, u, du, amax, dx)
+    _call("cenet_srm_bwd_apply_f32", x, dy, f, u, du, amax, dx, B, Cn, HW)
+
+
+# ---- glue ---------------------------------------------------------------------------------------------------
+def transpose(x, sxb, y, syb, B, R, Cc, x_off=0, y_off=0):
+    _chk(x, y)
+    _call("cenet_transpose_f32", C.c_void_p(x.data_ptr() + 4 * x_off), L(sxb), C.c_void_p(y.data_ptr() + 4 * y_off), L(syb),
+          B, R, Cc)
+
+
+def copy_batched(x, sxb, y, syb, B, n, accumulate=False, x_off=0, y_off=0):
+    _chk(x, y)
+    _call("cenet_copy_batched_f32", C.c_void_p(x.data_ptr() + 4 * x_off), L(sxb), C.c_void_p(y.data_ptr() + 4 * y_off),
+          L(syb), B, L(n), int(accumulate))
+
+
+def scale_batch(x, s, y, B, n):
+    _chk(x, s, y)
+    _call("cenet_scale_batch_f32", x, s, y, B, L(n))
+
+
+def act_fwd(x, y, n, act, slope=0.0):
+    _chk(x, y)
+    _call("cenet_act_fwd_f32", x, y, L(n), ACT[act], float(slope))
+
+
+def act_bwd(pre, dy, dx, n, act, slope=0.0):
+    _chk(pre, dy, dx)
+    _call("cenet_act_bwd_f32", pre, dy, dx, L(n), ACT[act], float(slope))
+
+
+def silu_mul_fwd(a, b, y, n):
+    _chk(a, b, y)
+    _call("cenet_silu_mul_fwd_f32", a, b, y, L(n))
+
+
+def silu_mul_bwd(a, b, dy, da, db, n):
+    _chk(a, b, dy, da, db)
+    _call("cenet_silu_mul_bwd_f32", a, b, dy, da, db, L(n))
+
+
+def mix_fwd(x, p, w, z, n):
+    _chk(x, p, w, z)
+    _call("cenet_mix_fwd_f32", x, p, w, z, L(n))
+
+
+def mix_bwd(x, p, w, dz, dx, dp, dw, n):
+    _chk(x, p, w, dz, dx, dp, dw)
+    _call("cenet_mix_bwd_acc_f32", x, p, w, dz, dx, dp, dw, L(n))
+
+
+def scale_residual_fwd(x, y, ls, out, B, Cn, HW):
+    _chk(x, y, ls, out)
+    _call("cenet_scale_residual_fwd_f32", x, y, ls, out, B, Cn, HW)
+
+
+def scale_chan(g, ls, out, B, Cn, HW):
+    _chk(g, ls, out)
+    _call("cenet_scale_chan_f32", g, ls, out, B, Cn, HW)
+
+
+def chan_dot(a, sab, b, sbb, out, B, Cn, HW):
+    _chk(a, b, out)
+    _call("cenet_chan_dot_acc_f32", a, L(sab), b, L(sbb), out, B, Cn, HW)
+
+
+def col_sum(a, out, R, Cn):
+    _chk(a, out)
+    _call("cenet_col_sum_acc_f32", a, out, L(R), Cn)
+
+
+def add_act_fwd(a, b, out, n, act="none", slope=0.0):
+    _chk(a, b, out)
+    _call("cenet_add_act_fwd_f32", a, b, out, L(n), ACT[act], float(slope))
+
+
+def lrelu_bwd_from_out(out, dy, dx, n, slope):
+    _chk(out, dy, dx)
+    _call("cenet_lrelu_bwd_from_out_f32", out, dy, dx, L(n), float(slope))
+
+
+def dseb_combine_fwd(y, rs, n, w, diff, ycoef, z, B, Cn, HW):
+    _chk(y, w, diff, z, *rs)
+    r = list(rs) + [None] * (3 - len(rs))
+    _call("cenet_dseb_combine_fwd_f32", y, r[0], r[1], r[2], n, w, diff, float(ycoef), z, B, Cn, HW)
+
+
+def dseb_combine_bwd(y, rs, n, w, diff, ycoef, dz, dy, drs, ddiff, dw, B, Cn, HW):
+    _chk(y, w, diff, dz, dy, ddiff, dw, *rs, *drs)
+    r = list(rs) + [None] * (3 - len(rs))
+    d = list(drs) + [None] * (3 - len(drs))
+    _call("cenet_dseb_combine_bwd_acc_f32", y, r[0], r[1], r[2], n, w, diff, float(ycoef), dz, dy, d[0], d[1], d[2], ddiff, dw, B,
+          Cn, HW)
+
+
+def diffattn_lambda_fwd(q1, k1, q2, k2, lam0, lam3, hd):
+    _chk(q1, k1, q2, k2, lam3)
+    _call("cenet_diffattn_lambda_fwd_f32", q1, k1, q2, k2, float(lam0), lam3, hd)
+
+
+def diffattn_lambda_bwd(q1, k1, q2, k2, lam3, dlam, dq1, dk1, dq2, dk2, hd):
+    _chk(q1, k1, q2, k2, lam3, dlam, dq1, dk1, dq2, dk2)
+    _call("cenet_diffattn_lambda_bwd_acc_f32", q1, k1, q2, k2, lam3, dlam, dq1, dk1, dq2, dk2, hd)
+
+
+def diffattn_combine_fwd(U, lam3, out, B, H, N, dv, eps, post):
+    _chk(U, lam3, out)
+    _call("cenet_diffattn_combine_fwd_f32", U, lam3, out, B, H, N, dv, float(eps), float(post))
+
+
+def diffattn_combine_bwd(U, lam3, dout, dU, dlam, B, H, N, dv, eps, post):
+    _chk(U, lam3, dout, dU, dlam)
+    _call("cenet_diffattn_combine_bwd_acc_f32", U, lam3, dout, dU, dlam, B, H, N, dv, float(eps), float(post))
+
+
+# ---- loss / optimiser --------------------------------------------------------------------------------------
+def dice_ce_fwd(logits, labels, acc, loss, B, K, HW, w_dice, w_ce):
+    _chk(logits, labels, acc, loss)
+    _call("cenet_dice_ce_fwd_f32", logits, labels, acc, loss, B, K, HW, float(w_dice), float(w_ce))
+
+
+def dice_ce_bwd(logits, labels, acc, gout, dlogits, B, K, HW, w_dice, w_ce):
+    _chk(logits, labels, acc, gout, dlogits)
+    _call("cenet_dice_ce_bwd_f32", logits, labels, acc, gout, dlogits, B, K, HW, float(w_dice), float(w_ce))
+
+
+def sgd_step(p, g, buf, hyper5, n):
+    _chk(p, g, buf, hyper5)
+    _call("cenet_sgd_step_f32", p, g, buf, hyper5, L(n))
+
+
+def zero_(t: torch.Tensor):
+    _chk(t)
+    _call("cenet_zero_f32", t, L(t.numel()))
+    return t

@@ -1,0 +1,143 @@
+"""Context Feature Attention Module on HIP kernels — mirrors reference src/networks/cenet/modules/cfam.py."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from .blocks import SepConvBN, bn_call
+from .nlb import Nonlocal
+
+
+class SRM(nn.Module):
+    """cfam.py:86-101."""
+
+    def __init__(self):
+        super().__init__()
+        self.pwc = nn.Conv2d(3, 1, kernel_size=1, bias=False)
+        self.dwc = nn.Conv2d(3, 1, kernel_size=3, padding=1, bias=False)
+        self.bn = nn.BatchNorm2d(1)
+
+    def forward(self, x):
+        b = self.bn
+        return ops.srm(x, self.pwc.weight, self.dwc.weight, b.weight, b.bias, b.running_mean, b.running_var,
+                       b.num_batches_tracked, b.training)
+
+
+class Mlp(nn.Module):
+    """cfam.py:104-159: 1x1 -> DW3x3(+bias) -> GELU -> SRM -> 1x1."""
+
+    def __init__(self, embed_dims, feedforward_channels, kernel_size=3, act_type='GELU', ffn_drop=0.):
+        super().__init__()
+        if kernel_size != 3 or act_type != "GELU" or ffn_drop != 0.:
+            raise NotImplementedError
+        self.fc1 = nn.Conv2d(embed_dims, feedforward_channels, 1)
+        self.dwconv = nn.Conv2d(feedforward_channels, feedforward_channels, 3, 1, 1, bias=True, groups=feedforward_channels)
+        self.fc2 = nn.Conv2d(feedforward_channels, embed_dims, 1)
+        self.srm = SRM()
+
+    def forward(self, x):
+        x = ops.conv1x1(x, self.fc1.weight, self.fc1.bias)
+        x = ops.dwconv_nchw(x, self.dwconv.weight, self.dwconv.bias, dil=1, act="gelu")
+        x = self.srm(x)
+        return ops.conv1x1(x, self.fc2.weight, self.fc2.bias)
+
+
+class MultiOrderDWConv(nn.Module):
+    """cfam.py:162-241: 5/16,5/16,5/16,1/16 channel split; three dilated SepConvBN branches + a pooled branch."""
+
+    def __init__(self, embed_dims, channel_split=[1, 3, 4, 2], rates=[6, 12, 18], flag_useAllChannels=False):
+        super().__init__()
+        if flag_useAllChannels:
+            raise NotImplementedError
+        g, q = int(5 / 16 * embed_dims), int(1 / 16 * embed_dims)
+        assert q > 0, "Ops. Channel split ratio is not correct"
+        self.channel_indices = [(0, g), (g, 2 * g), (2 * g, 3 * g), (3 * g, 3 * g + q)]
+        self.rates = list(rates)
+        self.dlps = nn.ModuleList([SepConvBN(g, g, kernel_size=3, stride=1, rate=r, depth_activation=True, epsilon=1e-5)
+                                   for r in rates])
+        self.dlps.append(nn.Sequential(
+            nn.AdaptiveAvgPool2d((7, 7)),
+            nn.Conv2d(q, q, kernel_size=1, bias=False),
+            nn.BatchNorm2d(q, eps=1e-5),
+            nn.LeakyReLU(),
+            nn.UpsamplingBilinear2d(scale_factor=7)))
+        self.embed_dims = embed_dims
+        self.PW_conv = nn.Conv2d(embed_dims, embed_dims, kernel_size=1)
+
+    def forward(self, x):
+        H, W = x.shape[2:]
+        parts = ops.split_channels(x, [hi - lo for lo, hi in self.channel_indices])
+        ys = [self.dlps[j](parts[j]) for j in range(3)]
+        pool = self.dlps[3]
+        y = ops.adaptive_avgpool(parts[3], 7, 7)
+        y = ops.conv1x1(y, pool[1].weight)
+        y = bn_call(pool[2], y, "lrelu", 0.01)
+        y = ops.interpolate_bilinear(y, scale_factor=7, align_corners=True)
+        if y.shape[2] != H or y.shape[3] != W:
+            y = ops.interpolate_bilinear(y, size=(H, W), align_corners=False)
+        ys.append(y)
+        x = ops.concat2(ops.concat2(ys[0], ys[1]), ops.concat2(ys[2], ys[3]))
+        return ops.conv1x1(x, self.PW_conv.weight, self.PW_conv.bias)
+
+
+class CCU(nn.Module):
+    """cfam.py:244-264."""
+
+    def __init__(self, channel, hidden_scale=3):
+        super().__init__()
+        if hidden_scale != 3:
+            raise NotImplementedError
+        self.fc1 = nn.Conv1d(channel, 3 * channel, kernel_size=3, groups=channel, bias=False)
+        self.fc2 = nn.Conv1d(3 * channel, channel, kernel_size=1, groups=channel, bias=False)
+        self.bn = nn.BatchNorm1d(channel)
+
+    def forward(self, x):
+        b = self.bn
+        return ops.ccu(x, self.fc1.weight, self.fc2.weight, b.weight, b.bias, b.running_mean, b.running_var,
+                       b.num_batches_tracked, b.training)
+
+
+class MCA(nn.Module):
+    """cfam.py:267-306."""
+
+    def __init__(self, embed_dims, attn_channel_split=[1, 3, 4], attn_act_type='SiLU', rates=[2, 3, 4]):
+        super().__init__()
+        if attn_act_type != "SiLU":
+            raise NotImplementedError
+        self.embed_dims = embed_dims
+        self.gate = nn.Conv2d(embed_dims, embed_dims, 1)
+        self.value = MultiOrderDWConv(embed_dims=embed_dims, rates=rates, channel_split=attn_channel_split)
+        self.proj_2 = nn.Conv2d(embed_dims, embed_dims, 1)
+        self.denoising_module = Nonlocal(embed_dims)
+        self.ccu = CCU(embed_dims)
+
+    def forward(self, x):
+        shortcut = x
+        x = self.ccu(x)
+        g = ops.conv1x1(x, self.gate.weight, self.gate.bias)
+        v = self.value(x)
+        x = ops.conv1x1(ops.silu_mul(g, v), self.proj_2.weight, self.proj_2.bias, resid=shortcut)
+        return self.denoising_module(x)
+
+
+class CFAModule(nn.Module):
+    """cfam.py:309-374: x + ls1*MCA(BN(x)); x + ls2*Mlp(BN(x))."""
+
+    def __init__(self, embed_dims, ffn_ratio=4., drop_rate=0., drop_path_rate=0., act_type='GELU', norm_type='BN',
+                 init_value=1e-5, attn_channel_split=[1, 3, 4], attn_act_type='SiLU', mca_rates=[6, 12, 18], writer=None):
+        super().__init__()
+        if norm_type != "BN" or drop_path_rate != 0.:
+            raise NotImplementedError("CENet uses CFAModule(norm_type='BN', drop_path_rate=0) only")
+        self.out_channels = embed_dims
+        self.norm1 = nn.BatchNorm2d(embed_dims, eps=1e-5)
+        self.mca = MCA(embed_dims, attn_channel_split=attn_channel_split, attn_act_type=attn_act_type, rates=mca_rates)
+        self.norm2 = nn.BatchNorm2d(embed_dims, eps=1e-5)
+        self.mlp = Mlp(embed_dims, int(embed_dims * ffn_ratio), 3, act_type, drop_rate)
+        self.layer_scale_1 = nn.Parameter(init_value * torch.ones((1, embed_dims, 1, 1)), requires_grad=True)
+        self.layer_scale_2 = nn.Parameter(init_value * torch.ones((1, embed_dims, 1, 1)), requires_grad=True)
+
+    def forward(self, x):
+        x = ops.scale_residual(x, self.mca(bn_call(self.norm1, x)), self.layer_scale_1)
+        x = ops.scale_residual(x, self.mlp(bn_call(self.norm2, x)), self.layer_scale_2)
+        return x

@@ -1,0 +1,40 @@
+"""Differential attention on HIP kernels — mirrors reference src/networks/cenet/modules/multihead_diffattn.py:28-129."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+
+
+def lambda_init_fn(depth):
+    return 0.8 - 0.6 * math.exp(-0.3 * depth)
+
+
+class MultiheadDiffAttn(nn.Module):
+    def __init__(self, embed_dim, depth, num_heads, model_parallel_size=1, decoder_kv_attention_heads=None, vis=False,
+                 return_2=False):
+        super().__init__()
+        if model_parallel_size != 1 or decoder_kv_attention_heads is not None or vis or return_2:
+            raise NotImplementedError("CENet uses MultiheadDiffAttn(embed_dim, depth, num_heads) only")
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.head_dim = embed_dim // num_heads // 2
+        self.q_proj = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.k_proj = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.v_proj = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.lambda_init = lambda_init_fn(depth)
+        for n in ("lambda_q1", "lambda_k1", "lambda_q2", "lambda_k2"):
+            setattr(self, n, nn.Parameter(torch.zeros(self.head_dim, dtype=torch.float32).normal_(mean=0, std=0.1)))
+
+    def forward(self, x, rel_pos=None, attn_mask=None):
+        if rel_pos is not None or attn_mask is not None:
+            raise NotImplementedError
+        q = ops.linear(x, self.q_proj.weight)
+        k = ops.linear(x, self.k_proj.weight)
+        v = ops.linear(x, self.v_proj.weight)
+        U = ops.diff_attention_heads(q, k, v, self.num_heads)  # [B, 2H, N, 2hd], two softmaxes per head, tiled
+        a = ops.diff_attention_combine(U, self.lambda_q1, self.lambda_k1, self.lambda_q2, self.lambda_k2, self.lambda_init)
+        return ops.linear(a, self.out_proj.weight)

@@ -1,0 +1,32 @@
+"""Non-local block on HIP kernels — mirrors reference src/networks/cenet/modules/nlb.py:6-148."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from .blocks import bn_call
+
+
+class Nonlocal(nn.Module):
+    def __init__(self, dim_inner, pool_size=None, instantiation="softmax", zero_init_final_conv=False,
+                 zero_init_final_norm=True, norm_eps=1e-5, norm_momentum=0.1, norm_module=nn.BatchNorm2d):
+        super().__init__()
+        if pool_size is not None or instantiation != "softmax":
+            raise NotImplementedError("CENet uses Nonlocal(softmax, no pooling) only")
+        self.dim_inner = dim_inner
+        self.conv_theta = nn.Conv2d(dim_inner, dim_inner, 1)
+        self.conv_phi = nn.Conv2d(dim_inner, dim_inner, 1)
+        self.conv_g = nn.Conv2d(dim_inner, dim_inner, 1)
+        self.conv_out = nn.Conv2d(dim_inner, dim_inner, 1)
+        self.bn = norm_module(num_features=dim_inner, eps=norm_eps, momentum=norm_momentum)
+        self.w = nn.Parameter(torch.tensor(0.5))
+
+    def forward(self, x):
+        theta = ops.conv1x1(x, self.conv_theta.weight, self.conv_theta.bias)
+        phi = ops.conv1x1(x, self.conv_phi.weight, self.conv_phi.bias)
+        g = ops.conv1x1(x, self.conv_g.weight, self.conv_g.bias)
+        y = ops.nonlocal_attention(theta, phi, g)  # flash-style: the N x N map is never materialised
+        p = ops.conv1x1(y, self.conv_out.weight, self.conv_out.bias)
+        p = bn_call(self.bn, p)
+        return ops.mix(x, p, self.w)

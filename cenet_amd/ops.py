@@ -1,0 +1,1177 @@
+"""Autograd operators of the CENet hot path, forward AND backward on hand-written HIP kernels.
+
+Each class is a `torch.autograd.Function` whose two methods only allocate tensors (torch caching allocator =
+"plumbing") and launch kernels from libcenet_hip.so through `cenet_amd.kern`.  There is no PyTorch-op
+fallback: on a non-GPU tensor `kern` raises.
+
+Parameter gradients are ACCUMULATED IN PLACE into `param.grad` (created zero-filled if absent) and the
+Function returns `None` for them; this lets all gradients live in one flat arena (cenet_amd.optim) that is
+zeroed with a single memset, updated by one fused SGD launch and all-reduced in large buckets.
+Reference file:line citations are relative to /root/reference/src/.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from . import kern
+
+Tensor = torch.Tensor
+
+
+def _empty(shape, ref: Tensor, dtype=torch.float32) -> Tensor:
+    return torch.empty(shape, device=ref.device, dtype=dtype)
+
+
+def _zeros(shape, ref: Tensor) -> Tensor:
+    t = torch.empty(shape, device=ref.device, dtype=torch.float32)
+    return kern.zero_(t)
+
+
+def grad_buf(p: Optional[Tensor]) -> Optional[Tensor]:
+    """fp32 buffer that gradient kernels ADD into for parameter `p` (None if p is frozen / absent)."""
+    if p is None or not p.requires_grad:
+        return None
+    if p.grad is None:
+        p.grad = _zeros(p.shape, p)
+    return p.grad
+
+
+def _c(t: Optional[Tensor]) -> Optional[Tensor]:
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+# =====================================================================================================
+# Linear in token layout (pvtv2.py:41,45,90,98,106; multihead_diffattn.py:79-81,126)
+# =====================================================================================================
+class LinearFn(Function):
+    """y = bscale[b] * (x W^T + b) + resid.  x [..., K] contiguous; bscale [B] needs x [B, n, K]."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, resid, bscale):
+        x = _c(x)
+        K = x.shape[-1]
+        N = W.shape[0]
+        y = _empty(x.shape[:-1] + (N,), x)
+        R = x.numel() // K
+        if bscale is None:
+            nb, M = 1, R
+        else:
+            nb, M = x.shape[0], R // x.shape[0]
+        resid = _c(resid)
+        kern.gemm(kern.mat_plain(x, K, 1, sb=M * K, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
+                  scb=M * N, nbatch=nb, bias=b, bscale=bscale, R=resid, srb=M * N, srr=N, src=1)
+        ctx.save_for_backward(x, W, bscale)
+        ctx.refs = (W, b)
+        ctx.has_resid = resid is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, bscale = ctx.saved_tensors
+        Wp, bp = ctx.refs
+        g = _c(g)
+        K, N = x.shape[-1], W.shape[0]
+        R = x.numel() // K
+        gs = g
+        if bscale is not None:
+            gs = torch.empty_like(g)
+            kern.scale_batch(g, bscale, gs, x.shape[0], g.numel() // x.shape[0])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            kern.gemm(kern.mat_plain(gs, N, 1, kfast=1), kern.mat_plain(W, K, 1, kfast=0), dx, R, K, N, scr=K, scc=1)
+        dW = grad_buf(Wp)
+        if dW is not None:
+            iters = (R + 31) // 32
+            kern.gemm(kern.mat_plain(gs, 1, N, kfast=0), kern.mat_plain(x, K, 1, kfast=0), dW, N, K, R, scr=K, scc=1,
+                      splits=kern.pick_splits(N, K, 1, iters), atomic=True)
+        db = grad_buf(bp)
+        if db is not None:
+            kern.col_sum(gs, db, R, N)
+        return dx, None, None, (g if ctx.has_resid else None), None
+
+
+def linear(x, W, b=None, resid=None, bscale=None):
+    return LinearFn.apply(x, W, b, resid, bscale)
+
+
+# =====================================================================================================
+# 1x1 convolution on NCHW (cfam.py:149,158,299,302; nlb.py:106-115,142; blocks.py:178,320; dseb.py:164)
+# =====================================================================================================
+class Conv1x1Fn(Function):
+    """y[b] = W x[b] + bias + resid ; x [B, Cin, *spatial] contiguous."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, resid):
+        x = _c(x)
+        B, Cin = x.shape[:2]
+        HW = x.numel() // (B * Cin)
+        Cout = W.shape[0]
+        y = _empty((B, Cout) + tuple(x.shape[2:]), x)
+        resid = _c(resid)
+        kern.gemm(kern.mat_plain(W, Cin, 1, kfast=1), kern.mat_plain(x, HW, 1, sb=Cin * HW), y, Cout, HW, Cin, scr=HW,
+                  scc=1, scb=Cout * HW, nbatch=B, bias=b, bias_on_row=True, R=resid, srb=Cout * HW, srr=HW, src=1)
+        ctx.save_for_backward(x, W)
+        ctx.refs = (W, b)
+        ctx.has_resid = resid is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        Wp, bp = ctx.refs
+        g = _c(g)
+        B, Cin = x.shape[:2]
+        HW = x.numel() // (B * Cin)
+        Cout = W.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            kern.gemm(kern.mat_plain(W, 1, Cin, kfast=0), kern.mat_plain(g, HW, 1, sb=Cout * HW), dx, Cin, HW, Cout,
+                      scr=HW, scc=1, scb=Cin * HW, nbatch=B)
+        dW = grad_buf(Wp)
+        if dW is not None:
+            iters = B * ((HW + 31) // 32)
+            kern.gemm(kern.mat_plain(g, HW, 1, skb=Cout * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Cin * HW, kfast=1),
+                      dW, Cout, Cin, HW, scr=Cin, scc=1, nkb=B, splits=kern.pick_splits(Cout, Cin, 1, iters), atomic=True)
+        db = grad_buf(bp)
+        if db is not None:
+            kern.chan_dot(g, Cout * HW, None, 0, db, B, Cout, HW)
+        return dx, None, None, (g if ctx.has_resid else None)
+
+
+def conv1x1(x, W, b=None, resid=None):
+    return Conv1x1Fn.apply(x, W, b, resid)
+
+
+# =====================================================================================================
+# dense k x k convolution as implicit GEMM (pvtv2.py:164,67; unet.py:156-197; blocks.py:211)
+# =====================================================================================================
+class Conv2dFn(Function):
+    """Input is addressed x[b*sb + c*sc + y*sy + x*sx] (geom), so NCHW maps, token-layout maps and the zero-stride
+    channel broadcast of net.py:55 are all read in place.  Output: 'nchw' [B,Cout,Ho,Wo] or 'tok' [B,Ho*Wo,Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, geom):
+        B, Cin, H, Wd, sb, sc, sy, sx, stride, pad, out_layout = geom
+        Cout, _, k, _ = W.shape
+        Ho = (H + 2 * pad - k) // stride + 1
+        Wo = (Wd + 2 * pad - k) // stride + 1
+        Kd = Cin * k * k
+        Bm = kern.mat_im2col(x, sb=sb, skb=0, sci=sc, sy=sy, sx=sx, KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride,
+                             pad=pad, dil=1, patch_is_row=1, transposed=0, kfast=0)
+        if out_layout == "nchw":
+            y = _empty((B, Cout, Ho, Wo), x)
+            scr, scc = Ho * Wo, 1
+        else:
+            y = _empty((B, Ho * Wo, Cout), x)
+            scr, scc = 1, Cout
+        kern.gemm(kern.mat_plain(W, Kd, 1, kfast=1), Bm, y, Cout, Ho * Wo, Kd, scr=scr, scc=scc, scb=Cout * Ho * Wo,
+                  nbatch=B, bias=b, bias_on_row=True)
+        ctx.save_for_backward(x, W)
+        ctx.refs = (W, b)
+        ctx.geom = geom
+        ctx.out_hw = (Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        Wp, bp = ctx.refs
+        B, Cin, H, Wd, sb, sc, sy, sx, stride, pad, out_layout = ctx.geom
+        Ho, Wo = ctx.out_hw
+        Cout, _, k, _ = W.shape
+        Kd = Cin * k * k
+        g = _c(g)
+        if out_layout == "nchw":
+            g_sc, g_sp = Ho * Wo, 1  # channel stride, pixel stride of dY
+        else:
+            g_sc, g_sp = 1, Cout
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dX[b][ci][q] = sum_{co,ky,kx} W[co,ci,ky,kx] * dY gathered (transposed map); written with x's strides
+            assert sy == Wd * sx, "conv2d data-gradient needs a pixel-linear input layout"
+            dx = torch.empty_like(x)
+            Bm = kern.mat_im2col(g, sb=Cout * Ho * Wo, skb=0, sci=g_sc, sy=Wo * g_sp, sx=g_sp, KH=k, KW=k, Pw=Wd, Hs=Ho,
+                                 Ws=Wo, stride=stride, pad=pad, dil=1, patch_is_row=1, transposed=1, kfast=0)
+            A = kern.mat_plain(W, k * k, 1, kfast=1, kinner=k * k, sk_outer=Cin * k * k)
+            kern.gemm(A, Bm, dx, Cin, H * Wd, Cout * k * k, scr=sc, scc=sx, scb=sb, nbatch=B)
+        dW = grad_buf(Wp)
+        if dW is not None:
+            Bm = kern.mat_im2col(x, sb=0, skb=sb, sci=sc, sy=sy, sx=sx, KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride,
+                                 pad=pad, dil=1, patch_is_row=0, transposed=0, kfast=1)
+            iters = B * ((Ho * Wo + 31) // 32)
+            kern.gemm(kern.mat_plain(g, g_sc, g_sp, skb=Cout * Ho * Wo, kfast=int(g_sp == 1)), Bm, dW, Cout, Kd, Ho * Wo,
+                      scr=Kd, scc=1, nkb=B, splits=kern.pick_splits(Cout, Kd, 1, iters), atomic=True)
+        db = grad_buf(bp)
+        if db is not None:
+            if out_layout == "nchw":
+                kern.chan_dot(g, Cout * Ho * Wo, None, 0, db, B, Cout, Ho * Wo)
+            else:
+                kern.col_sum(g, db, B * Ho * Wo, Cout)
+        return dx, None, None, None
+
+
+def conv2d_nchw(x, W, b=None, stride=1, pad=0, out_layout="nchw", expand_channels: int = 0):
+    """x [B,C,H,W] contiguous NCHW.  expand_channels=3 reads a 1-channel input as 3 identical channels (net.py:55)."""
+    x = _c(x)
+    B, C, H, Wd = x.shape
+    if expand_channels and C == 1:
+        geom = (B, expand_channels, H, Wd, H * Wd, 0, Wd, 1, stride, pad, out_layout)
+    else:
+        geom = (B, C, H, Wd, C * H * Wd, H * Wd, Wd, 1, stride, pad, out_layout)
+    return Conv2dFn.apply(x, W, b, geom)
+
+
+def conv2d_tok(x, H, Wd, W, b=None, stride=1, pad=0, out_layout="tok"):
+    """x [B, H*W, C] token layout read as an NCHW map (pvtv2.py:93-94)."""
+    x = _c(x)
+    B, N, C = x.shape
+    geom = (B, C, H, Wd, N * C, 1, Wd * C, C, stride, pad, out_layout)
+    return Conv2dFn.apply(x, W, b, geom)
+
+
+# =====================================================================================================
+# LayerNorm over the last dim (pvtv2.py:117,124,166,69,221-245)
+# =====================================================================================================
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        Cn = x.shape[-1]
+        rows = x.numel() // Cn
+        y = torch.empty_like(x)
+        mean, rstd = _empty((rows,), x), _empty((rows,), x)
+        kern.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, Cn, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.refs = (gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        gp, bp = ctx.refs
+        g = _c(g)
+        Cn = x.shape[-1]
+        rows = x.numel() // Cn
+        dx = torch.empty_like(x)
+        dg, db = grad_buf(gp), grad_buf(bp)
+        if dg is None:  # frozen affine: accumulate into scratch
+            dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
+        kern.layernorm_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn)
+        return dx, None, None, None
+
+
+def layernorm(x, gamma, beta, eps):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# =====================================================================================================
+# BatchNorm (+ fused activation) on NCHW or [B,C]  (cfam.py:22-32; blocks.py; nlb.py:81; unet.py:175-197)
+# =====================================================================================================
+class BatchNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, rmean, rvar, nbt, training, eps, act, slope, momentum):
+        x = _c(x)
+        B, Cn = x.shape[:2]
+        HW = x.numel() // (B * Cn)
+        y = torch.empty_like(x)
+        if training:
+            mean, var = _empty((Cn,), x), _empty((Cn,), x)
+            ws = _empty((2 * Cn,), x)
+            kern.bn_stats(x, Cn * HW, B, Cn, HW, ws, mean, var, rmean, rvar, momentum, nbt)
+        else:
+            mean, var = rmean, rvar
+        kern.bn_apply(x, Cn * HW, y, Cn * HW, mean, var, eps, weight, bias, act, slope, B, Cn, HW)
+        ctx.save_for_backward(x, weight, bias, mean, var)
+        ctx.refs = (weight, bias)
+        ctx.cfg = (training, eps, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias, mean, var = ctx.saved_tensors
+        wp, bp = ctx.refs
+        training, eps, act, slope = ctx.cfg
+        if not training:
+            raise RuntimeError("cenet_amd BatchNorm backward is implemented for training mode only")
+        g = _c(g)
+        B, Cn = x.shape[:2]
+        HW = x.numel() // (B * Cn)
+        dx = torch.empty_like(x)
+        ws = _empty((2 * Cn,), x)
+        dg, db = grad_buf(wp), grad_buf(bp)
+        if dg is None:
+            dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
+        kern.bn_bwd(g, Cn * HW, x, Cn * HW, dx, Cn * HW, mean, var, eps, weight, bias, act, slope, B, Cn, HW, ws, dg, db)
+        return (dx,) + (None,) * 10
+
+
+def batchnorm(x, weight, bias, rmean, rvar, nbt, training, eps=1e-5, act="none", slope=0.0, momentum=0.1):
+    return BatchNormFn.apply(x, weight, bias, rmean, rvar, nbt, training, eps, act, slope, momentum)
+
+
+# =====================================================================================================
+# depthwise 3x3 (+bias, +activation)
+# =====================================================================================================
+class DWConvTokFn(Function):
+    """pvtv2.py:42-43,359-370: GELU(DW3x3(x)+b) on [B, H*W, C] tokens."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, H, Wd, act):
+        x = _c(x)
+        B, N, Cn = x.shape
+        u = torch.empty_like(x)
+        a = torch.empty_like(x) if act != "none" else None
+        kern.dw_tok(x, w, b, u, a, B, Cn, H, Wd, 0, act)
+        ctx.save_for_backward(x, w, u if act != "none" else None)
+        ctx.refs = (w, b)
+        ctx.cfg = (H, Wd, act)
+        return a if a is not None else u
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, u = ctx.saved_tensors
+        wp, bp = ctx.refs
+        H, Wd, act = ctx.cfg
+        g = _c(g)
+        B, N, Cn = x.shape
+        gu = g
+        if act != "none":
+            gu = torch.empty_like(g)
+            kern.act_bwd(u, g, gu, g.numel(), act)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            kern.dw_tok(gu, w, None, dx, None, B, Cn, H, Wd, 1)
+        dw = grad_buf(wp)
+        if dw is not None:
+            kern.dw_wgrad_tok(x, gu, dw, grad_buf(bp), B, Cn, H, Wd)
+        return dx, None, None, None, None, None
+
+
+class DWConvNCHWFn(Function):
+    """cfam.py:150-151 (bias+GELU), blocks.py:173 (dilated, no bias), blocks.py:305."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dil, act):
+        x = _c(x)
+        B, Cn, H, Wd = x.shape
+        u = torch.empty_like(x)
+        a = torch.empty_like(x) if act != "none" else None
+        kern.dw_nchw(x, Cn * H * Wd, w, b, u, Cn * H * Wd, a, Cn * H * Wd, B, Cn, H, Wd, dil, 0, act)
+        ctx.save_for_backward(x, w, u if act != "none" else None)
+        ctx.refs = (w, b)
+        ctx.cfg = (dil, act)
+        return a if a is not None else u
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, u = ctx.saved_tensors
+        wp, bp = ctx.refs
+        dil, act = ctx.cfg
+        g = _c(g)
+        B, Cn, H, Wd = x.shape
+        sb = Cn * H * Wd
+        gu = g
+        if act != "none":
+            gu = torch.empty_like(g)
+            kern.act_bwd(u, g, gu, g.numel(), act)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            kern.dw_nchw(gu, sb, w, None, dx, sb, None, 0, B, Cn, H, Wd, dil, 1)
+        dw = grad_buf(wp)
+        if dw is not None:
+            kern.dw_wgrad_nchw(x, sb, gu, sb, dw, grad_buf(bp), B, Cn, H, Wd, dil)
+        return dx, None, None, None, None
+
+
+def dwconv_tok(x, w, b, H, Wd, act="none"):
+    return DWConvTokFn.apply(x, w, b, H, Wd, act)
+
+
+def dwconv_nchw(x, w, b=None, dil=1, act="none"):
+    return DWConvNCHWFn.apply(x, w, b, dil, act)
+
+
+# =====================================================================================================
+# attention
+# =====================================================================================================
+class _AttnDesc:
+    """strides/dims of one attention problem; tensors are addressed in place."""
+
+    def __init__(self, B, H, Nq, Nk, D, Dv, scale, vdiv, qs, ks, vs, os_, qoff=0, koff=0, voff=0):
+        self.B, self.H, self.Nq, self.Nk, self.D, self.Dv, self.scale, self.vdiv = B, H, Nq, Nk, D, Dv, scale, vdiv
+        self.qs, self.ks, self.vs, self.os = qs, ks, vs, os_  # each (sb, sh, si, sd)
+        self.qoff, self.koff, self.voff = qoff, koff, voff   # element offsets into q/k/v storage
+
+    def fill(self, a: "kern.AttnT", q, k, v, o, lse):
+        a.q, a.k, a.v = q.data_ptr() + 4 * self.qoff, k.data_ptr() + 4 * self.koff, v.data_ptr() + 4 * self.voff
+        a.o, a.lse = o.data_ptr(), lse.data_ptr() if lse is not None else None
+        a.qsb, a.qsh, a.qsi, a.qsd = self.qs
+        a.ksb, a.ksh, a.ksi, a.ksd = self.ks
+        a.vsb, a.vsh, a.vsi, a.vsd = self.vs
+        a.osb, a.osh, a.osi, a.osd = self.os
+        a.B, a.H, a.Nq, a.Nk, a.D, a.Dv, a.v_head_div = self.B, self.H, self.Nq, self.Nk, self.D, self.Dv, self.vdiv
+        a.scale = self.scale
+
+
+def _attn_forward(d: _AttnDesc, q, k, v, o):
+    """returns the tensors to save for backward: ('flash', lse) or ('mat', P)."""
+    kern._chk(q, k, v, o)
+    if kern.flash_supported(d.D, d.Dv):
+        lse = _empty((d.B, d.H, d.Nq), q)
+        a = kern.AttnT()
+        d.fill(a, q, k, v, o, lse)
+        kern.flash_fwd(a)
+        return "flash", lse
+    # materialised path (large head dims, small N): S = scale QK^T ; P = softmax ; O = P V
+    BH = d.B * d.H
+    S = _empty((BH, d.Nq, d.Nk), q)
+    kern.gemm(kern.mat_plain(q, d.qs[2], d.qs[3], sb=d.qs[0], sb2=d.qs[1], kfast=int(d.qs[3] == 1), offset=d.qoff),
+              kern.mat_plain(k, d.ks[3], d.ks[2], sb=d.ks[0], sb2=d.ks[1], kfast=int(d.ks[3] == 1), offset=d.koff),
+              S, d.Nq, d.Nk, d.D, scr=d.Nk, scc=1, scb=d.H * d.Nq * d.Nk, scb2=d.Nq * d.Nk, nbatch=BH, nb_inner=d.H,
+              alpha=d.scale)
+    P = torch.empty_like(S)
+    kern.softmax_rows_fwd(S, P, BH * d.Nq, d.Nk)
+    vh = d.vdiv
+    kern.gemm(kern.mat_plain(P, d.Nk, 1, sb=d.H * d.Nq * d.Nk, sb2=d.Nq * d.Nk, kfast=1),
+              _vmat(d, v, vh), o, d.Nq, d.Dv, d.Nk, scr=d.os[2], scc=d.os[3], scb=d.os[0], scb2=d.os[1], nbatch=BH,
+              nb_inner=d.H)
+    return "mat", P
+
+
+def _vmat(d: _AttnDesc, v, vh):
+    # B operand V[j, dv] for batch (b, h): head h // vh.  nb_inner=H indexes h, so use stride vs[1]/vh when vh divides
+    # evenly is not expressible -> when vh > 1 the caller loops over the two heads (see _attn_* below).
+    assert vh == 1
+    return kern.mat_plain(v, d.vs[2], d.vs[3], sb=d.vs[0], sb2=d.vs[1], kfast=int(d.vs[2] == 1), offset=d.voff)
+
+
+def _attn_backward(d: _AttnDesc, kind, saved, q, k, v, o, g, dq, dk, dv):
+    """dq/dk/dv are written in the layouts of q/k/v (offsets included); dv must be zero-filled when vdiv > 1."""
+    if kind == "flash":
+        a = kern.AttnT()
+        d.fill(a, q, k, v, o, saved)
+        delta = _empty((d.B, d.H, d.Nq), q)
+        a.dout = g.data_ptr()
+        a.dq, a.dk, a.dv = dq.data_ptr() + 4 * d.qoff, dk.data_ptr() + 4 * d.koff, dv.data_ptr() + 4 * d.voff
+        a.delta = delta.data_ptr()
+        kern.flash_bwd(a)
+        return
+    P = saved
+    BH = d.B * d.H
+    HN = d.H * d.Nq * d.Nk
+    NN = d.Nq * d.Nk
+    dP = torch.empty_like(P)
+    kern.gemm(kern.mat_plain(g, d.os[2], d.os[3], sb=d.os[0], sb2=d.os[1], kfast=int(d.os[3] == 1)),
+              kern.mat_plain(v, d.vs[3], d.vs[2], sb=d.vs[0], sb2=d.vs[1], kfast=int(d.vs[3] == 1), offset=d.voff),
+              dP, d.Nq, d.Nk, d.Dv, scr=d.Nk, scc=1, scb=HN, scb2=NN, nbatch=BH, nb_inner=d.H)
+    dS = torch.empty_like(P)
+    kern.softmax_rows_bwd(P, dP, dS, BH * d.Nq, d.Nk)
+    kern.gemm(kern.mat_plain(dS, d.Nk, 1, sb=HN, sb2=NN, kfast=1),
+              kern.mat_plain(k, d.ks[2], d.ks[3], sb=d.ks[0], sb2=d.ks[1], kfast=int(d.ks[2] == 1), offset=d.koff),
+              dq, d.Nq, d.D, d.Nk, scr=d.qs[2], scc=d.qs[3], scb=d.qs[0], scb2=d.qs[1], nbatch=BH, nb_inner=d.H,
+              alpha=d.scale, c_offset=d.qoff)
+    kern.gemm(kern.mat_plain(dS, 1, d.Nk, sb=HN, sb2=NN, kfast=0),
+              kern.mat_plain(q, d.qs[2], d.qs[3], sb=d.qs[0], sb2=d.qs[1], kfast=int(d.qs[2] == 1), offset=d.qoff),
+              dk, d.Nk, d.D, d.Nq, scr=d.ks[2], scc=d.ks[3], scb=d.ks[0], scb2=d.ks[1], nbatch=BH, nb_inner=d.H,
+              alpha=d.scale, c_offset=d.koff)
+    kern.gemm(kern.mat_plain(P, 1, d.Nk, sb=HN, sb2=NN, kfast=0),
+              kern.mat_plain(g, d.os[2], d.os[3], sb=d.os[0], sb2=d.os[1], kfast=int(d.os[2] == 1)),
+              dv, d.Nk, d.Dv, d.Nq, scr=d.vs[2], scc=d.vs[3], scb=d.vs[0], scb2=d.vs[1], nbatch=BH, nb_inner=d.H,
+              c_offset=d.voff)
+
+
+class SRAttentionFn(Function):
+    """pvtv2.py:88-109 core: q [B,N,C] (heads x hd), kv [B,Nk,2C] = [k | v] -> out [B,N,C]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads):
+        q, kv = _c(q), _c(kv)
+        B, N, Cn = q.shape
+        Nk = kv.shape[1]
+        hd = Cn // heads
+        d = _AttnDesc(B, heads, N, Nk, hd, hd, hd ** -0.5, 1, (N * Cn, hd, Cn, 1), (Nk * 2 * Cn, hd, 2 * Cn, 1),
+                      (Nk * 2 * Cn, hd, 2 * Cn, 1), (N * Cn, hd, Cn, 1), voff=Cn)
+        o = torch.empty_like(q)
+        kind, saved = _attn_forward(d, q, kv, kv, o)
+        ctx.save_for_backward(q, kv, o, saved)
+        ctx.d, ctx.kind = d, kind
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        q, kv, o, saved = ctx.saved_tensors
+        g = _c(g)
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        _attn_backward(ctx.d, ctx.kind, saved, q, kv, kv, o, g, dq, dkv, dkv)
+        return dq, dkv, None
+
+
+class NonlocalAttnFn(Function):
+    """nlb.py:117-138: theta, phi, g [B,C,N] channel-major -> y[b,c,i] = sum_j softmax_j(theta_i.phi_j / sqrt(C)) g[c,j]."""
+
+    @staticmethod
+    def forward(ctx, theta, phi, gx):
+        theta, phi, gx = _c(theta), _c(phi), _c(gx)
+        B, Cn = theta.shape[:2]
+        N = theta.numel() // (B * Cn)
+        st = (Cn * N, 0, 1, N)
+        d = _AttnDesc(B, 1, N, N, Cn, Cn, Cn ** -0.5, 1, st, st, st, st)
+        o = torch.empty_like(theta)
+        kind, saved = _attn_forward(d, theta, phi, gx, o)
+        ctx.save_for_backward(theta, phi, gx, o, saved)
+        ctx.d, ctx.kind = d, kind
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        theta, phi, gx, o, saved = ctx.saved_tensors
+        g = _c(g)
+        dt, dp, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(gx)
+        _attn_backward(ctx.d, ctx.kind, saved, theta, phi, gx, o, g, dt, dp, dg)
+        return dt, dp, dg
+
+
+class DiffAttnHeadsFn(Function):
+    """multihead_diffattn.py:83-109: q,k [B,N,2H,hd], v [B,N,H,2hd] -> U [B,2H,N,2hd], U[2h+s] = softmax(q_{2h+s} k^T) v_h."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H):
+        q, k, v = _c(q), _c(k), _c(v)
+        B, N, E = q.shape
+        hd = E // H // 2
+        dv = 2 * hd
+        U = _empty((B, 2 * H, N, dv), q)
+        if kern.flash_supported(hd, dv):
+            d = _AttnDesc(B, 2 * H, N, N, hd, dv, hd ** -0.5, 2, (N * E, hd, E, 1), (N * E, hd, E, 1), (N * E, dv, E, 1),
+                          (2 * H * N * dv, N * dv, dv, 1))
+            kind, saved = _attn_forward(d, q, k, v, U)
+            ctx.descs = [d]
+            saved_list = [saved]
+        else:
+            # materialised path: one problem per softmax branch s in {0,1}; both read value head h
+            ctx.descs, saved_list = [], []
+            for s in (0, 1):
+                d = _AttnDesc(B, H, N, N, hd, dv, hd ** -0.5, 1, (N * E, 2 * hd, E, 1), (N * E, 2 * hd, E, 1),
+                              (N * E, dv, E, 1), (2 * H * N * dv, 2 * N * dv, dv, 1), qoff=s * hd, koff=s * hd)
+                Us = U  # written through an offset view
+                kind, saved = _attn_forward(d, q, k, v, _OffsetView(Us, s * N * dv))
+                ctx.descs.append(d)
+                saved_list.append(saved)
+        ctx.kind = kind
+        ctx.save_for_backward(q, k, v, U, *saved_list)
+        ctx.H = H
+        return U
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, U = ctx.saved_tensors[:4]
+        saved_list = ctx.saved_tensors[4:]
+        g = _c(g)
+        B, N, E = q.shape
+        hd = E // ctx.H // 2
+        dv = 2 * hd
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        dvv = _zeros(v.shape, v)
+        if len(ctx.descs) == 1:
+            _attn_backward(ctx.descs[0], ctx.kind, saved_list[0], q, k, v, U, g, dq, dk, dvv)
+        else:
+            for s, (d, saved) in enumerate(zip(ctx.descs, saved_list)):
+                tmp = torch.empty_like(v)
+                _attn_backward(d, ctx.kind, saved, q, k, v, _OffsetView(U, s * N * dv), _OffsetView(g, s * N * dv), dq, dk, tmp)
+                kern.copy_batched(tmp, 0, dvv, 0, 1, tmp.numel(), accumulate=True)
+        return dq, dk, dvv, None
+
+
+class _OffsetView:
+    """a tensor seen from an element offset (only .data_ptr()/device/dtype are used by kern)."""
+
+    def __init__(self, t: Tensor, off: int):
+        self._t, self._off = t, off
+        self.device, self.dtype, self.is_cuda = t.device, t.dtype, t.is_cuda
+
+    def data_ptr(self):
+        return self._t.data_ptr() + 4 * self._off
+
+
+def sr_attention(q, kv, heads):
+    return SRAttentionFn.apply(q, kv, heads)
+
+
+def nonlocal_attention(theta, phi, g):
+    return NonlocalAttnFn.apply(theta, phi, g)
+
+
+def diff_attention_heads(q, k, v, H):
+    return DiffAttnHeadsFn.apply(q, k, v, H)
+
+
+class DiffAttnCombineFn(Function):
+    """multihead_diffattn.py:112-123: lambda, U[2h]-lambda U[2h+1], RMSNorm(2hd, eps 1e-5, no affine), *(1-lambda_init)."""
+
+    @staticmethod
+    def forward(ctx, U, lq1, lk1, lq2, lk2, lambda_init):
+        U = _c(U)
+        B, H2, N, dv = U.shape
+        H = H2 // 2
+        lam = _empty((3,), U)
+        kern.diffattn_lambda_fwd(lq1, lk1, lq2, lk2, lambda_init, lam, lq1.numel())
+        out = _empty((B, N, H * dv), U)
+        kern.diffattn_combine_fwd(U, lam, out, B, H, N, dv, 1e-5, 1.0 - lambda_init)
+        ctx.save_for_backward(U, lam, lq1, lk1, lq2, lk2)
+        ctx.refs = (lq1, lk1, lq2, lk2)
+        ctx.lambda_init = lambda_init
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        U, lam, lq1, lk1, lq2, lk2 = ctx.saved_tensors
+        g = _c(g)
+        B, H2, N, dv = U.shape
+        H = H2 // 2
+        dU = torch.empty_like(U)
+        dlam = _zeros((1,), U)
+        kern.diffattn_combine_bwd(U, lam, g, dU, dlam, B, H, N, dv, 1e-5, 1.0 - ctx.lambda_init)
+        gs = [grad_buf(p) for p in ctx.refs]
+        if gs[0] is not None:
+            kern.diffattn_lambda_bwd(lq1, lk1, lq2, lk2, lam, dlam, gs[0], gs[1], gs[2], gs[3], lq1.numel())
+        return dU, None, None, None, None, None
+
+
+def diff_attention_combine(U, lq1, lk1, lq2, lk2, lambda_init):
+    return DiffAttnCombineFn.apply(U, lq1, lk1, lq2, lk2, lambda_init)
+
+
+# =====================================================================================================
+# layout / glue
+# =====================================================================================================
+class TokToNCHWFn(Function):
+    """pvtv2.py:320-321: [B,N,C] -> [B,C,H,W] contiguous."""
+
+    @staticmethod
+    def forward(ctx, x, H, Wd):
+        x = _c(x)
+        B, N, Cn = x.shape
+        y = _empty((B, Cn, H, Wd), x)
+        kern.transpose(x, N * Cn, y, N * Cn, B, N, Cn)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        B, Cn, H, Wd = g.shape
+        dx = _empty((B, H * Wd, Cn), g)
+        kern.transpose(g, Cn * H * Wd, dx, Cn * H * Wd, B, Cn, H * Wd)
+        return dx, None, None
+
+
+def tok_to_nchw(x, H, Wd):
+    return TokToNCHWFn.apply(x, H, Wd)
+
+
+class Concat2Fn(Function):
+    """torch.cat([a, b], dim=1) for NCHW (dseb.py:156, out.py:63)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        B, Ca = a.shape[:2]
+        Cb = b.shape[1]
+        HW = a.numel() // (B * Ca)
+        y = _empty((B, Ca + Cb) + tuple(a.shape[2:]), a)
+        kern.copy_batched(a, Ca * HW, y, (Ca + Cb) * HW, B, Ca * HW)
+        kern.copy_batched(b, Cb * HW, y, (Ca + Cb) * HW, B, Cb * HW, y_off=Ca * HW)
+        ctx.dims = (Ca, Cb, HW)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        Ca, Cb, HW = ctx.dims
+        B = g.shape[0]
+        da = _empty((B, Ca) + tuple(g.shape[2:]), g)
+        db = _empty((B, Cb) + tuple(g.shape[2:]), g)
+        kern.copy_batched(g, (Ca + Cb) * HW, da, Ca * HW, B, Ca * HW)
+        kern.copy_batched(g, (Ca + Cb) * HW, db, Cb * HW, B, Cb * HW, x_off=Ca * HW)
+        return da, db
+
+
+def concat2(a, b):
+    return Concat2Fn.apply(a, b)
+
+
+class SplitChannelsFn(Function):
+    """x[:, lo:hi] for consecutive channel groups of an NCHW tensor, as contiguous tensors (cfam.py:230)."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        x = _c(x)
+        B, Cn = x.shape[:2]
+        HW = x.numel() // (B * Cn)
+        outs, lo = [], 0
+        for c in sizes:
+            y = _empty((B, c) + tuple(x.shape[2:]), x)
+            kern.copy_batched(x, Cn * HW, y, c * HW, B, c * HW, x_off=lo * HW)
+            outs.append(y)
+            lo += c
+        ctx.cfg = (tuple(x.shape), sizes, HW)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        shape, sizes, HW = ctx.cfg
+        B, Cn = shape[:2]
+        ref = next(g for g in gs if g is not None)
+        covered = sum(sizes) == Cn and all(g is not None for g in gs)
+        dx = _empty(shape, ref) if covered else _zeros(shape, ref)
+        lo = 0
+        for c, g in zip(sizes, gs):
+            if g is not None:
+                kern.copy_batched(_c(g), c * HW, dx, Cn * HW, B, c * HW, y_off=lo * HW)
+            lo += c
+        return (dx,) + (None,) * len(sizes)
+
+
+def split_channels(x, sizes):
+    return SplitChannelsFn.apply(x, *sizes)
+
+
+class AddActFn(Function):
+    """out = act(a + b) for act in {none, lrelu, relu} (unet.py:212-213; decoders.py:96)."""
+
+    @staticmethod
+    def forward(ctx, a, b, act, slope):
+        a, b = _c(a), _c(b)
+        out = torch.empty_like(a)
+        kern.add_act_fwd(a, b, out, a.numel(), act, slope)
+        ctx.cfg = (act, slope)
+        if act != "none":
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        act, slope = ctx.cfg
+        g = _c(g)
+        if act == "none":
+            return g, g, None, None
+        (out,) = ctx.saved_tensors
+        d = torch.empty_like(g)
+        kern.lrelu_bwd_from_out(out, g, d, g.numel(), slope if act == "lrelu" else 0.0)
+        return d, d, None, None
+
+
+def add_act(a, b, act="none", slope=0.0):
+    return AddActFn.apply(a, b, act, slope)
+
+
+class SiluMulFn(Function):
+    """cfam.py:302: SiLU(g) * SiLU(v)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        y = torch.empty_like(a)
+        kern.silu_mul_fwd(a, b, y, a.numel())
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _c(g)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        kern.silu_mul_bwd(a, b, g, da, db, a.numel())
+        return da, db
+
+
+def silu_mul(a, b):
+    return SiluMulFn.apply(a, b)
+
+
+class MixFn(Function):
+    """nlb.py:147: (1-w) x + w p with a learnable scalar w."""
+
+    @staticmethod
+    def forward(ctx, x, p, w):
+        x, p = _c(x), _c(p)
+        z = torch.empty_like(x)
+        kern.mix_fwd(x, p, w, z, x.numel())
+        ctx.save_for_backward(x, p, w)
+        ctx.refs = (w,)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        x, p, w = ctx.saved_tensors
+        g = _c(g)
+        dx, dp = torch.empty_like(x), torch.empty_like(p)
+        dw = grad_buf(ctx.refs[0])
+        if dw is None:
+            dw = _zeros((1,), x)
+        kern.mix_bwd(x, p, w, g, dx, dp, dw, x.numel())
+        return dx, dp, None
+
+
+def mix(x, p, w):
+    return MixFn.apply(x, p, w)
+
+
+class ScaleResidualFn(Function):
+    """cfam.py:368,372: x + layer_scale[c] * y."""
+
+    @staticmethod
+    def forward(ctx, x, y, ls):
+        x, y = _c(x), _c(y)
+        B, Cn = x.shape[:2]
+        HW = x.numel() // (B * Cn)
+        out = torch.empty_like(x)
+        kern.scale_residual_fwd(x, y, ls, out, B, Cn, HW)
+        ctx.save_for_backward(y, ls)
+        ctx.refs = (ls,)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, ls = ctx.saved_tensors
+        g = _c(g)
+        B, Cn = y.shape[:2]
+        HW = y.numel() // (B * Cn)
+        dy = torch.empty_like(y)
+        kern.scale_chan(g, ls, dy, B, Cn, HW)
+        dls = grad_buf(ctx.refs[0])
+        if dls is not None:
+            kern.chan_dot(g, Cn * HW, y, Cn * HW, dls, B, Cn, HW)
+        return g, dy, None
+
+
+def scale_residual(x, y, ls):
+    return ScaleResidualFn.apply(x, y, ls)
+
+
+# =====================================================================================================
+# resampling
+# =====================================================================================================
+class BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, sh, sw, align):
+        x = _c(x)
+        B, Cn, Hi, Wi = x.shape
+        y = _empty((B, Cn, Ho, Wo), x)
+        kern.bilinear_fwd(x, Cn * Hi * Wi, y, Cn * Ho * Wo, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align)
+        ctx.cfg = (Hi, Wi, Ho, Wo, sh, sw, align)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        Hi, Wi, Ho, Wo, sh, sw, align = ctx.cfg
+        g = _c(g)
+        B, Cn = g.shape[:2]
+        dx = _zeros((B, Cn, Hi, Wi), g)
+        kern.bilinear_bwd(g, Cn * Ho * Wo, dx, Cn * Hi * Wi, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align)
+        return dx, None, None, None, None, None
+
+
+def _f32(v: float) -> float:
+    return float(torch.tensor(v, dtype=torch.float32))
+
+
+def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=False):
+    """F.interpolate(mode='bilinear') with PyTorch's coordinate rules (recompute_scale_factor=None)."""
+    Hi, Wi = x.shape[2:]
+    if size is not None:
+        Ho, Wo = size
+        sfh = sfw = None
+    else:
+        Ho, Wo = int(math.floor(Hi * scale_factor)), int(math.floor(Wi * scale_factor))
+        sfh = sfw = scale_factor
+    if align_corners:
+        sh = _f32((Hi - 1) / (Ho - 1)) if Ho > 1 else 0.0
+        sw = _f32((Wi - 1) / (Wo - 1)) if Wo > 1 else 0.0
+    else:
+        sh = _f32(1.0 / sfh) if sfh else _f32(Hi / Ho)
+        sw = _f32(1.0 / sfw) if sfw else _f32(Wi / Wo)
+    return BilinearFn.apply(x, Ho, Wo, sh, sw, int(align_corners))
+
+
+class Nearest2xFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, Cn, Hi, Wi = x.shape
+        y = _empty((B, Cn, 2 * Hi, 2 * Wi), x)
+        kern.nearest2x_fwd(x, Cn * Hi * Wi, y, 4 * Cn * Hi * Wi, B, Cn, Hi, Wi)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        B, Cn, Ho, Wo = g.shape
+        Hi, Wi = Ho // 2, Wo // 2
+        dx = _empty((B, Cn, Hi, Wi), g)
+        kern.nearest2x_bwd(g, Cn * Ho * Wo, dx, Cn * Hi * Wi, B, Cn, Hi, Wi)
+        return dx
+
+
+def nearest2x(x):
+    return Nearest2xFn.apply(x)
+
+
+class AdaptiveAvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        x = _c(x)
+        B, Cn, Hi, Wi = x.shape
+        y = _empty((B, Cn, Ho, Wo), x)
+        kern.avgpool_fwd(x, Cn * Hi * Wi, y, Cn * Ho * Wo, B, Cn, Hi, Wi, Ho, Wo)
+        ctx.cfg = (Hi, Wi, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        Hi, Wi, Ho, Wo = ctx.cfg
+        g = _c(g)
+        B, Cn = g.shape[:2]
+        dx = _empty((B, Cn, Hi, Wi), g)
+        kern.avgpool_bwd(g, Cn * Ho * Wo, dx, Cn * Hi * Wi, B, Cn, Hi, Wi, Ho, Wo)
+        return dx, None, None
+
+
+def adaptive_avgpool(x, Ho, Wo):
+    return AdaptiveAvgPoolFn.apply(x, Ho, Wo)
+
+
+class MaxPool2ScaleFn(Function):
+    """out.py:43,70: w[c] * MaxPool2d(2,2)(x)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = _c(x)
+        B, Cn, Hi, Wi = x.shape
+        y = _empty((B, Cn, Hi // 2, Wi // 2), x)
+        kern.maxpool2_fwd(x, y, Cn * (Hi // 2) * (Wi // 2), w, B, Cn, Hi, Wi)
+        ctx.save_for_backward(x, w)
+        ctx.refs = (w,)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _c(g)
+        B, Cn, Hi, Wi = x.shape
+        dx = torch.empty_like(x)
+        kern.maxpool2_bwd(x, g, Cn * (Hi // 2) * (Wi // 2), dx, w, grad_buf(ctx.refs[0]), B, Cn, Hi, Wi)
+        return dx, None
+
+
+def maxpool2_scale(x, w):
+    return MaxPool2ScaleFn.apply(x, w)
+
+
+# =====================================================================================================
+# CCU and SRM gates (cfam.py:251-264, 93-101)
+# =====================================================================================================
+class CCUFn(Function):
+    @staticmethod
+    def forward(ctx, x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training):
+        x = _c(x)
+        B, Cn, H, Wd = x.shape
+        HW = H * Wd
+        u = _empty((B, Cn, 3), x)
+        amax = _empty((B, Cn), x, torch.int32)
+        z = _empty((B, Cn), x)
+        kern.ccu_stats_fwd(x, fc1, fc2, u, amax, z, B, Cn, HW)
+        use_bn = B > 1
+        mean = var = None
+        if use_bn:
+            zn = torch.empty_like(z)
+            if training:
+                mean, var = _empty((Cn,), x), _empty((Cn,), x)
+                ws = _empty((2 * Cn,), x)
+                kern.bn_stats(z, Cn, B, Cn, 1, ws, mean, var, bn_rm, bn_rv, 0.1, bn_nbt)
+            else:
+                mean, var = bn_rm, bn_rv
+            kern.bn_apply(z, Cn, zn, Cn, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, Cn, 1)
+        else:
+            zn = z
+        y = torch.empty_like(x)
+        kern.gate_chan_fwd(x, zn, y, B * Cn, HW)
+        ctx.save_for_backward(x, fc1, fc2, u, amax, z, zn, mean, var, bn_w, bn_b)
+        ctx.refs = (fc1, fc2, bn_w, bn_b)
+        ctx.cfg = (use_bn, training)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, fc1, fc2, u, amax, z, zn, mean, var, bn_w, bn_b = ctx.saved_tensors
+        use_bn, training = ctx.cfg
+        g = _c(g)
+        B, Cn, H, Wd = x.shape
+        HW = H * Wd
+        dzn = _empty((B, Cn), x)
+        kern.gate_chan_bwd_reduce(x, g, zn, dzn, B * Cn, HW)
+        if use_bn:
+            if not training:
+                raise RuntimeError("CCU backward needs training-mode BatchNorm")
+            dz = torch.empty_like(dzn)
+            ws = _empty((2 * Cn,), x)
+            dg, db = grad_buf(ctx.refs[2]), grad_buf(ctx.refs[3])
+            if dg is None:
+                dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
+            kern.bn_bwd(dzn, Cn, z, Cn, dz, Cn, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, Cn, 1, ws, dg, db)
+        else:
+            dz = dzn
+        d1, d2 = grad_buf(ctx.refs[0]), grad_buf(ctx.refs[1])
+        if d1 is None:
+            d1, d2 = _zeros(fc1.shape, x), _zeros(fc2.shape, x)
+        dx = torch.empty_like(x)
+        kern.ccu_bwd_apply(x, g, zn, dz, u, amax, fc1, fc2, d1, d2, dx, B, Cn, HW)
+        return (dx,) + (None,) * 8
+
+
+def ccu(x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training):
+    return CCUFn.apply(x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training)
+
+
+class SRMFn(Function):
+    @staticmethod
+    def forward(ctx, x, pwc, dwc, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training):
+        x = _c(x)
+        B, Cn, H, Wd = x.shape
+        HW = H * Wd
+        u = _empty((B, 3, H, Wd), x)
+        amax = _empty((B, HW), x, torch.int32)
+        kern.srm_stats_fwd(x, u, amax, B, Cn, HW)
+        f = _empty((B, 1, H, Wd), x)
+        kern.srm_conv_fwd(u, pwc, dwc, f, B, H, Wd)
+        fa = torch.empty_like(f)
+        kern.act_fwd(f, fa, f.numel(), "gelu")
+        if training:
+            mean, var = _empty((1,), x), _empty((1,), x)
+            ws = _empty((2,), x)
+            kern.bn_stats(fa, HW, B, 1, HW, ws, mean, var, bn_rm, bn_rv, 0.1, bn_nbt)
+        else:
+            mean, var = bn_rm, bn_rv
+        fb = torch.empty_like(f)
+        kern.bn_apply(fa, HW, fb, HW, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, 1, HW)
+        y = torch.empty_like(x)
+        kern.gate_pix_fwd(x, fb, y, B, Cn, HW)
+        ctx.save_for_backward(x, pwc, dwc, u, amax, f, fa, fb, mean, var, bn_w, bn_b)
+        ctx.refs = (pwc, dwc, bn_w, bn_b)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, pwc, dwc, u, amax, f, fa, fb, mean, var, bn_w, bn_b = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("SRM backward needs training-mode BatchNorm")
+        g = _c(g)
+        B, Cn, H, Wd = x.shape
+        HW = H * Wd
+        dfb = torch.empty_like(f)
+        kern.gate_pix_bwd_reduce(x, g, fb, dfb, B, Cn, HW)
+        dfa = torch.empty_like(f)
+        ws = _empty((2,), x)
+        dg, db = grad_buf(ctx.refs[2]), grad_buf(ctx.refs[3])
+        if dg is None:
+            dg, db = _zeros((1,), x), _zeros((1,), x)
+        kern.bn_bwd(dfb, HW, fa, HW, dfa, HW, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, 1, HW, ws, dg, db)
+        df = torch.empty_like(f)
+        kern.act_bwd(f, dfa, df, f.numel(), "gelu")
+        du = torch.empty_like(u)
+        dp, dd = grad_buf(ctx.refs[0]), grad_buf(ctx.refs[1])
+        if dp is None:
+            dp, dd = _zeros(pwc.shape, x), _zeros(dwc.shape, x)
+        kern.srm_conv_bwd(u, df, pwc, dwc, du, dp, dd, B, H, Wd)
+        dx = torch.empty_like(x)
+        kern.srm_bwd_apply(x, g, fb, u, du, amax, dx, B, Cn, HW)
+        return (dx,) + (None,) * 8
+
+
+def srm(x, pwc, dwc, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training):
+    return SRMFn.apply(x, pwc, dwc, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training)
+
+
+# =====================================================================================================
+# DSEB combine (dseb.py:40-50,63-76,156-163)
+# =====================================================================================================
+class DsebCombineFn(Function):
+    """z = ycoef*y + w[c]*edge(y, recon_s) + diff*y; `recons[s]` is None for scale 1.0 (e_s == 0); diff may be None."""
+
+    @staticmethod
+    def forward(ctx, y, w, diff, ycoef, n, *recons):
+        y, diff = _c(y), _c(diff)
+        recons = [_c(r) for r in recons]
+        B, Cn = y.shape[:2]
+        HW = y.numel() // (B * Cn)
+        z = torch.empty_like(y)
+        kern.dseb_combine_fwd(y, recons, n, w, diff, ycoef, z, B, Cn, HW)
+        ctx.save_for_backward(y, w, diff, *[r for r in recons if r is not None])
+        ctx.ycoef = ycoef
+        ctx.mask = [r is not None for r in recons]
+        ctx.refs = (w,)
+        ctx.n = n
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        y, w, diff = ctx.saved_tensors[:3]
+        present = list(ctx.saved_tensors[3:])
+        recons, it = [], iter(present)
+        for m in ctx.mask:
+            recons.append(next(it) if m else None)
+        g = _c(g)
+        B, Cn = y.shape[:2]
+        HW = y.numel() // (B * Cn)
+        dy = torch.empty_like(y)
+        ddiff = torch.empty_like(y) if diff is not None else None
+        drs = [torch.empty_like(y) if r is not None else None for r in recons]
+        dw = grad_buf(ctx.refs[0])
+        if dw is None:
+            dw = _zeros(w.shape, y)
+        kern.dseb_combine_bwd(y, recons, ctx.n, w, diff, ctx.ycoef, g, dy, drs, ddiff, dw, B, Cn, HW)
+        return (dy, None, ddiff, None, None) + tuple(drs)
+
+
+def dseb_combine(y, w, diff, recons: Sequence[Optional[Tensor]], ycoef: float = 2.0):
+    return DsebCombineFn.apply(y, w, diff, ycoef, len(recons), *recons)
+
+
+# =====================================================================================================
+# loss (utils/core.py:44-80,161-188)
+# =====================================================================================================
+class DiceCELossFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, w_dice, w_ce):
+        logits, labels = _c(logits), _c(labels)
+        B, K = logits.shape[:2]
+        HW = logits.numel() // (B * K)
+        acc = _empty((3 * K + 1,), logits)
+        loss = _empty((1,), logits)
+        kern.dice_ce_fwd(logits, labels, acc, loss, B, K, HW, w_dice, w_ce)
+        ctx.save_for_backward(logits, labels, acc)
+        ctx.cfg = (w_dice, w_ce)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, acc = ctx.saved_tensors
+        w_dice, w_ce = ctx.cfg
+        B, K = logits.shape[:2]
+        HW = logits.numel() // (B * K)
+        g = _c(g).reshape(1)
+        d = torch.empty_like(logits)
+        kern.dice_ce_bwd(logits, labels, acc, g, d, B, K, HW, w_dice, w_ce)
+        return d, None, None, None
+
+
+def dice_ce_loss(logits, labels, w_dice=0.5, w_ce=0.5):
+    return DiceCELossFn.apply(logits, labels, w_dice, w_ce)

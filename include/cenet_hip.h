@@ -1,0 +1,211 @@
+/* cenet_hip.h — C ABI of libcenet_hip.so, the MI355X (gfx950) kernel library behind cenet_amd.networks.CENet.
+ *
+ * The reference (xmindflow/cenet) is pure PyTorch: its "FFI" for this path is the ATen operator set its
+ * nn.Modules call.  Each entry point below replaces the ATen op group cited next to it (file:line relative to
+ * /root/reference/src/); cenet_amd/ops.py binds them with ctypes and wraps them in torch.autograd.Functions,
+ * and cenet_amd/networks mirrors the reference's nn.Module tree on top.
+ *
+ * Conventions: raw device pointers; no allocation, no ownership transfer and no host synchronisation inside;
+ * workspaces are passed in; every call takes the HIP stream to launch on and is re-entrant (called from the
+ * autograd worker thread); return 0 on success, non-zero error code otherwise (the Python wrapper raises).
+ * All tensors are fp32 ("f32" suffix).  "NCHW" tensors are addressed as ptr[b*sb + c*HW + y*W + x] so that a
+ * channel slice of a larger tensor is (ptr + lo*HW, sb = Ctotal*HW).  "TOK" tensors are [B, N, C] contiguous.
+ * Functions whose name ends in _acc ADD into their gradient outputs (the flat gradient arena is zeroed once
+ * per step), using float atomics where several workgroups share a destination.
+ */
+#ifndef CENET_HIP_H
+#define CENET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef CENET_HOSTSIM_BUILD
+typedef struct ihipStream_t* cenet_stream_t;
+#else
+typedef void* cenet_stream_t;
+#endif
+
+/* ---- GEMM / implicit-GEMM convolution (gemm.hip) ------------------------------------------------------- */
+/* Logical matrix operand. mode 0: elem(r,c) = ptr[b*sb + kb*skb + r*sr + c*sc].
+ * mode 1: on-the-fly im2col view of an image tensor: with patch index e=(ci,ky,kx) and pixel index p=(py,px)
+ *   (e,p) = patch_is_row ? (r,c) : (c,r);
+ *   !transposed: iy = py*stride - pad + ky*dil           (conv forward / weight-gradient gather)
+ *    transposed: iy = (py + pad - ky*dil)/stride if divisible   (data-gradient gather)
+ *   elem = in-range ? ptr[b*sb + kb*skb + ci*sci + iy*sy + ix*sx] : 0.
+ * kfast: 1 if consecutive k are adjacent in memory (picks the coalesced staging pattern). */
+typedef struct {
+  const float* ptr;
+  long sb, sb2, skb, sr, sc; /* batch z -> (z / nb_inner, z % nb_inner): offset = (z/nb_inner)*sb + (z%nb_inner)*sb2 */
+  long sk_outer;             /* mode 0 with kinner > 0: k -> (k / kinner)*sk_outer + (k % kinner)*(sc or sr) */
+  int kinner;
+  int mode, kfast;
+  int patch_is_row, transposed;
+  int KH, KW, Pw, Hs, Ws, stride, pad, dil;
+  long sci, sy, sx;
+} cenet_mat_t;
+
+/* Epilogue: v = alpha*acc; atomic ? C += v : C = bscale[b]*act(v + bias) + R. */
+typedef struct {
+  float* C;
+  long scb, scb2, scr, scc;
+  const float* bias;
+  int bias_on_row;
+  int act;
+  float slope;
+  const float* bscale;
+  const float* R;
+  long srb, srb2, srr, src;
+  int atomic;
+  float alpha;
+} cenet_epi_t;
+
+/* Replaces aten::addmm/mm/bmm/convolution(+_backward) — pvtv2.py:41,45,90,98,106,164; cfam.py:149,158,299,302;
+ * nlb.py:106-115,142; blocks.py:178,211,320; dseb.py:164; unet.py:156-197; multihead_diffattn.py:79-81,126. */
+int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K,
+                   int nbatch, int nb_inner, int nkb, int splits, cenet_stream_t stream);
+
+/* ---- attention (attn.hip) -------------------------------------------------------------------------------- */
+/* Element (b,h,i,d) of Q = q[b*qsb + h*qsh + i*qsi + d*qsd]; same for K (Nk rows), V (head h / v_head_div,
+ * width Dv) and O / dO (strides os*).  lse, delta: [B,H,Nq].  When v_head_div > 1 the backward ADDS into dv
+ * with atomics (caller zero-fills dv). */
+typedef struct {
+  const float *q, *k, *v;
+  float* o;
+  float* lse;
+  const float* dout;
+  float *dq, *dk, *dv, *delta;
+  long qsb, qsh, qsi, qsd, ksb, ksh, ksi, ksd, vsb, vsh, vsi, vsd, osb, osh, osi, osd;
+  int B, H, Nq, Nk, D, Dv, v_head_div;
+  float scale;
+} cenet_attn_t;
+/* Replaces q@k^T -> softmax -> @v (pvtv2.py:101-105; nlb.py:117-138; multihead_diffattn.py:96-116) and backward.
+ * Supported head dims: D<=64 with Dv<=128 (cenet_flash_attn_supported). */
+int cenet_flash_attn_supported(int D, int Dv);
+int cenet_flash_attn_fwd_f32(const cenet_attn_t* p, cenet_stream_t stream);
+int cenet_flash_attn_bwd_f32(const cenet_attn_t* p, cenet_stream_t stream);
+/* Row softmax for the materialised path (head dims > 128): aten::_softmax(+_backward_data). */
+int cenet_softmax_rows_fwd_f32(const float* x, float* y, long rows, int n, cenet_stream_t stream);
+int cenet_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long rows, int n, cenet_stream_t stream);
+
+/* ---- normalisation (norm.hip) ----------------------------------------------------------------------------- */
+/* aten::native_layer_norm(+_backward) — pvtv2.py:117,124,166,69,221-245. x,y [rows,C]. */
+int cenet_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            int rows, int C, float eps, cenet_stream_t stream);
+int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                float* dx, float* dgamma_acc, float* dbeta_acc, int rows, int C, cenet_stream_t stream);
+/* aten::native_batch_norm(+_backward), training mode — cfam.py:22-32,92,250; blocks.py:151,161,212,307; nlb.py:81;
+ * unet.py:175-197.  ws: 2*C floats of scratch.  stats writes batch mean / biased var and updates the running
+ * buffers (momentum, unbiased var) and num_batches_tracked when given. */
+int cenet_bn_stats_f32(const float* x, long sb, int B, int C, int HW, float* ws, float* mean, float* var,
+                       float* running_mean, float* running_var, float momentum, long* num_batches_tracked,
+                       cenet_stream_t stream);
+int cenet_bn_apply_f32(const float* x, long sxb, float* y, long syb, const float* mean, const float* var, float eps,
+                       const float* gamma, const float* beta, int act, float slope, int B, int C, int HW,
+                       cenet_stream_t stream);
+int cenet_bn_bwd_acc_f32(const float* dy, long sgb, const float* x, long sxb, float* dx, long sdb, const float* mean,
+                         const float* var, float eps, const float* gamma, const float* beta, int act, float slope, int B,
+                         int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, cenet_stream_t stream);
+
+/* ---- depthwise 3x3 conv (dwconv.hip) — aten::convolution(groups=C)(+_backward) ------------------------------ */
+/* pvtv2.py:359-370 (token layout), cfam.py:132-140, blocks.py:142-150,305 (NCHW). y = conv(x)+bias; a = act(y) if a. */
+int cenet_dwconv3x3_nchw_f32(const float* x, long sxb, const float* w, const float* bias, float* y, long syb, float* a,
+                             long sab, int B, int C, int H, int W, int dil, int flip, int act, float slope,
+                             cenet_stream_t stream);
+int cenet_dwconv3x3_tok_f32(const float* x, const float* w, const float* bias, float* y, float* a, int B, int C, int H, int W,
+                            int flip, int act, float slope, cenet_stream_t stream);
+int cenet_dwconv3x3_wgrad_nchw_acc_f32(const float* x, long sxb, const float* dy, long sgb, float* dw_acc, float* dbias_acc,
+                                       int B, int C, int H, int W, int dil, cenet_stream_t stream);
+int cenet_dwconv3x3_wgrad_tok_acc_f32(const float* x, const float* dy, float* dw_acc, float* dbias_acc, int B, int C, int H,
+                                      int W, cenet_stream_t stream);
+
+/* ---- resampling (resample.hip) ---------------------------------------------------------------------------- */
+/* aten::upsample_bilinear2d(+_backward) — dseb.py:67-68; cfam.py:217,232; blocks.py:210; out.py:74 */
+int cenet_bilinear_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                           float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
+int cenet_bilinear_bwd_acc_f32(const float* dy, long sgb, float* dx_acc, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                               float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
+/* aten::upsample_nearest2d(+_backward) x2 — blocks.py:304 */
+int cenet_nearest2x_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, cenet_stream_t stream);
+int cenet_nearest2x_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi, cenet_stream_t stream);
+/* aten::_adaptive_avg_pool2d(+_backward) — cfam.py:213 */
+int cenet_adaptive_avgpool_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                   cenet_stream_t stream);
+int cenet_adaptive_avgpool_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                   cenet_stream_t stream);
+/* aten::max_pool2d_with_indices(2,2)(+_backward) fused with the per-channel scale of out.py:70 */
+int cenet_maxpool2_fwd_f32(const float* x, float* y, long syb, const float* scale, int B, int C, int Hi, int Wi,
+                           cenet_stream_t stream);
+int cenet_maxpool2_bwd_acc_f32(const float* x, const float* dy, long sgb, float* dx, const float* scale, float* dscale_acc,
+                               int B, int C, int Hi, int Wi, cenet_stream_t stream);
+
+/* ---- CCU / SRM statistics gates (stats.hip) — cfam.py:251-264, 93-101 --------------------------------------- */
+int cenet_ccu_stats_fwd_f32(const float* x, const float* fc1, const float* fc2, float* u, int* amax, float* z, int B, int C,
+                            int HW, cenet_stream_t stream);
+int cenet_gate_chan_fwd_f32(const float* x, const float* g, float* y, int BC, int HW, cenet_stream_t stream);
+int cenet_gate_chan_bwd_reduce_f32(const float* x, const float* dy, const float* g, float* dg, int BC, int HW,
+                                   cenet_stream_t stream);
+int cenet_ccu_bwd_apply_acc_f32(const float* x, const float* dy, const float* g, const float* dz, const float* u,
+                                const int* amax, const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc,
+                                float* dx, int B, int C, int HW, cenet_stream_t stream);
+int cenet_srm_stats_fwd_f32(const float* x, float* u, int* amax, int B, int C, int HW, cenet_stream_t stream);
+int cenet_srm_conv_fwd_f32(const float* u, const float* pwc, const float* dwc, float* f, int B, int H, int W,
+                           cenet_stream_t stream);
+int cenet_srm_conv_bwd_acc_f32(const float* u, const float* df, const float* pwc, const float* dwc, float* du, float* dpwc_acc,
+                               float* ddwc_acc, int B, int H, int W, cenet_stream_t stream);
+int cenet_gate_pix_fwd_f32(const float* x, const float* f, float* y, int B, int C, int HW, cenet_stream_t stream);
+int cenet_gate_pix_bwd_reduce_f32(const float* x, const float* dy, const float* f, float* df, int B, int C, int HW,
+                                  cenet_stream_t stream);
+int cenet_srm_bwd_apply_f32(const float* x, const float* dy, const float* f, const float* u, const float* du, const int* amax,
+                            float* dx, int B, int C, int HW, cenet_stream_t stream);
+
+/* ---- glue (elementwise.hip) --------------------------------------------------------------------------------- */
+int cenet_transpose_f32(const float* x, long sxb, float* y, long syb, int B, int R, int Cc, cenet_stream_t stream);
+int cenet_copy_batched_f32(const float* x, long sxb, float* y, long syb, int B, long n, int accumulate, cenet_stream_t stream);
+int cenet_scale_batch_f32(const float* x, const float* s, float* y, int B, long n, cenet_stream_t stream);
+int cenet_act_fwd_f32(const float* x, float* y, long n, int act, float slope, cenet_stream_t stream);
+int cenet_act_bwd_f32(const float* pre, const float* dy, float* dx, long n, int act, float slope, cenet_stream_t stream);
+int cenet_silu_mul_fwd_f32(const float* a, const float* b, float* y, long n, cenet_stream_t stream);
+int cenet_silu_mul_bwd_f32(const float* a, const float* b, const float* dy, float* da, float* db, long n, cenet_stream_t stream);
+int cenet_mix_fwd_f32(const float* x, const float* p, const float* w, float* z, long n, cenet_stream_t stream);
+int cenet_mix_bwd_acc_f32(const float* x, const float* p, const float* w, const float* dz, float* dx, float* dp, float* dw_acc,
+                          long n, cenet_stream_t stream);
+int cenet_scale_residual_fwd_f32(const float* x, const float* y, const float* ls, float* out, int B, int C, int HW,
+                                 cenet_stream_t stream);
+int cenet_scale_chan_f32(const float* g, const float* ls, float* out, int B, int C, int HW, cenet_stream_t stream);
+int cenet_chan_dot_acc_f32(const float* a, long sab, const float* b, long sbb, float* out_acc, int B, int C, int HW,
+                           cenet_stream_t stream);
+int cenet_col_sum_acc_f32(const float* a, float* out_acc, long R, int C, cenet_stream_t stream);
+int cenet_add_act_fwd_f32(const float* a, const float* b, float* out, long n, int act, float slope, cenet_stream_t stream);
+int cenet_lrelu_bwd_from_out_f32(const float* out, const float* dy, float* dx, long n, float slope, cenet_stream_t stream);
+/* dseb.py:40-50,63-76,156-163: z = ycoef*y + w[c]*edge(y, r_0..r_{n-1}) + diff*y (r_s NULL = scale 1.0; diff NULL = 0) */
+int cenet_dseb_combine_fwd_f32(const float* y, const float* r0, const float* r1, const float* r2, int n, const float* w,
+                               const float* diff, float ycoef, float* z, int B, int C, int HW, cenet_stream_t stream);
+int cenet_dseb_combine_bwd_acc_f32(const float* y, const float* r0, const float* r1, const float* r2, int n, const float* w,
+                                   const float* diff, float ycoef, const float* dz, float* dy, float* dr0, float* dr1, float* dr2,
+                                   float* ddiff, float* dw_acc, int B, int C, int HW, cenet_stream_t stream);
+/* multihead_diffattn.py:112-123: lambda, A1-lambda*A2 combine, RMSNorm(2hd, eps, no affine), *(1-lambda_init) */
+int cenet_diffattn_lambda_fwd_f32(const float* q1, const float* k1, const float* q2, const float* k2, float lambda_init,
+                                  float* lam3, int hd, cenet_stream_t stream);
+int cenet_diffattn_lambda_bwd_acc_f32(const float* q1, const float* k1, const float* q2, const float* k2, const float* lam3,
+                                      const float* dlam, float* dq1, float* dk1, float* dq2, float* dk2, int hd,
+                                      cenet_stream_t stream);
+int cenet_diffattn_combine_fwd_f32(const float* U, const float* lam3, float* out, int B, int H, int N, int dv, float eps,
+                                   float post, cenet_stream_t stream);
+int cenet_diffattn_combine_bwd_acc_f32(const float* U, const float* lam3, const float* dout, float* dU, float* dlam_acc, int B,
+                                       int H, int N, int dv, float eps, float post, cenet_stream_t stream);
+
+/* ---- loss + optimiser (loss_optim.hip) ---------------------------------------------------------------------- */
+/* utils/core.py:44-80,161-188: loss = w_dice*Dice(softmax(logits), onehot(labels)) + w_ce*CE; acc: 3K+1 floats */
+int cenet_dice_ce_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int HW, float w_dice,
+                          float w_ce, cenet_stream_t stream);
+int cenet_dice_ce_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout, float* dlogits, int B,
+                          int K, int HW, float w_dice, float w_ce, cenet_stream_t stream);
+/* torch.optim.SGD(momentum, weight_decay) over a flat arena; hyper5 (device) = [lr, momentum, wd, grad_scale, first_step] */
+int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, cenet_stream_t stream);
+int cenet_zero_f32(float* p, long n, cenet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CENET_HIP_H */

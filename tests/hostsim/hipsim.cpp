@@ -1,0 +1,89 @@
+// hipsim.cpp — TEST INFRASTRUCTURE ONLY (see hipsim.h).
+#include "hipsim.h"
+
+uint3_sim threadIdx, blockIdx;
+dim3 blockDim, gridDim;
+
+namespace hipsim {
+static State g_state;
+static unsigned long g_progress = 0;
+State& st() { return g_state; }
+void note_progress() { ++g_progress; }
+
+static const size_t kStack = 256 * 1024;
+
+void yield() {
+  State& s = g_state;
+  int me = s.cur;
+  swapcontext(&s.fibers[me].ctx, &s.sched);
+  threadIdx = s.fibers[me].tid;
+}
+
+void wave_barrier() {
+  State& s = g_state;
+  int w = s.cur >> 6;
+  int nl = s.nthreads - w * 64;
+  if (nl > 64) nl = 64;
+  unsigned g = s.wgen[w];
+  if (++s.warrived[w] == nl) {
+    s.warrived[w] = 0;
+    s.wgen[w]++;
+    ++g_progress;
+  } else {
+    while (s.wgen[w] == g) yield();
+  }
+}
+
+static void trampoline() {
+  State& s = g_state;
+  s.body();
+  s.fibers[s.cur].done = true;
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  State& s = g_state;
+  int n = (int)(block.x * block.y * block.z);
+  if (n > 1024) { fprintf(stderr, "hipsim: block too large\n"); abort(); }
+  if ((int)s.fibers.size() < n) {
+    size_t old = s.fibers.size();
+    s.fibers.resize(n);
+    for (size_t i = old; i < (size_t)n; ++i) s.fibers[i].stack = (char*)malloc(kStack);
+  }
+  s.body = body;
+  s.nthreads = n;
+  blockDim = block;
+  gridDim = grid;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blockIdx = uint3_sim{bx, by, bz};
+        s.arrived = 0;
+        memset(s.warrived, 0, sizeof(s.warrived));
+        for (int t = 0; t < n; ++t) {
+          Fiber& f = s.fibers[t];
+          getcontext(&f.ctx);
+          f.ctx.uc_stack.ss_sp = f.stack;
+          f.ctx.uc_stack.ss_size = kStack;
+          f.ctx.uc_link = nullptr;
+          f.done = false;
+          f.tid = uint3_sim{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+          makecontext(&f.ctx, (void (*)())trampoline, 0);
+        }
+        int remaining = n;
+        while (remaining > 0) {
+          unsigned long before = g_progress;
+          for (int t = 0; t < n; ++t) {
+            Fiber& f = s.fibers[t];
+            if (f.done) continue;
+            s.cur = t;
+            threadIdx = f.tid;
+            swapcontext(&s.sched, &f.ctx);
+            if (f.done) { --remaining; ++g_progress; }
+          }
+          if (g_progress == before) { fprintf(stderr, "hipsim: deadlock (divergent barrier / shuffle?)\n"); abort(); }
+        }
+      }
+  s.cur = -1;
+}
+}  // namespace hipsim

@@ -1,0 +1,76 @@
+"""GEMM / implicit-GEMM kernel vs plain PyTorch fp32 (sim on CPU here, real kernels with -m gpu)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from backend import dev  # noqa: F401
+from cenet_amd import kern
+
+
+def rnd(*s, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*s, generator=g).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (70, 50, 45), (130, 33, 7)])
+def test_gemm_nt_bias(dev, M, N, K):
+    x, w, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, seed=1), rnd(N, dev=dev, seed=2)
+    y = torch.empty(M, N, device=dev)
+    kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(w, 1, K, kfast=1), y, M, N, K, scr=N, scc=1, bias=b)
+    torch.testing.assert_close(y.cpu(), F.linear(x, w, b).cpu(), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_batched_nn_epilogue(dev):
+    Bt, M, N, K = 3, 20, 70, 24
+    w, x = rnd(M, K, dev=dev), rnd(Bt, K, N, dev=dev, seed=1)
+    bias, R, bs = rnd(M, dev=dev, seed=2), rnd(Bt, M, N, dev=dev, seed=3), rnd(Bt, dev=dev, seed=4)
+    y = torch.empty(Bt, M, N, device=dev)
+    kern.gemm(kern.mat_plain(w, K, 1, kfast=1), kern.mat_plain(x, N, 1, sb=K * N), y, M, N, K, scr=N, scc=1,
+              scb=M * N, nbatch=Bt, bias=bias, bias_on_row=True, act="gelu", bscale=bs, R=R, srb=M * N, srr=N, src=1)
+    ref = F.gelu(torch.matmul(w, x) + bias[None, :, None]) * bs[:, None, None] + R
+    torch.testing.assert_close(y.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_splitk_atomic_kbatch(dev):
+    Bt, Co, Ci, HW = 4, 10, 12, 50
+    dy, x = rnd(Bt, Co, HW, dev=dev), rnd(Bt, Ci, HW, dev=dev, seed=1)
+    dw = torch.zeros(Co, Ci, device=dev)
+    kern.gemm(kern.mat_plain(dy, HW, 1, skb=Co * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Ci * HW, kfast=1), dw,
+              Co, Ci, HW, scr=Ci, scc=1, nkb=Bt, splits=3, atomic=True)
+    ref = torch.einsum("bop,bip->oi", dy, x)
+    torch.testing.assert_close(dw.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k,stride,pad,dil", [(3, 1, 1, 1), (7, 4, 3, 1), (3, 2, 1, 1), (2, 2, 0, 1), (5, 1, 2, 1)])
+def test_conv_igemm_fwd_dgrad_wgrad(dev, k, stride, pad, dil):
+    Bt, Ci, Co, H, W = 2, 5, 6, 13, 11
+    x, w = rnd(Bt, Ci, H, W, dev=dev), rnd(Co, Ci, k, k, dev=dev, seed=1)
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=stride, padding=pad, dilation=dil)
+    gy = rnd(Bt, Co, Ho, Wo, dev=dev, seed=2)
+    ref.backward(gy)
+    # forward: y[b] = W[Co, Ci*k*k] x im2col(x[b])
+    y = torch.empty(Bt, Co, Ho, Wo, device=dev)
+    Bm = kern.mat_im2col(x, sb=Ci * H * W, skb=0, sci=H * W, sy=W, sx=1, KH=k, KW=k, Pw=Wo, Hs=H, Ws=W,
+                         stride=stride, pad=pad, dil=dil, patch_is_row=1, transposed=0, kfast=0)
+    kern.gemm(kern.mat_plain(w, Ci * k * k, 1, kfast=1), Bm, y, Co, Ho * Wo, Ci * k * k, scr=Ho * Wo, scc=1,
+              scb=Co * Ho * Wo, nbatch=Bt)
+    torch.testing.assert_close(y.cpu(), ref.detach().cpu(), rtol=1e-4, atol=1e-4)
+    # dgrad: dx[b] = Wt[Ci, Co*k*k] x gather(dy[b])
+    wt = w.permute(1, 0, 2, 3).contiguous()
+    dx = torch.empty_like(x)
+    Bm = kern.mat_im2col(gy, sb=Co * Ho * Wo, skb=0, sci=Ho * Wo, sy=Wo, sx=1, KH=k, KW=k, Pw=W, Hs=Ho, Ws=Wo,
+                         stride=stride, pad=pad, dil=dil, patch_is_row=1, transposed=1, kfast=0)
+    kern.gemm(kern.mat_plain(wt, Co * k * k, 1, kfast=1), Bm, dx, Ci, H * W, Co * k * k, scr=H * W, scc=1,
+              scb=Ci * H * W, nbatch=Bt)
+    torch.testing.assert_close(dx.cpu(), xr.grad.cpu(), rtol=1e-4, atol=1e-4)
+    # wgrad: dW[Co, Ci*k*k] += sum_b dy[b] x im2col(x[b])^T
+    dw = torch.zeros_like(w)
+    Bm = kern.mat_im2col(x, sb=0, skb=Ci * H * W, sci=H * W, sy=W, sx=1, KH=k, KW=k, Pw=Wo, Hs=H, Ws=W,
+                         stride=stride, pad=pad, dil=dil, patch_is_row=0, transposed=0, kfast=1)
+    kern.gemm(kern.mat_plain(gy, Ho * Wo, 1, skb=Co * Ho * Wo, kfast=1), Bm, dw, Co, Ci * k * k, Ho * Wo,
+              scr=Ci * k * k, scc=1, nkb=Bt, splits=2, atomic=True)
+    torch.testing.assert_close(dw.cpu(), wr.grad.cpu(), rtol=1e-4, atol=1e-4)
