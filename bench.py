@@ -1,0 +1,186 @@
+"""bench.py — training throughput of the CENet hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = the reference's train-step body (src/main_acdc.py:237-257) on one synthetic batch already resident in
+HBM: zero_grad -> CENet forward -> Dice+CE (0.5/0.5) -> backward -> gradient all-reduce (RCCL) -> fused SGD.
+Workload = BASELINE.json configs[1]: ACDC 224x224, 4 classes, batch 32 per GPU, random-init PVTv2-b2 CENet.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, timed live with
+HIP events on the launch stream) and `cpu_baseline` (the oracle timed on the host cores, rank 0, N == 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE.json configs[1]: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def make_model(dev):
+    from cenet_amd.networks import CENet
+    torch.manual_seed(1234)
+    net = CENet(input_channels=1, num_classes=4, scale_factors=[1.0, 0.5], diffatt_num_heads=[4, 4, 4],
+                encoder="pvt_v2_b2", enc_pretrain=False, skip_mode="cat", dec_up_block="eucb", out_merge_mode="cat",
+                out_up_block="upcn", out_up_ks=3)
+    return net.to(dev).train()
+
+
+def synthetic(B, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 1, 224, 224, generator=g)
+    lab = torch.randint(0, 4, (B, 224, 224), generator=g).float()
+    return x.to(dev), lab.to(dev)
+
+
+def dominant_kernel_probe(dev, B):
+    """Times the single heaviest launch of the step in isolation with HIP events on the launch stream:
+    gemm_f32_kernel<im2col> computing out.rb.0.conv2 forward (5x5, 32->32 channels @224x224, reference out.py:41-44).
+    Algorithmic FLOPs per launch = 2 * B * Cout * Ho*Wo * Cin*k*k."""
+    from cenet_amd import ops
+    x = torch.randn(B, 32, 224, 224, device=dev)
+    w = torch.randn(32, 32, 5, 5, device=dev) * 0.03
+    with torch.no_grad():
+        for _ in range(2):
+            ops.conv2d_nchw(x, w, None, stride=1, pad=2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record()
+        for _ in range(reps):
+            ops.conv2d_nchw(x, w, None, stride=1, pad=2)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * B * 32 * 224 * 224 * 32 * 25
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_f32_kernel<im2col> (out.rb.0.conv2 fwd, 5x5 32->32 @224^2)",
+            "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4)}
+
+
+def cpu_baseline(steps):
+    """The oracle (plain PyTorch fp32 restatement, parity-pinned to the reference) timed on the host cores:
+    BASELINE.json configs[0] = ACDC 224x224 4-class, batch 4, forward + Dice/CE + backward + SGD."""
+    from oracle import cenet_oracle as O
+    cfg = O.CENetConfig()
+    n = min(os.cpu_count() or 8, 32)  # a batch-4 step stops scaling (and then regresses) beyond ~32 host threads
+    torch.set_num_threads(n)
+    sd = O.make_state_dict(cfg, seed=1)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    mom = {}
+    x, lab = O.synthetic_batch(4, 1, 4, seed=1234)
+
+    def step():
+        for v in params.values():
+            v.grad = None
+        loss = O.criterion(O.cenet_forward(sd, x, cfg, training=True), lab, 4)
+        loss.backward()
+        with torch.no_grad():
+            for k, v in params.items():
+                g = v.grad + 1e-4 * v
+                mom[k] = g.clone() if k not in mom else mom[k].mul_(0.9).add_(g)
+                v.sub_(0.01 * mom[k])
+    step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(4.0 / dt, 4), "unit": "images/s", "cores": n, "kind": "port",
+            "sample": f"{steps} train steps of ACDC 224x224 4-class batch=4 fp32 (oracle/cenet_oracle.py), {dt:.2f} s/step"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from cenet_amd import losses, optim, parallel
+    net = make_model(dev)
+    arena = optim.ParamArena(net, optim.cenet_segments())
+    reducer = parallel.GradReducer(arena) if world > 1 else None
+    if reducer is not None:
+        reducer.broadcast_state(net)
+        parallel.attach(net, reducer)
+    opt = optim.FusedSGD(arena, lr=0.01, momentum=0.9, weight_decay=1e-4, grad_scale=1.0 / world)
+    sched = optim.PolyLR(opt, max_iterations=100000)
+    crit = losses.Criterion(4, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
+    x, lab = synthetic(a.batch, dev, seed=1234 + rank)
+
+    def step():
+        opt.zero_grad()
+        loss = crit(net(x), lab)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        sched.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        out = {"metric": "training images/sec (224x224, 4-class)", "value": round(a.batch * world * a.steps / dt, 3),
+               "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "ACDC 224x224 4-class, batch=32/GPU, random-init PVTv2-b2 CENet, "
+                                      "fwd + Dice/CE + bwd + grad all-reduce + SGD(momentum .9, wd 1e-4)",
+                          "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                          "final_loss": round(final_loss, 5)}}
+        out["roofline"] = dominant_kernel_probe(dev, a.batch)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

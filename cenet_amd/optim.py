@@ -1,0 +1,140 @@
+"""Flat parameter/gradient arena, fused SGD and the poly LR schedule.
+
+Mirrors the reference's optimiser plumbing (src/utils/core.py:12-41: torch.optim.SGD(lr, momentum 0.9, weight_decay)
+and LambdaLR (1 - it/max)^0.9) on top of ONE contiguous fp32 buffer for parameters, one for gradients and one for
+momentum, so that per step there is one memset, one fused update kernel and a handful of large all-reduces instead
+of 630 small ones.  `torch.optim.SGD(net.parameters())` keeps working on arena-backed parameters
+(their `.data` / `.grad` are views), so the reference's `get_optimizer` can also be used unchanged.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import kern
+
+ALIGN = 64  # elements (256 B)
+
+
+class ParamArena:
+    """Re-homes every trainable parameter of `model` into one flat buffer (and its gradient into another).
+
+    segments: optional ordered list of (name, predicate(param_name) -> bool); parameters are laid out segment by
+    segment so that a gradient segment is one contiguous slice (used as an all-reduce bucket). Call AFTER the model
+    has been moved to its device.
+    """
+
+    def __init__(self, model: nn.Module, segments: Optional[Sequence[Tuple[str, Callable[[str], bool]]]] = None):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if not named:
+            raise ValueError("no trainable parameters")
+        dev = named[0][1].device
+        if segments is None:
+            segments = [("all", lambda n: True)]
+        order, self.segments = [], []
+        taken = set()
+        off = 0
+        for sname, pred in segments:
+            start = off
+            for n, p in named:
+                if n in taken or not pred(n):
+                    continue
+                taken.add(n)
+                order.append((n, p, off))
+                off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            self.segments.append((sname, start, off))
+        left = [n for n, _ in named if n not in taken]
+        if left:
+            raise ValueError(f"parameters not covered by any segment: {left[:5]}")
+        self.numel = off
+        self.params = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.index = {}
+        with torch.no_grad():
+            for n, p, o in order:
+                view = self.params[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grads[o:o + p.numel()].view(p.shape)
+                self.index[n] = (o, p.numel())
+        self._plist = [p for _, p, _ in order]
+        self._offs = [o for _, _, o in order]
+
+    def zero_grad(self):
+        """One memset for all gradients (re-attaches views if a caller set .grad to None)."""
+        kern.zero_(self.grads)
+        for p, o in zip(self._plist, self._offs):
+            if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
+                p.grad = self.grads[o:o + p.numel()].view(p.shape)
+
+    def segment_grad(self, i: int) -> torch.Tensor:
+        _, s, e = self.segments[i]
+        return self.grads[s:e]
+
+
+class FusedSGD:
+    """torch.optim.SGD(momentum, weight_decay, dampening 0, nesterov False) semantics, one kernel launch per step."""
+
+    def __init__(self, arena: ParamArena, lr: float, momentum: float = 0.9, weight_decay: float = 1e-4,
+                 grad_scale: float = 1.0):
+        self.arena = arena
+        self.lr, self.momentum, self.weight_decay, self.grad_scale = lr, momentum, weight_decay, grad_scale
+        self.buf = torch.zeros_like(arena.params)
+        self.hyper = torch.zeros(5, device=arena.params.device, dtype=torch.float32)
+        self._steps = 0
+        self._sync_hyper()
+
+    def _sync_hyper(self):
+        h = torch.tensor([self.lr, self.momentum, self.weight_decay, self.grad_scale, 1.0 if self._steps == 0 else 0.0],
+                         dtype=torch.float32)
+        self.hyper.copy_(h, non_blocking=True)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.arena.zero_grad()
+
+    def set_lr(self, lr: float):
+        self.lr = lr
+
+    def step(self):
+        self._sync_hyper()
+        kern.sgd_step(self.arena.params, self.arena.grads, self.buf, self.hyper, self.arena.numel)
+        self._steps += 1
+
+    @property
+    def param_groups(self):
+        return [{"lr": self.lr, "momentum": self.momentum, "weight_decay": self.weight_decay}]
+
+    def state_dict(self):
+        return {"buf": self.buf, "steps": self._steps, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.buf.copy_(sd["buf"])
+        self._steps, self.lr = sd["steps"], sd["lr"]
+
+
+class PolyLR:
+    """core.py:31: lr = base * (1 - step / max_iterations) ** 0.9 (LambdaLR semantics: step() after optimizer.step())."""
+
+    def __init__(self, optimizer: FusedSGD, max_iterations: int, power: float = 0.9):
+        self.opt, self.max_it, self.power = optimizer, max_iterations, power
+        self.base_lr = optimizer.lr
+        self.last_epoch = 0
+
+    def get_last_lr(self) -> List[float]:
+        return [self.opt.lr]
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.set_lr(self.base_lr * (1 - self.last_epoch / self.max_it) ** self.power)
+
+
+def cenet_segments():
+    """Arena layout for CENet in reverse-forward order: the gradient of each segment is complete (and can start its
+    all-reduce) when backward reaches the segment's input (cenet_amd.parallel)."""
+    return [("head+decoder", lambda n: n.startswith(("out.", "decoder."))),
+            ("stage4", lambda n: n.startswith(("backbone.patch_embed4", "backbone.block4", "backbone.norm4"))),
+            ("stage3", lambda n: n.startswith(("backbone.patch_embed3", "backbone.block3", "backbone.norm3"))),
+            ("stage2", lambda n: n.startswith(("backbone.patch_embed2", "backbone.block2", "backbone.norm2"))),
+            ("stage1", lambda n: n.startswith(("backbone.patch_embed1", "backbone.block1", "backbone.norm1")))]

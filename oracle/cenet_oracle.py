@@ -303,7 +303,7 @@ def multihead_diff_attn(sd: SD, p: str, x: Tensor, num_heads: int, depth: int) -
     v = F.linear(x, sd[p + ".v_proj.weight"]).view(B, N, num_heads, 2 * hd).transpose(1, 2)
     q = q * hd ** -0.5
     a = torch.nan_to_num(q @ k.transpose(-1, -2))
-    a = F.softmax(a, dim=-1, dtype=torch.float32)
+    a = F.softmax(a, dim=-1, dtype=torch.float32).type_as(a)
     l1 = torch.exp(torch.sum(sd[p + ".lambda_q1"] * sd[p + ".lambda_k1"], dim=-1).float())
     l2 = torch.exp(torch.sum(sd[p + ".lambda_q2"] * sd[p + ".lambda_k2"], dim=-1).float())
     lam = l1 - l2 + lam0

@@ -167,6 +167,24 @@ def gen_model_cases(core):
         rec["loss2"] = np.float64(loss2.item())
         for k in PROBE_KEYS:
             rec["p2." + k + ".head"] = params[k].detach().reshape(-1)[:16].numpy().copy()
+        # the same first training pass evaluated by the reference in float64: lets the tests bound the product's error
+        # by the reference's OWN fp32 rounding error on cancellation-dominated gradients (e.g. conv weights feeding a BN)
+        torch.manual_seed(5)
+        net64 = CENet(**kw)
+        sd64 = net64.state_dict()
+        O.fill_state_dict_(sd64, seed=42)
+        net64 = net64.double()
+        net64.train()
+        net64.backbone.reset_drop_path(0.0)
+        lt64 = net64(x.double())
+        loss64 = crit(lt64, lab.double())
+        loss64.backward()
+        rec["loss64"] = np.float64(loss64.item())
+        p64 = dict(net64.named_parameters())
+        for k in PROBE_KEYS:
+            gk = p64[k].grad.reshape(-1)
+            rec["g64." + k + ".norm"] = np.float64(gk.norm().item())
+            rec["g64." + k + ".head"] = gk[:16].numpy().copy()
         np.savez_compressed(os.path.join(OUT, f"model_{name}.npz"), **rec)
         print(f"[golden] model_{name}: loss {loss.item():.6f} -> {loss2.item():.6f}  dice_eval {rec['dice_eval']:.4f}")
 
