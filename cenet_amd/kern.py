@@ -423,3 +423,12 @@ def zero_(t: torch.Tensor):
     _chk(t)
     _call("cenet_zero_f32", t, L(t.numel()))
     return t
+
+
+def set_compute_bf16(on: bool) -> bool:
+    """GEMM/conv operand precision: False = fp32 (parity mode, default), True = bf16 operands + fp32 accumulate."""
+    return bool(_lib.lib().cenet_set_compute_bf16(int(bool(on))))
+
+
+def get_compute_bf16() -> bool:
+    return bool(_lib.lib().cenet_get_compute_bf16())

@@ -65,6 +65,11 @@ typedef struct {
 int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K,
                    int nbatch, int nb_inner, int nkb, int splits, cenet_stream_t stream);
 
+/* Process-wide operand precision of the GEMM / conv core: 0 = fp32 operands (exact, parity mode, default),
+ * 1 = operands rounded to bf16 on their way into LDS, fp32 accumulate (throughput mode). Returns the old value. */
+int cenet_set_compute_bf16(int on);
+int cenet_get_compute_bf16(void);
+
 /* ---- attention (attn.hip) -------------------------------------------------------------------------------- */
 /* Element (b,h,i,d) of Q = q[b*qsb + h*qsh + i*qsi + d*qsd]; same for K (Nk rows), V (head h / v_head_div,
  * width Dv) and O / dO (strides os*).  lse, delta: [B,H,Nq].  When v_head_div > 1 the backward ADDS into dv

@@ -74,3 +74,23 @@ def test_conv_igemm_fwd_dgrad_wgrad(dev, k, stride, pad, dil):
     kern.gemm(kern.mat_plain(gy, Ho * Wo, 1, skb=Co * Ho * Wo, kfast=1), Bm, dw, Co, Ci * k * k, Ho * Wo,
               scr=Ci * k * k, scc=1, nkb=Bt, splits=2, atomic=True)
     torch.testing.assert_close(dw.cpu(), wr.grad.cpu(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 150, 100), (32, 300, 70), (130, 64, 129)])
+def test_gemm_tiles_fp32_and_bf16(dev, M, N, K):
+    """larger shapes exercise the 128x128 / 32x256 tiles; bf16-operand mode is checked against bf16-rounded inputs."""
+    x, w, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, seed=1), rnd(N, dev=dev, seed=2)
+    y = torch.empty(M, N, device=dev)
+    kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(w, 1, K, kfast=1), y, M, N, K, scr=N, scc=1, bias=b)
+    torch.testing.assert_close(y.cpu(), F.linear(x, w, b).cpu(), rtol=1e-4, atol=1e-4)
+    # transposed operands (mfast staging): y2 = x^T-view GEMM
+    xt = x.t().contiguous()  # [K, M]
+    kern.gemm(kern.mat_plain(xt, 1, M, kfast=0), kern.mat_plain(w, 1, K, kfast=1), y, M, N, K, scr=N, scc=1, bias=b)
+    torch.testing.assert_close(y.cpu(), F.linear(x, w, b).cpu(), rtol=1e-4, atol=1e-4)
+    old = kern.set_compute_bf16(True)
+    try:
+        kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(w, 1, K, kfast=1), y, M, N, K, scr=N, scc=1, bias=b)
+    finally:
+        kern.set_compute_bf16(old)
+    ref = F.linear(x.bfloat16().float(), w.bfloat16().float(), b)
+    torch.testing.assert_close(y.cpu(), ref.cpu(), rtol=1e-3, atol=1e-3)

