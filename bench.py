@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE.json configs[1]: 32)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="operand precision of the MFMA contractions (accumulation, softmax and norm statistics stay fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -124,7 +126,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from cenet_amd import losses, optim, parallel
+    from cenet_amd import kern, losses, optim, parallel
+    kern.set_compute_bf16(a.dtype == "bf16")
     net = make_model(dev)
     arena = optim.ParamArena(net, optim.cenet_segments())
     reducer = parallel.GradReducer(arena) if world > 1 else None
@@ -168,7 +171,7 @@ def main():
         ms = dt / a.steps * 1e3
         out = {"metric": "training images/sec (224x224, 4-class)", "value": round(a.batch * world * a.steps / dt, 3),
                "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "ACDC 224x224 4-class, batch=32/GPU, random-init PVTv2-b2 CENet, "
                                       "fwd + Dice/CE + bwd + grad all-reduce + SGD(momentum .9, wd 1e-4)",
                           "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",

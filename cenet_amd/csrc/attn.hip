@@ -56,6 +56,44 @@ __device__ __forceinline__ void stage_tile(float* dst, int pitch, const float* s
   }
 }
 
+
+// Register prefetch of a [64 x COLS] tile (same element map as stage_tile): load() issues the HBM reads, store() writes
+// them to LDS one phase later, so a tile's loads fly under the previous tile's MFMAs.
+template <int COLS>
+struct TilePrefetch {
+  float r[64 * COLS / 256];
+  __device__ __forceinline__ void load(const float* src, long s_row, long s_col, int row0, int nrows, int cols, int dfast) {
+#pragma unroll
+    for (int j = 0; j < 64 * COLS / 256; ++j) {
+      const int idx = threadIdx.x + 256 * j;
+      int rr, c;
+      if (dfast) {
+        rr = idx / COLS;
+        c = idx - rr * COLS;
+      } else {
+        c = idx >> 6;
+        rr = idx & 63;
+      }
+      r[j] = (row0 + rr < nrows && c < cols) ? src[(long)(row0 + rr) * s_row + (long)c * s_col] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* dst, int pitch, int dfast) const {
+#pragma unroll
+    for (int j = 0; j < 64 * COLS / 256; ++j) {
+      const int idx = threadIdx.x + 256 * j;
+      int rr, c;
+      if (dfast) {
+        rr = idx / COLS;
+        c = idx - rr * COLS;
+      } else {
+        c = idx >> 6;
+        rr = idx & 63;
+      }
+      dst[rr * pitch + c] = r[j];
+    }
+  }
+};
+
 // acc[t] (16x16 tiles over 64 columns) = A[arow0..+16][0..kdim) * B^T where both operands are k-contiguous in LDS:
 // A frag: As[(arow0 + lane&15)*pa + k + (lane>>4)], B frag: Bs[(16t + lane&15)*pb + k + (lane>>4)]
 __device__ __forceinline__ void mma_rowsxrows(f32x4 acc[4], const float* As, int pa, int arow0, const float* Bs, int pb,
@@ -114,12 +152,20 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
     l[r] = 0.f;
   }
   const int fr = lane & 15, fq = lane >> 4;
+  TilePrefetch<DQ> pk;
+  TilePrefetch<DV> pv;
+  pk.load(kb, a.ksi, a.ksd, 0, a.Nk, a.D, a.k_dfast);
+  pv.load(vb, a.vsi, a.vsd, 0, a.Nk, a.Dv, a.v_dfast);
 
   for (int j0 = 0; j0 < a.Nk; j0 += TK) {
     __syncthreads();  // previous tile fully consumed (also orders the Q staging on the first pass)
-    stage_tile(Ks, PQ, kb, a.ksi, a.ksd, j0, a.Nk, a.D, DQ, a.k_dfast);
-    stage_tile(Vs, PV, vb, a.vsi, a.vsd, j0, a.Nk, a.Dv, DV, a.v_dfast);
+    pk.store(Ks, PQ, a.k_dfast);
+    pv.store(Vs, PV, a.v_dfast);
     __syncthreads();
+    if (j0 + TK < a.Nk) {  // next tile's loads fly under this tile's MFMAs
+      pk.load(kb, a.ksi, a.ksd, j0 + TK, a.Nk, a.D, a.k_dfast);
+      pv.load(vb, a.vsi, a.vsd, j0 + TK, a.Nk, a.Dv, a.v_dfast);
+    }
     f32x4 s[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -138,11 +184,11 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int o_ = 1; o_ < 16; o_ <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o_));
       float mnew = fmaxf(m[r], mx);
-      alpha[r] = expf(m[r] - mnew);
+      alpha[r] = fast_exp(m[r] - mnew);
       float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        float p = (j0 + 16 * t + fr < a.Nk) ? expf(s[t][r] - mnew) : 0.f;
+        float p = (j0 + 16 * t + fr < a.Nk) ? fast_exp(s[t][r] - mnew) : 0.f;
         s[t][r] = p;
         rs += p;
       }
@@ -222,11 +268,19 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < NQ; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  TilePrefetch<DQ> pk;
+  TilePrefetch<DV> pv;
+  pk.load(kb, a.ksi, a.ksd, 0, a.Nk, a.D, a.k_dfast);
+  pv.load(vb, a.vsi, a.vsd, 0, a.Nk, a.Dv, a.v_dfast);
   for (int j0 = 0; j0 < a.Nk; j0 += TK) {
     __syncthreads();
-    stage_tile(Ks, PK, kb, a.ksi, a.ksd, j0, a.Nk, a.D, DQ, a.k_dfast);
-    stage_tile(Vs, PV, vb, a.vsi, a.vsd, j0, a.Nk, a.Dv, DV, a.v_dfast);
+    pk.store(Ks, PK, a.k_dfast);
+    pv.store(Vs, PV, a.v_dfast);
     __syncthreads();
+    if (j0 + TK < a.Nk) {
+      pk.load(kb, a.ksi, a.ksd, j0 + TK, a.Nk, a.D, a.k_dfast);
+      pv.load(vb, a.vsi, a.vsd, j0 + TK, a.Nk, a.Dv, a.v_dfast);
+    }
     f32x4 s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -239,7 +293,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(AttnArgs a) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float p = (j0 + 16 * t + fr < a.Nk) ? expf(s[t][r] * a.scale - ls[r]) : 0.f;
+        float p = (j0 + 16 * t + fr < a.Nk) ? fast_exp(s[t][r] * a.scale - ls[r]) : 0.f;
         float ds = p * (dp[t][r] - dl[r]) * a.scale;
         Ps[(wave * 16 + fq * 4 + r) * PP + 16 * t + fr] = ds;
       }
@@ -289,16 +343,24 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < NV; ++t) dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  TilePrefetch<DQ> pq;
+  TilePrefetch<DV> pg;
+  pq.load(qb, a.qsi, a.qsd, 0, a.Nq, a.D, a.q_dfast);
+  pg.load(gb, a.osi, a.osd, 0, a.Nq, a.Dv, a.o_dfast);
   for (int i0 = 0; i0 < a.Nq; i0 += TQ) {
     __syncthreads();
-    stage_tile(Qs, PQ, qb, a.qsi, a.qsd, i0, a.Nq, a.D, DQ, a.q_dfast);
-    stage_tile(dOs, PV, gb, a.osi, a.osd, i0, a.Nq, a.Dv, DV, a.o_dfast);
+    pq.store(Qs, PQ, a.q_dfast);
+    pg.store(dOs, PV, a.o_dfast);
     if (threadIdx.x < TQ) {
       const int i = i0 + threadIdx.x;
       lse_s[threadIdx.x] = (i < a.Nq) ? a.lse[((long)b * a.H + h) * a.Nq + i] : 0.f;
       del_s[threadIdx.x] = (i < a.Nq) ? a.delta[((long)b * a.H + h) * a.Nq + i] : 0.f;
     }
     __syncthreads();
+    if (i0 + TQ < a.Nq) {
+      pq.load(qb, a.qsi, a.qsd, i0 + TQ, a.Nq, a.D, a.q_dfast);
+      pg.load(gb, a.osi, a.osd, i0 + TQ, a.Nq, a.Dv, a.o_dfast);
+    }
     f32x4 st[4], dpt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -316,7 +378,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int jr = wave * 16 + fq * 4 + r;
         const bool ok = iv && (j0 + jr < a.Nk);
-        float p = ok ? expf(st[t][r] * a.scale - lsev) : 0.f;
+        float p = ok ? fast_exp(st[t][r] * a.scale - lsev) : 0.f;
         float ds = p * (dpt[t][r] - delv) * a.scale;
         Pt[jr * PP + ic] = p;
         St[jr * PP + ic] = ds;
@@ -365,6 +427,7 @@ static void fill_args(AttnArgs& a, const cenet_attn_t* p) {
 }
 
 static int pick_variant(int D, int Dv) {
+  if (D <= 16 && Dv <= 32) return 4;
   if (D <= 32 && Dv <= 32) return 0;
   if (D <= 32 && Dv <= 64) return 1;
   if (D <= 64 && Dv <= 64) return 2;
@@ -385,6 +448,7 @@ extern "C" int cenet_flash_attn_fwd_f32(const cenet_attn_t* p, hipStream_t strea
     case 1: CENET_LAUNCH((flash_fwd_kernel<32, 64>), grid, dim3(256), stream, a); break;
     case 2: CENET_LAUNCH((flash_fwd_kernel<64, 64>), grid, dim3(256), stream, a); break;
     case 3: CENET_LAUNCH((flash_fwd_kernel<64, 128>), grid, dim3(256), stream, a); break;
+    case 4: CENET_LAUNCH((flash_fwd_kernel<16, 32>), grid, dim3(256), stream, a); break;
     default: return CENET_EUNSUPPORTED;
   }
   CENET_CHECK_LAUNCH();
@@ -414,6 +478,10 @@ extern "C" int cenet_flash_attn_bwd_f32(const cenet_attn_t* p, hipStream_t strea
       CENET_LAUNCH((flash_bwd_dq_kernel<64, 128>), gq, dim3(256), stream, a);
       CENET_LAUNCH((flash_bwd_dkv_kernel<64, 128>), gk, dim3(256), stream, a);
       break;
+    case 4:
+      CENET_LAUNCH((flash_bwd_dq_kernel<16, 32>), gq, dim3(256), stream, a);
+      CENET_LAUNCH((flash_bwd_dkv_kernel<16, 32>), gk, dim3(256), stream, a);
+      break;
     default: return CENET_EUNSUPPORTED;
   }
   CENET_CHECK_LAUNCH();
@@ -434,9 +502,9 @@ __global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __re
   for (int c = lane; c < n; c += 64) mx = fmaxf(mx, xr[c]);
   mx = wave_max(mx);
   float s = 0.f;
-  for (int c = lane; c < n; c += 64) s += expf(xr[c] - mx);
+  for (int c = lane; c < n; c += 64) s += fast_exp(xr[c] - mx);
   s = 1.f / wave_sum(s);
-  for (int c = lane; c < n; c += 64) yr[c] = expf(xr[c] - mx) * s;
+  for (int c = lane; c < n; c += 64) yr[c] = fast_exp(xr[c] - mx) * s;
 }
 
 // dx = y * (dy - sum(dy*y))

@@ -69,6 +69,13 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
+// hardware exponential (v_exp_f32 on the device build; libm on the host checker)
+#ifdef CENET_HOSTSIM_BUILD
+__device__ __forceinline__ float fast_exp(float x) { return expf(x); }
+#else
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+#endif
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
