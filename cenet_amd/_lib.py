@@ -30,7 +30,10 @@ class EpiT(C.Structure):
     _fields_ = [("C", C.c_void_p), ("scb", C.c_long), ("scb2", C.c_long), ("scr", C.c_long), ("scc", C.c_long),
                 ("bias", C.c_void_p), ("bias_on_row", C.c_int), ("act", C.c_int), ("slope", C.c_float),
                 ("bscale", C.c_void_p), ("R", C.c_void_p), ("srb", C.c_long), ("srb2", C.c_long), ("srr", C.c_long), ("src", C.c_long),
-                ("atomic", C.c_int), ("alpha", C.c_float)]
+                ("atomic", C.c_int), ("alpha", C.c_float),
+                ("cmode", C.c_int), ("cKH", C.c_int), ("cKW", C.c_int), ("cPw", C.c_int), ("cHs", C.c_int),
+                ("cWs", C.c_int), ("cstride", C.c_int), ("cpad", C.c_int),
+                ("csci", C.c_long), ("csy", C.c_long), ("csx", C.c_long)]
 
 
 def lib():

@@ -347,7 +347,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         int col = n0 + wn * (BN / 2) + j * 16 + fr;
         if (row < g.M && col < g.N) {
           float v = acc[i][j][r] * E.alpha;
-          if (E.atomic) {
+          if (E.cmode) {  // col2im scatter: row = (ci,ky,kx), col = (py,px)
+            const int kkw = E.cKH * E.cKW;
+            const int ci = row / kkw, rem = row - ci * kkw;
+            const int ky = rem / E.cKW, kx = rem - ky * E.cKW;
+            const int py = col / E.cPw, px = col - py * E.cPw;
+            const int iy = py * E.cstride - E.cpad + ky, ix = px * E.cstride - E.cpad + kx;
+            if (iy >= 0 && iy < E.cHs && ix >= 0 && ix < E.cWs) {
+              float* dst = &Cb[(long)ci * E.csci + (long)iy * E.csy + (long)ix * E.csx];
+              if (E.atomic) atomicAdd(dst, v);
+              else *dst = v;
+            }
+          } else if (E.atomic) {
             atomicAdd(&Cb[(long)row * E.scr + (long)col * E.scc], v);
           } else {
             if (E.bias) v += E.bias[E.bias_on_row ? row : col];
@@ -418,6 +429,7 @@ extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const 
   g.M = M; g.N = N; g.K = K; g.nkb = nkb; g.splits = splits; g.nb_inner = nb_inner;
   int bm, bn;
   pick_tile(M, N, nbatch, splits, &bm, &bn);
+  if (B->mode == 1 && B->kfast && bm == 32) bn = 64;  // weight-gradient view: keep the per-thread gather list short
   int rc;
   if (g_compute_bf16) {
     rc = (B->mode == 0) ? launch_tile<unsigned short, false>(g, bm, bn, nbatch, stream)

@@ -35,24 +35,51 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
   }
 }
 
-// scatter form of the backward: dx (pre-zeroed) += taps * dy
+// candidate output range [lo, hi) whose taps can touch input index i (conservative; exact weights are recomputed)
+__device__ __forceinline__ void bil_range(int i, float scale, int align, int out, int& lo, int& hi) {
+  if (scale < 1e-6f) {
+    lo = 0;
+    hi = out;
+    return;
+  }
+  const float off = align ? 0.f : 0.5f;
+  float a = (i - 1 + off) / scale - off, b = (i + 1 + off) / scale - off;
+  lo = (int)floorf(a) - 1;
+  hi = (int)ceilf(b) + 2;
+  if (lo < 0) lo = 0;
+  if (hi > out) hi = out;
+}
+
+// gather form of the backward: one thread per INPUT pixel sums the output gradients whose taps touch it
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, long sgb, float* __restrict__ dx,
                                                           long sdb, int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
                                                           int align) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
   const float* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
   float* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
-  for (int p = blockIdx.y * 256 + threadIdx.x; p < Ho * Wo; p += gridDim.y * 256) {
-    const int oy = p / Wo, ox = p - oy * Wo;
-    int y0, y1, x0, x1;
-    float ly, lx;
-    bil_coord(oy, sh, align, Hi, y0, y1, ly);
-    bil_coord(ox, sw, align, Wi, x0, x1, lx);
-    const float hy = 1.f - ly, hx = 1.f - lx, g = gp[p];
-    atomicAdd(&dp[y0 * Wi + x0], hy * hx * g);
-    atomicAdd(&dp[y0 * Wi + x1], hy * lx * g);
-    atomicAdd(&dp[y1 * Wi + x0], ly * hx * g);
-    atomicAdd(&dp[y1 * Wi + x1], ly * lx * g);
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < Hi * Wi; p += gridDim.y * 256) {
+    const int iy = p / Wi, ix = p - iy * Wi;
+    int ylo, yhi, xlo, xhi;
+    bil_range(iy, sh, align, Ho, ylo, yhi);
+    bil_range(ix, sw, align, Wo, xlo, xhi);
+    float acc = 0.f;
+    for (int oy = ylo; oy < yhi; ++oy) {
+      int y0, y1;
+      float ly;
+      bil_coord(oy, sh, align, Hi, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int ox = xlo; ox < xhi; ++ox) {
+        int x0, x1;
+        float lx;
+        bil_coord(ox, sw, align, Wi, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx != 0.f) row += wx * gp[oy * Wo + ox];
+      }
+      acc += wy * row;
+    }
+    dp[p] = acc;
   }
 }
 
@@ -182,13 +209,11 @@ extern "C" int cenet_bilinear_fwd_f32(const float* x, long sxb, float* y, long s
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-// dx must be zero-filled by the caller (it is accumulated into with float atomics)
-extern "C" int cenet_bilinear_bwd_acc_f32(const float* dy, long sgb, float* dx_acc, long sdb, int B, int C, int Hi, int Wi,
-                                          int Ho, int Wo, float scale_h, float scale_w, int align_corners,
-                                          hipStream_t stream) {
+extern "C" int cenet_bilinear_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi, int Ho,
+                                      int Wo, float scale_h, float scale_w, int align_corners, hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(bilinear_bwd_kernel, dim3(B * C, chunks_for(Ho * Wo)), dim3(256), stream, dy, sgb, dx_acc, sdb, C, Hi, Wi, Ho,
-               Wo, scale_h, scale_w, align_corners);
+  CENET_LAUNCH(bilinear_bwd_kernel, dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho, Wo,
+               scale_h, scale_w, align_corners);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

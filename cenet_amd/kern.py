@@ -76,7 +76,8 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
          nbatch: int = 1, nkb: int = 1, splits: int = 1, bias: Optional[torch.Tensor] = None, bias_on_row: bool = False,
          act: str = "none", slope: float = 0.0, bscale: Optional[torch.Tensor] = None,
          R: Optional[torch.Tensor] = None, srb: int = 0, srr: int = 0, src: int = 0, atomic: bool = False,
-         alpha: float = 1.0, c_offset: int = 0, r_offset: int = 0, nb_inner: int = 1, scb2: int = 0, srb2: int = 0):
+         alpha: float = 1.0, c_offset: int = 0, r_offset: int = 0, nb_inner: int = 1, scb2: int = 0, srb2: int = 0,
+         col2im: Optional[dict] = None):
     _chk(Cout, bias, bscale, R)
     e = EpiT()
     e.C = Cout.data_ptr() + 4 * c_offset
@@ -88,6 +89,11 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
     e.R = (R.data_ptr() + 4 * r_offset) if R is not None else None
     e.srb, e.srb2, e.srr, e.src = srb, srb2, srr, src
     e.atomic, e.alpha = int(atomic), alpha
+    if col2im is not None:  # scatter epilogue (data-gradient of strided convolutions)
+        e.cmode = 1
+        e.cKH, e.cKW, e.cPw = col2im["KH"], col2im["KW"], col2im["Pw"]
+        e.cHs, e.cWs, e.cstride, e.cpad = col2im["Hs"], col2im["Ws"], col2im["stride"], col2im["pad"]
+        e.csci, e.csy, e.csx = col2im["sci"], col2im["sy"], col2im["sx"]
     rc = _lib.lib().cenet_gemm_f32(C.byref(A), C.byref(B), C.byref(e), M, N, K, nbatch, nb_inner, nkb, splits, stream())
     _lib.check(rc, "cenet_gemm_f32")
 
@@ -207,7 +213,7 @@ def bilinear_fwd(x, sxb, y, syb, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align):
 
 def bilinear_bwd(dy, sgb, dx, sdb, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align):
     _chk(dy, dx)
-    _call("cenet_bilinear_bwd_acc_f32", dy, L(sgb), dx, L(sdb), B, Cn, Hi, Wi, Ho, Wo, float(sh), float(sw), int(align))
+    _call("cenet_bilinear_bwd_f32", dy, L(sgb), dx, L(sdb), B, Cn, Hi, Wi, Ho, Wo, float(sh), float(sw), int(align))
 
 
 def nearest2x_fwd(x, sxb, y, syb, B, Cn, Hi, Wi):

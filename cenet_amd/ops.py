@@ -195,11 +195,23 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             # dX[b][ci][q] = sum_{co,ky,kx} W[co,ci,ky,kx] * dY gathered (transposed map); written with x's strides
             assert sy == Wd * sx, "conv2d data-gradient needs a pixel-linear input layout"
-            dx = torch.empty_like(x)
-            Bm = kern.mat_im2col(g, sb=Cout * Ho * Wo, skb=0, sci=g_sc, sy=Wo * g_sp, sx=g_sp, KH=k, KW=k, Pw=Wd, Hs=Ho,
-                                 Ws=Wo, stride=stride, pad=pad, dil=1, patch_is_row=1, transposed=1, kfast=0)
-            A = kern.mat_plain(W, k * k, 1, kfast=1, kinner=k * k, sk_outer=Cin * k * k)
-            kern.gemm(A, Bm, dx, Cin, H * Wd, Cout * k * k, scr=sc, scc=sx, scb=sb, nbatch=B)
+            if stride == 1:
+                # gather form: dX = Wt[Cin, Cout*k*k] x transposed-gather(dY); no atomics, no wasted MACs
+                dx = torch.empty_like(x)
+                Bm = kern.mat_im2col(g, sb=Cout * Ho * Wo, skb=0, sci=g_sc, sy=Wo * g_sp, sx=g_sp, KH=k, KW=k, Pw=Wd,
+                                     Hs=Ho, Ws=Wo, stride=stride, pad=pad, dil=1, patch_is_row=1, transposed=1, kfast=0)
+                A = kern.mat_plain(W, k * k, 1, kfast=1, kinner=k * k, sk_outer=Cin * k * k)
+                kern.gemm(A, Bm, dx, Cin, H * Wd, Cout * k * k, scr=sc, scc=sx, scb=sb, nbatch=B)
+            else:
+                # strided conv: the gather form would multiply stride^2 - 1 zeros per useful MAC (64x for the 8x8/8
+                # SR conv). Dense GEMM dXcol[(ci,ky,kx), p] = W^T dY[:, p] with a col2im scatter epilogue instead.
+                overlap = k > stride
+                exact = (pad == 0 and H % stride == 0 and Wd % stride == 0 and k == stride)
+                dx = torch.empty_like(x) if exact else _zeros(x.shape, x)
+                kern.gemm(kern.mat_plain(W, 1, Kd, kfast=0), kern.mat_plain(g, g_sc, g_sp, sb=Cout * Ho * Wo,
+                                                                              kfast=int(g_sc == 1)),
+                          dx, Kd, Ho * Wo, Cout, scr=0, scc=0, scb=sb, nbatch=B, atomic=overlap,
+                          col2im=dict(KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride, pad=pad, sci=sc, sy=sy, sx=sx))
         dW = grad_buf(Wp)
         if dW is not None:
             Bm = kern.mat_im2col(x, sb=0, skb=sb, sci=sc, sy=sy, sx=sx, KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride,
@@ -874,7 +886,7 @@ class BilinearFn(Function):
         Hi, Wi, Ho, Wo, sh, sw, align = ctx.cfg
         g = _c(g)
         B, Cn = g.shape[:2]
-        dx = _zeros((B, Cn, Hi, Wi), g)
+        dx = _empty((B, Cn, Hi, Wi), g)
         kern.bilinear_bwd(g, Cn * Ho * Wo, dx, Cn * Hi * Wi, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align)
         return dx, None, None, None, None, None
 

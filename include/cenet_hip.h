@@ -58,6 +58,11 @@ typedef struct {
   long srb, srb2, srr, src;
   int atomic;
   float alpha;
+  /* cmode 1: col2im scatter — row = patch index (ci,ky,kx), col = output pixel (py,px);
+   * C address = b*scb + ci*csci + (py*cstride - cpad + ky)*csy + (px*cstride - cpad + kx)*csx, skipped when out of
+   * [0,cHs)x[0,cWs). Used for the data-gradient of strided convolutions (atomic when patches overlap). */
+  int cmode, cKH, cKW, cPw, cHs, cWs, cstride, cpad;
+  long csci, csy, csx;
 } cenet_epi_t;
 
 /* Replaces aten::addmm/mm/bmm/convolution(+_backward) — pvtv2.py:41,45,90,98,106,164; cfam.py:149,158,299,302;
@@ -128,8 +133,8 @@ int cenet_dwconv3x3_wgrad_tok_acc_f32(const float* x, const float* dy, float* dw
 /* aten::upsample_bilinear2d(+_backward) — dseb.py:67-68; cfam.py:217,232; blocks.py:210; out.py:74 */
 int cenet_bilinear_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo,
                            float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
-int cenet_bilinear_bwd_acc_f32(const float* dy, long sgb, float* dx_acc, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo,
-                               float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
+int cenet_bilinear_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                           float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
 /* aten::upsample_nearest2d(+_backward) x2 — blocks.py:304 */
 int cenet_nearest2x_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, cenet_stream_t stream);
 int cenet_nearest2x_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi, cenet_stream_t stream);
