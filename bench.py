@@ -122,15 +122,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # CENET_FORCE_DIST=1 runs the whole RCCL path (process group, hooks, side stream) even with a single rank, so the
+    # distributed code can be exercised on a 1-GPU box (tests/test_bench_dist.py)
+    use_dist = world > 1 or os.environ.get("CENET_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from cenet_amd import kern, losses, optim, parallel
     kern.set_compute_bf16(a.dtype == "bf16")
     net = make_model(dev)
     arena = optim.ParamArena(net, optim.cenet_segments())
-    reducer = parallel.GradReducer(arena) if world > 1 else None
+    reducer = parallel.GradReducer(arena, force=use_dist) if use_dist else None
     if reducer is not None:
         reducer.broadcast_state(net)
         parallel.attach(net, reducer)
@@ -151,17 +155,17 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -180,7 +184,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -39,35 +39,55 @@ __global__ __launch_bounds__(256) void dw3x3_nchw_kernel(const float* __restrict
   }
 }
 
-// token layout: element index e = (b*N + p)*C + c ; grid-stride over all elements
+// token layout [B, H*W, C]: thread = one channel (lanes along C: every load/store is a contiguous 1 KB row),
+// workgroup = (256-channel slab, strip of DW_SW pixels along x, image).  A 3x3 register window slides along the
+// strip, so each output costs 3 new loads instead of 9 and there is no per-element div/mod.
+#define DW_SW 8
 __global__ __launch_bounds__(256) void dw3x3_tok_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                       float* __restrict__ a, int B, int C, int H, int W, int flip, int act,
+                                                       float* __restrict__ a, int C, int H, int W, int flip, int act,
                                                        float slope) {
-  const long total = (long)B * H * W * C;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int c = (int)(e % C);
-    const long bp = e / C;
-    const int p = (int)(bp % (H * W));
-    const long b = bp / (H * W);
-    const int py = p / W, px = p - py * W;
-    float acc = bias ? bias[c] : 0.f;
-    const float* xb = x + b * (long)H * W * C;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int strips_per_row = (W + DW_SW - 1) / DW_SW;
+  const int py = blockIdx.y / strips_per_row;
+  const int px0 = (blockIdx.y - py * strips_per_row) * DW_SW;
+  const long img = (long)blockIdx.z * H * W * C;
+  const float* xb = x + img + c;
+  float wt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
+  const float bv = bias ? bias[c] : 0.f;
+  float win[3][3];  // win[ky][slot]: columns px-1, px, px+1
+  auto load_col = [&](int ix, float col[3]) {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = py + ky - 1;
-      if (iy < 0 || iy >= H) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = px + kx - 1;
-        if (ix < 0 || ix >= W) continue;
-        const int t = ky * 3 + kx;
-        acc += w[c * 9 + (flip ? 8 - t : t)] * xb[((long)iy * W + ix) * C + c];
-      }
+      col[ky] = (ix >= 0 && ix < W && iy >= 0 && iy < H) ? xb[((long)iy * W + ix) * C] : 0.f;
     }
-    y[e] = acc;
-    if (a) a[e] = act_fwd(act, acc, slope);
+  };
+  float c0[3], c1[3], c2[3];
+  load_col(px0 - 1, c0);
+  load_col(px0, c1);
+#pragma unroll
+  for (int i = 0; i < DW_SW; ++i) {
+    const int px = px0 + i;
+    load_col(px + 1, c2);
+    if (px < W) {
+      float acc = bv;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) acc += wt[ky * 3] * c0[ky] + wt[ky * 3 + 1] * c1[ky] + wt[ky * 3 + 2] * c2[ky];
+      const long e = img + ((long)py * W + px) * C + c;
+      y[e] = acc;
+      if (a) a[e] = act_fwd(act, acc, slope);
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      c0[ky] = c1[ky];
+      c1[ky] = c2[ky];
+    }
   }
+  (void)win;
 }
 
 // weight/bias gradient, NCHW: grid (C, splits); dw[c,t] += sum_{b,p} dy[b,c,p] * x[b,c,p+off_t]; db[c] += sum dy
@@ -111,34 +131,45 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_kernel(const float* __re
   }
 }
 
-// weight/bias gradient, token layout: thread = channel, block = (channel tile, pixel chunk, batch)
-#define DW_TOK_CHUNK 128
+// weight/bias gradient, token layout: thread = channel, workgroup = (256-channel slab, DW_WROWS image rows, image).
+// The 3x3 input window slides along each row (3 new loads + 1 gradient load per pixel); ten float atomics per thread
+// at the end.
+#define DW_WROWS 4
 __global__ __launch_bounds__(256) void dw3x3_wgrad_tok_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              float* __restrict__ dw, float* __restrict__ db, int C, int H,
                                                              int W) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const int N = H * W;
-  const int p0 = blockIdx.y * DW_TOK_CHUNK;
-  const int p1 = (p0 + DW_TOK_CHUNK < N) ? p0 + DW_TOK_CHUNK : N;
-  const float* xb = x + (long)blockIdx.z * N * C;
-  const float* gb = dy + (long)blockIdx.z * N * C;
+  const long img = (long)blockIdx.z * H * W * C;
+  const float* xb = x + img + c;
+  const float* gb = dy + img + c;
   float acc[10];
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t] = 0.f;
-  for (int p = p0; p < p1; ++p) {
-    const int py = p / W, px = p - py * W;
-    const float g = gb[(long)p * C + c];
-    acc[9] += g;
+  const int y0 = blockIdx.y * DW_WROWS;
+  for (int py = y0; py < y0 + DW_WROWS && py < H; ++py) {
+    float c0[3], c1[3], c2[3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = py + ky - 1;
-      if (iy < 0 || iy >= H) continue;
+      c0[ky] = 0.f;
+      c1[ky] = (iy >= 0 && iy < H) ? xb[((long)iy * W) * C] : 0.f;
+    }
+    for (int px = 0; px < W; ++px) {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = px + kx - 1;
-        if (ix < 0 || ix >= W) continue;
-        acc[ky * 3 + kx] += g * xb[((long)iy * W + ix) * C + c];
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = py + ky - 1;
+        c2[ky] = (px + 1 < W && iy >= 0 && iy < H) ? xb[((long)iy * W + px + 1) * C] : 0.f;
+      }
+      const float g = gb[((long)py * W + px) * C];
+      acc[9] += g;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        acc[ky * 3] += g * c0[ky];
+        acc[ky * 3 + 1] += g * c1[ky];
+        acc[ky * 3 + 2] += g * c2[ky];
+        c0[ky] = c1[ky];
+        c1[ky] = c2[ky];
       }
     }
   }
@@ -165,10 +196,9 @@ extern "C" int cenet_dwconv3x3_nchw_f32(const float* x, long sxb, const float* w
 extern "C" int cenet_dwconv3x3_tok_f32(const float* x, const float* w, const float* bias, float* y, float* a, int B, int C,
                                        int H, int W, int flip, int act, float slope, hipStream_t stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
-  long total = (long)B * C * H * W;
-  long blocks = (total + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  CENET_LAUNCH(dw3x3_tok_kernel, dim3((unsigned)blocks), dim3(256), stream, x, w, bias, y, a, B, C, H, W, flip, act, slope);
+  const int strips = H * ((W + DW_SW - 1) / DW_SW);
+  if (strips > 65535 || B > 65535) return CENET_EUNSUPPORTED;
+  CENET_LAUNCH(dw3x3_tok_kernel, dim3(cdiv(C, 256), strips, B), dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -192,7 +222,7 @@ extern "C" int cenet_dwconv3x3_wgrad_nchw_acc_f32(const float* x, long sxb, cons
 extern "C" int cenet_dwconv3x3_wgrad_tok_acc_f32(const float* x, const float* dy, float* dw_acc, float* dbias_acc, int B,
                                                  int C, int H, int W, hipStream_t stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(dw3x3_wgrad_tok_kernel, dim3(cdiv(C, 256), cdiv(H * W, DW_TOK_CHUNK), B), dim3(256), stream, x, dy, dw_acc,
+  CENET_LAUNCH(dw3x3_wgrad_tok_kernel, dim3(cdiv(C, 256), cdiv(H, DW_WROWS), B), dim3(256), stream, x, dy, dw_acc,
                dbias_acc, C, H, W);
   CENET_CHECK_LAUNCH();
   return CENET_OK;

@@ -20,10 +20,11 @@ from .optim import ParamArena
 
 
 class GradReducer:
-    def __init__(self, arena: ParamArena, group=None):
+    def __init__(self, arena: ParamArena, group=None, force: bool = False):
         self.arena = arena
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())  # force: run collectives even on one rank
         self.cuda = arena.grads.is_cuda
         self.side = torch.cuda.Stream() if self.cuda else None
         self._handles: List = []
@@ -32,7 +33,7 @@ class GradReducer:
     # ---- one-time state sync -------------------------------------------------------------------------------
     def broadcast_state(self, model: torch.nn.Module, src: int = 0):
         """Initial broadcast of parameters (one flat buffer) and buffers from rank `src`."""
-        if self.world == 1:
+        if not self.active:
             return
         dist.broadcast(self.arena.params, src, group=self.group)
         for b in model.buffers():
@@ -41,7 +42,7 @@ class GradReducer:
     # ---- per-step ---------------------------------------------------------------------------------------------
     def segment_ready(self, i: int):
         """Gradient segment i is final: start its all-reduce (idempotent; called from backward hooks)."""
-        if self.world == 1 or i in self._done:
+        if not self.active or i in self._done:
             return
         self._done.add(i)
         buf = self.arena.segment_grad(i)

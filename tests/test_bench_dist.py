@@ -1,0 +1,51 @@
+"""bench.py contract + the RCCL code path on the real GPU.
+
+Only one GPU is available to the tests, so the distributed path (process group, broadcast, backward-hook driven
+segment all-reduces on the side stream, max-over-ranks timing) is exercised with a ONE-rank RCCL group launched exactly
+the way the driver launches N ranks (`python -m torch.distributed.run ...`), forced on with CENET_FORCE_DIST=1.
+The N>1 arithmetic (mean of shard gradients, per-rank BN buffers) is pinned by tests/test_parallel_gloo.py on CPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _last_json(out: str):
+    for line in reversed(out.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in bench output:\n" + out[-2000:])
+
+
+@pytest.mark.gpu
+def test_bench_single_process_contract():
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    assert REQUIRED <= set(d), REQUIRED - set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 32 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] in ("mfma", "hbm") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_with_rccl_group():
+    env = dict(os.environ, CENET_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]  # not NaN
