@@ -1,4 +1,4 @@
-// gemm.hip — batched strided GEMM / implicit-GEMM convolution core on the gfx950 matrix cores (v2).
+// gemm.hip — batched strided GEMM / implicit-GEMM convolution core on the gfx950 matrix cores (v3).
 //
 // One kernel family serves every dense contraction of the CENet hot path:
 //   * nn.Linear fwd/bwd in token layout                      (pvtv2.py:41,45,90,98,106; multihead_diffattn.py:79-81,126)
@@ -7,20 +7,21 @@
 //   * materialised attention products for large head dims
 //
 // C[b] (+)= epilogue( alpha * sum_kb A[b,kb] (MxK) * B[b,kb] (KxN) )
-// A is a plain strided matrix; B is plain or an on-the-fly im2col / transposed-gather view of an image tensor.
+// A is a plain strided matrix; B is plain or an on-the-fly im2col / transposed-gather view of an image tensor; the
+// epilogue can scatter through a col2im map (data-gradient of strided convolutions).
 //
-// Structure (per 256-thread workgroup = 4 waves in a 2x2 grid, tile BM x BN, K step BK):
-//   * operands are read from HBM with lane-contiguous dword loads in whichever orientation is contiguous (kfast /
-//     mfast), one K-tile AHEAD into registers (software double buffering: the loads of tile t+1 fly under the MFMAs
-//     of tile t), then written k-contiguous into LDS with a 144-byte row pitch;
-//   * fragments are fetched with 16-byte ds_read_b128: lane (r = lane&15, q = lane>>4) owns k' = 8q..8q+7 of each
-//     32-deep slab, and MFMA step s multiplies slot s of A with slot s of B (a permutation of the k order, which a
-//     sum does not care about) — 4x fewer LDS instructions than dword reads;
-//   * OpT = float : v_mfma_f32_16x16x4_f32, exact fp32 FMA chain (parity mode, BK = 32)
-//     OpT = bf16  : operands rounded to bf16 when they enter LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulate
-//                   (throughput mode of BASELINE configs[1], BK = 64);
-//   * im2col addressing never divides per element: the k-side decomposition (ci,ky,kx | py,px) of each K-tile is
-//     written to a small LDS table by BK threads, the n-side decomposition is computed once per thread.
+// Structure (per 256-thread workgroup = 4 waves in a 2x2 grid, tile BM x BN, K step 32):
+//   * operands are read from HBM in whichever orientation is contiguous (kfast: 16-byte loads along k when alignment
+//     allows, else dwords; mfast: lane-contiguous dwords), one K-tile AHEAD into registers (software double buffering:
+//     the loads of tile t+1 fly under the MFMAs of tile t), then written k-contiguous into LDS;
+//   * fragments are fetched with 16-byte ds_read_b128: for fp32, lane (r = lane&15, q = lane>>4) owns k' = 8q..8q+7 and
+//     MFMA step s multiplies slot s of A with slot s of B (a permutation of the k order, which a sum does not care about);
+//   * OpT = float : v_mfma_f32_16x16x4_f32, exact fp32 FMA chain (parity mode)
+//     OpT = bf16  : operands rounded to bf16 when they enter LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulate;
+//   * SWAP: when C is row-major the MFMA is issued as (B-fragment, A-fragment) so a lane's four accumulator registers are
+//     four CONSECUTIVE COLUMNS of C and the epilogue moves 16 bytes per instruction (bias / residual / store);
+//   * im2col addressing never divides per element: forward/dgrad threads walk (kx,ky,ci) with carries, the
+//     weight-gradient view reads a per-workgroup LDS table of patch decompositions.
 #include "common.h"
 #include "../../include/cenet_hip.h"
 
@@ -28,6 +29,7 @@ struct GemmArgs {
   cenet_mat_t A, B;
   cenet_epi_t E;
   int M, N, K, nkb, splits, nb_inner;
+  int avec, bvec, cvec;  // 16-byte global access is legal for A / B staging / the epilogue
 };
 
 __device__ __forceinline__ unsigned f2bf_bits(float f) {
@@ -39,21 +41,15 @@ __device__ __forceinline__ unsigned f2bf_bits(float f) {
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return f2bf_bits(lo) | (f2bf_bits(hi) << 16); }
 
 template <typename OpT> struct OpTraits;
-template <> struct OpTraits<float> {
-  static constexpr int BK = 32;     // k elements per tile
-  static constexpr int PITCH = 36;  // LDS row pitch in elements (144 B)
-};
-template <> struct OpTraits<unsigned short> {
-  static constexpr int BK = 64;
-  static constexpr int PITCH = 72;  // 144 B
+template <> struct OpTraits<float> { static constexpr int PITCH = 36; };           // 144-byte rows
+template <> struct OpTraits<unsigned short> { static constexpr int PITCH = 40; };  // 80-byte rows
+#define BK 32
+
+struct KEntry {
+  int off;     // patch side: ci*sci
+  int dy, dx;  // patch side: ky*dil, kx*dil ; pixel side: py*stride-pad (or py+pad), px*stride-pad (or px+pad)
 };
 
-struct KEntry {  // per-k im2col table entry
-  int off;       // ci*sci (+ ky*dil*sy + kx*dil*sx for the non-transposed patch side)  or  iy0*sy + ix0*sx
-  int dy, dx;    // patch side: ky*dil, kx*dil ; pixel side: iy0, ix0
-};
-
-// plain element address (supports the split k index used by the conv data-gradient weight view)
 template <int KDIM>
 __device__ __forceinline__ long plain_off(const cenet_mat_t& d, int r, int c) {
   if (d.kinner > 0) {
@@ -68,7 +64,6 @@ __device__ __forceinline__ long plain_off(const cenet_mat_t& d, int r, int c) {
   return (long)r * d.sr + (long)c * d.sc;
 }
 
-// decompose a patch index e=(ci,ky,kx) or a pixel index p=(py,px) into a table entry
 __device__ __forceinline__ KEntry im2col_entry(const cenet_mat_t& d, int idx, bool is_patch) {
   KEntry e;
   if (is_patch) {
@@ -93,7 +88,6 @@ __device__ __forceinline__ KEntry im2col_entry(const cenet_mat_t& d, int idx, bo
   return e;
 }
 
-// combine a patch entry and a pixel entry into a value
 __device__ __forceinline__ float im2col_load(const cenet_mat_t& d, const float* base, const KEntry& pat, const KEntry& pix) {
   int iy, ix;
   if (!d.transposed) {
@@ -115,11 +109,31 @@ __device__ __forceinline__ float im2col_load(const cenet_mat_t& d, const float* 
   return base[(long)pat.off + (long)iy * d.sy + (long)ix * d.sx];
 }
 
-template <typename OpT, int BM, int BN, bool B_IM2COL>
+// write NV consecutive-k values of one LDS row (NV multiple of 4)
+template <typename OpT, int NV>
+__device__ __forceinline__ void lds_put(OpT* dst, const float* v) {
+  if (sizeof(OpT) == 4) {
+#pragma unroll
+    for (int q = 0; q < NV / 4; ++q) memcpy((char*)dst + 16 * q, v + 4 * q, 16);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NV / 4; ++q) {
+      unsigned pk[2] = {pack_bf2(v[4 * q], v[4 * q + 1]), pack_bf2(v[4 * q + 2], v[4 * q + 3])};
+      memcpy((char*)dst + 8 * q, pk, 8);
+    }
+  }
+}
+template <typename OpT>
+__device__ __forceinline__ void lds_put1(OpT* dst, float v) {
+  if (sizeof(OpT) == 4) memcpy(dst, &v, 4);
+  else *dst = (OpT)f2bf_bits(v);
+}
+
+template <typename OpT, int BM, int BN, bool B_IM2COL, bool SWAP>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  constexpr int BK = OpTraits<OpT>::BK, P = OpTraits<OpT>::PITCH;
+  constexpr int P = OpTraits<OpT>::PITCH;
   constexpr bool BF = (sizeof(OpT) == 2);
-  constexpr int MI = BM / 32, NJ = BN / 32;  // 16x16 tiles per wave in each direction
+  constexpr int MI = BM / 32, NJ = BN / 32;              // 16x16 tiles per wave in each direction
   constexpr int NA = BM * BK / 256, NB = BN * BK / 256;  // prefetch registers per thread
   __shared__ __attribute__((aligned(16))) OpT As[BM * P];
   __shared__ __attribute__((aligned(16))) OpT Bs[BN * P];
@@ -143,17 +157,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int it0 = split * chunk;
   const int it1 = (it0 + chunk < total) ? it0 + chunk : total;
 
-  // ---- thread -> tile-element maps (kfast: lanes along k ; mfast: lanes along the row index) ----
-  // kfast: kk = tid % BK, rows r = tid / BK + j * (256 / BK)
-  // mfast: row = tid % BMN, kq = tid / BMN ; k = kq * (BK / (256/BMN)) + j   (consecutive k per thread)
-  constexpr int A_RPP = 256 / BK;           // rows per pass (kfast)
-  constexpr int A_KG = 256 / BM > 0 ? 256 / BM : 1, A_KPT = BK / (256 / BM > 0 ? 256 / BM : 1);
-  constexpr int B_KG = 256 / BN > 0 ? 256 / BN : 1, B_KPT = BK / (256 / BN > 0 ? 256 / BN : 1);
-  static_assert(BM <= 256 && BN <= 256, "tile too large for the mfast map");
-  // for BN == 256 (BM == 32): one thread per column, all BK k's per thread
+  // thread -> tile-element maps
+  //   kfast scalar : kk = tid % 32,  rows r = tid / 32 + 8 j
+  //   kfast vec    : k4 = tid % 8,   rows r = tid / 8 + 32 j   (4 consecutive k per register quad)
+  //   mfast        : row = tid % BMN, kq = tid / BMN ; k = kq * KPT + j  (KPT consecutive k per thread)
+  constexpr int A_KPT = BK / (256 / BM), B_KPT = BK / (256 / BN);
+  static_assert(BM <= 256 && BN <= 256 && NA % 4 == 0 && NB % 4 == 0, "unsupported tile");
   float ra[NA], rb[NB];
 
-  // n-side im2col decomposition (fixed per thread): patch_is_row -> n is a pixel ; else n is a patch element
   KEntry nent;
   nent.off = nent.dy = nent.dx = 0;
   bool n_ok = true;
@@ -169,11 +180,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const float* baseA = g.A.ptr + (long)bo * g.A.sb + (long)bi * g.A.sb2 + (long)kb * g.A.skb;
     const float* baseB = g.B.ptr + (long)bo * g.B.sb + (long)bi * g.B.sb2 + (long)kb * g.B.skb;
     if (g.A.kfast) {
-      const int kk = tid % BK, r0 = tid / BK;
+      if (g.avec) {
+        const int k4 = (tid & 7) * 4, r0 = tid >> 3;
 #pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        int row = r0 + j * A_RPP;
-        ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? baseA[plain_off<1>(g.A, m0 + row, k0 + kk)] : 0.f;
+        for (int j = 0; j < NA / 4; ++j) {
+          int row = r0 + j * 32;
+          if (m0 + row < g.M && k0 + k4 < g.K) memcpy(&ra[4 * j], baseA + (long)(m0 + row) * g.A.sr + k0 + k4, 16);
+          else ra[4 * j] = ra[4 * j + 1] = ra[4 * j + 2] = ra[4 * j + 3] = 0.f;
+        }
+      } else {
+        const int kk = tid & 31, r0 = tid >> 5;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          int row = r0 + j * 8;
+          ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? baseA[plain_off<1>(g.A, m0 + row, k0 + kk)] : 0.f;
+        }
       }
     } else {
       const int row = tid % BM, kq = tid / BM;
@@ -185,11 +206,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
     if (!B_IM2COL) {
       if (g.B.kfast) {
-        const int kk = tid % BK, c0 = tid / BK;
+        if (g.bvec) {
+          const int k4 = (tid & 7) * 4, c0 = tid >> 3;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          int col = c0 + j * A_RPP;
-          rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? baseB[plain_off<0>(g.B, k0 + kk, n0 + col)] : 0.f;
+          for (int j = 0; j < NB / 4; ++j) {
+            int col = c0 + j * 32;
+            if (n0 + col < g.N && k0 + k4 < g.K) memcpy(&rb[4 * j], baseB + (long)(n0 + col) * g.B.sc + k0 + k4, 16);
+            else rb[4 * j] = rb[4 * j + 1] = rb[4 * j + 2] = rb[4 * j + 3] = 0.f;
+          }
+        } else {
+          const int kk = tid & 31, c0 = tid >> 5;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            int col = c0 + j * 8;
+            rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? baseB[plain_off<0>(g.B, k0 + kk, n0 + col)] : 0.f;
+          }
         }
       } else {
         const int col = tid % BN, kq = tid / BN;
@@ -203,13 +234,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const cenet_mat_t& d = g.B;
       if (d.kfast) {
         // weight-gradient view: this thread's k is ONE pixel of the tile, its NB columns are patch elements whose
-        // (ci,ky,kx) decomposition sits in the per-block LDS table ntab (n0 is fixed for the workgroup)
-        const int kk = tid % BK, c0 = tid / BK;
+        // (ci,ky,kx) decomposition sits in the per-workgroup LDS table ntab (n0 is fixed for the workgroup)
+        const int kk = tid & 31, c0 = tid >> 5;
         const bool kok = k0 + kk < g.K;
         const KEntry pe = im2col_entry(d, kok ? k0 + kk : 0, false);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          int col = c0 + j * A_RPP;
+          int col = c0 + j * 8;
           float v = 0.f;
           if (kok && n0 + col < g.N) v = im2col_load(d, baseB, ntab[col], pe);
           rb[j] = v;
@@ -256,38 +287,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   auto store_lds = [&]() {
     if (g.A.kfast) {
-      const int kk = tid % BK, r0 = tid / BK;
+      if (g.avec) {
+        const int k4 = (tid & 7) * 4, r0 = tid >> 3;
 #pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        int row = r0 + j * A_RPP;
-        if (BF) As[row * P + kk] = (OpT)f2bf_bits(ra[j]);
-        else memcpy(&As[row * P + kk], &ra[j], 4);
+        for (int j = 0; j < NA / 4; ++j) lds_put<OpT, 4>(&As[(r0 + j * 32) * P + k4], &ra[4 * j]);
+      } else {
+        const int kk = tid & 31, r0 = tid >> 5;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) lds_put1<OpT>(&As[(r0 + j * 8) * P + kk], ra[j]);
       }
     } else {
       const int row = tid % BM, kq = tid / BM;
-#pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        int kk = kq * A_KPT + j;
-        if (BF) As[row * P + kk] = (OpT)f2bf_bits(ra[j]);
-        else memcpy(&As[row * P + kk], &ra[j], 4);
-      }
+      lds_put<OpT, NA>(&As[row * P + kq * A_KPT], ra);
     }
     if (g.B.kfast) {
-      const int kk = tid % BK, c0 = tid / BK;
+      if (!B_IM2COL && g.bvec) {
+        const int k4 = (tid & 7) * 4, c0 = tid >> 3;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        int col = c0 + j * A_RPP;
-        if (BF) Bs[col * P + kk] = (OpT)f2bf_bits(rb[j]);
-        else memcpy(&Bs[col * P + kk], &rb[j], 4);
+        for (int j = 0; j < NB / 4; ++j) lds_put<OpT, 4>(&Bs[(c0 + j * 32) * P + k4], &rb[4 * j]);
+      } else {
+        const int kk = tid & 31, c0 = tid >> 5;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) lds_put1<OpT>(&Bs[(c0 + j * 8) * P + kk], rb[j]);
       }
     } else {
       const int col = tid % BN, kq = tid / BN;
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        int kk = kq * B_KPT + j;
-        if (BF) Bs[col * P + kk] = (OpT)f2bf_bits(rb[j]);
-        else memcpy(&Bs[col * P + kk], &rb[j], 4);
-      }
+      lds_put<OpT, NB>(&Bs[col * P + kq * B_KPT], rb);
     }
   };
 
@@ -313,26 +338,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-          for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[s], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < MI; ++i)
+            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(b[s], a[i][s], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[s], acc[i][j], 0, 0, 0);
       }
     } else {
+      bf16x8 a[MI];
 #pragma unroll
-      for (int ks = 0; ks < BK / 32; ++ks) {
-        bf16x8 a[MI], b[NJ];
+      for (int i = 0; i < MI; ++i) memcpy(&a[i], &As[(wm * (BM / 2) + i * 16 + fr) * P + fq * 8], 16);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) memcpy(&a[i], &As[(wm * (BM / 2) + i * 16 + fr) * P + ks * 32 + fq * 8], 16);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) memcpy(&b[j], &Bs[(wn * (BN / 2) + j * 16 + fr) * P + ks * 32 + fq * 8], 16);
+      for (int j = 0; j < NJ; ++j) {
+        bf16x8 b;
+        memcpy(&b, &Bs[(wn * (BN / 2) + j * 16 + fr) * P + fq * 8], 16);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();
   }
 
   // ---- epilogue ----
+  // !SWAP: acc[i][j][r] = C[row = .. + fq*4 + r][col = .. + fr]   (4 consecutive rows per lane)
+  //  SWAP: acc[i][j][r] = C[row = .. + fr][col = .. + fq*4 + r]   (4 consecutive columns per lane)
   const cenet_epi_t& E = g.E;
   float* Cb = E.C + (long)bo * E.scb + (long)bi * E.scb2;
   const float* Rb = E.R ? E.R + (long)bo * E.srb + (long)bi * E.srb2 : nullptr;
@@ -340,45 +369,67 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j) {
+      const int rbase = m0 + wm * (BM / 2) + i * 16 + (SWAP ? fr : fq * 4);
+      const int cbase = n0 + wn * (BN / 2) + j * 16 + (SWAP ? fq * 4 : fr);
+      const bool full = SWAP ? (rbase < g.M && cbase + 3 < g.N) : (rbase + 3 < g.M && cbase < g.N);
+      if (g.cvec && full && !E.atomic && !E.cmode) {
+        float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = m0 + wm * (BM / 2) + i * 16 + fq * 4 + r;
-        int col = n0 + wn * (BN / 2) + j * 16 + fr;
-        if (row < g.M && col < g.N) {
-          float v = acc[i][j][r] * E.alpha;
-          if (E.cmode) {  // col2im scatter: row = (ci,ky,kx), col = (py,px)
-            const int kkw = E.cKH * E.cKW;
-            const int ci = row / kkw, rem = row - ci * kkw;
-            const int ky = rem / E.cKW, kx = rem - ky * E.cKW;
-            const int py = col / E.cPw, px = col - py * E.cPw;
-            const int iy = py * E.cstride - E.cpad + ky, ix = px * E.cstride - E.cpad + kx;
-            if (iy >= 0 && iy < E.cHs && ix >= 0 && ix < E.cWs) {
-              float* dst = &Cb[(long)ci * E.csci + (long)iy * E.csy + (long)ix * E.csx];
-              if (E.atomic) atomicAdd(dst, v);
-              else *dst = v;
+        for (int r = 0; r < 4; ++r) {
+          const int row = SWAP ? rbase : rbase + r, col = SWAP ? cbase + r : cbase;
+          float t = acc[i][j][r] * E.alpha;
+          if (E.bias) t += E.bias[E.bias_on_row ? row : col];
+          v[r] = act_fwd(E.act, t, E.slope) * bs;
+        }
+        const long coff = (long)rbase * E.scr + (long)cbase * E.scc;
+        if (Rb) {
+          float rr[4];
+          memcpy(rr, Rb + (long)rbase * E.srr + (long)cbase * E.src, 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rr[r];
+        }
+        memcpy(Cb + coff, v, 16);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = SWAP ? rbase : rbase + r, col = SWAP ? cbase + r : cbase;
+          if (row < g.M && col < g.N) {
+            float v = acc[i][j][r] * E.alpha;
+            if (E.cmode) {  // col2im scatter: row = (ci,ky,kx), col = (py,px)
+              const int kkw = E.cKH * E.cKW;
+              const int ci = row / kkw, rem = row - ci * kkw;
+              const int ky = rem / E.cKW, kx = rem - ky * E.cKW;
+              const int py = col / E.cPw, px = col - py * E.cPw;
+              const int iy = py * E.cstride - E.cpad + ky, ix = px * E.cstride - E.cpad + kx;
+              if (iy >= 0 && iy < E.cHs && ix >= 0 && ix < E.cWs) {
+                float* dst = &Cb[(long)ci * E.csci + (long)iy * E.csy + (long)ix * E.csx];
+                if (E.atomic) atomicAdd(dst, v);
+                else *dst = v;
+              }
+            } else if (E.atomic) {
+              atomicAdd(&Cb[(long)row * E.scr + (long)col * E.scc], v);
+            } else {
+              if (E.bias) v += E.bias[E.bias_on_row ? row : col];
+              v = act_fwd(E.act, v, E.slope);
+              v *= bs;
+              if (Rb) v += Rb[(long)row * E.srr + (long)col * E.src];
+              Cb[(long)row * E.scr + (long)col * E.scc] = v;
             }
-          } else if (E.atomic) {
-            atomicAdd(&Cb[(long)row * E.scr + (long)col * E.scc], v);
-          } else {
-            if (E.bias) v += E.bias[E.bias_on_row ? row : col];
-            v = act_fwd(E.act, v, E.slope);
-            v *= bs;
-            if (Rb) v += Rb[(long)row * E.srr + (long)col * E.src];
-            Cb[(long)row * E.scr + (long)col * E.scc] = v;
           }
         }
       }
+    }
 }
 
-template <typename OpT, bool IM>
+template <typename OpT, bool IM, bool SWAP>
 static int launch_tile(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_t stream) {
   dim3 grid(cdiv(g.N, bn), cdiv(g.M, bm), nbatch * g.splits);
   if (grid.y > 65535 || grid.z > 65535) return CENET_EUNSUPPORTED;
-#define CENET_TILE(BMv, BNv)                                                              \
-  if (bm == BMv && bn == BNv) {                                                           \
-    CENET_LAUNCH((gemm_kernel<OpT, BMv, BNv, IM>), grid, dim3(256), stream, g);           \
-    return CENET_OK;                                                                      \
+#define CENET_TILE(BMv, BNv)                                                                   \
+  if (bm == BMv && bn == BNv) {                                                                \
+    CENET_LAUNCH((gemm_kernel<OpT, BMv, BNv, IM, SWAP>), grid, dim3(256), stream, g);          \
+    return CENET_OK;                                                                           \
   }
   CENET_TILE(128, 128)
   CENET_TILE(128, 64)
@@ -415,6 +466,9 @@ extern "C" int cenet_set_compute_bf16(int on) {
 }
 extern "C" int cenet_get_compute_bf16() { return g_compute_bf16; }
 
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static inline bool m4(long v) { return (v & 3) == 0; }
+
 extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K,
                               int nbatch, int nb_inner, int nkb, int splits, hipStream_t stream) {
   if (!A || !B || !E || !A->ptr || !B->ptr || !E->C) return CENET_EINVAL;
@@ -427,17 +481,35 @@ extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const 
   g.B = *B;
   g.E = *E;
   g.M = M; g.N = N; g.K = K; g.nkb = nkb; g.splits = splits; g.nb_inner = nb_inner;
+  // 16-byte staging: k-contiguous plain operand, every row/batch offset a multiple of 4 floats, K % 4 == 0
+  g.avec = A->kfast && A->kinner == 0 && A->sc == 1 && m4(A->sr) && m4(A->sb) && m4(A->sb2) && m4(A->skb) && m4(K) && al16(A->ptr);
+  g.bvec = B->mode == 0 && B->kfast && B->kinner == 0 && B->sr == 1 && m4(B->sc) && m4(B->sb) && m4(B->sb2) && m4(B->skb) &&
+           m4(K) && al16(B->ptr);
+  // row-major C: lanes own 4 consecutive columns (16-byte epilogue). Atomic epilogues keep the un-swapped layout: one
+  // atomic instruction then covers 4 rows x 16 consecutive floats (64-byte segments) instead of 16 rows x 4 strided.
+  const bool swap = (E->scc == 1) && !E->atomic && !E->cmode;
+  if (swap)
+    g.cvec = E->scc == 1 && m4(E->scr) && m4(E->scb) && m4(E->scb2) && al16(E->C) &&
+             (!E->R || (E->src == 1 && m4(E->srr) && m4(E->srb) && m4(E->srb2) && al16(E->R)));
+  else
+    g.cvec = E->scr == 1 && m4(E->scc) && m4(E->scb) && m4(E->scb2) && al16(E->C) &&
+             (!E->R || (E->srr == 1 && m4(E->src) && m4(E->srb) && m4(E->srb2) && al16(E->R)));
   int bm, bn;
   pick_tile(M, N, nbatch, splits, &bm, &bn);
   if (B->mode == 1 && B->kfast && bm == 32) bn = 64;  // weight-gradient view: keep the per-thread gather list short
+  const bool im = B->mode != 0;
   int rc;
+#define CENET_DISPATCH(T)                                                                          \
+  rc = im ? (swap ? launch_tile<T, true, true>(g, bm, bn, nbatch, stream)                          \
+                  : launch_tile<T, true, false>(g, bm, bn, nbatch, stream))                        \
+          : (swap ? launch_tile<T, false, true>(g, bm, bn, nbatch, stream)                         \
+                  : launch_tile<T, false, false>(g, bm, bn, nbatch, stream))
   if (g_compute_bf16) {
-    rc = (B->mode == 0) ? launch_tile<unsigned short, false>(g, bm, bn, nbatch, stream)
-                        : launch_tile<unsigned short, true>(g, bm, bn, nbatch, stream);
+    CENET_DISPATCH(unsigned short);
   } else {
-    rc = (B->mode == 0) ? launch_tile<float, false>(g, bm, bn, nbatch, stream)
-                        : launch_tile<float, true>(g, bm, bn, nbatch, stream);
+    CENET_DISPATCH(float);
   }
+#undef CENET_DISPATCH
   if (rc != CENET_OK) return rc;
   CENET_CHECK_LAUNCH();
   return CENET_OK;
