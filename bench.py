@@ -24,6 +24,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same guide)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -77,9 +78,63 @@ def dominant_kernel_probe(dev, B):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * B * 32 * 224 * 224 * 32 * 25
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_f32_kernel<im2col> (out.rb.0.conv2 fwd, 5x5 32->32 @224^2)",
-            "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4)}
+    peak = peak_tflops()
+    # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, calibrated for this access pattern,
+    # + WRITE_SIZE): profiles/r01_pmc_roofline_kernel.csv, measured at B=32 in fp32-operand mode; algorithmic = 411 MB
+    traffic = 1.157e9 if (B == 32 and peak == PEAK_F32_MFMA_TFLOPS) else None
+    return {"bound": "mfma", "kernel": "gemm_kernel<32,256,im2col> (out.rb.0.conv2 fwd, 5x5 32->32 @224^2)",
+            "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": traffic, "avg_launch_ms": round(ms, 4)}
+
+
+def peak_tflops():
+    from cenet_amd import kern
+    return PEAK_BF16_MFMA_TFLOPS if kern.get_compute_bf16() else PEAK_F32_MFMA_TFLOPS
+
+
+def _time(fn, reps=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def extra_kernel_probes(dev, B):
+    """Two more live-timed launches: the heaviest single launch of the step (flash backward dK/dV of DSEB-56^2: 8 softmax
+    heads, N=3136, hd=16, dv=32 — fp32 MFMA in every mode this round) and the largest plain GEMM (stage-1 Mlp fc1)."""
+    from cenet_amd import kern, ops
+    out = []
+    N, H, hd = 3136, 4, 16
+    E = 2 * H * hd
+    q, k, v = (torch.randn(B, N, E, device=dev, requires_grad=True) for _ in range(3))
+    U = ops.diff_attention_heads(q, k, v, H)
+    g = torch.randn_like(U)
+    t_f = _time(lambda: ops.diff_attention_heads(q.detach(), k.detach(), v.detach(), H))
+    t_fb = _time(lambda: ops.diff_attention_heads(q, k, v, H).backward(g))
+    fl_f = 2.0 * B * 2 * H * N * N * (hd + 2 * hd)
+    fl_b = 2.0 * B * 2 * H * N * N * (2 * hd + 2 * 2 * hd) + 2.0 * B * 2 * H * N * N * (2 * hd + 2 * hd)
+    out.append({"kernel": "flash_fwd_kernel<16,32> (DSEB-56^2 differential attention)", "bound": "mfma",
+                "achieved": round(fl_f / t_f / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl_f / t_f / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(t_f, 3)})
+    out.append({"kernel": "flash_bwd_dq+dkv_kernel<16,32> (same problem, both backward launches)", "bound": "mfma",
+                "achieved": round(fl_b / (t_fb - t_f) / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl_b / (t_fb - t_f) / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "avg_launch_ms": round(t_fb - t_f, 3)})
+    R, K, Nn = B * 3136, 64, 512
+    x = torch.randn(R, K, device=dev)
+    W = torch.randn(Nn, K, device=dev) * 0.05
+    y = torch.empty(R, Nn, device=dev)
+    t = _time(lambda: kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, R, Nn, K, scr=Nn, scc=1))
+    by = (R * K + Nn * K + R * Nn) * 4.0
+    out.append({"kernel": "gemm_kernel<128,128,plain> (stage-1 Mlp.fc1 fwd: 100352x64 @ 64x512)", "bound": "hbm",
+                "achieved": round(by / t / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / t / 1e6 / PEAK_HBM_GBS, 4),
+                "avg_launch_ms": round(t, 4)})
+    return out
 
 
 def cpu_baseline(steps):
@@ -181,6 +236,7 @@ def main():
                           "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                           "final_loss": round(final_loss, 5)}}
         out["roofline"] = dominant_kernel_probe(dev, a.batch)
+        out["roofline_extra"] = extra_kernel_probes(dev, a.batch)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps)
         print(json.dumps(out), flush=True)

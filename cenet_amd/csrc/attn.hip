@@ -435,11 +435,21 @@ static int pick_variant(int D, int Dv) {
   return -1;
 }
 
+// bf16-operand variants (attn_bf16.hip)
+int cenet_flashb_fwd(const cenet_attn_t* p, hipStream_t stream);
+int cenet_flashb_bwd(const cenet_attn_t* p, hipStream_t stream);
+
 extern "C" int cenet_flash_attn_supported(int D, int Dv) { return pick_variant(D, Dv) >= 0; }
 
 extern "C" int cenet_flash_attn_fwd_f32(const cenet_attn_t* p, hipStream_t stream) {
   if (!p || !p->q || !p->k || !p->v || !p->o || !p->lse) return CENET_EINVAL;
   if (p->B <= 0 || p->H <= 0 || p->Nq <= 0 || p->Nk <= 0 || p->D <= 0 || p->Dv <= 0) return CENET_EINVAL;
+  if (cenet_get_compute_bf16()) {  // throughput mode: bf16-operand kernels of attn_bf16.hip
+    int rc = cenet_flashb_fwd(p, stream);
+    if (rc != CENET_OK) return rc;
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   AttnArgs a;
   fill_args(a, p);
   dim3 grid(cdiv(a.Nq, TQ), a.B * a.H);
@@ -458,6 +468,12 @@ extern "C" int cenet_flash_attn_fwd_f32(const cenet_attn_t* p, hipStream_t strea
 extern "C" int cenet_flash_attn_bwd_f32(const cenet_attn_t* p, hipStream_t stream) {
   if (!p || !p->q || !p->k || !p->v || !p->o || !p->lse || !p->dout || !p->dq || !p->dk || !p->dv || !p->delta)
     return CENET_EINVAL;
+  if (cenet_get_compute_bf16()) {
+    int rc = cenet_flashb_bwd(p, stream);
+    if (rc != CENET_OK) return rc;
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   AttnArgs a;
   fill_args(a, p);
   dim3 gq(cdiv(a.Nq, TQ), a.B * a.H), gk(cdiv(a.Nk, TK), a.B * a.H);
