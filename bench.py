@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE.json configs[1]: 32)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="operand precision of the MFMA contractions (accumulation, softmax and norm statistics stay fp32)")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step as one captured hipGraph (auto: fall back to eager launches if capture fails)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -198,13 +200,30 @@ def main():
     crit = losses.Criterion(4, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
     x, lab = synthetic(a.batch, dev, seed=1234 + rank)
 
-    def step():
+    def body(sync_hyper=True):
         opt.zero_grad()
         loss = crit(net(x), lab)
         loss.backward()
         if reducer is not None:
             reducer.finish()
-        opt.step()
+        opt.step(sync_hyper=sync_hyper)
+        return loss
+
+    graphed = None
+    if a.graph != "off":
+        # the whole step (memset, ~1.8 k kernels, all-reduces, SGD) as ONE hipGraph replay per iteration
+        from cenet_amd.graph import GraphedStep
+        try:
+            graphed = GraphedStep(lambda: body(sync_hyper=False), optimizer=opt, warmup=2)
+        except Exception as e:  # capture is an optimisation: fall back to eager launches of the same kernels
+            if a.graph == "on":
+                raise
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graphed = None
+            torch.cuda.synchronize()
+
+    def step():
+        loss = graphed() if graphed is not None else body()
         sched.step()
         return loss
 
@@ -234,6 +253,7 @@ def main():
                "config": {"workload": "ACDC 224x224 4-class, batch=32/GPU, random-init PVTv2-b2 CENet, "
                                       "fwd + Dice/CE + bwd + grad all-reduce + SGD(momentum .9, wd 1e-4)",
                           "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                          "launch": "hipGraph replay" if graphed is not None else "eager",
                           "final_loss": round(final_loss, 5)}}
         out["roofline"] = dominant_kernel_probe(dev, a.batch)
         out["roofline_extra"] = extra_kernel_probes(dev, a.batch)

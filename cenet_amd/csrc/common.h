@@ -30,6 +30,10 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 // error codes returned through the C ABI (0 == ok)
 enum { CENET_OK = 0, CENET_EINVAL = 1, CENET_EUNSUPPORTED = 2 };
 
+// zero-fill n floats on `stream` with a kernel (hipMemsetAsync from a captured stream was observed not to be replayed
+// faithfully by hipGraph on this stack; a kernel node always is). Defined in loss_optim.hip.
+int cenet_zero_async(float* p, long n, hipStream_t stream);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // activation ids shared by several kernels

@@ -497,6 +497,18 @@ extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const 
   int bm, bn;
   pick_tile(M, N, nbatch, splits, &bm, &bn);
   if (B->mode == 1 && B->kfast && bm == 32) bn = 64;  // weight-gradient view: keep the per-thread gather list short
+  if (E->atomic && !E->cmode && splits > 1) {
+    // split-K: every split adds the whole MxN tile with float atomics (~1.3 TB/s chip-wide), so use only as many
+    // splits as it takes to fill the chip (~2 workgroups per CU) with the tile actually chosen, each >= 4 K-tiles deep
+    const long tiles = (long)cdiv(M, bm) * cdiv(N, bn) * nbatch;
+    const long iters = (long)nkb * cdiv(K, BK);
+    long s = (512 + tiles - 1) / tiles;
+    if (s > iters / 4) s = iters / 4;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    splits = (int)s;
+    g.splits = splits;
+  }
   const bool im = B->mode != 0;
   int rc;
 #define CENET_DISPATCH(T)                                                                          \

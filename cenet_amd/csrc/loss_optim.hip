@@ -136,14 +136,22 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+__global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ p, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0.f;
+}
+int cenet_zero_async(float* p, long n, hipStream_t stream) {
+  if (n <= 0) return CENET_OK;
+  long blocks = (n + 1023) / 1024;
+  if (blocks > 8192) blocks = 8192;
+  CENET_LAUNCH(zero_kernel, dim3((unsigned)blocks), dim3(256), stream, p, n);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
 extern "C" int cenet_dice_ce_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int HW,
                                      float w_dice, float w_ce, hipStream_t stream) {
   if (B <= 0 || K <= 0 || K > LOSS_MAXK || HW <= 0) return CENET_EINVAL;
-#ifdef CENET_HOSTSIM_BUILD
-  memset(acc, 0, sizeof(float) * (3 * K + 1));
-#else
-  if (hipMemsetAsync(acc, 0, sizeof(float) * (3 * K + 1), stream) != hipSuccess) return CENET_EINVAL;
-#endif
+  if (cenet_zero_async(acc, 3L * K + 1, stream) != CENET_OK) return CENET_EINVAL;
   const long npix = (long)B * HW;
   long blocks = (npix + 1023) / 1024;
   if (blocks > 2048) blocks = 2048;
@@ -173,10 +181,5 @@ extern "C" int cenet_sgd_step_f32(float* p, const float* g, float* buf, const fl
 }
 extern "C" int cenet_zero_f32(float* p, long n, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
-#ifdef CENET_HOSTSIM_BUILD
-  memset(p, 0, sizeof(float) * n);
-#else
-  if (hipMemsetAsync(p, 0, sizeof(float) * n, stream) != hipSuccess) return CENET_EINVAL;
-#endif
-  return CENET_OK;
+  return cenet_zero_async(p, n, stream);
 }

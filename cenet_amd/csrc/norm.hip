@@ -248,11 +248,7 @@ extern "C" int cenet_bn_stats_f32(const float* x, long sb, int B, int C, int HW,
                                   float* running_mean, float* running_var, float momentum, long* num_batches_tracked,
                                   hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-#ifdef CENET_HOSTSIM_BUILD
-  memset(ws, 0, sizeof(float) * 2 * C);
-#else
-  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, stream) != hipSuccess) return CENET_EINVAL;
-#endif
+  if (cenet_zero_async(ws, 2L * C, stream) != CENET_OK) return CENET_EINVAL;
   const long total = (long)B * HW;
   CENET_LAUNCH(bn_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, x, sb, B, HW, ws);
   CENET_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), stream, x, HW, (const float*)ws, C, (float)total, mean, var,
@@ -278,11 +274,7 @@ extern "C" int cenet_bn_bwd_acc_f32(const float* dy, long sgb, const float* x, l
                                     int act, float slope, int B, int C, int HW, float* ws, float* dgamma_acc,
                                     float* dbeta_acc, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-#ifdef CENET_HOSTSIM_BUILD
-  memset(ws, 0, sizeof(float) * 2 * C);
-#else
-  if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * C, stream) != hipSuccess) return CENET_EINVAL;
-#endif
+  if (cenet_zero_async(ws, 2L * C, stream) != CENET_OK) return CENET_EINVAL;
   const long total = (long)B * HW;
   CENET_LAUNCH(bn_bwd_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma,
                beta, act, slope, B, HW, ws);

@@ -87,9 +87,20 @@ class FusedSGD:
         self._sync_hyper()
 
     def _sync_hyper(self):
-        h = torch.tensor([self.lr, self.momentum, self.weight_decay, self.grad_scale, 1.0 if self._steps == 0 else 0.0],
-                         dtype=torch.float32)
-        self.hyper.copy_(h, non_blocking=True)
+        vals = [self.lr, self.momentum, self.weight_decay, self.grad_scale, 1.0 if self._steps == 0 else 0.0]
+        if self.hyper.is_cuda:
+            # asynchronous upload from PINNED staging (a pageable temporary could be recycled by the host before the copy
+            # executes when the host runs ahead of the GPU, e.g. under hipGraph replay); 4 slots rotate
+            if not hasattr(self, "_stage"):
+                self._stage = [torch.zeros(5, dtype=torch.float32).pin_memory() for _ in range(4)]
+                self._slot = 0
+            h = self._stage[self._slot]
+            self._slot = (self._slot + 1) % len(self._stage)
+            for i, v in enumerate(vals):
+                h[i] = v
+            self.hyper.copy_(h, non_blocking=True)
+        else:
+            self.hyper.copy_(torch.tensor(vals, dtype=torch.float32))
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()
@@ -97,10 +108,17 @@ class FusedSGD:
     def set_lr(self, lr: float):
         self.lr = lr
 
-    def step(self):
-        self._sync_hyper()
+    def step(self, sync_hyper: bool = True):
+        """sync_hyper=False: the caller has uploaded the hyper-parameters already (`prepare()`); needed when the step is
+        captured in a HIP graph, where a host->device copy is not allowed inside the captured region."""
+        if sync_hyper:
+            self._sync_hyper()
         kern.sgd_step(self.arena.params, self.arena.grads, self.buf, self.hyper, self.arena.numel)
         self._steps += 1
+
+    def prepare(self):
+        """Upload lr / momentum / wd / grad_scale / first-step flag for the NEXT step (call before a graph replay)."""
+        self._sync_hyper()
 
     @property
     def param_groups(self):
