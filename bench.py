@@ -210,7 +210,10 @@ def main():
         return loss
 
     graphed = None
-    if a.graph != "off":
+    # auto: capture on one GPU; with RCCL collectives inside the step (N > 1) stay eager unless --graph on is given
+    # (the step is GPU-bound, so replay vs eager launches is worth < 1 % today; capture of multi-rank collectives could not
+    # be exercised on the 1-GPU development box)
+    if a.graph == "on" or (a.graph == "auto" and not use_dist):
         # the whole step (memset, ~1.8 k kernels, all-reduces, SGD) as ONE hipGraph replay per iteration
         from cenet_amd.graph import GraphedStep
         try:

@@ -102,9 +102,10 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_kernel(const float* __re
   float acc[10];
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t] = 0.f;
-  for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
-    const int b = (int)(e / HW);
-    const int p = (int)(e - (long)b * HW);
+  for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
+  for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
+           pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
+       p < pend__; p += 256) {
     const int py = p / W, px = p - py * W;
     const float g = dy[(long)b * sgb + (long)c * HW + p];
     const float* xp = x + (long)b * sxb + (long)c * HW;

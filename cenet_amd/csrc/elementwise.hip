@@ -126,9 +126,10 @@ __global__ __launch_bounds__(256) void chan_dot_kernel(const float* __restrict__
   const int c = blockIdx.x;
   const long total = (long)B * HW;
   float s = 0.f;
-  for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
-    const int b = (int)(e / HW);
-    const int p = (int)(e - (long)b * HW);
+  for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
+  for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
+           pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
+       p < pend__; p += 256) {
     const float av = a[(long)b * sab + (long)c * HW + p];
     s += bb ? av * bb[(long)b * sbb + (long)c * HW + p] : av;
   }
@@ -282,69 +283,80 @@ __global__ __launch_bounds__(64) void diffattn_lambda_bwd_kernel(const float* q1
     atomicAdd(&dk2[i], g2 * q2[i]);
   }
 }
-// U [B, 2H, N, dv] -> out [B, N, H*dv]: a = U[2h] - lam*U[2h+1]; out = a * rsqrt(mean(a^2)+eps) * post
-// one wave per (b,h,n) vector
+// U [B, 2H, N, dv] -> out [B, N, H*dv]: a = U[2h] - lam*U[2h+1]; out = a * rsqrt(mean(a^2)+eps) * post.
+// A (b,h,n) vector is handled by a SUB-wave of `sub` lanes (16/32/64 >= min(dv,64)), so short vectors fill the wave.
+__device__ __forceinline__ float subwave_sum(float v, int sub) {
+  for (int o = sub >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 __global__ __launch_bounds__(256) void diffattn_combine_fwd_kernel(const float* __restrict__ U, const float* __restrict__ lam,
                                                                   float* __restrict__ out, int H, int N, int dv, float eps,
-                                                                  float post, long nvec) {
+                                                                  float post, long nvec, int sub) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long vec = (long)blockIdx.x * 4 + wave;
-  if (vec >= nvec) return;
-  const int n = (int)(vec % N);
-  const long bh = vec / N;
+  const int vpw = 64 / sub, sl = lane & (sub - 1);
+  const long vec = ((long)blockIdx.x * 4 + wave) * vpw + lane / sub;
+  const bool ok = vec < nvec;
+  const int n = ok ? (int)(vec % N) : 0;
+  const long bh = ok ? vec / N : 0;
   const int h = (int)(bh % H);
   const long b = bh / H;
   const float lm = lam[0];
   const float* u0 = U + (((b * 2 * H) + 2 * h) * N + n) * (long)dv;
   const float* u1 = u0 + (long)N * dv;
   float ss = 0.f;
-  for (int d = lane; d < dv; d += 64) {
-    const float av = u0[d] - lm * u1[d];
-    ss += av * av;
+  if (ok)
+    for (int d = sl; d < dv; d += sub) {
+      const float av = u0[d] - lm * u1[d];
+      ss += av * av;
+    }
+  const float r = rsqrtf(subwave_sum(ss, sub) / dv + eps) * post;
+  if (ok) {
+    float* o = out + (b * N + n) * (long)(H * dv) + (long)h * dv;
+    for (int d = sl; d < dv; d += sub) o[d] = (u0[d] - lm * u1[d]) * r;
   }
-  const float r = rsqrtf(wave_sum(ss) / dv + eps) * post;
-  float* o = out + (b * N + n) * (long)(H * dv) + (long)h * dv;
-  for (int d = lane; d < dv; d += 64) o[d] = (u0[d] - lm * u1[d]) * r;
 }
 __global__ __launch_bounds__(256) void diffattn_combine_bwd_kernel(const float* __restrict__ U, const float* __restrict__ lam,
                                                                   const float* __restrict__ dout, float* __restrict__ dU,
                                                                   float* __restrict__ dlam, int H, int N, int dv, float eps,
-                                                                  float post, long nvec) {
+                                                                  float post, long nvec, int sub) {
   __shared__ float part[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long vec = (long)blockIdx.x * 4 + wave;
-  float dl = 0.f;
-  if (vec < nvec) {
-    const int n = (int)(vec % N);
-    const long bh = vec / N;
-    const int h = (int)(bh % H);
-    const long b = bh / H;
-    const float lm = lam[0];
-    const long off0 = (((b * 2 * H) + 2 * h) * N + n) * (long)dv;
-    const float* u0 = U + off0;
-    const float* u1 = u0 + (long)N * dv;
-    const float* g = dout + (b * N + n) * (long)(H * dv) + (long)h * dv;
-    float ss = 0.f, ga = 0.f;
-    for (int d = lane; d < dv; d += 64) {
+  const int vpw = 64 / sub, sl = lane & (sub - 1);
+  const long vec = ((long)blockIdx.x * 4 + wave) * vpw + lane / sub;
+  const bool ok = vec < nvec;
+  const int n = ok ? (int)(vec % N) : 0;
+  const long bh = ok ? vec / N : 0;
+  const int h = (int)(bh % H);
+  const long b = bh / H;
+  const float lm = lam[0];
+  const long off0 = (((b * 2 * H) + 2 * h) * N + n) * (long)dv;
+  const float* u0 = U + off0;
+  const float* u1 = u0 + (long)N * dv;
+  const float* g = dout + (b * N + n) * (long)(H * dv) + (long)h * dv;
+  float ss = 0.f, ga = 0.f;
+  if (ok)
+    for (int d = sl; d < dv; d += sub) {
       const float av = u0[d] - lm * u1[d];
       ss += av * av;
       ga += g[d] * av;
     }
-    ss = wave_sum(ss);
-    ga = wave_sum(ga);
-    const float r = rsqrtf(ss / dv + eps);
-    const float k = r * r * ga / dv;
+  ss = subwave_sum(ss, sub);
+  ga = subwave_sum(ga, sub);
+  const float r = rsqrtf(ss / dv + eps);
+  const float k = r * r * ga / dv;
+  float dl = 0.f;
+  if (ok) {
     float* d0 = dU + off0;
     float* d1 = d0 + (long)N * dv;
-    for (int d = lane; d < dv; d += 64) {
+    for (int d = sl; d < dv; d += sub) {
       const float av = u0[d] - lm * u1[d];
       const float da = post * r * (g[d] - av * k);
       d0[d] = da;
       d1[d] = -lm * da;
       dl -= da * u1[d];
     }
-    dl = wave_sum(dl);
   }
+  dl = wave_sum(dl);
   if (lane == 0) part[wave] = dl;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(dlam, part[0] + part[1] + part[2] + part[3]);
@@ -508,8 +520,10 @@ extern "C" int cenet_diffattn_combine_fwd_f32(const float* U, const float* lam3,
                                               float eps, float post, hipStream_t stream) {
   if (B <= 0 || H <= 0 || N <= 0 || dv <= 0) return CENET_EINVAL;
   long nvec = (long)B * H * N;
-  CENET_LAUNCH(diffattn_combine_fwd_kernel, dim3((unsigned)((nvec + 3) / 4)), dim3(256), stream, U, lam3, out, H, N, dv, eps,
-               post, nvec);
+  const int sub = dv <= 16 ? 16 : (dv <= 32 ? 32 : 64);
+  const long per_block = 4L * (64 / sub);
+  CENET_LAUNCH(diffattn_combine_fwd_kernel, dim3((unsigned)((nvec + per_block - 1) / per_block)), dim3(256), stream, U, lam3, out,
+               H, N, dv, eps, post, nvec, sub);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -518,8 +532,10 @@ extern "C" int cenet_diffattn_combine_bwd_acc_f32(const float* U, const float* l
                                                   hipStream_t stream) {
   if (B <= 0 || H <= 0 || N <= 0 || dv <= 0) return CENET_EINVAL;
   long nvec = (long)B * H * N;
-  CENET_LAUNCH(diffattn_combine_bwd_kernel, dim3((unsigned)((nvec + 3) / 4)), dim3(256), stream, U, lam3, dout, dU, dlam_acc, H,
-               N, dv, eps, post, nvec);
+  const int sub = dv <= 16 ? 16 : (dv <= 32 ? 32 : 64);
+  const long per_block = 4L * (64 / sub);
+  CENET_LAUNCH(diffattn_combine_bwd_kernel, dim3((unsigned)((nvec + per_block - 1) / per_block)), dim3(256), stream, U, lam3, dout,
+               dU, dlam_acc, H, N, dv, eps, post, nvec, sub);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

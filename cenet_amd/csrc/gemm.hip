@@ -502,7 +502,8 @@ extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const 
     // splits as it takes to fill the chip (~2 workgroups per CU) with the tile actually chosen, each >= 4 K-tiles deep
     const long tiles = (long)cdiv(M, bm) * cdiv(N, bn) * nbatch;
     const long iters = (long)nkb * cdiv(K, BK);
-    long s = (512 + tiles - 1) / tiles;
+    const long target = (B->mode == 1) ? 1024 : 512;  // gather-heavy conv weight-gradients want more, shorter blocks
+    long s = (target + tiles - 1) / tiles;
     if (s > iters / 4) s = iters / 4;
     if (s > 256) s = 256;
     if (s < 1) s = 1;

@@ -34,59 +34,72 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-#define LN_MAXJ 8  // C <= 512
+// LayerNorm backward.  MAXJ = columns per lane (C <= 64*MAXJ); each wave walks its rows RPI at a time (independent
+// load -> reduce -> store chains in flight together), column partials of dgamma/dbeta stay in registers and meet in LDS.
 #define LN_ROWS_PER_BLOCK 64
+template <int MAXJ, int RPI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float* __restrict__ dx,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int rows, int C) {
-  __shared__ float red[2][4][LN_MAXJ * 64];
+  __shared__ float red[2][4][MAXJ * 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float dg[LN_MAXJ], db[LN_MAXJ], gm[LN_MAXJ];
+  float dg[MAXJ], db[MAXJ], gm[MAXJ];
 #pragma unroll
-  for (int j = 0; j < LN_MAXJ; ++j) {
+  for (int j = 0; j < MAXJ; ++j) {
     dg[j] = 0.f;
     db[j] = 0.f;
     int c = lane + 64 * j;
     gm[j] = c < C ? gamma[c] : 0.f;
   }
   const long r0 = (long)blockIdx.x * LN_ROWS_PER_BLOCK;
-  for (int i = wave; i < LN_ROWS_PER_BLOCK; i += 4) {
-    const long row = r0 + i;
-    if (row >= rows) break;  // wave-uniform
-    const float mu = mean[row], rs = rstd[row];
-    const float* xr = x + row * C;
-    const float* gr = dy + row * C;
-    float xh[LN_MAXJ], g[LN_MAXJ];
-    float s1 = 0.f, s2 = 0.f;
+  for (int i = wave * RPI; i < LN_ROWS_PER_BLOCK; i += 4 * RPI) {
+    float xh[RPI][MAXJ], g[RPI][MAXJ], s1[RPI], s2[RPI], rs[RPI];
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) {
-      int c = lane + 64 * j;
-      if (c < C) {
-        xh[j] = (xr[c] - mu) * rs;
-        g[j] = gr[c];
-      } else {
-        xh[j] = 0.f;
-        g[j] = 0.f;
+    for (int q = 0; q < RPI; ++q) {
+      const long row = r0 + i + q;
+      const bool rok = row < rows;  // wave-uniform
+      const float mu = rok ? mean[row] : 0.f;
+      rs[q] = rok ? rstd[row] : 0.f;
+      s1[q] = 0.f;
+      s2[q] = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        int c = lane + 64 * j;
+        if (rok && c < C) {
+          xh[q][j] = (x[row * C + c] - mu) * rs[q];
+          g[q][j] = dy[row * C + c];
+        } else {
+          xh[q][j] = 0.f;
+          g[q][j] = 0.f;
+        }
+        float gg = g[q][j] * gm[j];
+        s1[q] += gg;
+        s2[q] += gg * xh[q][j];
+        dg[j] += g[q][j] * xh[q][j];
+        db[j] += g[q][j];
       }
-      float gg = g[j] * gm[j];
-      s1 += gg;
-      s2 += gg * xh[j];
-      dg[j] += g[j] * xh[j];
-      db[j] += g[j];
     }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
-    float* dxr = dx + row * C;
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) {
-      int c = lane + 64 * j;
-      if (c < C) dxr[c] = rs * (g[j] * gm[j] - s1 - xh[j] * s2);
+    for (int q = 0; q < RPI; ++q) {
+      s1[q] = wave_sum(s1[q]) / C;
+      s2[q] = wave_sum(s2[q]) / C;
+    }
+#pragma unroll
+    for (int q = 0; q < RPI; ++q) {
+      const long row = r0 + i + q;
+      if (row < rows) {
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+          int c = lane + 64 * j;
+          if (c < C) dx[row * C + c] = rs[q] * (g[q][j] * gm[j] - s1[q] - xh[q][j] * s2[q]);
+        }
+      }
     }
   }
 #pragma unroll
-  for (int j = 0; j < LN_MAXJ; ++j) {
+  for (int j = 0; j < MAXJ; ++j) {
     red[0][wave][j * 64 + lane] = dg[j];
     red[1][wave][j * 64 + lane] = db[j];
   }
@@ -111,9 +124,16 @@ extern "C" int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, cons
                                            const float* rstd, float* dx, float* dgamma_acc, float* dbeta_acc, int rows,
                                            int C, hipStream_t stream) {
   if (rows <= 0 || C <= 0) return CENET_EINVAL;
-  if (C > LN_MAXJ * 64) return CENET_EUNSUPPORTED;
-  CENET_LAUNCH(layernorm_bwd_kernel, dim3(cdiv(rows, LN_ROWS_PER_BLOCK)), dim3(256), stream, dy, x, gamma, mean, rstd, dx,
-               dgamma_acc, dbeta_acc, rows, C);
+  if (C > 512) return CENET_EUNSUPPORTED;
+  dim3 grid(cdiv(rows, LN_ROWS_PER_BLOCK));
+#define CENET_LN(MJ, RP)                                                                                            \
+  CENET_LAUNCH((layernorm_bwd_kernel<MJ, RP>), grid, dim3(256), stream, dy, x, gamma, mean, rstd, dx, dgamma_acc, dbeta_acc, \
+               rows, C)
+  if (C <= 64) { CENET_LN(1, 4); }
+  else if (C <= 128) { CENET_LN(2, 4); }
+  else if (C <= 256) { CENET_LN(4, 2); }
+  else { CENET_LN(8, 1); }
+#undef CENET_LN
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -129,9 +149,10 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   const float shift = xc[0];
   const long total = (long)B * HW;
   float s1 = 0.f, s2 = 0.f;
-  for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
-    int b = (int)(e / HW);
-    int p = (int)(e - (long)b * HW);
+  for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
+  for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
+           pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
+       p < pend__; p += 256) {
     float v = xc[(long)b * sb + p] - shift;
     s1 += v;
     s2 += v * v;
@@ -190,9 +211,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
   const long total = (long)B * HW;
   float s1 = 0.f, s2 = 0.f;
-  for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
-    int b = (int)(e / HW);
-    int p = (int)(e - (long)b * HW);
+  for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
+  for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
+           pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
+       p < pend__; p += 256) {
     float xh = (x[(long)b * sxb + (long)c * HW + p] - mu) * rs;
     float g = dy[(long)b * sgb + (long)c * HW + p];
     if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);

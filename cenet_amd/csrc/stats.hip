@@ -154,33 +154,60 @@ __global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // SRM: channel statistics per pixel. x [B, C, HW]; u [B, 3, HW]; amax [B, HW]
 // ---------------------------------------------------------------------------------------------------------------
+// SRM channel statistics, single pass: workgroup = 64 pixels x 4 channel groups (lanes along pixels: every load is a
+// contiguous 256-byte row segment), shifted sums (shift = channel 0) for mean / unbiased std, groups meet in LDS.
 __global__ __launch_bounds__(256) void srm_stats_fwd_kernel(const float* __restrict__ x, float* __restrict__ u,
                                                            int* __restrict__ amax, int C, int HW) {
+  __shared__ float s1_s[4][64], s2_s[4][64], mx_s[4][64];
+  __shared__ int mi_s[4][64];
   const int b = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= HW) return;
-  const float* xb = x + (long)b * C * HW + p;
-  float s = 0.f, mx = -3.4e38f;
+  const int pl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + pl;
+  const bool ok = p < HW;
+  const float* xb = x + (long)b * C * HW + (ok ? p : 0);
+  const float shift = ok ? xb[0] : 0.f;
+  float s1 = 0.f, s2 = 0.f, mx = -3.4e38f;
   int mi = 0;
-  for (int c = 0; c < C; ++c) {
-    float v = xb[(long)c * HW];
-    s += v;
-    if (v > mx) {
-      mx = v;
-      mi = c;
+  if (ok) {
+    for (int c = cg; c < C; c += 4) {
+      const float v = xb[(long)c * HW];
+      const float d = v - shift;
+      s1 += d;
+      s2 += d * d;
+      if (v > mx) {
+        mx = v;
+        mi = c;
+      }
     }
   }
-  const float mean = s / C;
-  float q = 0.f;
-  for (int c = 0; c < C; ++c) {
-    float d = xb[(long)c * HW] - mean;
-    q += d * d;
+  s1_s[cg][pl] = s1;
+  s2_s[cg][pl] = s2;
+  mx_s[cg][pl] = mx;
+  mi_s[cg][pl] = mi;
+  __syncthreads();
+  if (cg == 0 && ok) {
+    float a1 = 0.f, a2 = 0.f, bm = mx_s[0][pl];
+    int bi = mi_s[0][pl];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      a1 += s1_s[g][pl];
+      a2 += s2_s[g][pl];
+      const float m = mx_s[g][pl];
+      const int i = mi_s[g][pl];
+      if (m > bm || (m == bm && i < bi)) {  // first maximal channel, like torch.max
+        bm = m;
+        bi = i;
+      }
+    }
+    const float mean_d = a1 / C;
+    float var = (a2 - a1 * mean_d) / (C - 1);
+    if (var < 0.f) var = 0.f;
+    float* ub = u + (long)b * 3 * HW + p;
+    ub[0] = bm;
+    ub[HW] = shift + mean_d;
+    ub[2 * HW] = sqrtf(var);
+    amax[(long)b * HW + p] = bi;
   }
-  float* ub = u + (long)b * 3 * HW + p;
-  ub[0] = mx;
-  ub[HW] = mean;
-  ub[2 * HW] = sqrtf(q / (C - 1));
-  amax[(long)b * HW + p] = mi;
 }
 
 // f[b,p] = pwc(u) + dwc(u): 3->1 1x1 plus 3->1 3x3 (pad 1), no bias
@@ -251,50 +278,54 @@ __global__ __launch_bounds__(256) void srm_conv_bwd_kernel(const float* __restri
   }
 }
 
-// y[b,c,p] = x[b,c,p] * sigmoid(f[b,p])
+// y[b,c,p] = x[b,c,p] * sigmoid(f[b,p]); grid (B*C planes, chunks)
 __global__ __launch_bounds__(256) void gate_pix_fwd_kernel(const float* __restrict__ x, const float* __restrict__ f,
                                                           float* __restrict__ y, int C, int HW) {
-  const int b = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= HW) return;
-  const float s = sigmoid_f(f[(long)b * HW + p]);
-  const long base = (long)b * C * HW + p;
-  for (int c = 0; c < C; ++c) y[base + (long)c * HW] = x[base + (long)c * HW] * s;
+  const int bc = blockIdx.x, b = bc / C;
+  const float* fb = f + (long)b * HW;
+  const long base = (long)bc * HW;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) y[base + p] = x[base + p] * sigmoid_f(fb[p]);
 }
 
-// df[b,p] = sigmoid'(f) * sum_c dy*x
+// df[b,p] = sigmoid'(f) * sum_c dy*x ; workgroup = 64 pixels x 4 channel groups
 __global__ __launch_bounds__(256) void gate_pix_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  const float* __restrict__ f, float* __restrict__ df, int C,
                                                                  int HW) {
+  __shared__ float part[4][64];
   const int b = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= HW) return;
-  const long base = (long)b * C * HW + p;
+  const int pl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + pl;
+  const bool ok = p < HW;
+  const long base = (long)b * C * HW + (ok ? p : 0);
   float s = 0.f;
-  for (int c = 0; c < C; ++c) s += x[base + (long)c * HW] * dy[base + (long)c * HW];
-  const float sg = sigmoid_f(f[(long)b * HW + p]);
-  df[(long)b * HW + p] = s * sg * (1.f - sg);
+  if (ok)
+    for (int c = cg; c < C; c += 4) s += x[base + (long)c * HW] * dy[base + (long)c * HW];
+  part[cg][pl] = s;
+  __syncthreads();
+  if (cg == 0 && ok) {
+    const float t = part[0][pl] + part[1][pl] + part[2][pl] + part[3][pl];
+    const float sg = sigmoid_f(f[(long)b * HW + p]);
+    df[(long)b * HW + p] = t * sg * (1.f - sg);
+  }
 }
 
-// dx = dy*sigmoid(f) + du_max*[c==amax] + du_mean/C + du_std*(x-mean)/((C-1)*std)
+// dx = dy*sigmoid(f) + du_max*[c==amax] + du_mean/C + du_std*(x-mean)/((C-1)*std); grid (B*C planes, chunks)
 __global__ __launch_bounds__(256) void srm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            const float* __restrict__ f, const float* __restrict__ u,
                                                            const float* __restrict__ du, const int* __restrict__ amax,
                                                            float* __restrict__ dx, int C, int HW) {
-  const int b = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= HW) return;
-  const float sg = sigmoid_f(f[(long)b * HW + p]);
-  const float* ub = u + (long)b * 3 * HW + p;
-  const float* db = du + (long)b * 3 * HW + p;
-  const float mean = ub[HW], sd = ub[2 * HW];
-  const float dmax = db[0], dmean = db[HW] / C, dstd = db[2 * HW] / ((C - 1) * sd);
-  const int am = amax[(long)b * HW + p];
-  const long base = (long)b * C * HW + p;
-  for (int c = 0; c < C; ++c) {
-    float v = dy[base + (long)c * HW] * sg + dmean + dstd * (x[base + (long)c * HW] - mean);
-    if (c == am) v += dmax;
-    dx[base + (long)c * HW] = v;
+  const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
+  const float* fb = f + (long)b * HW;
+  const float* ub = u + (long)b * 3 * HW;
+  const float* db = du + (long)b * 3 * HW;
+  const int* ab = amax + (long)b * HW;
+  const long base = (long)bc * HW;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) {
+    const float sg = sigmoid_f(fb[p]);
+    const float mean = ub[HW + p], sd = ub[2 * HW + p];
+    float v = dy[base + p] * sg + db[HW + p] / C + db[2 * HW + p] / ((C - 1) * sd) * (x[base + p] - mean);
+    if (c == ab[p]) v += db[p];
+    dx[base + p] = v;
   }
 }
 
@@ -334,7 +365,7 @@ extern "C" int cenet_ccu_bwd_apply_acc_f32(const float* x, const float* dy, cons
 }
 extern "C" int cenet_srm_stats_fwd_f32(const float* x, float* u, int* amax, int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(srm_stats_fwd_kernel, dim3(cdiv(HW, 256), B), dim3(256), stream, x, u, amax, C, HW);
+  CENET_LAUNCH(srm_stats_fwd_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -355,21 +386,21 @@ extern "C" int cenet_srm_conv_bwd_acc_f32(const float* u, const float* df, const
 }
 extern "C" int cenet_gate_pix_fwd_f32(const float* x, const float* f, float* y, int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(gate_pix_fwd_kernel, dim3(cdiv(HW, 256), B), dim3(256), stream, x, f, y, C, HW);
+  CENET_LAUNCH(gate_pix_fwd_kernel, dim3(B * C, chunks_for(HW)), dim3(256), stream, x, f, y, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
 extern "C" int cenet_gate_pix_bwd_reduce_f32(const float* x, const float* dy, const float* f, float* df, int B, int C,
                                              int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(gate_pix_bwd_reduce_kernel, dim3(cdiv(HW, 256), B), dim3(256), stream, x, dy, f, df, C, HW);
+  CENET_LAUNCH(gate_pix_bwd_reduce_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
 extern "C" int cenet_srm_bwd_apply_f32(const float* x, const float* dy, const float* f, const float* u, const float* du,
                                        const int* amax, float* dx, int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(srm_bwd_apply_kernel, dim3(cdiv(HW, 256), B), dim3(256), stream, x, dy, f, u, du, amax, dx, C, HW);
+  CENET_LAUNCH(srm_bwd_apply_kernel, dim3(B * C, chunks_for(HW)), dim3(256), stream, x, dy, f, u, du, amax, dx, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
