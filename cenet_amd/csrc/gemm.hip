@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) OpT As[BM * P];
   __shared__ __attribute__((aligned(16))) OpT Bs[BN * P];
   __shared__ KEntry ntab[B_IM2COL ? BN : 1];
+  __shared__ float cstrip[SWAP ? 1 : 4 * 16 * (BN / 2 + 1)];  // per-wave epilogue strips (atomic split-K path)
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -364,6 +365,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   //  SWAP: acc[i][j][r] = C[row = .. + fr][col = .. + fq*4 + r]   (4 consecutive columns per lane)
   const cenet_epi_t& E = g.E;
   float* Cb = E.C + (long)bo * E.scb + (long)bi * E.scb2;
+  if (!SWAP && E.atomic && !E.cmode && E.scc == 1) {
+    // split-K accumulation into a row-major C: float atomics reach their chip-wide rate only as 256 contiguous bytes per
+    // wave instruction, but an MFMA accumulator register spans 4 rows x 16 floats.  Each wave therefore transposes one
+    // 16-row strip at a time through a private LDS strip and issues the atomics with lane = column.
+    constexpr int WN = BN / 2;
+    float* strip = cstrip + wave * (16 * (WN + 1));
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) strip[(fq * 4 + r) * (WN + 1) + j * 16 + fr] = acc[i][j][r] * E.alpha;
+      __syncthreads();
+      const int row0 = m0 + wm * (BM / 2) + i * 16, col0 = n0 + wn * WN;
+      for (int idx = lane; idx < 16 * WN; idx += 64) {
+        const int r = idx / WN, c = idx - r * WN;
+        if (row0 + r < g.M && col0 + c < g.N) atomicAdd(&Cb[(long)(row0 + r) * E.scr + col0 + c], strip[r * (WN + 1) + c]);
+      }
+    }
+    return;
+  }
   const float* Rb = E.R ? E.R + (long)bo * E.srb + (long)bi * E.srb2 : nullptr;
   const float bs = E.bscale ? E.bscale[batch] : 1.f;
 #pragma unroll

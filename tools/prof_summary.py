@@ -1,0 +1,21 @@
+"""Summarise a rocprofv3 kernel trace: per-step wall/busy and time per kernel family (uses sgd_kernel as step delimiter)."""
+import csv, glob, collections, sys
+d = sys.argv[1]
+f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+sg = [i for i, r in enumerate(rows) if "sgd_kernel" in r["Kernel_Name"]]
+a, b = sg[-3], sg[-1]
+seg = rows[a + 1:b + 1]
+t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
+busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg)
+print(f"2 steps: wall {(t1 - t0) / 2e6:.2f} ms/step; busy {busy / 2e6:.2f} ms/step; kernels/step {len(seg) / 2:.0f}")
+grp, fam = collections.defaultdict(float), collections.defaultdict(float)
+for r in seg:
+    n = r["Kernel_Name"]; t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 2e6
+    k = n.split("(")[0].replace("void ", "")
+    grp[k] += t
+    fam["gemm_im2col" if ("gemm_kernel" in n and ", true, " in n) else "gemm_plain" if "gemm_kernel" in n else "flash" if "flash" in n else "other"] += t
+print({k: round(v, 2) for k, v in fam.items()})
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+for k, t in sorted(grp.items(), key=lambda kv: -kv[1])[:top]:
+    print(f"{t:7.2f}  {k[:100]}")
