@@ -82,10 +82,12 @@ def dominant_kernel_probe(dev, B):
     flops = 2.0 * B * 32 * 224 * 224 * 32 * 25
     achieved = flops / (ms * 1e-3) / 1e12
     peak = peak_tflops()
-    # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction, calibrated for this access pattern,
-    # + WRITE_SIZE): profiles/r01_pmc_roofline_kernel.csv, measured at B=32 in fp32-operand mode; algorithmic = 411 MB
-    traffic = 1.157e9 if (B == 32 and peak == PEAK_F32_MFMA_TFLOPS) else None
-    name = "gemm_kernel<32,256,im2col> (out.rb.0.conv2 fwd, 5x5 32->32 @224^2)"
+    # HBM bytes per launch from rocprofv3 PMC passes at B=32 (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/
+    # r01_pmc_roofline_kernel*.csv): fp32 mode = implicit-GEMM gather, bf16 mode = LDS-halo direct conv; algorithmic = 411 MB
+    bf16 = peak != PEAK_F32_MFMA_TFLOPS
+    traffic = (8.50e8 if bf16 else 1.157e9) if B == 32 else None
+    name = ("conv_direct_bf16_kernel<32,32,5>" if bf16 else "gemm_kernel<float,32,256,im2col>") + \
+        " (out.rb.0.conv2 fwd, 5x5 32->32 @224^2)"
     alg_bytes = 4.0 * (2 * B * 32 * 224 * 224 + 32 * 32 * 25)  # input + output + weights, fp32 in HBM
     # the binding roof depends on the operand mode: fp32 MFMA (157 TF) binds before HBM; at the bf16 MFMA rate (2.5 PF)
     # the same launch is HBM-bound (82 GFLOP / 2.5 PF = 33 us < 411 MB / 8 TB/s = 51 us)

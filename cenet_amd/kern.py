@@ -431,6 +431,16 @@ def zero_(t: torch.Tensor):
     return t
 
 
+def conv_direct_supported(Cin: int, Cout: int, k: int, stride: int, pad: int) -> bool:
+    return bool(_lib.lib().cenet_conv_direct_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
+
+
+def conv_direct(x, w, y, B, Cin, Cout, H, W, k, dgrad):
+    """bf16-operand direct convolution (LDS halo tiles, weights resident in LDS); dgrad: x=dY, w=forward weight, y=dX."""
+    _chk(x, w, y)
+    _call("cenet_conv_direct_bf16", x, w, y, B, Cin, Cout, H, W, k, int(dgrad))
+
+
 def set_compute_bf16(on: bool) -> bool:
     """GEMM/conv operand precision: False = fp32 (parity mode, default), True = bf16 operands + fp32 accumulate."""
     return bool(_lib.lib().cenet_set_compute_bf16(int(bool(on))))

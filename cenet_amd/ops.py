@@ -162,6 +162,16 @@ class Conv2dFn(Function):
         Ho = (H + 2 * pad - k) // stride + 1
         Wo = (Wd + 2 * pad - k) // stride + 1
         Kd = Cin * k * k
+        plain_nchw = (sb == Cin * H * Wd and sc == H * Wd and sy == Wd and sx == 1 and out_layout == "nchw" and b is None)
+        ctx.direct = bool(plain_nchw and kern.get_compute_bf16() and kern.conv_direct_supported(Cin, Cout, k, stride, pad))
+        if ctx.direct:  # bf16 mode, output-head convs: LDS-halo direct convolution (conv_direct.hip)
+            y = _empty((B, Cout, Ho, Wo), x)
+            kern.conv_direct(x, W, y, B, Cin, Cout, H, Wd, k, 0)
+            ctx.save_for_backward(x, W)
+            ctx.refs = (W, b)
+            ctx.geom = geom
+            ctx.out_hw = (Ho, Wo)
+            return y
         Bm = kern.mat_im2col(x, sb=sb, skb=0, sci=sc, sy=sy, sx=sx, KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride,
                              pad=pad, dil=1, patch_is_row=1, transposed=0, kfast=0)
         if out_layout == "nchw":
@@ -195,7 +205,11 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             # dX[b][ci][q] = sum_{co,ky,kx} W[co,ci,ky,kx] * dY gathered (transposed map); written with x's strides
             assert sy == Wd * sx, "conv2d data-gradient needs a pixel-linear input layout"
-            if stride == 1:
+            if (getattr(ctx, "direct", False) and kern.get_compute_bf16()
+                    and kern.conv_direct_supported(Cout, Cin, k, stride, pad)):
+                dx = torch.empty_like(x)  # same direct kernel, weights read transposed + flipped
+                kern.conv_direct(g, W, dx, B, Cout, Cin, H, Wd, k, 1)
+            elif stride == 1:
                 # gather form: dX = Wt[Cin, Cout*k*k] x transposed-gather(dY); no atomics, no wasted MACs
                 dx = torch.empty_like(x)
                 Bm = kern.mat_im2col(g, sb=Cout * Ho * Wo, skb=0, sci=g_sc, sy=Wo * g_sp, sx=g_sp, KH=k, KW=k, Pw=Wd,

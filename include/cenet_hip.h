@@ -75,6 +75,13 @@ int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t
 int cenet_set_compute_bf16(int on);
 int cenet_get_compute_bf16(void);
 
+/* Direct ("LDS halo") stride-1 same-padded convolution for the bf16-operand mode (conv_direct.hip): replaces
+ * aten::convolution(+ data-gradient) for out.py:41-49,59 (5x5 32->32, 3x3 64->64, 3x3 64->32 and their dgrads).
+ * dgrad = 1: x is dY [B,Cin,H,W], w is the ORIGINAL forward weight [Cin,Cout,k,k], y is dX [B,Cout,H,W]. */
+int cenet_conv_direct_supported(int Cin, int Cout, int k, int stride, int pad);
+int cenet_conv_direct_bf16(const float* x, const float* w, float* y, int B, int Cin, int Cout, int H, int W, int k, int dgrad,
+                           cenet_stream_t stream);
+
 /* ---- attention (attn.hip) -------------------------------------------------------------------------------- */
 /* Element (b,h,i,d) of Q = q[b*qsb + h*qsh + i*qsi + d*qsd]; same for K (Nk rows), V (head h / v_head_div,
  * width Dv) and O / dO (strides os*).  lse, delta: [B,H,Nq].  When v_head_div > 1 the backward ADDS into dv

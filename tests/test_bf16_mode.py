@@ -101,3 +101,26 @@ def test_whole_model_bf16_mode_stays_close_to_fp32_goldens():
     pred = O.predict(le)[:, ::5, ::5].numpy()
     assert (pred != z["pred_eval_sub"]).mean() < 1e-2
     assert abs(O.mean_class_dice(le, lab.cpu(), cfg.num_classes) - float(z["dice_eval"])) < 1e-3
+
+
+@pytest.mark.parametrize("Cin,Cout,k,H,W", [(32, 32, 5, 16, 40), (64, 64, 3, 12, 36), (64, 32, 3, 9, 33)])
+def test_direct_conv_bf16_fwd_and_dgrad(dev, bf16_mode, Cin, Cout, k, H, W):
+    """conv_direct.hip (LDS-halo direct convolution of the output head) vs fp32 torch conv, forward and data-gradient;
+    ragged tiles (H, W not multiples of the 8x32 tile) included.  The weight-gradient stays on the implicit-GEMM path."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).requires_grad_(True)
+    w = torch.nn.Parameter((torch.randn(Cout, Cin, k, k, generator=g) * 0.05).to(dev))
+    go = torch.randn(B, Cout, H, W, generator=g).to(dev)
+    bf16_mode()
+    assert kern.conv_direct_supported(Cin, Cout, k, 1, k // 2)
+    y = ops.conv2d_nchw(x, w, None, stride=1, pad=k // 2)
+    y.backward(go)
+    xr = x.detach().cpu().clone().requires_grad_(True)
+    wr = w.detach().cpu().clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, padding=k // 2)
+    ref.backward(go.cpu())
+    assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
+    assert _rel(x.grad.cpu(), xr.grad) < 2e-2
+    assert _rel(w.grad.cpu(), wr.grad) < 2e-2
