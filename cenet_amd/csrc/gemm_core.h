@@ -1,0 +1,530 @@
+// gemm_core.h — batched strided GEMM / implicit-GEMM convolution core on the gfx950 matrix cores (v3).
+//
+// One kernel family serves every dense contraction of the CENet hot path:
+//   * nn.Linear fwd/bwd in token layout                      (pvtv2.py:41,45,90,98,106; multihead_diffattn.py:79-81,126)
+//   * 1x1 convs in NCHW fwd/bwd                              (cfam.py:149,158,299,302; nlb.py:106-115,142; blocks.py:178,320; dseb.py:164)
+//   * dense k x k convs as implicit GEMM (fwd, dgrad, wgrad)  (pvtv2.py:164,67; unet.py:156-197; blocks.py:211)
+//   * materialised attention products for large head dims
+//
+// C[b] (+)= epilogue( alpha * sum_kb A[b,kb] (MxK) * B[b,kb] (KxN) )
+// A is a plain strided matrix; B is plain or an on-the-fly im2col / transposed-gather view of an image tensor; the
+// epilogue can scatter through a col2im map (data-gradient of strided convolutions).
+//
+// Structure (per 256-thread workgroup = 4 waves in a 2x2 grid, tile BM x BN, K step 32):
+//   * operands are read from HBM in whichever orientation is contiguous (kfast: 16-byte loads along k when alignment
+//     allows, else dwords; mfast: lane-contiguous dwords), one K-tile AHEAD into registers (software double buffering:
+//     the loads of tile t+1 fly under the MFMAs of tile t), then written k-contiguous into LDS;
+//   * fragments are fetched with 16-byte ds_read_b128: for fp32, lane (r = lane&15, q = lane>>4) owns k' = 8q..8q+7 and
+//     MFMA step s multiplies slot s of A with slot s of B (a permutation of the k order, which a sum does not care about);
+//   * OpT = float : v_mfma_f32_16x16x4_f32, exact fp32 FMA chain (parity mode)
+//     OpT = bf16  : operands rounded to bf16 when they enter LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulate;
+//   * SWAP: when C is row-major the MFMA is issued as (B-fragment, A-fragment) so a lane's four accumulator registers are
+//     four CONSECUTIVE COLUMNS of C and the epilogue moves 16 bytes per instruction (bias / residual / store);
+//   * im2col addressing never divides per element: forward/dgrad threads walk (kx,ky,ci) with carries, the
+//     weight-gradient view reads a per-workgroup LDS table of patch decompositions.
+#pragma once
+#include "common.h"
+#include "../../include/cenet_hip.h"
+
+struct GemmArgs {
+  cenet_mat_t A, B;
+  cenet_epi_t E;
+  int M, N, K, nkb, splits, nb_inner;
+  int avec, bvec, cvec;  // 16-byte global access is legal for A / B staging / the epilogue
+};
+
+__device__ __forceinline__ unsigned f2bf_bits(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return f2bf_bits(lo) | (f2bf_bits(hi) << 16); }
+
+template <typename OpT> struct OpTraits;
+template <> struct OpTraits<float> { static constexpr int PITCH = 36; };           // 144-byte rows
+template <> struct OpTraits<unsigned short> { static constexpr int PITCH = 40; };  // 80-byte rows
+#define BK 32
+
+struct KEntry {
+  int off;     // patch side: ci*sci
+  int dy, dx;  // patch side: ky*dil, kx*dil ; pixel side: py*stride-pad (or py+pad), px*stride-pad (or px+pad)
+};
+
+template <int KDIM>
+__device__ __forceinline__ long plain_off(const cenet_mat_t& d, int r, int c) {
+  if (d.kinner > 0) {
+    if (KDIM == 1) {
+      int ko = c / d.kinner, ki = c - ko * d.kinner;
+      return (long)r * d.sr + (long)ko * d.sk_outer + (long)ki * d.sc;
+    } else {
+      int ko = r / d.kinner, ki = r - ko * d.kinner;
+      return (long)ko * d.sk_outer + (long)ki * d.sr + (long)c * d.sc;
+    }
+  }
+  return (long)r * d.sr + (long)c * d.sc;
+}
+
+__device__ __forceinline__ KEntry im2col_entry(const cenet_mat_t& d, int idx, bool is_patch) {
+  KEntry e;
+  if (is_patch) {
+    int kk = d.KH * d.KW;
+    int ci = idx / kk;
+    int rem = idx - ci * kk;
+    int ky = rem / d.KW, kx = rem - ky * d.KW;
+    e.dy = ky * d.dil;
+    e.dx = kx * d.dil;
+    e.off = ci * (int)d.sci;
+  } else {
+    int py = idx / d.Pw, px = idx - py * d.Pw;
+    if (!d.transposed) {
+      e.dy = py * d.stride - d.pad;
+      e.dx = px * d.stride - d.pad;
+    } else {
+      e.dy = py + d.pad;
+      e.dx = px + d.pad;
+    }
+    e.off = 0;
+  }
+  return e;
+}
+
+__device__ __forceinline__ float im2col_load(const cenet_mat_t& d, const float* base, const KEntry& pat, const KEntry& pix) {
+  int iy, ix;
+  if (!d.transposed) {
+    iy = pix.dy + pat.dy;
+    ix = pix.dx + pat.dx;
+  } else {
+    int ty = pix.dy - pat.dy, tx = pix.dx - pat.dx;
+    if (ty < 0 || tx < 0) return 0.f;
+    if (d.stride == 1) {
+      iy = ty;
+      ix = tx;
+    } else {
+      iy = ty / d.stride;
+      ix = tx / d.stride;
+      if (iy * d.stride != ty || ix * d.stride != tx) return 0.f;
+    }
+  }
+  if (iy < 0 || iy >= d.Hs || ix < 0 || ix >= d.Ws) return 0.f;
+  return base[(long)pat.off + (long)iy * d.sy + (long)ix * d.sx];
+}
+
+// write NV consecutive-k values of one LDS row (NV multiple of 4)
+template <typename OpT, int NV>
+__device__ __forceinline__ void lds_put(OpT* dst, const float* v) {
+  if (sizeof(OpT) == 4) {
+#pragma unroll
+    for (int q = 0; q < NV / 4; ++q) memcpy((char*)dst + 16 * q, v + 4 * q, 16);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NV / 4; ++q) {
+      unsigned pk[2] = {pack_bf2(v[4 * q], v[4 * q + 1]), pack_bf2(v[4 * q + 2], v[4 * q + 3])};
+      memcpy((char*)dst + 8 * q, pk, 8);
+    }
+  }
+}
+template <typename OpT>
+__device__ __forceinline__ void lds_put1(OpT* dst, float v) {
+  if (sizeof(OpT) == 4) memcpy(dst, &v, 4);
+  else *dst = (OpT)f2bf_bits(v);
+}
+
+template <typename OpT, int BM, int BN, bool B_IM2COL, bool SWAP>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int P = OpTraits<OpT>::PITCH;
+  constexpr bool BF = (sizeof(OpT) == 2);
+  constexpr int MI = BM / 32, NJ = BN / 32;              // 16x16 tiles per wave in each direction
+  constexpr int NA = BM * BK / 256, NB = BN * BK / 256;  // prefetch registers per thread
+  __shared__ __attribute__((aligned(16))) OpT As[BM * P];
+  __shared__ __attribute__((aligned(16))) OpT Bs[BN * P];
+  __shared__ KEntry ntab[B_IM2COL ? BN : 1];
+  __shared__ float cstrip[SWAP ? 1 : 4 * 16 * (BN / 2 + 1)];  // per-wave epilogue strips (atomic split-K path)
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (linear id % 8, MI355X_MICROARCH.md "Workgroup
+  // dispatch"), so re-number them such that each XCD owns a contiguous range of tiles: neighbours along N re-read their
+  // A rows, and the tiles of one split-K chunk their operands, from that XCD's own L2.  Speed only, never correctness.
+  int bx, by, bz;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int T = gx * gy * (int)gridDim.z;
+    int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if (T >= 64) {
+      const int per = T >> 3, rem = T & 7, xcd = L & 7, idx = L >> 3;
+      L = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    }
+    bx = L % gx;
+    const int t = L / gx;
+    by = t % gy;
+    bz = t / gy;
+  }
+  const int batch = bz / g.splits, split = bz - batch * g.splits;
+  const int bo = batch / g.nb_inner, bi = batch - bo * g.nb_inner;
+  const int m0 = by * BM, n0 = bx * BN;
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int total = g.nkb * ktiles;
+  const int chunk = (total + g.splits - 1) / g.splits;
+  const int it0 = split * chunk;
+  const int it1 = (it0 + chunk < total) ? it0 + chunk : total;
+
+  // thread -> tile-element maps
+  //   kfast scalar : kk = tid % 32,  rows r = tid / 32 + 8 j
+  //   kfast vec    : k4 = tid % 8,   rows r = tid / 8 + 32 j   (4 consecutive k per register quad)
+  //   mfast        : row = tid % BMN, kq = tid / BMN ; k = kq * KPT + j  (KPT consecutive k per thread)
+  constexpr int A_KPT = BK / (256 / BM), B_KPT = BK / (256 / BN);
+  static_assert(BM <= 256 && BN <= 256 && NA % 4 == 0 && NB % 4 == 0, "unsupported tile");
+  float ra[NA], rb[NB];
+
+  KEntry nent;
+  nent.off = nent.dy = nent.dx = 0;
+  bool n_ok = true;
+  if (B_IM2COL) {
+    int ncol = g.B.kfast ? 0 : n0 + (tid % BN);
+    n_ok = ncol < g.N;
+    if (!g.B.kfast) nent = im2col_entry(g.B, n_ok ? ncol : 0, !g.B.patch_is_row);
+  }
+
+  auto fetch = [&](int it) __attribute__((always_inline)) {
+    const int kb = it / ktiles;
+    const int k0 = (it - kb * ktiles) * BK;
+    const float* baseA = g.A.ptr + (long)bo * g.A.sb + (long)bi * g.A.sb2 + (long)kb * g.A.skb;
+    const float* baseB = g.B.ptr + (long)bo * g.B.sb + (long)bi * g.B.sb2 + (long)kb * g.B.skb;
+    if (g.A.kfast) {
+      if (g.avec) {
+        const int k4 = (tid & 7) * 4, r0 = tid >> 3;
+#pragma unroll
+        for (int j = 0; j < NA / 4; ++j) {
+          int row = r0 + j * 32;
+          if (m0 + row < g.M && k0 + k4 < g.K) memcpy(&ra[4 * j], baseA + (long)(m0 + row) * g.A.sr + k0 + k4, 16);
+          else ra[4 * j] = ra[4 * j + 1] = ra[4 * j + 2] = ra[4 * j + 3] = 0.f;
+        }
+      } else {
+        const int kk = tid & 31, r0 = tid >> 5;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          int row = r0 + j * 8;
+          ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? baseA[plain_off<1>(g.A, m0 + row, k0 + kk)] : 0.f;
+        }
+      }
+    } else {
+      const int row = tid % BM, kq = tid / BM;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        int kk = kq * A_KPT + j;
+        ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? baseA[plain_off<1>(g.A, m0 + row, k0 + kk)] : 0.f;
+      }
+    }
+    if (!B_IM2COL) {
+      if (g.B.kfast) {
+        if (g.bvec) {
+          const int k4 = (tid & 7) * 4, c0 = tid >> 3;
+#pragma unroll
+          for (int j = 0; j < NB / 4; ++j) {
+            int col = c0 + j * 32;
+            if (n0 + col < g.N && k0 + k4 < g.K) memcpy(&rb[4 * j], baseB + (long)(n0 + col) * g.B.sc + k0 + k4, 16);
+            else rb[4 * j] = rb[4 * j + 1] = rb[4 * j + 2] = rb[4 * j + 3] = 0.f;
+          }
+        } else {
+          const int kk = tid & 31, c0 = tid >> 5;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            int col = c0 + j * 8;
+            rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? baseB[plain_off<0>(g.B, k0 + kk, n0 + col)] : 0.f;
+          }
+        }
+      } else {
+        const int col = tid % BN, kq = tid / BN;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          int kk = kq * B_KPT + j;
+          rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? baseB[plain_off<0>(g.B, k0 + kk, n0 + col)] : 0.f;
+        }
+      }
+    } else {
+      const cenet_mat_t& d = g.B;
+      if (d.kfast) {
+        // weight-gradient view: this thread's k is ONE pixel of the tile, its NB columns are patch elements whose
+        // (ci,ky,kx) decomposition sits in the per-workgroup LDS table ntab (n0 is fixed for the workgroup)
+        const int kk = tid & 31, c0 = tid >> 5;
+        const bool kok = k0 + kk < g.K;
+        const KEntry pe = im2col_entry(d, kok ? k0 + kk : 0, false);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          int col = c0 + j * 8;
+          float v = 0.f;
+          if (kok && n0 + col < g.N) v = im2col_load(d, baseB, ntab[col], pe);
+          rb[j] = v;
+        }
+      } else {
+        // forward / data-gradient view: this thread owns ONE pixel (nent) and B_KPT consecutive patch indices; walk
+        // (kx,ky,ci) with carries instead of decomposing every index
+        const int kq = tid / BN;
+        int e = k0 + kq * B_KPT;
+        const int kkw = d.KH * d.KW;
+        int ci = e / kkw;
+        int rem = e - ci * kkw;
+        int ky = rem / d.KW, kx = rem - ky * d.KW;
+        const bool fast = !(d.transposed && d.stride != 1);
+        if (fast) {
+          const int sg = d.transposed ? -1 : 1;
+          const int dsx = sg * d.dil * (int)d.sx, dsy = sg * d.dil * (int)d.sy, dd = sg * d.dil;
+          int iy = nent.dy + sg * ky * d.dil, ix = nent.dx + sg * kx * d.dil;
+          int off = ci * (int)d.sci + iy * (int)d.sy + ix * (int)d.sx;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const bool ok = n_ok && (e + j < g.K) && iy >= 0 && iy < d.Hs && ix >= 0 && ix < d.Ws;
+            rb[j] = ok ? baseB[off] : 0.f;
+            ++kx; ix += dd; off += dsx;
+            if (kx == d.KW) {
+              kx = 0; ix -= d.KW * dd; off -= d.KW * dsx;
+              ++ky; iy += dd; off += dsy;
+              if (ky == d.KH) {
+                ky = 0; iy -= d.KH * dd; off += (int)d.sci - d.KH * dsy;
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            float v = 0.f;
+            if (n_ok && e + j < g.K) v = im2col_load(d, baseB, im2col_entry(d, e + j, true), nent);
+            rb[j] = v;
+          }
+        }
+      }
+    }
+  };
+
+  auto store_lds = [&]() __attribute__((always_inline)) {
+    if (g.A.kfast) {
+      if (g.avec) {
+        const int k4 = (tid & 7) * 4, r0 = tid >> 3;
+#pragma unroll
+        for (int j = 0; j < NA / 4; ++j) lds_put<OpT, 4>(&As[(r0 + j * 32) * P + k4], &ra[4 * j]);
+      } else {
+        const int kk = tid & 31, r0 = tid >> 5;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) lds_put1<OpT>(&As[(r0 + j * 8) * P + kk], ra[j]);
+      }
+    } else {
+      const int row = tid % BM, kq = tid / BM;
+      lds_put<OpT, NA>(&As[row * P + kq * A_KPT], ra);
+    }
+    if (g.B.kfast) {
+      if (!B_IM2COL && g.bvec) {
+        const int k4 = (tid & 7) * 4, c0 = tid >> 3;
+#pragma unroll
+        for (int j = 0; j < NB / 4; ++j) lds_put<OpT, 4>(&Bs[(c0 + j * 32) * P + k4], &rb[4 * j]);
+      } else {
+        const int kk = tid & 31, c0 = tid >> 5;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) lds_put1<OpT>(&Bs[(c0 + j * 8) * P + kk], rb[j]);
+      }
+    } else {
+      const int col = tid % BN, kq = tid / BN;
+      lds_put<OpT, NB>(&Bs[col * P + kq * B_KPT], rb);
+    }
+  };
+
+  if (B_IM2COL && g.B.kfast) {
+    for (int c = tid; c < BN; c += 256) ntab[c] = im2col_entry(g.B, n0 + c < g.N ? n0 + c : 0, true);
+    __syncthreads();
+  }
+  if (it0 < it1) fetch(it0);
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int it = it0; it < it1; ++it) {
+    store_lds();
+    __syncthreads();
+    if (it + 1 < it1) fetch(it + 1);  // next tile's HBM loads fly under this tile's MFMAs
+    if (!BF) {
+      // lane owns k' = 8*fq .. 8*fq+7 ; step s pairs slot s of A with slot s of B
+      float a[MI][8];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) memcpy(a[i], &As[(wm * (BM / 2) + i * 16 + fr) * P + fq * 8], 32);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float b[8];
+        memcpy(b, &Bs[(wn * (BN / 2) + j * 16 + fr) * P + fq * 8], 32);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(b[s], a[i][s], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[s], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      bf16x8 a[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) memcpy(&a[i], &As[(wm * (BM / 2) + i * 16 + fr) * P + fq * 8], 16);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        bf16x8 b;
+        memcpy(&b, &Bs[(wn * (BN / 2) + j * 16 + fr) * P + fq * 8], 16);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  // !SWAP: acc[i][j][r] = C[row = .. + fq*4 + r][col = .. + fr]   (4 consecutive rows per lane)
+  //  SWAP: acc[i][j][r] = C[row = .. + fr][col = .. + fq*4 + r]   (4 consecutive columns per lane)
+  const cenet_epi_t& E = g.E;
+  float* Cb = E.C + (long)bo * E.scb + (long)bi * E.scb2;
+  if (!SWAP && E.atomic && !E.cmode && E.scc == 1) {
+    // split-K accumulation into a row-major C: float atomics reach their chip-wide rate only as 256 contiguous bytes per
+    // wave instruction, but an MFMA accumulator register spans 4 rows x 16 floats.  Each wave therefore transposes one
+    // 16-row strip at a time through a private LDS strip and issues the atomics with lane = column.
+    constexpr int WN = BN / 2;
+    float* strip = cstrip + wave * (16 * (WN + 1));
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) strip[(fq * 4 + r) * (WN + 1) + j * 16 + fr] = acc[i][j][r] * E.alpha;
+      __syncthreads();
+      const int row0 = m0 + wm * (BM / 2) + i * 16, col0 = n0 + wn * WN;
+      for (int idx = lane; idx < 16 * WN; idx += 64) {
+        const int r = idx / WN, c = idx - r * WN;
+        if (row0 + r < g.M && col0 + c < g.N) atomicAdd(&Cb[(long)(row0 + r) * E.scr + col0 + c], strip[r * (WN + 1) + c]);
+      }
+    }
+    return;
+  }
+  const float* Rb = E.R ? E.R + (long)bo * E.srb + (long)bi * E.srb2 : nullptr;
+  const float bs = E.bscale ? E.bscale[batch] : 1.f;
+  const int rwave = m0 + wm * (BM / 2) + (SWAP ? fr : fq * 4);
+  const int cwave = n0 + wn * (BN / 2) + (SWAP ? fq * 4 : fr);
+  if (g.cvec && !E.atomic && !E.cmode && E.act == ACT_NONE) {
+    // common case (plain store, optional bias / per-batch scale / residual), 16 bytes per lane and fragment.  This loop
+    // nest MUST stay small enough to unroll fully: if it does not, acc[][] is indexed dynamically, lives in scratch
+    // memory and is spilled there on every K step.
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int rbase = rwave + i * 16, cbase = cwave + j * 16;
+        const bool full = SWAP ? (rbase < g.M && cbase + 3 < g.N) : (rbase + 3 < g.M && cbase < g.N);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * E.alpha;
+        if (full) {
+          if (E.bias) {
+            if (SWAP != (bool)E.bias_on_row && ((uintptr_t)E.bias & 15) == 0) {  // bias index runs along the lane's 4 elements
+              float bb[4];
+              memcpy(bb, E.bias + (SWAP ? cbase : rbase), 16);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bb[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += E.bias[E.bias_on_row ? (SWAP ? rbase : rbase + r) : (SWAP ? cbase + r : cbase)];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= bs;
+          if (Rb) {
+            float rr[4];
+            memcpy(rr, Rb + (long)rbase * E.srr + (long)cbase * E.src, 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+          }
+          memcpy(Cb + (long)rbase * E.scr + (long)cbase * E.scc, v, 16);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = SWAP ? rbase : rbase + r, col = SWAP ? cbase + r : cbase;
+            if (row < g.M && col < g.N) {
+              float t = v[r];
+              if (E.bias) t += E.bias[E.bias_on_row ? row : col];
+              t *= bs;
+              if (Rb) t += Rb[(long)row * E.srr + (long)col * E.src];
+              Cb[(long)row * E.scr + (long)col * E.scc] = t;
+            }
+          }
+        }
+      }
+    return;
+  }
+  // everything else (activations, col2im scatter, strided atomics, unaligned C): a RUNTIME loop over the fragments; the
+  // fragment is picked with a chain of selects on static indices so that acc[][] stays in registers
+  for (int f = 0; f < MI * NJ; ++f) {
+    f32x4 t4 = acc[0][0];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (f == i * NJ + j) t4 = acc[i][j];
+    const int rbase = rwave + (f / NJ) * 16, cbase = cwave + (f % NJ) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = SWAP ? rbase : rbase + r, col = SWAP ? cbase + r : cbase;
+      if (row < g.M && col < g.N) {
+        float v = t4[r] * E.alpha;
+        if (E.cmode) {  // col2im scatter: row = (ci,ky,kx), col = (py,px)
+          const int kkw = E.cKH * E.cKW;
+          const int ci = row / kkw, rem = row - ci * kkw;
+          const int ky = rem / E.cKW, kx = rem - ky * E.cKW;
+          const int py = col / E.cPw, px = col - py * E.cPw;
+          const int iy = py * E.cstride - E.cpad + ky, ix = px * E.cstride - E.cpad + kx;
+          if (iy >= 0 && iy < E.cHs && ix >= 0 && ix < E.cWs) {
+            float* dst = &Cb[(long)ci * E.csci + (long)iy * E.csy + (long)ix * E.csx];
+            if (E.atomic) atomicAdd(dst, v);
+            else *dst = v;
+          }
+        } else if (E.atomic) {
+          atomicAdd(&Cb[(long)row * E.scr + (long)col * E.scc], v);
+        } else {
+          if (E.bias) v += E.bias[E.bias_on_row ? row : col];
+          v = act_fwd(E.act, v, E.slope);
+          v *= bs;
+          if (Rb) v += Rb[(long)row * E.srr + (long)col * E.src];
+          Cb[(long)row * E.scr + (long)col * E.scc] = v;
+        }
+      }
+    }
+  }
+}
+
+template <typename OpT, bool IM, bool SWAP>
+static int launch_tile(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_t stream) {
+  dim3 grid(cdiv(g.N, bn), cdiv(g.M, bm), nbatch * g.splits);
+  if (grid.y > 65535 || grid.z > 65535) return CENET_EUNSUPPORTED;
+#define CENET_TILE(BMv, BNv)                                                                   \
+  if (bm == BMv && bn == BNv) {                                                                \
+    CENET_LAUNCH((gemm_kernel<OpT, BMv, BNv, IM, SWAP>), grid, dim3(256), stream, g);          \
+    return CENET_OK;                                                                           \
+  }
+  CENET_TILE(128, 128)
+  CENET_TILE(128, 64)
+  CENET_TILE(64, 128)
+  CENET_TILE(64, 64)
+  CENET_TILE(32, 256)
+  CENET_TILE(32, 64)
+#undef CENET_TILE
+  return CENET_EUNSUPPORTED;
+}
+
+
+// one translation unit per (operand type, B view): gemm_inst_*.hip
+#define CENET_GEMM_INSTANCE(NAME, T, IM)                                                                     \
+  int NAME(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream) {                   \
+    return swap ? launch_tile<T, IM, true>(g, bm, bn, nbatch, stream) : launch_tile<T, IM, false>(g, bm, bn, nbatch, stream); \
+  }
+int cenet_gemm_launch_f32_plain(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
+int cenet_gemm_launch_f32_im2col(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
+int cenet_gemm_launch_bf16_plain(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
+int cenet_gemm_launch_bf16_im2col(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
