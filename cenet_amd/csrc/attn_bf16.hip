@@ -27,12 +27,7 @@ struct AttnArgsB {
   float scale;
 };
 
-__device__ __forceinline__ bf f2bf(float f) {
-  unsigned u;
-  memcpy(&u, &f, 4);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (bf)(u >> 16);
-}
+__device__ __forceinline__ bf f2bf(float f) { return (bf)cenet_f2bf(f); }
 
 // Register prefetch of a [64 x COLS] fp32 tile; store() writes bf16 [row][col] (pitch p) and, if dstT, [col][row] (pitch pT)
 template <int COLS>

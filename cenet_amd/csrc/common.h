@@ -21,6 +21,27 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 #define CENET_WAVE 64
 
+// fp32 -> bf16, round to nearest even.  gfx950 converts two floats per instruction (v_cvt_pk_bf16_f32); the host-side
+// checker build uses the equivalent integer rounding.
+#ifdef CENET_HOSTSIM_BUILD
+__device__ __forceinline__ unsigned cenet_f2bf(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ unsigned cenet_pack_bf2(float lo, float hi) { return cenet_f2bf(lo) | (cenet_f2bf(hi) << 16); }
+#else
+typedef __bf16 cenet_bf2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cenet_pack_bf2(float lo, float hi) {
+  cenet_bf2_t v = {(__bf16)lo, (__bf16)hi};
+  unsigned u;
+  memcpy(&u, &v, 4);
+  return u;
+}
+__device__ __forceinline__ unsigned cenet_f2bf(float f) { return cenet_pack_bf2(f, 0.f) & 0xFFFFu; }
+#endif
+
 #define CENET_CHECK_LAUNCH()                         \
   do {                                               \
     hipError_t e__ = hipGetLastError();              \

@@ -21,12 +21,7 @@
 #define TW 32
 typedef unsigned short bf;
 
-__device__ __forceinline__ unsigned cd_f2bf(float f) {
-  unsigned u;
-  memcpy(&u, &f, 4);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+__device__ __forceinline__ unsigned cd_f2bf(float f) { return cenet_f2bf(f); }
 
 struct ConvDirectArgs {
   const float* x;   // [B, CIN, H, W]
@@ -87,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_direct_bf16_kernel(ConvDirectArgs a)
       if (s < UNITS) {
         unsigned pk[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk[j] = cd_f2bf(pre[u][2 * j]) | (cd_f2bf(pre[u][2 * j + 1]) << 16);
+        for (int j = 0; j < 4; ++j) pk[j] = cenet_pack_bf2(pre[u][2 * j], pre[u][2 * j + 1]);
         memcpy(&Xs[s * 8], pk, 16);
       }
     }

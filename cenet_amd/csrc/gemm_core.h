@@ -33,13 +33,8 @@ struct GemmArgs {
   int avec, bvec, cvec;  // 16-byte global access is legal for A / B staging / the epilogue
 };
 
-__device__ __forceinline__ unsigned f2bf_bits(float f) {
-  unsigned u;
-  memcpy(&u, &f, 4);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
-__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return f2bf_bits(lo) | (f2bf_bits(hi) << 16); }
+__device__ __forceinline__ unsigned f2bf_bits(float f) { return cenet_f2bf(f); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return cenet_pack_bf2(lo, hi); }
 
 template <typename OpT> struct OpTraits;
 template <> struct OpTraits<float> { static constexpr int PITCH = 36; };           // 144-byte rows
@@ -130,6 +125,73 @@ __device__ __forceinline__ void lds_put1(OpT* dst, float v) {
   else *dst = (OpT)f2bf_bits(v);
 }
 
+
+// Staging geometry of one PLAIN operand, hoisted out of the K loop: a thread's registers walk either the operand's rows
+// (k-contiguous forms) or its k index (row-contiguous form) with a constant element stride, so the loop only adds.
+struct PlainStage {
+  long toff;    // thread's element offset inside a K tile (relative to the tile origin at row 0, k0)
+  long dj;      // element stride between consecutive registers (register quads for the 16-byte form)
+  unsigned ok;  // bit j: register j's row lies inside the matrix (k-contiguous forms); bit 0: the thread's row does
+  int kk;       // k index inside the tile of register 0
+};
+
+// rs / ks: element strides along the operand's row (M or N) index and along k; x0 / X: tile origin and matrix extent
+template <int BX, int NX>
+__device__ __forceinline__ PlainStage plain_stage(long rs, long ks, int kfast, int vec, int x0, int X, int tid) {
+  PlainStage s;
+  s.ok = 0;
+  if (kfast) {
+    const int rstep = vec ? 32 : 8, r0 = vec ? (tid >> 3) : (tid >> 5);
+    s.kk = vec ? (tid & 7) * 4 : (tid & 31);
+    s.toff = (long)(x0 + r0) * rs + (long)s.kk * ks;
+    s.dj = (long)rstep * rs;
+    const int nreg = vec ? NX / 4 : NX;
+    for (int j = 0; j < nreg; ++j)
+      if (x0 + r0 + j * rstep < X) s.ok |= 1u << j;
+  } else {
+    const int row = tid % BX, kq = tid / BX;
+    s.kk = kq * NX;  // NX == BK / (256 / BX) consecutive k per thread
+    s.toff = (long)(x0 + row) * rs + (long)s.kk * ks;
+    s.dj = ks;
+    s.ok = (x0 + row < X) ? 1u : 0u;
+  }
+  return s;
+}
+
+// tile = operand base of this batch / K-batch advanced to k0; klim = K - k0; interior: whole BX x BK tile inside the matrix
+template <int NX>
+__device__ __forceinline__ void plain_fetch(const PlainStage& s, const float* tile, int klim, int kfast, int vec,
+                                            bool interior, float* r) {
+  const float* p = tile + s.toff;
+  if (interior) {
+    if (kfast && vec) {
+#pragma unroll
+      for (int j = 0; j < NX / 4; ++j, p += s.dj) memcpy(&r[4 * j], p, 16);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NX; ++j, p += s.dj) r[j] = *p;
+    }
+    return;
+  }
+  if (kfast) {
+    const bool kok = s.kk < klim;
+    if (vec) {
+#pragma unroll
+      for (int j = 0; j < NX / 4; ++j, p += s.dj) {
+        if (kok && ((s.ok >> j) & 1u)) memcpy(&r[4 * j], p, 16);
+        else r[4 * j] = r[4 * j + 1] = r[4 * j + 2] = r[4 * j + 3] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NX; ++j, p += s.dj) r[j] = (kok && ((s.ok >> j) & 1u)) ? *p : 0.f;
+    }
+  } else {
+    const int lim = (s.ok & 1u) ? klim - s.kk : 0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j, p += s.dj) r[j] = (j < lim) ? *p : 0.f;
+  }
+}
+
 template <typename OpT, int BM, int BN, bool B_IM2COL, bool SWAP>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int P = OpTraits<OpT>::PITCH;
@@ -183,6 +245,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int A_KPT = BK / (256 / BM), B_KPT = BK / (256 / BN);
   static_assert(BM <= 256 && BN <= 256 && NA % 4 == 0 && NB % 4 == 0, "unsupported tile");
   float ra[NA], rb[NB];
+  // plain operands without the (ko,ki) split of k use hoisted pointer walks; the split form keeps per-element addressing
+  const bool a_fast = g.A.kinner == 0, b_fast = !B_IM2COL && g.B.kinner == 0;
+  const PlainStage sa = plain_stage<BM, NA>(g.A.sr, g.A.sc, g.A.kfast, g.avec, m0, g.M, tid);
+  const PlainStage sb = plain_stage<BN, NB>(g.B.sc, g.B.sr, g.B.kfast, g.bvec, n0, g.N, tid);
+  const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
 
   KEntry nent;
   nent.off = nent.dy = nent.dx = 0;
@@ -198,22 +265,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int k0 = (it - kb * ktiles) * BK;
     const float* baseA = g.A.ptr + (long)bo * g.A.sb + (long)bi * g.A.sb2 + (long)kb * g.A.skb;
     const float* baseB = g.B.ptr + (long)bo * g.B.sb + (long)bi * g.B.sb2 + (long)kb * g.B.skb;
-    if (g.A.kfast) {
-      if (g.avec) {
-        const int k4 = (tid & 7) * 4, r0 = tid >> 3;
+    const int klim = g.K - k0;
+    if (a_fast) {
+      plain_fetch<NA>(sa, baseA + (long)k0 * g.A.sc, klim, g.A.kfast, g.avec, a_in && klim >= BK, ra);
+    } else if (g.A.kfast) {
+      const int kk = tid & 31, r0 = tid >> 5;
 #pragma unroll
-        for (int j = 0; j < NA / 4; ++j) {
-          int row = r0 + j * 32;
-          if (m0 + row < g.M && k0 + k4 < g.K) memcpy(&ra[4 * j], baseA + (long)(m0 + row) * g.A.sr + k0 + k4, 16);
-          else ra[4 * j] = ra[4 * j + 1] = ra[4 * j + 2] = ra[4 * j + 3] = 0.f;
-        }
-      } else {
-        const int kk = tid & 31, r0 = tid >> 5;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-          int row = r0 + j * 8;
-          ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? baseA[plain_off<1>(g.A, m0 + row, k0 + kk)] : 0.f;
-        }
+      for (int j = 0; j < NA; ++j) {
+        int row = r0 + j * 8;
+        ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? baseA[plain_off<1>(g.A, m0 + row, k0 + kk)] : 0.f;
       }
     } else {
       const int row = tid % BM, kq = tid / BM;
@@ -224,22 +284,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       }
     }
     if (!B_IM2COL) {
-      if (g.B.kfast) {
-        if (g.bvec) {
-          const int k4 = (tid & 7) * 4, c0 = tid >> 3;
+      if (b_fast) {
+        plain_fetch<NB>(sb, baseB + (long)k0 * g.B.sr, klim, g.B.kfast, g.bvec, b_in && klim >= BK, rb);
+      } else if (g.B.kfast) {
+        const int kk = tid & 31, c0 = tid >> 5;
 #pragma unroll
-          for (int j = 0; j < NB / 4; ++j) {
-            int col = c0 + j * 32;
-            if (n0 + col < g.N && k0 + k4 < g.K) memcpy(&rb[4 * j], baseB + (long)(n0 + col) * g.B.sc + k0 + k4, 16);
-            else rb[4 * j] = rb[4 * j + 1] = rb[4 * j + 2] = rb[4 * j + 3] = 0.f;
-          }
-        } else {
-          const int kk = tid & 31, c0 = tid >> 5;
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            int col = c0 + j * 8;
-            rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? baseB[plain_off<0>(g.B, k0 + kk, n0 + col)] : 0.f;
-          }
+        for (int j = 0; j < NB; ++j) {
+          int col = c0 + j * 8;
+          rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? baseB[plain_off<0>(g.B, k0 + kk, n0 + col)] : 0.f;
         }
       } else {
         const int col = tid % BN, kq = tid / BN;
