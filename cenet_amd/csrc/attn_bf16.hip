@@ -1,18 +1,29 @@
-// attn_bf16.hip — bf16-operand variant of the tiled attention kernels of attn.hip (throughput mode).
+// attn_bf16.hip — bf16-operand tiled attention (throughput mode), register-resident probabilities.
 //
-// Same algorithm, same generic strides, same fp32 HBM tensors, same fp32 online softmax / LSE / delta / accumulators;
-// only the MFMA operands are rounded to bf16 on their way into LDS and every product is put in the form
-//     C[16 x 16t] += A[rows, k] . B[cols, k]^T      (BOTH operands k-contiguous in LDS)
-// so that each fragment is one 16-byte ds_read_b128 feeding v_mfma_f32_16x16x32_bf16.  Tiles that are contracted over
-// their row index elsewhere (V in P.V, K in dS.K, Q and dO in the dK/dV products) are written to LDS twice from the
-// prefetch registers: as staged and transposed.  Reference sites: pvtv2.py:101-105, nlb.py:117-138,
-// multihead_diffattn.py:96-116.
+// Same contract as attn.hip (generic strides, fp32 HBM tensors, fp32 online softmax / LSE / delta / accumulators); the
+// MFMA operands are rounded to bf16.  Reference sites: pvtv2.py:101-105, nlb.py:117-138, multihead_diffattn.py:96-116.
+//
+// Layout idea (v_mfma_f32_16x16x32_bf16: lane (fr = lane&15, fq = lane>>4) supplies A[row fr][k 8fq..8fq+7] and
+// B[k 8fq..8fq+7][col fr], and receives D[row 4fq+r][col fr], r = 0..3):
+//   * every score tile is computed TRANSPOSED with respect to the operand that stays fixed for the whole K loop, so the
+//     fixed side (queries in fwd / dQ, keys in dK/dV) is the MFMA column: one lane = one query (key), its softmax
+//     state (running max, sum, lse, delta) is a per-lane scalar, and row reductions are 16 in-lane values + 2 shuffles;
+//   * the probabilities / dS a lane holds (4 rows of two adjacent 16-row tiles = 8 values) are exactly one B fragment
+//     of the next product if that product's k index is enumerated in the same permuted order:
+//         k slot (fq, s)  <->  row 32c + 16 (s >> 2) + 4 fq + (s & 3)
+//     so P / dS never go through LDS; the other operand is read with two 8-byte LDS loads at rows 32c+4fq and
+//     32c+16+4fq of a [feature][row] (transposed) copy of the streamed tile;
+//   * the fixed side's own fragments (Q^T, dO^T or K^T, V^T) are loaded once from HBM into registers;
+//   * the streamed tiles are register-prefetched one tile ahead and double-buffered in LDS (one barrier per tile);
+//   * exponentials are v_exp_f32 (base 2): log2(e) is folded into the query scaling.
 #include "common.h"
 #include "../../include/cenet_hip.h"
 
-#define TQ 64
 #define TK 64
 #define NEG_BIG (-1.0e30f)
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define PT 72  // pitch (elements) of [feature][64 rows] transposed tiles: 144-byte rows
 typedef unsigned short bf;
 
 struct AttnArgsB {
@@ -23,356 +34,600 @@ struct AttnArgsB {
   float *dq, *dk, *dv, *delta;
   long qsb, qsh, qsi, qsd, ksb, ksh, ksi, ksd, vsb, vsh, vsi, vsd, osb, osh, osi, osd;
   int B, H, Nq, Nk, D, Dv, v_head_div;
-  int q_dfast, k_dfast, v_dfast, o_dfast, dv_atomic;
+  int q_al, k_al, v_al, o_al;  // every stride a multiple of 4 floats and the base 16-byte aligned
+  int dv_atomic, qsplit, tiles_per_split;
   float scale;
 };
 
-__device__ __forceinline__ bf f2bf(float f) { return (bf)cenet_f2bf(f); }
+#ifdef CENET_HOSTSIM_BUILD
+__device__ __forceinline__ float fast_exp2(float x) { return exp2f(x); }
+#else
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 
-// Register prefetch of a [64 x COLS] fp32 tile; store() writes bf16 [row][col] (pitch p) and, if dstT, [col][row] (pitch pT)
-template <int COLS>
-struct TileB {
-  float r[64 * COLS / 256];
-  __device__ __forceinline__ void load(const float* src, long s_row, long s_col, int row0, int nrows, int cols, int dfast) {
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  unsigned u[4] = {cenet_pack_bf2(v[0], v[1]), cenet_pack_bf2(v[2], v[3]), cenet_pack_bf2(v[4], v[5]),
+                   cenet_pack_bf2(v[6], v[7])};
+  bf16x8 o;
+  memcpy(&o, u, 16);
+  return o;
+}
+// B fragment from two adjacent accumulator tiles (rows 4fq+r of tile 2c and of tile 2c+1)
+__device__ __forceinline__ bf16x8 pack_tiles(const f32x4& lo, const f32x4& hi) {
+  unsigned u[4] = {cenet_pack_bf2(lo[0], lo[1]), cenet_pack_bf2(lo[2], lo[3]), cenet_pack_bf2(hi[0], hi[1]),
+                   cenet_pack_bf2(hi[2], hi[3])};
+  bf16x8 o;
+  memcpy(&o, u, 16);
+  return o;
+}
+// A fragment in the permuted k order from a transposed tile T[feature][row]: rows 32c+4fq..+3 and 32c+16+4fq..+3
+__device__ __forceinline__ bf16x8 frag_perm(const bf* T, int feature, int c, int fq) {
+  bf16x8 o;
+  const bf* p = T + feature * PT + 32 * c + 4 * fq;
+  memcpy(&o, p, 8);
+  memcpy((char*)&o + 8, p + 16, 8);
+  return o;
+}
+__device__ __forceinline__ bf16x8 frag_rm(const bf* T, int pitch, int row, int c, int fq) {
+  bf16x8 o;
+  memcpy(&o, T + row * pitch + 32 * c + 8 * fq, 16);
+  return o;
+}
+// fixed-side fragment straight from HBM: X[row][32c + 8fq .. +7] * mul, zero outside [0,nrows) x [0,cols)
+__device__ __forceinline__ bf16x8 frag_global(const float* x, long s_row, long s_col, int row, int nrows, int c, int fq,
+                                              int cols, float mul, int al) {
+  float v[8];
+  const int c0 = 32 * c + 8 * fq;
+  if (row < nrows && s_col == 1 && al && c0 + 7 < cols) {
+    memcpy(v, x + (long)row * s_row + c0, 32);
 #pragma unroll
-    for (int j = 0; j < 64 * COLS / 256; ++j) {
-      const int idx = threadIdx.x + 256 * j;
-      int rr, c;
-      if (dfast) {
-        rr = idx / COLS;
-        c = idx - rr * COLS;
-      } else {
-        c = idx >> 6;
-        rr = idx & 63;
-      }
-      r[j] = (row0 + rr < nrows && c < cols) ? src[(long)(row0 + rr) * s_row + (long)c * s_col] : 0.f;
+    for (int e = 0; e < 8; ++e) v[e] *= mul;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (row < nrows && c0 + e < cols) ? x[(long)row * s_row + (long)(c0 + e) * s_col] * mul : 0.f;
+  }
+  return pack8(v);
+}
+
+// Register prefetch of a streamed [64 rows x COLS] fp32 tile and its conversion into LDS as bf16, row-major
+// dst_rm[row][col] and / or transposed dst_tr[col][row].  A thread owns groups of 4 elements along the axis that is
+// contiguous in the LDS copy it must write packed (8-byte stores); the other copy, if wanted, gets 2-byte stores.
+template <int COLS>
+struct StageT {
+  static constexpr int NG = 64 * COLS / 1024;
+  float r[NG][4];
+  int own_cols, rowadj, vec;
+  __device__ __forceinline__ void setup(long s_row, long s_col, bool need_rm, bool need_tr, int aligned) {
+    if (s_col == 1) {
+      own_cols = need_rm;
+      rowadj = 0;
+      vec = own_cols && aligned;
+    } else if (s_row == 1) {
+      own_cols = !need_tr;
+      rowadj = 1;
+      vec = !own_cols && aligned;
+    } else {
+      own_cols = need_rm;
+      rowadj = 0;
+      vec = 0;
     }
   }
-  __device__ __forceinline__ void store(bf* dst, int p, bf* dstT, int pT, int dfast) const {
-#pragma unroll
-    for (int j = 0; j < 64 * COLS / 256; ++j) {
-      const int idx = threadIdx.x + 256 * j;
-      int rr, c;
-      if (dfast) {
-        rr = idx / COLS;
-        c = idx - rr * COLS;
+  __device__ __forceinline__ void coords(int g, int& row, int& col) const {
+    if (own_cols) {
+      if (!rowadj) {
+        row = g / (COLS / 4);
+        col = (g - row * (COLS / 4)) * 4;
       } else {
-        c = idx >> 6;
-        rr = idx & 63;
+        row = g & 63;
+        col = (g >> 6) * 4;
       }
-      const bf v = f2bf(r[j]);
-      if (dst) dst[rr * p + c] = v;
-      if (dstT) dstT[c * pT + rr] = v;
+    } else {
+      if (!rowadj) {
+        col = g % COLS;
+        row = (g / COLS) * 4;
+      } else {
+        row = (g & 15) * 4;
+        col = g >> 4;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(const float* src, long s_row, long s_col, int row0, int nrows, int cols) {
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      int row, col;
+      coords(threadIdx.x + 256 * j, row, col);
+      const long dr = own_cols ? 0 : s_row, dc = own_cols ? s_col : 0;
+      const int er = own_cols ? 0 : 1, ec = own_cols ? 1 : 0;
+      const float* p = src + (long)(row0 + row) * s_row + (long)col * s_col;
+      if (vec && row0 + row + 3 * er < nrows && col + 3 * ec < cols) {
+        memcpy(r[j], p, 16);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          r[j][e] = (row0 + row + e * er < nrows && col + e * ec < cols) ? p[e * (dr + dc)] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(bf* dst_rm, int p_rm, bf* dst_tr, float mul) const {
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      int row, col;
+      coords(threadIdx.x + 256 * j, row, col);
+      const unsigned pk[2] = {cenet_pack_bf2(r[j][0] * mul, r[j][1] * mul), cenet_pack_bf2(r[j][2] * mul, r[j][3] * mul)};
+      if (own_cols) {
+        if (dst_rm) memcpy(dst_rm + row * p_rm + col, pk, 8);
+        if (dst_tr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst_tr[(col + e) * PT + row] = (bf)((pk[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+        }
+      } else {
+        if (dst_tr) memcpy(dst_tr + col * PT + row, pk, 8);
+        if (dst_rm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst_rm[(row + e) * p_rm + col] = (bf)((pk[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+        }
+      }
     }
   }
 };
 
-// acc[t] += A[arow0 + (lane&15)][k] * B[16t + (lane&15)][k], k in [0, kdim), kdim % 32 == 0; 16-byte fragment reads
-template <int NT>
-__device__ __forceinline__ void mma_kc(f32x4 acc[NT], const bf* As, int pa, int arow0, const bf* Bs, int pb, int kdim, int lane) {
-  const int fr = lane & 15, fq = lane >> 4;
-  for (int k0 = 0; k0 < kdim; k0 += 32) {
-    bf16x8 a;
-    memcpy(&a, &As[(arow0 + fr) * pa + k0 + fq * 8], 16);
+__device__ __forceinline__ float quad_sum(float v) {  // over the 4 lanes that share fr (fq = 0..3)
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+
+// write 4 consecutive features (f0..f0+3) of one row
+__device__ __forceinline__ void put4(float* base, long s_row, long s_col, int row, int f0, int nf, const float* v, int al,
+                                     bool atomic) {
+  float* p = base + (long)row * s_row + (long)f0 * s_col;
+  if (atomic) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      bf16x8 b;
-      memcpy(&b, &Bs[(16 * t + fr) * pb + k0 + fq * 8], 16);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
-    }
+    for (int e = 0; e < 4; ++e)
+      if (f0 + e < nf) atomicAdd(p + e * s_col, v[e]);
+  } else if (s_col == 1 && al && f0 + 3 < nf) {
+    memcpy(p, v, 16);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (f0 + e < nf) p[e * s_col] = v[e];
   }
 }
 
-#define PT 72  // pitch of 64-wide k-contiguous tiles (144-byte rows)
-
-template <int DQ, int DV>
-__global__ __launch_bounds__(256) void flashb_fwd_kernel(AttnArgsB a) {
-  constexpr int PQ = DQ + 8, NV = DV / 16;
-  __shared__ __attribute__((aligned(16))) bf Qs[TQ * PQ];
-  __shared__ __attribute__((aligned(16))) bf Ks[TK * PQ];
-  __shared__ __attribute__((aligned(16))) bf Vt[DV * PT];  // [dv][key]
-  __shared__ __attribute__((aligned(16))) bf Ps[TQ * PT];  // [row][key]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ---------------------------------------------------------------------------------------------------------------
+// forward: one workgroup = 64*NQT queries of one (batch, head); wave w owns NQT 16-query tiles
+// ---------------------------------------------------------------------------------------------------------------
+template <int DQ, int DV, int NQT>
+__global__ __launch_bounds__(256) void flashc_fwd_kernel(AttnArgsB a) {
+  constexpr int PQ = DQ + 8, NC = DQ / 32, NU = DV / 16;
+  __shared__ __attribute__((aligned(16))) bf Ks[2][TK * PQ];  // [key][d]
+  __shared__ __attribute__((aligned(16))) bf Vt[2][DV * PT];  // [dv][key]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, hv = h / a.v_head_div;
-  const int i0 = blockIdx.x * TQ;
-  const int Dk = (a.D + 31) & ~31;
+  const int q0 = blockIdx.x * (64 * NQT) + wave * (16 * NQT);
   const float* qb = a.q + (long)b * a.qsb + (long)h * a.qsh;
   const float* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
   const float* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
-  {
-    TileB<DQ> tq;
-    tq.load(qb, a.qsi, a.qsd, i0, a.Nq, a.D, a.q_dfast);
-    tq.store(Qs, PQ, nullptr, 0, a.q_dfast);
-  }
-  f32x4 o[NV];
+
+  bf16x8 qf[NQT][NC];
 #pragma unroll
-  for (int t = 0; t < NV; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m[4], l[4];
+  for (int t = 0; t < NQT; ++t)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    m[r] = NEG_BIG;
-    l[r] = 0.f;
+    for (int c = 0; c < NC; ++c)
+      qf[t][c] = frag_global(qb, a.qsi, a.qsd, q0 + 16 * t + fr, a.Nq, c, fq, a.D, a.scale * LOG2E, a.q_al);
+  f32x4 o[NQT][NU];
+  float m[NQT], l[NQT];
+#pragma unroll
+  for (int t = 0; t < NQT; ++t) {
+    m[t] = NEG_BIG;
+    l[t] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) o[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int fr = lane & 15, fq = lane >> 4;
-  TileB<DQ> pk;
-  TileB<DV> pv;
-  pk.load(kb, a.ksi, a.ksd, 0, a.Nk, a.D, a.k_dfast);
-  pv.load(vb, a.vsi, a.vsd, 0, a.Nk, a.Dv, a.v_dfast);
+  StageT<DQ> sk;
+  StageT<DV> sv;
+  sk.setup(a.ksi, a.ksd, true, false, a.k_al);
+  sv.setup(a.vsi, a.vsd, false, true, a.v_al);
+  sk.load(kb, a.ksi, a.ksd, 0, a.Nk, a.D);
+  sv.load(vb, a.vsi, a.vsd, 0, a.Nk, a.Dv);
+  sk.store(Ks[0], PQ, nullptr, 1.f);
+  sv.store(nullptr, 0, Vt[0], 1.f);
+  __syncthreads();
+  int cur = 0;
   for (int j0 = 0; j0 < a.Nk; j0 += TK) {
-    __syncthreads();
-    pk.store(Ks, PQ, nullptr, 0, a.k_dfast);
-    pv.store(nullptr, 0, Vt, PT, a.v_dfast);
-    __syncthreads();
-    if (j0 + TK < a.Nk) {
-      pk.load(kb, a.ksi, a.ksd, j0 + TK, a.Nk, a.D, a.k_dfast);
-      pv.load(vb, a.vsi, a.vsd, j0 + TK, a.Nk, a.Dv, a.v_dfast);
+    const bool more = j0 + TK < a.Nk;
+    if (more) {
+      sk.load(kb, a.ksi, a.ksd, j0 + TK, a.Nk, a.D);
+      sv.load(vb, a.vsi, a.vsd, j0 + TK, a.Nk, a.Dv);
     }
-    f32x4 s[4];
+    const bf* K_ = Ks[cur];
+    const bf* V_ = Vt[cur];
+    f32x4 st[4][NQT];  // S^T: rows = keys 16kt + 4fq + r, column = query fr
 #pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_kc<4>(s, Qs, PQ, wave * 16, Ks, PQ, Dk, lane);
-    float alpha[4];
+    for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+      for (int t = 0; t < NQT; ++t) st[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const bf16x8 kf = frag_rm(K_, PQ, 16 * kt + fr, c, fq);
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) st[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][c], st[kt][t], 0, 0, 0);
+      }
+    }
+    if (j0 + TK > a.Nk) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (j0 + 16 * kt + 4 * fq + r >= a.Nk) {
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) st[kt][t][r] = NEG_BIG;
+          }
+    }
+    bf16x8 pb[NQT][2];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
       float mx = NEG_BIG;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float v = (j0 + 16 * t + fr < a.Nk) ? s[t][r] * a.scale : NEG_BIG;
-        s[t][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int o_ = 1; o_ < 16; o_ <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o_));
-      float mnew = fmaxf(m[r], mx);
-      alpha[r] = fast_exp(m[r] - mnew);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][t][r]);
+      mx = quad_max(mx);
+      const float mnew = fmaxf(m[t], mx);
+      const float alpha = fast_exp2(m[t] - mnew);
+      m[t] = mnew;
       float rs = 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float p = (j0 + 16 * t + fr < a.Nk) ? fast_exp(s[t][r] - mnew) : 0.f;
-        s[t][r] = p;
-        rs += p;
-      }
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int o_ = 1; o_ < 16; o_ <<= 1) rs += __shfl_xor(rs, o_);
-      l[r] = l[r] * alpha[r] + rs;
-      m[r] = mnew;
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(st[kt][t][r] - mnew);
+          st[kt][t][r] = p;
+          rs += p;
+        }
+      l[t] = l[t] * alpha + rs;  // per-lane partial sum (this lane's keys); the 4 fq lanes are added once at the end
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][u][r] *= alpha;
+      pb[t][0] = pack_tiles(st[0][t], st[1][t]);
+      pb[t][1] = pack_tiles(st[2][t], st[3][t]);
     }
+    // O^T[dv][query] += V^T[dv][keys] . P^T[keys][query]
 #pragma unroll
-    for (int t = 0; t < NV; ++t)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[t][r] *= alpha[r];
+      for (int c = 0; c < 2; ++c) {
+        const bf16x8 vf = frag_perm(V_, 16 * u + fr, c, fq);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ps[(wave * 16 + fq * 4 + r) * PT + 16 * t + fr] = f2bf(s[t][r]);
+        for (int t = 0; t < NQT; ++t) o[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[t][c], o[t][u], 0, 0, 0);
+      }
+    if (more) {
+      sk.store(Ks[cur ^ 1], PQ, nullptr, 1.f);
+      sv.store(nullptr, 0, Vt[cur ^ 1], 1.f);
+    }
     __syncthreads();
-    mma_kc<NV>(o, Ps, PT, wave * 16, Vt, PT, 64, lane);
+    cur ^= 1;
   }
   float* ob = a.o + (long)b * a.osb + (long)h * a.osh;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = i0 + wave * 16 + fq * 4 + r;
+  for (int t = 0; t < NQT; ++t) {
+    const float lt = quad_sum(l[t]);
+    const int i = q0 + 16 * t + fr;
     if (i < a.Nq) {
-      const float inv = 1.f / l[r];
+      const float inv = 1.f / lt;
 #pragma unroll
-      for (int t = 0; t < NV; ++t) {
-        const int d = 16 * t + fr;
-        if (d < a.Dv) ob[(long)i * a.osi + (long)d * a.osd] = o[t][r] * inv;
+      for (int u = 0; u < NU; ++u) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = o[t][u][r] * inv;
+        put4(ob, a.osi, a.osd, i, 16 * u + 4 * fq, a.Dv, v, a.o_al, false);
       }
-      if (fr == 0) a.lse[((long)b * a.H + h) * a.Nq + i] = m[r] + logf(l[r]);
+      if (fq == 0) a.lse[((long)b * a.H + h) * a.Nq + i] = m[t] * LN2 + logf(lt);
     }
   }
 }
 
-template <int DQ, int DV>
-__global__ __launch_bounds__(256) void flashb_bwd_dq_kernel(AttnArgsB a) {
-  constexpr int PQ = DQ + 8, PV = DV + 8, NQ = DQ / 16;
-  __shared__ __attribute__((aligned(16))) bf Qs[TQ * PQ];
-  __shared__ __attribute__((aligned(16))) bf Ks[TK * PQ];   // [j][d]
-  __shared__ __attribute__((aligned(16))) bf Kt[DQ * PT];   // [d][j]
-  __shared__ __attribute__((aligned(16))) bf Vs[TK * PV];   // [j][dv]
-  __shared__ __attribute__((aligned(16))) bf dOs[TQ * PV];  // [i][dv]
-  __shared__ __attribute__((aligned(16))) bf Ss[TQ * PT];   // dS [i][j]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ---------------------------------------------------------------------------------------------------------------
+// backward, dQ (and delta): one workgroup = 64*NQT queries; streams key tiles
+// ---------------------------------------------------------------------------------------------------------------
+template <int DQ, int DV, int NQT>
+__global__ __launch_bounds__(256) void flashc_bwd_dq_kernel(AttnArgsB a) {
+  constexpr int PQ = DQ + 8, PV = DV + 8, NC = DQ / 32, NCV = DV / 32, ND = DQ / 16;
+  __shared__ __attribute__((aligned(16))) bf Ks[2][TK * PQ];  // [key][d]
+  __shared__ __attribute__((aligned(16))) bf Kt[2][DQ * PT];  // [d][key]
+  __shared__ __attribute__((aligned(16))) bf Vs[2][TK * PV];  // [key][dv]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, hv = h / a.v_head_div;
-  const int i0 = blockIdx.x * TQ;
-  const int Dk = (a.D + 31) & ~31, Dvk = (a.Dv + 31) & ~31;
+  const int q0 = blockIdx.x * (64 * NQT) + wave * (16 * NQT);
   const float* qb = a.q + (long)b * a.qsb + (long)h * a.qsh;
   const float* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
   const float* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
   const float* ob = a.o + (long)b * a.osb + (long)h * a.osh;
   const float* gb = a.dout + (long)b * a.osb + (long)h * a.osh;
-  const int fr = lane & 15, fq = lane >> 4;
-  {
-    TileB<DQ> tq;
-    tq.load(qb, a.qsi, a.qsd, i0, a.Nq, a.D, a.q_dfast);
-    tq.store(Qs, PQ, nullptr, 0, a.q_dfast);
-    TileB<DV> tg;
-    tg.load(gb, a.osi, a.osd, i0, a.Nq, a.Dv, a.o_dfast);
-    tg.store(dOs, PV, nullptr, 0, a.o_dfast);
-  }
-  // delta = rowsum(dO * O) in fp32 straight from HBM (rows fq*4+r of this wave; 16 lanes split the row)
-  float dl[4], ls[4];
+
+  bf16x8 qf[NQT][NC], gf[NQT][NCV];
+  float lse2[NQT], dl[NQT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = i0 + wave * 16 + fq * 4 + r;
+  for (int t = 0; t < NQT; ++t) {
+    const int i = q0 + 16 * t + fr;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) qf[t][c] = frag_global(qb, a.qsi, a.qsd, i, a.Nq, c, fq, a.D, a.scale * LOG2E, a.q_al);
+#pragma unroll
+    for (int c = 0; c < NCV; ++c) gf[t][c] = frag_global(gb, a.osi, a.osd, i, a.Nq, c, fq, a.Dv, 1.f, a.o_al);
+    // delta = rowsum(dO * O) in fp32 from HBM: this lane's feature slots, then the 4 fq lanes
     float sacc = 0.f;
-    if (i < a.Nq)
-      for (int d = fr; d < a.Dv; d += 16) sacc += gb[(long)i * a.osi + (long)d * a.osd] * ob[(long)i * a.osi + (long)d * a.osd];
+    if (i < a.Nq) {
 #pragma unroll
-    for (int o_ = 1; o_ < 16; o_ <<= 1) sacc += __shfl_xor(sacc, o_);
-    dl[r] = sacc;
-    ls[r] = (i < a.Nq) ? a.lse[((long)b * a.H + h) * a.Nq + i] : 0.f;
-    if (fr == 0 && i < a.Nq) a.delta[((long)b * a.H + h) * a.Nq + i] = sacc;
+      for (int c = 0; c < NCV; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int d = 32 * c + 8 * fq + e;
+          if (d < a.Dv) sacc += gb[(long)i * a.osi + (long)d * a.osd] * ob[(long)i * a.osi + (long)d * a.osd];
+        }
+    }
+    sacc = quad_sum(sacc);
+    dl[t] = sacc;
+    lse2[t] = (i < a.Nq) ? a.lse[((long)b * a.H + h) * a.Nq + i] * LOG2E : -NEG_BIG;
+    if (fq == 0 && i < a.Nq) a.delta[((long)b * a.H + h) * a.Nq + i] = sacc;
   }
-  f32x4 dq[NQ];
+  f32x4 dq[NQT][ND];
 #pragma unroll
-  for (int t = 0; t < NQ; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  TileB<DQ> pk;
-  TileB<DV> pv;
-  pk.load(kb, a.ksi, a.ksd, 0, a.Nk, a.D, a.k_dfast);
-  pv.load(vb, a.vsi, a.vsd, 0, a.Nk, a.Dv, a.v_dfast);
+  for (int t = 0; t < NQT; ++t)
+#pragma unroll
+    for (int u = 0; u < ND; ++u) dq[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  StageT<DQ> sk;
+  StageT<DV> sv;
+  sk.setup(a.ksi, a.ksd, true, true, a.k_al);
+  sv.setup(a.vsi, a.vsd, true, false, a.v_al);
+  sk.load(kb, a.ksi, a.ksd, 0, a.Nk, a.D);
+  sv.load(vb, a.vsi, a.vsd, 0, a.Nk, a.Dv);
+  sk.store(Ks[0], PQ, Kt[0], 1.f);
+  sv.store(Vs[0], PV, nullptr, 1.f);
+  __syncthreads();
+  int cur = 0;
   for (int j0 = 0; j0 < a.Nk; j0 += TK) {
-    __syncthreads();
-    pk.store(Ks, PQ, Kt, PT, a.k_dfast);
-    pv.store(Vs, PV, nullptr, 0, a.v_dfast);
-    __syncthreads();
-    if (j0 + TK < a.Nk) {
-      pk.load(kb, a.ksi, a.ksd, j0 + TK, a.Nk, a.D, a.k_dfast);
-      pv.load(vb, a.vsi, a.vsd, j0 + TK, a.Nk, a.Dv, a.v_dfast);
+    const bool more = j0 + TK < a.Nk;
+    if (more) {
+      sk.load(kb, a.ksi, a.ksd, j0 + TK, a.Nk, a.D);
+      sv.load(vb, a.vsi, a.vsd, j0 + TK, a.Nk, a.Dv);
     }
-    f32x4 s[4], dp[4];
+    const bf* K_ = Ks[cur];
+    const bf* Kt_ = Kt[cur];
+    const bf* V_ = Vs[cur];
+    f32x4 st[4][NQT], dp[4][NQT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    mma_kc<4>(s, Qs, PQ, wave * 16, Ks, PQ, Dk, lane);
-    mma_kc<4>(dp, dOs, PV, wave * 16, Vs, PV, Dvk, lane);
+    for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = (j0 + 16 * t + fr < a.Nk) ? fast_exp(s[t][r] * a.scale - ls[r]) : 0.f;
-        Ss[(wave * 16 + fq * 4 + r) * PT + 16 * t + fr] = f2bf(p * (dp[t][r] - dl[r]) * a.scale);
+      for (int t = 0; t < NQT; ++t) {
+        st[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const bf16x8 kf = frag_rm(K_, PQ, 16 * kt + fr, c, fq);
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) st[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][c], st[kt][t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < NCV; ++c) {
+        const bf16x8 vf = frag_rm(V_, PV, 16 * kt + fr, c, fq);
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) dp[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[t][c], dp[kt][t], 0, 0, 0);
+      }
+    }
+    bf16x8 dsb[NQT][2];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(st[kt][t][r] - lse2[t]);
+          st[kt][t][r] = p * (dp[kt][t][r] - dl[t]);
+        }
+      dsb[t][0] = pack_tiles(st[0][t], st[1][t]);
+      dsb[t][1] = pack_tiles(st[2][t], st[3][t]);
+    }
+    // dQ^T[d][query] += K^T[d][keys] . dS^T[keys][query]   (keys beyond Nk carry zero K rows)
+#pragma unroll
+    for (int u = 0; u < ND; ++u)
+      if (16 * u < a.D) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bf16x8 kf = frag_perm(Kt_, 16 * u + fr, c, fq);
+#pragma unroll
+          for (int t = 0; t < NQT; ++t) dq[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsb[t][c], dq[t][u], 0, 0, 0);
+        }
+      }
+    if (more) {
+      sk.store(Ks[cur ^ 1], PQ, Kt[cur ^ 1], 1.f);
+      sv.store(Vs[cur ^ 1], PV, nullptr, 1.f);
+    }
     __syncthreads();
-    mma_kc<NQ>(dq, Ss, PT, wave * 16, Kt, PT, 64, lane);
+    cur ^= 1;
   }
   float* dqb = a.dq + (long)b * a.qsb + (long)h * a.qsh;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = i0 + wave * 16 + fq * 4 + r;
+  for (int t = 0; t < NQT; ++t) {
+    const int i = q0 + 16 * t + fr;
     if (i < a.Nq) {
 #pragma unroll
-      for (int t = 0; t < NQ; ++t) {
-        const int d = 16 * t + fr;
-        if (d < a.D) dqb[(long)i * a.qsi + (long)d * a.qsd] = dq[t][r];
+      for (int u = 0; u < ND; ++u) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = dq[t][u][r] * a.scale;
+        put4(dqb, a.qsi, a.qsd, i, 16 * u + 4 * fq, a.D, v, a.q_al, false);
       }
     }
   }
 }
 
-template <int DQ, int DV>
-__global__ __launch_bounds__(256) void flashb_bwd_dkv_kernel(AttnArgsB a) {
-  constexpr int PQ = DQ + 8, PV = DV + 8, NQ = DQ / 16, NV = DV / 16;
-  __shared__ __attribute__((aligned(16))) bf Ks[TK * PQ];    // [j][d]
-  __shared__ __attribute__((aligned(16))) bf Vs[TK * PV];    // [j][dv]
-  __shared__ __attribute__((aligned(16))) bf Qs[TQ * PQ];    // [i][d]
-  __shared__ __attribute__((aligned(16))) bf Qt[DQ * PT];    // [d][i]
-  __shared__ __attribute__((aligned(16))) bf dOs[TQ * PV];   // [i][dv]
-  __shared__ __attribute__((aligned(16))) bf dOt[DV * PT];   // [dv][i]
-  __shared__ __attribute__((aligned(16))) bf Pt[TK * PT];    // P^T  [j][i]
-  __shared__ __attribute__((aligned(16))) bf St[TK * PT];    // dS^T [j][i]
-  __shared__ float lse_s[TQ], del_s[TQ];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ---------------------------------------------------------------------------------------------------------------
+// backward, dK / dV: one workgroup = 64*NKT keys; streams query tiles (optionally only a slice of them: blockIdx.z)
+// ---------------------------------------------------------------------------------------------------------------
+template <int DQ, int DV, int NKT>
+__global__ __launch_bounds__(256) void flashc_bwd_dkv_kernel(AttnArgsB a) {
+  constexpr int PQ = DQ + 8, PV = DV + 8, NC = DQ / 32, NCV = DV / 32, ND = DQ / 16, NU = DV / 16;
+  constexpr int NBUF = (DV <= 64) ? 2 : 1;  // the widest instance keeps one LDS stage (two barriers per tile)
+  __shared__ __attribute__((aligned(16))) bf Qs[NBUF][64 * PQ];   // [query][d]   (scaled by scale*log2e)
+  __shared__ __attribute__((aligned(16))) bf Qt[NBUF][DQ * PT];   // [d][query]
+  __shared__ __attribute__((aligned(16))) bf Gs[NBUF][64 * PV];   // dO [query][dv]
+  __shared__ __attribute__((aligned(16))) bf Gt[NBUF][DV * PT];   // dO^T [dv][query]
+  __shared__ __attribute__((aligned(16))) float lse_s[NBUF][64], del_s[NBUF][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, hv = h / a.v_head_div;
-  const int j0 = blockIdx.x * TK;
-  const int Dk = (a.D + 31) & ~31, Dvk = (a.Dv + 31) & ~31;
+  const int k0 = blockIdx.x * (64 * NKT) + wave * (16 * NKT);
   const float* qb = a.q + (long)b * a.qsb + (long)h * a.qsh;
   const float* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
   const float* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
   const float* gb = a.dout + (long)b * a.osb + (long)h * a.osh;
-  const int fr = lane & 15, fq = lane >> 4;
-  {
-    TileB<DQ> tk;
-    tk.load(kb, a.ksi, a.ksd, j0, a.Nk, a.D, a.k_dfast);
-    tk.store(Ks, PQ, nullptr, 0, a.k_dfast);
-    TileB<DV> tv;
-    tv.load(vb, a.vsi, a.vsd, j0, a.Nk, a.Dv, a.v_dfast);
-    tv.store(Vs, PV, nullptr, 0, a.v_dfast);
+  const long stat0 = ((long)b * a.H + h) * a.Nq;
+
+  bf16x8 kf[NKT][NC], vf[NKT][NCV];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) kf[t][c] = frag_global(kb, a.ksi, a.ksd, k0 + 16 * t + fr, a.Nk, c, fq, a.D, 1.f, a.k_al);
+#pragma unroll
+    for (int c = 0; c < NCV; ++c) vf[t][c] = frag_global(vb, a.vsi, a.vsd, k0 + 16 * t + fr, a.Nk, c, fq, a.Dv, 1.f, a.v_al);
   }
-  f32x4 dk[NQ], dv[NV];
+  f32x4 dk[NKT][ND], dv[NKT][NU];
 #pragma unroll
-  for (int t = 0; t < NQ; ++t) dk[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NKT; ++t) {
 #pragma unroll
-  for (int t = 0; t < NV; ++t) dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  TileB<DQ> pq;
-  TileB<DV> pg;
-  pq.load(qb, a.qsi, a.qsd, 0, a.Nq, a.D, a.q_dfast);
-  pg.load(gb, a.osi, a.osd, 0, a.Nq, a.Dv, a.o_dfast);
-  for (int i0 = 0; i0 < a.Nq; i0 += TQ) {
-    __syncthreads();
-    pq.store(Qs, PQ, Qt, PT, a.q_dfast);
-    pg.store(dOs, PV, dOt, PT, a.o_dfast);
-    if (threadIdx.x < TQ) {
+    for (int u = 0; u < ND; ++u) dk[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NU; ++u) dv[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int ibeg = blockIdx.z * a.tiles_per_split * 64;
+  int iend = ibeg + a.tiles_per_split * 64;
+  if (iend > a.Nq) iend = a.Nq;
+  StageT<DQ> sq;
+  StageT<DV> sg;
+  sq.setup(a.qsi, a.qsd, true, true, a.q_al);
+  sg.setup(a.osi, a.osd, true, true, a.o_al);
+  float pl = 0.f, pd = 0.f;  // prefetched lse / delta of query ibeg + threadIdx.x (threads 0..63)
+  auto load_tile = [&](int i0) __attribute__((always_inline)) {
+    sq.load(qb, a.qsi, a.qsd, i0, iend, a.D);
+    sg.load(gb, a.osi, a.osd, i0, iend, a.Dv);
+    if (threadIdx.x < 64) {
       const int i = i0 + threadIdx.x;
-      lse_s[threadIdx.x] = (i < a.Nq) ? a.lse[((long)b * a.H + h) * a.Nq + i] : 0.f;
-      del_s[threadIdx.x] = (i < a.Nq) ? a.delta[((long)b * a.H + h) * a.Nq + i] : 0.f;
+      pl = (i < iend) ? a.lse[stat0 + i] * LOG2E : -NEG_BIG;
+      pd = (i < iend) ? a.delta[stat0 + i] : 0.f;
     }
-    __syncthreads();
-    if (i0 + TQ < a.Nq) {
-      pq.load(qb, a.qsi, a.qsd, i0 + TQ, a.Nq, a.D, a.q_dfast);
-      pg.load(gb, a.osi, a.osd, i0 + TQ, a.Nq, a.Dv, a.o_dfast);
+  };
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    sq.store(Qs[buf], PQ, Qt[buf], a.scale * LOG2E);
+    sg.store(Gs[buf], PV, Gt[buf], 1.f);
+    if (threadIdx.x < 64) {
+      lse_s[buf][threadIdx.x] = pl;
+      del_s[buf][threadIdx.x] = pd;
     }
-    f32x4 st[4], dpt[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dpt[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  if (ibeg < iend) load_tile(ibeg);
+  int cur = 0;
+  for (int i0 = ibeg; i0 < iend; i0 += 64) {
+    const bool more = i0 + 64 < iend;
+    if (NBUF == 1 || i0 == ibeg) {
+      if (NBUF == 1) __syncthreads();
+      store_tile(cur);
+      __syncthreads();
     }
-    mma_kc<4>(st, Ks, PQ, wave * 16, Qs, PQ, Dk, lane);     // S^T[j][i]
-    mma_kc<4>(dpt, Vs, PV, wave * 16, dOs, PV, Dvk, lane);  // dP^T[j][i]
+    if (more) load_tile(i0 + 64);
+    const bf* Q_ = Qs[cur];
+    const bf* Qt_ = Qt[cur];
+    const bf* G_ = Gs[cur];
+    const bf* Gt_ = Gt[cur];
+    f32x4 s[4][NKT], dp[4][NKT];  // rows = queries 16qt + 4fq + r, column = key fr
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int ic = 16 * t + fr;
-      const bool iv = (i0 + ic < a.Nq);
-      const float lsev = lse_s[ic], delv = del_s[ic];
+    for (int qt = 0; qt < 4; ++qt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int jr = wave * 16 + fq * 4 + r;
-        const bool ok = iv && (j0 + jr < a.Nk);
-        float p = ok ? fast_exp(st[t][r] * a.scale - lsev) : 0.f;
-        Pt[jr * PT + ic] = f2bf(p);
-        St[jr * PT + ic] = f2bf(p * (dpt[t][r] - delv) * a.scale);
+      for (int t = 0; t < NKT; ++t) {
+        s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const bf16x8 qa = frag_rm(Q_, PQ, 16 * qt + fr, c, fq);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[t][c], s[qt][t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < NCV; ++c) {
+        const bf16x8 ga = frag_rm(G_, PV, 16 * qt + fr, c, fq);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) dp[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf[t][c], dp[qt][t], 0, 0, 0);
+      }
+      float l4[4], d4[4];
+      memcpy(l4, &lse_s[cur][16 * qt + 4 * fq], 16);
+      memcpy(d4, &del_s[cur][16 * qt + 4 * fq], 16);
+#pragma unroll
+      for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(s[qt][t][r] - l4[r]);  // queries beyond the slice carry lse = +big -> p = 0
+          s[qt][t][r] = p;
+          dp[qt][t][r] = p * (dp[qt][t][r] - d4[r]);
+        }
     }
-    __syncthreads();
-    mma_kc<NV>(dv, Pt, PT, wave * 16, dOt, PT, 64, lane);
-    mma_kc<NQ>(dk, St, PT, wave * 16, Qt, PT, 64, lane);
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const bf16x8 pb0 = pack_tiles(s[0][t], s[1][t]), pb1 = pack_tiles(s[2][t], s[3][t]);
+      const bf16x8 db0 = pack_tiles(dp[0][t], dp[1][t]), db1 = pack_tiles(dp[2][t], dp[3][t]);
+      // dV^T[dv][key] += dO^T[dv][queries] . P[queries][key] ;  dK^T[d][key] += Q^T[d][queries] . dS[queries][key]
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+        if (16 * u < a.Dv) {
+          dv[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Gt_, 16 * u + fr, 0, fq), pb0, dv[t][u], 0, 0, 0);
+          dv[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Gt_, 16 * u + fr, 1, fq), pb1, dv[t][u], 0, 0, 0);
+        }
+#pragma unroll
+      for (int u = 0; u < ND; ++u)
+        if (16 * u < a.D) {
+          dk[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Qt_, 16 * u + fr, 0, fq), db0, dk[t][u], 0, 0, 0);
+          dk[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Qt_, 16 * u + fr, 1, fq), db1, dk[t][u], 0, 0, 0);
+        }
+    }
+    if (NBUF == 2) {
+      if (more) store_tile(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   float* dkb = a.dk + (long)b * a.ksb + (long)h * a.ksh;
   float* dvb = a.dv + (long)b * a.vsb + (long)hv * a.vsh;
+  const bool split = a.qsplit > 1;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int j = j0 + wave * 16 + fq * 4 + r;
+  for (int t = 0; t < NKT; ++t) {
+    const int j = k0 + 16 * t + fr;
     if (j < a.Nk) {
 #pragma unroll
-      for (int t = 0; t < NQ; ++t) {
-        const int d = 16 * t + fr;
-        if (d < a.D) dkb[(long)j * a.ksi + (long)d * a.ksd] = dk[t][r];
+      for (int u = 0; u < ND; ++u) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = dk[t][u][r] * LN2;  // Q was staged scaled by scale*log2e
+        put4(dkb, a.ksi, a.ksd, j, 16 * u + 4 * fq, a.D, v, a.k_al, split);
       }
 #pragma unroll
-      for (int t = 0; t < NV; ++t) {
-        const int d = 16 * t + fr;
-        if (d < a.Dv) {
-          float* dst = &dvb[(long)j * a.vsi + (long)d * a.vsd];
-          if (a.dv_atomic) atomicAdd(dst, dv[t][r]);
-          else *dst = dv[t][r];
-        }
+      for (int u = 0; u < NU; ++u) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = dv[t][u][r];
+        put4(dvb, a.vsi, a.vsd, j, 16 * u + 4 * fq, a.Dv, v, a.v_al, split || a.dv_atomic);
       }
     }
   }
+}
+
+static int al4(const void* p, long s0, long s1, long s2, long s3) {
+  auto m4 = [](long v) { return v == 1 || (v & 3) == 0; };
+  return (((uintptr_t)p & 15) == 0) && m4(s0) && m4(s1) && m4(s2) && m4(s3);
 }
 
 static void fill_b(AttnArgsB& a, const cenet_attn_t* p) {
@@ -384,8 +639,14 @@ static void fill_b(AttnArgsB& a, const cenet_attn_t* p) {
   a.osb = p->osb; a.osh = p->osh; a.osi = p->osi; a.osd = p->osd;
   a.B = p->B; a.H = p->H; a.Nq = p->Nq; a.Nk = p->Nk; a.D = p->D; a.Dv = p->Dv;
   a.v_head_div = p->v_head_div > 0 ? p->v_head_div : 1;
-  a.q_dfast = (p->qsd == 1); a.k_dfast = (p->ksd == 1); a.v_dfast = (p->vsd == 1); a.o_dfast = (p->osd == 1);
+  // 16-byte accesses: the base of every tensor the problem touches and all its strides
+  a.q_al = al4(p->q, p->qsb, p->qsh, p->qsi, p->qsd) && (!p->dq || ((uintptr_t)p->dq & 15) == 0);
+  a.k_al = al4(p->k, p->ksb, p->ksh, p->ksi, p->ksd) && (!p->dk || ((uintptr_t)p->dk & 15) == 0);
+  a.v_al = al4(p->v, p->vsb, p->vsh, p->vsi, p->vsd) && (!p->dv || ((uintptr_t)p->dv & 15) == 0);
+  a.o_al = al4(p->o, p->osb, p->osh, p->osi, p->osd) && (!p->dout || ((uintptr_t)p->dout & 15) == 0);
   a.dv_atomic = (a.v_head_div > 1);
+  a.qsplit = 1;
+  a.tiles_per_split = cdiv(a.Nq, 64);
   a.scale = p->scale;
 }
 
@@ -401,29 +662,54 @@ static int pick_b(int D, int Dv) {
 int cenet_flashb_fwd(const cenet_attn_t* p, hipStream_t stream) {
   AttnArgsB a;
   fill_b(a, p);
-  dim3 grid(cdiv(a.Nq, TQ), a.B * a.H);
-  switch (pick_b(a.D, a.Dv)) {
-    case 0: CENET_LAUNCH((flashb_fwd_kernel<32, 32>), grid, dim3(256), stream, a); break;
-    case 1: CENET_LAUNCH((flashb_fwd_kernel<32, 64>), grid, dim3(256), stream, a); break;
-    case 2: CENET_LAUNCH((flashb_fwd_kernel<64, 64>), grid, dim3(256), stream, a); break;
-    case 3: CENET_LAUNCH((flashb_fwd_kernel<64, 128>), grid, dim3(256), stream, a); break;
-    default: return CENET_EUNSUPPORTED;
+  const int cls = pick_b(a.D, a.Dv);
+  if (cls < 0) return CENET_EUNSUPPORTED;
+  const bool wide = a.Nq >= 1024 && cls != 3;  // two 16-query tiles per wave when there are enough queries to fill the chip
+  dim3 grid(cdiv(a.Nq, wide ? 128 : 64), a.B * a.H);
+#define CENET_FWD(DQv, DVv)                                                                      \
+  if (wide) CENET_LAUNCH((flashc_fwd_kernel<DQv, DVv, 2>), grid, dim3(256), stream, a);          \
+  else CENET_LAUNCH((flashc_fwd_kernel<DQv, DVv, 1>), grid, dim3(256), stream, a);
+  switch (cls) {
+    case 0: CENET_FWD(32, 32) break;
+    case 1: CENET_FWD(32, 64) break;
+    case 2: CENET_FWD(64, 64) break;
+    default: CENET_LAUNCH((flashc_fwd_kernel<64, 128, 1>), grid, dim3(256), stream, a); break;
   }
+#undef CENET_FWD
   return CENET_OK;
 }
+
 int cenet_flashb_bwd(const cenet_attn_t* p, hipStream_t stream) {
   AttnArgsB a;
   fill_b(a, p);
-  dim3 gq(cdiv(a.Nq, TQ), a.B * a.H), gk(cdiv(a.Nk, TK), a.B * a.H);
-#define CENET_BWD(DQv, DVv)                                                             \
-  CENET_LAUNCH((flashb_bwd_dq_kernel<DQv, DVv>), gq, dim3(256), stream, a);            \
-  CENET_LAUNCH((flashb_bwd_dkv_kernel<DQv, DVv>), gk, dim3(256), stream, a);
-  switch (pick_b(a.D, a.Dv)) {
-    case 0: CENET_BWD(32, 32) break;
-    case 1: CENET_BWD(32, 64) break;
-    case 2: CENET_BWD(64, 64) break;
-    case 3: CENET_BWD(64, 128) break;
-    default: return CENET_EUNSUPPORTED;
+  const int cls = pick_b(a.D, a.Dv);
+  if (cls < 0) return CENET_EUNSUPPORTED;
+  const bool wide_q = a.Nq >= 1024 && cls != 3;
+  const bool wide_k = a.Nk >= 1024 && cls <= 1;
+  dim3 gq(cdiv(a.Nq, wide_q ? 128 : 64), a.B * a.H);
+  // few key tiles under many queries (spatial-reduction attention: 49 keys): slice the query range over workgroups and
+  // accumulate dK / dV atomically — only when the caller guarantees zero-filled dk / dv
+  const int ktiles = cdiv(a.Nk, wide_k ? 128 : 64), qtiles = cdiv(a.Nq, 64);
+  if (p->dkv_zeroed && (long)ktiles * a.B * a.H < 512 && qtiles > 1) {
+    int s = cdiv(1024, (long)ktiles * a.B * a.H);
+    if (s > qtiles) s = qtiles;
+    a.tiles_per_split = cdiv(qtiles, s);
+    a.qsplit = cdiv(qtiles, a.tiles_per_split);
+  }
+  dim3 gk(ktiles, a.B * a.H, a.qsplit);
+#define CENET_BWD(DQv, DVv, WK)                                                                     \
+  if (wide_q) CENET_LAUNCH((flashc_bwd_dq_kernel<DQv, DVv, 2>), gq, dim3(256), stream, a);          \
+  else CENET_LAUNCH((flashc_bwd_dq_kernel<DQv, DVv, 1>), gq, dim3(256), stream, a);                 \
+  if (WK && wide_k) CENET_LAUNCH((flashc_bwd_dkv_kernel<DQv, DVv, (WK ? 2 : 1)>), gk, dim3(256), stream, a); \
+  else CENET_LAUNCH((flashc_bwd_dkv_kernel<DQv, DVv, 1>), gk, dim3(256), stream, a);
+  switch (cls) {
+    case 0: CENET_BWD(32, 32, 1) break;
+    case 1: CENET_BWD(32, 64, 1) break;
+    case 2: CENET_BWD(64, 64, 0) break;
+    default:
+      CENET_LAUNCH((flashc_bwd_dq_kernel<64, 128, 1>), gq, dim3(256), stream, a);
+      CENET_LAUNCH((flashc_bwd_dkv_kernel<64, 128, 1>), gk, dim3(256), stream, a);
+      break;
   }
 #undef CENET_BWD
   return CENET_OK;

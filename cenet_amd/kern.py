@@ -131,7 +131,7 @@ class AttnT(C.Structure):
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("delta", C.c_void_p)] + \
                [(n, C.c_long) for n in ("qsb", "qsh", "qsi", "qsd", "ksb", "ksh", "ksi", "ksd", "vsb", "vsh", "vsi", "vsd",
                                         "osb", "osh", "osi", "osd")] + \
-               [(n, C.c_int) for n in ("B", "H", "Nq", "Nk", "D", "Dv", "v_head_div")] + [("scale", C.c_float)]
+               [(n, C.c_int) for n in ("B", "H", "Nq", "Nk", "D", "Dv", "v_head_div")] + [("scale", C.c_float)] + [("dkv_zeroed", C.c_int)]
 
 
 def flash_supported(D: int, Dv: int) -> bool:

@@ -174,14 +174,22 @@ class Conv2dFn(Function):
             return y
         Bm = kern.mat_im2col(x, sb=sb, skb=0, sci=sc, sy=sy, sx=sx, KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride,
                              pad=pad, dil=1, patch_is_row=1, transposed=0, kfast=0)
-        if out_layout == "nchw":
-            y = _empty((B, Cout, Ho, Wo), x)
-            scr, scc = Ho * Wo, 1
+        shape = (B, Cout, Ho, Wo) if out_layout == "nchw" else (B, Ho * Wo, Cout)
+        scr, scc = (Ho * Wo, 1) if out_layout == "nchw" else (1, Cout)
+        tiles = B * ((Cout + 63) // 64) * ((Ho * Wo + 63) // 64)
+        if tiles < 256 and Kd >= 1024 and kern.get_compute_bf16():  # parity mode keeps a deterministic forward
+            # few output tiles under a long reduction (the 8x8/4x4/2x2 spatial-reduction convs of pvtv2.py:93-95): split K
+            # over workgroups; the partial sums are added atomically onto an output pre-filled with the bias
+            if b is None:
+                y = _zeros(shape, x)
+            else:
+                y = (b.view(1, Cout, 1, 1) if out_layout == "nchw" else b.view(1, 1, Cout)).expand(shape).contiguous()
+            kern.gemm(kern.mat_plain(W, Kd, 1, kfast=1), Bm, y, Cout, Ho * Wo, Kd, scr=scr, scc=scc, scb=Cout * Ho * Wo,
+                      nbatch=B, splits=kern.pick_splits(Cout, Ho * Wo, B, Kd // 32), atomic=True)
         else:
-            y = _empty((B, Ho * Wo, Cout), x)
-            scr, scc = 1, Cout
-        kern.gemm(kern.mat_plain(W, Kd, 1, kfast=1), Bm, y, Cout, Ho * Wo, Kd, scr=scr, scc=scc, scb=Cout * Ho * Wo,
-                  nbatch=B, bias=b, bias_on_row=True)
+            y = _empty(shape, x)
+            kern.gemm(kern.mat_plain(W, Kd, 1, kfast=1), Bm, y, Cout, Ho * Wo, Kd, scr=scr, scc=scc, scb=Cout * Ho * Wo,
+                      nbatch=B, bias=b, bias_on_row=True)
         ctx.save_for_backward(x, W)
         ctx.refs = (W, b)
         ctx.geom = geom
@@ -479,11 +487,13 @@ def _vmat(d: _AttnDesc, v, vh):
     return kern.mat_plain(v, d.vs[2], d.vs[3], sb=d.vs[0], sb2=d.vs[1], kfast=int(d.vs[2] == 1), offset=d.voff)
 
 
-def _attn_backward(d: _AttnDesc, kind, saved, q, k, v, o, g, dq, dk, dv):
-    """dq/dk/dv are written in the layouts of q/k/v (offsets included); dv must be zero-filled when vdiv > 1."""
+def _attn_backward(d: _AttnDesc, kind, saved, q, k, v, o, g, dq, dk, dv, dkv_zeroed=False):
+    """dq/dk/dv are written in the layouts of q/k/v (offsets included); dv must be zero-filled when vdiv > 1.
+    dkv_zeroed: dk and dv are zero-filled (lets the kernels split the query range when there are few keys)."""
     if kind == "flash":
         a = kern.AttnT()
         d.fill(a, q, k, v, o, saved)
+        a.dkv_zeroed = int(dkv_zeroed)
         delta = _empty((d.B, d.H, d.Nq), q)
         a.dout = g.data_ptr()
         a.dq, a.dk, a.dv = dq.data_ptr() + 4 * d.qoff, dk.data_ptr() + 4 * d.koff, dv.data_ptr() + 4 * d.voff
@@ -535,8 +545,9 @@ class SRAttentionFn(Function):
     def backward(ctx, g):
         q, kv, o, saved = ctx.saved_tensors
         g = _c(g)
-        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        _attn_backward(ctx.d, ctx.kind, saved, q, kv, kv, o, g, dq, dkv, dkv)
+        few_keys = ctx.d.Nk <= 128 and ctx.d.Nq >= 1024  # spatial-reduction attention: 49 keys under 784..3136 queries
+        dq, dkv = torch.empty_like(q), (_zeros(kv.shape, kv) if few_keys else torch.empty_like(kv))
+        _attn_backward(ctx.d, ctx.kind, saved, q, kv, kv, o, g, dq, dkv, dkv, dkv_zeroed=few_keys)
         return dq, dkv, None
 
 

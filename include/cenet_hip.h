@@ -95,6 +95,8 @@ typedef struct {
   long qsb, qsh, qsi, qsd, ksb, ksh, ksi, ksd, vsb, vsh, vsi, vsd, osb, osh, osi, osd;
   int B, H, Nq, Nk, D, Dv, v_head_div;
   float scale;
+  int dkv_zeroed; /* backward only: caller guarantees dk / dv are zero-filled, so the library may slice the query range
+                     over workgroups and accumulate dK / dV atomically (few keys under many queries) */
 } cenet_attn_t;
 /* Replaces q@k^T -> softmax -> @v (pvtv2.py:101-105; nlb.py:117-138; multihead_diffattn.py:96-116) and backward.
  * Supported head dims: D<=64 with Dv<=128 (cenet_flash_attn_supported). */
