@@ -17,6 +17,7 @@
 //   * the streamed tiles are register-prefetched one tile ahead and double-buffered in LDS (one barrier per tile);
 //   * exponentials are v_exp_f32 (base 2): log2(e) is folded into the query scaling.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cenet_hip.h"
 
 #define TK 64
@@ -203,7 +204,7 @@ __device__ __forceinline__ void put4(float* base, long s_row, long s_col, int ro
 // forward: one workgroup = 64*NQT queries of one (batch, head); wave w owns NQT 16-query tiles
 // ---------------------------------------------------------------------------------------------------------------
 template <int DQ, int DV, int NQT>
-__global__ __launch_bounds__(256) void flashc_fwd_kernel(AttnArgsB a) {
+__global__ __launch_bounds__(256, (DV <= 64 ? 2 : 1)) void flashc_fwd_kernel(AttnArgsB a) {
   constexpr int PQ = DQ + 8, NC = DQ / 32, NU = DV / 16;
   __shared__ __attribute__((aligned(16))) bf Ks[2][TK * PQ];  // [key][d]
   __shared__ __attribute__((aligned(16))) bf Vt[2][DV * PT];  // [dv][key]
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void flashc_fwd_kernel(AttnArgsB a) {
 // backward, dQ (and delta): one workgroup = 64*NQT queries; streams key tiles
 // ---------------------------------------------------------------------------------------------------------------
 template <int DQ, int DV, int NQT>
-__global__ __launch_bounds__(256) void flashc_bwd_dq_kernel(AttnArgsB a) {
+__global__ __launch_bounds__(256, ((DQ * NQT <= 64 && DV <= 64) ? 2 : 1)) void flashc_bwd_dq_kernel(AttnArgsB a) {
   constexpr int PQ = DQ + 8, PV = DV + 8, NC = DQ / 32, NCV = DV / 32, ND = DQ / 16;
   __shared__ __attribute__((aligned(16))) bf Ks[2][TK * PQ];  // [key][d]
   __shared__ __attribute__((aligned(16))) bf Kt[2][DQ * PT];  // [d][key]
@@ -400,51 +401,47 @@ __global__ __launch_bounds__(256) void flashc_bwd_dq_kernel(AttnArgsB a) {
     const bf* K_ = Ks[cur];
     const bf* Kt_ = Kt[cur];
     const bf* V_ = Vs[cur];
-    f32x4 st[4][NQT], dp[4][NQT];
+    // the 64 keys of the tile in two halves of 32 (= one permuted-k chunk each)
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int c = 0; c < 2; ++c) {
+      f32x4 st[2][NQT], dp[2][NQT];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int kt = 2 * c + e;
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+          st[e][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[e][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          const bf16x8 kf = frag_rm(K_, PQ, 16 * kt + fr, cc, fq);
+#pragma unroll
+          for (int t = 0; t < NQT; ++t) st[e][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][cc], st[e][t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCV; ++cc) {
+          const bf16x8 vf = frag_rm(V_, PV, 16 * kt + fr, cc, fq);
+#pragma unroll
+          for (int t = 0; t < NQT; ++t) dp[e][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[t][cc], dp[e][t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fast_exp2(st[e][t][r] - lse2[t]);
+            st[e][t][r] = p * (dp[e][t][r] - dl[t]);
+          }
+      }
+      // dQ^T[d][query] += K^T[d][keys] . dS^T[keys][query]   (keys beyond Nk carry zero K rows)
 #pragma unroll
       for (int t = 0; t < NQT; ++t) {
-        st[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dp[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+        const bf16x8 dsb = pack_tiles(st[0][t], st[1][t]);
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const bf16x8 kf = frag_rm(K_, PQ, 16 * kt + fr, c, fq);
-#pragma unroll
-        for (int t = 0; t < NQT; ++t) st[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][c], st[kt][t], 0, 0, 0);
-      }
-#pragma unroll
-      for (int c = 0; c < NCV; ++c) {
-        const bf16x8 vf = frag_rm(V_, PV, 16 * kt + fr, c, fq);
-#pragma unroll
-        for (int t = 0; t < NQT; ++t) dp[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[t][c], dp[kt][t], 0, 0, 0);
+        for (int u = 0; u < ND; ++u)
+          if (16 * u < a.D) dq[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Kt_, 16 * u + fr, c, fq), dsb, dq[t][u], 0, 0, 0);
       }
     }
-    bf16x8 dsb[NQT][2];
-#pragma unroll
-    for (int t = 0; t < NQT; ++t) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(st[kt][t][r] - lse2[t]);
-          st[kt][t][r] = p * (dp[kt][t][r] - dl[t]);
-        }
-      dsb[t][0] = pack_tiles(st[0][t], st[1][t]);
-      dsb[t][1] = pack_tiles(st[2][t], st[3][t]);
-    }
-    // dQ^T[d][query] += K^T[d][keys] . dS^T[keys][query]   (keys beyond Nk carry zero K rows)
-#pragma unroll
-    for (int u = 0; u < ND; ++u)
-      if (16 * u < a.D) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const bf16x8 kf = frag_perm(Kt_, 16 * u + fr, c, fq);
-#pragma unroll
-          for (int t = 0; t < NQT; ++t) dq[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsb[t][c], dq[t][u], 0, 0, 0);
-        }
-      }
     if (more) {
       sk.store(Ks[cur ^ 1], PQ, Kt[cur ^ 1], 1.f);
       sv.store(Vs[cur ^ 1], PV, nullptr, 1.f);
@@ -472,7 +469,7 @@ __global__ __launch_bounds__(256) void flashc_bwd_dq_kernel(AttnArgsB a) {
 // backward, dK / dV: one workgroup = 64*NKT keys; streams query tiles (optionally only a slice of them: blockIdx.z)
 // ---------------------------------------------------------------------------------------------------------------
 template <int DQ, int DV, int NKT>
-__global__ __launch_bounds__(256) void flashc_bwd_dkv_kernel(AttnArgsB a) {
+__global__ __launch_bounds__(256, ((DQ == 32 && DV == 32) ? 2 : 1)) void flashc_bwd_dkv_kernel(AttnArgsB a) {
   constexpr int PQ = DQ + 8, PV = DV + 8, NC = DQ / 32, NCV = DV / 32, ND = DQ / 16, NU = DV / 16;
   constexpr int NBUF = (DV <= 64) ? 2 : 1;  // the widest instance keeps one LDS stage (two barriers per tile)
   __shared__ __attribute__((aligned(16))) bf Qs[NBUF][64 * PQ];   // [query][d]   (scaled by scale*log2e)
@@ -544,55 +541,53 @@ __global__ __launch_bounds__(256) void flashc_bwd_dkv_kernel(AttnArgsB a) {
     const bf* Qt_ = Qt[cur];
     const bf* G_ = Gs[cur];
     const bf* Gt_ = Gt[cur];
-    f32x4 s[4][NKT], dp[4][NKT];  // rows = queries 16qt + 4fq + r, column = key fr
+    // the 64 queries of the tile in two halves of 32 (= one permuted-k chunk each) to keep the live score registers low
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int c = 0; c < 2; ++c) {
+      f32x4 s[2][NKT], dp[2][NKT];  // rows = queries 32c + 16e + 4fq + r, column = key fr
 #pragma unroll
-      for (int t = 0; t < NKT; ++t) {
-        s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dp[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int e = 0; e < 2; ++e) {
+        const int qt = 2 * c + e;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const bf16x8 qa = frag_rm(Q_, PQ, 16 * qt + fr, c, fq);
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[t][c], s[qt][t], 0, 0, 0);
-      }
-#pragma unroll
-      for (int c = 0; c < NCV; ++c) {
-        const bf16x8 ga = frag_rm(G_, PV, 16 * qt + fr, c, fq);
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) dp[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf[t][c], dp[qt][t], 0, 0, 0);
-      }
-      float l4[4], d4[4];
-      memcpy(l4, &lse_s[cur][16 * qt + 4 * fq], 16);
-      memcpy(d4, &del_s[cur][16 * qt + 4 * fq], 16);
-#pragma unroll
-      for (int t = 0; t < NKT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(s[qt][t][r] - l4[r]);  // queries beyond the slice carry lse = +big -> p = 0
-          s[qt][t][r] = p;
-          dp[qt][t][r] = p * (dp[qt][t][r] - d4[r]);
+        for (int t = 0; t < NKT; ++t) {
+          s[e][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[e][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    }
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      const bf16x8 pb0 = pack_tiles(s[0][t], s[1][t]), pb1 = pack_tiles(s[2][t], s[3][t]);
-      const bf16x8 db0 = pack_tiles(dp[0][t], dp[1][t]), db1 = pack_tiles(dp[2][t], dp[3][t]);
+        for (int cc = 0; cc < NC; ++cc) {
+          const bf16x8 qa = frag_rm(Q_, PQ, 16 * qt + fr, cc, fq);
+#pragma unroll
+          for (int t = 0; t < NKT; ++t) s[e][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[t][cc], s[e][t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cc = 0; cc < NCV; ++cc) {
+          const bf16x8 ga = frag_rm(G_, PV, 16 * qt + fr, cc, fq);
+#pragma unroll
+          for (int t = 0; t < NKT; ++t) dp[e][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf[t][cc], dp[e][t], 0, 0, 0);
+        }
+        float l4[4], d4[4];
+        memcpy(l4, &lse_s[cur][16 * qt + 4 * fq], 16);
+        memcpy(d4, &del_s[cur][16 * qt + 4 * fq], 16);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fast_exp2(s[e][t][r] - l4[r]);  // queries beyond the slice carry lse = +big -> p = 0
+            s[e][t][r] = p;
+            dp[e][t][r] = p * (dp[e][t][r] - d4[r]);
+          }
+      }
       // dV^T[dv][key] += dO^T[dv][queries] . P[queries][key] ;  dK^T[d][key] += Q^T[d][queries] . dS[queries][key]
 #pragma unroll
-      for (int u = 0; u < NU; ++u)
-        if (16 * u < a.Dv) {
-          dv[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Gt_, 16 * u + fr, 0, fq), pb0, dv[t][u], 0, 0, 0);
-          dv[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Gt_, 16 * u + fr, 1, fq), pb1, dv[t][u], 0, 0, 0);
-        }
+      for (int t = 0; t < NKT; ++t) {
+        const bf16x8 pb = pack_tiles(s[0][t], s[1][t]), db = pack_tiles(dp[0][t], dp[1][t]);
 #pragma unroll
-      for (int u = 0; u < ND; ++u)
-        if (16 * u < a.D) {
-          dk[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Qt_, 16 * u + fr, 0, fq), db0, dk[t][u], 0, 0, 0);
-          dk[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Qt_, 16 * u + fr, 1, fq), db1, dk[t][u], 0, 0, 0);
-        }
+        for (int u = 0; u < NU; ++u)
+          if (16 * u < a.Dv) dv[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Gt_, 16 * u + fr, c, fq), pb, dv[t][u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < ND; ++u)
+          if (16 * u < a.D) dk[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Qt_, 16 * u + fr, c, fq), db, dk[t][u], 0, 0, 0);
+      }
     }
     if (NBUF == 2) {
       if (more) store_tile(cur ^ 1);
@@ -685,7 +680,8 @@ int cenet_flashb_bwd(const cenet_attn_t* p, hipStream_t stream) {
   const int cls = pick_b(a.D, a.Dv);
   if (cls < 0) return CENET_EUNSUPPORTED;
   const bool wide_q = a.Nq >= 1024 && cls != 3;
-  const bool wide_k = a.Nk >= 1024 && cls <= 1;
+  const char* ev = getenv("CENET_ATTN_WIDEK");
+  const bool wide_k = a.Nk >= 1024 && cls <= 1 && !(ev && ev[0] == '0');
   dim3 gq(cdiv(a.Nq, wide_q ? 128 : 64), a.B * a.H);
   // few key tiles under many queries (spatial-reduction attention: 49 keys): slice the query range over workgroups and
   // accumulate dK / dV atomically — only when the caller guarantees zero-filled dk / dv
