@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void chan_dot_kernel(const float* __restrict__
   if (threadIdx.x == 0) atomicAdd(&out[c], s);
 }
 
-// ---- out[c] += sum_r a[r, c]  (row-major [R, C]); block = 64 columns x 4 row-lanes, grid (col tiles, row chunks) ---
+// ---- out[c] += sum_r a[r, c]  (row-major [R, C]) ---------------------------------------------------------------------
+// scalar form: block = 64 columns x 4 row-lanes, grid (col tiles, row chunks)
 #define CS_ROWS 256
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ a, float* __restrict__ out, long R, int C) {
   __shared__ float part[4][64];
@@ -150,6 +151,50 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
   part[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < C) atomicAdd(&out[c], part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]);
+}
+// 16-byte form (C % 4 == 0): a thread owns one column quad, TPR threads cover a row slab of 4*TPR columns and the other
+// 256/TPR thread groups take interleaved rows, 4 independent 16-byte loads in flight each
+template <int TPR>
+__global__ __launch_bounds__(256) void col_sum_v4_kernel(const float* __restrict__ a, float* __restrict__ out, long R, int C,
+                                                        int rows_per_block) {
+  constexpr int RL = 256 / TPR;
+  __shared__ float part[RL][TPR * 4];
+  const int q = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+  const int c = (blockIdx.x * TPR + q) * 4;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    long r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) memcpy(v[u], a + (r + u * RL) * C + c, 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += v[u][e];
+    }
+    for (; r < r1; r += RL) {
+      float v[4];
+      memcpy(v, a + r * C + c, 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[rl][q * 4 + e] = s[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < TPR * 4; i += 256) {
+    const int cc = blockIdx.x * TPR * 4 + i;
+    if (cc < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < RL; ++j) t += part[j][i];
+      atomicAdd(&out[cc], t);
+    }
+  }
 }
 
 // ---- out = act(a + b) ; backward from the output sign (LeakyReLU/ReLU preserve sign) -------------------------------
@@ -459,7 +504,21 @@ extern "C" int cenet_chan_dot_acc_f32(const float* a, long sab, const float* b, 
 }
 extern "C" int cenet_col_sum_acc_f32(const float* a, float* out_acc, long R, int C, hipStream_t stream) {
   if (R <= 0 || C <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(col_sum_kernel, dim3(cdiv(C, 64), (unsigned)((R + CS_ROWS - 1) / CS_ROWS)), dim3(256), stream, a, out_acc, R, C);
+  if ((C & 3) == 0 && (((uintptr_t)a) & 15) == 0) {
+    // ~2048 workgroups, each at least 64 rows deep
+    const int quads = C / 4;
+    const int tpr = quads >= 64 ? 64 : (quads >= 32 ? 32 : 16);
+    const int ctiles = cdiv(quads, tpr);
+    long rpb = (R * ctiles + 2047) / 2048;
+    if (rpb < 64) rpb = 64;
+    rpb = (rpb + 15) & ~15L;
+    dim3 grid(ctiles, (unsigned)((R + rpb - 1) / rpb));
+    if (tpr == 64) CENET_LAUNCH((col_sum_v4_kernel<64>), grid, dim3(256), stream, a, out_acc, R, C, (int)rpb);
+    else if (tpr == 32) CENET_LAUNCH((col_sum_v4_kernel<32>), grid, dim3(256), stream, a, out_acc, R, C, (int)rpb);
+    else CENET_LAUNCH((col_sum_v4_kernel<16>), grid, dim3(256), stream, a, out_acc, R, C, (int)rpb);
+  } else {
+    CENET_LAUNCH(col_sum_kernel, dim3(cdiv(C, 64), (unsigned)((R + CS_ROWS - 1) / CS_ROWS)), dim3(256), stream, a, out_acc, R, C);
+  }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -112,10 +112,202 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// ---- 16-byte LayerNorm kernels (C % 4 == 0, 16-byte aligned rows) -------------------------------------------------
+// A row is spread over LPR lanes (16 / 32 / 64), 4 consecutive columns per lane and pass, NP passes; a wave holds
+// 64 / LPR rows at once and a 256-thread workgroup 4 * 64 / LPR rows per step.  Row statistics are LPR-lane shuffles.
+template <int LPR>
+__device__ __forceinline__ float subrow_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+struct f4 {
+  float v[4];
+};
+__device__ __forceinline__ f4 ld4(const float* p) {
+  f4 r;
+  memcpy(r.v, p, 16);
+  return r;
+}
+__device__ __forceinline__ void st4(float* p, const f4& r) { memcpy(p, r.v, 16); }
+
+template <int LPR, int NP>
+__global__ __launch_bounds__(256) void ln_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int rows, int C,
+                                                       float eps, int steps) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, l = lane % LPR;
+  f4 gm[NP], bt[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c = 4 * (l + LPR * p);
+    if (c < C) {
+      gm[p] = ld4(gamma + c);
+      bt[p] = ld4(beta + c);
+    }
+  }
+  const float invC = 1.f / C;
+  for (int it = 0; it < steps; ++it) {
+    const long row = ((long)blockIdx.x * steps + it) * (4 * RPW) + wave * RPW + sub;
+    const bool rok = row < rows;
+    f4 v[NP];
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = 4 * (l + LPR * p);
+      if (rok && c < C) {
+        v[p] = ld4(x + row * C + c);
+        s += (v[p].v[0] + v[p].v[1]) + (v[p].v[2] + v[p].v[3]);
+      } else {
+        v[p].v[0] = v[p].v[1] = v[p].v[2] = v[p].v[3] = 0.f;
+      }
+    }
+    const float mu = subrow_sum<LPR>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = 4 * (l + LPR * p);
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = v[p].v[e] - mu;
+          q += d * d;
+        }
+      }
+    }
+    const float rs = rsqrtf(subrow_sum<LPR>(q) * invC + eps);
+    if (rok) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int c = 4 * (l + LPR * p);
+        if (c < C) {
+          f4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o.v[e] = (v[p].v[e] - mu) * rs * gm[p].v[e] + bt[p].v[e];
+          st4(y + row * C + c, o);
+        }
+      }
+      if (l == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+      }
+    }
+  }
+}
+
+template <int LPR, int NP>
+__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float* __restrict__ dx,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
+                                                       int steps) {
+  constexpr int RPW = 64 / LPR;
+  __shared__ float red[2][4][NP * LPR * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, l = lane % LPR;
+  f4 gm[NP], dg[NP], db[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c = 4 * (l + LPR * p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dg[p].v[e] = db[p].v[e] = gm[p].v[e] = 0.f;
+    if (c < C) gm[p] = ld4(gamma + c);
+  }
+  const float invC = 1.f / C;
+#pragma unroll 2
+  for (int it = 0; it < steps; ++it) {
+    const long row = ((long)blockIdx.x * steps + it) * (4 * RPW) + wave * RPW + sub;
+    const bool rok = row < rows;
+    const float mu = rok ? mean[row] : 0.f, rs = rok ? rstd[row] : 0.f;
+    f4 xh[NP], g[NP];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = 4 * (l + LPR * p);
+      if (rok && c < C) {
+        xh[p] = ld4(x + row * C + c);
+        g[p] = ld4(dy + row * C + c);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xh[p].v[e] = g[p].v[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[p].v[e] = (rok && c < C) ? (xh[p].v[e] - mu) * rs : 0.f;
+        const float gg = g[p].v[e] * gm[p].v[e];
+        s1 += gg;
+        s2 += gg * xh[p].v[e];
+        dg[p].v[e] += g[p].v[e] * xh[p].v[e];
+        db[p].v[e] += g[p].v[e];
+      }
+    }
+    s1 = subrow_sum<LPR>(s1) * invC;
+    s2 = subrow_sum<LPR>(s2) * invC;
+    if (rok) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int c = 4 * (l + LPR * p);
+        if (c < C) {
+          f4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o.v[e] = rs * (g[p].v[e] * gm[p].v[e] - s1 - xh[p].v[e] * s2);
+          st4(dx + row * C + c, o);
+        }
+      }
+    }
+  }
+  // column partials: rows held by the same wave (lanes l, l + LPR, ...), then the four waves through LDS
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        dg[p].v[e] += __shfl_xor(dg[p].v[e], o);
+        db[p].v[e] += __shfl_xor(db[p].v[e], o);
+      }
+      if (sub == 0) {
+        red[0][wave][(p * LPR + l) * 4 + e] = dg[p].v[e];
+        red[1][wave][(p * LPR + l) * 4 + e] = db[p].v[e];
+      }
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {  // column c sits at quad c/4 = l + LPR*p -> index (p*LPR + l)*4 + e == c
+    atomicAdd(&dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(&dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+static inline bool ln_v4_ok(const void* a, const void* b, const void* c, const void* d, int C) {
+  return (C & 3) == 0 && C <= 512 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0);
+}
+// rows per workgroup step = 4 * 64 / LPR; steps per workgroup chosen to keep >= ~1024 workgroups while amortising the
+// per-workgroup column reduction of the backward pass
+static inline int ln_steps(int rows, int rows_per_step) {
+  long st = rows / ((long)rows_per_step * 1024);
+  if (st < 1) st = 1;
+  if (st > 8) st = 8;
+  return (int)st;
+}
+
 extern "C" int cenet_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                        float* rstd, int rows, int C, float eps, hipStream_t stream) {
   if (rows <= 0 || C <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  if (ln_v4_ok(x, gamma, beta, y, C)) {
+#define CENET_LNF(LPRv, NPv)                                                                                          \
+  {                                                                                                                   \
+    const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps);                                                          \
+    CENET_LAUNCH((ln_fwd_v4_kernel<LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, x, gamma, beta, y, mean, rstd, \
+                 rows, C, eps, st);                                                                                   \
+  }
+    if (C <= 64) CENET_LNF(16, 1)
+    else if (C <= 128) CENET_LNF(32, 1)
+    else if (C <= 256) CENET_LNF(64, 1)
+    else CENET_LNF(64, 2)
+#undef CENET_LNF
+  } else {
+    CENET_LAUNCH(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -125,6 +317,21 @@ extern "C" int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, cons
                                            int C, hipStream_t stream) {
   if (rows <= 0 || C <= 0) return CENET_EINVAL;
   if (C > 512) return CENET_EUNSUPPORTED;
+  if (ln_v4_ok(dy, x, gamma, dx, C)) {
+#define CENET_LNB(LPRv, NPv)                                                                                          \
+  {                                                                                                                   \
+    const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps);                                                          \
+    CENET_LAUNCH((ln_bwd_v4_kernel<LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, \
+                 dgamma_acc, dbeta_acc, rows, C, st);                                                                 \
+  }
+    if (C <= 64) CENET_LNB(16, 1)
+    else if (C <= 128) CENET_LNB(32, 1)
+    else if (C <= 256) CENET_LNB(64, 1)
+    else CENET_LNB(64, 2)
+#undef CENET_LNB
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   dim3 grid(cdiv(rows, LN_ROWS_PER_BLOCK));
 #define CENET_LN(MJ, RP)                                                                                            \
   CENET_LAUNCH((layernorm_bwd_kernel<MJ, RP>), grid, dim3(256), stream, dy, x, gamma, mean, rstd, dx, dgamma_acc, dbeta_acc, \
@@ -256,6 +463,168 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ---- 16-byte BatchNorm kernels (HW % 4 == 0, 16-byte aligned planes) -----------------------------------------------------
+// Reductions walk the channel's B*HW/4 quads flat (grid-stride, four independent 16-byte loads in flight per thread).
+__global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restrict__ x, long sb, int B, int HW,
+                                                           float* __restrict__ ws) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, nq = HW >> 2;
+  const float* xc = x + (long)c * HW;
+  const float shift = xc[0];
+  const int total = B * nq, stride = gridDim.y * 256;
+  float s1 = 0.f, s2 = 0.f;
+  for (int q0 = blockIdx.y * 256 + threadIdx.x; q0 < total; q0 += 4 * stride) {
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u * stride;
+      if (q < total) {
+        const int b = q / nq, qi = q - b * nq;
+        memcpy(v[u], xc + (long)b * sb + 4 * qi, 16);
+      } else {
+        v[u][0] = v[u][1] = v[u][2] = v[u][3] = shift;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[u][e] - shift;
+        s1 += d;
+        s2 += d * d;
+      }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[2 * c], s1);
+    atomicAdd(&ws[2 * c + 1], s2);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restrict__ x, long sxb, float* __restrict__ y, long syb,
+                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                         float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int act, float slope, int C, int HW) {
+  const int bc = blockIdx.x;
+  const int b = bc / C, c = bc - b * C;
+  const float sc = gamma[c] * rsqrtf(var[c] + eps);
+  const float sh = beta[c] - mean[c] * sc;
+  const float* xp = x + (long)b * sxb + (long)c * HW;
+  float* yp = y + (long)b * syb + (long)c * HW;
+  const int nq = HW >> 2;
+  for (int q = blockIdx.y * blockDim.x + threadIdx.x; q < nq; q += gridDim.y * blockDim.x) {
+    float v[4];
+    memcpy(v, xp + 4 * q, 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_fwd(act, v[e] * sc + sh, slope);
+    memcpy(yp + 4 * q, v, 16);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __restrict__ dy, long sgb,
+                                                               const float* __restrict__ x, long sxb,
+                                                               const float* __restrict__ mean, const float* __restrict__ var,
+                                                               float eps, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int act, float slope, int B,
+                                                               int HW, float* __restrict__ ws) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, nq = HW >> 2;
+  const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
+  const int total = B * nq, stride = gridDim.y * 256;
+  float s1 = 0.f, s2 = 0.f;
+  for (int q0 = blockIdx.y * 256 + threadIdx.x; q0 < total; q0 += 2 * stride) {
+    float xv[2][4], gv[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = q0 + u * stride;
+      if (q < total) {
+        const int b = q / nq, qi = q - b * nq;
+        memcpy(xv[u], x + (long)b * sxb + (long)c * HW + 4 * qi, 16);
+        memcpy(gv[u], dy + (long)b * sgb + (long)c * HW + 4 * qi, 16);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xv[u][e] = mu;
+          gv[u][e] = 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[u][e] - mu) * rs;
+        float g = gv[u][e];
+        if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
+        s1 += g;
+        s2 += g * xh;
+      }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[2 * c], s1);
+    atomicAdd(&ws[2 * c + 1], s2);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ dy, long sgb, const float* __restrict__ x,
+                                                             long sxb, float* __restrict__ dx, long sdb,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             float eps, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int act, float slope, int C,
+                                                             int HW, float n, const float* __restrict__ ws, float* dgamma,
+                                                             float* dbeta) {
+  const int bc = blockIdx.x;
+  const int b = bc / C, c = bc - b * C;
+  const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
+  const float s1 = ws[2 * c], s2 = ws[2 * c + 1];
+  const float m1 = s1 / n, m2 = s2 / n;
+  const float* xp = x + (long)b * sxb + (long)c * HW;
+  const float* gp = dy + (long)b * sgb + (long)c * HW;
+  float* dp = dx + (long)b * sdb + (long)c * HW;
+  const int nq = HW >> 2;
+  for (int q = blockIdx.y * blockDim.x + threadIdx.x; q < nq; q += gridDim.y * blockDim.x) {
+    float xv[4], gv[4];
+    memcpy(xv, xp + 4 * q, 16);
+    memcpy(gv, gp + 4 * q, 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xv[e] - mu) * rs;
+      float g = gv[e];
+      if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
+      gv[e] = gm * rs * (g - m1 - xh * m2);
+    }
+    memcpy(dp + 4 * q, gv, 16);
+  }
+  if (b == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    atomicAdd(&dgamma[c], s2);
+    atomicAdd(&dbeta[c], s1);
+  }
+}
+
+static inline bool bn_v4_ok(int HW, const void* p0, long s0, const void* p1, long s1, const void* p2, long s2) {
+  return (HW & 3) == 0 && ((s0 | s1 | s2) & 3) == 0 && ((((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0);
+}
+// threads per plane workgroup and plane chunks of the element-wise passes (nq = quads per plane)
+static inline void bn_plane_launch(int nq, int* threads, int* chunks) {
+  *threads = nq <= 64 ? 64 : (nq <= 128 ? 128 : 256);
+  int ch = cdiv(nq, *threads * 2);
+  if (ch > 16) ch = 16;
+  if (ch < 1) ch = 1;
+  *chunks = ch;
+}
+// workgroups per channel of the reductions: ~2048 in all, each at least 1024 quads deep
+static inline int bn_splits_v4(int C, long quads) {
+  long want = 2048 / (C > 0 ? C : 1);
+  long maxs = (quads + 1023) / 1024;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  return (int)want;
+}
+
 static inline int bn_splits(int C, long total) {
   long want = 1024 / (C > 0 ? C : 1);
   long maxs = (total + 2047) / 2048;
@@ -272,7 +641,10 @@ extern "C" int cenet_bn_stats_f32(const float* x, long sb, int B, int C, int HW,
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   if (cenet_zero_async(ws, 2L * C, stream) != CENET_OK) return CENET_EINVAL;
   const long total = (long)B * HW;
-  CENET_LAUNCH(bn_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, x, sb, B, HW, ws);
+  if (bn_v4_ok(HW, x, sb, x, sb, x, sb))
+    CENET_LAUNCH(bn_partial_v4_kernel, dim3(C, bn_splits_v4(C, total / 4)), dim3(256), stream, x, sb, B, HW, ws);
+  else
+    CENET_LAUNCH(bn_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, x, sb, B, HW, ws);
   CENET_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), stream, x, HW, (const float*)ws, C, (float)total, mean, var,
                running_mean, running_var, momentum, num_batches_tracked);
   CENET_CHECK_LAUNCH();
@@ -283,10 +655,17 @@ extern "C" int cenet_bn_apply_f32(const float* x, long sxb, float* y, long syb, 
                                   float eps, const float* gamma, const float* beta, int act, float slope, int B, int C,
                                   int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  int chunks = cdiv(HW, 1024);
-  if (chunks > 64) chunks = 64;
-  CENET_LAUNCH(bn_apply_kernel, dim3(B * C, chunks), dim3(256), stream, x, sxb, y, syb, mean, var, eps, gamma, beta, act,
-               slope, C, HW);
+  if (bn_v4_ok(HW, x, sxb, y, syb, x, sxb)) {
+    int threads, chunks;
+    bn_plane_launch(HW / 4, &threads, &chunks);
+    CENET_LAUNCH(bn_apply_v4_kernel, dim3(B * C, chunks), dim3(threads), stream, x, sxb, y, syb, mean, var, eps, gamma, beta,
+                 act, slope, C, HW);
+  } else {
+    int chunks = cdiv(HW, 1024);
+    if (chunks > 64) chunks = 64;
+    CENET_LAUNCH(bn_apply_kernel, dim3(B * C, chunks), dim3(256), stream, x, sxb, y, syb, mean, var, eps, gamma, beta, act,
+                 slope, C, HW);
+  }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -298,12 +677,21 @@ extern "C" int cenet_bn_bwd_acc_f32(const float* dy, long sgb, const float* x, l
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   if (cenet_zero_async(ws, 2L * C, stream) != CENET_OK) return CENET_EINVAL;
   const long total = (long)B * HW;
-  CENET_LAUNCH(bn_bwd_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma,
-               beta, act, slope, B, HW, ws);
-  int chunks = cdiv(HW, 1024);
-  if (chunks > 64) chunks = 64;
-  CENET_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma,
-               beta, act, slope, C, HW, (float)total, (const float*)ws, dgamma_acc, dbeta_acc);
+  if (bn_v4_ok(HW, dy, sgb, x, sxb, dx, sdb)) {
+    CENET_LAUNCH(bn_bwd_partial_v4_kernel, dim3(C, bn_splits_v4(C, total / 4)), dim3(256), stream, dy, sgb, x, sxb, mean, var,
+                 eps, gamma, beta, act, slope, B, HW, ws);
+    int threads, chunks;
+    bn_plane_launch(HW / 4, &threads, &chunks);
+    CENET_LAUNCH(bn_bwd_apply_v4_kernel, dim3(B * C, chunks), dim3(threads), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps,
+                 gamma, beta, act, slope, C, HW, (float)total, (const float*)ws, dgamma_acc, dbeta_acc);
+  } else {
+    CENET_LAUNCH(bn_bwd_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma,
+                 beta, act, slope, B, HW, ws);
+    int chunks = cdiv(HW, 1024);
+    if (chunks > 64) chunks = 64;
+    CENET_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma,
+                 beta, act, slope, C, HW, (float)total, (const float*)ws, dgamma_acc, dbeta_acc);
+  }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -1,0 +1,134 @@
+"""Kernel-level checks of the bandwidth-bound helpers (16-byte and scalar forms) against plain PyTorch fp32:
+LayerNorm fwd/bwd, column sums, BatchNorm statistics / apply / backward, depthwise-conv weight gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from backend import dev  # noqa: F401
+from cenet_amd import kern
+
+
+# C = 50 exercises the scalar fallback; 320 and 512 the two-pass form; rows not a multiple of the workgroup step
+@pytest.mark.parametrize("rows,C", [(37, 64), (70, 128), (33, 256), (45, 320), (19, 512), (21, 50)])
+def test_layernorm_fwd_bwd(dev, rows, C):
+    g = torch.Generator().manual_seed(rows * 1000 + C)
+    x = torch.randn(rows, C, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    dy = torch.randn(rows, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    ref.backward(dy)
+    xd, gd, bd, dyd = (t.to(dev) for t in (x, gamma, beta, dy))
+    y, mean, rstd = torch.empty_like(xd), torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    kern.layernorm_fwd(xd, gd, bd, y, mean, rstd, rows, C, 1e-6)
+    torch.testing.assert_close(y.cpu(), ref.detach(), rtol=1e-5, atol=2e-5)
+    dx, dg, db = torch.empty_like(xd), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    kern.layernorm_bwd(dyd, xd, gd, mean, rstd, dx, dg, db, rows, C)
+    torch.testing.assert_close(dx.cpu(), xr.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("R,C", [(300, 64), (1000, 128), (129, 320), (77, 2048), (513, 30), (5, 4)])
+def test_col_sum_accumulates(dev, R, C):
+    g = torch.Generator().manual_seed(R + C)
+    a = torch.randn(R, C, generator=g)
+    out0 = torch.randn(C, generator=g)
+    out = out0.clone().to(dev)
+    kern.col_sum(a.to(dev), out, R, C)
+    torch.testing.assert_close(out.cpu(), out0 + a.sum(0), rtol=1e-4, atol=1e-4)
+
+
+# HW = 196 / 784: 16-byte kernels (64- and 256-thread plane workgroups); HW = 49: scalar fallback; Ctot > C: the input is a
+# channel slice of a wider tensor (batch stride != C*HW)
+@pytest.mark.parametrize("B,C,HW,Ctot,act", [(3, 5, 196, 5, "none"), (2, 4, 784, 6, "relu"), (4, 3, 49, 3, "relu"),
+                                             (2, 2, 2500, 2, "lrelu")])
+def test_batchnorm_train_fwd_bwd(dev, B, C, HW, Ctot, act):
+    g = torch.Generator().manual_seed(B * 100 + HW)
+    xfull = torch.randn(B, Ctot, HW, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    dy = torch.randn(B, C, HW, generator=g)
+    slope = 0.2
+    xr = xfull[:, :C].clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    pre = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    ref = {"none": pre, "relu": F.relu(pre), "lrelu": F.leaky_relu(pre, slope)}[act]
+    ref.backward(dy)
+    xd = xfull.to(dev)
+    sxb = Ctot * HW
+    mean, var, ws = (torch.empty(n, device=dev) for n in (C, C, 2 * C))
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+    kern.bn_stats(xd, sxb, B, C, HW, ws, mean, var, rm, rv, 0.1, nbt)
+    torch.testing.assert_close(mean.cpu(), xr.detach().transpose(0, 1).reshape(C, -1).mean(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(var.cpu(), xr.detach().transpose(0, 1).reshape(C, -1).var(1, unbiased=False), rtol=1e-4, atol=1e-5)
+    assert int(nbt.item()) == 1
+    y = torch.empty(B, C, HW, device=dev)
+    kern.bn_apply(xd, sxb, y, C * HW, mean, var, 1e-5, gamma.to(dev), beta.to(dev), act, slope, B, C, HW)
+    torch.testing.assert_close(y.cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    dx = torch.empty(B, C, HW, device=dev)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    kern.bn_bwd(dy.to(dev), C * HW, xd, sxb, dx, C * HW, mean, var, 1e-5, gamma.to(dev), beta.to(dev), act, slope, B, C, HW,
+                ws, dg, db)
+    torch.testing.assert_close(dx.cpu(), xr.grad, rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-3, atol=1e-4)
+
+
+def _dw_ref(x, w, b, dil):
+    return F.conv2d(x, w.view(-1, 1, 3, 3), b, padding=dil, dilation=dil, groups=x.shape[1])
+
+
+# W % 4 == 0: 16-byte NCHW kernels (rows of 8 / 12 pixels, dilation 1..3 reaching past both row ends); W = 7: scalar form
+@pytest.mark.parametrize("B,C,H,W,dil", [(2, 3, 6, 8, 1), (1, 2, 9, 12, 3), (2, 2, 5, 8, 2), (2, 3, 7, 7, 1)])
+def test_dwconv_nchw_fwd_dgrad_wgrad(dev, B, C, H, W, dil):
+    g = torch.Generator().manual_seed(B + C + H + W + dil)
+    x = torch.randn(B, C, H, W, generator=g)
+    w, b = torch.randn(C, 9, generator=g) * 0.3, torch.randn(C, generator=g)
+    dy = torch.randn(B, C, H, W, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = _dw_ref(xr, wr, br, dil)
+    F.gelu(pre).backward(dy)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    y, a = torch.empty_like(xd), torch.empty_like(xd)
+    kern.dw_nchw(xd, C * H * W, wd, bd, y, C * H * W, a, C * H * W, B, C, H, W, dil, False, act="gelu")
+    torch.testing.assert_close(y.cpu(), pre.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a.cpu(), F.gelu(pre.detach()), rtol=1e-4, atol=1e-5)
+    # gradient w.r.t. the pre-activation, then the data / weight gradients of the convolution itself
+    p2 = pre.detach().clone().requires_grad_(True)
+    F.gelu(p2).backward(dy)
+    gp = p2.grad
+    dx = torch.empty_like(xd)
+    kern.dw_nchw(gp.to(dev), C * H * W, wd, None, dx, C * H * W, None, 0, B, C, H, W, dil, True)
+    torch.testing.assert_close(dx.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    dw, db = torch.zeros(C, 9, device=dev), torch.zeros(C, device=dev)
+    kern.dw_wgrad_nchw(xd, C * H * W, gp.to(dev), C * H * W, dw, db, B, C, H, W, dil)
+    torch.testing.assert_close(dw.cpu(), wr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
+
+
+# C % 4 == 0: 16-byte token-layout kernels (C = 8: one partly filled wave; C = 260: two workgroup slabs); C = 6: scalar form
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 5, 9), (1, 260, 3, 10), (2, 6, 4, 5)])
+def test_dwconv_tok_fwd_dgrad_wgrad(dev, B, C, H, W):
+    g = torch.Generator().manual_seed(B + C + H + W)
+    xt = torch.randn(B, H * W, C, generator=g)
+    w, b = torch.randn(C, 9, generator=g) * 0.3, torch.randn(C, generator=g)
+    dyt = torch.randn(B, H * W, C, generator=g)
+    to_nchw = lambda t: t.transpose(1, 2).reshape(B, C, H, W)
+    to_tok = lambda t: t.reshape(B, C, H * W).transpose(1, 2)
+    xr, wr, br = to_nchw(xt).clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = _dw_ref(xr, wr, br, 1)
+    pre.backward(to_nchw(dyt))
+    xd, wd, bd, gd = xt.to(dev), w.to(dev), b.to(dev), dyt.contiguous().to(dev)
+    y, a = torch.empty_like(xd), torch.empty_like(xd)
+    kern.dw_tok(xd, wd, bd, y, a, B, C, H, W, False, act="gelu")
+    torch.testing.assert_close(y.cpu(), to_tok(pre.detach()), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a.cpu(), F.gelu(to_tok(pre.detach())), rtol=1e-4, atol=1e-5)
+    dx = torch.empty_like(xd)
+    kern.dw_tok(gd, wd, None, dx, None, B, C, H, W, True)
+    torch.testing.assert_close(dx.cpu(), to_tok(xr.grad), rtol=1e-4, atol=1e-5)
+    dw, db = torch.zeros(C, 9, device=dev), torch.zeros(C, device=dev)
+    kern.dw_wgrad_tok(xd, gd, dw, db, B, C, H, W)
+    torch.testing.assert_close(dw.cpu(), wr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
