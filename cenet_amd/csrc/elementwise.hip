@@ -367,38 +367,42 @@ __global__ __launch_bounds__(256) void diffattn_combine_bwd_kernel(const float* 
   __shared__ float part[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int vpw = 64 / sub, sl = lane & (sub - 1);
-  const long vec = ((long)blockIdx.x * 4 + wave) * vpw + lane / sub;
-  const bool ok = vec < nvec;
-  const int n = ok ? (int)(vec % N) : 0;
-  const long bh = ok ? vec / N : 0;
-  const int h = (int)(bh % H);
-  const long b = bh / H;
   const float lm = lam[0];
-  const long off0 = (((b * 2 * H) + 2 * h) * N + n) * (long)dv;
-  const float* u0 = U + off0;
-  const float* u1 = u0 + (long)N * dv;
-  const float* g = dout + (b * N + n) * (long)(H * dv) + (long)h * dv;
-  float ss = 0.f, ga = 0.f;
-  if (ok)
-    for (int d = sl; d < dv; d += sub) {
-      const float av = u0[d] - lm * u1[d];
-      ss += av * av;
-      ga += g[d] * av;
-    }
-  ss = subwave_sum(ss, sub);
-  ga = subwave_sum(ga, sub);
-  const float r = rsqrtf(ss / dv + eps);
-  const float k = r * r * ga / dv;
   float dl = 0.f;
-  if (ok) {
-    float* d0 = dU + off0;
-    float* d1 = d0 + (long)N * dv;
-    for (int d = sl; d < dv; d += sub) {
-      const float av = u0[d] - lm * u1[d];
-      const float da = post * r * (g[d] - av * k);
-      d0[d] = da;
-      d1[d] = -lm * da;
-      dl -= da * u1[d];
+  // grid-stride over the (b, h, n) vectors: one dlam atomic per workgroup, and few workgroups (the atomics all hit one
+  // address and serialise at ~12 ns each)
+  for (long v0 = (long)blockIdx.x * 4 * vpw; v0 < nvec; v0 += (long)gridDim.x * 4 * vpw) {
+    const long vec = v0 + wave * vpw + lane / sub;
+    const bool ok = vec < nvec;
+    const int n = ok ? (int)(vec % N) : 0;
+    const long bh = ok ? vec / N : 0;
+    const int h = (int)(bh % H);
+    const long b = bh / H;
+    const long off0 = (((b * 2 * H) + 2 * h) * N + n) * (long)dv;
+    const float* u0 = U + off0;
+    const float* u1 = u0 + (long)N * dv;
+    const float* g = dout + (b * N + n) * (long)(H * dv) + (long)h * dv;
+    float ss = 0.f, ga = 0.f;
+    if (ok)
+      for (int d = sl; d < dv; d += sub) {
+        const float av = u0[d] - lm * u1[d];
+        ss += av * av;
+        ga += g[d] * av;
+      }
+    ss = subwave_sum(ss, sub);
+    ga = subwave_sum(ga, sub);
+    const float r = rsqrtf(ss / dv + eps);
+    const float k = r * r * ga / dv;
+    if (ok) {
+      float* d0 = dU + off0;
+      float* d1 = d0 + (long)N * dv;
+      for (int d = sl; d < dv; d += sub) {
+        const float av = u0[d] - lm * u1[d];
+        const float da = post * r * (g[d] - av * k);
+        d0[d] = da;
+        d1[d] = -lm * da;
+        dl -= da * u1[d];
+      }
     }
   }
   dl = wave_sum(dl);
@@ -593,8 +597,10 @@ extern "C" int cenet_diffattn_combine_bwd_acc_f32(const float* U, const float* l
   long nvec = (long)B * H * N;
   const int sub = dv <= 16 ? 16 : (dv <= 32 ? 32 : 64);
   const long per_block = 4L * (64 / sub);
-  CENET_LAUNCH(diffattn_combine_bwd_kernel, dim3((unsigned)((nvec + per_block - 1) / per_block)), dim3(256), stream, U, lam3, dout,
-               dU, dlam_acc, H, N, dv, eps, post, nvec, sub);
+  long blocks = (nvec + per_block - 1) / per_block;
+  if (blocks > 2048) blocks = 2048;
+  CENET_LAUNCH(diffattn_combine_bwd_kernel, dim3((unsigned)blocks), dim3(256), stream, U, lam3, dout, dU, dlam_acc, H, N, dv, eps,
+               post, nvec, sub);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -48,14 +48,16 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restric
         }
       }
   }
-  for (int c = 0; c < K; ++c) {
-    float a0 = block_sum(part[c], red), a1 = block_sum(part[LOSS_MAXK + c], red), a2 = block_sum(part[2 * LOSS_MAXK + c], red);
-    if (threadIdx.x == 0) {
-      atomicAdd(&acc[c], a0);
-      atomicAdd(&acc[K + c], a1);
-      atomicAdd(&acc[2 * K + c], a2);
+#pragma unroll  // static indices: part[] must stay in registers
+  for (int c = 0; c < LOSS_MAXK; ++c)
+    if (c < K) {
+      float a0 = block_sum(part[c], red), a1 = block_sum(part[LOSS_MAXK + c], red), a2 = block_sum(part[2 * LOSS_MAXK + c], red);
+      if (threadIdx.x == 0) {
+        atomicAdd(&acc[c], a0);
+        atomicAdd(&acc[K + c], a1);
+        atomicAdd(&acc[2 * K + c], a2);
+      }
     }
-  }
   float ce = block_sum(part[3 * LOSS_MAXK], red);
   if (threadIdx.x == 0) atomicAdd(&acc[3 * K], ce);
 }

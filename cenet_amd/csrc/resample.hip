@@ -51,6 +51,7 @@ __device__ __forceinline__ void bil_range(int i, float scale, int align, int out
 }
 
 // gather form of the backward: one thread per INPUT pixel sums the output gradients whose taps touch it
+#define BIL_MAXR 16
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, long sgb, float* __restrict__ dx,
                                                           long sdb, int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
                                                           int align) {
@@ -63,21 +64,48 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     bil_range(iy, sh, align, Ho, ylo, yhi);
     bil_range(ix, sw, align, Wo, xlo, xhi);
     float acc = 0.f;
-    for (int oy = ylo; oy < yhi; ++oy) {
-      int y0, y1;
-      float ly;
-      bil_coord(oy, sh, align, Hi, y0, y1, ly);
-      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
-      if (wy == 0.f) continue;
-      float row = 0.f;
-      for (int ox = xlo; ox < xhi; ++ox) {
-        int x0, x1;
-        float lx;
-        bil_coord(ox, sw, align, Wi, x0, x1, lx);
-        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-        if (wx != 0.f) row += wx * gp[oy * Wo + ox];
+    if (xhi - xlo <= BIL_MAXR) {
+      // separable weights: the x taps of this input column are computed once, not once per output row
+      float wxs[BIL_MAXR];
+#pragma unroll
+      for (int k = 0; k < BIL_MAXR; ++k) {
+        wxs[k] = 0.f;
+        if (xlo + k < xhi) {
+          int x0, x1;
+          float lx;
+          bil_coord(xlo + k, sw, align, Wi, x0, x1, lx);
+          wxs[k] = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        }
       }
-      acc += wy * row;
+      for (int oy = ylo; oy < yhi; ++oy) {
+        int y0, y1;
+        float ly;
+        bil_coord(oy, sh, align, Hi, y0, y1, ly);
+        const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+#pragma unroll
+        for (int k = 0; k < BIL_MAXR; ++k)
+          if (xlo + k < xhi) row += wxs[k] * gp[oy * Wo + xlo + k];
+        acc += wy * row;
+      }
+    } else {
+      for (int oy = ylo; oy < yhi; ++oy) {
+        int y0, y1;
+        float ly;
+        bil_coord(oy, sh, align, Hi, y0, y1, ly);
+        const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = xlo; ox < xhi; ++ox) {
+          int x0, x1;
+          float lx;
+          bil_coord(ox, sw, align, Wi, x0, x1, lx);
+          const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+          if (wx != 0.f) row += wx * gp[oy * Wo + ox];
+        }
+        acc += wy * row;
+      }
     }
     dp[p] = acc;
   }
