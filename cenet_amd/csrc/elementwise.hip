@@ -137,6 +137,37 @@ __global__ __launch_bounds__(256) void chan_dot_kernel(const float* __restrict__
   if (threadIdx.x == 0) atomicAdd(&out[c], s);
 }
 
+// 16-byte form (HW % 4 == 0): flat grid-stride walk over the channel's B*HW/4 quads, two independent loads in flight
+__global__ __launch_bounds__(256) void chan_dot_v4_kernel(const float* __restrict__ a, long sab, const float* __restrict__ bb,
+                                                         long sbb, float* __restrict__ out, int B, int HW) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, nq = HW >> 2, total = B * nq, stride = gridDim.y * 256;
+  float s = 0.f;
+  for (int q0 = blockIdx.y * 256 + threadIdx.x; q0 < total; q0 += 2 * stride) {
+    float av[2][4], bv[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = q0 + u * stride;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        av[u][e] = 0.f;
+        bv[u][e] = 1.f;
+      }
+      if (q < total) {
+        const int b = q / nq, qi = q - b * nq;
+        memcpy(av[u], a + (long)b * sab + (long)c * HW + 4 * qi, 16);
+        if (bb) memcpy(bv[u], bb + (long)b * sbb + (long)c * HW + 4 * qi, 16);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += av[u][e] * bv[u][e];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(&out[c], s);
+}
+
 // ---- out[c] += sum_r a[r, c]  (row-major [R, C]) ---------------------------------------------------------------------
 // scalar form: block = 64 columns x 4 row-lanes, grid (col tiles, row chunks)
 #define CS_ROWS 256
@@ -502,7 +533,15 @@ extern "C" int cenet_chan_dot_acc_f32(const float* a, long sab, const float* b, 
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
-  CENET_LAUNCH(chan_dot_kernel, dim3(C, (unsigned)want), dim3(256), stream, a, sab, b, sbb, out_acc, B, HW);
+  if ((HW & 3) == 0 && ((sab | sbb) & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0)) {
+    long w4 = 2048 / C, m4 = (total / 4 + 1023) / 1024;
+    if (w4 > m4) w4 = m4;
+    if (w4 < 1) w4 = 1;
+    if (w4 > 256) w4 = 256;
+    CENET_LAUNCH(chan_dot_v4_kernel, dim3(C, (unsigned)w4), dim3(256), stream, a, sab, b, sbb, out_acc, B, HW);
+  } else {
+    CENET_LAUNCH(chan_dot_kernel, dim3(C, (unsigned)want), dim3(256), stream, a, sab, b, sbb, out_acc, B, HW);
+  }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -7,6 +7,10 @@
 #include "../../include/cenet_hip.h"
 
 #define LOSS_MAXK 16
+// the partial sums of a workgroup land in one of LOSS_SLOTS replicas of acc, LOSS_SLOT_STRIDE floats (256 bytes) apart: float
+// atomics onto one cache line serialise (~12 ns each), so thousands of workgroups must not share a line
+#define LOSS_SLOTS 16
+#define LOSS_SLOT_STRIDE 64
 
 // acc layout: [0..K) intersect, [K..2K) z_sum (p^2), [2K..3K) y_sum (t), [3K] ce_sum
 __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
@@ -48,22 +52,29 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restric
         }
       }
   }
+  float* slot = acc + (blockIdx.x % LOSS_SLOTS) * LOSS_SLOT_STRIDE;
 #pragma unroll  // static indices: part[] must stay in registers
   for (int c = 0; c < LOSS_MAXK; ++c)
     if (c < K) {
       float a0 = block_sum(part[c], red), a1 = block_sum(part[LOSS_MAXK + c], red), a2 = block_sum(part[2 * LOSS_MAXK + c], red);
       if (threadIdx.x == 0) {
-        atomicAdd(&acc[c], a0);
-        atomicAdd(&acc[K + c], a1);
-        atomicAdd(&acc[2 * K + c], a2);
+        atomicAdd(&slot[c], a0);
+        atomicAdd(&slot[K + c], a1);
+        atomicAdd(&slot[2 * K + c], a2);
       }
     }
   float ce = block_sum(part[3 * LOSS_MAXK], red);
-  if (threadIdx.x == 0) atomicAdd(&acc[3 * K], ce);
+  if (threadIdx.x == 0) atomicAdd(&slot[3 * K], ce);
 }
 
-__global__ void dice_ce_finalize_kernel(const float* __restrict__ acc, float* __restrict__ loss, int K, float npix,
+__global__ void dice_ce_finalize_kernel(float* __restrict__ acc, float* __restrict__ loss, int K, float npix,
                                         float w_dice, float w_ce) {
+  if (threadIdx.x < 3 * K + 1) {  // fold the replicas into slot 0 (what the backward kernel reads)
+    float t = 0.f;
+    for (int sidx = 0; sidx < LOSS_SLOTS; ++sidx) t += acc[sidx * LOSS_SLOT_STRIDE + threadIdx.x];
+    acc[threadIdx.x] = t;
+  }
+  __syncthreads();
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float d = 0.f;
     for (int c = 0; c < K; ++c) d += 1.f - (2.f * acc[c] + 1e-5f) / (acc[K + c] + acc[2 * K + c] + 1e-5f);
@@ -153,12 +164,12 @@ int cenet_zero_async(float* p, long n, hipStream_t stream) {
 extern "C" int cenet_dice_ce_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int HW,
                                      float w_dice, float w_ce, hipStream_t stream) {
   if (B <= 0 || K <= 0 || K > LOSS_MAXK || HW <= 0) return CENET_EINVAL;
-  if (cenet_zero_async(acc, 3L * K + 1, stream) != CENET_OK) return CENET_EINVAL;
+  if (cenet_zero_async(acc, (long)LOSS_SLOTS * LOSS_SLOT_STRIDE, stream) != CENET_OK) return CENET_EINVAL;
   const long npix = (long)B * HW;
-  long blocks = (npix + 1023) / 1024;
-  if (blocks > 2048) blocks = 2048;
+  long blocks = (npix + 2047) / 2048;
+  if (blocks > 1024) blocks = 1024;
   CENET_LAUNCH(dice_ce_fwd_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix);
-  CENET_LAUNCH(dice_ce_finalize_kernel, dim3(1), dim3(64), stream, (const float*)acc, loss, K, (float)npix, w_dice, w_ce);
+  CENET_LAUNCH(dice_ce_finalize_kernel, dim3(1), dim3(64), stream, acc, loss, K, (float)npix, w_dice, w_ce);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -44,14 +44,14 @@ __device__ __forceinline__ void bil_range(int i, float scale, int align, int out
   }
   const float off = align ? 0.f : 0.5f;
   float a = (i - 1 + off) / scale - off, b = (i + 1 + off) / scale - off;
-  lo = (int)floorf(a) - 1;
-  hi = (int)ceilf(b) + 2;
+  lo = (int)floorf(a);      // exact bounds are floor(a)+1 .. ceil(b)-1; one index of slack each side for rounding
+  hi = (int)ceilf(b) + 1;
   if (lo < 0) lo = 0;
   if (hi > out) hi = out;
 }
 
 // gather form of the backward: one thread per INPUT pixel sums the output gradients whose taps touch it
-#define BIL_MAXR 16
+#define BIL_MAXR 10
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, long sgb, float* __restrict__ dx,
                                                           long sdb, int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
                                                           int align) {

@@ -1191,7 +1191,7 @@ class DiceCELossFn(Function):
         logits, labels = _c(logits), _c(labels)
         B, K = logits.shape[:2]
         HW = logits.numel() // (B * K)
-        acc = _empty((3 * K + 1,), logits)
+        acc = _empty((1024,), logits)  # CENET_LOSS_ACC_FLOATS (include/cenet_hip.h): replicated partial sums
         loss = _empty((1,), logits)
         kern.dice_ce_fwd(logits, labels, acc, loss, B, K, HW, w_dice, w_ce)
         ctx.save_for_backward(logits, labels, acc)

@@ -132,3 +132,35 @@ def test_dwconv_tok_fwd_dgrad_wgrad(dev, B, C, H, W):
     kern.dw_wgrad_tok(xd, gd, dw, db, B, C, H, W)
     torch.testing.assert_close(dw.cpu(), wr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
+
+
+# up x2 / x4, down x0.5, odd target sizes, both corner conventions: forward and the gather-form backward
+@pytest.mark.parametrize("Hi,Wi,kw", [(6, 7, dict(scale_factor=2.0)), (5, 4, dict(scale_factor=4.0)),
+                                      (8, 10, dict(scale_factor=0.5)), (7, 5, dict(size=(11, 13))),
+                                      (6, 6, dict(size=(12, 12), align_corners=True)), (9, 8, dict(size=(4, 3), align_corners=True)),
+                                      (3, 3, dict(size=(1, 1)))])
+def test_bilinear_fwd_bwd(dev, Hi, Wi, kw):
+    from cenet_amd import ops
+    g = torch.Generator().manual_seed(Hi * 10 + Wi)
+    x = torch.randn(2, 3, Hi, Wi, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr, mode="bilinear", **kw)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.interpolate_bilinear(xd, size=kw.get("size"), scale_factor=kw.get("scale_factor"),
+                                 align_corners=kw.get("align_corners", False))
+    y.backward(dy.to(dev))
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,HW,with_b", [(3, 5, 196, True), (2, 4, 1028, False), (4, 3, 49, True)])
+def test_chan_dot_accumulates(dev, B, C, HW, with_b):
+    g = torch.Generator().manual_seed(B * C + HW)
+    a, b = torch.randn(B, C, HW, generator=g), torch.randn(B, C, HW, generator=g)
+    out0 = torch.randn(C, generator=g)
+    out = out0.clone().to(dev)
+    kern.chan_dot(a.to(dev), C * HW, b.to(dev) if with_b else None, C * HW if with_b else 0, out, B, C, HW)
+    ref = out0 + ((a * b) if with_b else a).sum((0, 2))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
