@@ -73,8 +73,16 @@ extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const 
   }
   const bool im = B->mode != 0;
   int rc;
-  if (g_compute_bf16)
-    rc = im ? cenet_gemm_launch_bf16_im2col(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_bf16_plain(g, bm, bn, nbatch, swap, stream);
+  if (g_compute_bf16) {
+    // plain operands with a reduction of at least two 64-steps: K step 64 halves the barriers and the serial
+    // load -> LDS -> MFMA round trips of the (mostly latency-bound) mid-size contractions
+    // (measured: a gain for the 64x64 / 32x64 tiles that these small launches get, a loss for the 128-wide tiles, whose
+    // doubled prefetch registers drop them to one workgroup per CU, and for the split-K weight gradients)
+    const bool k64 = !im && K >= 128 && bm <= 64 && bn == 64 && !E->atomic;
+    rc = im ? cenet_gemm_launch_bf16_im2col(g, bm, bn, nbatch, swap, stream)
+            : (k64 ? cenet_gemm_launch_bf16_plain_k64(g, bm, bn, nbatch, swap, stream)
+                   : cenet_gemm_launch_bf16_plain(g, bm, bn, nbatch, swap, stream));
+  }
   else
     rc = im ? cenet_gemm_launch_f32_im2col(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_f32_plain(g, bm, bn, nbatch, swap, stream);
   if (rc != CENET_OK) return rc;

@@ -36,10 +36,9 @@ struct GemmArgs {
 __device__ __forceinline__ unsigned f2bf_bits(float f) { return cenet_f2bf(f); }
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return cenet_pack_bf2(lo, hi); }
 
-template <typename OpT> struct OpTraits;
-template <> struct OpTraits<float> { static constexpr int PITCH = 36; };           // 144-byte rows
-template <> struct OpTraits<unsigned short> { static constexpr int PITCH = 40; };  // 80-byte rows
-#define BK 32
+// LDS row pitch in elements for a K step of KT: KT + 4 floats (144 / 272-byte rows) or KT + 8 bf16 (80 / 144-byte rows)
+template <typename OpT, int KT> struct OpTraits { static constexpr int PITCH = KT + (sizeof(OpT) == 4 ? 4 : 8); };
+#define BK 32  // K step of the implicit-GEMM (im2col) instances; plain bf16 instances may use 64
 
 struct KEntry {
   int off;     // patch side: ci*sci
@@ -136,13 +135,15 @@ struct PlainStage {
 };
 
 // rs / ks: element strides along the operand's row (M or N) index and along k; x0 / X: tile origin and matrix extent
-template <int BX, int NX>
+template <int BX, int NX, int KT>
 __device__ __forceinline__ PlainStage plain_stage(long rs, long ks, int kfast, int vec, int x0, int X, int tid) {
   PlainStage s;
   s.ok = 0;
   if (kfast) {
-    const int rstep = vec ? 32 : 8, r0 = vec ? (tid >> 3) : (tid >> 5);
-    s.kk = vec ? (tid & 7) * 4 : (tid & 31);
+    // 16-byte form: KT/4 lanes per row; scalar form: KT lanes per row
+    const int lpr = vec ? KT / 4 : KT;
+    const int rstep = 256 / lpr, r0 = tid / lpr;
+    s.kk = vec ? (tid % lpr) * 4 : (tid % lpr);
     s.toff = (long)(x0 + r0) * rs + (long)s.kk * ks;
     s.dj = (long)rstep * rs;
     const int nreg = vec ? NX / 4 : NX;
@@ -150,7 +151,7 @@ __device__ __forceinline__ PlainStage plain_stage(long rs, long ks, int kfast, i
       if (x0 + r0 + j * rstep < X) s.ok |= 1u << j;
   } else {
     const int row = tid % BX, kq = tid / BX;
-    s.kk = kq * NX;  // NX == BK / (256 / BX) consecutive k per thread
+    s.kk = kq * NX;  // NX == KT / (256 / BX) consecutive k per thread
     s.toff = (long)(x0 + row) * rs + (long)s.kk * ks;
     s.dj = ks;
     s.ok = (x0 + row < X) ? 1u : 0u;
@@ -192,12 +193,13 @@ __device__ __forceinline__ void plain_fetch(const PlainStage& s, const float* ti
   }
 }
 
-template <typename OpT, int BM, int BN, bool B_IM2COL, bool SWAP>
+template <typename OpT, int BM, int BN, bool B_IM2COL, bool SWAP, int KT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  constexpr int P = OpTraits<OpT>::PITCH;
+  static_assert(KT == 32 || (KT == 64 && !B_IM2COL), "K step: 32, or 64 for plain operands");
+  constexpr int P = OpTraits<OpT, KT>::PITCH;
   constexpr bool BF = (sizeof(OpT) == 2);
   constexpr int MI = BM / 32, NJ = BN / 32;              // 16x16 tiles per wave in each direction
-  constexpr int NA = BM * BK / 256, NB = BN * BK / 256;  // prefetch registers per thread
+  constexpr int NA = BM * KT / 256, NB = BN * KT / 256;  // prefetch registers per thread
   __shared__ __attribute__((aligned(16))) OpT As[BM * P];
   __shared__ __attribute__((aligned(16))) OpT Bs[BN * P];
   __shared__ KEntry ntab[B_IM2COL ? BN : 1];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int ktiles = (g.K + BK - 1) / BK;
+  const int ktiles = (g.K + KT - 1) / KT;
   const int total = g.nkb * ktiles;
   const int chunk = (total + g.splits - 1) / g.splits;
   const int it0 = split * chunk;
@@ -242,13 +244,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   //   kfast scalar : kk = tid % 32,  rows r = tid / 32 + 8 j
   //   kfast vec    : k4 = tid % 8,   rows r = tid / 8 + 32 j   (4 consecutive k per register quad)
   //   mfast        : row = tid % BMN, kq = tid / BMN ; k = kq * KPT + j  (KPT consecutive k per thread)
-  constexpr int A_KPT = BK / (256 / BM), B_KPT = BK / (256 / BN);
-  static_assert(BM <= 256 && BN <= 256 && NA % 4 == 0 && NB % 4 == 0, "unsupported tile");
+  constexpr int A_KPT = KT / (256 / BM), B_KPT = KT / (256 / BN);
+  static_assert(BM <= 256 && BN <= 256 && NA % 4 == 0 && NB % 4 == 0 && NA <= 32 && NB <= 32, "unsupported tile");
   float ra[NA], rb[NB];
   // plain operands without the (ko,ki) split of k use hoisted pointer walks; the split form keeps per-element addressing
   const bool a_fast = g.A.kinner == 0, b_fast = !B_IM2COL && g.B.kinner == 0;
-  const PlainStage sa = plain_stage<BM, NA>(g.A.sr, g.A.sc, g.A.kfast, g.avec, m0, g.M, tid);
-  const PlainStage sb = plain_stage<BN, NB>(g.B.sc, g.B.sr, g.B.kfast, g.bvec, n0, g.N, tid);
+  const PlainStage sa = plain_stage<BM, NA, KT>(g.A.sr, g.A.sc, g.A.kfast, g.avec, m0, g.M, tid);
+  const PlainStage sb = plain_stage<BN, NB, KT>(g.B.sc, g.B.sr, g.B.kfast, g.bvec, n0, g.N, tid);
   const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
 
   KEntry nent;
@@ -262,17 +264,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   auto fetch = [&](int it) __attribute__((always_inline)) {
     const int kb = it / ktiles;
-    const int k0 = (it - kb * ktiles) * BK;
+    const int k0 = (it - kb * ktiles) * KT;
     const float* baseA = g.A.ptr + (long)bo * g.A.sb + (long)bi * g.A.sb2 + (long)kb * g.A.skb;
     const float* baseB = g.B.ptr + (long)bo * g.B.sb + (long)bi * g.B.sb2 + (long)kb * g.B.skb;
     const int klim = g.K - k0;
     if (a_fast) {
-      plain_fetch<NA>(sa, baseA + (long)k0 * g.A.sc, klim, g.A.kfast, g.avec, a_in && klim >= BK, ra);
+      plain_fetch<NA>(sa, baseA + (long)k0 * g.A.sc, klim, g.A.kfast, g.avec, a_in && klim >= KT, ra);
     } else if (g.A.kfast) {
-      const int kk = tid & 31, r0 = tid >> 5;
+      const int kk = tid % KT, r0 = tid / KT;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
-        int row = r0 + j * 8;
+        int row = r0 + j * (256 / KT);
         ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? baseA[plain_off<1>(g.A, m0 + row, k0 + kk)] : 0.f;
       }
     } else {
@@ -285,12 +287,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
     if (!B_IM2COL) {
       if (b_fast) {
-        plain_fetch<NB>(sb, baseB + (long)k0 * g.B.sr, klim, g.B.kfast, g.bvec, b_in && klim >= BK, rb);
+        plain_fetch<NB>(sb, baseB + (long)k0 * g.B.sr, klim, g.B.kfast, g.bvec, b_in && klim >= KT, rb);
       } else if (g.B.kfast) {
-        const int kk = tid & 31, c0 = tid >> 5;
+        const int kk = tid % KT, c0 = tid / KT;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          int col = c0 + j * 8;
+          int col = c0 + j * (256 / KT);
           rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? baseB[plain_off<0>(g.B, k0 + kk, n0 + col)] : 0.f;
         }
       } else {
@@ -357,15 +359,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   };
 
   auto store_lds = [&]() __attribute__((always_inline)) {
+    constexpr int LV = KT / 4, RV = 256 / LV;  // 16-byte form: lanes per row, rows per pass
+    constexpr int RS = 256 / KT;               // scalar form: rows per pass
     if (g.A.kfast) {
       if (g.avec) {
-        const int k4 = (tid & 7) * 4, r0 = tid >> 3;
+        const int k4 = (tid % LV) * 4, r0 = tid / LV;
 #pragma unroll
-        for (int j = 0; j < NA / 4; ++j) lds_put<OpT, 4>(&As[(r0 + j * 32) * P + k4], &ra[4 * j]);
+        for (int j = 0; j < NA / 4; ++j) lds_put<OpT, 4>(&As[(r0 + j * RV) * P + k4], &ra[4 * j]);
       } else {
-        const int kk = tid & 31, r0 = tid >> 5;
+        const int kk = tid % KT, r0 = tid / KT;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) lds_put1<OpT>(&As[(r0 + j * 8) * P + kk], ra[j]);
+        for (int j = 0; j < NA; ++j) lds_put1<OpT>(&As[(r0 + j * RS) * P + kk], ra[j]);
       }
     } else {
       const int row = tid % BM, kq = tid / BM;
@@ -373,13 +377,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
     if (g.B.kfast) {
       if (!B_IM2COL && g.bvec) {
-        const int k4 = (tid & 7) * 4, c0 = tid >> 3;
+        const int k4 = (tid % LV) * 4, c0 = tid / LV;
 #pragma unroll
-        for (int j = 0; j < NB / 4; ++j) lds_put<OpT, 4>(&Bs[(c0 + j * 32) * P + k4], &rb[4 * j]);
+        for (int j = 0; j < NB / 4; ++j) lds_put<OpT, 4>(&Bs[(c0 + j * RV) * P + k4], &rb[4 * j]);
       } else {
-        const int kk = tid & 31, c0 = tid >> 5;
+        const int kk = tid % KT, c0 = tid / KT;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) lds_put1<OpT>(&Bs[(c0 + j * 8) * P + kk], rb[j]);
+        for (int j = 0; j < NB; ++j) lds_put1<OpT>(&Bs[(c0 + j * RS) * P + kk], rb[j]);
       }
     } else {
       const int col = tid % BN, kq = tid / BN;
@@ -397,34 +401,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     store_lds();
     __syncthreads();
     if (it + 1 < it1) fetch(it + 1);  // next tile's HBM loads fly under this tile's MFMAs
-    if (!BF) {
-      // lane owns k' = 8*fq .. 8*fq+7 ; step s pairs slot s of A with slot s of B
-      float a[MI][8];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) memcpy(a[i], &As[(wm * (BM / 2) + i * 16 + fr) * P + fq * 8], 32);
+    for (int kc = 0; kc < KT / 32; ++kc) {
+      if (!BF) {
+        // lane owns k' = 8*fq .. 8*fq+7 of this 32-chunk ; step s pairs slot s of A with slot s of B
+        float a[MI][8];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        float b[8];
-        memcpy(b, &Bs[(wn * (BN / 2) + j * 16 + fr) * P + fq * 8], 32);
+        for (int i = 0; i < MI; ++i) memcpy(a[i], &As[(wm * (BM / 2) + i * 16 + fr) * P + kc * 32 + fq * 8], 32);
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
+        for (int j = 0; j < NJ; ++j) {
+          float b[8];
+          memcpy(b, &Bs[(wn * (BN / 2) + j * 16 + fr) * P + kc * 32 + fq * 8], 32);
+#pragma unroll
+          for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+              acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(b[s], a[i][s], acc[i][j], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[s], acc[i][j], 0, 0, 0);
+        }
+      } else {
+        bf16x8 a[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) memcpy(&a[i], &As[(wm * (BM / 2) + i * 16 + fr) * P + kc * 32 + fq * 8], 16);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          bf16x8 b;
+          memcpy(&b, &Bs[(wn * (BN / 2) + j * 16 + fr) * P + kc * 32 + fq * 8], 16);
 #pragma unroll
           for (int i = 0; i < MI; ++i)
-            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(b[s], a[i][s], acc[i][j], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[s], acc[i][j], 0, 0, 0);
-      }
-    } else {
-      bf16x8 a[MI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) memcpy(&a[i], &As[(wm * (BM / 2) + i * 16 + fr) * P + fq * 8], 16);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        bf16x8 b;
-        memcpy(&b, &Bs[(wn * (BN / 2) + j * 16 + fr) * P + fq * 8], 16);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[i][j], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][j], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -551,32 +558,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
-template <typename OpT, bool IM, bool SWAP>
+template <typename OpT, bool IM, bool SWAP, int KT>
 static int launch_tile(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_t stream) {
   dim3 grid(cdiv(g.N, bn), cdiv(g.M, bm), nbatch * g.splits);
   if (grid.y > 65535 || grid.z > 65535) return CENET_EUNSUPPORTED;
 #define CENET_TILE(BMv, BNv)                                                                   \
   if (bm == BMv && bn == BNv) {                                                                \
-    CENET_LAUNCH((gemm_kernel<OpT, BMv, BNv, IM, SWAP>), grid, dim3(256), stream, g);          \
+    CENET_LAUNCH((gemm_kernel<OpT, BMv, BNv, IM, SWAP, KT>), grid, dim3(256), stream, g);      \
     return CENET_OK;                                                                           \
   }
-  CENET_TILE(128, 128)
-  CENET_TILE(128, 64)
-  CENET_TILE(64, 128)
-  CENET_TILE(64, 64)
-  CENET_TILE(32, 256)
-  CENET_TILE(32, 64)
-#undef CENET_TILE
+  if (KT == 32) {
+    CENET_TILE(128, 128)
+    CENET_TILE(128, 64)
+    CENET_TILE(64, 128)
+    CENET_TILE(64, 64)
+    CENET_TILE(32, 256)
+    CENET_TILE(32, 64)
+  }
   return CENET_EUNSUPPORTED;
 }
-
+// K step 64 (plain bf16 operands): only the small tiles, whose doubled prefetch registers keep two workgroups per CU
+template <typename OpT, bool SWAP>
+static int launch_tile_k64(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_t stream) {
+  dim3 grid(cdiv(g.N, bn), cdiv(g.M, bm), nbatch * g.splits);
+  if (grid.y > 65535 || grid.z > 65535) return CENET_EUNSUPPORTED;
+#define CENET_TILE64(BMv, BNv)                                                                 \
+  if (bm == BMv && bn == BNv) {                                                                \
+    CENET_LAUNCH((gemm_kernel<OpT, BMv, BNv, false, SWAP, 64>), grid, dim3(256), stream, g);   \
+    return CENET_OK;                                                                           \
+  }
+  CENET_TILE64(64, 64)
+  CENET_TILE64(32, 64)
+#undef CENET_TILE64
+  return CENET_EUNSUPPORTED;
+}
+#undef CENET_TILE
 
 // one translation unit per (operand type, B view): gemm_inst_*.hip
 #define CENET_GEMM_INSTANCE(NAME, T, IM)                                                                     \
   int NAME(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream) {                   \
-    return swap ? launch_tile<T, IM, true>(g, bm, bn, nbatch, stream) : launch_tile<T, IM, false>(g, bm, bn, nbatch, stream); \
+    return swap ? launch_tile<T, IM, true, 32>(g, bm, bn, nbatch, stream) : launch_tile<T, IM, false, 32>(g, bm, bn, nbatch, stream); \
+  }
+#define CENET_GEMM_INSTANCE_K64(NAME, T)                                                                     \
+  int NAME(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream) {                   \
+    return swap ? launch_tile_k64<T, true>(g, bm, bn, nbatch, stream) : launch_tile_k64<T, false>(g, bm, bn, nbatch, stream); \
   }
 int cenet_gemm_launch_f32_plain(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
 int cenet_gemm_launch_f32_im2col(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
 int cenet_gemm_launch_bf16_plain(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
 int cenet_gemm_launch_bf16_im2col(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
+int cenet_gemm_launch_bf16_plain_k64(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);

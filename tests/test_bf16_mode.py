@@ -125,3 +125,41 @@ def test_direct_conv_bf16_fwd_and_dgrad(dev, bf16_mode, Cin, Cout, k, H, W):
     assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
     assert _rel(x.grad.cpu(), xr.grad) < 2e-2
     assert _rel(w.grad.cpu(), wr.grad) < 2e-2
+
+
+# K >= 128 takes the K-step-64 GEMM instances: full and ragged last K tile, ragged M / N tiles, every operand orientation
+# (forward: k-contiguous x k-contiguous; dX: k-contiguous x row-contiguous; dW: row-contiguous pair with split-K atomics)
+@pytest.mark.parametrize("R,K,N", [(150, 192, 70), (70, 200, 130), (300, 128, 64), (33, 320, 320)])
+def test_linear_bf16_k64(dev, bf16_mode, R, K, N):
+    g = torch.Generator().manual_seed(R + K + N)
+    x = torch.randn(R, K, generator=g).to(dev).requires_grad_(True)
+    W = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.1).to(dev))
+    b = torch.nn.Parameter(torch.randn(N, generator=g).to(dev))
+    go = torch.randn(R, N, generator=g).to(dev)
+    bf16_mode()
+    y = ops.linear(x, W, b)
+    y.backward(go)
+    xr, Wr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, W, b))
+    ref = torch.nn.functional.linear(xr, Wr, br)
+    ref.backward(go.cpu())
+    assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
+    assert _rel(x.grad.cpu(), xr.grad) < 2e-2
+    assert _rel(W.grad.cpu(), Wr.grad) < 2e-2
+    assert _rel(b.grad.cpu(), br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,Cin,Cout,HW", [(2, 136, 72, 100), (1, 256, 130, 49)])
+def test_conv1x1_bf16_k64(dev, bf16_mode, B, Cin, Cout, HW):
+    g = torch.Generator().manual_seed(B + Cin + Cout + HW)
+    x = torch.randn(B, Cin, HW, 1, generator=g).to(dev).requires_grad_(True)
+    W = torch.nn.Parameter((torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1).to(dev))
+    go = torch.randn(B, Cout, HW, 1, generator=g).to(dev)
+    bf16_mode()
+    y = ops.conv1x1(x, W)
+    y.backward(go)
+    xr, Wr = (t.detach().cpu().clone().requires_grad_(True) for t in (x, W))
+    ref = torch.nn.functional.conv2d(xr, Wr)
+    ref.backward(go.cpu())
+    assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
+    assert _rel(x.grad.cpu(), xr.grad) < 2e-2
+    assert _rel(W.grad.cpu(), Wr.grad) < 2e-2
