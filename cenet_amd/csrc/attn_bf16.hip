@@ -337,8 +337,10 @@ __global__ __launch_bounds__(256, (DV <= 64 ? 2 : 1)) void flashc_fwd_kernel(Att
 // ---------------------------------------------------------------------------------------------------------------
 // backward, dQ (and delta): one workgroup = 64*NQT queries; streams key tiles
 // ---------------------------------------------------------------------------------------------------------------
-template <int DQ, int DV, int NQT>
-__global__ __launch_bounds__(256, ((DQ * NQT <= 64 && DV <= 64) ? 2 : 1)) void flashc_bwd_dq_kernel(AttnArgsB a) {
+// MINB = 2 caps the registers for two workgroups per CU; the 64-dim instances then spill a few dwords, which pays on long
+// key loops but costs a scratch set-up per launch on tiny problems — those take the MINB = 1 instance
+template <int DQ, int DV, int NQT, int MINB>
+__global__ __launch_bounds__(256, MINB) void flashc_bwd_dq_kernel(AttnArgsB a) {
   constexpr int PQ = DQ + 8, PV = DV + 8, NC = DQ / 32, NCV = DV / 32, ND = DQ / 16;
   __shared__ __attribute__((aligned(16))) bf Ks[2][TK * PQ];  // [key][d]
   __shared__ __attribute__((aligned(16))) bf Kt[2][DQ * PT];  // [d][key]
@@ -468,8 +470,8 @@ __global__ __launch_bounds__(256, ((DQ * NQT <= 64 && DV <= 64) ? 2 : 1)) void f
 // ---------------------------------------------------------------------------------------------------------------
 // backward, dK / dV: one workgroup = 64*NKT keys; streams query tiles (optionally only a slice of them: blockIdx.z)
 // ---------------------------------------------------------------------------------------------------------------
-template <int DQ, int DV, int NKT>
-__global__ __launch_bounds__(256, ((DQ == 32 && DV == 32) ? 2 : 1)) void flashc_bwd_dkv_kernel(AttnArgsB a) {
+template <int DQ, int DV, int NKT, int MINB>
+__global__ __launch_bounds__(256, MINB) void flashc_bwd_dkv_kernel(AttnArgsB a) {
   constexpr int PQ = DQ + 8, PV = DV + 8, NC = DQ / 32, NCV = DV / 32, ND = DQ / 16, NU = DV / 16;
   constexpr int NBUF = (DV <= 64) ? 2 : 1;  // the widest instance keeps one LDS stage (two barriers per tile)
   __shared__ __attribute__((aligned(16))) bf Qs[NBUF][64 * PQ];   // [query][d]   (scaled by scale*log2e)
@@ -693,20 +695,28 @@ int cenet_flashb_bwd(const cenet_attn_t* p, hipStream_t stream) {
     a.qsplit = cdiv(qtiles, a.tiles_per_split);
   }
   dim3 gk(ktiles, a.B * a.H, a.qsplit);
-#define CENET_BWD(DQv, DVv, WK)                                                                     \
-  if (wide_q) CENET_LAUNCH((flashc_bwd_dq_kernel<DQv, DVv, 2>), gq, dim3(256), stream, a);          \
-  else CENET_LAUNCH((flashc_bwd_dq_kernel<DQv, DVv, 1>), gq, dim3(256), stream, a);                 \
-  if (WK && wide_k) CENET_LAUNCH((flashc_bwd_dkv_kernel<DQv, DVv, (WK ? 2 : 1)>), gk, dim3(256), stream, a); \
-  else CENET_LAUNCH((flashc_bwd_dkv_kernel<DQv, DVv, 1>), gk, dim3(256), stream, a);
+  const bool big = (long)a.Nq * a.Nk >= 1024L * 1024L;  // long loops: the register-capped 64-dim instances
+#define CENET_DQ(DQv, DVv, NQTv, MB) CENET_LAUNCH((flashc_bwd_dq_kernel<DQv, DVv, NQTv, MB>), gq, dim3(256), stream, a)
+#define CENET_DKV(DQv, DVv, NKTv, MB) CENET_LAUNCH((flashc_bwd_dkv_kernel<DQv, DVv, NKTv, MB>), gk, dim3(256), stream, a)
   switch (cls) {
-    case 0: CENET_BWD(32, 32, 1) break;
-    case 1: CENET_BWD(32, 64, 1) break;
-    case 2: CENET_BWD(64, 64, 0) break;
+    case 0:
+      if (wide_q) CENET_DQ(32, 32, 2, 2); else CENET_DQ(32, 32, 1, 2);
+      if (wide_k) CENET_DKV(32, 32, 2, 2); else CENET_DKV(32, 32, 1, 2);
+      break;
+    case 1:
+      if (wide_q) CENET_DQ(32, 64, 2, 2); else CENET_DQ(32, 64, 1, 2);
+      if (wide_k) CENET_DKV(32, 64, 2, 1); else CENET_DKV(32, 64, 1, 1);
+      break;
+    case 2:
+      if (wide_q && big) CENET_DQ(64, 64, 2, 2); else if (wide_q) CENET_DQ(64, 64, 2, 1); else CENET_DQ(64, 64, 1, 2);
+      if (big) CENET_DKV(64, 64, 1, 2); else CENET_DKV(64, 64, 1, 1);
+      break;
     default:
-      CENET_LAUNCH((flashc_bwd_dq_kernel<64, 128, 1>), gq, dim3(256), stream, a);
-      CENET_LAUNCH((flashc_bwd_dkv_kernel<64, 128, 1>), gk, dim3(256), stream, a);
+      CENET_DQ(64, 128, 1, 1);
+      CENET_DKV(64, 128, 1, 1);
       break;
   }
-#undef CENET_BWD
+#undef CENET_DQ
+#undef CENET_DKV
   return CENET_OK;
 }
