@@ -59,13 +59,18 @@ extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const 
   pick_tile(M, N, nbatch, splits, &bm, &bn);
   if (B->mode == 1 && B->kfast && bm == 32) bn = 64;  // weight-gradient view: keep the per-thread gather list short
   if (E->atomic && !E->cmode && splits > 1) {
-    // split-K: every split adds the whole MxN tile with float atomics (~1.3 TB/s chip-wide), so use only as many
-    // splits as it takes to fill the chip (~2 workgroups per CU) with the tile actually chosen, each >= 4 K-tiles deep
+    // split-K: every split adds the whole MxN tile with float atomics (~1.3 TB/s chip-wide), and one workgroup's K loop is a
+    // serial chain of ~0.9 us (plain) / ~2 us (gathering) iterations, so with s splits
+    //     time ~ iters / s * t_iter  +  s * tiles * tile_bytes / 1.3 TB/s
+    // which is least at s = sqrt(iters * t_iter / per-split atomic time); never more workgroups than fit on the chip at once
     const long tiles = (long)cdiv(M, bm) * cdiv(N, bn) * nbatch;
     const long iters = (long)nkb * cdiv(K, BK);
-    const long target = (B->mode == 1) ? 1024 : 512;  // gather-heavy conv weight-gradients want more, shorter blocks
-    long s = (target + tiles - 1) / tiles;
-    if (s > iters / 4) s = iters / 4;
+    const double t_iter = (B->mode == 1) ? 2.0 : 0.9;
+    const double t_atom = (double)tiles * bm * bn * 4.0 / 1.3e6;  // us per split
+    long s = (long)(__builtin_sqrt((double)iters * t_iter / t_atom) + 0.5);
+    const long slots = (bm * bn >= 128 * 128) ? 512 : 1024;
+    if (s * tiles > slots) s = slots / tiles;
+    if (s > iters / 2) s = iters / 2;
     if (s > 256) s = 256;
     if (s < 1) s = 1;
     splits = (int)s;
