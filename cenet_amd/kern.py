@@ -441,6 +441,19 @@ def conv_direct(x, w, y, B, Cin, Cout, H, W, k, dgrad):
     _call("cenet_conv_direct_bf16", x, w, y, B, Cin, Cout, H, W, k, int(dgrad))
 
 
+def conv_wgrad_direct_supported(Cin: int, Cout: int, k: int, stride: int, pad: int) -> bool:
+    return bool(_lib.lib().cenet_conv_wgrad_direct_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
+
+
+def conv_wgrad_direct(x, dy, dw, B, Cin, Cout, H, W, k):
+    """bf16-operand direct weight gradient (LDS tiles of dY and the X halo, funnel-shifted tap windows): dw += dY (*) x."""
+    _chk(x, dy, dw)
+    fn = _lib.lib().cenet_conv_wgrad_direct_ws_floats
+    fn.restype = C.c_long
+    ws = torch.empty(int(fn(int(Cin), int(Cout), int(k))), device=x.device, dtype=torch.float32)
+    _call("cenet_conv_wgrad_direct_bf16", x, dy, dw, ws, B, Cin, Cout, H, W, k)
+
+
 def set_compute_bf16(on: bool) -> bool:
     """GEMM/conv operand precision: False = fp32 (parity mode, default), True = bf16 operands + fp32 accumulate."""
     return bool(_lib.lib().cenet_set_compute_bf16(int(bool(on))))

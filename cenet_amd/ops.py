@@ -235,7 +235,10 @@ class Conv2dFn(Function):
                           dx, Kd, Ho * Wo, Cout, scr=0, scc=0, scb=sb, nbatch=B, atomic=overlap,
                           col2im=dict(KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride, pad=pad, sci=sc, sy=sy, sx=sx))
         dW = grad_buf(Wp)
-        if dW is not None:
+        if (dW is not None and getattr(ctx, "direct", False) and kern.get_compute_bf16()
+                and kern.conv_wgrad_direct_supported(Cin, Cout, k, stride, pad)):
+            kern.conv_wgrad_direct(x, g, dW, B, Cin, Cout, H, Wd, k)  # conv_direct.hip, direct weight gradient
+        elif dW is not None:
             Bm = kern.mat_im2col(x, sb=0, skb=sb, sci=sc, sy=sy, sx=sx, KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride,
                                  pad=pad, dil=1, patch_is_row=0, transposed=0, kfast=1)
             iters = B * ((Ho * Wo + 31) // 32)

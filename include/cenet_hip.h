@@ -81,6 +81,13 @@ int cenet_get_compute_bf16(void);
 int cenet_conv_direct_supported(int Cin, int Cout, int k, int stride, int pad);
 int cenet_conv_direct_bf16(const float* x, const float* w, float* y, int B, int Cin, int Cout, int H, int W, int k, int dgrad,
                            cenet_stream_t stream);
+/* Weight gradient of the same convolutions in the same mode (replaces the implicit-GEMM wgrad of unet.py:156-197,
+ * blocks.py:211, out.py:41-49 for 5x5 32->32 and 3x3 64->64 / 64->32): dw_acc[Cout,Cin,k,k] += dY (*) X.
+ * ws: cenet_conv_wgrad_direct_ws_floats(Cin, Cout, k) floats of scratch (per-workgroup partial sums). */
+int cenet_conv_wgrad_direct_supported(int Cin, int Cout, int k, int stride, int pad);
+long cenet_conv_wgrad_direct_ws_floats(int Cin, int Cout, int k);
+int cenet_conv_wgrad_direct_bf16(const float* x, const float* dy, float* dw_acc, float* ws, int B, int Cin, int Cout, int H,
+                                 int W, int k, cenet_stream_t stream);
 
 /* ---- attention (attn.hip) -------------------------------------------------------------------------------- */
 /* Element (b,h,i,d) of Q = q[b*qsb + h*qsh + i*qsi + d*qsd]; same for K (Nk rows), V (head h / v_head_div,

@@ -104,10 +104,11 @@ def test_whole_model_bf16_mode_stays_close_to_fp32_goldens():
     assert abs(O.mean_class_dice(le, lab.cpu(), cfg.num_classes) - float(z["dice_eval"])) < 1e-3
 
 
-@pytest.mark.parametrize("Cin,Cout,k,H,W", [(32, 32, 5, 16, 40), (64, 64, 3, 12, 36), (64, 32, 3, 9, 33)])
+@pytest.mark.parametrize("Cin,Cout,k,H,W", [(32, 32, 5, 16, 40), (64, 64, 3, 12, 36), (64, 32, 3, 9, 33), (32, 32, 5, 11, 70)])
 def test_direct_conv_bf16_fwd_and_dgrad(dev, bf16_mode, Cin, Cout, k, H, W):
     """conv_direct.hip (LDS-halo direct convolution of the output head) vs fp32 torch conv, forward and data-gradient;
-    ragged tiles (H, W not multiples of the 8x32 tile) included.  The weight-gradient stays on the implicit-GEMM path."""
+    ragged tiles (H, W not multiples of the 8x32 tile, odd W) included; the weight gradient of the three forward shapes
+    is the direct kernel as well (LDS tiles + funnel-shifted tap windows)."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(3)
     B = 2
