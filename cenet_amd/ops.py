@@ -11,6 +11,7 @@ Reference file:line citations are relative to /root/reference/src/.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Optional, Sequence
 
@@ -38,6 +39,47 @@ def grad_buf(p: Optional[Tensor]) -> Optional[Tensor]:
     if p.grad is None:
         p.grad = _zeros(p.shape, p)
     return p.grad
+
+
+class _WgradSide:
+    """Weight-gradient kernels can run on a second HIP stream, concurrently with the data-gradient chain of the backward
+    pass: they only feed the optimizer, and most of them are short, latency-bound launches that leave the chip half idle.
+    Off by default; `set_wgrad_overlap(True)` turns it on (bench.py does); `wgrad_join()` makes the current stream wait
+    for them and must run before anything reads the gradients (FusedSGD.step and the gradient all-reduce call it)."""
+    enabled = False
+    stream = None
+    pending = False
+
+
+def set_wgrad_overlap(on: bool) -> bool:
+    old = _WgradSide.enabled
+    _WgradSide.enabled = bool(on)
+    return old
+
+
+@contextlib.contextmanager
+def _wgrad_side(*reads):
+    """runs the body on the weight-gradient stream, ordered after everything issued so far on the current stream"""
+    if not _WgradSide.enabled or kern._lib.is_hostsim():
+        yield
+        return
+    cur = torch.cuda.current_stream()
+    if _WgradSide.stream is None:
+        _WgradSide.stream = torch.cuda.Stream()
+    side = _WgradSide.stream
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        yield
+    for t in reads:
+        if isinstance(t, Tensor):
+            t.record_stream(side)  # keep the caching allocator from recycling these while the side stream reads them
+    _WgradSide.pending = True
+
+
+def wgrad_join():
+    if _WgradSide.pending:
+        torch.cuda.current_stream().wait_stream(_WgradSide.stream)
+        _WgradSide.pending = False
 
 
 def _c(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -80,18 +122,19 @@ class LinearFn(Function):
         if bscale is not None:
             gs = torch.empty_like(g)
             kern.scale_batch(g, bscale, gs, x.shape[0], g.numel() // x.shape[0])
+        dW, db = grad_buf(Wp), grad_buf(bp)
+        if dW is not None or db is not None:
+            with _wgrad_side(gs, x):
+                if dW is not None:
+                    iters = (R + 31) // 32
+                    kern.gemm(kern.mat_plain(gs, 1, N, kfast=0), kern.mat_plain(x, K, 1, kfast=0), dW, N, K, R, scr=K, scc=1,
+                              splits=kern.pick_splits(N, K, 1, iters), atomic=True)
+                if db is not None:
+                    kern.col_sum(gs, db, R, N)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             kern.gemm(kern.mat_plain(gs, N, 1, kfast=1), kern.mat_plain(W, K, 1, kfast=0), dx, R, K, N, scr=K, scc=1)
-        dW = grad_buf(Wp)
-        if dW is not None:
-            iters = (R + 31) // 32
-            kern.gemm(kern.mat_plain(gs, 1, N, kfast=0), kern.mat_plain(x, K, 1, kfast=0), dW, N, K, R, scr=K, scc=1,
-                      splits=kern.pick_splits(N, K, 1, iters), atomic=True)
-        db = grad_buf(bp)
-        if db is not None:
-            kern.col_sum(gs, db, R, N)
         return dx, None, None, (g if ctx.has_resid else None), None
 
 
@@ -128,19 +171,21 @@ class Conv1x1Fn(Function):
         B, Cin = x.shape[:2]
         HW = x.numel() // (B * Cin)
         Cout = W.shape[0]
+        dW, db = grad_buf(Wp), grad_buf(bp)
+        if dW is not None or db is not None:
+            with _wgrad_side(g, x):
+                if dW is not None:
+                    iters = B * ((HW + 31) // 32)
+                    kern.gemm(kern.mat_plain(g, HW, 1, skb=Cout * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Cin * HW, kfast=1),
+                              dW, Cout, Cin, HW, scr=Cin, scc=1, nkb=B, splits=kern.pick_splits(Cout, Cin, 1, iters),
+                              atomic=True)
+                if db is not None:
+                    kern.chan_dot(g, Cout * HW, None, 0, db, B, Cout, HW)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             kern.gemm(kern.mat_plain(W, 1, Cin, kfast=0), kern.mat_plain(g, HW, 1, sb=Cout * HW), dx, Cin, HW, Cout,
                       scr=HW, scc=1, scb=Cin * HW, nbatch=B)
-        dW = grad_buf(Wp)
-        if dW is not None:
-            iters = B * ((HW + 31) // 32)
-            kern.gemm(kern.mat_plain(g, HW, 1, skb=Cout * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Cin * HW, kfast=1),
-                      dW, Cout, Cin, HW, scr=Cin, scc=1, nkb=B, splits=kern.pick_splits(Cout, Cin, 1, iters), atomic=True)
-        db = grad_buf(bp)
-        if db is not None:
-            kern.chan_dot(g, Cout * HW, None, 0, db, B, Cout, HW)
         return dx, None, None, (g if ctx.has_resid else None)
 
 
@@ -234,22 +279,23 @@ class Conv2dFn(Function):
                                                                               kfast=int(g_sc == 1)),
                           dx, Kd, Ho * Wo, Cout, scr=0, scc=0, scb=sb, nbatch=B, atomic=overlap,
                           col2im=dict(KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride, pad=pad, sci=sc, sy=sy, sx=sx))
-        dW = grad_buf(Wp)
-        if (dW is not None and getattr(ctx, "direct", False) and kern.get_compute_bf16()
-                and kern.conv_wgrad_direct_supported(Cin, Cout, k, stride, pad)):
-            kern.conv_wgrad_direct(x, g, dW, B, Cin, Cout, H, Wd, k)  # conv_direct.hip, direct weight gradient
-        elif dW is not None:
-            Bm = kern.mat_im2col(x, sb=0, skb=sb, sci=sc, sy=sy, sx=sx, KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride,
-                                 pad=pad, dil=1, patch_is_row=0, transposed=0, kfast=1)
-            iters = B * ((Ho * Wo + 31) // 32)
-            kern.gemm(kern.mat_plain(g, g_sc, g_sp, skb=Cout * Ho * Wo, kfast=int(g_sp == 1)), Bm, dW, Cout, Kd, Ho * Wo,
-                      scr=Kd, scc=1, nkb=B, splits=kern.pick_splits(Cout, Kd, 1, iters), atomic=True)
-        db = grad_buf(bp)
-        if db is not None:
-            if out_layout == "nchw":
-                kern.chan_dot(g, Cout * Ho * Wo, None, 0, db, B, Cout, Ho * Wo)
-            else:
-                kern.col_sum(g, db, B * Ho * Wo, Cout)
+        dW, db = grad_buf(Wp), grad_buf(bp)
+        if dW is not None or db is not None:
+            with _wgrad_side(g, x):
+                if (dW is not None and getattr(ctx, "direct", False) and kern.get_compute_bf16()
+                        and kern.conv_wgrad_direct_supported(Cin, Cout, k, stride, pad)):
+                    kern.conv_wgrad_direct(x, g, dW, B, Cin, Cout, H, Wd, k)  # conv_direct.hip, direct weight gradient
+                elif dW is not None:
+                    Bm = kern.mat_im2col(x, sb=0, skb=sb, sci=sc, sy=sy, sx=sx, KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride,
+                                         pad=pad, dil=1, patch_is_row=0, transposed=0, kfast=1)
+                    iters = B * ((Ho * Wo + 31) // 32)
+                    kern.gemm(kern.mat_plain(g, g_sc, g_sp, skb=Cout * Ho * Wo, kfast=int(g_sp == 1)), Bm, dW, Cout, Kd,
+                              Ho * Wo, scr=Kd, scc=1, nkb=B, splits=kern.pick_splits(Cout, Kd, 1, iters), atomic=True)
+                if db is not None:
+                    if out_layout == "nchw":
+                        kern.chan_dot(g, Cout * Ho * Wo, None, 0, db, B, Cout, Ho * Wo)
+                    else:
+                        kern.col_sum(g, db, B * Ho * Wo, Cout)
         return dx, None, None, None
 
 
@@ -385,9 +431,10 @@ class DWConvTokFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             kern.dw_tok(gu, w, None, dx, None, B, Cn, H, Wd, 1)
-        dw = grad_buf(wp)
+        dw, db = grad_buf(wp), grad_buf(bp)
         if dw is not None:
-            kern.dw_wgrad_tok(x, gu, dw, grad_buf(bp), B, Cn, H, Wd)
+            with _wgrad_side(gu, x):
+                kern.dw_wgrad_tok(x, gu, dw, db, B, Cn, H, Wd)
         return dx, None, None, None, None, None
 
 
@@ -422,9 +469,10 @@ class DWConvNCHWFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             kern.dw_nchw(gu, sb, w, None, dx, sb, None, 0, B, Cn, H, Wd, dil, 1)
-        dw = grad_buf(wp)
+        dw, db = grad_buf(wp), grad_buf(bp)
         if dw is not None:
-            kern.dw_wgrad_nchw(x, sb, gu, sb, dw, grad_buf(bp), B, Cn, H, Wd, dil)
+            with _wgrad_side(gu, x):
+                kern.dw_wgrad_nchw(x, sb, gu, sb, dw, db, B, Cn, H, Wd, dil)
         return dx, None, None, None, None
 
 

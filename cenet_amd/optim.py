@@ -64,6 +64,8 @@ class ParamArena:
 
     def zero_grad(self):
         """One memset for all gradients (re-attaches views if a caller set .grad to None)."""
+        from . import ops
+        ops.wgrad_join()
         kern.zero_(self.grads)
         for p, o in zip(self._plist, self._offs):
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
@@ -113,6 +115,8 @@ class FusedSGD:
         captured in a HIP graph, where a host->device copy is not allowed inside the captured region."""
         if sync_hyper:
             self._sync_hyper()
+        from . import ops
+        ops.wgrad_join()  # weight gradients issued on the side stream (ops._WgradSide) must have landed
         kern.sgd_step(self.arena.params, self.arena.grads, self.buf, self.hyper, self.arena.numel)
         self._steps += 1
 

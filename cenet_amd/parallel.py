@@ -49,6 +49,8 @@ class GradReducer:
         if buf.numel() == 0:
             return
         if self.cuda:
+            from . import ops
+            ops.wgrad_join()  # weight gradients may still be running on their own stream (ops._WgradSide)
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
