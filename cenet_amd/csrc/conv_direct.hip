@@ -164,7 +164,11 @@ extern "C" int cenet_conv_direct_bf16(const float* x, const float* w, float* y, 
   a.tiles_x = cdiv(W, TW);
   a.tiles_y = cdiv(H, TH);
   a.ntiles = B * a.tiles_x * a.tiles_y;
-  int grid = a.ntiles < 256 ? a.ntiles : 256;  // one persistent workgroup per CU (LDS-limited)
+  // persistent workgroups: two per CU where two copies of the LDS image (weights + halo) fit in 160 KB — the staging of one
+  // then overlaps the MFMAs of the other — else one per CU.  (16-byte halo loads were tried and changed nothing.)
+  const bool two = !(k == 3 && Cin == 64 && Cout == 64);
+  const int slots = two ? 512 : 256;
+  int grid = a.ntiles < slots ? a.ntiles : slots;
   if (k == 5 && Cin == 32 && Cout == 32) {
     CENET_LAUNCH((conv_direct_bf16_kernel<32, 32, 5>), dim3(grid), dim3(256), stream, a);
   } else if (k == 3 && Cin == 64 && Cout == 64) {

@@ -32,9 +32,15 @@ def P(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """the current torch stream as a raw hipStream_t (this runs once per kernel launch: keep it cheap)"""
     if _lib.is_hostsim():
         return C.c_void_p(0)
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

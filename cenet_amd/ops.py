@@ -66,8 +66,13 @@ def _wgrad_side(*reads):
     cur = torch.cuda.current_stream()
     if _WgradSide.stream is None:
         _WgradSide.stream = torch.cuda.Stream()
+        _WgradSide.events = [torch.cuda.Event() for _ in range(64)]  # reused round-robin: creating one per op costs more
+        _WgradSide.next_event = 0
     side = _WgradSide.stream
-    side.wait_stream(cur)
+    ev = _WgradSide.events[_WgradSide.next_event & 63]
+    _WgradSide.next_event += 1
+    ev.record(cur)
+    side.wait_event(ev)
     with torch.cuda.stream(side):
         yield
     for t in reads:
