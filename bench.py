@@ -86,7 +86,7 @@ def dominant_kernel_probe(dev, B):
     # HBM bytes per launch from rocprofv3 PMC passes at B=32 (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/
     # r01_pmc_roofline_kernel*.csv): fp32 mode = implicit-GEMM gather, bf16 mode = LDS-halo direct conv; algorithmic = 411 MB
     bf16 = peak != PEAK_F32_MFMA_TFLOPS
-    traffic = (8.50e8 if bf16 else 1.157e9) if B == 32 else None
+    traffic = (8.66e8 if bf16 else 1.157e9) if B == 32 else None
     name = ("conv_direct_bf16_kernel<32,32,5>" if bf16 else "gemm_kernel<float,32,256,im2col>") + \
         " (out.rb.0.conv2 fwd, 5x5 32->32 @224^2)"
     alg_bytes = 4.0 * (2 * B * 32 * 224 * 224 + 32 * 32 * 25)  # input + output + weights, fp32 in HBM
@@ -135,8 +135,8 @@ def extra_kernel_probes(dev, B):
     fl_b = 2.0 * B * 2 * H * N * N * (2 * hd + 2 * 2 * hd) + 2.0 * B * 2 * H * N * N * (2 * hd + 2 * hd)
     peak = peak_tflops()
     bf = kern.get_compute_bf16()
-    kf = "flashb_fwd_kernel<32,32>" if bf else "flash_fwd_kernel<16,32>"
-    kb = "flashb_bwd_dq+dkv_kernel<32,32>" if bf else "flash_bwd_dq+dkv_kernel<16,32>"
+    kf = "flashc_fwd_kernel<32,32,2>" if bf else "flash_fwd_kernel<16,32>"
+    kb = "flashc_bwd_dq+dkv_kernel<32,32,2>" if bf else "flash_bwd_dq+dkv_kernel<16,32>"
     out.append({"kernel": kf + " (DSEB-56^2 differential attention: 8 heads, N=3136, hd=16, dv=32)", "bound": "mfma",
                 "achieved": round(fl_f / t_f / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl_f / t_f / 1e9 / peak, 4), "avg_launch_ms": round(t_f, 3)})
