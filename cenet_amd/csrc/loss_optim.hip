@@ -10,15 +10,20 @@
 // the partial sums of a workgroup land in one of LOSS_SLOTS replicas of acc, LOSS_SLOT_STRIDE floats (256 bytes) apart: float
 // atomics onto one cache line serialise (~12 ns each), so thousands of workgroups must not share a line
 #define LOSS_SLOTS 16
-#define LOSS_SLOT_STRIDE 64
+#define LOSS_SLOT_STRIDE 128
 
-// acc layout: [0..K) intersect, [K..2K) z_sum (p^2), [2K..3K) y_sum (t), [3K] ce_sum
+// acc layout: [0..K) intersect, [K..2K) z_sum (p^2), [2K..3K) y_sum (t), [3K] ce_sum, [3K+1..4K+1) boundary pixel counts
+// (BoundaryDoULoss, core.py:105-109), and after finalize [4K+1..5K+1) the per-class alpha of core.py:112-119
 __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
-                                                         float* __restrict__ acc, int K, int HW, long npix) {
+                                                         float* __restrict__ acc, int K, int HW, long npix, int W,
+                                                         int boundary) {
   __shared__ float red[16];
-  float part[3 * LOSS_MAXK + 1];
+  float part[3 * LOSS_MAXK + 1], bnd[LOSS_MAXK];
 #pragma unroll
   for (int i = 0; i < 3 * LOSS_MAXK + 1; ++i) part[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < LOSS_MAXK; ++i) bnd[i] = 0.f;
+  const int H = HW / W;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
     const long b = e / HW;
     const int p = (int)(e - b * HW);
@@ -40,9 +45,17 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restric
       }
     const float inv = 1.f / s;
     const int t = (int)labels[e];
+    bool edge = false;
+    if (boundary) {  // a foreground pixel of class t is a boundary pixel unless its four neighbours (zero padded) share t
+      const int py = p / W, px = p - py * W;
+      const float* lb = labels + b * HW;
+      edge = !(py > 0 && (int)lb[p - W] == t && py + 1 < H && (int)lb[p + W] == t && px > 0 && (int)lb[p - 1] == t &&
+               px + 1 < W && (int)lb[p + 1] == t);
+    }
 #pragma unroll
     for (int c = 0; c < LOSS_MAXK; ++c)
       if (c < K) {
+        if (c == t && edge) bnd[c] += 1.f;
         const float pc = v[c] * inv;
         part[LOSS_MAXK + c] += pc * pc;
         if (c == t) {
@@ -57,10 +70,12 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restric
   for (int c = 0; c < LOSS_MAXK; ++c)
     if (c < K) {
       float a0 = block_sum(part[c], red), a1 = block_sum(part[LOSS_MAXK + c], red), a2 = block_sum(part[2 * LOSS_MAXK + c], red);
+      const float a3 = boundary ? block_sum(bnd[c], red) : 0.f;
       if (threadIdx.x == 0) {
         atomicAdd(&slot[c], a0);
         atomicAdd(&slot[K + c], a1);
         atomicAdd(&slot[2 * K + c], a2);
+        if (boundary) atomicAdd(&slot[3 * K + 1 + c], a3);
       }
     }
   float ce = block_sum(part[3 * LOSS_MAXK], red);
@@ -68,33 +83,48 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restric
 }
 
 __global__ void dice_ce_finalize_kernel(float* __restrict__ acc, float* __restrict__ loss, int K, float npix,
-                                        float w_dice, float w_ce) {
-  if (threadIdx.x < 3 * K + 1) {  // fold the replicas into slot 0 (what the backward kernel reads)
+                                        float w_dice, float w_ce, float w_bd) {
+  if (threadIdx.x < 4 * K + 1) {  // fold the replicas into slot 0 (what the backward kernel reads)
     float t = 0.f;
     for (int sidx = 0; sidx < LOSS_SLOTS; ++sidx) t += acc[sidx * LOSS_SLOT_STRIDE + threadIdx.x];
     acc[threadIdx.x] = t;
   }
   __syncthreads();
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float d = 0.f;
-    for (int c = 0; c < K; ++c) d += 1.f - (2.f * acc[c] + 1e-5f) / (acc[K + c] + acc[2 * K + c] + 1e-5f);
-    loss[0] = w_dice * d / K + w_ce * acc[3 * K] / npix;
+    float d = 0.f, bd = 0.f;
+    for (int c = 0; c < K; ++c) {
+      const float I = acc[c], z = acc[K + c], y = acc[2 * K + c];
+      d += 1.f - (2.f * I + 1e-5f) / (z + y + 1e-5f);
+      // BoundaryDoU (core.py:110-121): alpha from the boundary / area ratio of the class mask, truncated at 0.8
+      float alpha = 2.f * (1.f - (acc[3 * K + 1 + c] + 1e-5f) / (y + 1e-5f)) - 1.f;
+      if (alpha > 0.8f) alpha = 0.8f;
+      acc[4 * K + 1 + c] = alpha;
+      bd += (z + y - 2.f * I + 1e-5f) / (z + y - (1.f + alpha) * I + 1e-5f);
+    }
+    loss[0] = w_dice * d / K + w_ce * acc[3 * K] / npix + w_bd * bd / K;
   }
 }
 
 __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                          const float* __restrict__ acc, const float* __restrict__ gout,
                                                          float* __restrict__ dlogits, int K, int HW, long npix, float w_dice,
-                                                         float w_ce) {
+                                                         float w_ce, float w_bd) {
   const float go = gout[0];
   float A[LOSS_MAXK], Bc[LOSS_MAXK];  // dL/dp_c = A_c * t_c + Bc_c * p_c
 #pragma unroll
   for (int c = 0; c < LOSS_MAXK; ++c)
     if (c < K) {
-      const float D = acc[K + c] + acc[2 * K + c] + 1e-5f;
-      const float num = 2.f * acc[c] + 1e-5f;
+      const float I = acc[c], zy = acc[K + c] + acc[2 * K + c];
+      const float D = zy + 1e-5f;
+      const float num = 2.f * I + 1e-5f;
       A[c] = -w_dice / K * 2.f / D;
       Bc[c] = w_dice / K * num * 2.f / (D * D);
+      if (w_bd != 0.f) {  // L_c = N / Db, N = z+y-2I+eps, Db = z+y-(1+alpha)I+eps ; dz/dp = 2p, dI/dp = t
+        const float alpha = acc[4 * K + 1 + c];
+        const float N = zy - 2.f * I + 1e-5f, Db = zy - (1.f + alpha) * I + 1e-5f;
+        A[c] += w_bd / K * (N * (1.f + alpha) - 2.f * Db) / (Db * Db);
+        Bc[c] += w_bd / K * 2.f * (Db - N) / (Db * Db);
+      }
     }
   const float cew = w_ce / (float)npix;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
@@ -161,28 +191,41 @@ int cenet_zero_async(float* p, long n, hipStream_t stream) {
   return CENET_OK;
 }
 
-extern "C" int cenet_dice_ce_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int HW,
-                                     float w_dice, float w_ce, hipStream_t stream) {
-  if (B <= 0 || K <= 0 || K > LOSS_MAXK || HW <= 0) return CENET_EINVAL;
+// loss = w_dice * Dice + w_ce * CE + w_bd * BoundaryDoU, all from one pass over the logits (labels [B,H,W] as floats)
+extern "C" int cenet_seg_loss_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int H,
+                                      int W, float w_dice, float w_ce, float w_bd, hipStream_t stream) {
+  if (B <= 0 || K <= 0 || K > LOSS_MAXK || H <= 0 || W <= 0) return CENET_EINVAL;
   if (cenet_zero_async(acc, (long)LOSS_SLOTS * LOSS_SLOT_STRIDE, stream) != CENET_OK) return CENET_EINVAL;
+  const int HW = H * W;
   const long npix = (long)B * HW;
   long blocks = (npix + 2047) / 2048;
   if (blocks > 1024) blocks = 1024;
-  CENET_LAUNCH(dice_ce_fwd_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix);
-  CENET_LAUNCH(dice_ce_finalize_kernel, dim3(1), dim3(64), stream, acc, loss, K, (float)npix, w_dice, w_ce);
+  CENET_LAUNCH(dice_ce_fwd_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W,
+               (int)(w_bd != 0.f));
+  CENET_LAUNCH(dice_ce_finalize_kernel, dim3(1), dim3(128), stream, acc, loss, K, (float)npix, w_dice, w_ce, w_bd);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_dice_ce_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout,
-                                     float* dlogits, int B, int K, int HW, float w_dice, float w_ce, hipStream_t stream) {
-  if (B <= 0 || K <= 0 || K > LOSS_MAXK || HW <= 0) return CENET_EINVAL;
+extern "C" int cenet_seg_loss_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout,
+                                      float* dlogits, int B, int K, int H, int W, float w_dice, float w_ce, float w_bd,
+                                      hipStream_t stream) {
+  if (B <= 0 || K <= 0 || K > LOSS_MAXK || H <= 0 || W <= 0) return CENET_EINVAL;
+  const int HW = H * W;
   const long npix = (long)B * HW;
   long blocks = (npix + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   CENET_LAUNCH(dice_ce_bwd_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix,
-               w_dice, w_ce);
+               w_dice, w_ce, w_bd);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
+}
+extern "C" int cenet_dice_ce_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int HW,
+                                     float w_dice, float w_ce, hipStream_t stream) {
+  return cenet_seg_loss_fwd_f32(logits, labels, acc, loss, B, K, 1, HW, w_dice, w_ce, 0.f, stream);
+}
+extern "C" int cenet_dice_ce_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout,
+                                     float* dlogits, int B, int K, int HW, float w_dice, float w_ce, hipStream_t stream) {
+  return cenet_seg_loss_bwd_f32(logits, labels, acc, gout, dlogits, B, K, 1, HW, w_dice, w_ce, 0.f, stream);
 }
 extern "C" int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;

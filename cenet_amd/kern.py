@@ -426,6 +426,16 @@ def dice_ce_bwd(logits, labels, acc, gout, dlogits, B, K, HW, w_dice, w_ce):
     _call("cenet_dice_ce_bwd_f32", logits, labels, acc, gout, dlogits, B, K, HW, float(w_dice), float(w_ce))
 
 
+def seg_loss_fwd(logits, labels, acc, loss, B, K, H, W, w_dice, w_ce, w_bd):
+    _chk(logits, labels, acc, loss)
+    _call("cenet_seg_loss_fwd_f32", logits, labels, acc, loss, B, K, H, W, float(w_dice), float(w_ce), float(w_bd))
+
+
+def seg_loss_bwd(logits, labels, acc, gout, dlogits, B, K, H, W, w_dice, w_ce, w_bd):
+    _chk(logits, labels, acc, gout, dlogits)
+    _call("cenet_seg_loss_bwd_f32", logits, labels, acc, gout, dlogits, B, K, H, W, float(w_dice), float(w_ce), float(w_bd))
+
+
 def sgd_step(p, g, buf, hyper5, n):
     _chk(p, g, buf, hyper5)
     _call("cenet_sgd_step_f32", p, g, buf, hyper5, L(n))

@@ -1,7 +1,8 @@
 """Loss interface mirroring reference src/utils/core.py:161-188 (`Criterion(num_classes, args)(outputs, labels)`).
 
-The Dice + cross-entropy pair (the hot-path loss of BASELINE.json) runs as one fused HIP kernel each way
-(cenet_amd.ops.dice_ce_loss); BoundaryDoULoss is SURVEY.md §8f "next" and raises NotImplementedError.
+Dice, cross-entropy and BoundaryDoULoss (core.py:44-131) are terms of ONE fused HIP kernel each way
+(cenet_amd.ops.dice_ce_loss): the per-class sums they share are accumulated once, the boundary-pixel counts of
+BoundaryDoULoss come from the same pass over the labels, and the backward is a single kernel for any weighting.
 """
 from __future__ import annotations
 
@@ -23,22 +24,33 @@ class DiceLoss(nn.Module):
         return ops.dice_ce_loss(inputs, target, 1.0, 0.0)
 
 
+class BoundaryDoULoss(nn.Module):
+    """core.py:83-131 (no hard-coded .cuda(): the boundary counts are computed on the device that holds the labels)."""
+
+    def __init__(self, n_classes):
+        super().__init__()
+        self.n_classes = n_classes
+
+    def forward(self, inputs, target):
+        return ops.dice_ce_loss(inputs, target, 0.0, 0.0, 1.0)
+
+
 class Criterion(nn.Module):
     def __init__(self, num_classes, args):
         super().__init__()
         self.num_classes = num_classes
         names = args.loss_type.split(',')
         weights = [float(w) for w in args.loss_weights.split(',')]
-        self.w_dice = self.w_ce = 0.0
+        self.w_dice = self.w_ce = self.w_bd = 0.0
         for n, w in zip(names, weights):
             if n == "dice":
                 self.w_dice += w
             elif n == "ce":
                 self.w_ce += w
             elif n == "boundary":
-                raise NotImplementedError("BoundaryDoULoss is not on the round-1 hot path (SURVEY.md §8f)")
+                self.w_bd += w
             else:
                 raise NotImplementedError(f"Loss {n} not implemented")
 
     def forward(self, outputs, labels):
-        return ops.dice_ce_loss(outputs, labels, self.w_dice, self.w_ce)
+        return ops.dice_ce_loss(outputs, labels, self.w_dice, self.w_ce, self.w_bd)

@@ -1242,29 +1242,30 @@ def dseb_combine(y, w, diff, recons: Sequence[Optional[Tensor]], ycoef: float = 
 # loss (utils/core.py:44-80,161-188)
 # =====================================================================================================
 class DiceCELossFn(Function):
+    """w_dice * Dice + w_ce * CE + w_bd * BoundaryDoU in one pass over the logits each way (core.py:44-131,161-188)."""
+
     @staticmethod
-    def forward(ctx, logits, labels, w_dice, w_ce):
+    def forward(ctx, logits, labels, w_dice, w_ce, w_bd=0.0):
         logits, labels = _c(logits), _c(labels)
         B, K = logits.shape[:2]
-        HW = logits.numel() // (B * K)
-        acc = _empty((1024,), logits)  # CENET_LOSS_ACC_FLOATS (include/cenet_hip.h): replicated partial sums
+        H, W = (logits.shape[2], logits.shape[3]) if logits.dim() == 4 else (1, logits.numel() // (B * K))
+        acc = _empty((2048,), logits)  # CENET_LOSS_ACC_FLOATS (include/cenet_hip.h): replicated partial sums
         loss = _empty((1,), logits)
-        kern.dice_ce_fwd(logits, labels, acc, loss, B, K, HW, w_dice, w_ce)
+        kern.seg_loss_fwd(logits, labels, acc, loss, B, K, H, W, w_dice, w_ce, w_bd)
         ctx.save_for_backward(logits, labels, acc)
-        ctx.cfg = (w_dice, w_ce)
+        ctx.cfg = (w_dice, w_ce, w_bd, H, W)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         logits, labels, acc = ctx.saved_tensors
-        w_dice, w_ce = ctx.cfg
+        w_dice, w_ce, w_bd, H, W = ctx.cfg
         B, K = logits.shape[:2]
-        HW = logits.numel() // (B * K)
         g = _c(g).reshape(1)
         d = torch.empty_like(logits)
-        kern.dice_ce_bwd(logits, labels, acc, g, d, B, K, HW, w_dice, w_ce)
-        return d, None, None, None
+        kern.seg_loss_bwd(logits, labels, acc, g, d, B, K, H, W, w_dice, w_ce, w_bd)
+        return d, None, None, None, None
 
 
-def dice_ce_loss(logits, labels, w_dice=0.5, w_ce=0.5):
-    return DiceCELossFn.apply(logits, labels, w_dice, w_ce)
+def dice_ce_loss(logits, labels, w_dice=0.5, w_ce=0.5, w_boundary=0.0):
+    return DiceCELossFn.apply(logits, labels, w_dice, w_ce, w_boundary)

@@ -224,11 +224,17 @@ int cenet_diffattn_combine_bwd_acc_f32(const float* U, const float* lam3, const 
 /* ---- loss + optimiser (loss_optim.hip) ---------------------------------------------------------------------- */
 /* utils/core.py:44-80,161-188: loss = w_dice*Dice(softmax(logits), onehot(labels)) + w_ce*CE.
  * acc: CENET_LOSS_ACC_FLOATS floats of workspace (replicated partial sums); its first 3K+1 floats are what bwd reads. */
-#define CENET_LOSS_ACC_FLOATS 1024
+#define CENET_LOSS_ACC_FLOATS 2048
 int cenet_dice_ce_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int HW, float w_dice,
                           float w_ce, cenet_stream_t stream);
 int cenet_dice_ce_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout, float* dlogits, int B,
                           int K, int HW, float w_dice, float w_ce, cenet_stream_t stream);
+/* The same with BoundaryDoULoss (utils/core.py:83-131, the loss of scripts/acdc.sh:63 / synapse.sh:67) as a third term:
+ * loss = w_dice*Dice + w_ce*CE + w_bd*BoundaryDoU; labels [B,H,W] (class ids as floats). */
+int cenet_seg_loss_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int H, int W,
+                           float w_dice, float w_ce, float w_bd, cenet_stream_t stream);
+int cenet_seg_loss_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout, float* dlogits,
+                           int B, int K, int H, int W, float w_dice, float w_ce, float w_bd, cenet_stream_t stream);
 /* torch.optim.SGD(momentum, weight_decay) over a flat arena; hyper5 (device) = [lr, momentum, wd, grad_scale, first_step] */
 int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, cenet_stream_t stream);
 int cenet_zero_f32(float* p, long n, cenet_stream_t stream);

@@ -393,6 +393,29 @@ def dice_loss(logits: Tensor, target: Tensor, n_classes: int) -> Tensor:
     return loss / n_classes
 
 
+def boundary_dou_loss(logits: Tensor, target: Tensor, n_classes: int) -> Tensor:
+    """core.py:83-131 (BoundaryDoULoss), device-agnostic.  Per class c, with t = (target == c) over the whole batch:
+    C = number of foreground pixels whose 4-neighbourhood (zero padded) is not all foreground (core.py:105-109: cross-kernel
+    conv * t, values 5 zeroed, count_nonzero), S = count_nonzero(t), alpha = min(2 (1 - (C+eps)/(S+eps)) - 1, 0.8),
+    loss_c = (z + y - 2 I + eps) / (z + y - (1 + alpha) I + eps) with I = sum(p t), y = sum(t t), z = sum(p p);
+    result = mean over classes (core.py:127-131).  alpha depends on the labels only and carries no gradient."""
+    p = torch.softmax(logits, dim=1)
+    kernel = torch.tensor([[0., 1., 0.], [1., 1., 1.], [0., 1., 0.]], dtype=logits.dtype).view(1, 1, 3, 3)
+    smooth = 1e-5
+    loss = 0.0
+    for i in range(n_classes):
+        t = (target == i).to(logits.dtype)
+        y = F.conv2d(t.unsqueeze(1), kernel, padding=1)[:, 0] * t
+        y = torch.where(y == 5, torch.zeros_like(y), y)
+        cnt, s = torch.count_nonzero(y), torch.count_nonzero(t)
+        alpha = 1 - (cnt + smooth) / (s + smooth)
+        alpha = min(float(2 * alpha - 1), 0.8)
+        score = p[:, i]
+        inter, y_sum, z_sum = torch.sum(score * t), torch.sum(t * t), torch.sum(score * score)
+        loss = loss + (z_sum + y_sum - 2 * inter + smooth) / (z_sum + y_sum - (1 + alpha) * inter + smooth)
+    return loss / n_classes
+
+
 def criterion(logits: Tensor, labels: Tensor, n_classes: int, loss_type=("dice", "ce"), weights=(0.5, 0.5)) -> Tensor:
     """core.py:179-188."""
     loss = 0.0
@@ -401,6 +424,8 @@ def criterion(logits: Tensor, labels: Tensor, n_classes: int, loss_type=("dice",
             loss = loss + w * F.cross_entropy(logits, labels.long())
         elif name == "dice":
             loss = loss + w * dice_loss(logits, labels, n_classes)
+        elif name == "boundary":
+            loss = loss + w * boundary_dou_loss(logits, labels, n_classes)
         else:
             raise NotImplementedError(name)
     return loss

@@ -60,6 +60,20 @@ def test_loss_golden():
         np.testing.assert_allclose(logits.grad.numpy(), z[f"K{K}.grad"], rtol=1e-4, atol=1e-8)
 
 
+def test_boundary_loss_golden():
+    """BoundaryDoULoss (core.py:83-131) and its 'boundary,ce' combination vs vectors produced by the reference class
+    (oracle/gen_golden_boundary.py); K = 9 has an absent class."""
+    z = np.load(os.path.join(GOLDEN, "loss_boundary.npz"))
+    for K in (4, 9, 2):
+        names, weights = str(z[f"K{K}.spec"][0]).split(","), [float(w) for w in str(z[f"K{K}.spec"][1]).split(",")]
+        logits = torch.from_numpy(z[f"K{K}.logits"]).clone().requires_grad_(True)
+        labels = torch.from_numpy(z[f"K{K}.labels"])
+        loss = O.criterion(logits, labels, K, loss_type=names, weights=weights)
+        loss.backward()
+        assert abs(loss.item() - float(z[f"K{K}.loss"])) < 1e-6
+        np.testing.assert_allclose(logits.grad.numpy(), z[f"K{K}.grad"], rtol=1e-4, atol=1e-8)
+
+
 @pytest.mark.parametrize("name", list(MODEL_CONFIGS))
 def test_schema_matches_reference(name):
     ref = json.load(open(os.path.join(GOLDEN, f"schema_{name}.json")))
