@@ -366,20 +366,25 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(&ws[2 * c], s1);
-    atomicAdd(&ws[2 * c + 1], s2);
+  if (threadIdx.x == 0) {  // one slot per (channel, split): no zero-fill, no atomics; the consumer adds the gridDim.y slots
+    ws[((long)c) * gridDim.y + blockIdx.y] = s1;
+    ws[((long)gridDim.x + c) * gridDim.y + blockIdx.y] = s2;
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ x, int HW, const float* __restrict__ ws, int C, float n,
+__global__ void bn_finalize_kernel(const float* __restrict__ x, int HW, const float* __restrict__ ws, int C, int S, float n,
                                    float* __restrict__ mean, float* __restrict__ var, float* running_mean,
                                    float* running_var, float momentum, long* nbt) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
     float shift = x[(long)c * HW];
-    float m = ws[2 * c] / n;
-    float v = ws[2 * c + 1] / n - m * m;
+    float a1 = 0.f, a2 = 0.f;
+    for (int i = 0; i < S; ++i) {
+      a1 += ws[(long)c * S + i];
+      a2 += ws[((long)C + c) * S + i];
+    }
+    float m = a1 / n;
+    float v = a2 / n - m * m;
     if (v < 0.f) v = 0.f;
     float mu = shift + m;
     mean[c] = mu;
@@ -430,9 +435,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(&ws[2 * c], s1);
-    atomicAdd(&ws[2 * c + 1], s2);
+  if (threadIdx.x == 0) {  // one slot per (channel, split): no zero-fill, no atomics; the consumer adds the gridDim.y slots
+    ws[((long)c) * gridDim.y + blockIdx.y] = s1;
+    ws[((long)gridDim.x + c) * gridDim.y + blockIdx.y] = s2;
   }
 }
 
@@ -441,12 +446,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                           const float* __restrict__ mean, const float* __restrict__ var,
                                                           float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int act, float slope, int C, int HW,
-                                                          float n, const float* __restrict__ ws, float* dgamma,
+                                                          float n, const float* __restrict__ ws, int S, float* dgamma,
                                                           float* dbeta) {
   const int bc = blockIdx.x;
   const int b = bc / C, c = bc - b * C;
   const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
-  const float s1 = ws[2 * c], s2 = ws[2 * c + 1];
+  __shared__ float red[16];
+  float p1 = 0.f, p2 = 0.f;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    p1 += ws[(long)c * S + i];
+    p2 += ws[((long)C + c) * S + i];
+  }
+  const float s1 = block_sum(p1, red), s2 = block_sum(p2, red);
   const float m1 = s1 / n, m2 = s2 / n;
   const float* xp = x + (long)b * sxb + (long)c * HW;
   const float* gp = dy + (long)b * sgb + (long)c * HW;
@@ -496,9 +507,9 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(&ws[2 * c], s1);
-    atomicAdd(&ws[2 * c + 1], s2);
+  if (threadIdx.x == 0) {  // one slot per (channel, split): no zero-fill, no atomics; the consumer adds the gridDim.y slots
+    ws[((long)c) * gridDim.y + blockIdx.y] = s1;
+    ws[((long)gridDim.x + c) * gridDim.y + blockIdx.y] = s2;
   }
 }
 
@@ -563,9 +574,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
-  if (threadIdx.x == 0) {
-    atomicAdd(&ws[2 * c], s1);
-    atomicAdd(&ws[2 * c + 1], s2);
+  if (threadIdx.x == 0) {  // one slot per (channel, split): no zero-fill, no atomics; the consumer adds the gridDim.y slots
+    ws[((long)c) * gridDim.y + blockIdx.y] = s1;
+    ws[((long)gridDim.x + c) * gridDim.y + blockIdx.y] = s2;
   }
 }
 
@@ -574,12 +585,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
                                                              const float* __restrict__ mean, const float* __restrict__ var,
                                                              float eps, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act, float slope, int C,
-                                                             int HW, float n, const float* __restrict__ ws, float* dgamma,
+                                                             int HW, float n, const float* __restrict__ ws, int S, float* dgamma,
                                                              float* dbeta) {
   const int bc = blockIdx.x;
   const int b = bc / C, c = bc - b * C;
   const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
-  const float s1 = ws[2 * c], s2 = ws[2 * c + 1];
+  __shared__ float red[16];
+  float p1 = 0.f, p2 = 0.f;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    p1 += ws[(long)c * S + i];
+    p2 += ws[((long)C + c) * S + i];
+  }
+  const float s1 = block_sum(p1, red), s2 = block_sum(p2, red);
   const float m1 = s1 / n, m2 = s2 / n;
   const float* xp = x + (long)b * sxb + (long)c * HW;
   const float* gp = dy + (long)b * sgb + (long)c * HW;
@@ -639,13 +656,16 @@ extern "C" int cenet_bn_stats_f32(const float* x, long sb, int B, int C, int HW,
                                   float* running_mean, float* running_var, float momentum, long* num_batches_tracked,
                                   hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  if (cenet_zero_async(ws, 2L * C, stream) != CENET_OK) return CENET_EINVAL;
   const long total = (long)B * HW;
-  if (bn_v4_ok(HW, x, sb, x, sb, x, sb))
-    CENET_LAUNCH(bn_partial_v4_kernel, dim3(C, bn_splits_v4(C, total / 4)), dim3(256), stream, x, sb, B, HW, ws);
-  else
-    CENET_LAUNCH(bn_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, x, sb, B, HW, ws);
-  CENET_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), stream, x, HW, (const float*)ws, C, (float)total, mean, var,
+  int S;
+  if (bn_v4_ok(HW, x, sb, x, sb, x, sb)) {
+    S = bn_splits_v4(C, total / 4);
+    CENET_LAUNCH(bn_partial_v4_kernel, dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
+  } else {
+    S = bn_splits(C, total);
+    CENET_LAUNCH(bn_partial_kernel, dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
+  }
+  CENET_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), stream, x, HW, (const float*)ws, C, S, (float)total, mean, var,
                running_mean, running_var, momentum, num_batches_tracked);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
@@ -675,22 +695,23 @@ extern "C" int cenet_bn_bwd_acc_f32(const float* dy, long sgb, const float* x, l
                                     int act, float slope, int B, int C, int HW, float* ws, float* dgamma_acc,
                                     float* dbeta_acc, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  if (cenet_zero_async(ws, 2L * C, stream) != CENET_OK) return CENET_EINVAL;
   const long total = (long)B * HW;
   if (bn_v4_ok(HW, dy, sgb, x, sxb, dx, sdb)) {
-    CENET_LAUNCH(bn_bwd_partial_v4_kernel, dim3(C, bn_splits_v4(C, total / 4)), dim3(256), stream, dy, sgb, x, sxb, mean, var,
-                 eps, gamma, beta, act, slope, B, HW, ws);
+    const int S = bn_splits_v4(C, total / 4);
+    CENET_LAUNCH(bn_bwd_partial_v4_kernel, dim3(C, S), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma, beta, act,
+                 slope, B, HW, ws);
     int threads, chunks;
     bn_plane_launch(HW / 4, &threads, &chunks);
     CENET_LAUNCH(bn_bwd_apply_v4_kernel, dim3(B * C, chunks), dim3(threads), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps,
-                 gamma, beta, act, slope, C, HW, (float)total, (const float*)ws, dgamma_acc, dbeta_acc);
+                 gamma, beta, act, slope, C, HW, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc);
   } else {
-    CENET_LAUNCH(bn_bwd_partial_kernel, dim3(C, bn_splits(C, total)), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma,
-                 beta, act, slope, B, HW, ws);
+    const int S = bn_splits(C, total);
+    CENET_LAUNCH(bn_bwd_partial_kernel, dim3(C, S), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma, beta, act, slope,
+                 B, HW, ws);
     int chunks = cdiv(HW, 1024);
     if (chunks > 64) chunks = 64;
     CENET_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma,
-                 beta, act, slope, C, HW, (float)total, (const float*)ws, dgamma_acc, dbeta_acc);
+                 beta, act, slope, C, HW, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;

@@ -370,7 +370,7 @@ class BatchNormFn(Function):
         y = torch.empty_like(x)
         if training:
             mean, var = _empty((Cn,), x), _empty((Cn,), x)
-            ws = _empty((2 * Cn,), x)
+            ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
             kern.bn_stats(x, Cn * HW, B, Cn, HW, ws, mean, var, rmean, rvar, momentum, nbt)
         else:
             mean, var = rmean, rvar
@@ -391,7 +391,7 @@ class BatchNormFn(Function):
         B, Cn = x.shape[:2]
         HW = x.numel() // (B * Cn)
         dx = torch.empty_like(x)
-        ws = _empty((2 * Cn,), x)
+        ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
         dg, db = grad_buf(wp), grad_buf(bp)
         if dg is None:
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
@@ -1087,7 +1087,7 @@ class CCUFn(Function):
             zn = torch.empty_like(z)
             if training:
                 mean, var = _empty((Cn,), x), _empty((Cn,), x)
-                ws = _empty((2 * Cn,), x)
+                ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
                 kern.bn_stats(z, Cn, B, Cn, 1, ws, mean, var, bn_rm, bn_rv, 0.1, bn_nbt)
             else:
                 mean, var = bn_rm, bn_rv
@@ -1114,7 +1114,7 @@ class CCUFn(Function):
             if not training:
                 raise RuntimeError("CCU backward needs training-mode BatchNorm")
             dz = torch.empty_like(dzn)
-            ws = _empty((2 * Cn,), x)
+            ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
             dg, db = grad_buf(ctx.refs[2]), grad_buf(ctx.refs[3])
             if dg is None:
                 dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
@@ -1148,7 +1148,7 @@ class SRMFn(Function):
         kern.act_fwd(f, fa, f.numel(), "gelu")
         if training:
             mean, var = _empty((1,), x), _empty((1,), x)
-            ws = _empty((2,), x)
+            ws = _empty((2 * 256,), x)  # CENET_BN_WS_FLOATS(1)
             kern.bn_stats(fa, HW, B, 1, HW, ws, mean, var, bn_rm, bn_rv, 0.1, bn_nbt)
         else:
             mean, var = bn_rm, bn_rv
@@ -1172,7 +1172,7 @@ class SRMFn(Function):
         dfb = torch.empty_like(f)
         kern.gate_pix_bwd_reduce(x, g, fb, dfb, B, Cn, HW)
         dfa = torch.empty_like(f)
-        ws = _empty((2,), x)
+        ws = _empty((2 * 256,), x)  # CENET_BN_WS_FLOATS(1)
         dg, db = grad_buf(ctx.refs[2]), grad_buf(ctx.refs[3])
         if dg is None:
             dg, db = _zeros((1,), x), _zeros((1,), x)

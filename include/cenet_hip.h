@@ -121,8 +121,10 @@ int cenet_layernorm_fwd_f32(const float* x, const float* gamma, const float* bet
 int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                 float* dx, float* dgamma_acc, float* dbeta_acc, int rows, int C, cenet_stream_t stream);
 /* aten::native_batch_norm(+_backward), training mode — cfam.py:22-32,92,250; blocks.py:151,161,212,307; nlb.py:81;
- * unet.py:175-197.  ws: 2*C floats of scratch.  stats writes batch mean / biased var and updates the running
+ * unet.py:175-197.  ws: CENET_BN_WS_FLOATS(C) floats of scratch (per-split partial sums, no zero-fill needed).
+ * stats writes batch mean / biased var and updates the running
  * buffers (momentum, unbiased var) and num_batches_tracked when given. */
+#define CENET_BN_WS_FLOATS(C) (2L * (C) * 256)
 int cenet_bn_stats_f32(const float* x, long sb, int B, int C, int HW, float* ws, float* mean, float* var,
                        float* running_mean, float* running_var, float momentum, long* num_batches_tracked,
                        cenet_stream_t stream);

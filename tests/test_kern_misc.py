@@ -57,7 +57,7 @@ def test_batchnorm_train_fwd_bwd(dev, B, C, HW, Ctot, act):
     ref.backward(dy)
     xd = xfull.to(dev)
     sxb = Ctot * HW
-    mean, var, ws = (torch.empty(n, device=dev) for n in (C, C, 2 * C))
+    mean, var, ws = (torch.empty(n, device=dev) for n in (C, C, 2 * C * 256))
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     nbt = torch.zeros(1, dtype=torch.int64, device=dev)
     kern.bn_stats(xd, sxb, B, C, HW, ws, mean, var, rm, rv, 0.1, nbt)
