@@ -239,3 +239,54 @@ extern "C" int cenet_zero_f32(float* p, long n, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
   return cenet_zero_async(p, n, stream);
 }
+
+// ---- evaluation: argmax mask + overlap counts (main_acdc.py:218-231, metrics_eval.py:24-34,46-49) ---------------------
+// pred[b,p] = argmax_c logits[b,c,p] (first maximum, like torch.argmax; softmax is monotone so it is skipped);
+// counts[c][0..2] = #(pred==c & gt==c), #(pred==c), #(gt==c) for c < K, and row K = the binary masks pred>0 / gt>0.
+__global__ __launch_bounds__(256) void argmax_counts_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                           float* __restrict__ pred, unsigned* __restrict__ counts, int K,
+                                                           int HW, long npix) {
+  __shared__ unsigned sc[(LOSS_MAXK + 1) * 3];
+  for (int i = threadIdx.x; i < (K + 1) * 3; i += 256) sc[i] = 0u;
+  __syncthreads();
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
+    const long b = e / HW;
+    const int p = (int)(e - b * HW);
+    const float* lp = logits + b * (long)K * HW + p;
+    float best = lp[0];
+    int arg = 0;
+    for (int c = 1; c < K; ++c) {
+      const float v = lp[(long)c * HW];
+      if (v > best) {
+        best = v;
+        arg = c;
+      }
+    }
+    if (pred) pred[e] = (float)arg;
+    if (labels) {
+      const int t = (int)labels[e];
+      atomicAdd(&sc[arg * 3 + 1], 1u);
+      if (t >= 0 && t < K) atomicAdd(&sc[t * 3 + 2], 1u);
+      if (t == arg) atomicAdd(&sc[arg * 3], 1u);
+      if (arg > 0) atomicAdd(&sc[K * 3 + 1], 1u);
+      if (t > 0) atomicAdd(&sc[K * 3 + 2], 1u);
+      if (arg > 0 && t > 0) atomicAdd(&sc[K * 3], 1u);
+    }
+  }
+  __syncthreads();
+  if (labels)
+    for (int i = threadIdx.x; i < (K + 1) * 3; i += 256)
+      if (sc[i]) atomicAdd(&counts[i], sc[i]);
+}
+
+extern "C" int cenet_argmax_counts_f32(const float* logits, const float* labels, float* pred, unsigned* counts, int B, int K,
+                                       int HW, hipStream_t stream) {
+  if (!logits || B <= 0 || K <= 0 || K > LOSS_MAXK || HW <= 0 || (labels && !counts)) return CENET_EINVAL;
+  const long npix = (long)B * HW;
+  if (labels && cenet_zero_async((float*)counts, (K + 1) * 3L, stream) != CENET_OK) return CENET_EINVAL;
+  long blocks = (npix + 2047) / 2048;
+  if (blocks > 256) blocks = 256;
+  CENET_LAUNCH(argmax_counts_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, pred, counts, K, HW, npix);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}

@@ -436,6 +436,11 @@ def seg_loss_bwd(logits, labels, acc, gout, dlogits, B, K, H, W, w_dice, w_ce, w
     _call("cenet_seg_loss_bwd_f32", logits, labels, acc, gout, dlogits, B, K, H, W, float(w_dice), float(w_ce), float(w_bd))
 
 
+def argmax_counts(logits, labels, pred, counts, B, K, HW):
+    _chk(logits, labels, pred)
+    _call("cenet_argmax_counts_f32", logits, labels, pred, counts, B, K, HW)
+
+
 def sgd_step(p, g, buf, hyper5, n):
     _chk(p, g, buf, hyper5)
     _call("cenet_sgd_step_f32", p, g, buf, hyper5, L(n))

@@ -237,6 +237,11 @@ int cenet_seg_loss_fwd_f32(const float* logits, const float* labels, float* acc,
                            float w_dice, float w_ce, float w_bd, cenet_stream_t stream);
 int cenet_seg_loss_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout, float* dlogits,
                            int B, int K, int H, int W, float w_dice, float w_ce, float w_bd, cenet_stream_t stream);
+/* Evaluation (main_acdc.py:218-231 val(), metrics_eval.py:24-34,46-49): pred[B,HW] = argmax over the K
+ * logit planes (class ids as floats, may be NULL), counts[(K+1)*3] (uint32, zero-filled by the call; may be NULL together with
+ * labels) = per class {|pred==c & gt==c|, |pred==c|, |gt==c|} and, in row K, the same for the binary masks pred>0 / gt>0. */
+int cenet_argmax_counts_f32(const float* logits, const float* labels, float* pred, unsigned* counts, int B, int K, int HW,
+                            cenet_stream_t stream);
 /* torch.optim.SGD(momentum, weight_decay) over a flat arena; hyper5 (device) = [lr, momentum, wd, grad_scale, first_step] */
 int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, cenet_stream_t stream);
 int cenet_zero_f32(float* p, long n, cenet_stream_t stream);
