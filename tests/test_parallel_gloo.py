@@ -72,7 +72,9 @@ def _worker(rank, world, port, q):
         grads = arena.grads.clone() * red.grad_scale
         with torch.no_grad():
             arena.params.sub_(0.1 * grads)
-        q.put((rank, grads, arena.params.clone(), net.a[1].running_mean.clone(), hooks_fired))
+        # plain numpy through the queue: torch tensors travel as shared-memory handles that the parent can only open while
+        # this process is still alive (a race that showed up as FileNotFoundError under a loaded machine)
+        q.put((rank, grads.numpy(), arena.params.clone().numpy(), net.a[1].running_mean.clone().numpy(), hooks_fired))
     finally:
         dist.destroy_process_group()
 
@@ -86,6 +88,7 @@ def test_two_rank_gradients_are_the_mean_of_shard_gradients():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(g), torch.from_numpy(p_), torch.from_numpy(rm), fired) for r, g, p_, rm, fired in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
