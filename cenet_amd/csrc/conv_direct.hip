@@ -31,7 +31,7 @@ struct ConvDirectArgs {
 };
 
 template <int CIN, int COUT, int KS>
-__global__ __launch_bounds__(256) void conv_direct_bf16_kernel(ConvDirectArgs a) {
+__global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv_direct_bf16_kernel(ConvDirectArgs a) {
   constexpr int CQ = CIN / 8, HH = TH + KS - 1, HW_ = TW + KS - 1, KK = KS * KS, PADK = KS / 2;
   constexpr int UNITS = CQ * HH * HW_;           // 16-byte halo slots
   constexpr int UPT = (UNITS + 255) / 256;       // slots per thread
@@ -59,18 +59,27 @@ __global__ __launch_bounds__(256) void conv_direct_bf16_kernel(ConvDirectArgs a)
 
   const int HWp = a.H * a.W;
   float pre[UPT][8];
+  // a thread's halo slots are the same in every tile: their (channel octet, row, column) split and element offset are
+  // computed once; a tile only adds its origin
+  int uhy[UPT], uhx[UPT];
+  long uoff[UPT];
+#pragma unroll
+  for (int u = 0; u < UPT; ++u) {
+    const int s = tid + 256 * u;
+    const int cq = s / (HH * HW_), rem = s - cq * (HH * HW_);
+    uhy[u] = (s < UNITS) ? rem / HW_ - PADK : -(1 << 20);  // out-of-range slots fail every row test
+    uhx[u] = rem % HW_ - PADK;
+    uoff[u] = (long)(cq * 8) * HWp + (long)uhy[u] * a.W + uhx[u];
+  }
   auto load_halo = [&](int tile) {
     const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
     const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
-    const float* xb = a.x + (long)b * CIN * HWp;
+    const float* xt = a.x + (long)b * CIN * HWp + (long)(ty * TH) * a.W + tx * TW;
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
-      const int s = tid + 256 * u;
-      const int cq = s / (HH * HW_), rem = s - cq * (HH * HW_);
-      const int hy = rem / HW_, hx = rem - hy * HW_;
-      const int iy = ty * TH + hy - PADK, ix = tx * TW + hx - PADK;
-      const bool ok = (s < UNITS) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float* p = xb + (long)(cq * 8) * HWp + (long)iy * a.W + ix;
+      const int iy = ty * TH + uhy[u], ix = tx * TW + uhx[u];
+      const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float* p = xt + uoff[u];
 #pragma unroll
       for (int j = 0; j < 8; ++j) pre[u][j] = ok ? p[(long)j * HWp] : 0.f;
     }
@@ -103,8 +112,12 @@ __global__ __launch_bounds__(256) void conv_direct_bf16_kernel(ConvDirectArgs a)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     // wave w owns tile rows 2w, 2w+1 ; ni -> (row = 2w + ni/2, xseg = 16*(ni&1))
+    // fully unrolled: every LDS address below is one per-lane base plus a compile-time offset (the rolled loop spent ~35
+    // VALU instructions per tap on divisions and address arithmetic — the kernel was VALU-bound, not MFMA- or HBM-bound)
+#pragma unroll
     for (int t = 0; t < KK; ++t) {
-      const int ky = t / KS, kx = t - ky * KS;
+      constexpr int KS_ = KS;
+      const int ky = t / KS_, kx = t - ky * KS_;
 #pragma unroll
       for (int kb = 0; kb < CIN / 32; ++kb) {
         bf16x8 wf[MT];
