@@ -155,17 +155,19 @@ struct StageT {
       int row, col;
       coords(threadIdx.x + 256 * j, row, col);
       const unsigned pk[2] = {cenet_pack_bf2(r[j][0] * mul, r[j][1] * mul), cenet_pack_bf2(r[j][2] * mul, r[j][3] * mul)};
+      // the scattered copy converts each element on its own: one conversion whose low half feeds ds_write_b16 directly is
+      // cheaper than cutting the packed pairs apart again (shift / mask / permute per element)
       if (own_cols) {
         if (dst_rm) memcpy(dst_rm + row * p_rm + col, pk, 8);
         if (dst_tr) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dst_tr[(col + e) * PT + row] = (bf)((pk[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+          for (int e = 0; e < 4; ++e) dst_tr[(col + e) * PT + row] = (bf)cenet_f2bf(r[j][e] * mul);
         }
       } else {
         if (dst_tr) memcpy(dst_tr + col * PT + row, pk, 8);
         if (dst_rm) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dst_rm[(row + e) * p_rm + col] = (bf)((pk[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+          for (int e = 0; e < 4; ++e) dst_rm[(row + e) * p_rm + col] = (bf)cenet_f2bf(r[j][e] * mul);
         }
       }
     }

@@ -39,7 +39,8 @@ __device__ __forceinline__ unsigned cenet_pack_bf2(float lo, float hi) {
   memcpy(&u, &v, 4);
   return u;
 }
-__device__ __forceinline__ unsigned cenet_f2bf(float f) { return cenet_pack_bf2(f, 0.f) & 0xFFFFu; }
+// low 16 bits = bf16(f); the high half is bf16(0) = 0, so no mask is needed
+__device__ __forceinline__ unsigned cenet_f2bf(float f) { return cenet_pack_bf2(f, 0.f); }
 #endif
 
 #define CENET_CHECK_LAUNCH()                         \
