@@ -194,7 +194,7 @@ __device__ __forceinline__ void plain_fetch(const PlainStage& s, const float* ti
 }
 
 template <typename OpT, int BM, int BN, bool B_IM2COL, bool SWAP, int KT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kernel(GemmArgs g) {  // 128x128: keep two workgroups per CU
   static_assert(KT == 32 || (KT == 64 && !B_IM2COL), "K step: 32, or 64 for plain operands");
   constexpr int P = OpTraits<OpT, KT>::PITCH;
   constexpr bool BF = (sizeof(OpT) == 2);
@@ -468,6 +468,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const float bs = E.bscale ? E.bscale[batch] : 1.f;
   const int rwave = m0 + wm * (BM / 2) + (SWAP ? fr : fq * 4);
   const int cwave = n0 + wn * (BN / 2) + (SWAP ? fq * 4 : fr);
+  if (g.cvec && !E.atomic && !E.cmode && E.act == ACT_NONE && m0 + BM <= g.M && n0 + BN <= g.N) {
+    // interior tile of the common case (plain store, optional bias / per-batch scale / residual): 16 bytes per lane and
+    // fragment, no bounds tests, one 64-bit offset per lane and constant strides per fragment (the general version below
+    // spends ~70 VALU instructions per fragment; on the K <= 128 GEMMs of stages 1-2 that made the epilogue the longest part
+    // of the kernel)
+    const float scale = E.alpha * bs;
+    float* crow = Cb + (long)rwave * E.scr + (long)cwave * E.scc;
+    const float* rrow = Rb ? Rb + (long)rwave * E.srr + (long)cwave * E.src : nullptr;
+    const long ci = 16 * E.scr, cj = 16 * E.scc, ri = 16 * E.srr, rj = 16 * E.src;
+    const bool bias_vec = E.bias && (SWAP != (bool)E.bias_on_row) && (((uintptr_t)E.bias & 15) == 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int rbase = rwave + i * 16, cbase = cwave + j * 16;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if (E.bias) {
+          if (bias_vec) {  // the bias index runs along the lane's four elements
+            float bb[4];
+            memcpy(bb, E.bias + (SWAP ? cbase : rbase), 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * E.alpha + bb[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              v[r] = v[r] * E.alpha + E.bias[E.bias_on_row ? (SWAP ? rbase : rbase + r) : (SWAP ? cbase + r : cbase)];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= bs;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= scale;
+        }
+        if (rrow) {
+          float rr[4];
+          memcpy(rr, rrow + i * ri + j * rj, 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rr[r];
+        }
+        memcpy(crow + i * ci + j * cj, v, 16);
+      }
+    return;
+  }
   if (g.cvec && !E.atomic && !E.cmode && E.act == ACT_NONE) {
     // common case (plain store, optional bias / per-batch scale / residual), 16 bytes per lane and fragment.  This loop
     // nest MUST stay small enough to unroll fully: if it does not, acc[][] is indexed dynamically, lives in scratch
