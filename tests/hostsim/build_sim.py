@@ -21,7 +21,7 @@ def build_sim(force=False, sanitize=False):
     lib = LIB.replace(".so", "_asan.so") if sanitize else LIB
     if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
         return lib
-    flags = ["-O2", "-g", "-std=c++17", "-fPIC", "-DCENET_HOSTSIM_BUILD", "-I", HERE, "-Wno-unused-function",
+    flags = ["-O3", "-std=c++17", "-fPIC", "-DCENET_HOSTSIM_BUILD", "-I", HERE, "-Wno-unused-function",
              "-Wno-attributes", "-fno-strict-aliasing"]
     if sanitize:
         flags += ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"]
