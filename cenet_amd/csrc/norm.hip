@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float* __restrict__ dx,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int rows, int C) {
+                                                           int rows, int C, const float* __restrict__ dx_add) {
   __shared__ float red[2][4][MAXJ * 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float dg[MAXJ], db[MAXJ], gm[MAXJ];
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
           int c = lane + 64 * j;
-          if (c < C) dx[row * C + c] = rs[q] * (g[q][j] * gm[j] - s1[q] - xh[q][j] * s2[q]);
+          if (c < C) dx[row * C + c] = rs[q] * (g[q][j] * gm[j] - s1[q] - xh[q][j] * s2[q]) + (dx_add ? dx_add[row * C + c] : 0.f);
         }
       }
     }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict_
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, float* __restrict__ dx,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                       int steps) {
+                                                       int steps, const float* __restrict__ dx_add) {
   constexpr int RPW = 64 / LPR;
   __shared__ float red[2][4][NP * LPR * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, l = lane % LPR;
@@ -251,6 +251,11 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict_
           f4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o.v[e] = rs * (g[p].v[e] * gm[p].v[e] - s1 - xh[p].v[e] * s2);
+          if (dx_add) {  // gradient arriving through the residual path that by-passed the LayerNorm
+            const f4 ad = ld4(dx_add + row * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.v[e] += ad.v[e];
+          }
           st4(dx + row * C + c, o);
         }
       }
@@ -312,17 +317,17 @@ extern "C" int cenet_layernorm_fwd_f32(const float* x, const float* gamma, const
   return CENET_OK;
 }
 
-extern "C" int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean,
-                                           const float* rstd, float* dx, float* dgamma_acc, float* dbeta_acc, int rows,
-                                           int C, hipStream_t stream) {
+extern "C" int cenet_layernorm_bwd_add_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                               const float* rstd, const float* dx_add, float* dx, float* dgamma_acc,
+                                               float* dbeta_acc, int rows, int C, hipStream_t stream) {
   if (rows <= 0 || C <= 0) return CENET_EINVAL;
   if (C > 512) return CENET_EUNSUPPORTED;
-  if (ln_v4_ok(dy, x, gamma, dx, C)) {
+  if (ln_v4_ok(dy, x, gamma, dx, C) && (((uintptr_t)dx_add & 15) == 0)) {
 #define CENET_LNB(LPRv, NPv)                                                                                          \
   {                                                                                                                   \
     const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps);                                                          \
     CENET_LAUNCH((ln_bwd_v4_kernel<LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, \
-                 dgamma_acc, dbeta_acc, rows, C, st);                                                                 \
+                 dgamma_acc, dbeta_acc, rows, C, st, dx_add);                                                         \
   }
     if (C <= 64) CENET_LNB(16, 1)
     else if (C <= 128) CENET_LNB(32, 1)
@@ -335,7 +340,7 @@ extern "C" int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, cons
   dim3 grid(cdiv(rows, LN_ROWS_PER_BLOCK));
 #define CENET_LN(MJ, RP)                                                                                            \
   CENET_LAUNCH((layernorm_bwd_kernel<MJ, RP>), grid, dim3(256), stream, dy, x, gamma, mean, rstd, dx, dgamma_acc, dbeta_acc, \
-               rows, C)
+               rows, C, dx_add)
   if (C <= 64) { CENET_LN(1, 4); }
   else if (C <= 128) { CENET_LN(2, 4); }
   else if (C <= 256) { CENET_LN(4, 2); }
@@ -343,6 +348,12 @@ extern "C" int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, cons
 #undef CENET_LN
   CENET_CHECK_LAUNCH();
   return CENET_OK;
+}
+
+extern "C" int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                           const float* rstd, float* dx, float* dgamma_acc, float* dbeta_acc, int rows,
+                                           int C, hipStream_t stream) {
+  return cenet_layernorm_bwd_add_acc_f32(dy, x, gamma, mean, rstd, nullptr, dx, dgamma_acc, dbeta_acc, rows, C, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

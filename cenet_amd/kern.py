@@ -168,9 +168,9 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, Cn, eps):
     _call("cenet_layernorm_fwd_f32", x, gamma, beta, y, mean, rstd, rows, Cn, float(eps))
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cn):
-    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta)
-    _call("cenet_layernorm_bwd_acc_f32", dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cn)
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cn, dx_add=None):
+    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add)
+    _call("cenet_layernorm_bwd_add_acc_f32", dy, x, gamma, mean, rstd, dx_add, dx, dgamma, dbeta, rows, Cn)
 
 
 def bn_stats(x, sb, B, Cn, HW, ws, mean, var, rmean, rvar, momentum, nbt):

@@ -118,10 +118,11 @@ class Block(nn.Module):
         return None
 
     def forward(self, x, H, W):
-        y = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = self.attn(y, H, W, resid=x, bscale=self._scale(x))
-        y = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        x = self.mlp(y, H, W, resid=x, bscale=self._scale(x))
+        # layernorm_res hands x back for the skip connection so that both gradients meet inside the LN backward kernel
+        y, xr = ops.layernorm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.attn(y, H, W, resid=xr, bscale=self._scale(x))
+        y, xr = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x = self.mlp(y, H, W, resid=xr, bscale=self._scale(x))
         return x
 
 

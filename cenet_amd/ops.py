@@ -358,6 +358,45 @@ def layernorm(x, gamma, beta, eps):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
+class LayerNormResFn(Function):
+    """(LN(x), x): the second output is x itself, routed through this node so that the gradient of the residual connection
+    x + f(LN(x)) arrives HERE together with the LayerNorm's own — one kernel writes their sum (pvtv2.py:141-142) instead of
+    LN-backward followed by autograd's aten::add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        Cn = x.shape[-1]
+        rows = x.numel() // Cn
+        y = torch.empty_like(x)
+        mean, rstd = _empty((rows,), x), _empty((rows,), x)
+        kern.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, Cn, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.refs = (gamma, beta)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, g_res):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        gp, bp = ctx.refs
+        Cn = x.shape[-1]
+        rows = x.numel() // Cn
+        if g is None:  # only the residual path carried a gradient
+            return g_res, None, None, None
+        g = _c(g)
+        dx = torch.empty_like(x)
+        dg, db = grad_buf(gp), grad_buf(bp)
+        if dg is None:
+            dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
+        kern.layernorm_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, dx_add=_c(g_res))
+        return dx, None, None, None
+
+
+def layernorm_res(x, gamma, beta, eps):
+    """returns (LN(x), x_residual): use x_residual (not x) for the skip connection around the normalised branch"""
+    return LayerNormResFn.apply(x, gamma, beta, eps)
+
+
 # =====================================================================================================
 # BatchNorm (+ fused activation) on NCHW or [B,C]  (cfam.py:22-32; blocks.py; nlb.py:81; unet.py:175-197)
 # =====================================================================================================

@@ -120,6 +120,11 @@ int cenet_layernorm_fwd_f32(const float* x, const float* gamma, const float* bet
                             int rows, int C, float eps, cenet_stream_t stream);
 int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                 float* dx, float* dgamma_acc, float* dbeta_acc, int rows, int C, cenet_stream_t stream);
+/* the same with dx = LN-backward(dy) + dx_add: the gradient of a residual connection that by-passed the LayerNorm
+ * (x + f(LN(x)), pvtv2.py:141-142) is folded in here instead of a separate aten::add; dx_add may be NULL. */
+int cenet_layernorm_bwd_add_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                    const float* dx_add, float* dx, float* dgamma_acc, float* dbeta_acc, int rows, int C,
+                                    cenet_stream_t stream);
 /* aten::native_batch_norm(+_backward), training mode — cfam.py:22-32,92,250; blocks.py:151,161,212,307; nlb.py:81;
  * unet.py:175-197.  ws: CENET_BN_WS_FLOATS(C) floats of scratch (per-split partial sums, no zero-fill needed).
  * stats writes batch mean / biased var and updates the running
