@@ -12,10 +12,56 @@ void note_progress() { ++g_progress; }
 
 static const size_t kStack = 256 * 1024;
 
+#if HIPSIM_FAST_SWITCH
+// void hipsim_switch(Ctx* from, Ctx* to): save the SysV callee-saved registers and the stack pointer of the running fiber,
+// load those of the target, return into it
+extern "C" void hipsim_switch(Ctx* from, Ctx* to);
+asm(R"(
+.text
+.globl hipsim_switch
+.type hipsim_switch,@function
+hipsim_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq (%rsi), %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipsim_switch,.-hipsim_switch
+)");
+static inline void ctx_switch(Ctx* from, Ctx* to) { hipsim_switch(from, to); }
+static void ctx_make(Ctx* c, char* stack, size_t size, void (*entry)()) {
+  // entry must see rsp == 8 (mod 16), as right after a call: the return slot sits on a 16-byte boundary
+  uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+  void** sp = (void**)(top - 16);
+  *sp = (void*)entry;  // popped by the final `ret` of hipsim_switch
+  for (int i = 0; i < 6; ++i) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
+  c->rsp = sp;
+}
+#else
+static inline void ctx_switch(Ctx* from, Ctx* to) { swapcontext(&from->uc, &to->uc); }
+static void ctx_make(Ctx* c, char* stack, size_t size, void (*entry)()) {
+  getcontext(&c->uc);
+  c->uc.uc_stack.ss_sp = stack;
+  c->uc.uc_stack.ss_size = size;
+  c->uc.uc_link = nullptr;
+  makecontext(&c->uc, entry, 0);
+}
+#endif
+
 void yield() {
   State& s = g_state;
   int me = s.cur;
-  swapcontext(&s.fibers[me].ctx, &s.sched);
+  ctx_switch(&s.fibers[me].ctx, &s.sched);
   threadIdx = s.fibers[me].tid;
 }
 
@@ -38,7 +84,7 @@ static void trampoline() {
   State& s = g_state;
   s.body();
   s.fibers[s.cur].done = true;
-  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+  ctx_switch(&s.fibers[s.cur].ctx, &s.sched);
 }
 
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
@@ -62,13 +108,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         memset(s.warrived, 0, sizeof(s.warrived));
         for (int t = 0; t < n; ++t) {
           Fiber& f = s.fibers[t];
-          getcontext(&f.ctx);
-          f.ctx.uc_stack.ss_sp = f.stack;
-          f.ctx.uc_stack.ss_size = kStack;
-          f.ctx.uc_link = nullptr;
           f.done = false;
           f.tid = uint3_sim{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
-          makecontext(&f.ctx, (void (*)())trampoline, 0);
+          ctx_make(&f.ctx, f.stack, kStack, trampoline);
         }
         int remaining = n;
         while (remaining > 0) {
@@ -78,7 +120,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             if (f.done) continue;
             s.cur = t;
             threadIdx = f.tid;
-            swapcontext(&s.sched, &f.ctx);
+            ctx_switch(&s.sched, &f.ctx);
             if (f.done) { --remaining; ++g_progress; }
           }
           if (g_progress == before) { fprintf(stderr, "hipsim: deadlock (divergent barrier / shuffle?)\n"); abort(); }

@@ -43,15 +43,28 @@ static inline const char* hipGetErrorString(hipError_t) { return "hostsim"; }
 #define __restrict__ __restrict
 
 namespace hipsim {
+// Fiber switch.  x86-64: a hand-rolled callee-saved-register switch (glibc's swapcontext makes a sigprocmask system call per
+// switch, which dominated the run time of barrier-heavy kernels); elsewhere: ucontext.
+#if defined(__x86_64__)
+#define HIPSIM_FAST_SWITCH 1
+struct Ctx {
+  void* rsp = nullptr;
+};
+#else
+#define HIPSIM_FAST_SWITCH 0
+struct Ctx {
+  ucontext_t uc;
+};
+#endif
 struct Fiber {
-  ucontext_t ctx;
+  Ctx ctx;
   char* stack = nullptr;
   bool done = true;
   uint3_sim tid;
 };
 struct State {
   std::vector<Fiber> fibers;
-  ucontext_t sched;
+  Ctx sched;
   int cur = -1;
   int nthreads = 0;
   // block barrier

@@ -106,10 +106,6 @@ def test_droppath_training_runs_and_differs():
 
 
 @pytest.mark.slow
-@pytest.mark.skipif(os.environ.get("CENET_SLOW_TESTS") != "1",
-                    reason="~2 minutes on the host SIMT checker (113 s of it in the GEMM fibers); set CENET_SLOW_TESTS=1. "
-                           "The per-module cases of test_modules_parity.py run the same kernels on the checker, and the "
-                           "whole-model wiring is covered by the -m gpu tests above")
 def test_small_model_forward_on_host_checker():
     """The full module wiring on the host SIMT checker at 32x32 (eval forward) against the oracle — runs without a GPU."""
     from cenet_amd import _lib
