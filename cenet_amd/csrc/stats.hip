@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const float* __restr
   const float sg = sigmoid_f(g[bc]);
   const float mean = u[bc * 3 + 1], sd = u[bc * 3 + 2];
   const int am = amax[bc];
-  const float dmax = du_s[0], dmean = du_s[1] / HW, dstd = du_s[2] / (HW * sd);
+  // std backward at std == 0 (constant plane, e.g. a 1x1 map): aten::std_backward masks the 0/0 to 0
+  const float dmax = du_s[0], dmean = du_s[1] / HW, dstd = (sd > 0.f) ? du_s[2] / (HW * sd) : 0.f;
   const float* xp = x + (long)bc * HW;
   const float* gp = dy + (long)bc * HW;
   float* dp = dx + (long)bc * HW;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void srm_bwd_apply_kernel(const float* __restr
   for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) {
     const float sg = sigmoid_f(fb[p]);
     const float mean = ub[HW + p], sd = ub[2 * HW + p];
-    float v = dy[base + p] * sg + db[HW + p] / C + db[2 * HW + p] / ((C - 1) * sd) * (x[base + p] - mean);
+    float v = dy[base + p] * sg + db[HW + p] / C + ((sd > 0.f) ? db[2 * HW + p] / ((C - 1) * sd) * (x[base + p] - mean) : 0.f);
     if (c == ab[p]) v += db[p];
     dx[base + p] = v;
   }

@@ -164,3 +164,43 @@ def test_chan_dot_accumulates(dev, B, C, HW, with_b):
     kern.chan_dot(a.to(dev), C * HW, b.to(dev) if with_b else None, C * HW if with_b else 0, out, B, C, HW)
     ref = out0 + ((a * b) if with_b else a).sum((0, 2))
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_zero_std_planes_give_finite_gradients(dev):
+    """A constant plane / constant pixel has std == 0; aten::std_backward masks the 0/0 to 0, and so must the CCU and SRM
+    backward kernels (a whole-model training step at 32x32 — 1x1 maps in the last decoder stage — turned every backbone
+    gradient into NaN before they did)."""
+    from cenet_amd.networks.cenet.modules.cfam import CCU, SRM
+    from oracle import cenet_oracle as O
+    g = torch.Generator().manual_seed(9)
+    # CCU: per-(sample, channel) statistics over the plane; sample 0 / channel 1 is constant, and a 1x1 map is all-constant
+    for shape in [(2, 4, 3, 3), (2, 4, 1, 1)]:
+        x = torch.randn(*shape, generator=g)
+        if shape[2] > 1:
+            x[0, 1] = 0.7
+        mod = CCU(shape[1]).train()
+        sd = {"m." + k: v.detach().clone() for k, v in mod.state_dict().items()}
+        xr = x.clone().requires_grad_(True)
+        ref = O.ccu(sd, "m", xr, True)
+        go = torch.randn(ref.shape, generator=g)
+        ref.backward(go)
+        xd = x.to(dev).requires_grad_(True)
+        out = mod.to(dev)(xd)
+        out.backward(go.to(dev))
+        assert torch.isfinite(xd.grad).all()
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=2e-3, atol=2e-4)
+    # SRM: per-pixel statistics over channels; one pixel has identical channels
+    x = torch.randn(2, 5, 4, 4, generator=g)
+    x[1, :, 2, 3] = -0.3
+    mod = SRM().train()
+    sd = {"m." + k: v.detach().clone() for k, v in mod.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.srm(sd, "m", xr, True)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd = x.to(dev).requires_grad_(True)
+    out = mod.to(dev)(xd)
+    out.backward(go.to(dev))
+    assert torch.isfinite(xd.grad).all()
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=2e-3, atol=2e-4)
