@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void dw3x3_nchw_kernel(const float* __restrict
 // workgroup = (256-channel slab, strip of DW_SW pixels along x, image).  A 3x3 register window slides along the
 // strip, so each output costs 3 new loads instead of 9 and there is no per-element div/mod.
 #define DW_SW 8
+// DW_SR output rows per thread: (DW_SR + 2) input rows x (DW_SW + 2) columns feed DW_SR x DW_SW outputs — 1.9 loads per output
+// at DW_SR = 4 (4.1 TB/s at 56x56x512), 2.5 at DW_SR = 2 (more workgroups for the small maps), 3.75 for single rows
+template <int DW_SR>
 __global__ __launch_bounds__(256) void dw3x3_tok_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        float* __restrict__ a, int C, int H, int W, int flip, int act,
@@ -50,44 +53,45 @@ __global__ __launch_bounds__(256) void dw3x3_tok_kernel(const float* __restrict_
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const int strips_per_row = (W + DW_SW - 1) / DW_SW;
-  const int py = blockIdx.y / strips_per_row;
-  const int px0 = (blockIdx.y - py * strips_per_row) * DW_SW;
+  const int py = (blockIdx.y / strips_per_row) * DW_SR;
+  const int px0 = (blockIdx.y % strips_per_row) * DW_SW;
   const long img = (long)blockIdx.z * H * W * C;
   const float* xb = x + img + c;
   float wt[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
   const float bv = bias ? bias[c] : 0.f;
-  float win[3][3];  // win[ky][slot]: columns px-1, px, px+1
-  auto load_col = [&](int ix, float col[3]) {
+  // col[slot][r]: input rows py-1 .. py+DW_SR of one column; three columns slide along the strip
+  float col[3][DW_SR + 2];
+  auto load_col = [&](int ix, float* dst) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = py + ky - 1;
-      col[ky] = (ix >= 0 && ix < W && iy >= 0 && iy < H) ? xb[((long)iy * W + ix) * C] : 0.f;
+    for (int r = 0; r < DW_SR + 2; ++r) {
+      const int iy = py + r - 1;
+      dst[r] = (ix >= 0 && ix < W && iy >= 0 && iy < H) ? xb[((long)iy * W + ix) * C] : 0.f;
     }
   };
-  float c0[3], c1[3], c2[3];
-  load_col(px0 - 1, c0);
-  load_col(px0, c1);
+  load_col(px0 - 1, col[0]);
+  load_col(px0, col[1]);
 #pragma unroll
   for (int i = 0; i < DW_SW; ++i) {
     const int px = px0 + i;
-    load_col(px + 1, c2);
+    load_col(px + 1, col[(i + 2) % 3]);
     if (px < W) {
-      float acc = bv;
+      const float* c0 = col[i % 3];
+      const float* c1 = col[(i + 1) % 3];
+      const float* c2 = col[(i + 2) % 3];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) acc += wt[ky * 3] * c0[ky] + wt[ky * 3 + 1] * c1[ky] + wt[ky * 3 + 2] * c2[ky];
-      const long e = img + ((long)py * W + px) * C + c;
-      y[e] = acc;
-      if (a) a[e] = act_fwd(act, acc, slope);
-    }
+      for (int r = 0; r < DW_SR; ++r)
+        if (py + r < H) {
+          float acc = bv;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      c0[ky] = c1[ky];
-      c1[ky] = c2[ky];
+          for (int ky = 0; ky < 3; ++ky) acc += wt[ky * 3] * c0[r + ky] + wt[ky * 3 + 1] * c1[r + ky] + wt[ky * 3 + 2] * c2[r + ky];
+          const long e = img + ((long)(py + r) * W + px) * C + c;
+          y[e] = acc;
+          if (a) a[e] = act_fwd(act, acc, slope);
+        }
     }
   }
-  (void)win;
 }
 
 // weight/bias gradient, NCHW: grid (C, splits); dw[c,t] += sum_{b,p} dy[b,c,p] * x[b,c,p+off_t]; db[c] += sum dy
@@ -375,10 +379,14 @@ extern "C" int cenet_dwconv3x3_nchw_f32(const float* x, long sxb, const float* w
 extern "C" int cenet_dwconv3x3_tok_f32(const float* x, const float* w, const float* bias, float* y, float* a, int B, int C,
                                        int H, int W, int flip, int act, float slope, hipStream_t stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
-  const int strips = H * ((W + DW_SW - 1) / DW_SW);
+  const int sr = H >= 28 ? 4 : 2;
+  const int strips = ((H + sr - 1) / sr) * ((W + DW_SW - 1) / DW_SW);
   if (strips > 65535 || B > 65535) return CENET_EUNSUPPORTED;
   // (a 16-byte-per-thread variant of this kernel measured slower: 2.6 vs 3.0 TB/s at 56x56x512)
-  CENET_LAUNCH(dw3x3_tok_kernel, dim3(cdiv(C, 256), strips, B), dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
+  if (sr == 4)
+    CENET_LAUNCH((dw3x3_tok_kernel<4>), dim3(cdiv(C, 256), strips, B), dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
+  else
+    CENET_LAUNCH((dw3x3_tok_kernel<2>), dim3(cdiv(C, 256), strips, B), dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -51,7 +51,9 @@ __device__ __forceinline__ void bil_range(int i, float scale, int align, int out
 }
 
 // gather form of the backward: one thread per INPUT pixel sums the output gradients whose taps touch it
-#define BIL_MAXR 10
+// MAXR = most output columns whose taps can touch one input column (range from bil_range): 6 covers scale >= 0.5 (x2
+// up-sampling and every down-sampling), 10 covers x4; anything wider takes the unbounded loop
+template <int BIL_MAXR>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, long sgb, float* __restrict__ dx,
                                                           long sdb, int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
                                                           int align) {
@@ -240,8 +242,12 @@ extern "C" int cenet_bilinear_fwd_f32(const float* x, long sxb, float* y, long s
 extern "C" int cenet_bilinear_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi, int Ho,
                                       int Wo, float scale_h, float scale_w, int align_corners, hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(bilinear_bwd_kernel, dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho, Wo,
-               scale_h, scale_w, align_corners);
+  if (scale_w >= 0.5f)
+    CENET_LAUNCH((bilinear_bwd_kernel<6>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
+                 Wo, scale_h, scale_w, align_corners);
+  else
+    CENET_LAUNCH((bilinear_bwd_kernel<10>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
+                 Wo, scale_h, scale_w, align_corners);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -109,7 +109,8 @@ def test_dwconv_nchw_fwd_dgrad_wgrad(dev, B, C, H, W, dil):
 
 
 # C % 4 == 0: 16-byte token-layout kernels (C = 8: one partly filled wave; C = 260: two workgroup slabs); C = 6: scalar form
-@pytest.mark.parametrize("B,C,H,W", [(2, 8, 5, 9), (1, 260, 3, 10), (2, 6, 4, 5)])
+# H = 30: the four-rows-per-thread forward (H >= 28), ragged in both directions
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 5, 9), (1, 260, 3, 10), (2, 6, 4, 5), (1, 8, 30, 11)])
 def test_dwconv_tok_fwd_dgrad_wgrad(dev, B, C, H, W):
     g = torch.Generator().manual_seed(B + C + H + W)
     xt = torch.randn(B, H * W, C, generator=g)
