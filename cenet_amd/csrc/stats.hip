@@ -288,6 +288,110 @@ __global__ __launch_bounds__(256) void gate_pix_fwd_kernel(const float* __restri
   for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) y[base + p] = x[base + p] * sigmoid_f(fb[p]);
 }
 
+// 16-byte forms (HW % 4 == 0): workgroup = 64 pixels x 16 channel groups; a thread owns 4 consecutive pixels of every 16th
+// channel (16 lanes cover a contiguous 256-byte row segment), 4 independent 16-byte loads in flight, groups meet in LDS
+__global__ __launch_bounds__(256) void srm_stats_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ u,
+                                                              int* __restrict__ amax, int C, int HW) {
+  __shared__ float s1_s[16][64], s2_s[16][64], mx_s[16][64];
+  __shared__ int mi_s[16][64];
+  const int b = blockIdx.y;
+  const int pq = threadIdx.x & 15, cg = threadIdx.x >> 4;
+  const int p = blockIdx.x * 64 + 4 * pq;
+  const bool ok = p < HW;
+  const float* xb = x + (long)b * C * HW + (ok ? p : 0);
+  float shift[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ok) memcpy(shift, xb, 16);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, mx[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+  int mi[4] = {0, 0, 0, 0};
+  if (ok) {
+#pragma unroll 4
+    for (int c = cg; c < C; c += 16) {
+      float v[4];
+      memcpy(v, xb + (long)c * HW, 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[e] - shift[e];
+        s1[e] += d;
+        s2[e] += d * d;
+        if (v[e] > mx[e]) {
+          mx[e] = v[e];
+          mi[e] = c;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s1_s[cg][4 * pq + e] = s1[e];
+    s2_s[cg][4 * pq + e] = s2[e];
+    mx_s[cg][4 * pq + e] = mx[e];
+    mi_s[cg][4 * pq + e] = mi[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int pl = threadIdx.x, pp = blockIdx.x * 64 + pl;
+    if (pp < HW) {
+      float a1 = 0.f, a2 = 0.f, bm = mx_s[0][pl];
+      int bi = mi_s[0][pl];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        a1 += s1_s[g][pl];
+        a2 += s2_s[g][pl];
+        const float m = mx_s[g][pl];
+        const int i = mi_s[g][pl];
+        if (m > bm || (m == bm && i < bi)) {  // first maximal channel, like torch.max
+          bm = m;
+          bi = i;
+        }
+      }
+      const float sh = x[(long)b * C * HW + pp];
+      const float mean_d = a1 / C;
+      float var = (a2 - a1 * mean_d) / (C - 1);
+      if (var < 0.f) var = 0.f;
+      float* ub = u + (long)b * 3 * HW + pp;
+      ub[0] = bm;
+      ub[HW] = sh + mean_d;
+      ub[2 * HW] = sqrtf(var);
+      amax[(long)b * HW + pp] = bi;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_pix_bwd_reduce_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    const float* __restrict__ f, float* __restrict__ df, int C,
+                                                                    int HW) {
+  __shared__ float part[16][64];
+  const int b = blockIdx.y;
+  const int pq = threadIdx.x & 15, cg = threadIdx.x >> 4;
+  const int p = blockIdx.x * 64 + 4 * pq;
+  const bool ok = p < HW;
+  const long base = (long)b * C * HW + (ok ? p : 0);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+#pragma unroll 4
+    for (int c = cg; c < C; c += 16) {
+      float xv[4], gv[4];
+      memcpy(xv, x + base + (long)c * HW, 16);
+      memcpy(gv, dy + base + (long)c * HW, 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += xv[e] * gv[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[cg][4 * pq + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int pl = threadIdx.x, pp = blockIdx.x * 64 + pl;
+    if (pp < HW) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += part[g][pl];
+      const float sg = sigmoid_f(f[(long)b * HW + pp]);
+      df[(long)b * HW + pp] = t * sg * (1.f - sg);
+    }
+  }
+}
+
 // df[b,p] = sigmoid'(f) * sum_c dy*x ; workgroup = 64 pixels x 4 channel groups
 __global__ __launch_bounds__(256) void gate_pix_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  const float* __restrict__ f, float* __restrict__ df, int C,
@@ -366,7 +470,10 @@ extern "C" int cenet_ccu_bwd_apply_acc_f32(const float* x, const float* dy, cons
 }
 extern "C" int cenet_srm_stats_fwd_f32(const float* x, float* u, int* amax, int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(srm_stats_fwd_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
+  if ((HW & 3) == 0 && (((uintptr_t)x) & 15) == 0)
+    CENET_LAUNCH(srm_stats_fwd_v4_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
+  else
+    CENET_LAUNCH(srm_stats_fwd_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -394,7 +501,10 @@ extern "C" int cenet_gate_pix_fwd_f32(const float* x, const float* f, float* y, 
 extern "C" int cenet_gate_pix_bwd_reduce_f32(const float* x, const float* dy, const float* f, float* df, int B, int C,
                                              int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(gate_pix_bwd_reduce_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
+  if ((HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)dy)) & 15) == 0)
+    CENET_LAUNCH(gate_pix_bwd_reduce_v4_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
+  else
+    CENET_LAUNCH(gate_pix_bwd_reduce_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
