@@ -113,6 +113,9 @@ class Block(nn.Module):
         self.apply(_init_weights)
 
     def _scale(self, x):
+        pend = getattr(self, "_dp_pending", None)
+        if pend:  # sampled for the whole encoder in one shot (PyramidVisionTransformerImpr.forward_features)
+            return pend.pop()
         if isinstance(self.drop_path, DropPath):
             return self.drop_path.sample_scale(x.shape[0], x.device)
         return None
@@ -185,8 +188,26 @@ class PyramidVisionTransformerImpr(nn.Module):
                     blk.drop_path = DropPath(dpr[cur + i])
             cur += self.depths[s]
 
+    def _sample_drop_path(self, batch, device):
+        """All stochastic-depth scales of one forward pass from ONE uniform draw (two per block: attention and MLP branch)
+        instead of two tiny RNG launches per use; same distribution as DropPath.sample_scale."""
+        blocks = [b for s in range(4) for b in getattr(self, f"block{s + 1}")
+                  if isinstance(b.drop_path, DropPath) and b.drop_path.training and b.drop_path.drop_prob > 0.0]
+        if not blocks:
+            return
+        probs = tuple(1.0 - b.drop_path.drop_prob for b in blocks for _ in range(2))
+        cache = getattr(self, "_dp_keep", None)
+        if cache is None or cache[0] != probs or cache[1].device != device:  # uploaded once, not per step
+            cache = self._dp_keep = (probs, torch.tensor(probs, device=device))
+        keep = cache[1]
+        scale = (torch.rand(keep.numel(), batch, device=device) < keep[:, None]).float() / keep[:, None]
+        for i, b in enumerate(blocks):
+            b._dp_pending = [scale[2 * i + 1], scale[2 * i]]  # popped from the end: attention first, then MLP
+
     def forward_features(self, x):
         outs = []
+        if self.training:
+            self._sample_drop_path(x.shape[0], x.device)
         for s in range(4):
             t, H, W = getattr(self, f"patch_embed{s + 1}")(x)
             for blk in getattr(self, f"block{s + 1}"):
