@@ -81,6 +81,12 @@ def _wgrad_side(*reads):
     _WgradSide.pending = True
 
 
+def wgrad_stream():
+    """the weight-gradient stream if kernels may be pending on it, else None (for consumers that order another stream
+    after it without stalling the compute stream, e.g. the gradient all-reduce)"""
+    return _WgradSide.stream if _WgradSide.pending else None
+
+
 def wgrad_join():
     if _WgradSide.pending:
         torch.cuda.current_stream().wait_stream(_WgradSide.stream)

@@ -50,7 +50,12 @@ class GradReducer:
             return
         if self.cuda:
             from . import ops
-            ops.wgrad_join()  # weight gradients may still be running on their own stream (ops._WgradSide)
+            # the collective must see the segment's weight gradients, which may still be running on their own stream
+            # (ops._WgradSide): the COMMUNICATION stream waits for that stream and for the compute stream; the compute
+            # stream itself is not held up
+            wg = ops.wgrad_stream()
+            if wg is not None:
+                self.side.wait_stream(wg)
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
