@@ -544,46 +544,35 @@ __global__ __launch_bounds__(256, MINB) void flashc_bwd_dkv_kernel(AttnArgsB a) 
     const bf* Qt_ = Qt[cur];
     const bf* G_ = Gs[cur];
     const bf* Gt_ = Gt[cur];
-    // the 64 queries of the tile in two halves of 32 (= one permuted-k chunk each) to keep the live score registers low
+    // the 64 queries of the tile in two halves of 32 (= one permuted-k chunk each), one 16-key tile at a time, to keep the
+    // live score registers low (the Q / dO fragments are re-read from LDS per key tile)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      f32x4 s[2][NKT], dp[2][NKT];  // rows = queries 32c + 16e + 4fq + r, column = key fr
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int qt = 2 * c + e;
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-          s[e][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-          dp[e][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int cc = 0; cc < NC; ++cc) {
-          const bf16x8 qa = frag_rm(Q_, PQ, 16 * qt + fr, cc, fq);
-#pragma unroll
-          for (int t = 0; t < NKT; ++t) s[e][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[t][cc], s[e][t], 0, 0, 0);
-        }
-#pragma unroll
-        for (int cc = 0; cc < NCV; ++cc) {
-          const bf16x8 ga = frag_rm(G_, PV, 16 * qt + fr, cc, fq);
-#pragma unroll
-          for (int t = 0; t < NKT; ++t) dp[e][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf[t][cc], dp[e][t], 0, 0, 0);
-        }
-        float l4[4], d4[4];
-        memcpy(l4, &lse_s[cur][16 * qt + 4 * fq], 16);
-        memcpy(d4, &del_s[cur][16 * qt + 4 * fq], 16);
-#pragma unroll
-        for (int t = 0; t < NKT; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = fast_exp2(s[e][t][r] - l4[r]);  // queries beyond the slice carry lse = +big -> p = 0
-            s[e][t][r] = p;
-            dp[e][t][r] = p * (dp[e][t][r] - d4[r]);
-          }
-      }
-      // dV^T[dv][key] += dO^T[dv][queries] . P[queries][key] ;  dK^T[d][key] += Q^T[d][queries] . dS[queries][key]
 #pragma unroll
       for (int t = 0; t < NKT; ++t) {
-        const bf16x8 pb = pack_tiles(s[0][t], s[1][t]), db = pack_tiles(dp[0][t], dp[1][t]);
+        f32x4 s[2], dp[2];  // rows = queries 32c + 16e + 4fq + r, column = key fr
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int qt = 2 * c + e;
+          s[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int cc = 0; cc < NC; ++cc)
+            s[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Q_, PQ, 16 * qt + fr, cc, fq), kf[t][cc], s[e], 0, 0, 0);
+#pragma unroll
+          for (int cc = 0; cc < NCV; ++cc)
+            dp[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(G_, PV, 16 * qt + fr, cc, fq), vf[t][cc], dp[e], 0, 0, 0);
+          float l4[4], d4[4];
+          memcpy(l4, &lse_s[cur][16 * qt + 4 * fq], 16);
+          memcpy(d4, &del_s[cur][16 * qt + 4 * fq], 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = fast_exp2(s[e][r] - l4[r]);  // queries beyond the slice carry lse = +big -> p = 0
+            s[e][r] = p;
+            dp[e][r] = p * (dp[e][r] - d4[r]);
+          }
+        }
+        const bf16x8 pb = pack_tiles(s[0], s[1]), db = pack_tiles(dp[0], dp[1]);
 #pragma unroll
         for (int u = 0; u < NU; ++u)
           if (16 * u < a.Dv) dv[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_perm(Gt_, 16 * u + fr, c, fq), pb, dv[t][u], 0, 0, 0);
@@ -702,7 +691,9 @@ int cenet_flashb_bwd(const cenet_attn_t* p, hipStream_t stream) {
     case 0:
       // the wide dQ instance runs three workgroups per CU at the price of a 20-byte spill: 1.59 -> 1.22 ms on DSEB-56^2
       if (wide_q) CENET_DQ(32, 32, 2, 3); else CENET_DQ(32, 32, 1, 2);
-      if (wide_k) CENET_DKV(32, 32, 2, 2); else CENET_DKV(32, 32, 1, 2);
+      // wide dK/dV: key tiles one at a time (fewer live score registers) lets it run three workgroups per CU with a 92-byte
+      // spill: 2.56 -> 2.44 ms on DSEB-56^2 (the same order at two workgroups per CU is slower: 2.8 ms)
+      if (wide_k) CENET_DKV(32, 32, 2, 3); else CENET_DKV(32, 32, 1, 2);
       break;
     case 1:
       if (wide_q) CENET_DQ(32, 64, 2, 2); else CENET_DQ(32, 64, 1, 2);
