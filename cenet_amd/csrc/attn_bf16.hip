@@ -697,7 +697,7 @@ int cenet_flashb_bwd(const cenet_attn_t* p, hipStream_t stream) {
       break;
     case 1:
       if (wide_q) CENET_DQ(32, 64, 2, 2); else CENET_DQ(32, 64, 1, 2);
-      if (wide_k) CENET_DKV(32, 64, 2, 1); else CENET_DKV(32, 64, 1, 1);
+      if (wide_k) CENET_DKV(32, 64, 2, 1); else CENET_DKV(32, 64, 1, 2);  // two workgroups per CU (20-byte spill)
       break;
     case 2:
       if (wide_q && big) CENET_DQ(64, 64, 2, 2); else if (wide_q) CENET_DQ(64, 64, 2, 1); else CENET_DQ(64, 64, 1, 2);
