@@ -44,6 +44,57 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(const float* __restri
     yb[i] = accumulate ? yb[i] + xb[i] : xb[i];
 }
 
+// ---- space-to-depth of a token map: the kernel == stride spatial-reduction conv of pvtv2.py:93-95 reads each input
+// pixel exactly once, so gathering the s x s patches into rows turns it into a dense GEMM with both operands k-contiguous.
+// tok [B, Ho*S, Wo*S, C] <-> patch [B*Ho*Wo, C*S*S], k = (c, ky, kx) as in the conv weight [Cout, C, S, S].
+// One thread moves the S*S values of one (patch, channel): token side coalesced over c, patch side S contiguous floats.
+template <int S, bool INV>
+__global__ __launch_bounds__(256) void patch_tok_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int Ho,
+                                                       int Wo, long total) {
+  const long Wd = (long)Wo * S;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long r = idx / C;
+    const int ox = (int)(r % Wo);
+    const long t = r / Wo;
+    const int oy = (int)(t % Ho);
+    const long b = t / Ho;
+    const long tbase = (((b * Ho + oy) * S) * Wd + (long)ox * S) * C + c;
+    const long pbase = (r * C + c) * (S * S);
+#pragma unroll
+    for (int ky = 0; ky < S; ++ky) {
+      float v[S];
+      if (INV) {
+        const float* p = src + pbase + ky * S;
+        if (S == 2) {
+          const float2 q = *reinterpret_cast<const float2*>(p);
+          v[0] = q.x, v[1] = q.y;
+        } else {
+#pragma unroll
+          for (int j = 0; j < S; j += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(p + j);
+            v[j] = q.x, v[j + 1] = q.y, v[j + 2] = q.z, v[j + 3] = q.w;
+          }
+        }
+#pragma unroll
+        for (int kx = 0; kx < S; ++kx) dst[tbase + (ky * Wd + kx) * C] = v[kx];
+      } else {
+#pragma unroll
+        for (int kx = 0; kx < S; ++kx) v[kx] = src[tbase + (ky * Wd + kx) * C];
+        float* p = dst + pbase + ky * S;
+        if (S == 2) {
+          float2 q;
+          q.x = v[0], q.y = v[1];
+          *reinterpret_cast<float2*>(p) = q;
+        } else {
+#pragma unroll
+          for (int j = 0; j < S; j += 4) *reinterpret_cast<float4*>(p + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+        }
+      }
+    }
+  }
+}
+
 // ---- y[b, i] = s[b] * x[b, i] ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scale_batch_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                          float* __restrict__ y, long n) {
@@ -460,6 +511,23 @@ extern "C" int cenet_copy_batched_f32(const float* x, long sxb, float* y, long s
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   CENET_LAUNCH(copy_batched_kernel, dim3((unsigned)blocks, B), dim3(256), stream, x, sxb, y, syb, n, accumulate);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_patch_tok_f32(const float* src, float* dst, int B, int Ho, int Wo, int C, int S, int inverse,
+                                   hipStream_t stream) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (S != 2 && S != 4 && S != 8)) return CENET_EINVAL;
+  const long total = (long)B * Ho * Wo * C;
+#define PATCH_GO(S_, INV_) \
+  CENET_LAUNCH((patch_tok_kernel<S_, INV_>), EW_GRID(total), dim3(256), stream, src, dst, C, Ho, Wo, total)
+  if (S == 2) {
+    if (inverse) PATCH_GO(2, true); else PATCH_GO(2, false);
+  } else if (S == 4) {
+    if (inverse) PATCH_GO(4, true); else PATCH_GO(4, false);
+  } else {
+    if (inverse) PATCH_GO(8, true); else PATCH_GO(8, false);
+  }
+#undef PATCH_GO
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

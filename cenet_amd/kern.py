@@ -316,6 +316,12 @@ def copy_batched(x, sxb, y, syb, B, n, accumulate=False, x_off=0, y_off=0):
           L(syb), B, L(n), int(accumulate))
 
 
+def patch_tok(src, dst, B, Ho, Wo, C, S, inverse=False):
+    """Space-to-depth of a token map (inverse: patch rows back to tokens); pvtv2.py:93-95 kernel == stride conv."""
+    _chk(src, dst)
+    _call("cenet_patch_tok_f32", src, dst, B, Ho, Wo, C, S, int(inverse))
+
+
 def scale_batch(x, s, y, B, n):
     _chk(x, s, y)
     _call("cenet_scale_batch_f32", x, s, y, B, L(n))

@@ -104,19 +104,35 @@ class LinearFn(Function):
     """y = bscale[b] * (x W^T + b) + resid.  x [..., K] contiguous; bscale [B] needs x [B, n, K]."""
 
     @staticmethod
-    def forward(ctx, x, W, b, resid, bscale):
+    def forward(ctx, x, W, b, resid, bscale, split_k=False):
         x = _c(x)
         K = x.shape[-1]
         N = W.shape[0]
-        y = _empty(x.shape[:-1] + (N,), x)
         R = x.numel() // K
         if bscale is None:
             nb, M = 1, R
         else:
             nb, M = x.shape[0], R // x.shape[0]
         resid = _c(resid)
-        kern.gemm(kern.mat_plain(x, K, 1, sb=M * K, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
-                  scb=M * N, nbatch=nb, bias=b, bscale=bscale, R=resid, srb=M * N, srr=N, src=1)
+        shape = x.shape[:-1] + (N,)
+        splits = 1
+        if split_k and bscale is None and K >= 1024 and kern.get_compute_bf16():  # parity mode keeps a deterministic forward
+            splits = kern.pick_splits(M, N, 1, K // 32)
+        if splits > 1:
+            # few output tiles under a long reduction: split K over workgroups; the partial sums are added atomically
+            # onto an output pre-filled with bias + residual
+            if resid is not None:
+                y = resid + b if b is not None else resid.clone()
+            elif b is not None:
+                y = b.expand(shape).contiguous()
+            else:
+                y = _zeros(shape, x)
+            kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
+                      splits=splits, atomic=True)
+        else:
+            y = _empty(shape, x)
+            kern.gemm(kern.mat_plain(x, K, 1, sb=M * K, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
+                      scb=M * N, nbatch=nb, bias=b, bscale=bscale, R=resid, srb=M * N, srr=N, src=1)
         ctx.save_for_backward(x, W, bscale)
         ctx.refs = (W, b)
         ctx.has_resid = resid is not None
@@ -146,11 +162,11 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             kern.gemm(kern.mat_plain(gs, N, 1, kfast=1), kern.mat_plain(W, K, 1, kfast=0), dx, R, K, N, scr=K, scc=1)
-        return dx, None, None, (g if ctx.has_resid else None), None
+        return dx, None, None, (g if ctx.has_resid else None), None, None
 
 
-def linear(x, W, b=None, resid=None, bscale=None):
-    return LinearFn.apply(x, W, b, resid, bscale)
+def linear(x, W, b=None, resid=None, bscale=None, split_k=False):
+    return LinearFn.apply(x, W, b, resid, bscale, split_k)
 
 
 # =====================================================================================================
@@ -321,10 +337,39 @@ def conv2d_nchw(x, W, b=None, stride=1, pad=0, out_layout="nchw", expand_channel
     return Conv2dFn.apply(x, W, b, geom)
 
 
+class PatchTokFn(Function):
+    """tokens [B, H*W, C] -> patch rows [B, (H/s)*(W/s), C*s*s], k = (c, ky, kx) (cenet_patch_tok_f32); the backward is
+    the inverse scatter, which writes every input-gradient element exactly once."""
+
+    @staticmethod
+    def forward(ctx, x, H, Wd, s):
+        x = _c(x)
+        B, N, C = x.shape
+        Ho, Wo = H // s, Wd // s
+        xp = _empty((B, Ho * Wo, C * s * s), x)
+        kern.patch_tok(x, xp, B, Ho, Wo, C, s)
+        ctx.geom = (B, Ho, Wo, C, s, N)
+        return xp
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Ho, Wo, C, s, N = ctx.geom
+        g = _c(g)
+        dx = _empty((B, N, C), g)
+        kern.patch_tok(g, dx, B, Ho, Wo, C, s, inverse=True)
+        return dx, None, None, None
+
+
 def conv2d_tok(x, H, Wd, W, b=None, stride=1, pad=0, out_layout="tok"):
     """x [B, H*W, C] token layout read as an NCHW map (pvtv2.py:93-94)."""
     x = _c(x)
     B, N, C = x.shape
+    k = W.shape[2]
+    if (out_layout == "tok" and k == stride and W.shape[3] == k and pad == 0 and k in (2, 4, 8) and H % k == 0
+            and Wd % k == 0 and N == H * Wd and W.is_contiguous()):
+        # non-overlapping patches (the spatial-reduction conv): gather the patches once, then it is a Linear layer over
+        # rows of C*k*k with the weight in its own [Cout, (c, ky, kx)] order -- both GEMM operands k-contiguous
+        return linear(PatchTokFn.apply(x, H, Wd, k), W, b, split_k=True)
     geom = (B, C, H, Wd, N * C, 1, Wd * C, C, stride, pad, out_layout)
     return Conv2dFn.apply(x, W, b, geom)
 

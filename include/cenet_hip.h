@@ -195,6 +195,11 @@ int cenet_srm_bwd_apply_f32(const float* x, const float* dy, const float* f, con
 /* ---- glue (elementwise.hip) --------------------------------------------------------------------------------- */
 int cenet_transpose_f32(const float* x, long sxb, float* y, long syb, int B, int R, int Cc, cenet_stream_t stream);
 int cenet_copy_batched_f32(const float* x, long sxb, float* y, long syb, int B, long n, int accumulate, cenet_stream_t stream);
+/* Space-to-depth of a token map for the kernel == stride spatial-reduction conv (reference networks/cenet/pvtv2.py:93-95,
+ * `self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)` applied to x.permute(0,2,1).reshape(B,C,H,W)):
+ * inverse == 0 gathers tok [B, Ho*S, Wo*S, C] into patch rows [B*Ho*Wo, C*S*S] (k = (c, ky, kx), the weight's own order);
+ * inverse == 1 scatters patch rows back to the token map (the data gradient). S in {2, 4, 8}. */
+int cenet_patch_tok_f32(const float* src, float* dst, int B, int Ho, int Wo, int C, int S, int inverse, cenet_stream_t stream);
 int cenet_scale_batch_f32(const float* x, const float* s, float* y, int B, long n, cenet_stream_t stream);
 int cenet_act_fwd_f32(const float* x, float* y, long n, int act, float slope, cenet_stream_t stream);
 int cenet_act_bwd_f32(const float* pre, const float* dy, float* dx, long n, int act, float slope, cenet_stream_t stream);

@@ -164,3 +164,25 @@ def test_conv1x1_bf16_k64(dev, bf16_mode, B, Cin, Cout, HW):
     assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
     assert _rel(x.grad.cpu(), xr.grad) < 2e-2
     assert _rel(W.grad.cpu(), Wr.grad) < 2e-2
+
+
+# spatial-reduction conv in throughput mode: K = C*s*s >= 1024 takes the split-K forward (atomics onto a bias-filled output)
+@pytest.mark.parametrize("B,C,Cout,H,W,s", [(2, 64, 40, 8, 8, 4), (1, 16, 24, 16, 8, 8)])
+def test_sr_conv_tok_bf16_split_k(dev, bf16_mode, B, C, Cout, H, W, s):
+    g = torch.Generator().manual_seed(C + Cout + s)
+    x = torch.randn(B, H * W, C, generator=g).to(dev).requires_grad_(True)
+    Wt = torch.nn.Parameter((torch.randn(Cout, C, s, s, generator=g) * 0.05).to(dev))
+    b = torch.nn.Parameter(torch.randn(Cout, generator=g).to(dev))
+    Ho, Wo = H // s, W // s
+    go = torch.randn(B, Ho * Wo, Cout, generator=g).to(dev)
+    bf16_mode()
+    y = ops.conv2d_tok(x, H, W, Wt, b, stride=s, pad=0, out_layout="tok")
+    y.backward(go)
+    xr, Wr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, Wt, b))
+    ref = torch.nn.functional.conv2d(xr.transpose(1, 2).reshape(B, C, H, W), Wr, br, stride=s)
+    ref = ref.reshape(B, Cout, Ho * Wo).transpose(1, 2)
+    ref.backward(go.cpu())
+    assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
+    assert _rel(x.grad.cpu(), xr.grad) < 2e-2
+    assert _rel(Wt.grad.cpu(), Wr.grad) < 2e-2
+    assert _rel(b.grad.cpu(), br.grad) < 1e-4

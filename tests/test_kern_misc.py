@@ -206,3 +206,36 @@ def test_zero_std_planes_give_finite_gradients(dev):
     out.backward(go.to(dev))
     assert torch.isfinite(xd.grad).all()
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=2e-3, atol=2e-4)
+
+
+# kernel == stride spatial-reduction conv on a token map (pvtv2.py:93-95): patch gather + dense GEMM against F.conv2d,
+# forward, data gradient (inverse scatter) and weight / bias gradients; s = 2, 4, 8; C not a multiple of 64; Cout ragged
+@pytest.mark.parametrize("B,C,Cout,H,W,s", [(2, 8, 12, 4, 6, 2), (1, 20, 8, 8, 4, 4), (2, 4, 6, 8, 16, 8), (3, 36, 36, 6, 6, 2)])
+def test_sr_conv_tok_patch_path(dev, B, C, Cout, H, W, s):
+    from cenet_amd import ops
+    g = torch.Generator().manual_seed(B + C + H + s)
+    xt = torch.randn(B, H * W, C, generator=g)
+    w = torch.randn(Cout, C, s, s, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    Ho, Wo = H // s, W // s
+    dy = torch.randn(B, Ho * Wo, Cout, generator=g)
+    xr, wr, br = xt.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr.transpose(1, 2).reshape(B, C, H, W), wr, br, stride=s).reshape(B, Cout, Ho * Wo).transpose(1, 2)
+    ref.backward(dy)
+    # the gather itself, both directions: a bijection between the token map and the patch rows
+    xd = xt.to(dev)
+    xp = torch.empty(B, Ho * Wo, C * s * s, device=dev)
+    kern.patch_tok(xd, xp, B, Ho, Wo, C, s)
+    want = xt.reshape(B, Ho, s, Wo, s, C).permute(0, 1, 3, 5, 2, 4).reshape(B, Ho * Wo, C * s * s)
+    assert torch.equal(xp.cpu(), want)
+    back = torch.empty_like(xd)
+    kern.patch_tok(xp, back, B, Ho, Wo, C, s, inverse=True)
+    assert torch.equal(back.cpu(), xt)
+    # the op as the model calls it
+    xq, wq, bq = xt.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.conv2d_tok(xq, H, W, wq, bq, stride=s, pad=0, out_layout="tok")
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    y.backward(dy.to(dev))
+    torch.testing.assert_close(xq.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(wq.grad.cpu(), wr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bq.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4)
