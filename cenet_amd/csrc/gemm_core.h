@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
     return;
   }
   const float* Rb = E.R ? E.R + (long)bo * E.srb + (long)bi * E.srb2 : nullptr;
-  const float bs = E.bscale ? E.bscale[batch] : 1.f;
+  const int bsr = E.bscale ? E.bscale_rows : 0;  // > 0: per-sample scale looked up by row (flat batch)
+  const float bs = (E.bscale && bsr == 0) ? E.bscale[batch] : 1.f;
   const int rwave = m0 + wm * (BM / 2) + (SWAP ? fr : fq * 4);
   const int cwave = n0 + wn * (BN / 2) + (SWAP ? fq * 4 : fr);
   if (g.cvec && !E.atomic && !E.cmode && E.act == ACT_NONE && m0 + BM <= g.M && n0 + BN <= g.N) {
@@ -503,6 +504,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] *= scale;
         }
+        if (bsr > 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= E.bscale[(SWAP ? rbase : rbase + r) / bsr];
+        }
         if (rrow) {
           float rr[4];
           memcpy(rr, rrow + i * ri + j * rj, 16);
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
             }
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= bs;
+          for (int r = 0; r < 4; ++r) v[r] *= bsr > 0 ? E.bscale[(SWAP ? rbase : rbase + r) / bsr] : bs;
           if (Rb) {
             float rr[4];
             memcpy(rr, Rb + (long)rbase * E.srr + (long)cbase * E.src, 16);
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
             if (row < g.M && col < g.N) {
               float t = v[r];
               if (E.bias) t += E.bias[E.bias_on_row ? row : col];
-              t *= bs;
+              t *= bsr > 0 ? E.bscale[row / bsr] : bs;
               if (Rb) t += Rb[(long)row * E.srr + (long)col * E.src];
               Cb[(long)row * E.scr + (long)col * E.scc] = t;
             }
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
         } else {
           if (E.bias) v += E.bias[E.bias_on_row ? row : col];
           v = act_fwd(E.act, v, E.slope);
-          v *= bs;
+          v *= bsr > 0 ? E.bscale[row / bsr] : bs;
           if (Rb) v += Rb[(long)row * E.srr + (long)col * E.src];
           Cb[(long)row * E.scr + (long)col * E.scc] = v;
         }

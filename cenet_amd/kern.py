@@ -83,7 +83,7 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
          act: str = "none", slope: float = 0.0, bscale: Optional[torch.Tensor] = None,
          R: Optional[torch.Tensor] = None, srb: int = 0, srr: int = 0, src: int = 0, atomic: bool = False,
          alpha: float = 1.0, c_offset: int = 0, r_offset: int = 0, nb_inner: int = 1, scb2: int = 0, srb2: int = 0,
-         col2im: Optional[dict] = None):
+         col2im: Optional[dict] = None, bscale_rows: int = 0):
     _chk(Cout, bias, bscale, R)
     e = EpiT()
     e.C = Cout.data_ptr() + 4 * c_offset
@@ -92,6 +92,7 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
     e.bias_on_row = int(bias_on_row)
     e.act, e.slope = ACT[act], slope
     e.bscale = bscale.data_ptr() if bscale is not None else None
+    e.bscale_rows = bscale_rows
     e.R = (R.data_ptr() + 4 * r_offset) if R is not None else None
     e.srb, e.srb2, e.srr, e.src = srb, srb2, srr, src
     e.atomic, e.alpha = int(atomic), alpha

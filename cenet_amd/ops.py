@@ -109,10 +109,8 @@ class LinearFn(Function):
         K = x.shape[-1]
         N = W.shape[0]
         R = x.numel() // K
-        if bscale is None:
-            nb, M = 1, R
-        else:
-            nb, M = x.shape[0], R // x.shape[0]
+        M = R  # one flat GEMM over all rows; the per-sample scale is looked up by row (bscale_rows)
+        bs_rows = 0 if bscale is None else R // x.shape[0]
         resid = _c(resid)
         shape = x.shape[:-1] + (N,)
         splits = 1
@@ -131,8 +129,8 @@ class LinearFn(Function):
                       splits=splits, atomic=True)
         else:
             y = _empty(shape, x)
-            kern.gemm(kern.mat_plain(x, K, 1, sb=M * K, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
-                      scb=M * N, nbatch=nb, bias=b, bscale=bscale, R=resid, srb=M * N, srr=N, src=1)
+            kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
+                      bias=b, bscale=bscale, bscale_rows=bs_rows, R=resid, srr=N, src=1)
         ctx.save_for_backward(x, W, bscale)
         ctx.refs = (W, b)
         ctx.has_resid = resid is not None
@@ -249,7 +247,7 @@ class Conv2dFn(Function):
         shape = (B, Cout, Ho, Wo) if out_layout == "nchw" else (B, Ho * Wo, Cout)
         scr, scc = (Ho * Wo, 1) if out_layout == "nchw" else (1, Cout)
         tiles = B * ((Cout + 63) // 64) * ((Ho * Wo + 63) // 64)
-        if tiles < 256 and Kd >= 1024 and kern.get_compute_bf16():  # parity mode keeps a deterministic forward
+        if tiles <= 256 and Kd >= 1024 and kern.get_compute_bf16():  # parity mode keeps a deterministic forward
             # few output tiles under a long reduction (the 8x8/4x4/2x2 spatial-reduction convs of pvtv2.py:93-95): split K
             # over workgroups; the partial sums are added atomically onto an output pre-filled with the bias
             if b is None:

@@ -63,6 +63,9 @@ typedef struct {
    * [0,cHs)x[0,cWs). Used for the data-gradient of strided convolutions (atomic when patches overlap). */
   int cmode, cKH, cKW, cPw, cHs, cWs, cstride, cpad;
   long csci, csy, csx;
+  /* > 0: bscale is indexed by (row / bscale_rows) instead of by batch -- a [B, n, K] activation run as ONE flat GEMM of
+   * B*n rows with the per-sample DropPath scale of pvtv2.py:117-118 still applied per sample (bscale_rows = n). */
+  int bscale_rows;
 } cenet_epi_t;
 
 /* Replaces aten::addmm/mm/bmm/convolution(+_backward) — pvtv2.py:41,45,90,98,106,164; cfam.py:149,158,299,302;

@@ -31,6 +31,28 @@ def test_gemm_batched_nn_epilogue(dev):
     torch.testing.assert_close(y.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4)
 
 
+# per-sample scale looked up by row in ONE flat GEMM (DropPath of pvtv2.py:117-118 on [B, n, K] activations): samples that
+# straddle tile boundaries (n = 50, 100), interior tiles (lean epilogue) and ragged edge tiles, with and without bias / residual,
+# and through the activation (generic) epilogue
+@pytest.mark.parametrize("Bt,n,N,K,bias,resid,act", [(3, 50, 70, 24, True, True, "none"), (2, 100, 128, 40, False, True, "none"),
+                                                      (4, 64, 64, 32, True, False, "none"), (3, 50, 36, 20, True, True, "gelu")])
+def test_gemm_flat_per_row_sample_scale(dev, Bt, n, N, K, bias, resid, act):
+    x, w = rnd(Bt, n, K, dev=dev), rnd(N, K, dev=dev, seed=1)
+    b = rnd(N, dev=dev, seed=2) if bias else None
+    R = rnd(Bt, n, N, dev=dev, seed=3) if resid else None
+    bs = rnd(Bt, dev=dev, seed=4)
+    y = torch.empty(Bt, n, N, device=dev)
+    kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(w, 1, K, kfast=1), y, Bt * n, N, K, scr=N, scc=1, bias=b,
+              act=act, bscale=bs, bscale_rows=n, R=R, srr=N, src=1)
+    ref = F.linear(x, w, b)
+    if act == "gelu":
+        ref = F.gelu(ref)
+    ref = ref * bs[:, None, None]
+    if resid:
+        ref = ref + R
+    torch.testing.assert_close(y.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4)
+
+
 def test_gemm_splitk_atomic_kbatch(dev):
     Bt, Co, Ci, HW = 4, 10, 12, 50
     dy, x = rnd(Bt, Co, HW, dev=dev), rnd(Bt, Ci, HW, dev=dev, seed=1)
