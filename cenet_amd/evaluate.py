@@ -6,14 +6,19 @@ Mirrors the reference's call sites:
   * `calculate_dice_percase` / `test_single_volume` of src/utils/metrics_eval.py:24-34,37-84 — per foreground class over a
     whole volume, with the wrapper rules (pred>0 & gt==0 -> 1, otherwise 0)  -> `volume_class_dice`
 The reference predicts slice by slice with batch size 1 and computes the metric on the host; here a volume's slices go
-through the network in batches and one kernel produces the masks and the overlap counts (loss_optim.hip).  HD95 / ASD
-(medpy surface distances) and the scipy cubic `zoom` of non-224 slices stay host-side and are not part of this module:
-slices must already have the network's input size.
+through the network in batches and one kernel produces the masks and the overlap counts (loss_optim.hip).
+  * `calculate_metric_percase` of src/utils/metrics_eval.py:9-21 — (dice, hd95, jaccard, assd) per class  ->
+    `metric_percase`, `test_single_volume`.  medpy's surface distances (border extraction + distance of every border voxel
+    to the other border) run on the device in exact integer arithmetic (metrics.hip); only the final percentile / mean of
+    the few thousand distances is taken on the host, in float64 like numpy does.
+The scipy cubic `zoom` of slices that do not have the network's input size is the reference's own host-side dependency
+(metrics_eval.py:45,55) and is called the same way here.
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Tuple
+from typing import Iterable, List, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import kern
@@ -79,3 +84,98 @@ def volume_class_dice(net, volume: torch.Tensor, label: torch.Tensor, classes: i
         _, counts = predict_counts(net(x), label[s:s + batch_slices])
         total += counts.long()
     return class_dice(total)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# surface-distance metrics (metrics_eval.py:9-21 -> medpy.metric.binary.{hd95, assd, jc})
+# ---------------------------------------------------------------------------------------------------------------------
+def surface_points(mask: torch.Tensor) -> torch.Tensor:
+    """Border voxels of a boolean volume [D,H,W] (or image [H,W]) as int32 (z,y,x) rows: mask XOR its erosion by the
+    face-connected structuring element with background outside the array (medpy `__surface_distances`)."""
+    if mask.dim() == 2:
+        mask = mask.unsqueeze(0)
+        # a 2-D input has no z neighbours in medpy (2-D structuring element): pad so the z faces count as set
+        m = (mask != 0).to(torch.uint8).repeat(3, 1, 1).contiguous()
+        border = torch.empty_like(m)
+        kern.surface_border(m, border, 3, m.shape[1], m.shape[2])
+        pts = torch.nonzero(border[1:2]).to(torch.int32).contiguous()
+        return pts
+    m = (mask != 0).to(torch.uint8).contiguous()
+    border = torch.empty_like(m)
+    kern.surface_border(m, border, m.shape[0], m.shape[1], m.shape[2])
+    return torch.nonzero(border).to(torch.int32).contiguous()
+
+
+def _directed_sq(a_pts: torch.Tensor, b_pts: torch.Tensor) -> torch.Tensor:
+    out = torch.full((a_pts.shape[0],), 2 ** 31 - 1, dtype=torch.int32, device=a_pts.device)
+    kern.min_sqdist(a_pts, b_pts, out)
+    return out
+
+
+def surface_distances(result: torch.Tensor, reference: torch.Tensor) -> Tuple[np.ndarray, np.ndarray]:
+    """Both directed surface-distance sets (result->reference, reference->result) as float64 arrays, unit voxel spacing.
+    Raises RuntimeError on an empty mask, as medpy does."""
+    ra, rb = surface_points(result), surface_points(reference)
+    if ra.shape[0] == 0:
+        raise RuntimeError("The first supplied array does not contain any binary object.")
+    if rb.shape[0] == 0:
+        raise RuntimeError("The second supplied array does not contain any binary object.")
+    d1 = _directed_sq(ra, rb).cpu().numpy().astype(np.float64)
+    d2 = _directed_sq(rb, ra).cpu().numpy().astype(np.float64)
+    return np.sqrt(d1), np.sqrt(d2)
+
+
+def hd95(result: torch.Tensor, reference: torch.Tensor) -> float:
+    d1, d2 = surface_distances(result, reference)
+    return float(np.percentile(np.hstack((d1, d2)), 95))
+
+
+def assd(result: torch.Tensor, reference: torch.Tensor) -> float:
+    d1, d2 = surface_distances(result, reference)
+    return float(np.mean((d1.mean(), d2.mean())))
+
+
+def metric_percase(pred: torch.Tensor, gt: torch.Tensor) -> Tuple[float, float, float, float]:
+    """calculate_metric_percase (metrics_eval.py:9-21): (dice, hd95, jaccard, assd) of two binary volumes, with its rules
+    for empty masks."""
+    p, g = pred != 0, gt != 0
+    np_, ng = int(p.sum()), int(g.sum())
+    if np_ > 0 and ng > 0:
+        inter = int((p & g).sum())
+        dice = 2.0 * inter / float(np_ + ng)
+        jac = inter / float(np_ + ng - inter)
+        d1, d2 = surface_distances(p, g)
+        return dice, float(np.percentile(np.hstack((d1, d2)), 95)), jac, float(np.mean((d1.mean(), d2.mean())))
+    if np_ > 0 and ng == 0:
+        return 1, 0, 1, 0
+    return 0, 0, 0, 0
+
+
+@torch.no_grad()
+def test_single_volume(image, label, net, classes: int, patch_size: Sequence[int] = (224, 224), batch_slices: int = 32,
+                       device=None) -> List[Tuple[float, float, float, float]]:
+    """test_single_volume (metrics_eval.py:37-84) for a 3-D volume: image / label [1,D,H,W] or [D,H,W] (tensor or ndarray).
+    Slices are resized to `patch_size` with scipy's cubic zoom and the predictions back with order 0 exactly as the
+    reference does (host side), but the network runs on batches of slices and the metrics on the device.
+    Returns [(dice, hd95, jaccard, assd)] for classes 1..classes-1."""
+    from scipy.ndimage import zoom
+    image = image.squeeze(0).cpu().numpy() if torch.is_tensor(image) else np.asarray(image)
+    label = label.squeeze(0).cpu().numpy() if torch.is_tensor(label) else np.asarray(label)
+    assert image.ndim == 3, "volume [D,H,W] expected"
+    device = device or next(net.parameters()).device
+    net.eval()
+    D, x, y = image.shape
+    resize = (x != patch_size[0] or y != patch_size[1])
+    prediction = np.zeros_like(label)
+    for s in range(0, D, batch_slices):
+        sl = image[s:s + batch_slices]
+        if resize:
+            sl = np.stack([zoom(a, (patch_size[0] / x, patch_size[1] / y), order=3) for a in sl])
+        inp = torch.from_numpy(np.ascontiguousarray(sl)).unsqueeze(1).float().to(device)
+        pred, _ = predict_counts(net(inp))
+        out = pred.reshape(-1, patch_size[0], patch_size[1]).cpu().numpy()
+        for i in range(out.shape[0]):
+            prediction[s + i] = zoom(out[i], (x / patch_size[0], y / patch_size[1]), order=0) if resize else out[i]
+    pred_d = torch.from_numpy(np.ascontiguousarray(prediction)).to(device)
+    lab_d = torch.from_numpy(np.ascontiguousarray(label)).to(device)
+    return [metric_percase(pred_d == c, lab_d == c) for c in range(1, classes)]

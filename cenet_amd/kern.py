@@ -21,8 +21,8 @@ def _chk(*ts):
     for t in ts:
         if t is None:
             continue
-        if t.dtype != torch.float32 and t.dtype != torch.int32 and t.dtype != torch.int64:
-            raise TypeError(f"cenet_amd kernels are fp32; got {t.dtype}")
+        if t.dtype not in (torch.float32, torch.int32, torch.int64, torch.uint8):
+            raise TypeError(f"cenet_amd kernels are fp32 (int32 / int64 / uint8 for indices and masks); got {t.dtype}")
         if not t.is_cuda and not _lib.is_hostsim():
             raise RuntimeError("cenet_amd kernels run on the MI355X only: tensor is not on a CUDA/HIP device "
                                "(there is no CPU fallback)")
@@ -446,6 +446,16 @@ def seg_loss_bwd(logits, labels, acc, gout, dlogits, B, K, H, W, w_dice, w_ce, w
 def argmax_counts(logits, labels, pred, counts, B, K, HW):
     _chk(logits, labels, pred)
     _call("cenet_argmax_counts_f32", logits, labels, pred, counts, B, K, HW)
+
+
+def surface_border(mask_u8, border_u8, D, H, W):
+    _chk(mask_u8, border_u8)
+    _call("cenet_surface_border_u8", mask_u8, border_u8, D, H, W)
+
+
+def min_sqdist(a_i32, b_i32, out_i32):
+    _chk(a_i32, b_i32, out_i32)
+    _call("cenet_min_sqdist_i32", a_i32, a_i32.shape[0], b_i32, b_i32.shape[0], out_i32)
 
 
 def sgd_step(p, g, buf, hyper5, n):

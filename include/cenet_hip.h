@@ -255,6 +255,14 @@ int cenet_seg_loss_bwd_f32(const float* logits, const float* labels, const float
  * labels) = per class {|pred==c & gt==c|, |pred==c|, |gt==c|} and, in row K, the same for the binary masks pred>0 / gt>0. */
 int cenet_argmax_counts_f32(const float* logits, const float* labels, float* pred, unsigned* counts, int B, int K, int HW,
                             cenet_stream_t stream);
+/* Surface-distance metrics of metrics_eval.py:9-21 (`calculate_metric_percase`: medpy.metric.binary.hd95 / assd, medpy==0.5.2,
+ * requirements.txt:7; medpy is a third-party dependency absent from the reference tree, its published algorithm is restated).
+ * border[D*H*W] = mask XOR binary_erosion(mask) with the 6-neighbourhood and background outside the volume (0/1 bytes). */
+int cenet_surface_border_u8(const unsigned char* mask, unsigned char* border, int D, int H, int W, cenet_stream_t stream);
+/* out[i] = min(out[i], min_j |a_i - b_j|^2): a [na,3], b [nb,3] int32 voxel coordinates (z,y,x), unit spacing as the
+ * reference's calls use; out [na] int32 pre-filled by the caller with INT_MAX. The distance transform of medpy's
+ * __surface_distances sampled at the other surface, kept in exact integer arithmetic (host takes the square root). */
+int cenet_min_sqdist_i32(const int* a, int na, const int* b, int nb, int* out, cenet_stream_t stream);
 /* torch.optim.SGD(momentum, weight_decay) over a flat arena; hyper5 (device) = [lr, momentum, wd, grad_scale, first_step] */
 int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, cenet_stream_t stream);
 int cenet_zero_f32(float* p, long n, cenet_stream_t stream);

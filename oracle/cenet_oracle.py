@@ -12,15 +12,18 @@ this file, and only as the checker / reported CPU baseline — never as the ship
 Parity pinning: `tests/test_oracle_golden.py` checks every function here against
 golden vectors produced by the *imported, unmodified reference* in the build
 container (`oracle/gen_golden.py`, fixtures under `tests/golden/`).
-Third-party arithmetic not under /root/reference: medpy==0.5.2 `binary.dc`
-(restated in `dice_metric`, parity unpinned — medpy is absent and the reference holds
-no test for it); timm==1.0.16 DropPath (restated in `_drop_path`).
+Third-party arithmetic not under /root/reference: medpy==0.5.2 `binary.dc`, `binary.jc`,
+`binary.hd95`, `binary.assd` (restated in `dice_metric`, `jaccard_metric`, `surface_distances`,
+`hd95_metric`, `assd_metric` from medpy's published algorithm on the scipy.ndimage calls it is
+built on; parity unpinned — medpy is absent and the reference holds no test for it); timm==1.0.16 DropPath (restated in `_drop_path`).
 
 All file:line citations are relative to /root/reference/src/.
 """
 from __future__ import annotations
 
 import math
+
+import numpy as np
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
@@ -437,6 +440,53 @@ def dice_metric(pred: Tensor, gt: Tensor) -> float:
     a, b = pred.bool(), gt.bool()
     denom = int(a.sum()) + int(b.sum())
     return 2.0 * int((a & b).sum()) / denom if denom else 0.0
+
+
+def jaccard_metric(pred, gt) -> float:
+    """medpy.metric.binary.jc (published formula): |A∩B| / |A∪B| on boolean masks.  PARITY UNPINNED (medpy absent)."""
+    a, b = np.asarray(pred).astype(bool), np.asarray(gt).astype(bool)
+    return float(np.count_nonzero(a & b)) / float(np.count_nonzero(a | b))
+
+
+def surface_distances(result, reference, voxelspacing=None, connectivity: int = 1):
+    """medpy.metric.binary.__surface_distances (medpy 0.5.2, published algorithm): border = mask XOR its erosion by
+    generate_binary_structure(ndim, connectivity); the Euclidean distance transform of the complement of the reference
+    border, read at the result border.  Raises RuntimeError on an empty mask.  PARITY UNPINNED (medpy absent)."""
+    from scipy.ndimage import binary_erosion, distance_transform_edt, generate_binary_structure
+    result = np.atleast_1d(np.asarray(result).astype(bool))
+    reference = np.atleast_1d(np.asarray(reference).astype(bool))
+    footprint = generate_binary_structure(result.ndim, connectivity)
+    if 0 == np.count_nonzero(result):
+        raise RuntimeError("The first supplied array does not contain any binary object.")
+    if 0 == np.count_nonzero(reference):
+        raise RuntimeError("The second supplied array does not contain any binary object.")
+    result_border = result ^ binary_erosion(result, structure=footprint, iterations=1)
+    reference_border = reference ^ binary_erosion(reference, structure=footprint, iterations=1)
+    dt = distance_transform_edt(~reference_border, sampling=voxelspacing)
+    return dt[result_border]
+
+
+def hd95_metric(result, reference) -> float:
+    """medpy.metric.binary.hd95: 95th percentile (numpy, linear interpolation) of both directed distance sets together."""
+    hd1 = surface_distances(result, reference)
+    hd2 = surface_distances(reference, result)
+    return float(np.percentile(np.hstack((hd1, hd2)), 95))
+
+
+def assd_metric(result, reference) -> float:
+    """medpy.metric.binary.assd: mean of the two directed average surface distances."""
+    return float(np.mean((surface_distances(result, reference).mean(), surface_distances(reference, result).mean())))
+
+
+def metric_percase(pred, gt):
+    """calculate_metric_percase (src/utils/metrics_eval.py:9-21): (dice, hd95, jaccard, assd) with its empty-mask rules."""
+    pred, gt = (np.asarray(pred) > 0), (np.asarray(gt) > 0)
+    if pred.sum() > 0 and gt.sum() > 0:
+        dice = 2.0 * np.count_nonzero(pred & gt) / float(np.count_nonzero(pred) + np.count_nonzero(gt))
+        return dice, hd95_metric(pred, gt), jaccard_metric(pred, gt), assd_metric(pred, gt)
+    if pred.sum() > 0 and gt.sum() == 0:
+        return 1, 0, 1, 0
+    return 0, 0, 0, 0
 
 
 def predict(logits: Tensor) -> Tensor:

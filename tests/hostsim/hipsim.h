@@ -135,6 +135,7 @@ template <typename T> static inline T __shfl(T v, int src, int width = 64) {
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 
 typedef float f32x4 __attribute__((vector_size(16)));

@@ -61,3 +61,98 @@ def test_validate_and_volume(dev):
     v = evaluate.validate(net, [(vol[:4].unsqueeze(1).to(dev), lab[:4].to(dev)), (vol[4:].unsqueeze(1).to(dev), lab[4:].to(dev))])
     ref = (O.dice_metric(pred[:4] > 0, lab[:4] > 0) + O.dice_metric(pred[4:] > 0, lab[4:] > 0)) / 2
     assert abs(v - ref) < 1e-12
+
+
+def _blobs(shape, seed, thresh=0.55):
+    """smooth random blobs: low-resolution noise upsampled, thresholded"""
+    import numpy as np
+    from scipy.ndimage import zoom
+    rng = np.random.default_rng(seed)
+    low = rng.random(tuple(max(2, s // 4) for s in shape))
+    v = zoom(low, [s / l for s, l in zip(shape, low.shape)], order=1)
+    return v > thresh
+
+
+# surface distances / HD95 / ASSD / Jaccard (metrics_eval.py:9-21 -> medpy 0.5.2) against the scipy-based restatement:
+# bit-exact distances (integer squared distances on the device, float64 square root), objects touching the volume faces,
+# a single voxel, identical masks, 2-D masks, and a set large enough to span several LDS tiles and b-chunks
+@pytest.mark.parametrize("shape,seed", [((6, 20, 24), 0), ((3, 9, 7), 1), ((10, 40, 36), 2), ((1, 12, 12), 3), ((24, 24), 4),
+                                        ((12, 64, 64), 5)])
+def test_surface_metrics_match_restated_medpy(dev, shape, seed):
+    import numpy as np
+    a, b = _blobs(shape, seed), _blobs(shape, seed + 100)
+    if not a.any():
+        a.flat[0] = True
+    if not b.any():
+        b.flat[-1] = True
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    d1, d2 = evaluate.surface_distances(ta, tb)
+    r1, r2 = O.surface_distances(a, b), O.surface_distances(b, a)
+    # same multiset of distances in the same (C) order of border voxels, exactly
+    assert d1.shape == r1.shape and d2.shape == r2.shape
+    assert np.array_equal(d1, r1) and np.array_equal(d2, r2)
+    assert evaluate.hd95(ta, tb) == O.hd95_metric(a, b)
+    assert evaluate.assd(ta, tb) == O.assd_metric(a, b)
+    got, want = evaluate.metric_percase(ta, tb), O.metric_percase(a, b)
+    assert all(abs(g - w) < 1e-12 for g, w in zip(got, want))
+
+
+def test_surface_metrics_edge_cases(dev):
+    import numpy as np
+    z = np.zeros((4, 8, 8), bool)
+    one = z.copy()
+    one[2, 3, 4] = True
+    far = z.copy()
+    far[0, 0, 0] = True
+    full = np.ones((4, 8, 8), bool)
+    T = lambda m: torch.from_numpy(m).to(dev)
+    assert evaluate.metric_percase(T(one), T(one)) == O.metric_percase(one, one) == (1.0, 0.0, 1.0, 0.0)
+    assert evaluate.metric_percase(T(one), T(far)) == O.metric_percase(one, far)
+    assert evaluate.metric_percase(T(full), T(one)) == O.metric_percase(full, one)
+    assert evaluate.metric_percase(T(one), T(z)) == (1, 0, 1, 0) == O.metric_percase(one, z)  # pred>0, gt empty
+    assert evaluate.metric_percase(T(z), T(one)) == (0, 0, 0, 0) == O.metric_percase(z, one)
+    assert evaluate.metric_percase(T(z), T(z)) == (0, 0, 0, 0)
+    with pytest.raises(RuntimeError):
+        evaluate.surface_distances(T(z), T(one))
+
+
+class _ConstNet(torch.nn.Module):
+    """stands in for the network: logits that depend on the input intensity only (so the zoom path decides the result)"""
+
+    def __init__(self, K):
+        super().__init__()
+        self.K = K
+        self.p = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        levels = torch.linspace(0.2, 0.8, self.K, device=x.device).view(1, self.K, 1, 1)
+        return -(x - levels).abs()
+
+
+# whole test_single_volume: cubic zoom to the patch size, batched prediction, order-0 zoom back, per-class metrics; compared
+# with the reference's slice-by-slice procedure restated on the host
+@pytest.mark.parametrize("size,patch", [((5, 30, 26), (16, 16)), ((4, 16, 16), (16, 16))])
+def test_single_volume_matches_slicewise_procedure(dev, size, patch):
+    import numpy as np
+    from scipy.ndimage import zoom
+    K = 4
+    rng = np.random.default_rng(7)
+    low = rng.random((size[0], 6, 6))
+    image = np.stack([zoom(s, (size[1] / 6, size[2] / 6), order=1) for s in low]).astype(np.float32)
+    label = np.clip((image * K).astype(np.int64), 0, K - 1).astype(np.float32)
+    net = _ConstNet(K).to(dev)
+    got = evaluate.test_single_volume(torch.from_numpy(image)[None], torch.from_numpy(label)[None], net, K, patch_size=patch,
+                                      batch_slices=2, device=dev)
+    # the reference's procedure (metrics_eval.py:37-71) on the host
+    pred = np.zeros_like(label)
+    for i in range(size[0]):
+        s = image[i]
+        x, y = s.shape
+        if (x, y) != tuple(patch):
+            s = zoom(s, (patch[0] / x, patch[1] / y), order=3)
+        out = O.predict(net.cpu()(torch.from_numpy(s)[None, None].float())).squeeze(0).numpy()
+        net.to(dev)
+        pred[i] = zoom(out, (x / patch[0], y / patch[1]), order=0) if (x, y) != tuple(patch) else out
+    want = [O.metric_percase(pred == c, label == c) for c in range(1, K)]
+    for g, w in zip(got, want):
+        assert all(abs(a - b) < 1e-12 for a, b in zip(g, w))
