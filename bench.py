@@ -86,7 +86,7 @@ def dominant_kernel_probe(dev, B):
     # HBM bytes per launch from rocprofv3 PMC passes at B=32 (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/
     # r01_pmc_roofline_kernel*.csv): fp32 mode = implicit-GEMM gather, bf16 mode = LDS-halo direct conv; algorithmic = 411 MB
     bf16 = peak != PEAK_F32_MFMA_TFLOPS
-    traffic = (8.66e8 if bf16 else 1.157e9) if B == 32 else None
+    traffic = (4.2e8 if bf16 else 1.157e9) if B == 32 else None
     name = ("conv_direct_bf16_kernel<32,32,5>" if bf16 else "gemm_kernel<float,32,256,im2col>") + \
         " (out.rb.0.conv2 fwd, 5x5 32->32 @224^2)"
     alg_bytes = 4.0 * (2 * B * 32 * 224 * 224 + 32 * 32 * 25)  # input + output + weights, fp32 in HBM

@@ -97,14 +97,22 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile < a.ntiles) load_halo(tile);
-  for (; tile < a.ntiles; tile += gridDim.x) {
+  // XCD-aware tile walk: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  XCD x walks
+  // the contiguous eighth [x*per, (x+1)*per) of the tile list (whole images), its workgroups taking consecutive tiles, so
+  // the tiles that share halo rows / columns and 128-byte lines run on the same L2 at about the same time.  (Dealing tiles
+  // by blockIdx instead put every neighbour on another XCD: 866 MB fetched + written for 411 MB algorithmic; now 417 MB.)
+  const int G = gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = blockIdx.x % G, nloc = ((int)gridDim.x + G - 1 - xcd) / G;  // workgroups on this XCD
+  const int per = (a.ntiles + G - 1) / G;
+  const int t_end = (xcd + 1) * per < a.ntiles ? (xcd + 1) * per : a.ntiles;
+  int tile = xcd * per + (int)blockIdx.x / G;
+  if (tile < t_end) load_halo(tile);
+  for (; tile < t_end; tile += nloc) {
     __syncthreads();  // previous tile's fragments consumed (and, first time, weights visible after the next barrier)
     store_halo();
     __syncthreads();
-    const int nxt = tile + gridDim.x;
-    if (nxt < a.ntiles) load_halo(nxt);  // next halo flies under this tile's MFMAs
+    const int nxt = tile + nloc;
+    if (nxt < t_end) load_halo(nxt);  // next halo flies under this tile's MFMAs
 
     f32x4 acc[MT][4];
 #pragma unroll
