@@ -21,6 +21,28 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 #define CENET_WAVE 64
 
+// XCD-aware block numbering.  Workgroups are dealt round-robin over the 8 XCDs by linear id (MI355X_MICROARCH.md "Workgroup
+// dispatch"), each XCD with its own L2, so spatial neighbours of a 3-D grid land on different L2s and every shared halo row
+// is fetched from HBM once per XCD.  Re-number so that each XCD owns a contiguous range of the grid (x fastest).  Speed only.
+struct cenet_bid {
+  int x, y, z;
+};
+__device__ __forceinline__ cenet_bid cenet_xcd_block() {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int T = gx * gy * (int)gridDim.z;
+  int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  if (T >= 64) {
+    const int per = T >> 3, rem = T & 7, xcd = L & 7, idx = L >> 3;
+    L = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  }
+  cenet_bid b;
+  b.x = L % gx;
+  const int t = L / gx;
+  b.y = t % gy;
+  b.z = t / gy;
+  return b;
+}
+
 // fp32 -> bf16, round to nearest even.  gfx950 converts two floats per instruction (v_cvt_pk_bf16_f32); the host-side
 // checker build uses the equivalent integer rounding.
 #ifdef CENET_HOSTSIM_BUILD

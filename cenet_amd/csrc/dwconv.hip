@@ -50,12 +50,13 @@ __global__ __launch_bounds__(256) void dw3x3_tok_kernel(const float* __restrict_
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        float* __restrict__ a, int C, int H, int W, int flip, int act,
                                                        float slope) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const cenet_bid bid = cenet_xcd_block();  // row-neighbour strips share their halo rows through one L2
+  const int c = bid.x * 256 + threadIdx.x;
   if (c >= C) return;
   const int strips_per_row = (W + DW_SW - 1) / DW_SW;
-  const int py = (blockIdx.y / strips_per_row) * DW_SR;
-  const int px0 = (blockIdx.y % strips_per_row) * DW_SW;
-  const long img = (long)blockIdx.z * H * W * C;
+  const int py = (bid.y / strips_per_row) * DW_SR;
+  const int px0 = (bid.y % strips_per_row) * DW_SW;
+  const long img = (long)bid.z * H * W * C;
   const float* xb = x + img + c;
   float wt[9];
 #pragma unroll
@@ -201,9 +202,10 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_tok_v4_kernel(const float* __
                                                                 int W) {
   __shared__ float red[4][10][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = (blockIdx.x * 64 + lane) * 4;
-  const int py = blockIdx.y * 4 + wave;
-  const long img = (long)blockIdx.z * H * W * C;
+  const cenet_bid bid = cenet_xcd_block();
+  const int c = (bid.x * 64 + lane) * 4;
+  const int py = bid.y * 4 + wave;
+  const long img = (long)bid.z * H * W * C;
   float acc[4][10];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_tok_v4_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < 10; ++t) red[wave][t][lane * 4 + e] = acc[e][t];
   __syncthreads();
-  const int cc = blockIdx.x * 256 + threadIdx.x;  // one channel per thread now
+  const int cc = bid.x * 256 + threadIdx.x;  // one channel per thread now
   if (cc < C) {
 #pragma unroll
     for (int t = 0; t < 10; ++t) {
