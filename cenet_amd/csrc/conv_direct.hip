@@ -247,7 +247,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  // XCD-aware tile walk, as in the forward kernel: each XCD owns a contiguous eighth of the tile list
+  const int G = gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = blockIdx.x % G, nloc = ((int)gridDim.x + G - 1 - xcd) / G;
+  const int per = (a.ntiles + G - 1) / G;
+  const int t_end = (xcd + 1) * per < a.ntiles ? (xcd + 1) * per : a.ntiles;
+  for (int tile = xcd * per + (int)blockIdx.x / G; tile < t_end; tile += nloc) {
     const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
     const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
     const int y0 = ty * TH_, x0 = tx * 32;
