@@ -14,7 +14,11 @@ for r in seg:
     n = r["Kernel_Name"]; t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 2e6
     k = n.split("(")[0].replace("void ", "")
     grp[k] += t
-    fam["gemm_im2col" if ("gemm_kernel" in n and ", true, " in n) else "gemm_plain" if "gemm_kernel" in n else "flash" if "flash" in n else "other"] += t
+    if "gemm_kernel<" in n:  # gemm_kernel<OpT, BM, BN, B_IM2COL, SWAP, KT>
+        args = n.split("gemm_kernel<")[1].split(">")[0].split(",")
+        fam["gemm_im2col" if args[3].strip() == "true" else "gemm_plain"] += t
+    else:
+        fam["flash" if "flash" in n else "other"] += t
 print({k: round(v, 2) for k, v in fam.items()})
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 for k, t in sorted(grp.items(), key=lambda kv: -kv[1])[:top]:
