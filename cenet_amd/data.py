@@ -10,7 +10,7 @@ Mirrors src/datasets/dataset_acdc.py:
   * `ACDCdataset` (:51-78) and `ACDCdatasetFast` (:81-114) — same constructor and `__getitem__` contract
     (`{'image', 'label', 'case_name'}`; the transform only on split 'train').
 The reference builds `DataLoader(db_train, batch_size, shuffle=True)` with `num_workers=0` (src/main_acdc.py:140): one host
-core runs two cubic zooms per sample, ~100 samples/s, against ~750 images/s per GPU for the training step.
+process does all the resampling, 30 samples/s measured (tools/data_bench.py), against ~750 images/s per GPU for the step.
 `make_train_loader` + `DevicePrefetcher` are the replacement; with `num_workers=0` the loader is the reference's.
 """
 from __future__ import annotations
@@ -26,27 +26,37 @@ from scipy.ndimage import zoom
 from torch.utils.data import DataLoader, Dataset
 
 
+def _apply_pair(fn, image, label):
+    return fn(image), fn(label)
+
+
 def random_rot_flip(image, label):
-    """dataset_acdc.py:15-22 — k quarter turns, then a flip along a random axis (same np.random draws, same order)."""
+    """dataset_acdc.py:15-22 — k quarter turns, then a flip along a random axis.  Draw order (np.random): k, then axis."""
     k = np.random.randint(0, 4)
-    image = np.rot90(image, k)
-    label = np.rot90(label, k)
+    image, label = _apply_pair(lambda a: np.rot90(a, k), image, label)
     axis = np.random.randint(0, 2)
-    image = np.flip(image, axis=axis).copy()
-    label = np.flip(label, axis=axis).copy()
-    return image, label
+    return _apply_pair(lambda a: np.flip(a, axis=axis).copy(), image, label)
 
 
 def random_rotate(image, label):
-    """dataset_acdc.py:25-29 — whole-degree rotation in [-20, 20), nearest sampling for both, shape kept."""
+    """dataset_acdc.py:25-29 — whole-degree rotation in [-20, 20) (one np.random draw), nearest sampling for image and
+    label alike, output shape kept."""
     angle = np.random.randint(-20, 20)
-    image = ndimage.rotate(image, angle, order=0, reshape=False)
-    label = ndimage.rotate(label, angle, order=0, reshape=False)
-    return image, label
+    return _apply_pair(lambda a: ndimage.rotate(a, angle, order=0, reshape=False), image, label)
+
+
+def _resize_pair(image, label, size):
+    """Cubic spline for the image, nearest for the label, scipy's default (non-grid) coordinate mapping (dataset_acdc.py:43-44)."""
+    h, w = image.shape
+    if h == size[0] and w == size[1]:
+        return image, label
+    factors = (size[0] / h, size[1] / w)
+    return zoom(image, factors, order=3), zoom(label, factors, order=0)
 
 
 class RandomGenerator(object):
-    """dataset_acdc.py:32-48.  sample {'image' [H,W], 'label' [H,W]} -> {'image' float32 [1,h,w], 'label' int64 [h,w]}."""
+    """dataset_acdc.py:32-48.  sample {'image' [H,W], 'label' [H,W]} -> {'image' float32 [1,h,w], 'label' int64 [h,w]}.
+    `random` draws: one to choose the quarter-turn branch; only if that fails a second one to choose the rotation branch."""
 
     def __init__(self, output_size: Sequence[int]):
         self.output_size = output_size
@@ -57,13 +67,10 @@ class RandomGenerator(object):
             image, label = random_rot_flip(image, label)
         elif random.random() > 0.5:
             image, label = random_rotate(image, label)
-        x, y = image.shape
-        if x != self.output_size[0] or y != self.output_size[1]:
-            image = zoom(image, (self.output_size[0] / x, self.output_size[1] / y), order=3)
-            label = zoom(label, (self.output_size[0] / x, self.output_size[1] / y), order=0)
-        image = torch.from_numpy(image.astype(np.float32)).unsqueeze(0)
-        label = torch.from_numpy(label.astype(np.float32))
-        return {'image': image, 'label': label.long()}
+        image, label = _resize_pair(image, label, self.output_size)
+        image_t = torch.from_numpy(image.astype(np.float32)).unsqueeze(0)
+        label_t = torch.from_numpy(label.astype(np.float32)).long()
+        return {'image': image_t, 'label': label_t}
 
 
 class ACDCdataset(Dataset):
