@@ -6,7 +6,9 @@ Mirrors the reference's call sites:
   * `calculate_dice_percase` / `test_single_volume` of src/utils/metrics_eval.py:24-34,37-84 — per foreground class over a
     whole volume, with the wrapper rules (pred>0 & gt==0 -> 1, otherwise 0)  -> `volume_class_dice`
 The reference predicts slice by slice with batch size 1 and computes the metric on the host; here a volume's slices go
-through the network in batches and one kernel produces the masks and the overlap counts (loss_optim.hip).
+through the network in batches (under `ops.batch1_semantics()`, so that every slice is computed exactly as a batch-1
+forward would: CCU's BatchNorm1d is the one batch-size-dependent op of the eval-mode network, cfam.py:260) and one kernel
+produces the masks and the overlap counts (loss_optim.hip).
   * `calculate_metric_percase` of src/utils/metrics_eval.py:9-21 — (dice, hd95, jaccard, assd) per class  ->
     `metric_percase`, `test_single_volume`.  medpy's surface distances (border extraction + distance of every border voxel
     to the other border) run on the device in exact integer arithmetic (metrics.hip); only the final percentile / mean of
@@ -21,7 +23,7 @@ from typing import Iterable, List, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import kern
+from . import kern, ops
 
 
 def predict_counts(logits: torch.Tensor, labels: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -81,7 +83,9 @@ def volume_class_dice(net, volume: torch.Tensor, label: torch.Tensor, classes: i
     total = torch.zeros((classes + 1, 3), device=volume.device, dtype=torch.int64)
     for s in range(0, volume.shape[0], batch_slices):
         x = volume[s:s + batch_slices].unsqueeze(1).float()
-        _, counts = predict_counts(net(x), label[s:s + batch_slices])
+        with ops.batch1_semantics():  # the reference feeds one slice per forward (metrics_eval.py:46-49): CCU skips its BN
+            logits = net(x)
+        _, counts = predict_counts(logits, label[s:s + batch_slices])
         total += counts.long()
     return class_dice(total)
 
@@ -172,7 +176,9 @@ def test_single_volume(image, label, net, classes: int, patch_size: Sequence[int
         if resize:
             sl = np.stack([zoom(a, (patch_size[0] / x, patch_size[1] / y), order=3) for a in sl])
         inp = torch.from_numpy(np.ascontiguousarray(sl)).unsqueeze(1).float().to(device)
-        pred, _ = predict_counts(net(inp))
+        with ops.batch1_semantics():  # slice-by-slice semantics of the reference (CCU's `if B > 1` BatchNorm, cfam.py:260)
+            logits = net(inp)
+        pred, _ = predict_counts(logits)
         out = pred.reshape(-1, patch_size[0], patch_size[1]).cpu().numpy()
         for i in range(out.shape[0]):
             prediction[s + i] = zoom(out[i], (x / patch_size[0], y / patch_size[1]), order=0) if resize else out[i]

@@ -188,9 +188,25 @@ class PyramidVisionTransformerImpr(nn.Module):
                     blk.drop_path = DropPath(dpr[cur + i])
             cur += self.depths[s]
 
+    def set_drop_path_masks(self, masks):
+        """Inject the stochastic-depth draws of the NEXT training forward: {(stage, i): (keep_attn[B], keep_mlp[B])} of 0/1
+        keep masks (what `bernoulli_(keep_prob)` returns inside timm's DropPath, pvtv2.py:123,145-149); they are divided by
+        keep_prob here as DropPath does.  Blocks without an entry (rate 0 -> Identity) are left alone.  Used by the parity
+        tests (tests/test_model_parity.py) — a training run samples its own masks."""
+        self._dp_injected = masks
+
     def _sample_drop_path(self, batch, device):
         """All stochastic-depth scales of one forward pass from ONE uniform draw (two per block: attention and MLP branch)
         instead of two tiny RNG launches per use; same distribution as DropPath.sample_scale."""
+        inj = getattr(self, "_dp_injected", None)
+        if inj is not None:
+            self._dp_injected = None
+            for (s, i), (ma, mm) in inj.items():
+                b = getattr(self, f"block{s + 1}")[i]
+                keep = 1.0 - b.drop_path.drop_prob
+                b._dp_pending = [(mm.to(device=device, dtype=torch.float32) / keep).contiguous(),
+                                 (ma.to(device=device, dtype=torch.float32) / keep).contiguous()]
+            return
         blocks = [b for s in range(4) for b in getattr(self, f"block{s + 1}")
                   if isinstance(b.drop_path, DropPath) and b.drop_path.training and b.drop_path.drop_prob > 0.0]
         if not blocks:

@@ -37,7 +37,10 @@ def grad_buf(p: Optional[Tensor]) -> Optional[Tensor]:
     if p is None or not p.requires_grad:
         return None
     if p.grad is None:
-        p.grad = _zeros(p.shape, p)
+        # a parameter that lives in a ParamArena gets its arena slot back (a caller ran zero_grad(set_to_none=True) or set
+        # .grad = None): FusedSGD reads the arena, a free-standing buffer would leave it with a stale gradient
+        home = getattr(p, "_cenet_grad_home", None)
+        p.grad = home() if home is not None else _zeros(p.shape, p)
     return p.grad
 
 
@@ -49,6 +52,7 @@ class _WgradSide:
     enabled = False
     stream = None
     pending = False
+    keep = []  # tensors the side stream still reads (see _wgrad_side): released in wgrad_join()
 
 
 def set_wgrad_overlap(on: bool) -> bool:
@@ -78,6 +82,11 @@ def _wgrad_side(*reads):
     for t in reads:
         if isinstance(t, Tensor):
             t.record_stream(side)  # keep the caching allocator from recycling these while the side stream reads them
+            # ... and keep a reference until the streams are joined: a gradient tensor that the Function also RETURNS (the
+            # residual gradient of Conv1x1Fn / LinearFn) would otherwise be accumulated into IN PLACE on the main stream by
+            # autograd when it has a second consumer (use_count == 1 lets the engine steal the buffer), while the side
+            # stream is still reading it.  With the extra reference autograd accumulates out of place.
+            _WgradSide.keep.append(t)
     _WgradSide.pending = True
 
 
@@ -91,6 +100,7 @@ def wgrad_join():
     if _WgradSide.pending:
         torch.cuda.current_stream().wait_stream(_WgradSide.stream)
         _WgradSide.pending = False
+    _WgradSide.keep.clear()
 
 
 def _c(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -1159,6 +1169,23 @@ def maxpool2_scale(x, w):
 # =====================================================================================================
 # CCU and SRM gates (cfam.py:251-264, 93-101)
 # =====================================================================================================
+class _Batch1:
+    """cfam.py:260: CCU applies its BatchNorm1d only `if B > 1`, so the reference's slice-by-slice evaluation
+    (metrics_eval.py:46-49, batch 1) never runs it.  Inside `batch1_semantics()` a batch of B slices is computed as B
+    independent batch-1 forwards would be (the only batch-dependent op of the eval-mode network)."""
+    on = False
+
+
+@contextlib.contextmanager
+def batch1_semantics(on: bool = True):
+    old = _Batch1.on
+    _Batch1.on = bool(on)
+    try:
+        yield
+    finally:
+        _Batch1.on = old
+
+
 class CCUFn(Function):
     @staticmethod
     def forward(ctx, x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training):
@@ -1169,7 +1196,7 @@ class CCUFn(Function):
         amax = _empty((B, Cn), x, torch.int32)
         z = _empty((B, Cn), x)
         kern.ccu_stats_fwd(x, fc1, fc2, u, amax, z, B, Cn, HW)
-        use_bn = B > 1
+        use_bn = B > 1 and not _Batch1.on
         mean = var = None
         if use_bn:
             zn = torch.empty_like(z)

@@ -58,9 +58,17 @@ class ParamArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grads[o:o + p.numel()].view(p.shape)
+                p._cenet_grad_home = self._home(o, p.numel(), tuple(p.shape))  # ops.grad_buf: re-attach after .grad = None
                 self.index[n] = (o, p.numel())
         self._plist = [p for _, p, _ in order]
         self._offs = [o for _, _, o in order]
+
+    def _home(self, o: int, n: int, shape):
+        def home():
+            g = self.grads[o:o + n]
+            kern.zero_(g)  # the slot still holds the previous step's gradient
+            return g.view(shape)
+        return home
 
     def zero_grad(self):
         """One memset for all gradients (re-attaches views if a caller set .grad to None)."""
@@ -82,25 +90,44 @@ class FusedSGD:
     def __init__(self, arena: ParamArena, lr: float, momentum: float = 0.9, weight_decay: float = 1e-4,
                  grad_scale: float = 1.0):
         self.arena = arena
-        self.lr, self.momentum, self.weight_decay, self.grad_scale = lr, momentum, weight_decay, grad_scale
+        # ONE persistent group dict, as torch.optim exposes it: `for g in opt.param_groups: g["lr"] = x` (warm-up code, torch
+        # LR schedulers) must take effect.  lr / momentum / weight_decay are read from it at every step.
+        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay, "params": arena._plist}]
+        self.grad_scale = grad_scale
         self.buf = torch.zeros_like(arena.params)
         self.hyper = torch.zeros(5, device=arena.params.device, dtype=torch.float32)
         self._steps = 0
         self._sync_hyper()
 
+    # lr / momentum / weight_decay live in param_groups[0] (torch.optim idiom); these properties are the short spelling
+    lr = property(lambda self: self.param_groups[0]["lr"], lambda self, v: self.param_groups[0].__setitem__("lr", v))
+    momentum = property(lambda self: self.param_groups[0]["momentum"],
+                        lambda self, v: self.param_groups[0].__setitem__("momentum", v))
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"],
+                            lambda self, v: self.param_groups[0].__setitem__("weight_decay", v))
+
     def _sync_hyper(self):
         vals = [self.lr, self.momentum, self.weight_decay, self.grad_scale, 1.0 if self._steps == 0 else 0.0]
         if self.hyper.is_cuda:
             # asynchronous upload from PINNED staging (a pageable temporary could be recycled by the host before the copy
-            # executes when the host runs ahead of the GPU, e.g. under hipGraph replay); 4 slots rotate
+            # executes when the host runs ahead of the GPU, e.g. under hipGraph replay).  4 slots rotate; a slot is reused
+            # only after the copy that last read it has executed (its event), which also bounds how far the host can run
+            # ahead of the GPU: 4 steps.
             if not hasattr(self, "_stage"):
                 self._stage = [torch.zeros(5, dtype=torch.float32).pin_memory() for _ in range(4)]
+                self._stage_ev = [None] * 4
                 self._slot = 0
-            h = self._stage[self._slot]
-            self._slot = (self._slot + 1) % len(self._stage)
-            for i, v in enumerate(vals):
-                h[i] = v
+            i = self._slot
+            self._slot = (i + 1) % len(self._stage)
+            if self._stage_ev[i] is not None:
+                self._stage_ev[i].synchronize()
+            h = self._stage[i]
+            for j, v in enumerate(vals):
+                h[j] = v
             self.hyper.copy_(h, non_blocking=True)
+            if self._stage_ev[i] is None:
+                self._stage_ev[i] = torch.cuda.Event()
+            self._stage_ev[i].record()
         else:
             self.hyper.copy_(torch.tensor(vals, dtype=torch.float32))
 
@@ -123,10 +150,6 @@ class FusedSGD:
     def prepare(self):
         """Upload lr / momentum / wd / grad_scale / first-step flag for the NEXT step (call before a graph replay)."""
         self._sync_hyper()
-
-    @property
-    def param_groups(self):
-        return [{"lr": self.lr, "momentum": self.momentum, "weight_decay": self.weight_decay}]
 
     def state_dict(self):
         return {"buf": self.buf, "steps": self._steps, "lr": self.lr}

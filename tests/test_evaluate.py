@@ -156,3 +156,28 @@ def test_single_volume_matches_slicewise_procedure(dev, size, patch):
     want = [O.metric_percase(pred == c, label == c) for c in range(1, K)]
     for g, w in zip(got, want):
         assert all(abs(a - b) < 1e-12 for a, b in zip(g, w))
+
+
+@pytest.mark.gpu
+def test_batched_eval_equals_slice_by_slice_on_real_cenet():
+    """CENet is NOT batch-invariant in eval — CCU applies its BatchNorm1d only `if B > 1` (cfam.py:260) and the
+    reference evaluates one slice per forward (metrics_eval.py:46-49).  Under `ops.batch1_semantics()` (what evaluate.py
+    uses) a batch of slices must give the logits of the slice-by-slice procedure; without it, it must not."""
+    from backend import use_hip
+    from cenet_amd import ops
+    from cenet_amd.networks import CENet
+    from oracle import cenet_oracle as O
+    from oracle.golden_cases import MODEL_CONFIGS, config_from_kwargs
+    dev = use_hip()
+    kw = MODEL_CONFIGS["acdc"]["kw"]
+    net = CENet(**kw)
+    net.load_state_dict(O.make_state_dict(config_from_kwargs(kw), seed=42), strict=True)
+    net = net.to(dev).eval()
+    x = torch.randn(3, 1, 224, 224, generator=torch.Generator().manual_seed(8)).to(dev)
+    with torch.no_grad():
+        single = torch.cat([net(x[i:i + 1]) for i in range(3)])
+        with ops.batch1_semantics():
+            batched = net(x)
+        plain = net(x)
+    torch.testing.assert_close(batched, single, rtol=1e-4, atol=1e-4)
+    assert (plain - single).abs().max().item() > 1e-3  # the B > 1 branch really is a different function

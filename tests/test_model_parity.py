@@ -91,6 +91,37 @@ def test_model_train_two_sgd_steps(name):
 
 
 @pytest.mark.gpu
+def test_droppath_injected_masks_parity():
+    """SURVEY §8 a5 with stochastic depth ACTIVE: the reference run with injected keep masks (oracle/gen_golden_droppath.py,
+    default drop_path_rate 0.1) vs the product given the same masks through `backbone.set_drop_path_masks` — the per-sample
+    scale rides in the proj / fc2 GEMM epilogues, its backward in scale_batch + the flat weight-gradient GEMMs."""
+    from cenet_amd import losses
+    from test_oracle_golden import load_drop_masks
+    dev = use_hip()
+    net, cfg, _, x, lab = build("acdc", dev)
+    z = np.load(os.path.join(GOLDEN, "model_acdc_droppath.npz"))
+    net.train()
+    net.backbone.set_drop_path_masks(load_drop_masks(z))
+    crit = losses.Criterion(cfg.num_classes, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
+    lt = net(x)
+    loss = crit(lt, lab)
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 2e-4, (loss.item(), float(z["loss"]))
+    np.testing.assert_allclose(lt.detach().cpu()[:, :, ::9, ::9].numpy(), z["logits_train_sub"], rtol=1e-3, atol=1e-3)
+    params = dict(net.named_parameters())
+    for k in PROBE_KEYS:
+        g = params[k].grad.reshape(-1).cpu()
+        n32, n64, nmine = float(z["g." + k + ".norm"]), float(z["g64." + k + ".norm"]), g.double().norm().item()
+        rel = 2e-2 if g.numel() == 1 else 3e-3
+        assert abs(nmine - n64) <= 6.0 * abs(n32 - n64) + rel * n64 + 1e-7, (k, nmine, n32, n64)
+        g64, g32 = z["g64." + k + ".head"], z["g." + k + ".head"].astype(np.float64)
+        budget = 6.0 * np.abs(g32 - g64).max() + (rel / 3) * np.abs(g64).max() + 1e-9
+        assert np.abs(g[:16].double().numpy() - g64).max() <= budget, k
+    # the injection is one-shot: the next forward samples its own masks again
+    assert getattr(net.backbone, "_dp_injected", None) is None
+
+
+@pytest.mark.gpu
 def test_droppath_training_runs_and_differs():
     """Stochastic depth active (default rates): loss is finite and differs from the deterministic pass."""
     from cenet_amd import losses

@@ -127,3 +127,39 @@ def test_model_golden(name):
                 v.sub_(0.01 * mom[k])
         for k in PROBE_KEYS:
             np.testing.assert_allclose(params[k].detach().reshape(-1)[:16].numpy(), z[pk + k + ".head"], rtol=1e-3, atol=2e-5)
+
+
+def load_drop_masks(z):
+    """{(stage, i): (mask_attn[B], mask_mlp[B])} from model_acdc_droppath.npz"""
+    out = {}
+    for k in z.files:
+        if k.startswith("mask."):
+            _, s, i = k.split(".")
+            m = torch.from_numpy(z[k])
+            out[(int(s), int(i))] = (m[0], m[1])
+    return out
+
+
+@pytest.mark.slow
+def test_model_droppath_golden():
+    """stochastic depth with INJECTED keep masks (pvtv2.py:145-149; timm DropPath semantics): the oracle's drop_masks path
+    against the reference run with the same masks (oracle/gen_golden_droppath.py)."""
+    mc = MODEL_CONFIGS["acdc"]
+    kw = mc["kw"]
+    cfg = config_from_kwargs(kw)
+    K = kw["num_classes"]
+    z = np.load(os.path.join(GOLDEN, "model_acdc_droppath.npz"))
+    sd = O.make_state_dict(cfg, seed=int(z["fill_seed"]))
+    x, lab = O.synthetic_batch(mc["batch"], kw["input_channels"], K, seed=int(z["x_seed"]))
+    params = {k: v for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+    for v in params.values():
+        v.requires_grad_(True)
+    lt = O.cenet_forward(sd, x, cfg, training=True, drop_masks=load_drop_masks(z))
+    loss = O.criterion(lt, lab, K)
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) < 2e-4
+    np.testing.assert_allclose(lt.detach()[:, :, ::9, ::9].numpy(), z["logits_train_sub"], rtol=1e-3, atol=1e-3)
+    for k in PROBE_KEYS:
+        g = params[k].grad.reshape(-1)
+        ref_n = float(z["g." + k + ".norm"])
+        assert abs(g.double().norm().item() - ref_n) <= 2e-3 * ref_n + 1e-7, k

@@ -50,3 +50,42 @@ def test_wgrad_overlap_is_transparent(bf16):
     assert abs(l0 - l1) <= 30 * abs(l0 - l2) + 1e-5
     assert (g0 - g1).abs().max().item() <= 30 * base_g + 1e-6 * scale
     assert (p0 - p1).abs().max().item() <= 30 * base_p + 1e-6
+
+
+@pytest.mark.gpu
+def test_wgrad_overlap_with_backlogged_side_stream():
+    """Conv1x1Fn / LinearFn hand the SAME gradient tensor to the weight-gradient stream and back to autograd as
+    the residual gradient.  Where the residual source has a second consumer (MCA's `shortcut`, DSEB's `skip`) autograd adds
+    into it — in place if nobody else holds it — while the side stream may still be reading.  The side stream is stalled
+    here (a long sleep ahead of every weight-gradient kernel), so any such write-before-read changes proj_2 / mixer dW."""
+    from cenet_amd import losses, ops, optim
+    from cenet_amd.networks import CENet
+    dev = use_hip()
+    kw = MODEL_CONFIGS["acdc"]["kw"]
+    crit = losses.Criterion(4, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 1, 224, 224, generator=g).to(dev)
+    lab = torch.randint(0, 4, (2, 224, 224), generator=g).float().to(dev)
+    out = {}
+    try:
+        for tag, overlap in (("off", False), ("off2", False), ("stalled", True)):
+            ops.set_wgrad_overlap(overlap)
+            torch.manual_seed(5)
+            net = CENet(**kw).to(dev).train()
+            net.backbone.reset_drop_path(0.0)
+            arena = optim.ParamArena(net, optim.cenet_segments())
+            opt = optim.FusedSGD(arena, lr=0.05)
+            opt.zero_grad()
+            loss = crit(net(x), lab)
+            if overlap:
+                with ops._wgrad_side():  # creates the stream; then park ~50 ms of sleep on it ahead of the backward
+                    torch.cuda._sleep(int(1e8))
+            loss.backward()
+            ops.wgrad_join()
+            torch.cuda.synchronize()
+            out[tag] = arena.grads.clone()
+    finally:
+        ops.set_wgrad_overlap(False)
+    scale = out["off"].abs().max().item()
+    base = (out["off"] - out["off2"]).abs().max().item()
+    assert (out["off"] - out["stalled"]).abs().max().item() <= 30 * base + 1e-6 * scale
