@@ -65,8 +65,9 @@ def dominant_kernel_probe(dev, B):
     """Times the single heaviest launch of the step in isolation with HIP events on the launch stream:
     gemm_f32_kernel<im2col> computing out.rb.0.conv2 forward (5x5, 32->32 channels @224x224, reference out.py:41-44).
     Algorithmic FLOPs per launch = 2 * B * Cout * Ho*Wo * Cin*k*k."""
-    from cenet_amd import ops
-    x = torch.randn(B, 32, 224, 224, device=dev)
+    from cenet_amd import kern, ops
+    dt = torch.bfloat16 if kern.get_compute_bf16() else torch.float32
+    x = torch.randn(B, 32, 224, 224, device=dev).to(dt)
     w = torch.randn(32, 32, 5, 5, device=dev) * 0.03
     with torch.no_grad():
         for _ in range(2):
@@ -126,7 +127,8 @@ def extra_kernel_probes(dev, B):
     out = []
     N, H, hd = 3136, 4, 16
     E = 2 * H * hd
-    q, k, v = (torch.randn(B, N, E, device=dev, requires_grad=True) for _ in range(3))
+    dt = torch.bfloat16 if kern.get_compute_bf16() else torch.float32
+    q, k, v = (torch.randn(B, N, E, device=dev).to(dt).requires_grad_(True) for _ in range(3))
     U = ops.diff_attention_heads(q, k, v, H)
     g = torch.randn_like(U)
     t_f = _time(lambda: ops.diff_attention_heads(q.detach(), k.detach(), v.detach(), H))
@@ -144,9 +146,9 @@ def extra_kernel_probes(dev, B):
                 "achieved": round(fl_b / (t_fb - t_f) / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(fl_b / (t_fb - t_f) / 1e9 / peak, 4), "avg_launch_ms": round(t_fb - t_f, 3)})
     R, K, Nn = B * 3136, 64, 512
-    x = torch.randn(R, K, device=dev)
-    W = torch.randn(Nn, K, device=dev) * 0.05
-    y = torch.empty(R, Nn, device=dev)
+    x = torch.randn(R, K, device=dev).to(dt)
+    W = (torch.randn(Nn, K, device=dev) * 0.05).to(dt)
+    y = torch.empty(R, Nn, device=dev, dtype=dt)
     t = _time(lambda: kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, R, Nn, K, scr=Nn, scc=1))
     by = (R * K + Nn * K + R * Nn) * 4.0
     out.append({"kernel": "gemm_kernel<128,128,plain> (stage-1 Mlp.fc1 fwd: 100352x64 @ 64x512)", "bound": "hbm",

@@ -413,8 +413,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(AttnArgs a) {
 }
 
 static void fill_args(AttnArgs& a, const cenet_attn_t* p) {
-  a.q = p->q; a.k = p->k; a.v = p->v; a.o = p->o; a.lse = p->lse;
-  a.dout = p->dout; a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.delta = p->delta;
+  a.q = (const float*)p->q; a.k = (const float*)p->k; a.v = (const float*)p->v; a.o = (float*)p->o; a.lse = p->lse;
+  a.dout = (const float*)p->dout; a.dq = (float*)p->dq; a.dk = (float*)p->dk; a.dv = (float*)p->dv; a.delta = p->delta;
   a.qsb = p->qsb; a.qsh = p->qsh; a.qsi = p->qsi; a.qsd = p->qsd;
   a.ksb = p->ksb; a.ksh = p->ksh; a.ksi = p->ksi; a.ksd = p->ksd;
   a.vsb = p->vsb; a.vsh = p->vsh; a.vsi = p->vsi; a.vsd = p->vsd;
@@ -440,16 +440,26 @@ int cenet_flashb_fwd(const cenet_attn_t* p, hipStream_t stream);
 int cenet_flashb_bwd(const cenet_attn_t* p, hipStream_t stream);
 
 extern "C" int cenet_flash_attn_supported(int D, int Dv) { return pick_variant(D, Dv) >= 0; }
+// bf16 tensors (throughput mode): the register-resident kernels of attn_bf16.hip
+extern "C" int cenet_flash_attn_fwd_bf16(const cenet_attn_t* p, hipStream_t stream) {
+  if (!p || !p->q || !p->k || !p->v || !p->o || !p->lse) return CENET_EINVAL;
+  int rc = cenet_flashb_fwd(p, stream);
+  if (rc != CENET_OK) return rc;
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_flash_attn_bwd_bf16(const cenet_attn_t* p, hipStream_t stream) {
+  if (!p || !p->q || !p->k || !p->v || !p->o || !p->lse || !p->dout || !p->dq || !p->dk || !p->dv || !p->delta)
+    return CENET_EINVAL;
+  int rc = cenet_flashb_bwd(p, stream);
+  if (rc != CENET_OK) return rc;
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
 
 extern "C" int cenet_flash_attn_fwd_f32(const cenet_attn_t* p, hipStream_t stream) {
   if (!p || !p->q || !p->k || !p->v || !p->o || !p->lse) return CENET_EINVAL;
   if (p->B <= 0 || p->H <= 0 || p->Nq <= 0 || p->Nk <= 0 || p->D <= 0 || p->Dv <= 0) return CENET_EINVAL;
-  if (cenet_get_compute_bf16()) {  // throughput mode: bf16-operand kernels of attn_bf16.hip
-    int rc = cenet_flashb_fwd(p, stream);
-    if (rc != CENET_OK) return rc;
-    CENET_CHECK_LAUNCH();
-    return CENET_OK;
-  }
   AttnArgs a;
   fill_args(a, p);
   dim3 grid(cdiv(a.Nq, TQ), a.B * a.H);
@@ -468,12 +478,6 @@ extern "C" int cenet_flash_attn_fwd_f32(const cenet_attn_t* p, hipStream_t strea
 extern "C" int cenet_flash_attn_bwd_f32(const cenet_attn_t* p, hipStream_t stream) {
   if (!p || !p->q || !p->k || !p->v || !p->o || !p->lse || !p->dout || !p->dq || !p->dk || !p->dv || !p->delta)
     return CENET_EINVAL;
-  if (cenet_get_compute_bf16()) {
-    int rc = cenet_flashb_bwd(p, stream);
-    if (rc != CENET_OK) return rc;
-    CENET_CHECK_LAUNCH();
-    return CENET_OK;
-  }
   AttnArgs a;
   fill_args(a, p);
   dim3 gq(cdiv(a.Nq, TQ), a.B * a.H), gk(cdiv(a.Nk, TK), a.B * a.H);
@@ -507,46 +511,52 @@ extern "C" int cenet_flash_attn_bwd_f32(const cenet_attn_t* p, hipStream_t strea
 // ------------------------------------------------------------------------------------------------
 // Row softmax over contiguous rows (materialised-attention path for head dims > 128): one wave per row.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
-                                                              int n) {
+// x (scores) and dy (score gradients) are fp32 in every mode; the probabilities y and dx have the operand storage type T
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __restrict__ x, T* __restrict__ y, long rows, int n) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
   const float* xr = x + row * n;
-  float* yr = y + row * n;
+  T* yr = y + row * n;
   float mx = NEG_BIG;
   for (int c = lane; c < n; c += 64) mx = fmaxf(mx, xr[c]);
   mx = wave_max(mx);
   float s = 0.f;
   for (int c = lane; c < n; c += 64) s += fast_exp(xr[c] - mx);
   s = 1.f / wave_sum(s);
-  for (int c = lane; c < n; c += 64) yr[c] = fast_exp(xr[c] - mx) * s;
+  for (int c = lane; c < n; c += 64) stf(yr + c, fast_exp(xr[c] - mx) * s);
 }
 
 // dx = y * (dy - sum(dy*y))
-__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
-                                                              float* __restrict__ dx, long rows, int n) {
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restrict__ y, const float* __restrict__ dy,
+                                                              T* __restrict__ dx, long rows, int n) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
-  const float* yr = y + row * n;
+  const T* yr = y + row * n;
   const float* gr = dy + row * n;
   float s = 0.f;
-  for (int c = lane; c < n; c += 64) s += yr[c] * gr[c];
+  for (int c = lane; c < n; c += 64) s += ldf(yr + c) * gr[c];
   s = wave_sum(s);
-  float* dr = dx + row * n;
-  for (int c = lane; c < n; c += 64) dr[c] = yr[c] * (gr[c] - s);
+  T* dr = dx + row * n;
+  for (int c = lane; c < n; c += 64) stf(dr + c, ldf(yr + c) * (gr[c] - s));
 }
 
-extern "C" int cenet_softmax_rows_fwd_f32(const float* x, float* y, long rows, int n, hipStream_t stream) {
+template <typename T>
+static int softmax_rows_fwd_impl(const float* x, T* y, long rows, int n, hipStream_t stream) {
   if (rows <= 0 || n <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(softmax_rows_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, x, y, rows, n);
+  CENET_LAUNCH((softmax_rows_fwd_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, x, y, rows, n);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long rows, int n, hipStream_t stream) {
+CENET_TWIN(softmax_rows_fwd, (const float* x, T* y, long rows, int n, hipStream_t stream), (x, y, rows, n, stream))
+template <typename T>
+static int softmax_rows_bwd_impl(const T* y, const float* dy, T* dx, long rows, int n, hipStream_t stream) {
   if (rows <= 0 || n <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(softmax_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, y, dy, dx, rows, n);
+  CENET_LAUNCH((softmax_rows_bwd_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, y, dy, dx, rows, n);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(softmax_rows_bwd, (const T* y, const float* dy, T* dx, long rows, int n, hipStream_t stream), (y, dy, dx, rows, n, stream))

@@ -1,7 +1,7 @@
 // attn_bf16.hip — bf16-operand tiled attention (throughput mode), register-resident probabilities.
 //
-// Same contract as attn.hip (generic strides, fp32 HBM tensors, fp32 online softmax / LSE / delta / accumulators); the
-// MFMA operands are rounded to bf16.  Reference sites: pvtv2.py:101-105, nlb.py:117-138, multihead_diffattn.py:96-116.
+// Same contract as attn.hip (generic strides, fp32 online softmax / LSE / delta / accumulators) on bf16 tensors: q, k, v, o,
+// dO, dq (and dk / dv unless `dkv_f32`) are bf16 in HBM.  Reference sites: pvtv2.py:101-105, nlb.py:117-138, multihead_diffattn.py:96-116.
 //
 // Layout idea (v_mfma_f32_16x16x32_bf16: lane (fr = lane&15, fq = lane>>4) supplies A[row fr][k 8fq..8fq+7] and
 // B[k 8fq..8fq+7][col fr], and receives D[row 4fq+r][col fr], r = 0..3):
@@ -27,11 +27,14 @@
 typedef unsigned short bf;
 
 struct AttnArgsB {
-  const float *q, *k, *v;
-  float* o;
+  const bf *q, *k, *v;
+  bf* o;
   float* lse;
-  const float* dout;
-  float *dq, *dk, *dv, *delta;
+  const bf* dout;
+  bf* dq;
+  void *dk, *dv;  // bf16, or fp32 accumulators when dkv_f32 (atomic adds: shared V heads, query-range slices)
+  float* delta;
+  int dkv_f32;
   long qsb, qsh, qsi, qsd, ksb, ksh, ksi, ksd, vsb, vsh, vsi, vsd, osb, osh, osi, osd;
   int B, H, Nq, Nk, D, Dv, v_head_div;
   int q_al, k_al, v_al, o_al;  // every stride a multiple of 4 floats and the base 16-byte aligned
@@ -74,22 +77,24 @@ __device__ __forceinline__ bf16x8 frag_rm(const bf* T, int pitch, int row, int c
   return o;
 }
 // fixed-side fragment straight from HBM: X[row][32c + 8fq .. +7] * mul, zero outside [0,nrows) x [0,cols)
-__device__ __forceinline__ bf16x8 frag_global(const float* x, long s_row, long s_col, int row, int nrows, int c, int fq,
+__device__ __forceinline__ bf16x8 frag_global(const bf* x, long s_row, long s_col, int row, int nrows, int c, int fq,
                                               int cols, float mul, int al) {
   float v[8];
   const int c0 = 32 * c + 8 * fq;
   if (row < nrows && s_col == 1 && al && c0 + 7 < cols) {
-    memcpy(v, x + (long)row * s_row + c0, 32);
+    ld4v(v, x + (long)row * s_row + c0);
+    ld4v(v + 4, x + (long)row * s_row + c0 + 4);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= mul;
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (row < nrows && c0 + e < cols) ? x[(long)row * s_row + (long)(c0 + e) * s_col] * mul : 0.f;
+    for (int e = 0; e < 8; ++e)
+      v[e] = (row < nrows && c0 + e < cols) ? ldf(x + (long)row * s_row + (long)(c0 + e) * s_col) * mul : 0.f;
   }
   return pack8(v);
 }
 
-// Register prefetch of a streamed [64 rows x COLS] fp32 tile and its conversion into LDS as bf16, row-major
+// Register prefetch of a streamed [64 rows x COLS] bf16 tile (as fp32: it may be scaled) and its way into LDS, row-major
 // dst_rm[row][col] and / or transposed dst_tr[col][row].  A thread owns groups of 4 elements along the axis that is
 // contiguous in the LDS copy it must write packed (8-byte stores); the other copy, if wanted, gets 2-byte stores.
 template <int COLS>
@@ -131,20 +136,20 @@ struct StageT {
       }
     }
   }
-  __device__ __forceinline__ void load(const float* src, long s_row, long s_col, int row0, int nrows, int cols) {
+  __device__ __forceinline__ void load(const bf* src, long s_row, long s_col, int row0, int nrows, int cols) {
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       int row, col;
       coords(threadIdx.x + 256 * j, row, col);
       const long dr = own_cols ? 0 : s_row, dc = own_cols ? s_col : 0;
       const int er = own_cols ? 0 : 1, ec = own_cols ? 1 : 0;
-      const float* p = src + (long)(row0 + row) * s_row + (long)col * s_col;
+      const bf* p = src + (long)(row0 + row) * s_row + (long)col * s_col;
       if (vec && row0 + row + 3 * er < nrows && col + 3 * ec < cols) {
-        memcpy(r[j], p, 16);
+        ld4v(r[j], p);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          r[j][e] = (row0 + row + e * er < nrows && col + e * ec < cols) ? p[e * (dr + dc)] : 0.f;
+          r[j][e] = (row0 + row + e * er < nrows && col + e * ec < cols) ? ldf(p + e * (dr + dc)) : 0.f;
       }
     }
   }
@@ -184,20 +189,23 @@ __device__ __forceinline__ float quad_max(float v) {
   return v;
 }
 
-// write 4 consecutive features (f0..f0+3) of one row
-__device__ __forceinline__ void put4(float* base, long s_row, long s_col, int row, int f0, int nf, const float* v, int al,
+// write 4 consecutive features (f0..f0+3) of one row; T = bf (plain stores) or float (fp32 accumulator, optionally atomic)
+template <typename T>
+__device__ __forceinline__ void put4(T* base, long s_row, long s_col, int row, int f0, int nf, const float* v, int al,
                                      bool atomic) {
-  float* p = base + (long)row * s_row + (long)f0 * s_col;
+  T* p = base + (long)row * s_row + (long)f0 * s_col;
   if (atomic) {
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (f0 + e < nf) atomicAdd(p + e * s_col, v[e]);
+      for (int e = 0; e < 4; ++e)
+        if (f0 + e < nf) atomicAdd((float*)p + e * s_col, v[e]);
+    }
   } else if (s_col == 1 && al && f0 + 3 < nf) {
-    memcpy(p, v, 16);
+    st4v(p, v);
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (f0 + e < nf) p[e * s_col] = v[e];
+      if (f0 + e < nf) stf(p + e * s_col, v[e]);
   }
 }
 
@@ -212,9 +220,9 @@ __global__ __launch_bounds__(256, (DV <= 64 ? 2 : 1)) void flashc_fwd_kernel(Att
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, hv = h / a.v_head_div;
   const int q0 = blockIdx.x * (64 * NQT) + wave * (16 * NQT);
-  const float* qb = a.q + (long)b * a.qsb + (long)h * a.qsh;
-  const float* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
-  const float* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
+  const bf* qb = a.q + (long)b * a.qsb + (long)h * a.qsh;
+  const bf* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
+  const bf* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
 
   bf16x8 qf[NQT][NC];
 #pragma unroll
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(256, (DV <= 64 ? 2 : 1)) void flashc_fwd_kernel(Att
     __syncthreads();
     cur ^= 1;
   }
-  float* ob = a.o + (long)b * a.osb + (long)h * a.osh;
+  bf* ob = a.o + (long)b * a.osb + (long)h * a.osh;
 #pragma unroll
   for (int t = 0; t < NQT; ++t) {
     const float lt = quad_sum(l[t]);
@@ -349,11 +357,11 @@ __global__ __launch_bounds__(256, MINB) void flashc_bwd_dq_kernel(AttnArgsB a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, hv = h / a.v_head_div;
   const int q0 = blockIdx.x * (64 * NQT) + wave * (16 * NQT);
-  const float* qb = a.q + (long)b * a.qsb + (long)h * a.qsh;
-  const float* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
-  const float* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
-  const float* ob = a.o + (long)b * a.osb + (long)h * a.osh;
-  const float* gb = a.dout + (long)b * a.osb + (long)h * a.osh;
+  const bf* qb = a.q + (long)b * a.qsb + (long)h * a.qsh;
+  const bf* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
+  const bf* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
+  const bf* ob = a.o + (long)b * a.osb + (long)h * a.osh;
+  const bf* gb = a.dout + (long)b * a.osb + (long)h * a.osh;
 
   bf16x8 qf[NQT][NC], gf[NQT][NCV];
   float lse2[NQT], dl[NQT];
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(256, MINB) void flashc_bwd_dq_kernel(AttnArgsB a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int d = 32 * c + 8 * fq + e;
-          if (d < a.Dv) sacc += gb[(long)i * a.osi + (long)d * a.osd] * ob[(long)i * a.osi + (long)d * a.osd];
+          if (d < a.Dv) sacc += ldf(gb + (long)i * a.osi + (long)d * a.osd) * ldf(ob + (long)i * a.osi + (long)d * a.osd);
         }
     }
     sacc = quad_sum(sacc);
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(256, MINB) void flashc_bwd_dq_kernel(AttnArgsB a) {
     __syncthreads();
     cur ^= 1;
   }
-  float* dqb = a.dq + (long)b * a.qsb + (long)h * a.qsh;
+  bf* dqb = a.dq + (long)b * a.qsb + (long)h * a.qsh;
 #pragma unroll
   for (int t = 0; t < NQT; ++t) {
     const int i = q0 + 16 * t + fr;
@@ -483,10 +491,10 @@ __global__ __launch_bounds__(256, MINB) void flashc_bwd_dkv_kernel(AttnArgsB a) 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, hv = h / a.v_head_div;
   const int k0 = blockIdx.x * (64 * NKT) + wave * (16 * NKT);
-  const float* qb = a.q + (long)b * a.qsb + (long)h * a.qsh;
-  const float* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
-  const float* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
-  const float* gb = a.dout + (long)b * a.osb + (long)h * a.osh;
+  const bf* qb = a.q + (long)b * a.qsb + (long)h * a.qsh;
+  const bf* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
+  const bf* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
+  const bf* gb = a.dout + (long)b * a.osb + (long)h * a.osh;
   const long stat0 = ((long)b * a.H + h) * a.Nq;
 
   bf16x8 kf[NKT][NC], vf[NKT][NCV];
@@ -587,8 +595,7 @@ __global__ __launch_bounds__(256, MINB) void flashc_bwd_dkv_kernel(AttnArgsB a) 
       cur ^= 1;
     }
   }
-  float* dkb = a.dk + (long)b * a.ksb + (long)h * a.ksh;
-  float* dvb = a.dv + (long)b * a.vsb + (long)hv * a.vsh;
+  const long dko = (long)b * a.ksb + (long)h * a.ksh, dvo = (long)b * a.vsb + (long)hv * a.vsh;
   const bool split = a.qsplit > 1;
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
@@ -599,27 +606,31 @@ __global__ __launch_bounds__(256, MINB) void flashc_bwd_dkv_kernel(AttnArgsB a) 
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = dk[t][u][r] * LN2;  // Q was staged scaled by scale*log2e
-        put4(dkb, a.ksi, a.ksd, j, 16 * u + 4 * fq, a.D, v, a.k_al, split);
+        if (a.dkv_f32) put4((float*)a.dk + dko, a.ksi, a.ksd, j, 16 * u + 4 * fq, a.D, v, a.k_al, split);
+        else put4((bf*)a.dk + dko, a.ksi, a.ksd, j, 16 * u + 4 * fq, a.D, v, a.k_al, false);
       }
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = dv[t][u][r];
-        put4(dvb, a.vsi, a.vsd, j, 16 * u + 4 * fq, a.Dv, v, a.v_al, split || a.dv_atomic);
+        if (a.dkv_f32) put4((float*)a.dv + dvo, a.vsi, a.vsd, j, 16 * u + 4 * fq, a.Dv, v, a.v_al, split || a.dv_atomic);
+        else put4((bf*)a.dv + dvo, a.vsi, a.vsd, j, 16 * u + 4 * fq, a.Dv, v, a.v_al, false);
       }
     }
   }
 }
 
+// quads of bf16 (8 bytes)
 static int al4(const void* p, long s0, long s1, long s2, long s3) {
   auto m4 = [](long v) { return v == 1 || (v & 3) == 0; };
-  return (((uintptr_t)p & 15) == 0) && m4(s0) && m4(s1) && m4(s2) && m4(s3);
+  return (((uintptr_t)p & 7) == 0) && m4(s0) && m4(s1) && m4(s2) && m4(s3);
 }
 
 static void fill_b(AttnArgsB& a, const cenet_attn_t* p) {
-  a.q = p->q; a.k = p->k; a.v = p->v; a.o = p->o; a.lse = p->lse;
-  a.dout = p->dout; a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.delta = p->delta;
+  a.q = (const bf*)p->q; a.k = (const bf*)p->k; a.v = (const bf*)p->v; a.o = (bf*)p->o; a.lse = p->lse;
+  a.dout = (const bf*)p->dout; a.dq = (bf*)p->dq; a.dk = p->dk; a.dv = p->dv; a.delta = p->delta;
+  a.dkv_f32 = p->dkv_f32;
   a.qsb = p->qsb; a.qsh = p->qsh; a.qsi = p->qsi; a.qsd = p->qsd;
   a.ksb = p->ksb; a.ksh = p->ksh; a.ksi = p->ksi; a.ksd = p->ksd;
   a.vsb = p->vsb; a.vsh = p->vsh; a.vsi = p->vsi; a.vsd = p->vsd;
@@ -627,10 +638,10 @@ static void fill_b(AttnArgsB& a, const cenet_attn_t* p) {
   a.B = p->B; a.H = p->H; a.Nq = p->Nq; a.Nk = p->Nk; a.D = p->D; a.Dv = p->Dv;
   a.v_head_div = p->v_head_div > 0 ? p->v_head_div : 1;
   // 16-byte accesses: the base of every tensor the problem touches and all its strides
-  a.q_al = al4(p->q, p->qsb, p->qsh, p->qsi, p->qsd) && (!p->dq || ((uintptr_t)p->dq & 15) == 0);
+  a.q_al = al4(p->q, p->qsb, p->qsh, p->qsi, p->qsd) && (!p->dq || ((uintptr_t)p->dq & 7) == 0);
   a.k_al = al4(p->k, p->ksb, p->ksh, p->ksi, p->ksd) && (!p->dk || ((uintptr_t)p->dk & 15) == 0);
   a.v_al = al4(p->v, p->vsb, p->vsh, p->vsi, p->vsd) && (!p->dv || ((uintptr_t)p->dv & 15) == 0);
-  a.o_al = al4(p->o, p->osb, p->osh, p->osi, p->osd) && (!p->dout || ((uintptr_t)p->dout & 15) == 0);
+  a.o_al = al4(p->o, p->osb, p->osh, p->osi, p->osd) && (!p->dout || ((uintptr_t)p->dout & 7) == 0);
   a.dv_atomic = (a.v_head_div > 1);
   a.qsplit = 1;
   a.tiles_per_split = cdiv(a.Nq, 64);
@@ -677,7 +688,8 @@ int cenet_flashb_bwd(const cenet_attn_t* p, hipStream_t stream) {
   // few key tiles under many queries (spatial-reduction attention: 49 keys): slice the query range over workgroups and
   // accumulate dK / dV atomically — only when the caller guarantees zero-filled dk / dv
   const int ktiles = cdiv(a.Nk, wide_k ? 128 : 64), qtiles = cdiv(a.Nq, 64);
-  if (p->dkv_zeroed && (long)ktiles * a.B * a.H < 512 && qtiles > 1) {
+  if (a.dv_atomic && !a.dkv_f32) return CENET_EINVAL;  // shared V heads add atomically: dk / dv must be fp32 accumulators
+  if (p->dkv_zeroed && a.dkv_f32 && (long)ktiles * a.B * a.H < 512 && qtiles > 1) {
     int s = cdiv(1024, (long)ktiles * a.B * a.H);
     if (s > qtiles) s = qtiles;
     a.tiles_per_split = cdiv(qtiles, s);

@@ -65,6 +65,117 @@ __device__ __forceinline__ unsigned cenet_pack_bf2(float lo, float hi) {
 __device__ __forceinline__ unsigned cenet_f2bf(float f) { return cenet_pack_bf2(f, 0.f); }
 #endif
 
+// ---- storage-type-generic element access ----------------------------------------------------------------------------
+// Activation tensors are fp32 (parity mode) or bf16 (throughput mode: `_bf16` entry points); kernels are templates over the
+// storage type T and do all arithmetic in fp32.  A "quad" = 4 consecutive elements = one 16-byte (fp32) or 8-byte (bf16)
+// access; an "oct" = 8 consecutive bf16 = 16 bytes.
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float cenet_bf2f(unsigned h) {
+  unsigned u = h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return cenet_bf2f(*p); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)cenet_f2bf(v); }
+struct f4 {
+  float v[4];
+};
+__device__ __forceinline__ f4 ld4(const float* p) {
+  f4 r;
+  memcpy(r.v, p, 16);
+  return r;
+}
+__device__ __forceinline__ f4 ld4(const bf16_t* p) {
+  unsigned u[2];
+  memcpy(u, p, 8);
+  f4 r;
+  r.v[0] = cenet_bf2f(u[0] & 0xFFFFu);
+  r.v[1] = cenet_bf2f(u[0] >> 16);
+  r.v[2] = cenet_bf2f(u[1] & 0xFFFFu);
+  r.v[3] = cenet_bf2f(u[1] >> 16);
+  return r;
+}
+__device__ __forceinline__ void st4(float* p, const f4& r) { memcpy(p, r.v, 16); }
+__device__ __forceinline__ void st4(bf16_t* p, const f4& r) {
+  const unsigned u[2] = {cenet_pack_bf2(r.v[0], r.v[1]), cenet_pack_bf2(r.v[2], r.v[3])};
+  memcpy(p, u, 8);
+}
+// raw-array forms (float v[4]) used by kernels that keep plain arrays
+__device__ __forceinline__ void ld4v(float* v, const float* p) { memcpy(v, p, 16); }
+__device__ __forceinline__ void ld4v(float* v, const bf16_t* p) {
+  const f4 r = ld4(p);
+  v[0] = r.v[0], v[1] = r.v[1], v[2] = r.v[2], v[3] = r.v[3];
+}
+__device__ __forceinline__ void st4v(float* p, const float* v) { memcpy(p, v, 16); }
+__device__ __forceinline__ void st4v(bf16_t* p, const float* v) {
+  const unsigned u[2] = {cenet_pack_bf2(v[0], v[1]), cenet_pack_bf2(v[2], v[3])};
+  memcpy(p, u, 8);
+}
+// V consecutive elements (V = 1, 4 or 8) -> fp32 registers and back
+template <int V>
+__device__ __forceinline__ void ldv(float* v, const float* p) {
+  if (V == 1) v[0] = *p;
+  else memcpy(v, p, 4 * V);
+}
+template <int V>
+__device__ __forceinline__ void ldv(float* v, const bf16_t* p) {
+  if (V == 1) {
+    v[0] = cenet_bf2f(*p);
+  } else {
+    unsigned u[V / 2 > 0 ? V / 2 : 1];
+    memcpy(u, p, 2 * V);
+#pragma unroll
+    for (int e = 0; e < V / 2; ++e) {
+      v[2 * e] = cenet_bf2f(u[e] & 0xFFFFu);
+      v[2 * e + 1] = cenet_bf2f(u[e] >> 16);
+    }
+  }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const float* v) {
+  if (V == 1) *p = v[0];
+  else memcpy(p, v, 4 * V);
+}
+template <int V>
+__device__ __forceinline__ void stv(bf16_t* p, const float* v) {
+  if (V == 1) {
+    *p = (bf16_t)cenet_f2bf(v[0]);
+  } else {
+    unsigned u[V / 2 > 0 ? V / 2 : 1];
+#pragma unroll
+    for (int e = 0; e < V / 2; ++e) u[e] = cenet_pack_bf2(v[2 * e], v[2 * e + 1]);
+    memcpy(p, u, 2 * V);
+  }
+}
+// host side: widest vector (8, 4 or 1 elements) that n elements behind these pointers allow; a null pointer allows anything
+template <typename T>
+static inline int vec_width(long n, const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr,
+                            const void* e = nullptr, const void* f = nullptr) {
+  const uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f;
+  if ((n & 7) == 0 && (m & (8 * sizeof(T) - 1)) == 0 && sizeof(T) == 2) return 8;
+  if ((n & 3) == 0 && (m & (4 * sizeof(T) - 1)) == 0) return 4;
+  return 1;
+}
+// host side: a quad access at p is legal
+template <typename T>
+static inline bool quad_aligned(const void* p) {
+  return (((uintptr_t)p) & (4 * sizeof(T) - 1)) == 0;
+}
+// One template implementation -> the two C-ABI entry points `cenet_<name>_f32` and `cenet_<name>_bf16`: PARAMS is the
+// parameter list written with the storage type `T`, ARGS the forwarded argument list.
+#define CENET_TWIN(NAME, PARAMS, ARGS)                                                    \
+  namespace twin_f32 {                                                                    \
+  typedef float T;                                                                        \
+  extern "C" int cenet_##NAME##_f32 PARAMS { return NAME##_impl<T> ARGS; }                \
+  }                                                                                       \
+  namespace twin_bf16 {                                                                   \
+  typedef bf16_t T;                                                                       \
+  extern "C" int cenet_##NAME##_bf16 PARAMS { return NAME##_impl<T> ARGS; }               \
+  }
+
 #define CENET_CHECK_LAUNCH()                         \
   do {                                               \
     hipError_t e__ = hipGetLastError();              \

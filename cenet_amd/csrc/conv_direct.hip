@@ -13,20 +13,22 @@
 //   * the next tile's halo is prefetched into registers while the current tile runs its KK*(CIN/32) k-steps of
 //     v_mfma_f32_16x16x32_bf16 (pixels on the MFMA row so a lane owns 4 consecutive x -> 16-byte stores);
 //   * the data-gradient is the same kernel reading the weights transposed and flipped.
-// fp32 in HBM, fp32 accumulate; only the MFMA operands are bf16 (same contract as the bf16 GEMM core).
+// Throughput mode only: activations (x, y, dY) are bf16 in HBM and go to LDS without conversion; weights are read from their
+// fp32 master copy (a few KB per launch) and rounded once per workgroup; fp32 accumulate.  fp32 tensors (parity mode) take
+// the exact implicit-GEMM path of gemm_core.h instead.
 #include "common.h"
 #include "../../include/cenet_hip.h"
 
 #define TH 8
 #define TW 32
-typedef unsigned short bf;
+typedef bf16_t bf;
 
 __device__ __forceinline__ unsigned cd_f2bf(float f) { return cenet_f2bf(f); }
 
 struct ConvDirectArgs {
-  const float* x;   // [B, CIN, H, W]
+  const bf16_t* x;  // [B, CIN, H, W]
   const float* w;   // fwd: [COUT, CIN, KS, KS] ; dgrad: [CIN(kernel in = conv out), COUT(kernel out = conv in), KS, KS]
-  float* y;         // [B, COUT, H, W]
+  bf16_t* y;        // [B, COUT, H, W]
   int B, H, W, dgrad, tiles_x, tiles_y, ntiles;
 };
 
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
   }
 
   const int HWp = a.H * a.W;
-  float pre[UPT][8];
+  unsigned pre[UPT][8];  // raw bf16 bit patterns of the 8 channels of one halo pixel
   // a thread's halo slots are the same in every tile: their (channel octet, row, column) split and element offset are
   // computed once; a tile only adds its origin
   int uhy[UPT], uhx[UPT];
@@ -74,14 +76,14 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
   auto load_halo = [&](int tile) {
     const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
     const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
-    const float* xt = a.x + (long)b * CIN * HWp + (long)(ty * TH) * a.W + tx * TW;
+    const bf16_t* xt = a.x + (long)b * CIN * HWp + (long)(ty * TH) * a.W + tx * TW;
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
       const int iy = ty * TH + uhy[u], ix = tx * TW + uhx[u];
       const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float* p = xt + uoff[u];
+      const bf16_t* p = xt + uoff[u];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pre[u][j] = ok ? p[(long)j * HWp] : 0.f;
+      for (int j = 0; j < 8; ++j) pre[u][j] = ok ? (unsigned)p[(long)j * HWp] : 0u;
     }
   };
   auto store_halo = [&]() {
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
       if (s < UNITS) {
         unsigned pk[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk[j] = cenet_pack_bf2(pre[u][2 * j], pre[u][2 * j + 1]);
+        for (int j = 0; j < 4; ++j) pk[j] = pre[u][2 * j] | (pre[u][2 * j + 1] << 16);
         memcpy(&Xs[s * 8], pk, 16);
       }
     }
@@ -144,21 +146,21 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
     // epilogue: acc[mi][ni][r] = out[co = 16 mi + fr][y = ty*TH + row][x = tx*TW + xs + 4 fq + r]
     const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
     const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
-    float* yb = a.y + (long)b * COUT * HWp;
+    bf16_t* yb = a.y + (long)b * COUT * HWp;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int oy = ty * TH + 2 * wave + (ni >> 1), ox = tx * TW + 16 * (ni & 1) + 4 * fq;
       if (oy < a.H && ox < a.W) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
-          float* dst = yb + (long)(mi * 16 + fr) * HWp + (long)oy * a.W + ox;
+          bf16_t* dst = yb + (long)(mi * 16 + fr) * HWp + (long)oy * a.W + ox;
           if (ox + 3 < a.W && (a.W & 3) == 0) {
             float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-            memcpy(dst, v, 16);
+            st4v(dst, v);
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (ox + r < a.W) dst[r] = acc[mi][ni][r];
+              if (ox + r < a.W) stf(dst + r, acc[mi][ni][r]);
           }
         }
       }
@@ -176,9 +178,10 @@ extern "C" int cenet_conv_direct_supported(int Cin, int Cout, int k, int stride,
 
 // dgrad = 0: y[B,Cout,H,W] = conv(x[B,Cin,H,W], w[Cout,Cin,k,k]);  dgrad = 1: y = dX[B,Cout,H,W] from x = dY[B,Cin,H,W]
 // and the ORIGINAL forward weight w[Cin,Cout,k,k] (Cin/Cout here name the kernel's input/output channel counts).
-extern "C" int cenet_conv_direct_bf16(const float* x, const float* w, float* y, int B, int Cin, int Cout, int H, int W, int k,
+extern "C" int cenet_conv_direct_bf16(const bf16_t* x, const float* w, bf16_t* y, int B, int Cin, int Cout, int H, int W, int k,
                                       int dgrad, hipStream_t stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+  if (((uintptr_t)y & 7) != 0) return CENET_EINVAL;  // output rows are stored as 8-byte quads
   if (!cenet_conv_direct_supported(Cin, Cout, k, 1, k / 2)) return CENET_EUNSUPPORTED;
   ConvDirectArgs a;
   a.x = x; a.w = w; a.y = y; a.B = B; a.H = H; a.W = W; a.dgrad = dgrad;
@@ -218,9 +221,9 @@ extern "C" int cenet_conv_direct_bf16(const float* x, const float* w, float* y, 
 // coalesced 16-byte stores into a per-workgroup slab and a second kernel folds the slabs into dW.
 // =====================================================================================================================
 struct ConvWgradArgs {
-  const float* x;   // [B, CIN, H, W]
-  const float* dy;  // [B, COUT, H, W]
-  float* ws;        // [gridDim.x][COUT*CIN*KS*KS] partial sums, register order
+  const bf16_t* x;   // [B, CIN, H, W]
+  const bf16_t* dy;  // [B, COUT, H, W]
+  float* ws;         // [gridDim.x][COUT*CIN*KS*KS] partial sums, register order
   int B, H, W, tiles_x, tiles_y, ntiles;
 };
 
@@ -256,27 +259,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
     const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
     const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
     const int y0 = ty * TH_, x0 = tx * 32;
-    const float* xb = a.x + (long)b * CIN * HWp;
-    const float* gb = a.dy + (long)b * COUT * HWp;
+    const bf16_t* xb = a.x + (long)b * CIN * HWp;
+    const bf16_t* gb = a.dy + (long)b * COUT * HWp;
     __syncthreads();  // the previous tile's fragments are consumed
     // ---- X halo: dwords 3..20 of every (ci, halo row) = pixels x0-2 .. x0+33 ; 8 pairs in flight per thread
     constexpr int NXU = CIN * HH * 18;
     for (int u0 = tid; u0 < NXU; u0 += 256 * 8) {
-      float v[8][2];
+      unsigned v[8];  // packed pixel pairs, raw bf16
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int u = u0 + 256 * q;
-        v[q][0] = v[q][1] = 0.f;
+        v[q] = 0u;
         if (u < NXU) {
           const int d = u % 18, r2 = u / 18, hy = r2 % HH, ci = r2 / HH;
           const int iy = y0 - P + hy, ix = x0 - 2 + 2 * d;
           if (iy >= 0 && iy < a.H) {
-            const float* p = xb + (long)ci * HWp + (long)iy * a.W + ix;
+            const bf16_t* p = xb + (long)ci * HWp + (long)iy * a.W + ix;
             if (w_even && ix >= 0 && ix + 1 < a.W) {
-              memcpy(v[q], p, 8);
+              memcpy(&v[q], p, 4);
             } else {
-              if (ix >= 0 && ix < a.W) v[q][0] = p[0];
-              if (ix + 1 >= 0 && ix + 1 < a.W) v[q][1] = p[1];
+              if (ix >= 0 && ix < a.W) v[q] = p[0];
+              if (ix + 1 >= 0 && ix + 1 < a.W) v[q] |= (unsigned)p[1] << 16;
             }
           }
         }
@@ -286,28 +289,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
         const int u = u0 + 256 * q;
         if (u < NXU) {
           const int d = u % 18, r2 = u / 18, hy = r2 % HH, ci = r2 / HH;
-          Xs[ci * XPL + hy * XROW + 3 + d] = cenet_pack_bf2(v[q][0], v[q][1]);
+          Xs[ci * XPL + hy * XROW + 3 + d] = v[q];
         }
       }
     }
     // ---- dY tile
     constexpr int NGU = COUT * TH_ * 16;
     for (int u0 = tid; u0 < NGU; u0 += 256 * 8) {
-      float v[8][2];
+      unsigned v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int u = u0 + 256 * q;
-        v[q][0] = v[q][1] = 0.f;
+        v[q] = 0u;
         if (u < NGU) {
           const int d = u & 15, r2 = u >> 4, yy = r2 % TH_, co = r2 / TH_;
           const int iy = y0 + yy, ix = x0 + 2 * d;
           if (iy < a.H) {
-            const float* p = gb + (long)co * HWp + (long)iy * a.W + ix;
+            const bf16_t* p = gb + (long)co * HWp + (long)iy * a.W + ix;
             if (w_even && ix + 1 < a.W) {
-              memcpy(v[q], p, 8);
+              memcpy(&v[q], p, 4);
             } else {
-              if (ix < a.W) v[q][0] = p[0];
-              if (ix + 1 < a.W) v[q][1] = p[1];
+              if (ix < a.W) v[q] = p[0];
+              if (ix + 1 < a.W) v[q] |= (unsigned)p[1] << 16;
             }
           }
         }
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
         const int u = u0 + 256 * q;
         if (u < NGU) {
           const int d = u & 15, r2 = u >> 4, yy = r2 % TH_, co = r2 / TH_;
-          Gs[co * GPL + yy * 16 + d] = cenet_pack_bf2(v[q][0], v[q][1]);
+          Gs[co * GPL + yy * 16 + d] = v[q];
         }
       }
     }
@@ -385,9 +388,10 @@ extern "C" int cenet_conv_wgrad_direct_supported(int Cin, int Cout, int k, int s
 extern "C" long cenet_conv_wgrad_direct_ws_floats(int Cin, int Cout, int k) {
   return cenet_conv_wgrad_direct_supported(Cin, Cout, k, 1, k / 2) ? (long)CENET_WGRAD_SLABS * Cin * Cout * k * k : 0;
 }
-extern "C" int cenet_conv_wgrad_direct_bf16(const float* x, const float* dy, float* dw_acc, float* ws, int B, int Cin, int Cout,
+extern "C" int cenet_conv_wgrad_direct_bf16(const bf16_t* x, const bf16_t* dy, float* dw_acc, float* ws, int B, int Cin, int Cout,
                                             int H, int W, int k, hipStream_t stream) {
   if (!x || !dy || !dw_acc || !ws || B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+  if ((((uintptr_t)x | (uintptr_t)dy) & 3) != 0) return CENET_EINVAL;  // pixel pairs are fetched as 4-byte words
   if (!cenet_conv_wgrad_direct_supported(Cin, Cout, k, 1, k / 2)) return CENET_EUNSUPPORTED;
   ConvWgradArgs a;
   a.x = x; a.dy = dy; a.ws = ws; a.B = B; a.H = H; a.W = W;

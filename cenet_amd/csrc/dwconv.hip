@@ -4,13 +4,15 @@
 //                               blocks.py:142-150,173; EUCB depthwise blocks.py:305
 // HBM-bound: one thread per output element; NCHW threads run along x (coalesced rows, neighbours from L1/L2),
 // token-layout threads run along C.  The data-gradient is the same kernel with the 3x3 taps flipped.
+// Templates over the activation storage type T (float / bf16_t, common.h); weights, bias and their gradients are fp32.
 #include "common.h"
 #include "../../include/cenet_hip.h"
 
 // grid (B*C, chunks). y_pre = conv(x)+bias ; if a != nullptr: a = act(y_pre)
-__global__ __launch_bounds__(256) void dw3x3_nchw_kernel(const float* __restrict__ x, long sxb, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ y, long syb,
-                                                        float* __restrict__ a, long sab, int C, int H, int W, int dil,
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_nchw_kernel(const T* __restrict__ x, long sxb, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, T* __restrict__ y, long syb,
+                                                        T* __restrict__ a, long sab, int C, int H, int W, int dil,
                                                         int flip, int act, float slope) {
   const int bc = blockIdx.x;
   const int b = bc / C, c = bc - b * C;
@@ -19,7 +21,7 @@ __global__ __launch_bounds__(256) void dw3x3_nchw_kernel(const float* __restrict
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
   const float bv = bias ? bias[c] : 0.f;
-  const float* xp = x + (long)b * sxb + (long)c * HW;
+  const T* xp = x + (long)b * sxb + (long)c * HW;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) {
     const int py = p / W, px = p - py * W;
     float acc = bv;
@@ -31,11 +33,11 @@ __global__ __launch_bounds__(256) void dw3x3_nchw_kernel(const float* __restrict
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = px + (kx - 1) * dil;
         if (ix < 0 || ix >= W) continue;
-        acc += wt[ky * 3 + kx] * xp[iy * W + ix];
+        acc += wt[ky * 3 + kx] * ldf(xp + iy * W + ix);
       }
     }
-    y[(long)b * syb + (long)c * HW + p] = acc;
-    if (a) a[(long)b * sab + (long)c * HW + p] = act_fwd(act, acc, slope);
+    if (y) stf(y + (long)b * syb + (long)c * HW + p, acc);
+    if (a) stf(a + (long)b * sab + (long)c * HW + p, act_fwd(act, acc, slope));
   }
 }
 
@@ -45,30 +47,39 @@ __global__ __launch_bounds__(256) void dw3x3_nchw_kernel(const float* __restrict
 #define DW_SW 8
 // DW_SR output rows per thread: (DW_SR + 2) input rows x (DW_SW + 2) columns feed DW_SR x DW_SW outputs — 1.9 loads per output
 // at DW_SR = 4 (4.1 TB/s at 56x56x512), 2.5 at DW_SR = 2 (more workgroups for the small maps), 3.75 for single rows
-template <int DW_SR>
-__global__ __launch_bounds__(256) void dw3x3_tok_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                       float* __restrict__ a, int C, int H, int W, int flip, int act,
+// CPT channels per thread (1 for fp32; 2 for bf16, so that a lane still moves 4 bytes per access)
+template <typename T, int DW_SR, int CPT>
+__global__ __launch_bounds__(256) void dw3x3_tok_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, T* __restrict__ y,
+                                                       T* __restrict__ a, int C, int H, int W, int flip, int act,
                                                        float slope) {
   const cenet_bid bid = cenet_xcd_block();  // row-neighbour strips share their halo rows through one L2
-  const int c = bid.x * 256 + threadIdx.x;
+  const int c = (bid.x * 256 + threadIdx.x) * CPT;
   if (c >= C) return;
   const int strips_per_row = (W + DW_SW - 1) / DW_SW;
   const int py = (bid.y / strips_per_row) * DW_SR;
   const int px0 = (bid.y % strips_per_row) * DW_SW;
   const long img = (long)bid.z * H * W * C;
-  const float* xb = x + img + c;
-  float wt[9];
+  const T* xb = x + img + c;
+  float wt[CPT][9], bv[CPT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
-  const float bv = bias ? bias[c] : 0.f;
+  for (int e = 0; e < CPT; ++e) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[e][t] = w[(c + e) * 9 + (flip ? 8 - t : t)];
+    bv[e] = bias ? bias[c + e] : 0.f;
+  }
   // col[slot][r]: input rows py-1 .. py+DW_SR of one column; three columns slide along the strip
-  float col[3][DW_SR + 2];
-  auto load_col = [&](int ix, float* dst) __attribute__((always_inline)) {
+  float col[3][DW_SR + 2][CPT];
+  auto load_col = [&](int ix, float (*dst)[CPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < DW_SR + 2; ++r) {
       const int iy = py + r - 1;
-      dst[r] = (ix >= 0 && ix < W && iy >= 0 && iy < H) ? xb[((long)iy * W + ix) * C] : 0.f;
+      if (ix >= 0 && ix < W && iy >= 0 && iy < H) {
+        ldv<CPT>(dst[r], xb + ((long)iy * W + ix) * C);
+      } else {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) dst[r][e] = 0.f;
+      }
     }
   };
   load_col(px0 - 1, col[0]);
@@ -78,26 +89,33 @@ __global__ __launch_bounds__(256) void dw3x3_tok_kernel(const float* __restrict_
     const int px = px0 + i;
     load_col(px + 1, col[(i + 2) % 3]);
     if (px < W) {
-      const float* c0 = col[i % 3];
-      const float* c1 = col[(i + 1) % 3];
-      const float* c2 = col[(i + 2) % 3];
+      const float(*c0)[CPT] = col[i % 3];
+      const float(*c1)[CPT] = col[(i + 1) % 3];
+      const float(*c2)[CPT] = col[(i + 2) % 3];
 #pragma unroll
       for (int r = 0; r < DW_SR; ++r)
         if (py + r < H) {
-          float acc = bv;
+          float acc[CPT], av[CPT];
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky) acc += wt[ky * 3] * c0[r + ky] + wt[ky * 3 + 1] * c1[r + ky] + wt[ky * 3 + 2] * c2[r + ky];
-          const long e = img + ((long)(py + r) * W + px) * C + c;
-          y[e] = acc;
-          if (a) a[e] = act_fwd(act, acc, slope);
+          for (int e = 0; e < CPT; ++e) {
+            acc[e] = bv[e];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+              acc[e] += wt[e][ky * 3] * c0[r + ky][e] + wt[e][ky * 3 + 1] * c1[r + ky][e] + wt[e][ky * 3 + 2] * c2[r + ky][e];
+            av[e] = act_fwd(act, acc[e], slope);
+          }
+          const long o = img + ((long)(py + r) * W + px) * C + c;
+          if (y) stv<CPT>(y + o, acc);
+          if (a) stv<CPT>(a + o, av);
         }
     }
   }
 }
 
 // weight/bias gradient, NCHW: grid (C, splits); dw[c,t] += sum_{b,p} dy[b,c,p] * x[b,c,p+off_t]; db[c] += sum dy
-__global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_kernel(const float* __restrict__ x, long sxb,
-                                                              const float* __restrict__ dy, long sgb,
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_kernel(const T* __restrict__ x, long sxb,
+                                                              const T* __restrict__ dy, long sgb,
                                                               float* __restrict__ dw, float* __restrict__ db, int B, int C,
                                                               int H, int W, int dil) {
   __shared__ float red[16];
@@ -112,8 +130,8 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_kernel(const float* __re
            pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
        p < pend__; p += 256) {
     const int py = p / W, px = p - py * W;
-    const float g = dy[(long)b * sgb + (long)c * HW + p];
-    const float* xp = x + (long)b * sxb + (long)c * HW;
+    const float g = ldf(dy + (long)b * sgb + (long)c * HW + p);
+    const T* xp = x + (long)b * sxb + (long)c * HW;
     acc[9] += g;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -123,7 +141,7 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_kernel(const float* __re
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = px + (kx - 1) * dil;
         if (ix < 0 || ix >= W) continue;
-        acc[ky * 3 + kx] += g * xp[iy * W + ix];
+        acc[ky * 3 + kx] += g * ldf(xp + iy * W + ix);
       }
     }
   }
@@ -141,14 +159,15 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_kernel(const float* __re
 // The 3x3 input window slides along each row (3 new loads + 1 gradient load per pixel); ten float atomics per thread
 // at the end.
 #define DW_WROWS 4
-__global__ __launch_bounds__(256) void dw3x3_wgrad_tok_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_tok_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                              float* __restrict__ dw, float* __restrict__ db, int C, int H,
                                                              int W) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const long img = (long)blockIdx.z * H * W * C;
-  const float* xb = x + img + c;
-  const float* gb = dy + img + c;
+  const T* xb = x + img + c;
+  const T* gb = dy + img + c;
   float acc[10];
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t] = 0.f;
@@ -159,15 +178,15 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_tok_kernel(const float* __res
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = py + ky - 1;
       c0[ky] = 0.f;
-      c1[ky] = (iy >= 0 && iy < H) ? xb[((long)iy * W) * C] : 0.f;
+      c1[ky] = (iy >= 0 && iy < H) ? ldf(xb + ((long)iy * W) * C) : 0.f;
     }
     for (int px = 0; px < W; ++px) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int iy = py + ky - 1;
-        c2[ky] = (px + 1 < W && iy >= 0 && iy < H) ? xb[((long)iy * W + px + 1) * C] : 0.f;
+        c2[ky] = (px + 1 < W && iy >= 0 && iy < H) ? ldf(xb + ((long)iy * W + px + 1) * C) : 0.f;
       }
-      const float g = gb[((long)py * W + px) * C];
+      const float g = ldf(gb + ((long)py * W + px) * C);
       acc[9] += g;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
@@ -188,16 +207,18 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_tok_kernel(const float* __res
 struct q4 {
   float v[4];
 };
-__device__ __forceinline__ q4 ldq(const float* p) {
+template <typename T>
+__device__ __forceinline__ q4 ldq(const T* p) {
   q4 r;
-  memcpy(r.v, p, 16);
+  ld4v(r.v, p);
   return r;
 }
 __device__ __forceinline__ q4 zq() { return q4{{0.f, 0.f, 0.f, 0.f}}; }
 
 // weight / bias gradient: workgroup = 4 waves = 4 image rows x (64 channel quads); each wave slides the 3x3 window along
 // its row (many rows in flight per CU), the four waves meet in LDS and one set of atomics leaves the workgroup
-__global__ __launch_bounds__(256) void dw3x3_wgrad_tok_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_tok_v4_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                 float* __restrict__ dw, float* __restrict__ db, int C, int H,
                                                                 int W) {
   __shared__ float red[4][10][256];
@@ -212,8 +233,8 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_tok_v4_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[e][t] = 0.f;
   if (c < C && py < H) {
-    const float* xb = x + img + c;
-    const float* gb = dy + img + c;
+    const T* xb = x + img + c;
+    const T* gb = dy + img + c;
     q4 c0[3], c1[3], c2[3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -264,18 +285,20 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_tok_v4_kernel(const float* __
 
 // ---- 16-byte NCHW kernels (W % 4 == 0): a thread owns 4 consecutive pixels of one row --------------------------------
 // x window of tap column kx for the quad at (iy, px..px+3): unaligned 16-byte load inside the row, masked scalars at its ends
-__device__ __forceinline__ q4 ld_row4(const float* row, int ix0, int W) {
+template <typename T>
+__device__ __forceinline__ q4 ld_row4(const T* row, int ix0, int W) {
   if (ix0 >= 0 && ix0 + 3 < W) return ldq(row + ix0);
   q4 r;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r.v[e] = (ix0 + e >= 0 && ix0 + e < W) ? row[ix0 + e] : 0.f;
+  for (int e = 0; e < 4; ++e) r.v[e] = (ix0 + e >= 0 && ix0 + e < W) ? ldf(row + ix0 + e) : 0.f;
   return r;
 }
 
 // grid (B*C, chunks), any block size; y_pre = conv(x)+bias ; if a != nullptr: a = act(y_pre)
-__global__ __launch_bounds__(256) void dw3x3_nchw_v4_kernel(const float* __restrict__ x, long sxb, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ y, long syb,
-                                                           float* __restrict__ a, long sab, int C, int H, int W, int dil,
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_nchw_v4_kernel(const T* __restrict__ x, long sxb, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ y, long syb,
+                                                           T* __restrict__ a, long sab, int C, int H, int W, int dil,
                                                            int flip, int act, float slope) {
   const int bc = blockIdx.x;
   const int b = bc / C, c = bc - b * C;
@@ -284,7 +307,7 @@ __global__ __launch_bounds__(256) void dw3x3_nchw_v4_kernel(const float* __restr
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
   const float bv = bias ? bias[c] : 0.f;
-  const float* xp = x + (long)b * sxb + (long)c * HW;
+  const T* xp = x + (long)b * sxb + (long)c * HW;
   for (int q = blockIdx.y * blockDim.x + threadIdx.x; q < nq; q += gridDim.y * blockDim.x) {
     const int py = q / wq, px = (q - py * wq) * 4;
     q4 acc = q4{{bv, bv, bv, bv}};
@@ -299,18 +322,19 @@ __global__ __launch_bounds__(256) void dw3x3_nchw_v4_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) acc.v[e] += wt[ky * 3 + kx] * v.v[e];
       }
     }
-    memcpy(y + (long)b * syb + (long)c * HW + 4 * q, acc.v, 16);
+    if (y) st4v(y + (long)b * syb + (long)c * HW + 4 * q, acc.v);
     if (a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc.v[e] = act_fwd(act, acc.v[e], slope);
-      memcpy(a + (long)b * sab + (long)c * HW + 4 * q, acc.v, 16);
+      st4v(a + (long)b * sab + (long)c * HW + 4 * q, acc.v);
     }
   }
 }
 
 // grid (C, splits): flat walk over the channel's B*HW/4 quads
-__global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_v4_kernel(const float* __restrict__ x, long sxb,
-                                                                 const float* __restrict__ dy, long sgb,
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_v4_kernel(const T* __restrict__ x, long sxb,
+                                                                 const T* __restrict__ dy, long sgb,
                                                                  float* __restrict__ dw, float* __restrict__ db, int B, int C,
                                                                  int H, int W, int dil) {
   __shared__ float red[4][10];
@@ -323,7 +347,7 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_v4_kernel(const float* _
     const int b = qg / nq, q = qg - b * nq;
     const int py = q / wq, px = (q - py * wq) * 4;
     const q4 g = ldq(dy + (long)b * sgb + (long)c * HW + 4 * q);
-    const float* xp = x + (long)b * sxb + (long)c * HW;
+    const T* xp = x + (long)b * sxb + (long)c * HW;
     acc[9] += (g.v[0] + g.v[1]) + (g.v[2] + g.v[3]);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
@@ -350,8 +374,9 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_v4_kernel(const float* _
   }
 }
 
+template <typename T>
 static inline bool al16p(const void* a, const void* b, const void* c) {
-  return ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0);
+  return ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & (4 * sizeof(T) - 1)) == 0);
 }
 
 static inline int plane_chunks(int HW) {
@@ -359,43 +384,58 @@ static inline int plane_chunks(int HW) {
   return ch > 64 ? 64 : ch;
 }
 
-extern "C" int cenet_dwconv3x3_nchw_f32(const float* x, long sxb, const float* w, const float* bias, float* y, long syb,
-                                        float* a, long sab, int B, int C, int H, int W, int dil, int flip, int act,
-                                        float slope, hipStream_t stream) {
-  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || dil <= 0) return CENET_EINVAL;
-  if ((W & 3) == 0 && ((sxb | syb | sab) & 3) == 0 && al16p(x, y, a)) {
+// y (pre-activation) may be NULL when only the activated output a is wanted
+template <typename T>
+static int dwconv3x3_nchw_impl(const T* x, long sxb, const float* w, const float* bias, T* y, long syb, T* a, long sab, int B,
+                               int C, int H, int W, int dil, int flip, int act, float slope, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || dil <= 0 || (!y && !a)) return CENET_EINVAL;
+  if ((W & 3) == 0 && ((sxb | syb | sab) & 3) == 0 && al16p<T>(x, y, a)) {
     const int nq = H * W / 4;
     const int th = nq <= 64 ? 64 : (nq <= 128 ? 128 : 256);
     int ch = cdiv(nq, th * 2);
     if (ch > 16) ch = 16;
-    CENET_LAUNCH(dw3x3_nchw_v4_kernel, dim3(B * C, ch), dim3(th), stream, x, sxb, w, bias, y, syb, a, sab, C, H, W, dil, flip,
+    CENET_LAUNCH((dw3x3_nchw_v4_kernel<T>), dim3(B * C, ch), dim3(th), stream, x, sxb, w, bias, y, syb, a, sab, C, H, W, dil, flip,
                  act, slope);
   } else {
-    CENET_LAUNCH(dw3x3_nchw_kernel, dim3(B * C, plane_chunks(H * W)), dim3(256), stream, x, sxb, w, bias, y, syb, a, sab, C, H,
-                 W, dil, flip, act, slope);
+    CENET_LAUNCH((dw3x3_nchw_kernel<T>), dim3(B * C, plane_chunks(H * W)), dim3(256), stream, x, sxb, w, bias, y, syb, a, sab, C,
+                 H, W, dil, flip, act, slope);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(dwconv3x3_nchw, (const T* x, long sxb, const float* w, const float* bias, T* y, long syb, T* a, long sab, int B, int C,
+                            int H, int W, int dil, int flip, int act, float slope, hipStream_t stream),
+           (x, sxb, w, bias, y, syb, a, sab, B, C, H, W, dil, flip, act, slope, stream))
 
-extern "C" int cenet_dwconv3x3_tok_f32(const float* x, const float* w, const float* bias, float* y, float* a, int B, int C,
-                                       int H, int W, int flip, int act, float slope, hipStream_t stream) {
-  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+template <typename T>
+static int dwconv3x3_tok_impl(const T* x, const float* w, const float* bias, T* y, T* a, int B, int C, int H, int W, int flip,
+                              int act, float slope, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (!y && !a)) return CENET_EINVAL;
   const int sr = H >= 28 ? 4 : 2;
   const int strips = ((H + sr - 1) / sr) * ((W + DW_SW - 1) / DW_SW);
   if (strips > 65535 || B > 65535) return CENET_EUNSUPPORTED;
-  // (a 16-byte-per-thread variant of this kernel measured slower: 2.6 vs 3.0 TB/s at 56x56x512)
-  if (sr == 4)
-    CENET_LAUNCH((dw3x3_tok_kernel<4>), dim3(cdiv(C, 256), strips, B), dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
-  else
-    CENET_LAUNCH((dw3x3_tok_kernel<2>), dim3(cdiv(C, 256), strips, B), dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
+  // (a 16-byte-per-thread fp32 variant of this kernel measured slower: 2.6 vs 3.0 TB/s at 56x56x512)
+  // bf16: two channels per thread (4-byte accesses) when C is even and the tensors are 4-byte aligned
+  constexpr int CP2 = sizeof(T) == 2 ? 2 : 1;
+  const bool two = CP2 == 2 && (C & 1) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)a) & 3) == 0);
+  if (two) {
+    const dim3 grid(cdiv(C, 512), strips, B);
+    if (sr == 4) CENET_LAUNCH((dw3x3_tok_kernel<T, 4, CP2>), grid, dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
+    else CENET_LAUNCH((dw3x3_tok_kernel<T, 2, CP2>), grid, dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
+  } else {
+    const dim3 grid(cdiv(C, 256), strips, B);
+    if (sr == 4) CENET_LAUNCH((dw3x3_tok_kernel<T, 4, 1>), grid, dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
+    else CENET_LAUNCH((dw3x3_tok_kernel<T, 2, 1>), grid, dim3(256), stream, x, w, bias, y, a, C, H, W, flip, act, slope);
+  }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(dwconv3x3_tok, (const T* x, const float* w, const float* bias, T* y, T* a, int B, int C, int H, int W, int flip,
+                           int act, float slope, hipStream_t stream), (x, w, bias, y, a, B, C, H, W, flip, act, slope, stream))
 
-extern "C" int cenet_dwconv3x3_wgrad_nchw_acc_f32(const float* x, long sxb, const float* dy, long sgb, float* dw_acc,
-                                                  float* dbias_acc, int B, int C, int H, int W, int dil,
-                                                  hipStream_t stream) {
+template <typename T>
+static int dwconv3x3_wgrad_nchw_acc_impl(const T* x, long sxb, const T* dy, long sgb, float* dw_acc, float* dbias_acc, int B,
+                                         int C, int H, int W, int dil, hipStream_t stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
   long total = (long)B * H * W;
   long want = 1024 / C;
@@ -403,31 +443,37 @@ extern "C" int cenet_dwconv3x3_wgrad_nchw_acc_f32(const float* x, long sxb, cons
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
-  if ((W & 3) == 0 && ((sxb | sgb) & 3) == 0 && al16p(x, dy, nullptr)) {
+  if ((W & 3) == 0 && ((sxb | sgb) & 3) == 0 && al16p<T>(x, dy, nullptr)) {
     long w4 = 2048 / C, m4 = (total / 4 + 1023) / 1024;  // ~2048 workgroups, each >= 1024 quads deep
     if (w4 > m4) w4 = m4;
     if (w4 < 1) w4 = 1;
     if (w4 > 256) w4 = 256;
-    CENET_LAUNCH(dw3x3_wgrad_nchw_v4_kernel, dim3(C, (unsigned)w4), dim3(256), stream, x, sxb, dy, sgb, dw_acc, dbias_acc, B,
-                 C, H, W, dil);
+    CENET_LAUNCH((dw3x3_wgrad_nchw_v4_kernel<T>), dim3(C, (unsigned)w4), dim3(256), stream, x, sxb, dy, sgb, dw_acc, dbias_acc,
+                 B, C, H, W, dil);
   } else {
-    CENET_LAUNCH(dw3x3_wgrad_nchw_kernel, dim3(C, (unsigned)want), dim3(256), stream, x, sxb, dy, sgb, dw_acc, dbias_acc, B, C,
-                 H, W, dil);
+    CENET_LAUNCH((dw3x3_wgrad_nchw_kernel<T>), dim3(C, (unsigned)want), dim3(256), stream, x, sxb, dy, sgb, dw_acc, dbias_acc, B,
+                 C, H, W, dil);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(dwconv3x3_wgrad_nchw_acc, (const T* x, long sxb, const T* dy, long sgb, float* dw_acc, float* dbias_acc, int B, int C,
+                                      int H, int W, int dil, hipStream_t stream),
+           (x, sxb, dy, sgb, dw_acc, dbias_acc, B, C, H, W, dil, stream))
 
-extern "C" int cenet_dwconv3x3_wgrad_tok_acc_f32(const float* x, const float* dy, float* dw_acc, float* dbias_acc, int B,
-                                                 int C, int H, int W, hipStream_t stream) {
+template <typename T>
+static int dwconv3x3_wgrad_tok_acc_impl(const T* x, const T* dy, float* dw_acc, float* dbias_acc, int B, int C, int H, int W,
+                                        hipStream_t stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
-  if ((C & 3) == 0 && al16p(x, dy, nullptr)) {
-    CENET_LAUNCH(dw3x3_wgrad_tok_v4_kernel, dim3(cdiv(C, 256), cdiv(H, 4), B), dim3(256), stream, x, dy, dw_acc, dbias_acc, C,
-                 H, W);
+  if ((C & 3) == 0 && al16p<T>(x, dy, nullptr)) {
+    CENET_LAUNCH((dw3x3_wgrad_tok_v4_kernel<T>), dim3(cdiv(C, 256), cdiv(H, 4), B), dim3(256), stream, x, dy, dw_acc, dbias_acc,
+                 C, H, W);
   } else {
-    CENET_LAUNCH(dw3x3_wgrad_tok_kernel, dim3(cdiv(C, 256), cdiv(H, DW_WROWS), B), dim3(256), stream, x, dy, dw_acc,
+    CENET_LAUNCH((dw3x3_wgrad_tok_kernel<T>), dim3(cdiv(C, 256), cdiv(H, DW_WROWS), B), dim3(256), stream, x, dy, dw_acc,
                  dbias_acc, C, H, W);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(dwconv3x3_wgrad_tok_acc, (const T* x, const T* dy, float* dw_acc, float* dbias_acc, int B, int C, int H, int W,
+                                     hipStream_t stream), (x, dy, dw_acc, dbias_acc, B, C, H, W, stream))

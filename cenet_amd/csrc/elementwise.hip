@@ -7,24 +7,35 @@
 //   DSEB combine: (FEA(y)+y) + diff*y         dseb.py:40-50,63-76,156-163
 //   differential-attention combine + RMSNorm  multihead_diffattn.py:112-123, rms_norm.py:15-22
 //   per-channel / per-column gradient reducers (bias, layer-scale, FEA weight gradients)
+// Every kernel is a template over the activation storage type T (float: parity mode, bf16_t: throughput mode) — arithmetic is
+// fp32 either way, parameters / statistics / parameter gradients are always fp32 — and the pointwise ones over a vector
+// width V (8 / 4 / 1 elements per thread and access, picked on the host from the length and the pointer alignment).
 #include "common.h"
 #include "../../include/cenet_hip.h"
 
 #define EW_GRID(total) dim3((unsigned)((((total) + 255) / 256) > 8192 ? 8192 : (((total) + 255) / 256)))
+// launch a pointwise kernel template KERNEL<T, V> over n elements with the widest legal vector width
+#define EW_LAUNCH_V(KERNEL, n, vw, ...)                                                                          \
+  do {                                                                                                           \
+    if ((vw) == 8) CENET_LAUNCH((KERNEL<T, 8>), EW_GRID((n) / 8), dim3(256), stream, __VA_ARGS__, (long)((n) / 8)); \
+    else if ((vw) == 4) CENET_LAUNCH((KERNEL<T, 4>), EW_GRID((n) / 4), dim3(256), stream, __VA_ARGS__, (long)((n) / 4)); \
+    else CENET_LAUNCH((KERNEL<T, 1>), EW_GRID(n), dim3(256), stream, __VA_ARGS__, (long)(n));                    \
+  } while (0)
 
 // ---- batched 2-D transpose: y[b][j][i] = x[b][i][j], x: [R x Cc] per batch -------------------------------------
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, long sxb, float* __restrict__ y, long syb,
-                                                       int R, int Cc) {
-  __shared__ float tile[32][33];
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y, long syb, int R,
+                                                       int Cc) {
+  __shared__ T tile[32][33];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const float* xb = x + (long)b * sxb;
-  float* yb = y + (long)b * syb;
+  const T* xb = x + (long)b * sxb;
+  T* yb = y + (long)b * syb;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int r = r0 + ty + 8 * i, c = c0 + tx;
-    tile[ty + 8 * i][tx] = (r < R && c < Cc) ? xb[(long)r * Cc + c] : 0.f;
+    tile[ty + 8 * i][tx] = (r < R && c < Cc) ? xb[(long)r * Cc + c] : (T)0;
   }
   __syncthreads();
 #pragma unroll
@@ -33,24 +44,64 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     if (r < R && c < Cc) yb[(long)c * R + r] = tile[tx][ty + 8 * i];
   }
 }
+// bf16, both extents multiples of 2: a thread moves 2x2 blocks, so both sides are 4-byte accesses (64 x 64 tiles)
+__global__ __launch_bounds__(256) void transpose_bf16x2_kernel(const bf16_t* __restrict__ x, long sxb, bf16_t* __restrict__ y,
+                                                              long syb, int R, int Cc) {
+  __shared__ unsigned tile[64][33];  // [row][col pair]
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const bf16_t* xb = x + (long)b * sxb;
+  bf16_t* yb = y + (long)b * syb;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + 2 * tx;
+    unsigned v = 0;
+    if (r < R && c < Cc) memcpy(&v, xb + (long)r * Cc + c, 4);
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    // output row c = c0 + (ty + 8 i) * ... : thread writes the pair (r, r+1) of output row c
+    const int cl = ty + 8 * i;            // local column 0..63
+    const int c = c0 + cl, r = r0 + 2 * tx;
+    if (c < Cc && r < R) {
+      const unsigned a = tile[2 * tx][cl >> 1], bq = tile[2 * tx + 1][cl >> 1];
+      const unsigned lo = (cl & 1) ? (a >> 16) : (a & 0xFFFFu), hi = (cl & 1) ? (bq >> 16) : (bq & 0xFFFFu);
+      const unsigned v = lo | (hi << 16);
+      memcpy(yb + (long)c * R + r, &v, 4);
+    }
+  }
+}
 
 // ---- strided batch copy: y[b*syb + i] = x[b*sxb + i], i < n (channel-slice concat / split) ----------------------
-__global__ __launch_bounds__(256) void copy_batched_kernel(const float* __restrict__ x, long sxb, float* __restrict__ y,
-                                                          long syb, long n, int accumulate) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void copy_batched_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y, long syb,
+                                                          int accumulate, long n) {
   const int b = blockIdx.y;
-  const float* xb = x + (long)b * sxb;
-  float* yb = y + (long)b * syb;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    yb[i] = accumulate ? yb[i] + xb[i] : xb[i];
+  const T* xb = x + (long)b * sxb;
+  T* yb = y + (long)b * syb;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v[V];
+    ldv<V>(v, xb + i * V);
+    if (accumulate) {
+      float o[V];
+      ldv<V>(o, yb + i * V);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = o[e] + v[e];
+    }
+    stv<V>(yb + i * V, v);
+  }
 }
 
 // ---- space-to-depth of a token map: the kernel == stride spatial-reduction conv of pvtv2.py:93-95 reads each input
 // pixel exactly once, so gathering the s x s patches into rows turns it into a dense GEMM with both operands k-contiguous.
 // tok [B, Ho*S, Wo*S, C] <-> patch [B*Ho*Wo, C*S*S], k = (c, ky, kx) as in the conv weight [Cout, C, S, S].
-// One thread moves the S*S values of one (patch, channel): token side coalesced over c, patch side S contiguous floats.
-template <int S, bool INV>
-__global__ __launch_bounds__(256) void patch_tok_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int Ho,
-                                                       int Wo, long total) {
+// One thread moves the S*S values of one (patch, channel): token side coalesced over c, patch side S contiguous elements.
+template <typename T, int S, bool INV>
+__global__ __launch_bounds__(256) void patch_tok_kernel(const T* __restrict__ src, T* __restrict__ dst, int C, int Ho, int Wo,
+                                                       long total) {
   const long Wd = (long)Wo * S;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int c = (int)(idx % C);
@@ -63,134 +114,184 @@ __global__ __launch_bounds__(256) void patch_tok_kernel(const float* __restrict_
     const long pbase = (r * C + c) * (S * S);
 #pragma unroll
     for (int ky = 0; ky < S; ++ky) {
-      float v[S];
+      T v[S];
       if (INV) {
-        const float* p = src + pbase + ky * S;
-        if (S == 2) {
-          const float2 q = *reinterpret_cast<const float2*>(p);
-          v[0] = q.x, v[1] = q.y;
-        } else {
-#pragma unroll
-          for (int j = 0; j < S; j += 4) {
-            const float4 q = *reinterpret_cast<const float4*>(p + j);
-            v[j] = q.x, v[j + 1] = q.y, v[j + 2] = q.z, v[j + 3] = q.w;
-          }
-        }
+        memcpy(v, src + pbase + ky * S, S * sizeof(T));  // S * sizeof(T)-byte aligned: pbase is a multiple of S*S
 #pragma unroll
         for (int kx = 0; kx < S; ++kx) dst[tbase + (ky * Wd + kx) * C] = v[kx];
       } else {
 #pragma unroll
         for (int kx = 0; kx < S; ++kx) v[kx] = src[tbase + (ky * Wd + kx) * C];
-        float* p = dst + pbase + ky * S;
-        if (S == 2) {
-          float2 q;
-          q.x = v[0], q.y = v[1];
-          *reinterpret_cast<float2*>(p) = q;
-        } else {
-#pragma unroll
-          for (int j = 0; j < S; j += 4) *reinterpret_cast<float4*>(p + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
-        }
+        memcpy(dst + pbase + ky * S, v, S * sizeof(T));
       }
     }
   }
 }
 
 // ---- y[b, i] = s[b] * x[b, i] ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scale_batch_kernel(const float* __restrict__ x, const float* __restrict__ s,
-                                                         float* __restrict__ y, long n) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void scale_batch_kernel(const T* __restrict__ x, const float* __restrict__ s,
+                                                         T* __restrict__ y, long n) {
   const int b = blockIdx.y;
   const float sv = s[b];
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[b * n + i] = sv * x[b * n + i];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v[V];
+    ldv<V>(v, x + (b * n + i) * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = sv * v[e];
+    stv<V>(y + (b * n + i) * V, v);
+  }
 }
 
 // ---- dx = dy * act'(pre) -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dy,
-                                                     float* __restrict__ dx, long n, int act, float slope) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    dx[i] = dy[i] * act_bwd(act, pre[i], slope);
+template <typename T, int V>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ pre, const T* __restrict__ dy, T* __restrict__ dx,
+                                                     int act, float slope, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float p[V], g[V];
+    ldv<V>(p, pre + i * V);
+    ldv<V>(g, dy + i * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] = g[e] * act_bwd(act, p[e], slope);
+    stv<V>(dx + i * V, g);
+  }
 }
-__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act,
-                                                     float slope) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = act_fwd(act, x[i], slope);
+template <typename T, int V>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int act, float slope, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v[V];
+    ldv<V>(v, x + i * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = act_fwd(act, v[e], slope);
+    stv<V>(y + i * V, v);
+  }
 }
 
 // ---- y = silu(a)*silu(b) -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                          float* __restrict__ y, long n) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    y[i] = act_fwd(ACT_SILU, a[i], 0.f) * act_fwd(ACT_SILU, b[i], 0.f);
-}
-__global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                          const float* __restrict__ dy, float* __restrict__ da,
-                                                          float* __restrict__ db, long n) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
+                                                          long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float g = dy[i], av = a[i], bv = b[i];
-    da[i] = g * act_fwd(ACT_SILU, bv, 0.f) * act_bwd(ACT_SILU, av, 0.f);
-    db[i] = g * act_fwd(ACT_SILU, av, 0.f) * act_bwd(ACT_SILU, bv, 0.f);
+    float av[V], bv[V];
+    ldv<V>(av, a + i * V);
+    ldv<V>(bv, b + i * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) av[e] = act_fwd(ACT_SILU, av[e], 0.f) * act_fwd(ACT_SILU, bv[e], 0.f);
+    stv<V>(y + i * V, av);
+  }
+}
+template <typename T, int V>
+__global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                          const T* __restrict__ dy, T* __restrict__ da, T* __restrict__ db,
+                                                          long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float g[V], av[V], bv[V], oa[V], ob[V];
+    ldv<V>(g, dy + i * V);
+    ldv<V>(av, a + i * V);
+    ldv<V>(bv, b + i * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      oa[e] = g[e] * act_fwd(ACT_SILU, bv[e], 0.f) * act_bwd(ACT_SILU, av[e], 0.f);
+      ob[e] = g[e] * act_fwd(ACT_SILU, av[e], 0.f) * act_bwd(ACT_SILU, bv[e], 0.f);
+    }
+    stv<V>(da + i * V, oa);
+    stv<V>(db + i * V, ob);
   }
 }
 
 // ---- z = (1-w)x + w p ; w is a device scalar ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ x, const float* __restrict__ p,
-                                                     const float* __restrict__ w, float* __restrict__ z, long n) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void mix_fwd_kernel(const T* __restrict__ x, const T* __restrict__ p,
+                                                     const float* __restrict__ w, T* __restrict__ z, long n) {
   const float wv = w[0];
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) z[i] = (1.f - wv) * x[i] + wv * p[i];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float xv[V], pv[V];
+    ldv<V>(xv, x + i * V);
+    ldv<V>(pv, p + i * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) xv[e] = (1.f - wv) * xv[e] + wv * pv[e];
+    stv<V>(z + i * V, xv);
+  }
 }
-__global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ x, const float* __restrict__ p,
-                                                     const float* __restrict__ w, const float* __restrict__ dz,
-                                                     float* __restrict__ dx, float* __restrict__ dp, float* __restrict__ dw,
-                                                     long n) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const T* __restrict__ x, const T* __restrict__ p,
+                                                     const float* __restrict__ w, const T* __restrict__ dz, T* __restrict__ dx,
+                                                     T* __restrict__ dp, float* __restrict__ dw, long n) {
   __shared__ float red[16];
   const float wv = w[0];
   float s = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float g = dz[i];
-    dx[i] = (1.f - wv) * g;
-    dp[i] = wv * g;
-    s += g * (p[i] - x[i]);
+    float g[V], xv[V], pv[V], ox[V], op[V];
+    ldv<V>(g, dz + i * V);
+    ldv<V>(xv, x + i * V);
+    ldv<V>(pv, p + i * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      ox[e] = (1.f - wv) * g[e];
+      op[e] = wv * g[e];
+      s += g[e] * (pv[e] - xv[e]);
+    }
+    stv<V>(dx + i * V, ox);
+    stv<V>(dp + i * V, op);
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) atomicAdd(dw, s);
 }
 
-// ---- out = x + ls[c]*y (NCHW) ; dy = ls[c]*g -----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                                const float* __restrict__ ls, float* __restrict__ out, int C,
-                                                                int HW) {
+// ---- out = x + ls[c]*y (NCHW) ; dy = ls[c]*g ; HWv = plane length in units of V -----------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(256) void scale_residual_fwd_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                                const float* __restrict__ ls, T* __restrict__ out, int C,
+                                                                int HWv) {
   const int bc = blockIdx.x, c = bc % C;
   const float s = ls[c];
-  const long base = (long)bc * HW;
-  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) out[base + p] = x[base + p] + s * y[base + p];
+  const long base = (long)bc * HWv * V;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HWv; p += gridDim.y * 256) {
+    float xv[V], yv[V];
+    ldv<V>(xv, x + base + (long)p * V);
+    ldv<V>(yv, y + base + (long)p * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) xv[e] = xv[e] + s * yv[e];
+    stv<V>(out + base + (long)p * V, xv);
+  }
 }
-__global__ __launch_bounds__(256) void scale_chan_kernel(const float* __restrict__ g, const float* __restrict__ ls,
-                                                        float* __restrict__ out, int C, int HW) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void scale_chan_kernel(const T* __restrict__ g, const float* __restrict__ ls,
+                                                        T* __restrict__ out, int C, int HWv) {
   const int bc = blockIdx.x, c = bc % C;
   const float s = ls[c];
-  const long base = (long)bc * HW;
-  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) out[base + p] = s * g[base + p];
+  const long base = (long)bc * HWv * V;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HWv; p += gridDim.y * 256) {
+    float v[V];
+    ldv<V>(v, g + base + (long)p * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = s * v[e];
+    stv<V>(out + base + (long)p * V, v);
+  }
 }
 
 // ---- out[c] += sum_{b,p} a[b,c,p] * (bb ? bb[b,c,p] : 1)  (grid C x splits) -------------------------------------
-__global__ __launch_bounds__(256) void chan_dot_kernel(const float* __restrict__ a, long sab, const float* __restrict__ bb,
-                                                      long sbb, float* __restrict__ out, int B, int HW) {
+template <typename T>
+__global__ __launch_bounds__(256) void chan_dot_kernel(const T* __restrict__ a, long sab, const T* __restrict__ bb, long sbb,
+                                                      float* __restrict__ out, int B, int HW) {
   __shared__ float red[16];
   const int c = blockIdx.x;
-  const long total = (long)B * HW;
   float s = 0.f;
   for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
   for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
            pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
        p < pend__; p += 256) {
-    const float av = a[(long)b * sab + (long)c * HW + p];
-    s += bb ? av * bb[(long)b * sbb + (long)c * HW + p] : av;
+    const float av = ldf(a + (long)b * sab + (long)c * HW + p);
+    s += bb ? av * ldf(bb + (long)b * sbb + (long)c * HW + p) : av;
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) atomicAdd(&out[c], s);
 }
 
-// 16-byte form (HW % 4 == 0): flat grid-stride walk over the channel's B*HW/4 quads, two independent loads in flight
-__global__ __launch_bounds__(256) void chan_dot_v4_kernel(const float* __restrict__ a, long sab, const float* __restrict__ bb,
-                                                         long sbb, float* __restrict__ out, int B, int HW) {
+// quad form (HW % 4 == 0): flat grid-stride walk over the channel's B*HW/4 quads, two independent loads in flight
+template <typename T>
+__global__ __launch_bounds__(256) void chan_dot_v4_kernel(const T* __restrict__ a, long sab, const T* __restrict__ bb, long sbb,
+                                                         float* __restrict__ out, int B, int HW) {
   __shared__ float red[16];
   const int c = blockIdx.x, nq = HW >> 2, total = B * nq, stride = gridDim.y * 256;
   float s = 0.f;
@@ -206,8 +307,8 @@ __global__ __launch_bounds__(256) void chan_dot_v4_kernel(const float* __restric
       }
       if (q < total) {
         const int b = q / nq, qi = q - b * nq;
-        memcpy(av[u], a + (long)b * sab + (long)c * HW + 4 * qi, 16);
-        if (bb) memcpy(bv[u], bb + (long)b * sbb + (long)c * HW + 4 * qi, 16);
+        ld4v(av[u], a + (long)b * sab + (long)c * HW + 4 * qi);
+        if (bb) ld4v(bv[u], bb + (long)b * sbb + (long)c * HW + 4 * qi);
       }
     }
 #pragma unroll
@@ -222,22 +323,23 @@ __global__ __launch_bounds__(256) void chan_dot_v4_kernel(const float* __restric
 // ---- out[c] += sum_r a[r, c]  (row-major [R, C]) ---------------------------------------------------------------------
 // scalar form: block = 64 columns x 4 row-lanes, grid (col tiles, row chunks)
 #define CS_ROWS 256
-__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ a, float* __restrict__ out, long R, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void col_sum_kernel(const T* __restrict__ a, float* __restrict__ out, long R, int C) {
   __shared__ float part[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const long r0 = (long)blockIdx.y * CS_ROWS;
   float s = 0.f;
   if (c < C)
-    for (long r = r0 + rl; r < r0 + CS_ROWS && r < R; r += 4) s += a[r * C + c];
+    for (long r = r0 + rl; r < r0 + CS_ROWS && r < R; r += 4) s += ldf(a + r * C + c);
   part[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < C) atomicAdd(&out[c], part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]);
 }
-// 16-byte form (C % 4 == 0): a thread owns one column quad, TPR threads cover a row slab of 4*TPR columns and the other
-// 256/TPR thread groups take interleaved rows, 4 independent 16-byte loads in flight each
-template <int TPR>
-__global__ __launch_bounds__(256) void col_sum_v4_kernel(const float* __restrict__ a, float* __restrict__ out, long R, int C,
+// quad form (C % 4 == 0): a thread owns one column quad, TPR threads cover a row slab of 4*TPR columns and the other
+// 256/TPR thread groups take interleaved rows, 4 independent loads in flight each
+template <typename T, int TPR>
+__global__ __launch_bounds__(256) void col_sum_v4_kernel(const T* __restrict__ a, float* __restrict__ out, long R, int C,
                                                         int rows_per_block) {
   constexpr int RL = 256 / TPR;
   __shared__ float part[RL][TPR * 4];
@@ -252,7 +354,7 @@ __global__ __launch_bounds__(256) void col_sum_v4_kernel(const float* __restrict
     for (; r + 3 * RL < r1; r += 4 * RL) {
       float v[4][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) memcpy(v[u], a + (r + u * RL) * C + c, 16);
+      for (int u = 0; u < 4; ++u) ld4v(v[u], a + (r + u * RL) * C + c);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -260,7 +362,7 @@ __global__ __launch_bounds__(256) void col_sum_v4_kernel(const float* __restrict
     }
     for (; r < r1; r += RL) {
       float v[4];
-      memcpy(v, a + r * C + c, 16);
+      ld4v(v, a + r * C + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] += v[e];
     }
@@ -280,102 +382,146 @@ __global__ __launch_bounds__(256) void col_sum_v4_kernel(const float* __restrict
 }
 
 // ---- out = act(a + b) ; backward from the output sign (LeakyReLU/ReLU preserve sign) -------------------------------
-__global__ __launch_bounds__(256) void add_act_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         float* __restrict__ out, long n, int act, float slope) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    out[i] = act_fwd(act, a[i] + b[i], slope);
+template <typename T, int V>
+__global__ __launch_bounds__(256) void add_act_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                         int act, float slope, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float av[V], bv[V];
+    ldv<V>(av, a + i * V);
+    ldv<V>(bv, b + i * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) av[e] = act_fwd(act, av[e] + bv[e], slope);
+    stv<V>(out + i * V, av);
+  }
 }
-__global__ __launch_bounds__(256) void lrelu_bwd_from_out_kernel(const float* __restrict__ out, const float* __restrict__ dy,
-                                                                float* __restrict__ dx, long n, float slope) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    dx[i] = out[i] > 0.f ? dy[i] : dy[i] * slope;
+template <typename T, int V>
+__global__ __launch_bounds__(256) void lrelu_bwd_from_out_kernel(const T* __restrict__ out, const T* __restrict__ dy,
+                                                                T* __restrict__ dx, float slope, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float o[V], g[V];
+    ldv<V>(o, out + i * V);
+    ldv<V>(g, dy + i * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] = o[e] > 0.f ? g[e] : g[e] * slope;
+    stv<V>(dx + i * V, g);
+  }
 }
 
 // ---- DSEB combine ---------------------------------------------------------------------------------------------------
 // z = 2y + w[c]*edge + diff*y,  edge = (1/m) sum_{i<j} | e_i - e_j |,  e_s = | y - r_s |  (r_s == nullptr: scale 1.0 -> e_s = 0)
+template <typename T>
 struct DsebArgs {
-  const float* y;
-  const float* r[3];
+  const T* y;
+  const T* r[3];
   const float* w;
-  const float* diff;
-  float* z;
+  const T* diff;
+  T* z;
   // backward
-  const float* dz;
-  float* dy;
-  float* dr[3];
-  float* ddiff;
+  const T* dz;
+  T* dy;
+  T* dr[3];
+  T* ddiff;
   float* dw;
-  int n, C, HW;
+  int n, C, HW;  // HW in units of V
   float ycoef;
 };
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
-__global__ __launch_bounds__(256) void dseb_combine_fwd_kernel(DsebArgs a) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dseb_combine_fwd_kernel(DsebArgs<T> a) {
   const int bc = blockIdx.x, c = bc % a.C;
   const float wc = a.w[c];
-  const long base = (long)bc * a.HW;
+  const long base = (long)bc * a.HW * V;
   const float inv_m = 1.f / (float)(a.n * (a.n - 1) / 2);
   for (int p = blockIdx.y * 256 + threadIdx.x; p < a.HW; p += gridDim.y * 256) {
-    const float yv = a.y[base + p];
-    float e[3];
+    const long o = base + (long)p * V;
+    float yv[V], rv[3][V], dv[V], zv[V];
+    ldv<V>(yv, a.y + o);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) e[s] = (s < a.n && a.r[s]) ? fabsf(yv - a.r[s][base + p]) : 0.f;
-    float edge = 0.f;
+    for (int s = 0; s < 3; ++s)
+      if (s < a.n && a.r[s]) ldv<V>(rv[s], a.r[s] + o);
+    if (a.diff) ldv<V>(dv, a.diff + o);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < V; ++k) {
+      float e[3];
 #pragma unroll
-      for (int j = i + 1; j < 3; ++j)
-        if (j < a.n) edge += fabsf(e[i] - e[j]);
-    edge *= inv_m;
-    a.z[base + p] = a.ycoef * yv + wc * edge + (a.diff ? a.diff[base + p] * yv : 0.f);
+      for (int s = 0; s < 3; ++s) e[s] = (s < a.n && a.r[s]) ? fabsf(yv[k] - rv[s][k]) : 0.f;
+      float edge = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j)
+          if (j < a.n) edge += fabsf(e[i] - e[j]);
+      edge *= inv_m;
+      zv[k] = a.ycoef * yv[k] + wc * edge + (a.diff ? dv[k] * yv[k] : 0.f);
+    }
+    stv<V>(a.z + o, zv);
   }
 }
-__global__ __launch_bounds__(256) void dseb_combine_bwd_kernel(DsebArgs a) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dseb_combine_bwd_kernel(DsebArgs<T> a) {
   __shared__ float red[16];
   const int bc = blockIdx.x, c = bc % a.C;
   const float wc = a.w[c];
-  const long base = (long)bc * a.HW;
+  const long base = (long)bc * a.HW * V;
   const float inv_m = 1.f / (float)(a.n * (a.n - 1) / 2);
   float dws = 0.f;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < a.HW; p += gridDim.y * 256) {
-    const float yv = a.y[base + p], g = a.dz[base + p], df = a.diff ? a.diff[base + p] : 0.f;
-    float e[3], sy[3];
+    const long o = base + (long)p * V;
+    float yv[V], gv[V], dfv[V], rv[3][V], dyo[V], dro[3][V], ddo[V];
+    ldv<V>(yv, a.y + o);
+    ldv<V>(gv, a.dz + o);
+    if (a.diff) ldv<V>(dfv, a.diff + o);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (s < a.n && a.r[s]) {
-        const float d = yv - a.r[s][base + p];
-        e[s] = fabsf(d);
-        sy[s] = sgn(d);
-      } else {
-        e[s] = 0.f;
-        sy[s] = 0.f;
-      }
-    }
-    float edge = 0.f, de[3] = {0.f, 0.f, 0.f};
+    for (int s = 0; s < 3; ++s)
+      if (s < a.n && a.r[s]) ldv<V>(rv[s], a.r[s] + o);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < V; ++k) {
+      const float g = gv[k], df = a.diff ? dfv[k] : 0.f;
+      float e[3], sy[3];
 #pragma unroll
-      for (int j = i + 1; j < 3; ++j)
-        if (j < a.n) {
-          const float d = e[i] - e[j];
-          edge += fabsf(d);
-          const float sd = sgn(d);
-          de[i] += sd;
-          de[j] -= sd;
+      for (int s = 0; s < 3; ++s) {
+        if (s < a.n && a.r[s]) {
+          const float d = yv[k] - rv[s][k];
+          e[s] = fabsf(d);
+          sy[s] = sgn(d);
+        } else {
+          e[s] = 0.f;
+          sy[s] = 0.f;
         }
-    edge *= inv_m;
-    dws += g * edge;
-    float dyv = a.ycoef * g + g * df;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      if (s < a.n && a.r[s]) {
-        const float t = wc * g * inv_m * de[s] * sy[s];
-        dyv += t;
-        a.dr[s][base + p] = -t;
       }
+      float edge = 0.f, de[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j)
+          if (j < a.n) {
+            const float d = e[i] - e[j];
+            edge += fabsf(d);
+            const float sd = sgn(d);
+            de[i] += sd;
+            de[j] -= sd;
+          }
+      edge *= inv_m;
+      dws += g * edge;
+      float dyv = a.ycoef * g + g * df;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        dro[s][k] = 0.f;
+        if (s < a.n && a.r[s]) {
+          const float t = wc * g * inv_m * de[s] * sy[s];
+          dyv += t;
+          dro[s][k] = -t;
+        }
+      }
+      dyo[k] = dyv;
+      ddo[k] = g * yv[k];
     }
-    a.dy[base + p] = dyv;
-    if (a.ddiff) a.ddiff[base + p] = g * yv;
+    stv<V>(a.dy + o, dyo);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (s < a.n && a.r[s]) stv<V>(a.dr[s] + o, dro[s]);
+    if (a.ddiff) stv<V>(a.ddiff + o, ddo);
   }
   dws = block_sum(dws, red);
   if (threadIdx.x == 0) atomicAdd(&a.dw[c], dws);
@@ -416,8 +562,9 @@ __device__ __forceinline__ float subwave_sum(float v, int sub) {
   for (int o = sub >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-__global__ __launch_bounds__(256) void diffattn_combine_fwd_kernel(const float* __restrict__ U, const float* __restrict__ lam,
-                                                                  float* __restrict__ out, int H, int N, int dv, float eps,
+template <typename T>
+__global__ __launch_bounds__(256) void diffattn_combine_fwd_kernel(const T* __restrict__ U, const float* __restrict__ lam,
+                                                                  T* __restrict__ out, int H, int N, int dv, float eps,
                                                                   float post, long nvec, int sub) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int vpw = 64 / sub, sl = lane & (sub - 1);
@@ -428,22 +575,23 @@ __global__ __launch_bounds__(256) void diffattn_combine_fwd_kernel(const float* 
   const int h = (int)(bh % H);
   const long b = bh / H;
   const float lm = lam[0];
-  const float* u0 = U + (((b * 2 * H) + 2 * h) * N + n) * (long)dv;
-  const float* u1 = u0 + (long)N * dv;
+  const T* u0 = U + (((b * 2 * H) + 2 * h) * N + n) * (long)dv;
+  const T* u1 = u0 + (long)N * dv;
   float ss = 0.f;
   if (ok)
     for (int d = sl; d < dv; d += sub) {
-      const float av = u0[d] - lm * u1[d];
+      const float av = ldf(u0 + d) - lm * ldf(u1 + d);
       ss += av * av;
     }
   const float r = rsqrtf(subwave_sum(ss, sub) / dv + eps) * post;
   if (ok) {
-    float* o = out + (b * N + n) * (long)(H * dv) + (long)h * dv;
-    for (int d = sl; d < dv; d += sub) o[d] = (u0[d] - lm * u1[d]) * r;
+    T* o = out + (b * N + n) * (long)(H * dv) + (long)h * dv;
+    for (int d = sl; d < dv; d += sub) stf(o + d, (ldf(u0 + d) - lm * ldf(u1 + d)) * r);
   }
 }
-__global__ __launch_bounds__(256) void diffattn_combine_bwd_kernel(const float* __restrict__ U, const float* __restrict__ lam,
-                                                                  const float* __restrict__ dout, float* __restrict__ dU,
+template <typename T>
+__global__ __launch_bounds__(256) void diffattn_combine_bwd_kernel(const T* __restrict__ U, const float* __restrict__ lam,
+                                                                  const T* __restrict__ dout, T* __restrict__ dU,
                                                                   float* __restrict__ dlam, int H, int N, int dv, float eps,
                                                                   float post, long nvec, int sub) {
   __shared__ float part[4];
@@ -461,29 +609,30 @@ __global__ __launch_bounds__(256) void diffattn_combine_bwd_kernel(const float* 
     const int h = (int)(bh % H);
     const long b = bh / H;
     const long off0 = (((b * 2 * H) + 2 * h) * N + n) * (long)dv;
-    const float* u0 = U + off0;
-    const float* u1 = u0 + (long)N * dv;
-    const float* g = dout + (b * N + n) * (long)(H * dv) + (long)h * dv;
+    const T* u0 = U + off0;
+    const T* u1 = u0 + (long)N * dv;
+    const T* g = dout + (b * N + n) * (long)(H * dv) + (long)h * dv;
     float ss = 0.f, ga = 0.f;
     if (ok)
       for (int d = sl; d < dv; d += sub) {
-        const float av = u0[d] - lm * u1[d];
+        const float av = ldf(u0 + d) - lm * ldf(u1 + d);
         ss += av * av;
-        ga += g[d] * av;
+        ga += ldf(g + d) * av;
       }
     ss = subwave_sum(ss, sub);
     ga = subwave_sum(ga, sub);
     const float r = rsqrtf(ss / dv + eps);
     const float k = r * r * ga / dv;
     if (ok) {
-      float* d0 = dU + off0;
-      float* d1 = d0 + (long)N * dv;
+      T* d0 = dU + off0;
+      T* d1 = d0 + (long)N * dv;
       for (int d = sl; d < dv; d += sub) {
-        const float av = u0[d] - lm * u1[d];
-        const float da = post * r * (g[d] - av * k);
-        d0[d] = da;
-        d1[d] = -lm * da;
-        dl -= da * u1[d];
+        const float u1v = ldf(u1 + d);
+        const float av = ldf(u0 + d) - lm * u1v;
+        const float da = post * r * (ldf(g + d) - av * k);
+        stf(d0 + d, da);
+        stf(d1 + d, -lm * da);
+        dl -= da * u1v;
       }
     }
   }
@@ -499,27 +648,49 @@ static inline int chunks_for(int n) {
   return ch > 64 ? 64 : (ch < 1 ? 1 : ch);
 }
 
-extern "C" int cenet_transpose_f32(const float* x, long sxb, float* y, long syb, int B, int R, int Cc, hipStream_t stream) {
+template <typename T>
+static int transpose_impl(const T* x, long sxb, T* y, long syb, int B, int R, int Cc, hipStream_t stream) {
   if (B <= 0 || R <= 0 || Cc <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(R, 32), B), dim3(256), stream, x, sxb, y, syb, R, Cc);
+  CENET_LAUNCH((transpose_kernel<T>), dim3(cdiv(Cc, 32), cdiv(R, 32), B), dim3(256), stream, x, sxb, y, syb, R, Cc);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_copy_batched_f32(const float* x, long sxb, float* y, long syb, int B, long n, int accumulate,
-                                      hipStream_t stream) {
+template <>
+int transpose_impl<bf16_t>(const bf16_t* x, long sxb, bf16_t* y, long syb, int B, int R, int Cc, hipStream_t stream) {
+  if (B <= 0 || R <= 0 || Cc <= 0) return CENET_EINVAL;
+  if (((R | Cc) & 1) == 0 && ((sxb | syb) & 1) == 0 && ((((uintptr_t)x | (uintptr_t)y) & 3) == 0))
+    CENET_LAUNCH(transpose_bf16x2_kernel, dim3(cdiv(Cc, 64), cdiv(R, 64), B), dim3(256), stream, x, sxb, y, syb, R, Cc);
+  else
+    CENET_LAUNCH((transpose_kernel<bf16_t>), dim3(cdiv(Cc, 32), cdiv(R, 32), B), dim3(256), stream, x, sxb, y, syb, R, Cc);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+CENET_TWIN(transpose, (const T* x, long sxb, T* y, long syb, int B, int R, int Cc, hipStream_t stream),
+           (x, sxb, y, syb, B, R, Cc, stream))
+
+template <typename T>
+static int copy_batched_impl(const T* x, long sxb, T* y, long syb, int B, long n, int accumulate, hipStream_t stream) {
   if (B <= 0 || n <= 0) return CENET_EINVAL;
-  long blocks = (n + 255) / 256;
+  int vw = vec_width<T>(n, x, y);
+  if (vw > 1 && ((sxb | syb) % vw) != 0) vw = (vw == 8 && ((sxb | syb) & 3) == 0) ? 4 : 1;
+  long blocks = (n / vw + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  CENET_LAUNCH(copy_batched_kernel, dim3((unsigned)blocks, B), dim3(256), stream, x, sxb, y, syb, n, accumulate);
+  const dim3 grid((unsigned)blocks, B);
+  if (vw == 8) CENET_LAUNCH((copy_batched_kernel<T, 8>), grid, dim3(256), stream, x, sxb, y, syb, accumulate, n / 8);
+  else if (vw == 4) CENET_LAUNCH((copy_batched_kernel<T, 4>), grid, dim3(256), stream, x, sxb, y, syb, accumulate, n / 4);
+  else CENET_LAUNCH((copy_batched_kernel<T, 1>), grid, dim3(256), stream, x, sxb, y, syb, accumulate, n);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_patch_tok_f32(const float* src, float* dst, int B, int Ho, int Wo, int C, int S, int inverse,
-                                   hipStream_t stream) {
+CENET_TWIN(copy_batched, (const T* x, long sxb, T* y, long syb, int B, long n, int accumulate, hipStream_t stream),
+           (x, sxb, y, syb, B, n, accumulate, stream))
+
+template <typename T>
+static int patch_tok_impl(const T* src, T* dst, int B, int Ho, int Wo, int C, int S, int inverse, hipStream_t stream) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (S != 2 && S != 4 && S != 8)) return CENET_EINVAL;
   const long total = (long)B * Ho * Wo * C;
 #define PATCH_GO(S_, INV_) \
-  CENET_LAUNCH((patch_tok_kernel<S_, INV_>), EW_GRID(total), dim3(256), stream, src, dst, C, Ho, Wo, total)
+  CENET_LAUNCH((patch_tok_kernel<T, S_, INV_>), EW_GRID(total), dim3(256), stream, src, dst, C, Ho, Wo, total)
   if (S == 2) {
     if (inverse) PATCH_GO(2, true); else PATCH_GO(2, false);
   } else if (S == 4) {
@@ -531,91 +702,146 @@ extern "C" int cenet_patch_tok_f32(const float* src, float* dst, int B, int Ho, 
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_scale_batch_f32(const float* x, const float* s, float* y, int B, long n, hipStream_t stream) {
+CENET_TWIN(patch_tok, (const T* src, T* dst, int B, int Ho, int Wo, int C, int S, int inverse, hipStream_t stream),
+           (src, dst, B, Ho, Wo, C, S, inverse, stream))
+
+template <typename T>
+static int scale_batch_impl(const T* x, const float* s, T* y, int B, long n, hipStream_t stream) {
   if (B <= 0 || n <= 0) return CENET_EINVAL;
-  long blocks = (n + 255) / 256;
+  const int vw = vec_width<T>(n, x, y);
+  long blocks = (n / vw + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  CENET_LAUNCH(scale_batch_kernel, dim3((unsigned)blocks, B), dim3(256), stream, x, s, y, n);
+  const dim3 grid((unsigned)blocks, B);
+  if (vw == 8) CENET_LAUNCH((scale_batch_kernel<T, 8>), grid, dim3(256), stream, x, s, y, n / 8);
+  else if (vw == 4) CENET_LAUNCH((scale_batch_kernel<T, 4>), grid, dim3(256), stream, x, s, y, n / 4);
+  else CENET_LAUNCH((scale_batch_kernel<T, 1>), grid, dim3(256), stream, x, s, y, n);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_act_fwd_f32(const float* x, float* y, long n, int act, float slope, hipStream_t stream) {
+CENET_TWIN(scale_batch, (const T* x, const float* s, T* y, int B, long n, hipStream_t stream), (x, s, y, B, n, stream))
+
+template <typename T>
+static int act_fwd_impl(const T* x, T* y, long n, int act, float slope, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(act_fwd_kernel, EW_GRID(n), dim3(256), stream, x, y, n, act, slope);
+  EW_LAUNCH_V(act_fwd_kernel, n, vec_width<T>(n, x, y), x, y, act, slope);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_act_bwd_f32(const float* pre, const float* dy, float* dx, long n, int act, float slope,
-                                 hipStream_t stream) {
+CENET_TWIN(act_fwd, (const T* x, T* y, long n, int act, float slope, hipStream_t stream), (x, y, n, act, slope, stream))
+
+template <typename T>
+static int act_bwd_impl(const T* pre, const T* dy, T* dx, long n, int act, float slope, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(act_bwd_kernel, EW_GRID(n), dim3(256), stream, pre, dy, dx, n, act, slope);
+  EW_LAUNCH_V(act_bwd_kernel, n, vec_width<T>(n, pre, dy, dx), pre, dy, dx, act, slope);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_silu_mul_fwd_f32(const float* a, const float* b, float* y, long n, hipStream_t stream) {
+CENET_TWIN(act_bwd, (const T* pre, const T* dy, T* dx, long n, int act, float slope, hipStream_t stream),
+           (pre, dy, dx, n, act, slope, stream))
+
+template <typename T>
+static int silu_mul_fwd_impl(const T* a, const T* b, T* y, long n, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(silu_mul_fwd_kernel, EW_GRID(n), dim3(256), stream, a, b, y, n);
+  EW_LAUNCH_V(silu_mul_fwd_kernel, n, vec_width<T>(n, a, b, y), a, b, y);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_silu_mul_bwd_f32(const float* a, const float* b, const float* dy, float* da, float* db, long n,
-                                      hipStream_t stream) {
+CENET_TWIN(silu_mul_fwd, (const T* a, const T* b, T* y, long n, hipStream_t stream), (a, b, y, n, stream))
+
+template <typename T>
+static int silu_mul_bwd_impl(const T* a, const T* b, const T* dy, T* da, T* db, long n, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(silu_mul_bwd_kernel, EW_GRID(n), dim3(256), stream, a, b, dy, da, db, n);
+  int vw = vec_width<T>(n, a, b, dy, da, db);
+  if (vw == 8) vw = 4;  // five streams of 8 would not fit the register budget of a grid-stride loop comfortably
+  EW_LAUNCH_V(silu_mul_bwd_kernel, n, vw, a, b, dy, da, db);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_mix_fwd_f32(const float* x, const float* p, const float* w, float* z, long n, hipStream_t stream) {
+CENET_TWIN(silu_mul_bwd, (const T* a, const T* b, const T* dy, T* da, T* db, long n, hipStream_t stream),
+           (a, b, dy, da, db, n, stream))
+
+template <typename T>
+static int mix_fwd_impl(const T* x, const T* p, const float* w, T* z, long n, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(mix_fwd_kernel, EW_GRID(n), dim3(256), stream, x, p, w, z, n);
+  EW_LAUNCH_V(mix_fwd_kernel, n, vec_width<T>(n, x, p, z), x, p, w, z);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_mix_bwd_acc_f32(const float* x, const float* p, const float* w, const float* dz, float* dx, float* dp,
-                                     float* dw_acc, long n, hipStream_t stream) {
+CENET_TWIN(mix_fwd, (const T* x, const T* p, const float* w, T* z, long n, hipStream_t stream), (x, p, w, z, n, stream))
+
+template <typename T>
+static int mix_bwd_acc_impl(const T* x, const T* p, const float* w, const T* dz, T* dx, T* dp, float* dw_acc, long n,
+                            hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
-  long blocks = (n + 255) / 256;
+  int vw = vec_width<T>(n, x, p, dz, dx, dp);
+  if (vw == 8) vw = 4;
+  if (sizeof(T) == 4) vw = 1;  // fp32 keeps the one-element-per-thread walk: the summation order of dw in parity mode is pinned
+  long blocks = (n / vw + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  CENET_LAUNCH(mix_bwd_kernel, dim3((unsigned)blocks), dim3(256), stream, x, p, w, dz, dx, dp, dw_acc, n);
+  if (vw == 4) CENET_LAUNCH((mix_bwd_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), stream, x, p, w, dz, dx, dp, dw_acc, n / 4);
+  else CENET_LAUNCH((mix_bwd_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), stream, x, p, w, dz, dx, dp, dw_acc, n);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_scale_residual_fwd_f32(const float* x, const float* y, const float* ls, float* out, int B, int C, int HW,
-                                            hipStream_t stream) {
+CENET_TWIN(mix_bwd_acc, (const T* x, const T* p, const float* w, const T* dz, T* dx, T* dp, float* dw_acc, long n,
+                         hipStream_t stream), (x, p, w, dz, dx, dp, dw_acc, n, stream))
+
+template <typename T>
+static int scale_residual_fwd_impl(const T* x, const T* y, const float* ls, T* out, int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(scale_residual_fwd_kernel, dim3(B * C, chunks_for(HW)), dim3(256), stream, x, y, ls, out, C, HW);
+  const int vw = vec_width<T>(HW, x, y, out);
+  const dim3 grid(B * C, chunks_for(HW / vw));
+  if (vw == 8) CENET_LAUNCH((scale_residual_fwd_kernel<T, 8>), grid, dim3(256), stream, x, y, ls, out, C, HW / 8);
+  else if (vw == 4) CENET_LAUNCH((scale_residual_fwd_kernel<T, 4>), grid, dim3(256), stream, x, y, ls, out, C, HW / 4);
+  else CENET_LAUNCH((scale_residual_fwd_kernel<T, 1>), grid, dim3(256), stream, x, y, ls, out, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_scale_chan_f32(const float* g, const float* ls, float* out, int B, int C, int HW, hipStream_t stream) {
+CENET_TWIN(scale_residual_fwd, (const T* x, const T* y, const float* ls, T* out, int B, int C, int HW, hipStream_t stream),
+           (x, y, ls, out, B, C, HW, stream))
+
+template <typename T>
+static int scale_chan_impl(const T* g, const float* ls, T* out, int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(scale_chan_kernel, dim3(B * C, chunks_for(HW)), dim3(256), stream, g, ls, out, C, HW);
+  const int vw = vec_width<T>(HW, g, out);
+  const dim3 grid(B * C, chunks_for(HW / vw));
+  if (vw == 8) CENET_LAUNCH((scale_chan_kernel<T, 8>), grid, dim3(256), stream, g, ls, out, C, HW / 8);
+  else if (vw == 4) CENET_LAUNCH((scale_chan_kernel<T, 4>), grid, dim3(256), stream, g, ls, out, C, HW / 4);
+  else CENET_LAUNCH((scale_chan_kernel<T, 1>), grid, dim3(256), stream, g, ls, out, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_chan_dot_acc_f32(const float* a, long sab, const float* b, long sbb, float* out_acc, int B, int C, int HW,
-                                      hipStream_t stream) {
+CENET_TWIN(scale_chan, (const T* g, const float* ls, T* out, int B, int C, int HW, hipStream_t stream),
+           (g, ls, out, B, C, HW, stream))
+
+template <typename T>
+static int chan_dot_acc_impl(const T* a, long sab, const T* b, long sbb, float* out_acc, int B, int C, int HW,
+                             hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   long total = (long)B * HW;
   long want = 1024 / C, maxs = (total + 2047) / 2048;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
-  if ((HW & 3) == 0 && ((sab | sbb) & 3) == 0 && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0)) {
+  if ((HW & 3) == 0 && ((sab | sbb) & 3) == 0 && quad_aligned<T>(a) && quad_aligned<T>(b)) {
     long w4 = 2048 / C, m4 = (total / 4 + 1023) / 1024;
     if (w4 > m4) w4 = m4;
     if (w4 < 1) w4 = 1;
     if (w4 > 256) w4 = 256;
-    CENET_LAUNCH(chan_dot_v4_kernel, dim3(C, (unsigned)w4), dim3(256), stream, a, sab, b, sbb, out_acc, B, HW);
+    CENET_LAUNCH((chan_dot_v4_kernel<T>), dim3(C, (unsigned)w4), dim3(256), stream, a, sab, b, sbb, out_acc, B, HW);
   } else {
-    CENET_LAUNCH(chan_dot_kernel, dim3(C, (unsigned)want), dim3(256), stream, a, sab, b, sbb, out_acc, B, HW);
+    CENET_LAUNCH((chan_dot_kernel<T>), dim3(C, (unsigned)want), dim3(256), stream, a, sab, b, sbb, out_acc, B, HW);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_col_sum_acc_f32(const float* a, float* out_acc, long R, int C, hipStream_t stream) {
+CENET_TWIN(chan_dot_acc, (const T* a, long sab, const T* b, long sbb, float* out_acc, int B, int C, int HW, hipStream_t stream),
+           (a, sab, b, sbb, out_acc, B, C, HW, stream))
+
+template <typename T>
+static int col_sum_acc_impl(const T* a, float* out_acc, long R, int C, hipStream_t stream) {
   if (R <= 0 || C <= 0) return CENET_EINVAL;
-  if ((C & 3) == 0 && (((uintptr_t)a) & 15) == 0) {
+  if ((C & 3) == 0 && quad_aligned<T>(a)) {
     // ~2048 workgroups, each at least 64 rows deep
     const int quads = C / 4;
     const int tpr = quads >= 64 ? 64 : (quads >= 32 ? 32 : 16);
@@ -624,53 +850,79 @@ extern "C" int cenet_col_sum_acc_f32(const float* a, float* out_acc, long R, int
     if (rpb < 64) rpb = 64;
     rpb = (rpb + 15) & ~15L;
     dim3 grid(ctiles, (unsigned)((R + rpb - 1) / rpb));
-    if (tpr == 64) CENET_LAUNCH((col_sum_v4_kernel<64>), grid, dim3(256), stream, a, out_acc, R, C, (int)rpb);
-    else if (tpr == 32) CENET_LAUNCH((col_sum_v4_kernel<32>), grid, dim3(256), stream, a, out_acc, R, C, (int)rpb);
-    else CENET_LAUNCH((col_sum_v4_kernel<16>), grid, dim3(256), stream, a, out_acc, R, C, (int)rpb);
+    if (tpr == 64) CENET_LAUNCH((col_sum_v4_kernel<T, 64>), grid, dim3(256), stream, a, out_acc, R, C, (int)rpb);
+    else if (tpr == 32) CENET_LAUNCH((col_sum_v4_kernel<T, 32>), grid, dim3(256), stream, a, out_acc, R, C, (int)rpb);
+    else CENET_LAUNCH((col_sum_v4_kernel<T, 16>), grid, dim3(256), stream, a, out_acc, R, C, (int)rpb);
   } else {
-    CENET_LAUNCH(col_sum_kernel, dim3(cdiv(C, 64), (unsigned)((R + CS_ROWS - 1) / CS_ROWS)), dim3(256), stream, a, out_acc, R, C);
+    CENET_LAUNCH((col_sum_kernel<T>), dim3(cdiv(C, 64), (unsigned)((R + CS_ROWS - 1) / CS_ROWS)), dim3(256), stream, a, out_acc,
+                 R, C);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_add_act_fwd_f32(const float* a, const float* b, float* out, long n, int act, float slope,
-                                     hipStream_t stream) {
+CENET_TWIN(col_sum_acc, (const T* a, float* out_acc, long R, int C, hipStream_t stream), (a, out_acc, R, C, stream))
+
+template <typename T>
+static int add_act_fwd_impl(const T* a, const T* b, T* out, long n, int act, float slope, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(add_act_fwd_kernel, EW_GRID(n), dim3(256), stream, a, b, out, n, act, slope);
+  EW_LAUNCH_V(add_act_fwd_kernel, n, vec_width<T>(n, a, b, out), a, b, out, act, slope);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_lrelu_bwd_from_out_f32(const float* out, const float* dy, float* dx, long n, float slope,
-                                            hipStream_t stream) {
+CENET_TWIN(add_act_fwd, (const T* a, const T* b, T* out, long n, int act, float slope, hipStream_t stream),
+           (a, b, out, n, act, slope, stream))
+
+template <typename T>
+static int lrelu_bwd_from_out_impl(const T* out, const T* dy, T* dx, long n, float slope, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(lrelu_bwd_from_out_kernel, EW_GRID(n), dim3(256), stream, out, dy, dx, n, slope);
+  EW_LAUNCH_V(lrelu_bwd_from_out_kernel, n, vec_width<T>(n, out, dy, dx), out, dy, dx, slope);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_dseb_combine_fwd_f32(const float* y, const float* r0, const float* r1, const float* r2, int n,
-                                          const float* w, const float* diff, float ycoef, float* z, int B, int C,
-                                          int HW, hipStream_t stream) {
+CENET_TWIN(lrelu_bwd_from_out, (const T* out, const T* dy, T* dx, long n, float slope, hipStream_t stream),
+           (out, dy, dx, n, slope, stream))
+
+template <typename T>
+static int dseb_combine_fwd_impl(const T* y, const T* r0, const T* r1, const T* r2, int n, const float* w, const T* diff,
+                                 float ycoef, T* z, int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0 || n < 2 || n > 3) return CENET_EINVAL;
-  DsebArgs a;
+  DsebArgs<T> a;
   memset(&a, 0, sizeof(a));
-  a.y = y; a.r[0] = r0; a.r[1] = r1; a.r[2] = r2; a.w = w; a.diff = diff; a.z = z; a.n = n; a.C = C; a.HW = HW; a.ycoef = ycoef;
-  CENET_LAUNCH(dseb_combine_fwd_kernel, dim3(B * C, chunks_for(HW)), dim3(256), stream, a);
+  a.y = y; a.r[0] = r0; a.r[1] = r1; a.r[2] = r2; a.w = w; a.diff = diff; a.z = z; a.n = n; a.C = C; a.ycoef = ycoef;
+  const int vw = vec_width<T>(HW, y, r0, r1, r2, diff, z) >= 4 ? 4 : 1;
+  a.HW = HW / vw;
+  if (vw == 4) CENET_LAUNCH((dseb_combine_fwd_kernel<T, 4>), dim3(B * C, chunks_for(a.HW)), dim3(256), stream, a);
+  else CENET_LAUNCH((dseb_combine_fwd_kernel<T, 1>), dim3(B * C, chunks_for(a.HW)), dim3(256), stream, a);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_dseb_combine_bwd_acc_f32(const float* y, const float* r0, const float* r1, const float* r2, int n,
-                                              const float* w, const float* diff, float ycoef, const float* dz, float* dy,
-                                              float* dr0, float* dr1, float* dr2, float* ddiff, float* dw_acc, int B, int C,
-                                              int HW, hipStream_t stream) {
+CENET_TWIN(dseb_combine_fwd, (const T* y, const T* r0, const T* r1, const T* r2, int n, const float* w, const T* diff,
+                              float ycoef, T* z, int B, int C, int HW, hipStream_t stream),
+           (y, r0, r1, r2, n, w, diff, ycoef, z, B, C, HW, stream))
+
+template <typename T>
+static int dseb_combine_bwd_acc_impl(const T* y, const T* r0, const T* r1, const T* r2, int n, const float* w, const T* diff,
+                                     float ycoef, const T* dz, T* dy, T* dr0, T* dr1, T* dr2, T* ddiff, float* dw_acc, int B,
+                                     int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0 || n < 2 || n > 3) return CENET_EINVAL;
-  DsebArgs a;
+  DsebArgs<T> a;
   memset(&a, 0, sizeof(a));
-  a.y = y; a.r[0] = r0; a.r[1] = r1; a.r[2] = r2; a.w = w; a.diff = diff; a.n = n; a.C = C; a.HW = HW; a.ycoef = ycoef;
+  a.y = y; a.r[0] = r0; a.r[1] = r1; a.r[2] = r2; a.w = w; a.diff = diff; a.n = n; a.C = C; a.ycoef = ycoef;
   a.dz = dz; a.dy = dy; a.dr[0] = dr0; a.dr[1] = dr1; a.dr[2] = dr2; a.ddiff = ddiff; a.dw = dw_acc;
-  CENET_LAUNCH(dseb_combine_bwd_kernel, dim3(B * C, chunks_for(HW)), dim3(256), stream, a);
+  const uintptr_t m = (uintptr_t)y | (uintptr_t)r0 | (uintptr_t)r1 | (uintptr_t)r2 | (uintptr_t)diff | (uintptr_t)dz |
+                      (uintptr_t)dy | (uintptr_t)dr0 | (uintptr_t)dr1 | (uintptr_t)dr2 | (uintptr_t)ddiff;
+  const int vw = ((HW & 3) == 0 && (m & (4 * sizeof(T) - 1)) == 0) ? 4 : 1;
+  a.HW = HW / vw;
+  if (vw == 4) CENET_LAUNCH((dseb_combine_bwd_kernel<T, 4>), dim3(B * C, chunks_for(a.HW)), dim3(256), stream, a);
+  else CENET_LAUNCH((dseb_combine_bwd_kernel<T, 1>), dim3(B * C, chunks_for(a.HW)), dim3(256), stream, a);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(dseb_combine_bwd_acc, (const T* y, const T* r0, const T* r1, const T* r2, int n, const float* w, const T* diff,
+                                  float ycoef, const T* dz, T* dy, T* dr0, T* dr1, T* dr2, T* ddiff, float* dw_acc, int B, int C,
+                                  int HW, hipStream_t stream),
+           (y, r0, r1, r2, n, w, diff, ycoef, dz, dy, dr0, dr1, dr2, ddiff, dw_acc, B, C, HW, stream))
+
 extern "C" int cenet_diffattn_lambda_fwd_f32(const float* q1, const float* k1, const float* q2, const float* k2,
                                              float lambda_init, float* lam3, int hd, hipStream_t stream) {
   if (hd <= 0) return CENET_EINVAL;
@@ -686,28 +938,35 @@ extern "C" int cenet_diffattn_lambda_bwd_acc_f32(const float* q1, const float* k
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_diffattn_combine_fwd_f32(const float* U, const float* lam3, float* out, int B, int H, int N, int dv,
-                                              float eps, float post, hipStream_t stream) {
+template <typename T>
+static int diffattn_combine_fwd_impl(const T* U, const float* lam3, T* out, int B, int H, int N, int dv, float eps, float post,
+                                     hipStream_t stream) {
   if (B <= 0 || H <= 0 || N <= 0 || dv <= 0) return CENET_EINVAL;
   long nvec = (long)B * H * N;
   const int sub = dv <= 16 ? 16 : (dv <= 32 ? 32 : 64);
   const long per_block = 4L * (64 / sub);
-  CENET_LAUNCH(diffattn_combine_fwd_kernel, dim3((unsigned)((nvec + per_block - 1) / per_block)), dim3(256), stream, U, lam3, out,
-               H, N, dv, eps, post, nvec, sub);
+  CENET_LAUNCH((diffattn_combine_fwd_kernel<T>), dim3((unsigned)((nvec + per_block - 1) / per_block)), dim3(256), stream, U, lam3,
+               out, H, N, dv, eps, post, nvec, sub);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_diffattn_combine_bwd_acc_f32(const float* U, const float* lam3, const float* dout, float* dU,
-                                                  float* dlam_acc, int B, int H, int N, int dv, float eps, float post,
-                                                  hipStream_t stream) {
+CENET_TWIN(diffattn_combine_fwd, (const T* U, const float* lam3, T* out, int B, int H, int N, int dv, float eps, float post,
+                                  hipStream_t stream), (U, lam3, out, B, H, N, dv, eps, post, stream))
+
+template <typename T>
+static int diffattn_combine_bwd_acc_impl(const T* U, const float* lam3, const T* dout, T* dU, float* dlam_acc, int B, int H,
+                                         int N, int dv, float eps, float post, hipStream_t stream) {
   if (B <= 0 || H <= 0 || N <= 0 || dv <= 0) return CENET_EINVAL;
   long nvec = (long)B * H * N;
   const int sub = dv <= 16 ? 16 : (dv <= 32 ? 32 : 64);
   const long per_block = 4L * (64 / sub);
   long blocks = (nvec + per_block - 1) / per_block;
   if (blocks > 2048) blocks = 2048;
-  CENET_LAUNCH(diffattn_combine_bwd_kernel, dim3((unsigned)blocks), dim3(256), stream, U, lam3, dout, dU, dlam_acc, H, N, dv, eps,
-               post, nvec, sub);
+  CENET_LAUNCH((diffattn_combine_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), stream, U, lam3, dout, dU, dlam_acc, H, N, dv,
+               eps, post, nvec, sub);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(diffattn_combine_bwd_acc, (const T* U, const float* lam3, const T* dout, T* dU, float* dlam_acc, int B, int H, int N,
+                                      int dv, float eps, float post, hipStream_t stream),
+           (U, lam3, dout, dU, dlam_acc, B, H, N, dv, eps, post, stream))

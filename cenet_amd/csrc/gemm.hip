@@ -19,42 +19,43 @@ static void pick_tile(int M, int N, int nbatch, int splits, int* bm, int* bn) {
   *bn = n;
 }
 
-static int g_compute_bf16 = 0;
-extern "C" int cenet_set_compute_bf16(int on) {
-  int old = g_compute_bf16;
-  g_compute_bf16 = on ? 1 : 0;
-  return old;
-}
-extern "C" int cenet_get_compute_bf16() { return g_compute_bf16; }
-
-static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static inline bool m4(long v) { return (v & 3) == 0; }
+static inline bool m2(long v) { return (v & 1) == 0; }
 
-extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K,
-                              int nbatch, int nb_inner, int nkb, int splits, hipStream_t stream) {
+// esz: element size of A / B (and of C / R unless the epilogue is atomic): 4 = fp32 (exact MFMA chain), 2 = bf16
+static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K, int nbatch,
+                         int nb_inner, int nkb, int splits, int esz, hipStream_t stream) {
   if (!A || !B || !E || !A->ptr || !B->ptr || !E->C) return CENET_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0 || nbatch <= 0 || nb_inner <= 0 || nkb <= 0 || splits <= 0) return CENET_EINVAL;
   if (A->mode != 0) return CENET_EUNSUPPORTED;
   if (splits > 1 && !E->atomic) return CENET_EINVAL;
   if (E->atomic && (E->bias || E->R || E->act != ACT_NONE || E->bscale)) return CENET_EINVAL;
+  const bool bf = esz == 2;
+  const uintptr_t qmask = 4 * esz - 1;  // a quad of elements: 16 bytes (fp32) / 8 bytes (bf16)
+  auto alq = [&](const void* p) { return ((uintptr_t)p & qmask) == 0; };
   GemmArgs g;
   g.A = *A;
   g.B = *B;
   g.E = *E;
   g.M = M; g.N = N; g.K = K; g.nkb = nkb; g.splits = splits; g.nb_inner = nb_inner;
-  // 16-byte staging: k-contiguous plain operand, every row/batch offset a multiple of 4 floats, K % 4 == 0
-  g.avec = A->kfast && A->kinner == 0 && A->sc == 1 && m4(A->sr) && m4(A->sb) && m4(A->sb2) && m4(A->skb) && m4(K) && al16(A->ptr);
+  // quad staging: k-contiguous plain operand, every row/batch offset a multiple of 4 elements, K % 4 == 0
+  g.avec = A->kfast && A->kinner == 0 && A->sc == 1 && m4(A->sr) && m4(A->sb) && m4(A->sb2) && m4(A->skb) && m4(K) && alq(A->ptr);
   g.bvec = B->mode == 0 && B->kfast && B->kinner == 0 && B->sr == 1 && m4(B->sc) && m4(B->sb) && m4(B->sb2) && m4(B->skb) &&
-           m4(K) && al16(B->ptr);
-  // row-major C: lanes own 4 consecutive columns (16-byte epilogue). Atomic epilogues keep the un-swapped layout: one
+           m4(K) && alq(B->ptr);
+  // bf16 row-contiguous operands: two adjacent rows per 4-byte load (even extents and offsets)
+  g.apair = bf && !A->kfast && A->kinner == 0 && A->sr == 1 && m2(A->sc) && m2(A->sb) && m2(A->sb2) && m2(A->skb) && m2(M) &&
+            (((uintptr_t)A->ptr & 3) == 0);
+  g.bpair = bf && B->mode == 0 && !B->kfast && B->kinner == 0 && B->sc == 1 && m2(B->sr) && m2(B->sb) && m2(B->sb2) &&
+            m2(B->skb) && m2(N) && (((uintptr_t)B->ptr & 3) == 0);
+  // row-major C: lanes own 4 consecutive columns (quad epilogue). Atomic epilogues keep the un-swapped layout: one
   // atomic instruction then covers 4 rows x 16 consecutive floats (64-byte segments) instead of 16 rows x 4 strided.
   const bool swap = (E->scc == 1) && !E->atomic && !E->cmode;
   if (swap)
-    g.cvec = E->scc == 1 && m4(E->scr) && m4(E->scb) && m4(E->scb2) && al16(E->C) &&
-             (!E->R || (E->src == 1 && m4(E->srr) && m4(E->srb) && m4(E->srb2) && al16(E->R)));
+    g.cvec = E->scc == 1 && m4(E->scr) && m4(E->scb) && m4(E->scb2) && alq(E->C) &&
+             (!E->R || (E->src == 1 && m4(E->srr) && m4(E->srb) && m4(E->srb2) && alq(E->R)));
   else
-    g.cvec = E->scr == 1 && m4(E->scc) && m4(E->scb) && m4(E->scb2) && al16(E->C) &&
-             (!E->R || (E->srr == 1 && m4(E->src) && m4(E->srb) && m4(E->srb2) && al16(E->R)));
+    g.cvec = E->scr == 1 && m4(E->scc) && m4(E->scb) && m4(E->scb2) && alq(E->C) &&
+             (!E->R || (E->srr == 1 && m4(E->src) && m4(E->srb) && m4(E->srb2) && alq(E->R)));
   int bm, bn;
   pick_tile(M, N, nbatch, splits, &bm, &bn);
   if (B->mode == 1 && B->kfast && bm == 32) bn = 64;  // weight-gradient view: keep the per-thread gather list short
@@ -78,7 +79,7 @@ extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const 
   }
   const bool im = B->mode != 0;
   int rc;
-  if (g_compute_bf16) {
+  if (bf) {
     // plain operands with a reduction of at least two 64-steps: K step 64 halves the barriers and the serial
     // load -> LDS -> MFMA round trips of the (mostly latency-bound) mid-size contractions
     // (measured: a gain for the 64x64 / 32x64 tiles that these small launches get, a loss for the 128-wide tiles, whose
@@ -93,4 +94,13 @@ extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const 
   if (rc != CENET_OK) return rc;
   CENET_CHECK_LAUNCH();
   return CENET_OK;
+}
+
+extern "C" int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K,
+                              int nbatch, int nb_inner, int nkb, int splits, hipStream_t stream) {
+  return gemm_dispatch(A, B, E, M, N, K, nbatch, nb_inner, nkb, splits, 4, stream);
+}
+extern "C" int cenet_gemm_bf16(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K,
+                               int nbatch, int nb_inner, int nkb, int splits, hipStream_t stream) {
+  return gemm_dispatch(A, B, E, M, N, K, nbatch, nb_inner, nkb, splits, 2, stream);
 }

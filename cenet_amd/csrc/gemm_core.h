@@ -16,8 +16,11 @@
 //     the loads of tile t+1 fly under the MFMAs of tile t), then written k-contiguous into LDS;
 //   * fragments are fetched with 16-byte ds_read_b128: for fp32, lane (r = lane&15, q = lane>>4) owns k' = 8q..8q+7 and
 //     MFMA step s multiplies slot s of A with slot s of B (a permutation of the k order, which a sum does not care about);
-//   * OpT = float : v_mfma_f32_16x16x4_f32, exact fp32 FMA chain (parity mode)
-//     OpT = bf16  : operands rounded to bf16 when they enter LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulate;
+//   * OpT = float : fp32 tensors in HBM, v_mfma_f32_16x16x4_f32, exact fp32 FMA chain (parity mode)
+//     OpT = bf16  : bf16 tensors in HBM (throughput mode: activations, activation gradients and the bf16 shadow of the
+//                   weights), copied to LDS without conversion (8-byte k-contiguous quads, or row pairs re-packed with one
+//                   v_perm per dword when the operand is row-contiguous), v_mfma_f32_16x16x32_bf16, fp32 accumulate; C / R
+//                   are bf16 except in atomic (split-K / scatter-add) epilogues, which always add into fp32;
 //   * SWAP: when C is row-major the MFMA is issued as (B-fragment, A-fragment) so a lane's four accumulator registers are
 //     four CONSECUTIVE COLUMNS of C and the epilogue moves 16 bytes per instruction (bias / residual / store);
 //   * im2col addressing never divides per element: forward/dgrad threads walk (kx,ky,ci) with carries, the
@@ -30,7 +33,8 @@ struct GemmArgs {
   cenet_mat_t A, B;
   cenet_epi_t E;
   int M, N, K, nkb, splits, nb_inner;
-  int avec, bvec, cvec;  // 16-byte global access is legal for A / B staging / the epilogue
+  int avec, bvec, cvec;  // quad (16-byte fp32 / 8-byte bf16) global access is legal for A / B staging / the epilogue
+  int apair, bpair;      // bf16, row-contiguous operand: adjacent rows may be fetched as 4-byte pairs
 };
 
 __device__ __forceinline__ unsigned f2bf_bits(float f) { return cenet_f2bf(f); }
@@ -83,7 +87,8 @@ __device__ __forceinline__ KEntry im2col_entry(const cenet_mat_t& d, int idx, bo
   return e;
 }
 
-__device__ __forceinline__ float im2col_load(const cenet_mat_t& d, const float* base, const KEntry& pat, const KEntry& pix) {
+template <typename GT>
+__device__ __forceinline__ float im2col_load(const cenet_mat_t& d, const GT* base, const KEntry& pat, const KEntry& pix) {
   int iy, ix;
   if (!d.transposed) {
     iy = pix.dy + pat.dy;
@@ -101,7 +106,7 @@ __device__ __forceinline__ float im2col_load(const cenet_mat_t& d, const float* 
     }
   }
   if (iy < 0 || iy >= d.Hs || ix < 0 || ix >= d.Ws) return 0.f;
-  return base[(long)pat.off + (long)iy * d.sy + (long)ix * d.sx];
+  return ldf(base + (long)pat.off + (long)iy * d.sy + (long)ix * d.sx);
 }
 
 // write NV consecutive-k values of one LDS row (NV multiple of 4)
@@ -131,14 +136,48 @@ struct PlainStage {
   long toff;    // thread's element offset inside a K tile (relative to the tile origin at row 0, k0)
   long dj;      // element stride between consecutive registers (register quads for the 16-byte form)
   unsigned ok;  // bit j: register j's row lies inside the matrix (k-contiguous forms); bit 0: the thread's row does
+                // (pair form: bit 1 = the second row of the pair does)
   int kk;       // k index inside the tile of register 0
+  int pair;     // bf16, row-contiguous operand: the thread owns TWO adjacent rows (4-byte loads) and NX/2 consecutive k
 };
+// staging registers of one operand: fp32 values (fp32 operands; bf16 fallback paths, converted when they enter LDS) or raw
+// 32-bit words (bf16 fast paths: packed k-quads / row pairs)
+template <int N>
+union StageRegs {
+  float f[N];
+  unsigned u[N];
+};
+// (lo halves, hi halves) of two packed words: w0 = (a0 | b0 << 16), w1 = (a1 | b1 << 16)  ->  (a0 | a1 << 16), (b0 | b1 << 16)
+__device__ __forceinline__ unsigned pack_lo16(unsigned w0, unsigned w1) {
+#ifdef CENET_HOSTSIM_BUILD
+  return (w0 & 0xFFFFu) | (w1 << 16);
+#else
+  return __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+#endif
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned w0, unsigned w1) {
+#ifdef CENET_HOSTSIM_BUILD
+  return (w0 >> 16) | (w1 & 0xFFFF0000u);
+#else
+  return __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+#endif
+}
 
 // rs / ks: element strides along the operand's row (M or N) index and along k; x0 / X: tile origin and matrix extent
 template <int BX, int NX, int KT>
-__device__ __forceinline__ PlainStage plain_stage(long rs, long ks, int kfast, int vec, int x0, int X, int tid) {
+__device__ __forceinline__ PlainStage plain_stage(long rs, long ks, int kfast, int vec, int x0, int X, int tid, int pair) {
   PlainStage s;
   s.ok = 0;
+  s.pair = 0;
+  if (!kfast && pair) {
+    const int row = 2 * (tid % (BX / 2)), kq = tid / (BX / 2);
+    s.pair = 1;
+    s.kk = kq * (NX / 2);
+    s.toff = (long)(x0 + row) * rs + (long)s.kk * ks;
+    s.dj = ks;
+    s.ok = (x0 + row < X ? 1u : 0u) | (x0 + row + 1 < X ? 2u : 0u);
+    return s;
+  }
   if (kfast) {
     // 16-byte form: KT/4 lanes per row; scalar form: KT lanes per row
     const int lpr = vec ? KT / 4 : KT;
@@ -160,9 +199,47 @@ __device__ __forceinline__ PlainStage plain_stage(long rs, long ks, int kfast, i
 }
 
 // tile = operand base of this batch / K-batch advanced to k0; klim = K - k0; interior: whole BX x BK tile inside the matrix
+// bf16 operands: k-contiguous quads as raw 8-byte words, row pairs as raw 4-byte words; the scalar forms convert to fp32
+template <int NX>
+__device__ __forceinline__ void plain_fetch(const PlainStage& s, const bf16_t* tile, int klim, int kfast, int vec,
+                                            bool interior, StageRegs<NX>& rg) {
+  const bf16_t* p = tile + s.toff;
+  if (s.pair) {
+    const int lim = interior ? NX / 2 : (klim - s.kk);
+#pragma unroll
+    for (int j = 0; j < NX / 2; ++j, p += s.dj) {
+      unsigned w = 0;
+      if (j < lim) {
+        if ((s.ok & 3u) == 3u) memcpy(&w, p, 4);
+        else if (s.ok & 1u) w = *p;
+      }
+      rg.u[j] = w;
+    }
+    return;
+  }
+  if (kfast && vec) {
+    const bool kok = interior || s.kk < klim;
+#pragma unroll
+    for (int j = 0; j < NX / 4; ++j, p += s.dj) {
+      if (kok && (interior || ((s.ok >> j) & 1u))) memcpy(&rg.u[2 * j], p, 8);
+      else rg.u[2 * j] = rg.u[2 * j + 1] = 0u;
+    }
+    return;
+  }
+  if (kfast) {
+    const bool kok = s.kk < klim;
+#pragma unroll
+    for (int j = 0; j < NX; ++j, p += s.dj) rg.f[j] = (interior || (kok && ((s.ok >> j) & 1u))) ? cenet_bf2f(*p) : 0.f;
+  } else {
+    const int lim = interior ? NX : ((s.ok & 1u) ? klim - s.kk : 0);
+#pragma unroll
+    for (int j = 0; j < NX; ++j, p += s.dj) rg.f[j] = (j < lim) ? cenet_bf2f(*p) : 0.f;
+  }
+}
 template <int NX>
 __device__ __forceinline__ void plain_fetch(const PlainStage& s, const float* tile, int klim, int kfast, int vec,
-                                            bool interior, float* r) {
+                                            bool interior, StageRegs<NX>& rg) {
+  float* r = rg.f;
   const float* p = tile + s.toff;
   if (interior) {
     if (kfast && vec) {
@@ -200,6 +277,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
   constexpr bool BF = (sizeof(OpT) == 2);
   constexpr int MI = BM / 32, NJ = BN / 32;              // 16x16 tiles per wave in each direction
   constexpr int NA = BM * KT / 256, NB = BN * KT / 256;  // prefetch registers per thread
+  typedef OpT GT;                                          // element type of A, B (and of C / R in non-atomic epilogues)
   __shared__ __attribute__((aligned(16))) OpT As[BM * P];
   __shared__ __attribute__((aligned(16))) OpT Bs[BN * P];
   __shared__ KEntry ntab[B_IM2COL ? BN : 1];
@@ -246,11 +324,14 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
   //   mfast        : row = tid % BMN, kq = tid / BMN ; k = kq * KPT + j  (KPT consecutive k per thread)
   constexpr int A_KPT = KT / (256 / BM), B_KPT = KT / (256 / BN);
   static_assert(BM <= 256 && BN <= 256 && NA % 4 == 0 && NB % 4 == 0 && NA <= 32 && NB <= 32, "unsupported tile");
-  float ra[NA], rb[NB];
+  StageRegs<NA> rga;
+  StageRegs<NB> rgb;
+  float* const ra = rga.f;
+  float* const rb = rgb.f;
   // plain operands without the (ko,ki) split of k use hoisted pointer walks; the split form keeps per-element addressing
   const bool a_fast = g.A.kinner == 0, b_fast = !B_IM2COL && g.B.kinner == 0;
-  const PlainStage sa = plain_stage<BM, NA, KT>(g.A.sr, g.A.sc, g.A.kfast, g.avec, m0, g.M, tid);
-  const PlainStage sb = plain_stage<BN, NB, KT>(g.B.sc, g.B.sr, g.B.kfast, g.bvec, n0, g.N, tid);
+  const PlainStage sa = plain_stage<BM, NA, KT>(g.A.sr, g.A.sc, g.A.kfast, g.avec, m0, g.M, tid, BF && a_fast && g.apair);
+  const PlainStage sb = plain_stage<BN, NB, KT>(g.B.sc, g.B.sr, g.B.kfast, g.bvec, n0, g.N, tid, BF && b_fast && g.bpair);
   const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
 
   KEntry nent;
@@ -265,42 +346,42 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
   auto fetch = [&](int it) __attribute__((always_inline)) {
     const int kb = it / ktiles;
     const int k0 = (it - kb * ktiles) * KT;
-    const float* baseA = g.A.ptr + (long)bo * g.A.sb + (long)bi * g.A.sb2 + (long)kb * g.A.skb;
-    const float* baseB = g.B.ptr + (long)bo * g.B.sb + (long)bi * g.B.sb2 + (long)kb * g.B.skb;
+    const GT* baseA = (const GT*)g.A.ptr + (long)bo * g.A.sb + (long)bi * g.A.sb2 + (long)kb * g.A.skb;
+    const GT* baseB = (const GT*)g.B.ptr + (long)bo * g.B.sb + (long)bi * g.B.sb2 + (long)kb * g.B.skb;
     const int klim = g.K - k0;
     if (a_fast) {
-      plain_fetch<NA>(sa, baseA + (long)k0 * g.A.sc, klim, g.A.kfast, g.avec, a_in && klim >= KT, ra);
+      plain_fetch<NA>(sa, baseA + (long)k0 * g.A.sc, klim, g.A.kfast, g.avec, a_in && klim >= KT, rga);
     } else if (g.A.kfast) {
       const int kk = tid % KT, r0 = tid / KT;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         int row = r0 + j * (256 / KT);
-        ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? baseA[plain_off<1>(g.A, m0 + row, k0 + kk)] : 0.f;
+        ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? ldf(baseA + plain_off<1>(g.A, m0 + row, k0 + kk)) : 0.f;
       }
     } else {
       const int row = tid % BM, kq = tid / BM;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         int kk = kq * A_KPT + j;
-        ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? baseA[plain_off<1>(g.A, m0 + row, k0 + kk)] : 0.f;
+        ra[j] = (m0 + row < g.M && k0 + kk < g.K) ? ldf(baseA + plain_off<1>(g.A, m0 + row, k0 + kk)) : 0.f;
       }
     }
     if (!B_IM2COL) {
       if (b_fast) {
-        plain_fetch<NB>(sb, baseB + (long)k0 * g.B.sr, klim, g.B.kfast, g.bvec, b_in && klim >= KT, rb);
+        plain_fetch<NB>(sb, baseB + (long)k0 * g.B.sr, klim, g.B.kfast, g.bvec, b_in && klim >= KT, rgb);
       } else if (g.B.kfast) {
         const int kk = tid % KT, c0 = tid / KT;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           int col = c0 + j * (256 / KT);
-          rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? baseB[plain_off<0>(g.B, k0 + kk, n0 + col)] : 0.f;
+          rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? ldf(baseB + plain_off<0>(g.B, k0 + kk, n0 + col)) : 0.f;
         }
       } else {
         const int col = tid % BN, kq = tid / BN;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           int kk = kq * B_KPT + j;
-          rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? baseB[plain_off<0>(g.B, k0 + kk, n0 + col)] : 0.f;
+          rb[j] = (n0 + col < g.N && k0 + kk < g.K) ? ldf(baseB + plain_off<0>(g.B, k0 + kk, n0 + col)) : 0.f;
         }
       }
     } else {
@@ -336,7 +417,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
             const bool ok = n_ok && (e + j < g.K) && iy >= 0 && iy < d.Hs && ix >= 0 && ix < d.Ws;
-            rb[j] = ok ? baseB[off] : 0.f;
+            rb[j] = ok ? ldf(baseB + off) : 0.f;
             ++kx; ix += dd; off += dsx;
             if (kx == d.KW) {
               kx = 0; ix -= d.KW * dd; off -= d.KW * dsx;
@@ -361,11 +442,27 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
   auto store_lds = [&]() __attribute__((always_inline)) {
     constexpr int LV = KT / 4, RV = 256 / LV;  // 16-byte form: lanes per row, rows per pass
     constexpr int RS = 256 / KT;               // scalar form: rows per pass
-    if (g.A.kfast) {
+    if (BF && sa.pair) {
+      // row pairs -> two k-contiguous runs of NA / 2 elements (one v_perm per dword)
+      const int row = 2 * (tid % (BM / 2)), kq = tid / (BM / 2);
+      unsigned lo[NA / 4 > 0 ? NA / 4 : 1], hi[NA / 4 > 0 ? NA / 4 : 1];
+#pragma unroll
+      for (int q = 0; q < NA / 4; ++q) {
+        lo[q] = pack_lo16(rga.u[2 * q], rga.u[2 * q + 1]);
+        hi[q] = pack_hi16(rga.u[2 * q], rga.u[2 * q + 1]);
+      }
+      memcpy(&As[row * P + kq * (NA / 2)], lo, NA);
+      memcpy(&As[(row + 1) * P + kq * (NA / 2)], hi, NA);
+    } else if (g.A.kfast) {
       if (g.avec) {
         const int k4 = (tid % LV) * 4, r0 = tid / LV;
+        if (BF) {
 #pragma unroll
-        for (int j = 0; j < NA / 4; ++j) lds_put<OpT, 4>(&As[(r0 + j * RV) * P + k4], &ra[4 * j]);
+          for (int j = 0; j < NA / 4; ++j) memcpy(&As[(r0 + j * RV) * P + k4], &rga.u[2 * j], 8);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NA / 4; ++j) lds_put<OpT, 4>(&As[(r0 + j * RV) * P + k4], &ra[4 * j]);
+        }
       } else {
         const int kk = tid % KT, r0 = tid / KT;
 #pragma unroll
@@ -375,11 +472,26 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
       const int row = tid % BM, kq = tid / BM;
       lds_put<OpT, NA>(&As[row * P + kq * A_KPT], ra);
     }
-    if (g.B.kfast) {
+    if (BF && !B_IM2COL && sb.pair) {
+      const int col = 2 * (tid % (BN / 2)), kq = tid / (BN / 2);
+      unsigned lo[NB / 4 > 0 ? NB / 4 : 1], hi[NB / 4 > 0 ? NB / 4 : 1];
+#pragma unroll
+      for (int q = 0; q < NB / 4; ++q) {
+        lo[q] = pack_lo16(rgb.u[2 * q], rgb.u[2 * q + 1]);
+        hi[q] = pack_hi16(rgb.u[2 * q], rgb.u[2 * q + 1]);
+      }
+      memcpy(&Bs[col * P + kq * (NB / 2)], lo, NB);
+      memcpy(&Bs[(col + 1) * P + kq * (NB / 2)], hi, NB);
+    } else if (g.B.kfast) {
       if (!B_IM2COL && g.bvec) {
         const int k4 = (tid % LV) * 4, c0 = tid / LV;
+        if (BF) {
 #pragma unroll
-        for (int j = 0; j < NB / 4; ++j) lds_put<OpT, 4>(&Bs[(c0 + j * RV) * P + k4], &rb[4 * j]);
+          for (int j = 0; j < NB / 4; ++j) memcpy(&Bs[(c0 + j * RV) * P + k4], &rgb.u[2 * j], 8);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NB / 4; ++j) lds_put<OpT, 4>(&Bs[(c0 + j * RV) * P + k4], &rb[4 * j]);
+        }
       } else {
         const int kk = tid % KT, c0 = tid / KT;
 #pragma unroll
@@ -441,7 +553,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
   // !SWAP: acc[i][j][r] = C[row = .. + fq*4 + r][col = .. + fr]   (4 consecutive rows per lane)
   //  SWAP: acc[i][j][r] = C[row = .. + fr][col = .. + fq*4 + r]   (4 consecutive columns per lane)
   const cenet_epi_t& E = g.E;
-  float* Cb = E.C + (long)bo * E.scb + (long)bi * E.scb2;
+  float* const Cf = (float*)E.C + (long)bo * E.scb + (long)bi * E.scb2;  // atomic epilogues: C is fp32 whatever OpT is
+  GT* const Cb = (GT*)E.C + (long)bo * E.scb + (long)bi * E.scb2;
   if (!SWAP && E.atomic && !E.cmode && E.scc == 1) {
     // split-K accumulation into a row-major C: float atomics reach their chip-wide rate only as 256 contiguous bytes per
     // wave instruction, but an MFMA accumulator register spans 4 rows x 16 floats.  Each wave therefore transposes one
@@ -459,12 +572,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
       const int row0 = m0 + wm * (BM / 2) + i * 16, col0 = n0 + wn * WN;
       for (int idx = lane; idx < 16 * WN; idx += 64) {
         const int r = idx / WN, c = idx - r * WN;
-        if (row0 + r < g.M && col0 + c < g.N) atomicAdd(&Cb[(long)(row0 + r) * E.scr + col0 + c], strip[r * (WN + 1) + c]);
+        if (row0 + r < g.M && col0 + c < g.N) atomicAdd(&Cf[(long)(row0 + r) * E.scr + col0 + c], strip[r * (WN + 1) + c]);
       }
     }
     return;
   }
-  const float* Rb = E.R ? E.R + (long)bo * E.srb + (long)bi * E.srb2 : nullptr;
+  const GT* Rb = E.R ? (const GT*)E.R + (long)bo * E.srb + (long)bi * E.srb2 : nullptr;
   const int bsr = E.bscale ? E.bscale_rows : 0;  // > 0: per-sample scale looked up by row (flat batch)
   const float bs = (E.bscale && bsr == 0) ? E.bscale[batch] : 1.f;
   const int rwave = m0 + wm * (BM / 2) + (SWAP ? fr : fq * 4);
@@ -475,8 +588,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
     // spends ~70 VALU instructions per fragment; on the K <= 128 GEMMs of stages 1-2 that made the epilogue the longest part
     // of the kernel)
     const float scale = E.alpha * bs;
-    float* crow = Cb + (long)rwave * E.scr + (long)cwave * E.scc;
-    const float* rrow = Rb ? Rb + (long)rwave * E.srr + (long)cwave * E.src : nullptr;
+    GT* crow = Cb + (long)rwave * E.scr + (long)cwave * E.scc;
+    const GT* rrow = Rb ? Rb + (long)rwave * E.srr + (long)cwave * E.src : nullptr;
     const long ci = 16 * E.scr, cj = 16 * E.scc, ri = 16 * E.srr, rj = 16 * E.src;
     const bool bias_vec = E.bias && (SWAP != (bool)E.bias_on_row) && (((uintptr_t)E.bias & 15) == 0);
 #pragma unroll
@@ -510,11 +623,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
         }
         if (rrow) {
           float rr[4];
-          memcpy(rr, rrow + i * ri + j * rj, 16);
+          ld4v(rr, rrow + i * ri + j * rj);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += rr[r];
         }
-        memcpy(crow + i * ci + j * cj, v, 16);
+        st4v(crow + i * ci + j * cj, v);
       }
     return;
   }
@@ -547,11 +660,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
           for (int r = 0; r < 4; ++r) v[r] *= bsr > 0 ? E.bscale[(SWAP ? rbase : rbase + r) / bsr] : bs;
           if (Rb) {
             float rr[4];
-            memcpy(rr, Rb + (long)rbase * E.srr + (long)cbase * E.src, 16);
+            ld4v(rr, Rb + (long)rbase * E.srr + (long)cbase * E.src);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rr[r];
           }
-          memcpy(Cb + (long)rbase * E.scr + (long)cbase * E.scc, v, 16);
+          st4v(Cb + (long)rbase * E.scr + (long)cbase * E.scc, v);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -560,8 +673,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
               float t = v[r];
               if (E.bias) t += E.bias[E.bias_on_row ? row : col];
               t *= bsr > 0 ? E.bscale[row / bsr] : bs;
-              if (Rb) t += Rb[(long)row * E.srr + (long)col * E.src];
-              Cb[(long)row * E.scr + (long)col * E.scc] = t;
+              if (Rb) t += ldf(Rb + (long)row * E.srr + (long)col * E.src);
+              stf(Cb + (long)row * E.scr + (long)col * E.scc, t);
             }
           }
         }
@@ -590,18 +703,18 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
           const int py = col / E.cPw, px = col - py * E.cPw;
           const int iy = py * E.cstride - E.cpad + ky, ix = px * E.cstride - E.cpad + kx;
           if (iy >= 0 && iy < E.cHs && ix >= 0 && ix < E.cWs) {
-            float* dst = &Cb[(long)ci * E.csci + (long)iy * E.csy + (long)ix * E.csx];
-            if (E.atomic) atomicAdd(dst, v);
-            else *dst = v;
+            const long o = (long)ci * E.csci + (long)iy * E.csy + (long)ix * E.csx;
+            if (E.atomic) atomicAdd(&Cf[o], v);
+            else stf(&Cb[o], v);
           }
         } else if (E.atomic) {
-          atomicAdd(&Cb[(long)row * E.scr + (long)col * E.scc], v);
+          atomicAdd(&Cf[(long)row * E.scr + (long)col * E.scc], v);
         } else {
           if (E.bias) v += E.bias[E.bias_on_row ? row : col];
           v = act_fwd(E.act, v, E.slope);
           v *= bsr > 0 ? E.bscale[row / bsr] : bs;
-          if (Rb) v += Rb[(long)row * E.srr + (long)col * E.src];
-          Cb[(long)row * E.scr + (long)col * E.scc] = v;
+          if (Rb) v += ldf(Rb + (long)row * E.srr + (long)col * E.src);
+          stf(&Cb[(long)row * E.scr + (long)col * E.scc], v);
         }
       }
     }

@@ -14,7 +14,8 @@
 
 // acc layout: [0..K) intersect, [K..2K) z_sum (p^2), [2K..3K) y_sum (t), [3K] ce_sum, [3K+1..4K+1) boundary pixel counts
 // (BoundaryDoULoss, core.py:105-109), and after finalize [4K+1..5K+1) the per-class alpha of core.py:112-119
-__global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+template <typename T>
+__global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ labels,
                                                          float* __restrict__ acc, int K, int HW, long npix, int W,
                                                          int boundary) {
   __shared__ float red[16];
@@ -27,13 +28,13 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const float* __restric
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
     const long b = e / HW;
     const int p = (int)(e - b * HW);
-    const float* lp = logits + b * (long)K * HW + p;
+    const T* lp = logits + b * (long)K * HW + p;
     float v[LOSS_MAXK];
     float mx = -3.4e38f;
 #pragma unroll
     for (int c = 0; c < LOSS_MAXK; ++c)
       if (c < K) {
-        v[c] = lp[(long)c * HW];
+        v[c] = ldf(lp + (long)c * HW);
         mx = fmaxf(mx, v[c]);
       }
     float s = 0.f;
@@ -105,9 +106,10 @@ __global__ void dice_ce_finalize_kernel(float* __restrict__ acc, float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+template <typename T>
+__global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ labels,
                                                          const float* __restrict__ acc, const float* __restrict__ gout,
-                                                         float* __restrict__ dlogits, int K, int HW, long npix, float w_dice,
+                                                         T* __restrict__ dlogits, int K, int HW, long npix, float w_dice,
                                                          float w_ce, float w_bd) {
   const float go = gout[0];
   float A[LOSS_MAXK], Bc[LOSS_MAXK];  // dL/dp_c = A_c * t_c + Bc_c * p_c
@@ -130,14 +132,14 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const float* __restric
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
     const long b = e / HW;
     const int p = (int)(e - b * HW);
-    const float* lp = logits + b * (long)K * HW + p;
-    float* dp = dlogits + b * (long)K * HW + p;
+    const T* lp = logits + b * (long)K * HW + p;
+    T* dp = dlogits + b * (long)K * HW + p;
     float v[LOSS_MAXK];
     float mx = -3.4e38f;
 #pragma unroll
     for (int c = 0; c < LOSS_MAXK; ++c)
       if (c < K) {
-        v[c] = lp[(long)c * HW];
+        v[c] = ldf(lp + (long)c * HW);
         mx = fmaxf(mx, v[c]);
       }
     float s = 0.f;
@@ -160,14 +162,15 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const float* __restric
       }
 #pragma unroll
     for (int c = 0; c < LOSS_MAXK; ++c)
-      if (c < K) dp[(long)c * HW] = go * (v[c] * (gp[c] - dot) + cew * (v[c] - (c == t ? 1.f : 0.f)));
+      if (c < K) stf(dp + (long)c * HW, go * (v[c] * (gp[c] - dot) + cew * (v[c] - (c == t ? 1.f : 0.f))));
   }
 }
 
 // p -= lr * buf, buf = momentum*buf + (g*gscale + wd*p)   (first step: buf = g*gscale + wd*p)
 // hyper (device): [lr, momentum, weight_decay, gscale, first_step_flag]
+// shadow (may be NULL): bf16 copy of the updated parameters, the operand the throughput-mode GEMMs read
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                 const float* __restrict__ hyper, long n) {
+                                                 const float* __restrict__ hyper, long n, bf16_t* __restrict__ shadow) {
   const float lr = hyper[0], mom = hyper[1], wd = hyper[2], gs = hyper[3];
   const bool first = hyper[4] != 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -175,8 +178,18 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     const float d = g[i] * gs + wd * pv;
     const float bv = first ? d : mom * buf[i] + d;
     buf[i] = bv;
-    p[i] = pv - lr * bv;
+    const float pn = pv - lr * bv;
+    p[i] = pn;
+    if (shadow) shadow[i] = (bf16_t)cenet_f2bf(pn);
   }
+}
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) stf(y + i, ldf(x + i));
+}
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast4_kernel(const TI* __restrict__ x, TO* __restrict__ y, long nq) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long)gridDim.x * 256) st4(y + 4 * i, ld4(x + 4 * i));
 }
 
 __global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ p, long n) {
@@ -192,48 +205,85 @@ int cenet_zero_async(float* p, long n, hipStream_t stream) {
 }
 
 // loss = w_dice * Dice + w_ce * CE + w_bd * BoundaryDoU, all from one pass over the logits (labels [B,H,W] as floats)
-extern "C" int cenet_seg_loss_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int H,
-                                      int W, float w_dice, float w_ce, float w_bd, hipStream_t stream) {
+template <typename T>
+static int seg_loss_fwd_impl(const T* logits, const float* labels, float* acc, float* loss, int B, int K, int H, int W,
+                             float w_dice, float w_ce, float w_bd, hipStream_t stream) {
   if (B <= 0 || K <= 0 || K > LOSS_MAXK || H <= 0 || W <= 0) return CENET_EINVAL;
   if (cenet_zero_async(acc, (long)LOSS_SLOTS * LOSS_SLOT_STRIDE, stream) != CENET_OK) return CENET_EINVAL;
   const int HW = H * W;
   const long npix = (long)B * HW;
   long blocks = (npix + 2047) / 2048;
   if (blocks > 1024) blocks = 1024;
-  CENET_LAUNCH(dice_ce_fwd_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W,
+  CENET_LAUNCH((dice_ce_fwd_kernel<T>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W,
                (int)(w_bd != 0.f));
   CENET_LAUNCH(dice_ce_finalize_kernel, dim3(1), dim3(128), stream, acc, loss, K, (float)npix, w_dice, w_ce, w_bd);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_seg_loss_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout,
-                                      float* dlogits, int B, int K, int H, int W, float w_dice, float w_ce, float w_bd,
-                                      hipStream_t stream) {
+CENET_TWIN(seg_loss_fwd, (const T* logits, const float* labels, float* acc, float* loss, int B, int K, int H, int W, float w_dice,
+                          float w_ce, float w_bd, hipStream_t stream),
+           (logits, labels, acc, loss, B, K, H, W, w_dice, w_ce, w_bd, stream))
+
+template <typename T>
+static int seg_loss_bwd_impl(const T* logits, const float* labels, const float* acc, const float* gout, T* dlogits, int B, int K,
+                             int H, int W, float w_dice, float w_ce, float w_bd, hipStream_t stream) {
   if (B <= 0 || K <= 0 || K > LOSS_MAXK || H <= 0 || W <= 0) return CENET_EINVAL;
   const int HW = H * W;
   const long npix = (long)B * HW;
   long blocks = (npix + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  CENET_LAUNCH(dice_ce_bwd_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix,
-               w_dice, w_ce, w_bd);
+  CENET_LAUNCH((dice_ce_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW,
+               npix, w_dice, w_ce, w_bd);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(seg_loss_bwd, (const T* logits, const float* labels, const float* acc, const float* gout, T* dlogits, int B, int K,
+                          int H, int W, float w_dice, float w_ce, float w_bd, hipStream_t stream),
+           (logits, labels, acc, gout, dlogits, B, K, H, W, w_dice, w_ce, w_bd, stream))
+
 extern "C" int cenet_dice_ce_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int HW,
                                      float w_dice, float w_ce, hipStream_t stream) {
-  return cenet_seg_loss_fwd_f32(logits, labels, acc, loss, B, K, 1, HW, w_dice, w_ce, 0.f, stream);
+  return seg_loss_fwd_impl<float>(logits, labels, acc, loss, B, K, 1, HW, w_dice, w_ce, 0.f, stream);
 }
 extern "C" int cenet_dice_ce_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout,
                                      float* dlogits, int B, int K, int HW, float w_dice, float w_ce, hipStream_t stream) {
-  return cenet_seg_loss_bwd_f32(logits, labels, acc, gout, dlogits, B, K, 1, HW, w_dice, w_ce, 0.f, stream);
+  return seg_loss_bwd_impl<float>(logits, labels, acc, gout, dlogits, B, K, 1, HW, w_dice, w_ce, 0.f, stream);
 }
-extern "C" int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, hipStream_t stream) {
+static int sgd_launch(float* p, const float* g, float* buf, const float* hyper5, long n, bf16_t* shadow, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
   long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  CENET_LAUNCH(sgd_kernel, dim3((unsigned)blocks), dim3(256), stream, p, g, buf, hyper5, n);
+  CENET_LAUNCH(sgd_kernel, dim3((unsigned)blocks), dim3(256), stream, p, g, buf, hyper5, n, shadow);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
+}
+extern "C" int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, hipStream_t stream) {
+  return sgd_launch(p, g, buf, hyper5, n, nullptr, stream);
+}
+extern "C" int cenet_sgd_step_shadow_f32(float* p, const float* g, float* buf, const float* hyper5, long n,
+                                         unsigned short* shadow_bf16, hipStream_t stream) {
+  return sgd_launch(p, g, buf, hyper5, n, shadow_bf16, stream);
+}
+template <typename TI, typename TO>
+static int cast_launch(const TI* x, TO* y, long n, hipStream_t stream) {
+  if (n <= 0) return CENET_EINVAL;
+  if ((n & 3) == 0 && quad_aligned<TI>(x) && quad_aligned<TO>(y)) {
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    CENET_LAUNCH((cast4_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), stream, x, y, n / 4);
+  } else {
+    long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    CENET_LAUNCH((cast_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), stream, x, y, n);
+  }
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_cast_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t stream) {
+  return cast_launch<float, bf16_t>(x, y, n, stream);
+}
+extern "C" int cenet_cast_bf16_to_f32(const unsigned short* x, float* y, long n, hipStream_t stream) {
+  return cast_launch<bf16_t, float>(x, y, n, stream);
 }
 extern "C" int cenet_zero_f32(float* p, long n, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
@@ -243,7 +293,8 @@ extern "C" int cenet_zero_f32(float* p, long n, hipStream_t stream) {
 // ---- evaluation: argmax mask + overlap counts (main_acdc.py:218-231, metrics_eval.py:24-34,46-49) ---------------------
 // pred[b,p] = argmax_c logits[b,c,p] (first maximum, like torch.argmax; softmax is monotone so it is skipped);
 // counts[c][0..2] = #(pred==c & gt==c), #(pred==c), #(gt==c) for c < K, and row K = the binary masks pred>0 / gt>0.
-__global__ __launch_bounds__(256) void argmax_counts_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_counts_kernel(const T* __restrict__ logits, const float* __restrict__ labels,
                                                            float* __restrict__ pred, unsigned* __restrict__ counts, int K,
                                                            int HW, long npix) {
   __shared__ unsigned sc[(LOSS_MAXK + 1) * 3];
@@ -252,11 +303,11 @@ __global__ __launch_bounds__(256) void argmax_counts_kernel(const float* __restr
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
     const long b = e / HW;
     const int p = (int)(e - b * HW);
-    const float* lp = logits + b * (long)K * HW + p;
-    float best = lp[0];
+    const T* lp = logits + b * (long)K * HW + p;
+    float best = ldf(lp);
     int arg = 0;
     for (int c = 1; c < K; ++c) {
-      const float v = lp[(long)c * HW];
+      const float v = ldf(lp + (long)c * HW);
       if (v > best) {
         best = v;
         arg = c;
@@ -279,14 +330,17 @@ __global__ __launch_bounds__(256) void argmax_counts_kernel(const float* __restr
       if (sc[i]) atomicAdd(&counts[i], sc[i]);
 }
 
-extern "C" int cenet_argmax_counts_f32(const float* logits, const float* labels, float* pred, unsigned* counts, int B, int K,
-                                       int HW, hipStream_t stream) {
+template <typename T>
+static int argmax_counts_impl(const T* logits, const float* labels, float* pred, unsigned* counts, int B, int K, int HW,
+                              hipStream_t stream) {
   if (!logits || B <= 0 || K <= 0 || K > LOSS_MAXK || HW <= 0 || (labels && !counts)) return CENET_EINVAL;
   const long npix = (long)B * HW;
   if (labels && cenet_zero_async((float*)counts, (K + 1) * 3L, stream) != CENET_OK) return CENET_EINVAL;
   long blocks = (npix + 2047) / 2048;
   if (blocks > 256) blocks = 256;
-  CENET_LAUNCH(argmax_counts_kernel, dim3((unsigned)blocks), dim3(256), stream, logits, labels, pred, counts, K, HW, npix);
+  CENET_LAUNCH((argmax_counts_kernel<T>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, pred, counts, K, HW, npix);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(argmax_counts, (const T* logits, const float* labels, float* pred, unsigned* counts, int B, int K, int HW,
+                           hipStream_t stream), (logits, labels, pred, counts, B, K, HW, stream))

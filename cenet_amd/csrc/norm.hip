@@ -1,7 +1,8 @@
 // norm.hip — LayerNorm (token layout) and train-mode BatchNorm (NCHW planes) forward/backward.
 //   LayerNorm : pvtv2.py:117,124,166,69,221-245 (eps 1e-6 in blocks, 1e-5 in patch-embed / sr norm)
 //   BatchNorm : cfam.py:22-32, blocks.py:151,161,212,307, nlb.py:81, unet.py:175-197, cfam.py:92,250
-// All statistics in fp32; BN batch statistics use per-channel shifted sums (shift = first element) so that
+// Kernels are templates over the activation storage type T (float / bf16_t, common.h); gamma / beta / statistics / parameter
+// gradients are fp32.  All statistics in fp32; BN batch statistics use per-channel shifted sums (shift = first element) so that
 // E[x^2]-E[x]^2 does not cancel; partial sums from several workgroups per channel meet in float atomics.
 #include "common.h"
 #include "../../include/cenet_hip.h"
@@ -9,25 +10,26 @@
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, 4 rows per 256-thread workgroup.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ y,
                                                            float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                            int C, float eps) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;  // wave-uniform
-  const float* xr = x + row * C;
+  const T* xr = x + row * C;
   float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += xr[c];
+  for (int c = lane; c < C; c += 64) s += ldf(xr + c);
   const float mu = wave_sum(s) / C;
   float v = 0.f;
   for (int c = lane; c < C; c += 64) {
-    float d = xr[c] - mu;
+    float d = ldf(xr + c) - mu;
     v += d * d;
   }
   const float rs = rsqrtf(wave_sum(v) / C + eps);
-  float* yr = y + row * C;
-  for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mu) * rs * gamma[c] + beta[c];
+  T* yr = y + row * C;
+  for (int c = lane; c < C; c += 64) stf(yr + c, (ldf(xr + c) - mu) * rs * gamma[c] + beta[c]);
   if (lane == 0) {
     mean[row] = mu;
     rstd[row] = rs;
@@ -37,12 +39,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // LayerNorm backward.  MAXJ = columns per lane (C <= 64*MAXJ); each wave walks its rows RPI at a time (independent
 // load -> reduce -> store chains in flight together), column partials of dgamma/dbeta stay in registers and meet in LDS.
 #define LN_ROWS_PER_BLOCK 64
-template <int MAXJ, int RPI>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T, int MAXJ, int RPI>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, float* __restrict__ dx,
+                                                           const float* __restrict__ rstd, T* __restrict__ dx,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int rows, int C, const float* __restrict__ dx_add) {
+                                                           int rows, int C, const T* __restrict__ dx_add) {
   __shared__ float red[2][4][MAXJ * 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float dg[MAXJ], db[MAXJ], gm[MAXJ];
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       for (int j = 0; j < MAXJ; ++j) {
         int c = lane + 64 * j;
         if (rok && c < C) {
-          xh[q][j] = (x[row * C + c] - mu) * rs[q];
-          g[q][j] = dy[row * C + c];
+          xh[q][j] = (ldf(x + row * C + c) - mu) * rs[q];
+          g[q][j] = ldf(dy + row * C + c);
         } else {
           xh[q][j] = 0.f;
           g[q][j] = 0.f;
@@ -93,7 +95,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
           int c = lane + 64 * j;
-          if (c < C) dx[row * C + c] = rs[q] * (g[q][j] * gm[j] - s1[q] - xh[q][j] * s2[q]) + (dx_add ? dx_add[row * C + c] : 0.f);
+          if (c < C)
+            stf(dx + row * C + c,
+                rs[q] * (g[q][j] * gm[j] - s1[q] - xh[q][j] * s2[q]) + (dx_add ? ldf(dx_add + row * C + c) : 0.f));
         }
       }
     }
@@ -121,19 +125,10 @@ __device__ __forceinline__ float subrow_sum(float v) {
   for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-struct f4 {
-  float v[4];
-};
-__device__ __forceinline__ f4 ld4(const float* p) {
-  f4 r;
-  memcpy(r.v, p, 16);
-  return r;
-}
-__device__ __forceinline__ void st4(float* p, const f4& r) { memcpy(p, r.v, 16); }
 
-template <int LPR, int NP>
-__global__ __launch_bounds__(256) void ln_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ y,
+template <typename T, int LPR, int NP>
+__global__ __launch_bounds__(256) void ln_fwd_v4_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, T* __restrict__ y,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int rows, int C,
                                                        float eps, int steps) {
   constexpr int RPW = 64 / LPR;
@@ -196,12 +191,12 @@ __global__ __launch_bounds__(256) void ln_fwd_v4_kernel(const float* __restrict_
   }
 }
 
-template <int LPR, int NP>
-__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T, int LPR, int NP>
+__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, float* __restrict__ dx,
+                                                       const float* __restrict__ rstd, T* __restrict__ dx,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                       int steps, const float* __restrict__ dx_add) {
+                                                       int steps, const T* __restrict__ dx_add) {
   constexpr int RPW = 64 / LPR;
   __shared__ float red[2][4][NP * LPR * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, l = lane % LPR;
@@ -283,8 +278,11 @@ __global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict_
   }
 }
 
+// activation pointers a, b (quads of T) and parameter pointers c, d (quads of float)
+template <typename T>
 static inline bool ln_v4_ok(const void* a, const void* b, const void* c, const void* d, int C) {
-  return (C & 3) == 0 && C <= 512 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0);
+  return (C & 3) == 0 && C <= 512 && ((((uintptr_t)a | (uintptr_t)b) & (4 * sizeof(T) - 1)) == 0) &&
+         ((((uintptr_t)c | (uintptr_t)d) & 15) == 0);
 }
 // rows per workgroup step = 4 * 64 / LPR; steps per workgroup chosen to keep >= ~1024 workgroups while amortising the
 // per-workgroup column reduction of the backward pass
@@ -295,14 +293,15 @@ static inline int ln_steps(int rows, int rows_per_step) {
   return (int)st;
 }
 
-extern "C" int cenet_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                       float* rstd, int rows, int C, float eps, hipStream_t stream) {
+template <typename T>
+static int layernorm_fwd_impl(const T* x, const float* gamma, const float* beta, T* y, float* mean, float* rstd, int rows, int C,
+                              float eps, hipStream_t stream) {
   if (rows <= 0 || C <= 0) return CENET_EINVAL;
-  if (ln_v4_ok(x, gamma, beta, y, C)) {
+  if (ln_v4_ok<T>(x, y, gamma, beta, C)) {
 #define CENET_LNF(LPRv, NPv)                                                                                          \
   {                                                                                                                   \
     const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps);                                                          \
-    CENET_LAUNCH((ln_fwd_v4_kernel<LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, x, gamma, beta, y, mean, rstd, \
+    CENET_LAUNCH((ln_fwd_v4_kernel<T, LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, x, gamma, beta, y, mean, rstd, \
                  rows, C, eps, st);                                                                                   \
   }
     if (C <= 64) CENET_LNF(16, 1)
@@ -311,22 +310,25 @@ extern "C" int cenet_layernorm_fwd_f32(const float* x, const float* gamma, const
     else CENET_LNF(64, 2)
 #undef CENET_LNF
   } else {
-    CENET_LAUNCH(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+    CENET_LAUNCH((layernorm_fwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(layernorm_fwd, (const T* x, const float* gamma, const float* beta, T* y, float* mean, float* rstd, int rows, int C,
+                           float eps, hipStream_t stream), (x, gamma, beta, y, mean, rstd, rows, C, eps, stream))
 
-extern "C" int cenet_layernorm_bwd_add_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean,
-                                               const float* rstd, const float* dx_add, float* dx, float* dgamma_acc,
-                                               float* dbeta_acc, int rows, int C, hipStream_t stream) {
+template <typename T>
+static int layernorm_bwd_add_acc_impl(const T* dy, const T* x, const float* gamma, const float* mean, const float* rstd,
+                                      const T* dx_add, T* dx, float* dgamma_acc, float* dbeta_acc, int rows, int C,
+                                      hipStream_t stream) {
   if (rows <= 0 || C <= 0) return CENET_EINVAL;
   if (C > 512) return CENET_EUNSUPPORTED;
-  if (ln_v4_ok(dy, x, gamma, dx, C) && (((uintptr_t)dx_add & 15) == 0)) {
+  if (ln_v4_ok<T>(dy, x, gamma, gamma, C) && quad_aligned<T>(dx) && quad_aligned<T>(dx_add)) {
 #define CENET_LNB(LPRv, NPv)                                                                                          \
   {                                                                                                                   \
     const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps);                                                          \
-    CENET_LAUNCH((ln_bwd_v4_kernel<LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, \
+    CENET_LAUNCH((ln_bwd_v4_kernel<T, LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, \
                  dgamma_acc, dbeta_acc, rows, C, st, dx_add);                                                         \
   }
     if (C <= 64) CENET_LNB(16, 1)
@@ -339,7 +341,7 @@ extern "C" int cenet_layernorm_bwd_add_acc_f32(const float* dy, const float* x, 
   }
   dim3 grid(cdiv(rows, LN_ROWS_PER_BLOCK));
 #define CENET_LN(MJ, RP)                                                                                            \
-  CENET_LAUNCH((layernorm_bwd_kernel<MJ, RP>), grid, dim3(256), stream, dy, x, gamma, mean, rstd, dx, dgamma_acc, dbeta_acc, \
+  CENET_LAUNCH((layernorm_bwd_kernel<T, MJ, RP>), grid, dim3(256), stream, dy, x, gamma, mean, rstd, dx, dgamma_acc, dbeta_acc, \
                rows, C, dx_add)
   if (C <= 64) { CENET_LN(1, 4); }
   else if (C <= 128) { CENET_LN(2, 4); }
@@ -350,28 +352,36 @@ extern "C" int cenet_layernorm_bwd_add_acc_f32(const float* dy, const float* x, 
   return CENET_OK;
 }
 
-extern "C" int cenet_layernorm_bwd_acc_f32(const float* dy, const float* x, const float* gamma, const float* mean,
-                                           const float* rstd, float* dx, float* dgamma_acc, float* dbeta_acc, int rows,
-                                           int C, hipStream_t stream) {
-  return cenet_layernorm_bwd_add_acc_f32(dy, x, gamma, mean, rstd, nullptr, dx, dgamma_acc, dbeta_acc, rows, C, stream);
+CENET_TWIN(layernorm_bwd_add_acc, (const T* dy, const T* x, const float* gamma, const float* mean, const float* rstd,
+                                   const T* dx_add, T* dx, float* dgamma_acc, float* dbeta_acc, int rows, int C,
+                                   hipStream_t stream),
+           (dy, x, gamma, mean, rstd, dx_add, dx, dgamma_acc, dbeta_acc, rows, C, stream))
+template <typename T>
+static int layernorm_bwd_acc_impl(const T* dy, const T* x, const float* gamma, const float* mean, const float* rstd, T* dx,
+                                  float* dgamma_acc, float* dbeta_acc, int rows, int C, hipStream_t stream) {
+  return layernorm_bwd_add_acc_impl<T>(dy, x, gamma, mean, rstd, nullptr, dx, dgamma_acc, dbeta_acc, rows, C, stream);
 }
+CENET_TWIN(layernorm_bwd_acc, (const T* dy, const T* x, const float* gamma, const float* mean, const float* rstd, T* dx,
+                               float* dgamma_acc, float* dbeta_acc, int rows, int C, hipStream_t stream),
+           (dy, x, gamma, mean, rstd, dx, dgamma_acc, dbeta_acc, rows, C, stream))
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm (training): statistics over (B, HW) per channel of x[b*sb + c*HW + p].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, long sb, int B, int HW,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, long sb, int B, int HW,
                                                         float* __restrict__ ws) {
   __shared__ float red[16];
   const int c = blockIdx.x;
-  const float* xc = x + (long)c * HW;
-  const float shift = xc[0];
+  const T* xc = x + (long)c * HW;
+  const float shift = ldf(xc);
   const long total = (long)B * HW;
   float s1 = 0.f, s2 = 0.f;
   for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
   for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
            pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
        p < pend__; p += 256) {
-    float v = xc[(long)b * sb + p] - shift;
+    float v = ldf(xc + (long)b * sb + p) - shift;
     s1 += v;
     s2 += v * v;
   }
@@ -383,12 +393,13 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ x, int HW, const float* __restrict__ ws, int C, int S, float n,
+template <typename T>
+__global__ void bn_finalize_kernel(const T* __restrict__ x, int HW, const float* __restrict__ ws, int C, int S, float n,
                                    float* __restrict__ mean, float* __restrict__ var, float* running_mean,
                                    float* running_var, float momentum, long* nbt) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
-    float shift = x[(long)c * HW];
+    float shift = ldf(x + (long)c * HW);
     float a1 = 0.f, a2 = 0.f;
     for (int i = 0; i < S; ++i) {
       a1 += ws[(long)c * S + i];
@@ -409,7 +420,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, int HW, const fl
 }
 
 // y = act(gamma*(x-mean)*rsqrt(var+eps)+beta); grid (B*C, chunks)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, long sxb, float* __restrict__ y, long syb,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y, long syb,
                                                       const float* __restrict__ mean, const float* __restrict__ var,
                                                       float eps, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int act, float slope, int C, int HW) {
@@ -417,14 +429,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   const int b = bc / C, c = bc - b * C;
   const float sc = gamma[c] * rsqrtf(var[c] + eps);
   const float sh = beta[c] - mean[c] * sc;
-  const float* xp = x + (long)b * sxb + (long)c * HW;
-  float* yp = y + (long)b * syb + (long)c * HW;
-  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) yp[p] = act_fwd(act, xp[p] * sc + sh, slope);
+  const T* xp = x + (long)b * sxb + (long)c * HW;
+  T* yp = y + (long)b * syb + (long)c * HW;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) stf(yp + p, act_fwd(act, ldf(xp + p) * sc + sh, slope));
 }
 
 // partial sums of g' = dy*act'(pre) and g'*xhat per channel
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, long sgb,
-                                                            const float* __restrict__ x, long sxb,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dy, long sgb,
+                                                            const T* __restrict__ x, long sxb,
                                                             const float* __restrict__ mean, const float* __restrict__ var,
                                                             float eps, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int act, float slope, int B,
@@ -438,8 +451,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
            pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
        p < pend__; p += 256) {
-    float xh = (x[(long)b * sxb + (long)c * HW + p] - mu) * rs;
-    float g = dy[(long)b * sgb + (long)c * HW + p];
+    float xh = (ldf(x + (long)b * sxb + (long)c * HW + p) - mu) * rs;
+    float g = ldf(dy + (long)b * sgb + (long)c * HW + p);
     if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
     s1 += g;
     s2 += g * xh;
@@ -452,8 +465,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, long sgb, const float* __restrict__ x,
-                                                          long sxb, float* __restrict__ dx, long sdb,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, long sgb, const T* __restrict__ x,
+                                                          long sxb, T* __restrict__ dx, long sdb,
                                                           const float* __restrict__ mean, const float* __restrict__ var,
                                                           float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int act, float slope, int C, int HW,
@@ -470,14 +484,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
   const float s1 = block_sum(p1, red), s2 = block_sum(p2, red);
   const float m1 = s1 / n, m2 = s2 / n;
-  const float* xp = x + (long)b * sxb + (long)c * HW;
-  const float* gp = dy + (long)b * sgb + (long)c * HW;
-  float* dp = dx + (long)b * sdb + (long)c * HW;
+  const T* xp = x + (long)b * sxb + (long)c * HW;
+  const T* gp = dy + (long)b * sgb + (long)c * HW;
+  T* dp = dx + (long)b * sdb + (long)c * HW;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) {
-    float xh = (xp[p] - mu) * rs;
-    float g = gp[p];
+    float xh = (ldf(xp + p) - mu) * rs;
+    float g = ldf(gp + p);
     if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
-    dp[p] = gm * rs * (g - m1 - xh * m2);
+    stf(dp + p, gm * rs * (g - m1 - xh * m2));
   }
   if (b == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     atomicAdd(&dgamma[c], s2);
@@ -487,12 +501,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // ---- 16-byte BatchNorm kernels (HW % 4 == 0, 16-byte aligned planes) -----------------------------------------------------
 // Reductions walk the channel's B*HW/4 quads flat (grid-stride, four independent 16-byte loads in flight per thread).
-__global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restrict__ x, long sb, int B, int HW,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* __restrict__ x, long sb, int B, int HW,
                                                            float* __restrict__ ws) {
   __shared__ float red[16];
   const int c = blockIdx.x, nq = HW >> 2;
-  const float* xc = x + (long)c * HW;
-  const float shift = xc[0];
+  const T* xc = x + (long)c * HW;
+  const float shift = ldf(xc);
   const int total = B * nq, stride = gridDim.y * 256;
   float s1 = 0.f, s2 = 0.f;
   for (int q0 = blockIdx.y * 256 + threadIdx.x; q0 < total; q0 += 4 * stride) {
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
       const int q = q0 + u * stride;
       if (q < total) {
         const int b = q / nq, qi = q - b * nq;
-        memcpy(v[u], xc + (long)b * sb + 4 * qi, 16);
+        ld4v(v[u], xc + (long)b * sb + 4 * qi);
       } else {
         v[u][0] = v[u][1] = v[u][2] = v[u][3] = shift;
       }
@@ -524,7 +539,8 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restrict__ x, long sxb, float* __restrict__ y, long syb,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_v4_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y, long syb,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          float eps, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, int act, float slope, int C, int HW) {
@@ -532,20 +548,21 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restric
   const int b = bc / C, c = bc - b * C;
   const float sc = gamma[c] * rsqrtf(var[c] + eps);
   const float sh = beta[c] - mean[c] * sc;
-  const float* xp = x + (long)b * sxb + (long)c * HW;
-  float* yp = y + (long)b * syb + (long)c * HW;
+  const T* xp = x + (long)b * sxb + (long)c * HW;
+  T* yp = y + (long)b * syb + (long)c * HW;
   const int nq = HW >> 2;
   for (int q = blockIdx.y * blockDim.x + threadIdx.x; q < nq; q += gridDim.y * blockDim.x) {
     float v[4];
-    memcpy(v, xp + 4 * q, 16);
+    ld4v(v, xp + 4 * q);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_fwd(act, v[e] * sc + sh, slope);
-    memcpy(yp + 4 * q, v, 16);
+    st4v(yp + 4 * q, v);
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __restrict__ dy, long sgb,
-                                                               const float* __restrict__ x, long sxb,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const T* __restrict__ dy, long sgb,
+                                                               const T* __restrict__ x, long sxb,
                                                                const float* __restrict__ mean, const float* __restrict__ var,
                                                                float eps, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int act, float slope, int B,
@@ -562,8 +579,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
       const int q = q0 + u * stride;
       if (q < total) {
         const int b = q / nq, qi = q - b * nq;
-        memcpy(xv[u], x + (long)b * sxb + (long)c * HW + 4 * qi, 16);
-        memcpy(gv[u], dy + (long)b * sgb + (long)c * HW + 4 * qi, 16);
+        ld4v(xv[u], x + (long)b * sxb + (long)c * HW + 4 * qi);
+        ld4v(gv[u], dy + (long)b * sgb + (long)c * HW + 4 * qi);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -591,8 +608,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ dy, long sgb, const float* __restrict__ x,
-                                                             long sxb, float* __restrict__ dx, long sdb,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* __restrict__ dy, long sgb, const T* __restrict__ x,
+                                                             long sxb, T* __restrict__ dx, long sdb,
                                                              const float* __restrict__ mean, const float* __restrict__ var,
                                                              float eps, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act, float slope, int C,
@@ -609,14 +627,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
   }
   const float s1 = block_sum(p1, red), s2 = block_sum(p2, red);
   const float m1 = s1 / n, m2 = s2 / n;
-  const float* xp = x + (long)b * sxb + (long)c * HW;
-  const float* gp = dy + (long)b * sgb + (long)c * HW;
-  float* dp = dx + (long)b * sdb + (long)c * HW;
+  const T* xp = x + (long)b * sxb + (long)c * HW;
+  const T* gp = dy + (long)b * sgb + (long)c * HW;
+  T* dp = dx + (long)b * sdb + (long)c * HW;
   const int nq = HW >> 2;
   for (int q = blockIdx.y * blockDim.x + threadIdx.x; q < nq; q += gridDim.y * blockDim.x) {
     float xv[4], gv[4];
-    memcpy(xv, xp + 4 * q, 16);
-    memcpy(gv, gp + 4 * q, 16);
+    ld4v(xv, xp + 4 * q);
+    ld4v(gv, gp + 4 * q);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float xh = (xv[e] - mu) * rs;
@@ -624,7 +642,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
       if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
       gv[e] = gm * rs * (g - m1 - xh * m2);
     }
-    memcpy(dp + 4 * q, gv, 16);
+    st4v(dp + 4 * q, gv);
   }
   if (b == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     atomicAdd(&dgamma[c], s2);
@@ -632,8 +650,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
   }
 }
 
+template <typename T>
 static inline bool bn_v4_ok(int HW, const void* p0, long s0, const void* p1, long s1, const void* p2, long s2) {
-  return (HW & 3) == 0 && ((s0 | s1 | s2) & 3) == 0 && ((((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0);
+  return (HW & 3) == 0 && ((s0 | s1 | s2) & 3) == 0 &&
+         ((((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & (4 * sizeof(T) - 1)) == 0);
 }
 // threads per plane workgroup and plane chunks of the element-wise passes (nq = quads per plane)
 static inline void bn_plane_launch(int nq, int* threads, int* chunks) {
@@ -663,67 +683,78 @@ static inline int bn_splits(int C, long total) {
   return (int)want;
 }
 
-extern "C" int cenet_bn_stats_f32(const float* x, long sb, int B, int C, int HW, float* ws, float* mean, float* var,
-                                  float* running_mean, float* running_var, float momentum, long* num_batches_tracked,
-                                  hipStream_t stream) {
+template <typename T>
+static int bn_stats_impl(const T* x, long sb, int B, int C, int HW, float* ws, float* mean, float* var, float* running_mean,
+                         float* running_var, float momentum, long* num_batches_tracked, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   const long total = (long)B * HW;
   int S;
-  if (bn_v4_ok(HW, x, sb, x, sb, x, sb)) {
+  if (bn_v4_ok<T>(HW, x, sb, x, sb, x, sb)) {
     S = bn_splits_v4(C, total / 4);
-    CENET_LAUNCH(bn_partial_v4_kernel, dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
+    CENET_LAUNCH((bn_partial_v4_kernel<T>), dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
   } else {
     S = bn_splits(C, total);
-    CENET_LAUNCH(bn_partial_kernel, dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
+    CENET_LAUNCH((bn_partial_kernel<T>), dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
   }
-  CENET_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), stream, x, HW, (const float*)ws, C, S, (float)total, mean, var,
-               running_mean, running_var, momentum, num_batches_tracked);
+  CENET_LAUNCH((bn_finalize_kernel<T>), dim3(cdiv(C, 64)), dim3(64), stream, x, HW, (const float*)ws, C, S, (float)total, mean,
+               var, running_mean, running_var, momentum, num_batches_tracked);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(bn_stats, (const T* x, long sb, int B, int C, int HW, float* ws, float* mean, float* var, float* running_mean,
+                      float* running_var, float momentum, long* num_batches_tracked, hipStream_t stream),
+           (x, sb, B, C, HW, ws, mean, var, running_mean, running_var, momentum, num_batches_tracked, stream))
 
-extern "C" int cenet_bn_apply_f32(const float* x, long sxb, float* y, long syb, const float* mean, const float* var,
-                                  float eps, const float* gamma, const float* beta, int act, float slope, int B, int C,
-                                  int HW, hipStream_t stream) {
+template <typename T>
+static int bn_apply_impl(const T* x, long sxb, T* y, long syb, const float* mean, const float* var, float eps,
+                         const float* gamma, const float* beta, int act, float slope, int B, int C, int HW,
+                         hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  if (bn_v4_ok(HW, x, sxb, y, syb, x, sxb)) {
+  if (bn_v4_ok<T>(HW, x, sxb, y, syb, x, sxb)) {
     int threads, chunks;
     bn_plane_launch(HW / 4, &threads, &chunks);
-    CENET_LAUNCH(bn_apply_v4_kernel, dim3(B * C, chunks), dim3(threads), stream, x, sxb, y, syb, mean, var, eps, gamma, beta,
-                 act, slope, C, HW);
+    CENET_LAUNCH((bn_apply_v4_kernel<T>), dim3(B * C, chunks), dim3(threads), stream, x, sxb, y, syb, mean, var, eps, gamma,
+                 beta, act, slope, C, HW);
   } else {
     int chunks = cdiv(HW, 1024);
     if (chunks > 64) chunks = 64;
-    CENET_LAUNCH(bn_apply_kernel, dim3(B * C, chunks), dim3(256), stream, x, sxb, y, syb, mean, var, eps, gamma, beta, act,
+    CENET_LAUNCH((bn_apply_kernel<T>), dim3(B * C, chunks), dim3(256), stream, x, sxb, y, syb, mean, var, eps, gamma, beta, act,
                  slope, C, HW);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(bn_apply, (const T* x, long sxb, T* y, long syb, const float* mean, const float* var, float eps, const float* gamma,
+                      const float* beta, int act, float slope, int B, int C, int HW, hipStream_t stream),
+           (x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, stream))
 
-extern "C" int cenet_bn_bwd_acc_f32(const float* dy, long sgb, const float* x, long sxb, float* dx, long sdb,
-                                    const float* mean, const float* var, float eps, const float* gamma, const float* beta,
-                                    int act, float slope, int B, int C, int HW, float* ws, float* dgamma_acc,
-                                    float* dbeta_acc, hipStream_t stream) {
+template <typename T>
+static int bn_bwd_acc_impl(const T* dy, long sgb, const T* x, long sxb, T* dx, long sdb, const float* mean, const float* var,
+                           float eps, const float* gamma, const float* beta, int act, float slope, int B, int C, int HW,
+                           float* ws, float* dgamma_acc, float* dbeta_acc, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   const long total = (long)B * HW;
-  if (bn_v4_ok(HW, dy, sgb, x, sxb, dx, sdb)) {
+  if (bn_v4_ok<T>(HW, dy, sgb, x, sxb, dx, sdb)) {
     const int S = bn_splits_v4(C, total / 4);
-    CENET_LAUNCH(bn_bwd_partial_v4_kernel, dim3(C, S), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma, beta, act,
+    CENET_LAUNCH((bn_bwd_partial_v4_kernel<T>), dim3(C, S), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma, beta, act,
                  slope, B, HW, ws);
     int threads, chunks;
     bn_plane_launch(HW / 4, &threads, &chunks);
-    CENET_LAUNCH(bn_bwd_apply_v4_kernel, dim3(B * C, chunks), dim3(threads), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps,
+    CENET_LAUNCH((bn_bwd_apply_v4_kernel<T>), dim3(B * C, chunks), dim3(threads), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps,
                  gamma, beta, act, slope, C, HW, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc);
   } else {
     const int S = bn_splits(C, total);
-    CENET_LAUNCH(bn_bwd_partial_kernel, dim3(C, S), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma, beta, act, slope,
+    CENET_LAUNCH((bn_bwd_partial_kernel<T>), dim3(C, S), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma, beta, act, slope,
                  B, HW, ws);
     int chunks = cdiv(HW, 1024);
     if (chunks > 64) chunks = 64;
-    CENET_LAUNCH(bn_bwd_apply_kernel, dim3(B * C, chunks), dim3(256), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma,
+    CENET_LAUNCH((bn_bwd_apply_kernel<T>), dim3(B * C, chunks), dim3(256), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma,
                  beta, act, slope, C, HW, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(bn_bwd_acc, (const T* dy, long sgb, const T* x, long sxb, T* dx, long sdb, const float* mean, const float* var,
+                        float eps, const float* gamma, const float* beta, int act, float slope, int B, int C, int HW, float* ws,
+                        float* dgamma_acc, float* dbeta_acc, hipStream_t stream),
+           (dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma, beta, act, slope, B, C, HW, ws, dgamma_acc, dbeta_acc, stream))

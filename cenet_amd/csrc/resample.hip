@@ -5,6 +5,8 @@
 //   max pool 2x2 stride 2                                            out.py:43
 // Planes are addressed ptr[b*sb + c*HW + p] (channel-slice views).  PyTorch coordinate conventions are restated
 // exactly (area_pixel_compute_source_index): align: src = scale*dst ; else src = max(scale*(dst+0.5)-0.5, 0).
+// Templates over the activation storage type T (float / bf16_t) and, for the large maps, over OPT = outputs per thread
+// (2 adjacent x positions for bf16 when the output width is even, so that a lane stores 4 bytes).
 #include "common.h"
 #include "../../include/cenet_hip.h"
 
@@ -18,20 +20,31 @@ __device__ __forceinline__ void bil_coord(int dst, float scale, int align, int i
 }
 
 // grid (B*C, chunks)
-__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x, long sxb, float* __restrict__ y, long syb,
+template <typename T, int OPT>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y, long syb,
                                                           int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
                                                           int align) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
-  const float* xp = x + (long)b * sxb + (long)c * Hi * Wi;
-  float* yp = y + (long)b * syb + (long)c * Ho * Wo;
-  for (int p = blockIdx.y * 256 + threadIdx.x; p < Ho * Wo; p += gridDim.y * 256) {
-    const int oy = p / Wo, ox = p - oy * Wo;
-    int y0, y1, x0, x1;
-    float ly, lx;
+  const T* xp = x + (long)b * sxb + (long)c * Hi * Wi;
+  T* yp = y + (long)b * syb + (long)c * Ho * Wo;
+  for (int pp = blockIdx.y * 256 + threadIdx.x; pp < Ho * Wo / OPT; pp += gridDim.y * 256) {
+    const int p = pp * OPT;
+    const int oy = p / Wo, ox0 = p - oy * Wo;
+    int y0, y1;
+    float ly;
     bil_coord(oy, sh, align, Hi, y0, y1, ly);
-    bil_coord(ox, sw, align, Wi, x0, x1, lx);
-    const float hy = 1.f - ly, hx = 1.f - lx;
-    yp[p] = hy * (hx * xp[y0 * Wi + x0] + lx * xp[y0 * Wi + x1]) + ly * (hx * xp[y1 * Wi + x0] + lx * xp[y1 * Wi + x1]);
+    const float hy = 1.f - ly;
+    float o[OPT];
+#pragma unroll
+    for (int e = 0; e < OPT; ++e) {
+      int x0, x1;
+      float lx;
+      bil_coord(ox0 + e, sw, align, Wi, x0, x1, lx);
+      const float hx = 1.f - lx;
+      o[e] = hy * (hx * ldf(xp + y0 * Wi + x0) + lx * ldf(xp + y0 * Wi + x1)) +
+             ly * (hx * ldf(xp + y1 * Wi + x0) + lx * ldf(xp + y1 * Wi + x1));
+    }
+    stv<OPT>(yp + p, o);
   }
 }
 
@@ -53,13 +66,13 @@ __device__ __forceinline__ void bil_range(int i, float scale, int align, int out
 // gather form of the backward: one thread per INPUT pixel sums the output gradients whose taps touch it
 // MAXR = most output columns whose taps can touch one input column (range from bil_range): 6 covers scale >= 0.5 (x2
 // up-sampling and every down-sampling), 10 covers x4; anything wider takes the unbounded loop
-template <int BIL_MAXR>
-__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, long sgb, float* __restrict__ dx,
+template <typename T, int BIL_MAXR>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx,
                                                           long sdb, int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
                                                           int align) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
-  const float* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
-  float* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
+  const T* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
+  T* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < Hi * Wi; p += gridDim.y * 256) {
     const int iy = p / Wi, ix = p - iy * Wi;
     int ylo, yhi, xlo, xhi;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
         float row = 0.f;
 #pragma unroll
         for (int k = 0; k < BIL_MAXR; ++k)
-          if (xlo + k < xhi) row += wxs[k] * gp[oy * Wo + xlo + k];
+          if (xlo + k < xhi) row += wxs[k] * ldf(gp + oy * Wo + xlo + k);
         acc += wy * row;
       }
     } else {
@@ -104,61 +117,73 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
           float lx;
           bil_coord(ox, sw, align, Wi, x0, x1, lx);
           const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-          if (wx != 0.f) row += wx * gp[oy * Wo + ox];
+          if (wx != 0.f) row += wx * ldf(gp + oy * Wo + ox);
         }
         acc += wy * row;
       }
     }
-    dp[p] = acc;
+    stf(dp + p, acc);
   }
 }
 
-__global__ __launch_bounds__(256) void nearest2x_fwd_kernel(const float* __restrict__ x, long sxb, float* __restrict__ y, long syb,
+// one thread per INPUT pixel: writes its 2x2 output block (two 2-element row stores)
+template <typename T>
+__global__ __launch_bounds__(256) void nearest2x_fwd_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y, long syb,
                                                            int C, int Hi, int Wi) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
-  const int Ho = 2 * Hi, Wo = 2 * Wi;
-  const float* xp = x + (long)b * sxb + (long)c * Hi * Wi;
-  float* yp = y + (long)b * syb + (long)c * Ho * Wo;
-  for (int p = blockIdx.y * 256 + threadIdx.x; p < Ho * Wo; p += gridDim.y * 256) {
-    const int oy = p / Wo, ox = p - oy * Wo;
-    yp[p] = xp[(oy >> 1) * Wi + (ox >> 1)];
+  const int Wo = 2 * Wi;
+  const T* xp = x + (long)b * sxb + (long)c * Hi * Wi;
+  T* yp = y + (long)b * syb + (long)c * 4 * Hi * Wi;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < Hi * Wi; p += gridDim.y * 256) {
+    const int iy = p / Wi, ix = p - iy * Wi;
+    const T v = xp[p];
+    const T vv[2] = {v, v};
+    T* o = yp + (2 * iy) * Wo + 2 * ix;  // even element offset inside an even-sized plane: 2-element aligned when the base is
+    memcpy(o, vv, 2 * sizeof(T));
+    memcpy(o + Wo, vv, 2 * sizeof(T));
   }
 }
-__global__ __launch_bounds__(256) void nearest2x_bwd_kernel(const float* __restrict__ dy, long sgb, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void nearest2x_bwd_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx,
                                                            long sdb, int C, int Hi, int Wi) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
   const int Wo = 2 * Wi;
-  const float* gp = dy + (long)b * sgb + (long)c * 4 * Hi * Wi;
-  float* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
+  const T* gp = dy + (long)b * sgb + (long)c * 4 * Hi * Wi;
+  T* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < Hi * Wi; p += gridDim.y * 256) {
     const int iy = p / Wi, ix = p - iy * Wi;
-    const float* g = gp + (2 * iy) * Wo + 2 * ix;
-    dp[p] = g[0] + g[1] + g[Wo] + g[Wo + 1];
+    const T* g = gp + (2 * iy) * Wo + 2 * ix;
+    float r0[2], r1[2];
+    ldv<2>(r0, g);
+    ldv<2>(r1, g + Wo);
+    stf(dp + p, r0[0] + r0[1] + r1[0] + r1[1]);
   }
 }
 
 __device__ __forceinline__ int ap_start(int o, int in, int out) { return (o * in) / out; }
 __device__ __forceinline__ int ap_end(int o, int in, int out) { return ((o + 1) * in + out - 1) / out; }
 
-__global__ __launch_bounds__(64) void adaptive_avgpool_fwd_kernel(const float* __restrict__ x, long sxb, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(64) void adaptive_avgpool_fwd_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y,
                                                                  long syb, int C, int Hi, int Wi, int Ho, int Wo) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
-  const float* xp = x + (long)b * sxb + (long)c * Hi * Wi;
-  float* yp = y + (long)b * syb + (long)c * Ho * Wo;
+  const T* xp = x + (long)b * sxb + (long)c * Hi * Wi;
+  T* yp = y + (long)b * syb + (long)c * Ho * Wo;
   for (int p = threadIdx.x; p < Ho * Wo; p += 64) {
     const int oy = p / Wo, ox = p - oy * Wo;
     const int ys = ap_start(oy, Hi, Ho), ye = ap_end(oy, Hi, Ho), xs = ap_start(ox, Wi, Wo), xe = ap_end(ox, Wi, Wo);
     float s = 0.f;
     for (int iy = ys; iy < ye; ++iy)
-      for (int ix = xs; ix < xe; ++ix) s += xp[iy * Wi + ix];
-    yp[p] = s / (float)((ye - ys) * (xe - xs));
+      for (int ix = xs; ix < xe; ++ix) s += ldf(xp + iy * Wi + ix);
+    stf(yp + p, s / (float)((ye - ys) * (xe - xs)));
   }
 }
-__global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, long sgb, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx,
                                                                   long sdb, int C, int Hi, int Wi, int Ho, int Wo) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
-  const float* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
-  float* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
+  const T* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
+  T* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < Hi * Wi; p += gridDim.y * 256) {
     const int iy = p / Wi, ix = p - iy * Wi;
     float s = 0.f;
@@ -168,57 +193,65 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* 
       for (int ox = 0; ox < Wo; ++ox) {
         const int xs = ap_start(ox, Wi, Wo), xe = ap_end(ox, Wi, Wo);
         if (ix < xs || ix >= xe) continue;
-        s += gp[oy * Wo + ox] / (float)((ye - ys) * (xe - xs));
+        s += ldf(gp + oy * Wo + ox) / (float)((ye - ys) * (xe - xs));
       }
     }
-    dp[p] = s;
+    stf(dp + p, s);
   }
 }
 
 // y = scale[c] * maxpool2x2(x)   (out.py:70: self.w * self.rb(x)); scale may be null
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long syb,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long syb,
                                                           const float* __restrict__ scale, int C, int Hi, int Wi) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
   const int Ho = Hi / 2, Wo = Wi / 2;
-  const float* xp = x + (long)bc * Hi * Wi;
-  float* yp = y + (long)b * syb + (long)c * Ho * Wo;
+  const T* xp = x + (long)bc * Hi * Wi;
+  T* yp = y + (long)b * syb + (long)c * Ho * Wo;
   const float sc = scale ? scale[c] : 1.f;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < Ho * Wo; p += gridDim.y * 256) {
     const int oy = p / Wo, ox = p - oy * Wo;
-    const float* q = xp + (2 * oy) * Wi + 2 * ox;
-    yp[p] = sc * fmaxf(fmaxf(q[0], q[1]), fmaxf(q[Wi], q[Wi + 1]));
+    const T* q = xp + (2 * oy) * Wi + 2 * ox;
+    float r0[2], r1[2];
+    ldv<2>(r0, q);
+    ldv<2>(r1, q + Wi);
+    stf(yp + p, sc * fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r1[0], r1[1])));
   }
 }
 // dx: gradient to the first maximal element of each window (PyTorch tie rule); dscale[c] += sum dy*maxpool(x)
-__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long sgb,
-                                                          float* __restrict__ dx, const float* __restrict__ scale,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, long sgb,
+                                                          T* __restrict__ dx, const float* __restrict__ scale,
                                                           float* __restrict__ dscale, int C, int Hi, int Wi) {
   __shared__ float red[16];
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
   const int Ho = Hi / 2, Wo = Wi / 2;
-  const float* xp = x + (long)bc * Hi * Wi;
-  const float* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
-  float* dp = dx + (long)bc * Hi * Wi;
+  const T* xp = x + (long)bc * Hi * Wi;
+  const T* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
+  T* dp = dx + (long)bc * Hi * Wi;
   const float sc = scale ? scale[c] : 1.f;
   float ds = 0.f;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < Ho * Wo; p += gridDim.y * 256) {
     const int oy = p / Wo, ox = p - oy * Wo;
     const int base = (2 * oy) * Wi + 2 * ox;
-    const int off[4] = {0, 1, Wi, Wi + 1};
+    float w4[4];
+    ldv<2>(w4, xp + base);
+    ldv<2>(w4 + 2, xp + base + Wi);
     int am = 0;
-    float mv = xp[base];
+    float mv = w4[0];
 #pragma unroll
     for (int t = 1; t < 4; ++t) {
-      float v = xp[base + off[t]];
-      if (v > mv) {
-        mv = v;
+      if (w4[t] > mv) {
+        mv = w4[t];
         am = t;
       }
     }
-    const float g = gp[p];
+    const float g = ldf(gp + p);
     ds += g * mv;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) dp[base + off[t]] = (t == am) ? g * sc : 0.f;
+    for (int t = 0; t < 4; ++t) w4[t] = (t == am) ? g * sc : 0.f;
+    stv<2>(dp + base, w4);
+    stv<2>(dp + base + Wi, w4 + 2);
   }
   if (dscale) {
     ds = block_sum(ds, red);
@@ -231,67 +264,105 @@ static inline int chunks_for(int n) {
   return ch > 64 ? 64 : (ch < 1 ? 1 : ch);
 }
 
-extern "C" int cenet_bilinear_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, int Ho,
-                                      int Wo, float scale_h, float scale_w, int align_corners, hipStream_t stream) {
+template <typename T>
+static int bilinear_fwd_impl(const T* x, long sxb, T* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
+                             float scale_w, int align_corners, hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(bilinear_fwd_kernel, dim3(B * C, chunks_for(Ho * Wo)), dim3(256), stream, x, sxb, y, syb, C, Hi, Wi, Ho, Wo,
-               scale_h, scale_w, align_corners);
-  CENET_CHECK_LAUNCH();
-  return CENET_OK;
-}
-extern "C" int cenet_bilinear_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi, int Ho,
-                                      int Wo, float scale_h, float scale_w, int align_corners, hipStream_t stream) {
-  if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
-  if (scale_w >= 0.5f)
-    CENET_LAUNCH((bilinear_bwd_kernel<6>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
+  if (sizeof(T) == 2 && (Wo & 1) == 0 && (syb & 1) == 0 && ((uintptr_t)y & 3) == 0)
+    CENET_LAUNCH((bilinear_fwd_kernel<T, 2>), dim3(B * C, chunks_for(Ho * Wo / 2)), dim3(256), stream, x, sxb, y, syb, C, Hi, Wi, Ho,
                  Wo, scale_h, scale_w, align_corners);
   else
-    CENET_LAUNCH((bilinear_bwd_kernel<10>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
+    CENET_LAUNCH((bilinear_fwd_kernel<T, 1>), dim3(B * C, chunks_for(Ho * Wo)), dim3(256), stream, x, sxb, y, syb, C, Hi, Wi, Ho, Wo,
+                 scale_h, scale_w, align_corners);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+CENET_TWIN(bilinear_fwd, (const T* x, long sxb, T* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
+                          float scale_w, int align_corners, hipStream_t stream),
+           (x, sxb, y, syb, B, C, Hi, Wi, Ho, Wo, scale_h, scale_w, align_corners, stream))
+
+template <typename T>
+static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
+                             float scale_w, int align_corners, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
+  if (scale_w >= 0.5f)
+    CENET_LAUNCH((bilinear_bwd_kernel<T, 6>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
+                 Wo, scale_h, scale_w, align_corners);
+  else
+    CENET_LAUNCH((bilinear_bwd_kernel<T, 10>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
                  Wo, scale_h, scale_w, align_corners);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_nearest2x_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi,
-                                       hipStream_t stream) {
+CENET_TWIN(bilinear_bwd, (const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
+                          float scale_w, int align_corners, hipStream_t stream),
+           (dy, sgb, dx, sdb, B, C, Hi, Wi, Ho, Wo, scale_h, scale_w, align_corners, stream))
+
+template <typename T>
+static int nearest2x_fwd_impl(const T* x, long sxb, T* y, long syb, int B, int C, int Hi, int Wi, hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(nearest2x_fwd_kernel, dim3(B * C, chunks_for(4 * Hi * Wi)), dim3(256), stream, x, sxb, y, syb, C, Hi, Wi);
+  if ((syb & 1) || ((uintptr_t)y & (2 * sizeof(T) - 1))) return CENET_EINVAL;  // output rows are written as element pairs
+  CENET_LAUNCH((nearest2x_fwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, x, sxb, y, syb, C, Hi, Wi);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_nearest2x_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi,
-                                       hipStream_t stream) {
+CENET_TWIN(nearest2x_fwd, (const T* x, long sxb, T* y, long syb, int B, int C, int Hi, int Wi, hipStream_t stream),
+           (x, sxb, y, syb, B, C, Hi, Wi, stream))
+
+template <typename T>
+static int nearest2x_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(nearest2x_bwd_kernel, dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi);
+  if ((sgb & 1) || ((uintptr_t)dy & (2 * sizeof(T) - 1))) return CENET_EINVAL;  // gradient rows are read as element pairs
+  CENET_LAUNCH((nearest2x_bwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_adaptive_avgpool_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi,
-                                              int Ho, int Wo, hipStream_t stream) {
+CENET_TWIN(nearest2x_bwd, (const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, hipStream_t stream),
+           (dy, sgb, dx, sdb, B, C, Hi, Wi, stream))
+
+template <typename T>
+static int adaptive_avgpool_fwd_impl(const T* x, long sxb, T* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                     hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(adaptive_avgpool_fwd_kernel, dim3(B * C), dim3(64), stream, x, sxb, y, syb, C, Hi, Wi, Ho, Wo);
+  CENET_LAUNCH((adaptive_avgpool_fwd_kernel<T>), dim3(B * C), dim3(64), stream, x, sxb, y, syb, C, Hi, Wi, Ho, Wo);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_adaptive_avgpool_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi,
-                                              int Ho, int Wo, hipStream_t stream) {
+CENET_TWIN(adaptive_avgpool_fwd, (const T* x, long sxb, T* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                  hipStream_t stream), (x, sxb, y, syb, B, C, Hi, Wi, Ho, Wo, stream))
+
+template <typename T>
+static int adaptive_avgpool_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                     hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(adaptive_avgpool_bwd_kernel, dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi,
+  CENET_LAUNCH((adaptive_avgpool_bwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi,
                Ho, Wo);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_maxpool2_fwd_f32(const float* x, float* y, long syb, const float* scale, int B, int C, int Hi, int Wi,
-                                      hipStream_t stream) {
+CENET_TWIN(adaptive_avgpool_bwd, (const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                  hipStream_t stream), (dy, sgb, dx, sdb, B, C, Hi, Wi, Ho, Wo, stream))
+
+template <typename T>
+static int maxpool2_fwd_impl(const T* x, T* y, long syb, const float* scale, int B, int C, int Hi, int Wi, hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 1 || Wi <= 1 || (Hi & 1) || (Wi & 1)) return CENET_EINVAL;
-  CENET_LAUNCH(maxpool2_fwd_kernel, dim3(B * C, chunks_for(Hi * Wi / 4)), dim3(256), stream, x, y, syb, scale, C, Hi, Wi);
+  if ((uintptr_t)x & (2 * sizeof(T) - 1)) return CENET_EINVAL;  // windows are read as element pairs
+  CENET_LAUNCH((maxpool2_fwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi / 4)), dim3(256), stream, x, y, syb, scale, C, Hi, Wi);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_maxpool2_bwd_acc_f32(const float* x, const float* dy, long sgb, float* dx, const float* scale,
-                                          float* dscale_acc, int B, int C, int Hi, int Wi, hipStream_t stream) {
+CENET_TWIN(maxpool2_fwd, (const T* x, T* y, long syb, const float* scale, int B, int C, int Hi, int Wi, hipStream_t stream),
+           (x, y, syb, scale, B, C, Hi, Wi, stream))
+
+template <typename T>
+static int maxpool2_bwd_acc_impl(const T* x, const T* dy, long sgb, T* dx, const float* scale, float* dscale_acc, int B, int C,
+                                 int Hi, int Wi, hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 1 || Wi <= 1 || (Hi & 1) || (Wi & 1)) return CENET_EINVAL;
-  CENET_LAUNCH(maxpool2_bwd_kernel, dim3(B * C, chunks_for(Hi * Wi / 4)), dim3(256), stream, x, dy, sgb, dx, scale, dscale_acc,
-               C, Hi, Wi);
+  if (((uintptr_t)x | (uintptr_t)dx) & (2 * sizeof(T) - 1)) return CENET_EINVAL;
+  CENET_LAUNCH((maxpool2_bwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi / 4)), dim3(256), stream, x, dy, sgb, dx, scale,
+               dscale_acc, C, Hi, Wi);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(maxpool2_bwd_acc, (const T* x, const T* dy, long sgb, T* dx, const float* scale, float* dscale_acc, int B, int C,
+                              int Hi, int Wi, hipStream_t stream), (x, dy, sgb, dx, scale, dscale_acc, B, C, Hi, Wi, stream))

@@ -5,35 +5,48 @@
 //          cfam.py:93-101
 // The BN steps in the middle reuse the generic BatchNorm kernels of norm.hip; the kernels here do the
 // reductions, the tiny per-channel MLP / 3->1 conv, and the scatter of the statistic gradients back onto x.
+// Templates over the activation storage type T (x, y, dy, dx: float or bf16_t); the statistic maps (u, z, f, du, df: 1/HW or
+// 1/C of the activation) are always fp32.  Plane kernels take a vector width V (4 when HW % 4 == 0 and the planes are
+// quad-aligned, else 1); HWv = HW / V.
 #include "common.h"
 #include "../../include/cenet_hip.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // CCU forward: grid (B*C); u[bc*3+{0,1,2}] = max, mean, std ; amax[bc] = argmax ; z[bc] = fc2(relu(fc1(u)))
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ccu_stats_fwd_kernel(const float* __restrict__ x, const float* __restrict__ fc1,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void ccu_stats_fwd_kernel(const T* __restrict__ x, const float* __restrict__ fc1,
                                                            const float* __restrict__ fc2, float* __restrict__ u,
-                                                           int* __restrict__ amax, float* __restrict__ z, int C, int HW) {
+                                                           int* __restrict__ amax, float* __restrict__ z, int C, int HWv) {
   __shared__ float red[16];
   __shared__ float rv[4];
   __shared__ int ri[4];
-  const int bc = blockIdx.x, c = bc % C;
-  const float* xp = x + (long)bc * HW;
+  const int bc = blockIdx.x, c = bc % C, HW = HWv * V;
+  const T* xp = x + (long)bc * HW;
   float s = 0.f, mx = -3.4e38f;
   int mi = 0;
-  for (int p = threadIdx.x; p < HW; p += 256) {
-    float v = xp[p];
-    s += v;
-    if (v > mx) {
-      mx = v;
-      mi = p;
+  for (int p = threadIdx.x; p < HWv; p += 256) {
+    float v[V];
+    ldv<V>(v, xp + p * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      s += v[e];
+      if (v[e] > mx) {
+        mx = v[e];
+        mi = p * V + e;
+      }
     }
   }
   const float mean = block_sum(s, red) / HW;
   float q = 0.f;
-  for (int p = threadIdx.x; p < HW; p += 256) {
-    float d = xp[p] - mean;
-    q += d * d;
+  for (int p = threadIdx.x; p < HWv; p += 256) {
+    float v[V];
+    ldv<V>(v, xp + p * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float d = v[e] - mean;
+      q += d * d;
+    }
   }
   const float var = block_sum(q, red) / HW;
   // arg-max: wave reduce (value, smallest index on ties), then across waves
@@ -76,25 +89,39 @@ __global__ __launch_bounds__(256) void ccu_stats_fwd_kernel(const float* __restr
 }
 
 // y = x * sigmoid(g[bc])
-__global__ __launch_bounds__(256) void gate_chan_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                           float* __restrict__ y, int HW) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gate_chan_fwd_kernel(const T* __restrict__ x, const float* __restrict__ g,
+                                                           T* __restrict__ y, int HWv) {
   const int bc = blockIdx.x;
   const float s = sigmoid_f(g[bc]);
-  const float* xp = x + (long)bc * HW;
-  float* yp = y + (long)bc * HW;
-  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) yp[p] = xp[p] * s;
+  const T* xp = x + (long)bc * HWv * V;
+  T* yp = y + (long)bc * HWv * V;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HWv; p += gridDim.y * 256) {
+    float v[V];
+    ldv<V>(v, xp + p * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = v[e] * s;
+    stv<V>(yp + p * V, v);
+  }
 }
 
 // dg[bc] = sigmoid'(g) * sum_p dy*x    (grid B*C)
-__global__ __launch_bounds__(256) void gate_chan_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gate_chan_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                   const float* __restrict__ g, float* __restrict__ dg,
-                                                                  int HW) {
+                                                                  int HWv) {
   __shared__ float red[16];
   const int bc = blockIdx.x;
-  const float* xp = x + (long)bc * HW;
-  const float* gp = dy + (long)bc * HW;
+  const T* xp = x + (long)bc * HWv * V;
+  const T* gp = dy + (long)bc * HWv * V;
   float s = 0.f;
-  for (int p = threadIdx.x; p < HW; p += 256) s += xp[p] * gp[p];
+  for (int p = threadIdx.x; p < HWv; p += 256) {
+    float xv[V], gv[V];
+    ldv<V>(xv, xp + p * V);
+    ldv<V>(gv, gp + p * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) s += xv[e] * gv[e];
+  }
   s = block_sum(s, red);
   if (threadIdx.x == 0) {
     float sg = sigmoid_f(g[bc]);
@@ -104,14 +131,15 @@ __global__ __launch_bounds__(256) void gate_chan_bwd_reduce_kernel(const float* 
 
 // CCU backward apply (grid B*C): from dz[bc] (grad of the pre-BN MLP output) rebuild du through the MLP, accumulate
 // fc1/fc2 gradients, and write dx = dy*sigmoid(g) + du_max*[p==amax] + du_mean/HW + du_std*(x-mean)/(HW*std)
-__global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const float* __restrict__ g, const float* __restrict__ dz,
                                                            const float* __restrict__ u, const int* __restrict__ amax,
                                                            const float* __restrict__ fc1, const float* __restrict__ fc2,
                                                            float* __restrict__ dfc1, float* __restrict__ dfc2,
-                                                           float* __restrict__ dx, int C, int HW) {
+                                                           T* __restrict__ dx, int C, int HWv) {
   __shared__ float du_s[3];
-  const int bc = blockIdx.x, c = bc % C;
+  const int bc = blockIdx.x, c = bc % C, HW = HWv * V;
   if (threadIdx.x == 0) {
     const float mx = u[bc * 3], mean = u[bc * 3 + 1], sd = u[bc * 3 + 2];
     const float gz = dz[bc];
@@ -142,13 +170,20 @@ __global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const float* __restr
   const int am = amax[bc];
   // std backward at std == 0 (constant plane, e.g. a 1x1 map): aten::std_backward masks the 0/0 to 0
   const float dmax = du_s[0], dmean = du_s[1] / HW, dstd = (sd > 0.f) ? du_s[2] / (HW * sd) : 0.f;
-  const float* xp = x + (long)bc * HW;
-  const float* gp = dy + (long)bc * HW;
-  float* dp = dx + (long)bc * HW;
-  for (int p = threadIdx.x; p < HW; p += 256) {
-    float v = gp[p] * sg + dmean + dstd * (xp[p] - mean);
-    if (p == am) v += dmax;
-    dp[p] = v;
+  const T* xp = x + (long)bc * HW;
+  const T* gp = dy + (long)bc * HW;
+  T* dp = dx + (long)bc * HW;
+  for (int p = threadIdx.x; p < HWv; p += 256) {
+    float xv[V], gv[V];
+    ldv<V>(xv, xp + p * V);
+    ldv<V>(gv, gp + p * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float v = gv[e] * sg + dmean + dstd * (xv[e] - mean);
+      if (p * V + e == am) v += dmax;
+      gv[e] = v;
+    }
+    stv<V>(dp + p * V, gv);
   }
 }
 
@@ -157,7 +192,8 @@ __global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------------------
 // SRM channel statistics, single pass: workgroup = 64 pixels x 4 channel groups (lanes along pixels: every load is a
 // contiguous 256-byte row segment), shifted sums (shift = channel 0) for mean / unbiased std, groups meet in LDS.
-__global__ __launch_bounds__(256) void srm_stats_fwd_kernel(const float* __restrict__ x, float* __restrict__ u,
+template <typename T>
+__global__ __launch_bounds__(256) void srm_stats_fwd_kernel(const T* __restrict__ x, float* __restrict__ u,
                                                            int* __restrict__ amax, int C, int HW) {
   __shared__ float s1_s[4][64], s2_s[4][64], mx_s[4][64];
   __shared__ int mi_s[4][64];
@@ -165,13 +201,13 @@ __global__ __launch_bounds__(256) void srm_stats_fwd_kernel(const float* __restr
   const int pl = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + pl;
   const bool ok = p < HW;
-  const float* xb = x + (long)b * C * HW + (ok ? p : 0);
-  const float shift = ok ? xb[0] : 0.f;
+  const T* xb = x + (long)b * C * HW + (ok ? p : 0);
+  const float shift = ok ? ldf(xb) : 0.f;
   float s1 = 0.f, s2 = 0.f, mx = -3.4e38f;
   int mi = 0;
   if (ok) {
     for (int c = cg; c < C; c += 4) {
-      const float v = xb[(long)c * HW];
+      const float v = ldf(xb + (long)c * HW);
       const float d = v - shift;
       s1 += d;
       s2 += d * d;
@@ -280,17 +316,26 @@ __global__ __launch_bounds__(256) void srm_conv_bwd_kernel(const float* __restri
 }
 
 // y[b,c,p] = x[b,c,p] * sigmoid(f[b,p]); grid (B*C planes, chunks)
-__global__ __launch_bounds__(256) void gate_pix_fwd_kernel(const float* __restrict__ x, const float* __restrict__ f,
-                                                          float* __restrict__ y, int C, int HW) {
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gate_pix_fwd_kernel(const T* __restrict__ x, const float* __restrict__ f,
+                                                          T* __restrict__ y, int C, int HWv) {
   const int bc = blockIdx.x, b = bc / C;
-  const float* fb = f + (long)b * HW;
-  const long base = (long)bc * HW;
-  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) y[base + p] = x[base + p] * sigmoid_f(fb[p]);
+  const float* fb = f + (long)b * HWv * V;
+  const long base = (long)bc * HWv * V;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < HWv; p += gridDim.y * 256) {
+    float xv[V], fv[V];
+    ldv<V>(xv, x + base + p * V);
+    ldv<V>(fv, fb + p * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) xv[e] = xv[e] * sigmoid_f(fv[e]);
+    stv<V>(y + base + p * V, xv);
+  }
 }
 
 // 16-byte forms (HW % 4 == 0): workgroup = 64 pixels x 16 channel groups; a thread owns 4 consecutive pixels of every 16th
 // channel (16 lanes cover a contiguous 256-byte row segment), 4 independent 16-byte loads in flight, groups meet in LDS
-__global__ __launch_bounds__(256) void srm_stats_fwd_v4_kernel(const float* __restrict__ x, float* __restrict__ u,
+template <typename T>
+__global__ __launch_bounds__(256) void srm_stats_fwd_v4_kernel(const T* __restrict__ x, float* __restrict__ u,
                                                               int* __restrict__ amax, int C, int HW) {
   __shared__ float s1_s[16][64], s2_s[16][64], mx_s[16][64];
   __shared__ int mi_s[16][64];
@@ -298,16 +343,16 @@ __global__ __launch_bounds__(256) void srm_stats_fwd_v4_kernel(const float* __re
   const int pq = threadIdx.x & 15, cg = threadIdx.x >> 4;
   const int p = blockIdx.x * 64 + 4 * pq;
   const bool ok = p < HW;
-  const float* xb = x + (long)b * C * HW + (ok ? p : 0);
+  const T* xb = x + (long)b * C * HW + (ok ? p : 0);
   float shift[4] = {0.f, 0.f, 0.f, 0.f};
-  if (ok) memcpy(shift, xb, 16);
+  if (ok) ld4v(shift, xb);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, mx[4] = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
   int mi[4] = {0, 0, 0, 0};
   if (ok) {
 #pragma unroll 4
     for (int c = cg; c < C; c += 16) {
       float v[4];
-      memcpy(v, xb + (long)c * HW, 16);
+      ld4v(v, xb + (long)c * HW);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float d = v[e] - shift[e];
@@ -344,7 +389,7 @@ __global__ __launch_bounds__(256) void srm_stats_fwd_v4_kernel(const float* __re
           bi = i;
         }
       }
-      const float sh = x[(long)b * C * HW + pp];
+      const float sh = ldf(x + (long)b * C * HW + pp);
       const float mean_d = a1 / C;
       float var = (a2 - a1 * mean_d) / (C - 1);
       if (var < 0.f) var = 0.f;
@@ -357,7 +402,8 @@ __global__ __launch_bounds__(256) void srm_stats_fwd_v4_kernel(const float* __re
   }
 }
 
-__global__ __launch_bounds__(256) void gate_pix_bwd_reduce_v4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void gate_pix_bwd_reduce_v4_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                     const float* __restrict__ f, float* __restrict__ df, int C,
                                                                     int HW) {
   __shared__ float part[16][64];
@@ -371,8 +417,8 @@ __global__ __launch_bounds__(256) void gate_pix_bwd_reduce_v4_kernel(const float
 #pragma unroll 4
     for (int c = cg; c < C; c += 16) {
       float xv[4], gv[4];
-      memcpy(xv, x + base + (long)c * HW, 16);
-      memcpy(gv, dy + base + (long)c * HW, 16);
+      ld4v(xv, x + base + (long)c * HW);
+      ld4v(gv, dy + base + (long)c * HW);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] += xv[e] * gv[e];
     }
@@ -393,7 +439,8 @@ __global__ __launch_bounds__(256) void gate_pix_bwd_reduce_v4_kernel(const float
 }
 
 // df[b,p] = sigmoid'(f) * sum_c dy*x ; workgroup = 64 pixels x 4 channel groups
-__global__ __launch_bounds__(256) void gate_pix_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void gate_pix_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  const float* __restrict__ f, float* __restrict__ df, int C,
                                                                  int HW) {
   __shared__ float part[4][64];
@@ -404,7 +451,7 @@ __global__ __launch_bounds__(256) void gate_pix_bwd_reduce_kernel(const float* _
   const long base = (long)b * C * HW + (ok ? p : 0);
   float s = 0.f;
   if (ok)
-    for (int c = cg; c < C; c += 4) s += x[base + (long)c * HW] * dy[base + (long)c * HW];
+    for (int c = cg; c < C; c += 4) s += ldf(x + base + (long)c * HW) * ldf(dy + base + (long)c * HW);
   part[cg][pl] = s;
   __syncthreads();
   if (cg == 0 && ok) {
@@ -415,22 +462,31 @@ __global__ __launch_bounds__(256) void gate_pix_bwd_reduce_kernel(const float* _
 }
 
 // dx = dy*sigmoid(f) + du_max*[c==amax] + du_mean/C + du_std*(x-mean)/((C-1)*std); grid (B*C planes, chunks)
-__global__ __launch_bounds__(256) void srm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void srm_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const float* __restrict__ f, const float* __restrict__ u,
                                                            const float* __restrict__ du, const int* __restrict__ amax,
-                                                           float* __restrict__ dx, int C, int HW) {
-  const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
+                                                           T* __restrict__ dx, int C, int HWv) {
+  const int bc = blockIdx.x, b = bc / C, c = bc - b * C, HW = HWv * V;
   const float* fb = f + (long)b * HW;
   const float* ub = u + (long)b * 3 * HW;
   const float* db = du + (long)b * 3 * HW;
   const int* ab = amax + (long)b * HW;
   const long base = (long)bc * HW;
-  for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) {
-    const float sg = sigmoid_f(fb[p]);
-    const float mean = ub[HW + p], sd = ub[2 * HW + p];
-    float v = dy[base + p] * sg + db[HW + p] / C + ((sd > 0.f) ? db[2 * HW + p] / ((C - 1) * sd) * (x[base + p] - mean) : 0.f);
-    if (c == ab[p]) v += db[p];
-    dx[base + p] = v;
+  for (int pv = blockIdx.y * 256 + threadIdx.x; pv < HWv; pv += gridDim.y * 256) {
+    float xv[V], gv[V];
+    ldv<V>(xv, x + base + pv * V);
+    ldv<V>(gv, dy + base + pv * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int p = pv * V + e;
+      const float sg = sigmoid_f(fb[p]);
+      const float mean = ub[HW + p], sd = ub[2 * HW + p];
+      float v = gv[e] * sg + db[HW + p] / C + ((sd > 0.f) ? db[2 * HW + p] / ((C - 1) * sd) * (xv[e] - mean) : 0.f);
+      if (c == ab[p]) v += db[p];
+      gv[e] = v;
+    }
+    stv<V>(dx + base + pv * V, gv);
   }
 }
 
@@ -439,44 +495,79 @@ static inline int chunks_for(int n) {
   return ch > 64 ? 64 : (ch < 1 ? 1 : ch);
 }
 
-extern "C" int cenet_ccu_stats_fwd_f32(const float* x, const float* fc1, const float* fc2, float* u, int* amax, float* z,
-                                       int B, int C, int HW, hipStream_t stream) {
+// plane vector width: 4 when the planes split into aligned quads, else 1
+template <typename T>
+static inline int plane_vw(int HW, const void* a, const void* b = nullptr, const void* c = nullptr) {
+  const uintptr_t m = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
+  return ((HW & 3) == 0 && (m & (4 * sizeof(T) - 1)) == 0) ? 4 : 1;
+}
+
+template <typename T>
+static int ccu_stats_fwd_impl(const T* x, const float* fc1, const float* fc2, float* u, int* amax, float* z, int B, int C, int HW,
+                              hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(ccu_stats_fwd_kernel, dim3(B * C), dim3(256), stream, x, fc1, fc2, u, amax, z, C, HW);
+  // fp32 keeps the one-element-per-thread walk: the summation order of the parity mode is pinned
+  if (sizeof(T) == 2 && plane_vw<T>(HW, x) == 4) CENET_LAUNCH((ccu_stats_fwd_kernel<T, 4>), dim3(B * C), dim3(256), stream, x, fc1, fc2, u, amax, z, C, HW / 4);
+  else CENET_LAUNCH((ccu_stats_fwd_kernel<T, 1>), dim3(B * C), dim3(256), stream, x, fc1, fc2, u, amax, z, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_gate_chan_fwd_f32(const float* x, const float* g, float* y, int BC, int HW, hipStream_t stream) {
+CENET_TWIN(ccu_stats_fwd, (const T* x, const float* fc1, const float* fc2, float* u, int* amax, float* z, int B, int C, int HW,
+                           hipStream_t stream), (x, fc1, fc2, u, amax, z, B, C, HW, stream))
+
+template <typename T>
+static int gate_chan_fwd_impl(const T* x, const float* g, T* y, int BC, int HW, hipStream_t stream) {
   if (BC <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(gate_chan_fwd_kernel, dim3(BC, chunks_for(HW)), dim3(256), stream, x, g, y, HW);
+  if (plane_vw<T>(HW, x, y) == 4) CENET_LAUNCH((gate_chan_fwd_kernel<T, 4>), dim3(BC, chunks_for(HW / 4)), dim3(256), stream, x, g, y, HW / 4);
+  else CENET_LAUNCH((gate_chan_fwd_kernel<T, 1>), dim3(BC, chunks_for(HW)), dim3(256), stream, x, g, y, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_gate_chan_bwd_reduce_f32(const float* x, const float* dy, const float* g, float* dg, int BC, int HW,
-                                              hipStream_t stream) {
+CENET_TWIN(gate_chan_fwd, (const T* x, const float* g, T* y, int BC, int HW, hipStream_t stream), (x, g, y, BC, HW, stream))
+
+template <typename T>
+static int gate_chan_bwd_reduce_impl(const T* x, const T* dy, const float* g, float* dg, int BC, int HW, hipStream_t stream) {
   if (BC <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(gate_chan_bwd_reduce_kernel, dim3(BC), dim3(256), stream, x, dy, g, dg, HW);
+  if (sizeof(T) == 2 && plane_vw<T>(HW, x, dy) == 4) CENET_LAUNCH((gate_chan_bwd_reduce_kernel<T, 4>), dim3(BC), dim3(256), stream, x, dy, g, dg, HW / 4);
+  else CENET_LAUNCH((gate_chan_bwd_reduce_kernel<T, 1>), dim3(BC), dim3(256), stream, x, dy, g, dg, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_ccu_bwd_apply_acc_f32(const float* x, const float* dy, const float* g, const float* dz, const float* u,
-                                           const int* amax, const float* fc1, const float* fc2, float* dfc1_acc,
-                                           float* dfc2_acc, float* dx, int B, int C, int HW, hipStream_t stream) {
+CENET_TWIN(gate_chan_bwd_reduce, (const T* x, const T* dy, const float* g, float* dg, int BC, int HW, hipStream_t stream),
+           (x, dy, g, dg, BC, HW, stream))
+
+template <typename T>
+static int ccu_bwd_apply_acc_impl(const T* x, const T* dy, const float* g, const float* dz, const float* u, const int* amax,
+                                  const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc, T* dx, int B, int C,
+                                  int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(ccu_bwd_apply_kernel, dim3(B * C), dim3(256), stream, x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc, dx,
-               C, HW);
-  CENET_CHECK_LAUNCH();
-  return CENET_OK;
-}
-extern "C" int cenet_srm_stats_fwd_f32(const float* x, float* u, int* amax, int B, int C, int HW, hipStream_t stream) {
-  if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
-  if ((HW & 3) == 0 && (((uintptr_t)x) & 15) == 0)
-    CENET_LAUNCH(srm_stats_fwd_v4_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
+  if (plane_vw<T>(HW, x, dy, dx) == 4)
+    CENET_LAUNCH((ccu_bwd_apply_kernel<T, 4>), dim3(B * C), dim3(256), stream, x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc,
+                 dx, C, HW / 4);
   else
-    CENET_LAUNCH(srm_stats_fwd_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
+    CENET_LAUNCH((ccu_bwd_apply_kernel<T, 1>), dim3(B * C), dim3(256), stream, x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc,
+                 dx, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(ccu_bwd_apply_acc, (const T* x, const T* dy, const float* g, const float* dz, const float* u, const int* amax,
+                               const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc, T* dx, int B, int C, int HW,
+                               hipStream_t stream),
+           (x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc, dx, B, C, HW, stream))
+
+template <typename T>
+static int srm_stats_fwd_impl(const T* x, float* u, int* amax, int B, int C, int HW, hipStream_t stream) {
+  if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
+  if ((HW & 3) == 0 && quad_aligned<T>(x))
+    CENET_LAUNCH((srm_stats_fwd_v4_kernel<T>), dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
+  else
+    CENET_LAUNCH((srm_stats_fwd_kernel<T>), dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+CENET_TWIN(srm_stats_fwd, (const T* x, float* u, int* amax, int B, int C, int HW, hipStream_t stream),
+           (x, u, amax, B, C, HW, stream))
+
 extern "C" int cenet_srm_conv_fwd_f32(const float* u, const float* pwc, const float* dwc, float* f, int B, int H, int W,
                                       hipStream_t stream) {
   if (B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
@@ -492,26 +583,44 @@ extern "C" int cenet_srm_conv_bwd_acc_f32(const float* u, const float* df, const
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_gate_pix_fwd_f32(const float* x, const float* f, float* y, int B, int C, int HW, hipStream_t stream) {
+
+template <typename T>
+static int gate_pix_fwd_impl(const T* x, const float* f, T* y, int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(gate_pix_fwd_kernel, dim3(B * C, chunks_for(HW)), dim3(256), stream, x, f, y, C, HW);
-  CENET_CHECK_LAUNCH();
-  return CENET_OK;
-}
-extern "C" int cenet_gate_pix_bwd_reduce_f32(const float* x, const float* dy, const float* f, float* df, int B, int C,
-                                             int HW, hipStream_t stream) {
-  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  if ((HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)dy)) & 15) == 0)
-    CENET_LAUNCH(gate_pix_bwd_reduce_v4_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
+  if (plane_vw<T>(HW, x, y) == 4 && (((uintptr_t)f) & 15) == 0)
+    CENET_LAUNCH((gate_pix_fwd_kernel<T, 4>), dim3(B * C, chunks_for(HW / 4)), dim3(256), stream, x, f, y, C, HW / 4);
   else
-    CENET_LAUNCH(gate_pix_bwd_reduce_kernel, dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
+    CENET_LAUNCH((gate_pix_fwd_kernel<T, 1>), dim3(B * C, chunks_for(HW)), dim3(256), stream, x, f, y, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
-extern "C" int cenet_srm_bwd_apply_f32(const float* x, const float* dy, const float* f, const float* u, const float* du,
-                                       const int* amax, float* dx, int B, int C, int HW, hipStream_t stream) {
+CENET_TWIN(gate_pix_fwd, (const T* x, const float* f, T* y, int B, int C, int HW, hipStream_t stream), (x, f, y, B, C, HW, stream))
+
+template <typename T>
+static int gate_pix_bwd_reduce_impl(const T* x, const T* dy, const float* f, float* df, int B, int C, int HW,
+                                    hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  if ((HW & 3) == 0 && quad_aligned<T>(x) && quad_aligned<T>(dy))
+    CENET_LAUNCH((gate_pix_bwd_reduce_v4_kernel<T>), dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
+  else
+    CENET_LAUNCH((gate_pix_bwd_reduce_kernel<T>), dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+CENET_TWIN(gate_pix_bwd_reduce, (const T* x, const T* dy, const float* f, float* df, int B, int C, int HW, hipStream_t stream),
+           (x, dy, f, df, B, C, HW, stream))
+
+template <typename T>
+static int srm_bwd_apply_impl(const T* x, const T* dy, const float* f, const float* u, const float* du, const int* amax, T* dx,
+                              int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(srm_bwd_apply_kernel, dim3(B * C, chunks_for(HW)), dim3(256), stream, x, dy, f, u, du, amax, dx, C, HW);
+  if (plane_vw<T>(HW, x, dy, dx) == 4)
+    CENET_LAUNCH((srm_bwd_apply_kernel<T, 4>), dim3(B * C, chunks_for(HW / 4)), dim3(256), stream, x, dy, f, u, du, amax, dx, C,
+                 HW / 4);
+  else
+    CENET_LAUNCH((srm_bwd_apply_kernel<T, 1>), dim3(B * C, chunks_for(HW)), dim3(256), stream, x, dy, f, u, du, amax, dx, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+CENET_TWIN(srm_bwd_apply, (const T* x, const T* dy, const float* f, const float* u, const float* du, const int* amax, T* dx,
+                           int B, int C, int HW, hipStream_t stream), (x, dy, f, u, du, amax, dx, B, C, HW, stream))

@@ -1,8 +1,10 @@
 """Thin, autograd-free Python bindings over the C ABI in include/cenet_hip.h.
 
 Every function here launches hand-written HIP kernels on the current torch stream with raw data pointers.
-Tensors must be fp32 and live on the GPU (the only exception is the tests' host-side SIMT checker, which
-swaps the library handle — see cenet_amd/_lib.py).
+Tensors must live on the GPU (the only exception is the tests' host-side SIMT checker, which swaps the library handle — see
+cenet_amd/_lib.py).  Activation tensors are fp32 (parity mode) or bf16 (throughput mode); a call whose tensor arguments
+include a bf16 tensor goes to the `_bf16` twin of the entry point (include/cenet_hip.h), in which every ACTIVATION pointer
+is bf16 while parameters, statistics and parameter gradients stay fp32.
 """
 from __future__ import annotations
 
@@ -21,8 +23,9 @@ def _chk(*ts):
     for t in ts:
         if t is None:
             continue
-        if t.dtype not in (torch.float32, torch.int32, torch.int64, torch.uint8):
-            raise TypeError(f"cenet_amd kernels are fp32 (int32 / int64 / uint8 for indices and masks); got {t.dtype}")
+        if t.dtype not in (torch.float32, torch.bfloat16, torch.int32, torch.int64, torch.uint8):
+            raise TypeError(f"cenet_amd kernels take fp32 / bf16 tensors (int32 / int64 / uint8 for indices and masks); "
+                            f"got {t.dtype}")
         if not t.is_cuda and not _lib.is_hostsim():
             raise RuntimeError("cenet_amd kernels run on the MI355X only: tensor is not on a CUDA/HIP device "
                                "(there is no CPU fallback)")
@@ -47,10 +50,23 @@ def stream():
 # ------------------------------------------------------------------------------------------------
 # GEMM / implicit GEMM
 # ------------------------------------------------------------------------------------------------
+BF16 = torch.bfloat16
+
+
+def is_bf16(t) -> bool:
+    return t is not None and t.dtype == BF16
+
+
+def esz(t) -> int:
+    """bytes per element of a tensor-like (tensors, ops._OffsetView)"""
+    return 2 if t.dtype == BF16 else 4
+
+
 def mat_plain(t: torch.Tensor, sr: int, sc: int, sb: int = 0, skb: int = 0, kfast: int = 0, offset: int = 0,
               sb2: int = 0, kinner: int = 0, sk_outer: int = 0) -> MatT:
     m = MatT()
-    m.ptr = t.data_ptr() + 4 * offset
+    m.bf16 = t.dtype == BF16  # python-side attribute: picks cenet_gemm_bf16
+    m.ptr = t.data_ptr() + esz(t) * offset
     m.sb, m.sb2, m.skb, m.sr, m.sc = sb, sb2, skb, sr, sc
     m.kinner, m.sk_outer = kinner, sk_outer
     m.mode, m.kfast = 0, kfast
@@ -61,7 +77,8 @@ def mat_im2col(t: torch.Tensor, *, sb: int, skb: int, sci: int, sy: int, sx: int
                Hs: int, Ws: int, stride: int, pad: int, dil: int, patch_is_row: int, transposed: int,
                kfast: int, offset: int = 0) -> MatT:
     m = MatT()
-    m.ptr = t.data_ptr() + 4 * offset
+    m.bf16 = t.dtype == BF16
+    m.ptr = t.data_ptr() + esz(t) * offset
     m.sb, m.skb, m.sr, m.sc = sb, skb, 0, 0
     m.mode, m.kfast = 1, kfast
     m.patch_is_row, m.transposed = patch_is_row, transposed
@@ -85,15 +102,21 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
          alpha: float = 1.0, c_offset: int = 0, r_offset: int = 0, nb_inner: int = 1, scb2: int = 0, srb2: int = 0,
          col2im: Optional[dict] = None, bscale_rows: int = 0):
     _chk(Cout, bias, bscale, R)
+    if A.bf16 != B.bf16:
+        raise TypeError("cenet_gemm: A and B must have the same element type (fp32 or bf16)")
+    want = torch.float32 if (atomic or not A.bf16) else BF16  # atomic epilogues always add into fp32
+    if Cout.dtype != want or (R is not None and R.dtype != want):
+        raise TypeError(f"cenet_gemm: C / R must be {want} here (operands {'bf16' if A.bf16 else 'fp32'}, atomic={atomic}); "
+                        f"got {Cout.dtype}" + (f" / {R.dtype}" if R is not None else ""))
     e = EpiT()
-    e.C = Cout.data_ptr() + 4 * c_offset
+    e.C = Cout.data_ptr() + esz(Cout) * c_offset
     e.scb, e.scb2, e.scr, e.scc = scb, scb2, scr, scc
     e.bias = bias.data_ptr() if bias is not None else None
     e.bias_on_row = int(bias_on_row)
     e.act, e.slope = ACT[act], slope
     e.bscale = bscale.data_ptr() if bscale is not None else None
     e.bscale_rows = bscale_rows
-    e.R = (R.data_ptr() + 4 * r_offset) if R is not None else None
+    e.R = (R.data_ptr() + esz(R) * r_offset) if R is not None else None
     e.srb, e.srb2, e.srr, e.src = srb, srb2, srr, src
     e.atomic, e.alpha = int(atomic), alpha
     if col2im is not None:  # scatter epilogue (data-gradient of strided convolutions)
@@ -101,17 +124,33 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
         e.cKH, e.cKW, e.cPw = col2im["KH"], col2im["KW"], col2im["Pw"]
         e.cHs, e.cWs, e.cstride, e.cpad = col2im["Hs"], col2im["Ws"], col2im["stride"], col2im["pad"]
         e.csci, e.csy, e.csx = col2im["sci"], col2im["sy"], col2im["sx"]
-    rc = _lib.lib().cenet_gemm_f32(C.byref(A), C.byref(B), C.byref(e), M, N, K, nbatch, nb_inner, nkb, splits, stream())
-    _lib.check(rc, "cenet_gemm_f32")
+    fn = _lib.lib().cenet_gemm_bf16 if A.bf16 else _lib.lib().cenet_gemm_f32
+    rc = fn(C.byref(A), C.byref(B), C.byref(e), M, N, K, nbatch, nb_inner, nkb, splits, stream())
+    _lib.check(rc, "cenet_gemm_bf16" if A.bf16 else "cenet_gemm_f32")
 
 
 # ------------------------------------------------------------------------------------------------
 # generic call helper
 # ------------------------------------------------------------------------------------------------
+class Ptr:
+    """a tensor seen from an element offset: Ptr(t, off) is passed to _call like a tensor"""
+
+    def __init__(self, t, off: int = 0):
+        self.t, self.off = t, off
+        self.dtype = t.dtype
+
+    def data_ptr(self):
+        return self.t.data_ptr() + esz(self.t) * self.off
+
+
 def _call(name, *args):
+    """name ends in `_f32`; a bf16 tensor among the arguments selects the `_bf16` twin (all activation arguments of one call
+    share their element type)"""
     cargs = []
+    bf = False
     for a in args:
-        if isinstance(a, torch.Tensor):
+        if isinstance(a, (torch.Tensor, Ptr)):
+            bf = bf or a.dtype == BF16
             cargs.append(C.c_void_p(a.data_ptr()))
         elif a is None:
             cargs.append(C.c_void_p(0))
@@ -123,6 +162,9 @@ def _call(name, *args):
             cargs.append(C.c_long(a) if abs(a) > 0x7FFFFFFF else C.c_int(a))
         else:
             cargs.append(a)
+    if bf:
+        assert name.endswith("_f32"), name
+        name = name[:-4] + "_bf16"
     rc = getattr(_lib.lib(), name)(*cargs, stream())
     _lib.check(rc, name)
 
@@ -138,19 +180,27 @@ class AttnT(C.Structure):
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("delta", C.c_void_p)] + \
                [(n, C.c_long) for n in ("qsb", "qsh", "qsi", "qsd", "ksb", "ksh", "ksi", "ksd", "vsb", "vsh", "vsi", "vsd",
                                         "osb", "osh", "osi", "osd")] + \
-               [(n, C.c_int) for n in ("B", "H", "Nq", "Nk", "D", "Dv", "v_head_div")] + [("scale", C.c_float)] + [("dkv_zeroed", C.c_int)]
+               [(n, C.c_int) for n in ("B", "H", "Nq", "Nk", "D", "Dv", "v_head_div")] + [("scale", C.c_float)] + \
+               [("dkv_zeroed", C.c_int), ("dkv_f32", C.c_int)]
 
 
 def flash_supported(D: int, Dv: int) -> bool:
     return bool(_lib.lib().cenet_flash_attn_supported(int(D), int(Dv)))
 
 
-def flash_fwd(a: AttnT):
-    _lib.check(_lib.lib().cenet_flash_attn_fwd_f32(C.byref(a), stream()), "cenet_flash_attn_fwd_f32")
+def flashb_supported(D: int, Dv: int) -> bool:
+    """head dims the bf16 (throughput-mode) tiled attention kernels cover: D <= 64, Dv <= 128"""
+    return D <= 64 and Dv <= 128
 
 
-def flash_bwd(a: AttnT):
-    _lib.check(_lib.lib().cenet_flash_attn_bwd_f32(C.byref(a), stream()), "cenet_flash_attn_bwd_f32")
+def flash_fwd(a: AttnT, bf16: bool = False):
+    name = "cenet_flash_attn_fwd_bf16" if bf16 else "cenet_flash_attn_fwd_f32"
+    _lib.check(getattr(_lib.lib(), name)(C.byref(a), stream()), name)
+
+
+def flash_bwd(a: AttnT, bf16: bool = False):
+    name = "cenet_flash_attn_bwd_bf16" if bf16 else "cenet_flash_attn_bwd_f32"
+    _lib.check(getattr(_lib.lib(), name)(C.byref(a), stream()), name)
 
 
 def softmax_rows_fwd(x, y, rows, n):
@@ -307,14 +357,12 @@ def srm_bwd_apply(x, dy, f, u, du, amax, dx, B, Cn, HW):
 # ---- glue ---------------------------------------------------------------------------------------------------
 def transpose(x, sxb, y, syb, B, R, Cc, x_off=0, y_off=0):
     _chk(x, y)
-    _call("cenet_transpose_f32", C.c_void_p(x.data_ptr() + 4 * x_off), L(sxb), C.c_void_p(y.data_ptr() + 4 * y_off), L(syb),
-          B, R, Cc)
+    _call("cenet_transpose_f32", Ptr(x, x_off), L(sxb), Ptr(y, y_off), L(syb), B, R, Cc)
 
 
 def copy_batched(x, sxb, y, syb, B, n, accumulate=False, x_off=0, y_off=0):
     _chk(x, y)
-    _call("cenet_copy_batched_f32", C.c_void_p(x.data_ptr() + 4 * x_off), L(sxb), C.c_void_p(y.data_ptr() + 4 * y_off),
-          L(syb), B, L(n), int(accumulate))
+    _call("cenet_copy_batched_f32", Ptr(x, x_off), L(sxb), Ptr(y, y_off), L(syb), B, L(n), int(accumulate))
 
 
 def patch_tok(src, dst, B, Ho, Wo, C, S, inverse=False):
@@ -458,14 +506,63 @@ def min_sqdist(a_i32, b_i32, out_i32):
     _call("cenet_min_sqdist_i32", a_i32, a_i32.shape[0], b_i32, b_i32.shape[0], out_i32)
 
 
-def sgd_step(p, g, buf, hyper5, n):
-    _chk(p, g, buf, hyper5)
-    _call("cenet_sgd_step_f32", p, g, buf, hyper5, L(n))
+def sgd_step(p, g, buf, hyper5, n, shadow=None):
+    """shadow: bf16 copy of the parameters, rewritten by the same kernel (the GEMM operand of the throughput mode)"""
+    _chk(p, g, buf, hyper5, shadow)
+    if shadow is None:
+        _call("cenet_sgd_step_f32", p, g, buf, hyper5, L(n))
+    else:
+        rc = _lib.lib().cenet_sgd_step_shadow_f32(P(p), P(g), P(buf), P(hyper5), L(n), P(shadow), stream())
+        _lib.check(rc, "cenet_sgd_step_shadow_f32")
+
+
+def cast(x: torch.Tensor, dtype) -> torch.Tensor:
+    """fp32 <-> bf16 copy of a contiguous tensor (cenet_cast_*); returns x itself when it already has `dtype`"""
+    if x.dtype == dtype:
+        return x
+    _chk(x)
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=dtype)
+    name = "cenet_cast_f32_to_bf16" if dtype == BF16 else "cenet_cast_bf16_to_f32"
+    _lib.check(getattr(_lib.lib(), name)(P(x), P(y), L(x.numel()), stream()), name)
+    return y
+
+
+def cast_into(x: torch.Tensor, y: torch.Tensor):
+    name = "cenet_cast_f32_to_bf16" if y.dtype == BF16 else "cenet_cast_bf16_to_f32"
+    assert x.dtype != y.dtype and x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous()
+    _lib.check(getattr(_lib.lib(), name)(P(x), P(y), L(x.numel()), stream()), name)
+
+
+def wq(W: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """The weight as the GEMM operand for activations of `like`'s type: W itself (fp32) or its bf16 shadow.
+    A parameter that lives in a `ParamArena` has a slot in the arena's bf16 buffer, refreshed by the fused SGD kernel; any
+    other tensor gets a private shadow.  A shadow is re-cast whenever the tensor was modified in place through torch since
+    (`Tensor._version`), e.g. by load_state_dict or a torch optimizer."""
+    if like.dtype != BF16 or W is None:
+        return W
+    sh = getattr(W, "_cenet_shadow", None)
+    if sh is None:
+        slot = getattr(W, "_cenet_arena_slot", None)
+        if slot is not None and slot[0].params.device == W.device:
+            slot[0].enable_shadow()
+            sh = W._cenet_shadow
+    if sh is None or sh.shape != W.shape or sh.device != W.device:
+        sh = torch.empty(W.shape, device=W.device, dtype=BF16)
+        W._cenet_shadow = sh
+        W._cenet_shadow_ver = -1
+    if W._cenet_shadow_ver != W._version:
+        cast_into(W.detach() if W.is_contiguous() else W.detach().contiguous(), sh)
+        W._cenet_shadow_ver = W._version
+    return sh
 
 
 def zero_(t: torch.Tensor):
+    """zero-fill with the library's own kernel (a kernel node replays faithfully in a hipGraph; hipMemsetAsync did not)"""
     _chk(t)
-    _call("cenet_zero_f32", t, L(t.numel()))
+    nbytes = t.numel() * t.element_size()
+    assert t.is_contiguous() and nbytes % 4 == 0, "zero_: contiguous tensor of a whole number of 32-bit words"
+    _lib.check(_lib.lib().cenet_zero_f32(P(t), L(nbytes // 4), stream()), "cenet_zero_f32")
     return t
 
 
@@ -474,9 +571,12 @@ def conv_direct_supported(Cin: int, Cout: int, k: int, stride: int, pad: int) ->
 
 
 def conv_direct(x, w, y, B, Cin, Cout, H, W, k, dgrad):
-    """bf16-operand direct convolution (LDS halo tiles, weights resident in LDS); dgrad: x=dY, w=forward weight, y=dX."""
+    """direct convolution on bf16 tensors (LDS halo tiles, weights resident in LDS; w = fp32 master weight);
+    dgrad: x=dY, w=forward weight, y=dX."""
     _chk(x, w, y)
-    _call("cenet_conv_direct_bf16", x, w, y, B, Cin, Cout, H, W, k, int(dgrad))
+    assert x.dtype == BF16 and y.dtype == BF16 and w.dtype == torch.float32
+    rc = _lib.lib().cenet_conv_direct_bf16(P(x), P(w), P(y), B, Cin, Cout, H, W, k, int(dgrad), stream())
+    _lib.check(rc, "cenet_conv_direct_bf16")
 
 
 def conv_wgrad_direct_supported(Cin: int, Cout: int, k: int, stride: int, pad: int) -> bool:
@@ -486,16 +586,30 @@ def conv_wgrad_direct_supported(Cin: int, Cout: int, k: int, stride: int, pad: i
 def conv_wgrad_direct(x, dy, dw, B, Cin, Cout, H, W, k):
     """bf16-operand direct weight gradient (LDS tiles of dY and the X halo, funnel-shifted tap windows): dw += dY (*) x."""
     _chk(x, dy, dw)
+    assert x.dtype == BF16 and dy.dtype == BF16 and dw.dtype == torch.float32
     fn = _lib.lib().cenet_conv_wgrad_direct_ws_floats
     fn.restype = C.c_long
     ws = torch.empty(int(fn(int(Cin), int(Cout), int(k))), device=x.device, dtype=torch.float32)
-    _call("cenet_conv_wgrad_direct_bf16", x, dy, dw, ws, B, Cin, Cout, H, W, k)
+    rc = _lib.lib().cenet_conv_wgrad_direct_bf16(P(x), P(dy), P(dw), P(ws), B, Cin, Cout, H, W, k, stream())
+    _lib.check(rc, "cenet_conv_wgrad_direct_bf16")
+
+
+# ---- precision mode ------------------------------------------------------------------------------------------------
+# The element type of the tensors decides which kernels run: fp32 tensors take the exact fp32 MFMA chain (parity mode),
+# bf16 tensors the throughput path (bf16 in HBM and in the MFMA operands, fp32 accumulation / softmax / statistics).  This
+# flag only tells `CENet.forward` to cast its input (and thereby the whole network) to bf16.
+_COMPUTE_BF16 = False
 
 
 def set_compute_bf16(on: bool) -> bool:
-    """GEMM/conv operand precision: False = fp32 (parity mode, default), True = bf16 operands + fp32 accumulate."""
-    return bool(_lib.lib().cenet_set_compute_bf16(int(bool(on))))
+    """False (default): CENet runs in fp32, the mode every parity claim is made in.  True: CENet casts its input to bf16 and
+    all activations, activation gradients and GEMM operands are bf16 (weights through a bf16 shadow of the fp32 master
+    copy); logits come back as bf16.  Returns the previous setting."""
+    global _COMPUTE_BF16
+    old = _COMPUTE_BF16
+    _COMPUTE_BF16 = bool(on)
+    return old
 
 
 def get_compute_bf16() -> bool:
-    return bool(_lib.lib().cenet_get_compute_bf16())
+    return _COMPUTE_BF16

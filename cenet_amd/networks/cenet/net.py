@@ -1,8 +1,10 @@
 """CENet — mirrors reference src/networks/cenet/net.py:8-64 (same ctor signature, attributes and state-dict keys)."""
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
+from ... import kern
 from .decoders import Decoder
 from .encoder import get_encoder2d
 from .out import OutHead
@@ -23,6 +25,10 @@ class CENet(nn.Module):
                            up_block=out_up_block, up_ks=out_up_ks)
 
     def forward(self, x):
+        # throughput mode (kern.set_compute_bf16): the whole network runs on bf16 tensors — the input is rounded once here
+        # and every kernel downstream follows the element type of its input; logits come back as bf16
+        if kern.get_compute_bf16() and x.dtype == torch.float32:
+            x = kern.cast(x, torch.bfloat16)
         # grayscale input: the 3-channel replication of net.py:55 is a zero-stride channel read in patch_embed1
         x1, x2, x3, x4 = self.backbone(x)
         sync = getattr(self, "_grad_sync", None)

@@ -24,7 +24,24 @@ Tensor = torch.Tensor
 
 
 def _empty(shape, ref: Tensor, dtype=torch.float32) -> Tensor:
+    """fp32 (statistics, workspaces, parameter-gradient scratch) unless a dtype is given"""
     return torch.empty(shape, device=ref.device, dtype=dtype)
+
+
+def _act(shape, ref: Tensor) -> Tensor:
+    """an ACTIVATION tensor: the storage type of `ref` (fp32 in parity mode, bf16 in throughput mode)"""
+    return torch.empty(shape, device=ref.device, dtype=ref.dtype)
+
+
+def _bf(t: Tensor) -> bool:
+    return t.dtype == torch.bfloat16
+
+
+def _acc32(shape, ref: Tensor, like: Optional[Tensor] = None) -> Tensor:
+    """fp32 accumulator for an atomic epilogue (zero-filled, or a copy of `like`)"""
+    if like is not None:
+        return kern.cast(like, torch.float32) if like.dtype != torch.float32 else like.clone()
+    return _zeros(shape, ref)
 
 
 def _zeros(shape, ref: Tensor) -> Tensor:
@@ -124,22 +141,26 @@ class LinearFn(Function):
         resid = _c(resid)
         shape = x.shape[:-1] + (N,)
         splits = 1
-        if split_k and bscale is None and K >= 1024 and kern.get_compute_bf16():  # parity mode keeps a deterministic forward
+        Wq = kern.wq(W, x)  # fp32 weight, or its bf16 shadow for bf16 activations
+        if split_k and bscale is None and K >= 1024 and _bf(x):  # parity mode keeps a deterministic forward
             splits = kern.pick_splits(M, N, 1, K // 32)
         if splits > 1:
             # few output tiles under a long reduction: split K over workgroups; the partial sums are added atomically
-            # onto an output pre-filled with bias + residual
+            # onto an fp32 output pre-filled with bias + residual, which is then rounded to the activation type
             if resid is not None:
-                y = resid + b if b is not None else resid.clone()
+                y = _acc32(shape, x, resid)
+                if b is not None:
+                    y += b
             elif b is not None:
                 y = b.expand(shape).contiguous()
             else:
                 y = _zeros(shape, x)
-            kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
+            kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(Wq, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
                       splits=splits, atomic=True)
+            y = kern.cast(y, x.dtype)
         else:
-            y = _empty(shape, x)
-            kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
+            y = _act(shape, x)
+            kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(Wq, 1, K, kfast=1), y, M, N, K, scr=N, scc=1,
                       bias=b, bscale=bscale, bscale_rows=bs_rows, R=resid, srr=N, src=1)
         ctx.save_for_backward(x, W, bscale)
         ctx.refs = (W, b)
@@ -169,7 +190,8 @@ class LinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            kern.gemm(kern.mat_plain(gs, N, 1, kfast=1), kern.mat_plain(W, K, 1, kfast=0), dx, R, K, N, scr=K, scc=1)
+            kern.gemm(kern.mat_plain(gs, N, 1, kfast=1), kern.mat_plain(kern.wq(Wp, x), K, 1, kfast=0), dx, R, K, N, scr=K,
+                      scc=1)
         return dx, None, None, (g if ctx.has_resid else None), None, None
 
 
@@ -189,9 +211,9 @@ class Conv1x1Fn(Function):
         B, Cin = x.shape[:2]
         HW = x.numel() // (B * Cin)
         Cout = W.shape[0]
-        y = _empty((B, Cout) + tuple(x.shape[2:]), x)
+        y = _act((B, Cout) + tuple(x.shape[2:]), x)
         resid = _c(resid)
-        kern.gemm(kern.mat_plain(W, Cin, 1, kfast=1), kern.mat_plain(x, HW, 1, sb=Cin * HW), y, Cout, HW, Cin, scr=HW,
+        kern.gemm(kern.mat_plain(kern.wq(W, x), Cin, 1, kfast=1), kern.mat_plain(x, HW, 1, sb=Cin * HW), y, Cout, HW, Cin, scr=HW,
                   scc=1, scb=Cout * HW, nbatch=B, bias=b, bias_on_row=True, R=resid, srb=Cout * HW, srr=HW, src=1)
         ctx.save_for_backward(x, W)
         ctx.refs = (W, b)
@@ -219,7 +241,7 @@ class Conv1x1Fn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            kern.gemm(kern.mat_plain(W, 1, Cin, kfast=0), kern.mat_plain(g, HW, 1, sb=Cout * HW), dx, Cin, HW, Cout,
+            kern.gemm(kern.mat_plain(kern.wq(Wp, x), 1, Cin, kfast=0), kern.mat_plain(g, HW, 1, sb=Cout * HW), dx, Cin, HW, Cout,
                       scr=HW, scc=1, scb=Cin * HW, nbatch=B)
         return dx, None, None, (g if ctx.has_resid else None)
 
@@ -243,9 +265,9 @@ class Conv2dFn(Function):
         Wo = (Wd + 2 * pad - k) // stride + 1
         Kd = Cin * k * k
         plain_nchw = (sb == Cin * H * Wd and sc == H * Wd and sy == Wd and sx == 1 and out_layout == "nchw" and b is None)
-        ctx.direct = bool(plain_nchw and kern.get_compute_bf16() and kern.conv_direct_supported(Cin, Cout, k, stride, pad))
-        if ctx.direct:  # bf16 mode, output-head convs: LDS-halo direct convolution (conv_direct.hip)
-            y = _empty((B, Cout, Ho, Wo), x)
+        ctx.direct = bool(plain_nchw and _bf(x) and kern.conv_direct_supported(Cin, Cout, k, stride, pad))
+        if ctx.direct:  # bf16 tensors, output-head convs: LDS-halo direct convolution (conv_direct.hip)
+            y = _act((B, Cout, Ho, Wo), x)
             kern.conv_direct(x, W, y, B, Cin, Cout, H, Wd, k, 0)
             ctx.save_for_backward(x, W)
             ctx.refs = (W, b)
@@ -257,18 +279,20 @@ class Conv2dFn(Function):
         shape = (B, Cout, Ho, Wo) if out_layout == "nchw" else (B, Ho * Wo, Cout)
         scr, scc = (Ho * Wo, 1) if out_layout == "nchw" else (1, Cout)
         tiles = B * ((Cout + 63) // 64) * ((Ho * Wo + 63) // 64)
-        if tiles <= 256 and Kd >= 1024 and kern.get_compute_bf16():  # parity mode keeps a deterministic forward
+        Wq = kern.wq(W, x)
+        if tiles <= 256 and Kd >= 1024 and _bf(x):  # parity mode keeps a deterministic forward
             # few output tiles under a long reduction (the 8x8/4x4/2x2 spatial-reduction convs of pvtv2.py:93-95): split K
-            # over workgroups; the partial sums are added atomically onto an output pre-filled with the bias
+            # over workgroups; the partial sums are added atomically onto an fp32 output pre-filled with the bias
             if b is None:
                 y = _zeros(shape, x)
             else:
                 y = (b.view(1, Cout, 1, 1) if out_layout == "nchw" else b.view(1, 1, Cout)).expand(shape).contiguous()
-            kern.gemm(kern.mat_plain(W, Kd, 1, kfast=1), Bm, y, Cout, Ho * Wo, Kd, scr=scr, scc=scc, scb=Cout * Ho * Wo,
+            kern.gemm(kern.mat_plain(Wq, Kd, 1, kfast=1), Bm, y, Cout, Ho * Wo, Kd, scr=scr, scc=scc, scb=Cout * Ho * Wo,
                       nbatch=B, splits=kern.pick_splits(Cout, Ho * Wo, B, Kd // 32), atomic=True)
+            y = kern.cast(y, x.dtype)
         else:
-            y = _empty(shape, x)
-            kern.gemm(kern.mat_plain(W, Kd, 1, kfast=1), Bm, y, Cout, Ho * Wo, Kd, scr=scr, scc=scc, scb=Cout * Ho * Wo,
+            y = _act(shape, x)
+            kern.gemm(kern.mat_plain(Wq, Kd, 1, kfast=1), Bm, y, Cout, Ho * Wo, Kd, scr=scr, scc=scc, scb=Cout * Ho * Wo,
                       nbatch=B, bias=b, bias_on_row=True)
         ctx.save_for_backward(x, W)
         ctx.refs = (W, b)
@@ -293,8 +317,8 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             # dX[b][ci][q] = sum_{co,ky,kx} W[co,ci,ky,kx] * dY gathered (transposed map); written with x's strides
             assert sy == Wd * sx, "conv2d data-gradient needs a pixel-linear input layout"
-            if (getattr(ctx, "direct", False) and kern.get_compute_bf16()
-                    and kern.conv_direct_supported(Cout, Cin, k, stride, pad)):
+            Wq = kern.wq(Wp, x)
+            if getattr(ctx, "direct", False) and _bf(g) and kern.conv_direct_supported(Cout, Cin, k, stride, pad):
                 dx = torch.empty_like(x)  # same direct kernel, weights read transposed + flipped
                 kern.conv_direct(g, W, dx, B, Cout, Cin, H, Wd, k, 1)
             elif stride == 1:
@@ -302,22 +326,27 @@ class Conv2dFn(Function):
                 dx = torch.empty_like(x)
                 Bm = kern.mat_im2col(g, sb=Cout * Ho * Wo, skb=0, sci=g_sc, sy=Wo * g_sp, sx=g_sp, KH=k, KW=k, Pw=Wd,
                                      Hs=Ho, Ws=Wo, stride=stride, pad=pad, dil=1, patch_is_row=1, transposed=1, kfast=0)
-                A = kern.mat_plain(W, k * k, 1, kfast=1, kinner=k * k, sk_outer=Cin * k * k)
+                A = kern.mat_plain(Wq, k * k, 1, kfast=1, kinner=k * k, sk_outer=Cin * k * k)
                 kern.gemm(A, Bm, dx, Cin, H * Wd, Cout * k * k, scr=sc, scc=sx, scb=sb, nbatch=B)
             else:
                 # strided conv: the gather form would multiply stride^2 - 1 zeros per useful MAC (64x for the 8x8/8
                 # SR conv). Dense GEMM dXcol[(ci,ky,kx), p] = W^T dY[:, p] with a col2im scatter epilogue instead.
                 overlap = k > stride
                 exact = (pad == 0 and H % stride == 0 and Wd % stride == 0 and k == stride)
-                dx = torch.empty_like(x) if exact else _zeros(x.shape, x)
-                kern.gemm(kern.mat_plain(W, 1, Kd, kfast=0), kern.mat_plain(g, g_sc, g_sp, sb=Cout * Ho * Wo,
-                                                                              kfast=int(g_sc == 1)),
+                # overlapping patches are scatter-ADDED (atomics): that needs an fp32 image, rounded to the activation type after
+                if overlap:
+                    dx = _zeros(x.shape, x)
+                else:
+                    dx = torch.empty_like(x) if exact else kern.zero_(torch.empty_like(x))
+                kern.gemm(kern.mat_plain(Wq, 1, Kd, kfast=0), kern.mat_plain(g, g_sc, g_sp, sb=Cout * Ho * Wo,
+                                                                               kfast=int(g_sc == 1)),
                           dx, Kd, Ho * Wo, Cout, scr=0, scc=0, scb=sb, nbatch=B, atomic=overlap,
                           col2im=dict(KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride, pad=pad, sci=sc, sy=sy, sx=sx))
+                dx = kern.cast(dx, x.dtype)
         dW, db = grad_buf(Wp), grad_buf(bp)
         if dW is not None or db is not None:
             with _wgrad_side(g, x):
-                if (dW is not None and getattr(ctx, "direct", False) and kern.get_compute_bf16()
+                if (dW is not None and getattr(ctx, "direct", False) and _bf(g)
                         and kern.conv_wgrad_direct_supported(Cin, Cout, k, stride, pad)):
                     kern.conv_wgrad_direct(x, g, dW, B, Cin, Cout, H, Wd, k)  # conv_direct.hip, direct weight gradient
                 elif dW is not None:
@@ -354,7 +383,7 @@ class PatchTokFn(Function):
         x = _c(x)
         B, N, C = x.shape
         Ho, Wo = H // s, Wd // s
-        xp = _empty((B, Ho * Wo, C * s * s), x)
+        xp = _act((B, Ho * Wo, C * s * s), x)
         kern.patch_tok(x, xp, B, Ho, Wo, C, s)
         ctx.geom = (B, Ho, Wo, C, s, N)
         return xp
@@ -363,7 +392,7 @@ class PatchTokFn(Function):
     def backward(ctx, g):
         B, Ho, Wo, C, s, N = ctx.geom
         g = _c(g)
-        dx = _empty((B, N, C), g)
+        dx = _act((B, N, C), g)
         kern.patch_tok(g, dx, B, Ho, Wo, C, s, inverse=True)
         return dx, None, None, None
 
@@ -599,7 +628,8 @@ class _AttnDesc:
         self.qoff, self.koff, self.voff = qoff, koff, voff   # element offsets into q/k/v storage
 
     def fill(self, a: "kern.AttnT", q, k, v, o, lse):
-        a.q, a.k, a.v = q.data_ptr() + 4 * self.qoff, k.data_ptr() + 4 * self.koff, v.data_ptr() + 4 * self.voff
+        e = kern.esz(q)
+        a.q, a.k, a.v = q.data_ptr() + e * self.qoff, k.data_ptr() + e * self.koff, v.data_ptr() + e * self.voff
         a.o, a.lse = o.data_ptr(), lse.data_ptr() if lse is not None else None
         a.qsb, a.qsh, a.qsi, a.qsd = self.qs
         a.ksb, a.ksh, a.ksi, a.ksd = self.ks
@@ -612,20 +642,22 @@ class _AttnDesc:
 def _attn_forward(d: _AttnDesc, q, k, v, o):
     """returns the tensors to save for backward: ('flash', lse) or ('mat', P)."""
     kern._chk(q, k, v, o)
-    if kern.flash_supported(d.D, d.Dv):
+    bf = _bf(q)
+    if kern.flashb_supported(d.D, d.Dv) if bf else kern.flash_supported(d.D, d.Dv):
         lse = _empty((d.B, d.H, d.Nq), q)
         a = kern.AttnT()
         d.fill(a, q, k, v, o, lse)
-        kern.flash_fwd(a)
+        kern.flash_fwd(a, bf)
         return "flash", lse
-    # materialised path (large head dims, small N): S = scale QK^T ; P = softmax ; O = P V
+    # materialised path (large head dims, small N): S = scale QK^T ; P = softmax ; O = P V.  The scores stay fp32 in both
+    # modes (bf16 operands: the GEMM adds atomically into a zero-filled fp32 S); P has the operand type.
     BH = d.B * d.H
-    S = _empty((BH, d.Nq, d.Nk), q)
+    S = _zeros((BH, d.Nq, d.Nk), q) if bf else _empty((BH, d.Nq, d.Nk), q)
     kern.gemm(kern.mat_plain(q, d.qs[2], d.qs[3], sb=d.qs[0], sb2=d.qs[1], kfast=int(d.qs[3] == 1), offset=d.qoff),
               kern.mat_plain(k, d.ks[3], d.ks[2], sb=d.ks[0], sb2=d.ks[1], kfast=int(d.ks[3] == 1), offset=d.koff),
               S, d.Nq, d.Nk, d.D, scr=d.Nk, scc=1, scb=d.H * d.Nq * d.Nk, scb2=d.Nq * d.Nk, nbatch=BH, nb_inner=d.H,
-              alpha=d.scale)
-    P = torch.empty_like(S)
+              alpha=d.scale, atomic=bf)
+    P = _act(S.shape, q)
     kern.softmax_rows_fwd(S, P, BH * d.Nq, d.Nk)
     vh = d.vdiv
     kern.gemm(kern.mat_plain(P, d.Nk, 1, sb=d.H * d.Nq * d.Nk, sb2=d.Nq * d.Nk, kfast=1),
@@ -644,24 +676,28 @@ def _vmat(d: _AttnDesc, v, vh):
 def _attn_backward(d: _AttnDesc, kind, saved, q, k, v, o, g, dq, dk, dv, dkv_zeroed=False):
     """dq/dk/dv are written in the layouts of q/k/v (offsets included); dv must be zero-filled when vdiv > 1.
     dkv_zeroed: dk and dv are zero-filled (lets the kernels split the query range when there are few keys)."""
+    bf = _bf(q)
     if kind == "flash":
         a = kern.AttnT()
         d.fill(a, q, k, v, o, saved)
         a.dkv_zeroed = int(dkv_zeroed)
         delta = _empty((d.B, d.H, d.Nq), q)
         a.dout = g.data_ptr()
-        a.dq, a.dk, a.dv = dq.data_ptr() + 4 * d.qoff, dk.data_ptr() + 4 * d.koff, dv.data_ptr() + 4 * d.voff
+        a.dq = dq.data_ptr() + kern.esz(dq) * d.qoff
+        a.dk, a.dv = dk.data_ptr() + kern.esz(dk) * d.koff, dv.data_ptr() + kern.esz(dv) * d.voff
+        a.dkv_f32 = int(bf and dk.dtype == torch.float32)
+        assert dk.dtype == dv.dtype
         a.delta = delta.data_ptr()
-        kern.flash_bwd(a)
+        kern.flash_bwd(a, bf)
         return
     P = saved
     BH = d.B * d.H
     HN = d.H * d.Nq * d.Nk
     NN = d.Nq * d.Nk
-    dP = torch.empty_like(P)
+    dP = _zeros(P.shape, P) if bf else torch.empty_like(P)  # fp32 in both modes (see _attn_forward)
     kern.gemm(kern.mat_plain(g, d.os[2], d.os[3], sb=d.os[0], sb2=d.os[1], kfast=int(d.os[3] == 1)),
               kern.mat_plain(v, d.vs[3], d.vs[2], sb=d.vs[0], sb2=d.vs[1], kfast=int(d.vs[3] == 1), offset=d.voff),
-              dP, d.Nq, d.Nk, d.Dv, scr=d.Nk, scc=1, scb=HN, scb2=NN, nbatch=BH, nb_inner=d.H)
+              dP, d.Nq, d.Nk, d.Dv, scr=d.Nk, scc=1, scb=HN, scb2=NN, nbatch=BH, nb_inner=d.H, atomic=bf)
     dS = torch.empty_like(P)
     kern.softmax_rows_bwd(P, dP, dS, BH * d.Nq, d.Nk)
     kern.gemm(kern.mat_plain(dS, d.Nk, 1, sb=HN, sb2=NN, kfast=1),
@@ -700,9 +736,10 @@ class SRAttentionFn(Function):
         q, kv, o, saved = ctx.saved_tensors
         g = _c(g)
         few_keys = ctx.d.Nk <= 128 and ctx.d.Nq >= 1024  # spatial-reduction attention: 49 keys under 784..3136 queries
+        # (the query range is then sliced over workgroups and dK / dV are added atomically: fp32 accumulator)
         dq, dkv = torch.empty_like(q), (_zeros(kv.shape, kv) if few_keys else torch.empty_like(kv))
         _attn_backward(ctx.d, ctx.kind, saved, q, kv, kv, o, g, dq, dkv, dkv, dkv_zeroed=few_keys)
-        return dq, dkv, None
+        return dq, kern.cast(dkv, kv.dtype), None
 
 
 class NonlocalAttnFn(Function):
@@ -739,8 +776,8 @@ class DiffAttnHeadsFn(Function):
         B, N, E = q.shape
         hd = E // H // 2
         dv = 2 * hd
-        U = _empty((B, 2 * H, N, dv), q)
-        if kern.flash_supported(hd, dv):
+        U = _act((B, 2 * H, N, dv), q)
+        if kern.flashb_supported(hd, dv) if _bf(q) else kern.flash_supported(hd, dv):
             d = _AttnDesc(B, 2 * H, N, N, hd, dv, hd ** -0.5, 2, (N * E, hd, E, 1), (N * E, hd, E, 1), (N * E, dv, E, 1),
                           (2 * H * N * dv, N * dv, dv, 1))
             kind, saved = _attn_forward(d, q, k, v, U)
@@ -769,15 +806,24 @@ class DiffAttnHeadsFn(Function):
         B, N, E = q.shape
         hd = E // ctx.H // 2
         dv = 2 * hd
-        dq, dk = torch.empty_like(q), torch.empty_like(k)
-        dvv = _zeros(v.shape, v)
+        dq = torch.empty_like(q)
         if len(ctx.descs) == 1:
+            # the two softmax heads of a pair ADD into the gradient of their shared value head: fp32 accumulators (dk rides
+            # along: one flag covers both)
+            dvv = _zeros(v.shape, v)
+            dk = _empty(k.shape, k) if _bf(k) else torch.empty_like(k)
             _attn_backward(ctx.descs[0], ctx.kind, saved_list[0], q, k, v, U, g, dq, dk, dvv)
+            dk, dvv = kern.cast(dk, k.dtype), kern.cast(dvv, v.dtype)
         else:
+            dk = torch.empty_like(k)
+            dvv = None
             for s, (d, saved) in enumerate(zip(ctx.descs, saved_list)):
                 tmp = torch.empty_like(v)
                 _attn_backward(d, ctx.kind, saved, q, k, v, _OffsetView(U, s * N * dv), _OffsetView(g, s * N * dv), dq, dk, tmp)
-                kern.copy_batched(tmp, 0, dvv, 0, 1, tmp.numel(), accumulate=True)
+                if dvv is None:
+                    dvv = tmp
+                else:
+                    kern.copy_batched(tmp, 0, dvv, 0, 1, tmp.numel(), accumulate=True)
         return dq, dk, dvv, None
 
 
@@ -789,7 +835,7 @@ class _OffsetView:
         self.device, self.dtype, self.is_cuda = t.device, t.dtype, t.is_cuda
 
     def data_ptr(self):
-        return self._t.data_ptr() + 4 * self._off
+        return self._t.data_ptr() + kern.esz(self._t) * self._off
 
 
 def sr_attention(q, kv, heads):
@@ -814,7 +860,7 @@ class DiffAttnCombineFn(Function):
         H = H2 // 2
         lam = _empty((3,), U)
         kern.diffattn_lambda_fwd(lq1, lk1, lq2, lk2, lambda_init, lam, lq1.numel())
-        out = _empty((B, N, H * dv), U)
+        out = _act((B, N, H * dv), U)
         kern.diffattn_combine_fwd(U, lam, out, B, H, N, dv, 1e-5, 1.0 - lambda_init)
         ctx.save_for_backward(U, lam, lq1, lk1, lq2, lk2)
         ctx.refs = (lq1, lk1, lq2, lk2)
@@ -850,7 +896,7 @@ class TokToNCHWFn(Function):
     def forward(ctx, x, H, Wd):
         x = _c(x)
         B, N, Cn = x.shape
-        y = _empty((B, Cn, H, Wd), x)
+        y = _act((B, Cn, H, Wd), x)
         kern.transpose(x, N * Cn, y, N * Cn, B, N, Cn)
         return y
 
@@ -858,7 +904,7 @@ class TokToNCHWFn(Function):
     def backward(ctx, g):
         g = _c(g)
         B, Cn, H, Wd = g.shape
-        dx = _empty((B, H * Wd, Cn), g)
+        dx = _act((B, H * Wd, Cn), g)
         kern.transpose(g, Cn * H * Wd, dx, Cn * H * Wd, B, Cn, H * Wd)
         return dx, None, None
 
@@ -876,7 +922,7 @@ class Concat2Fn(Function):
         B, Ca = a.shape[:2]
         Cb = b.shape[1]
         HW = a.numel() // (B * Ca)
-        y = _empty((B, Ca + Cb) + tuple(a.shape[2:]), a)
+        y = _act((B, Ca + Cb) + tuple(a.shape[2:]), a)
         kern.copy_batched(a, Ca * HW, y, (Ca + Cb) * HW, B, Ca * HW)
         kern.copy_batched(b, Cb * HW, y, (Ca + Cb) * HW, B, Cb * HW, y_off=Ca * HW)
         ctx.dims = (Ca, Cb, HW)
@@ -887,8 +933,8 @@ class Concat2Fn(Function):
         g = _c(g)
         Ca, Cb, HW = ctx.dims
         B = g.shape[0]
-        da = _empty((B, Ca) + tuple(g.shape[2:]), g)
-        db = _empty((B, Cb) + tuple(g.shape[2:]), g)
+        da = _act((B, Ca) + tuple(g.shape[2:]), g)
+        db = _act((B, Cb) + tuple(g.shape[2:]), g)
         kern.copy_batched(g, (Ca + Cb) * HW, da, Ca * HW, B, Ca * HW)
         kern.copy_batched(g, (Ca + Cb) * HW, db, Cb * HW, B, Cb * HW, x_off=Ca * HW)
         return da, db
@@ -908,7 +954,7 @@ class SplitChannelsFn(Function):
         HW = x.numel() // (B * Cn)
         outs, lo = [], 0
         for c in sizes:
-            y = _empty((B, c) + tuple(x.shape[2:]), x)
+            y = _act((B, c) + tuple(x.shape[2:]), x)
             kern.copy_batched(x, Cn * HW, y, c * HW, B, c * HW, x_off=lo * HW)
             outs.append(y)
             lo += c
@@ -921,7 +967,7 @@ class SplitChannelsFn(Function):
         B, Cn = shape[:2]
         ref = next(g for g in gs if g is not None)
         covered = sum(sizes) == Cn and all(g is not None for g in gs)
-        dx = _empty(shape, ref) if covered else _zeros(shape, ref)
+        dx = _act(shape, ref) if covered else kern.zero_(_act(shape, ref))
         lo = 0
         for c, g in zip(sizes, gs):
             if g is not None:
@@ -1055,7 +1101,7 @@ class BilinearFn(Function):
     def forward(ctx, x, Ho, Wo, sh, sw, align):
         x = _c(x)
         B, Cn, Hi, Wi = x.shape
-        y = _empty((B, Cn, Ho, Wo), x)
+        y = _act((B, Cn, Ho, Wo), x)
         kern.bilinear_fwd(x, Cn * Hi * Wi, y, Cn * Ho * Wo, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align)
         ctx.cfg = (Hi, Wi, Ho, Wo, sh, sw, align)
         return y
@@ -1065,7 +1111,7 @@ class BilinearFn(Function):
         Hi, Wi, Ho, Wo, sh, sw, align = ctx.cfg
         g = _c(g)
         B, Cn = g.shape[:2]
-        dx = _empty((B, Cn, Hi, Wi), g)
+        dx = _act((B, Cn, Hi, Wi), g)
         kern.bilinear_bwd(g, Cn * Ho * Wo, dx, Cn * Hi * Wi, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align)
         return dx, None, None, None, None, None
 
@@ -1097,7 +1143,7 @@ class Nearest2xFn(Function):
     def forward(ctx, x):
         x = _c(x)
         B, Cn, Hi, Wi = x.shape
-        y = _empty((B, Cn, 2 * Hi, 2 * Wi), x)
+        y = _act((B, Cn, 2 * Hi, 2 * Wi), x)
         kern.nearest2x_fwd(x, Cn * Hi * Wi, y, 4 * Cn * Hi * Wi, B, Cn, Hi, Wi)
         return y
 
@@ -1106,7 +1152,7 @@ class Nearest2xFn(Function):
         g = _c(g)
         B, Cn, Ho, Wo = g.shape
         Hi, Wi = Ho // 2, Wo // 2
-        dx = _empty((B, Cn, Hi, Wi), g)
+        dx = _act((B, Cn, Hi, Wi), g)
         kern.nearest2x_bwd(g, Cn * Ho * Wo, dx, Cn * Hi * Wi, B, Cn, Hi, Wi)
         return dx
 
@@ -1120,7 +1166,7 @@ class AdaptiveAvgPoolFn(Function):
     def forward(ctx, x, Ho, Wo):
         x = _c(x)
         B, Cn, Hi, Wi = x.shape
-        y = _empty((B, Cn, Ho, Wo), x)
+        y = _act((B, Cn, Ho, Wo), x)
         kern.avgpool_fwd(x, Cn * Hi * Wi, y, Cn * Ho * Wo, B, Cn, Hi, Wi, Ho, Wo)
         ctx.cfg = (Hi, Wi, Ho, Wo)
         return y
@@ -1130,7 +1176,7 @@ class AdaptiveAvgPoolFn(Function):
         Hi, Wi, Ho, Wo = ctx.cfg
         g = _c(g)
         B, Cn = g.shape[:2]
-        dx = _empty((B, Cn, Hi, Wi), g)
+        dx = _act((B, Cn, Hi, Wi), g)
         kern.avgpool_bwd(g, Cn * Ho * Wo, dx, Cn * Hi * Wi, B, Cn, Hi, Wi, Ho, Wo)
         return dx, None, None
 
@@ -1146,7 +1192,7 @@ class MaxPool2ScaleFn(Function):
     def forward(ctx, x, w):
         x = _c(x)
         B, Cn, Hi, Wi = x.shape
-        y = _empty((B, Cn, Hi // 2, Wi // 2), x)
+        y = _act((B, Cn, Hi // 2, Wi // 2), x)
         kern.maxpool2_fwd(x, y, Cn * (Hi // 2) * (Wi // 2), w, B, Cn, Hi, Wi)
         ctx.save_for_backward(x, w)
         ctx.refs = (w,)

@@ -62,6 +62,21 @@ class ParamArena:
                 self.index[n] = (o, p.numel())
         self._plist = [p for _, p, _ in order]
         self._offs = [o for _, _, o in order]
+        # bf16 shadow of the parameters (the GEMM operand of the throughput mode), created on first use by kern.wq
+        self.shadow = None
+        for p, o in zip(self._plist, self._offs):
+            p._cenet_arena_slot = (self, o)
+
+    def enable_shadow(self):
+        """One flat bf16 copy of `params`; every parameter's `_cenet_shadow` is a view into it.  `FusedSGD.step` rewrites it
+        in the same kernel that updates the fp32 master copy."""
+        if self.shadow is not None:
+            return
+        self.shadow = torch.empty(self.numel, device=self.params.device, dtype=torch.bfloat16)
+        kern.cast_into(self.params, self.shadow)
+        for p, o in zip(self._plist, self._offs):
+            p._cenet_shadow = self.shadow[o:o + p.numel()].view(p.shape)
+            p._cenet_shadow_ver = p._version
 
     def _home(self, o: int, n: int, shape):
         def home():
@@ -144,7 +159,7 @@ class FusedSGD:
             self._sync_hyper()
         from . import ops
         ops.wgrad_join()  # weight gradients issued on the side stream (ops._WgradSide) must have landed
-        kern.sgd_step(self.arena.params, self.arena.grads, self.buf, self.hyper, self.arena.numel)
+        kern.sgd_step(self.arena.params, self.arena.grads, self.buf, self.hyper, self.arena.numel, self.arena.shadow)
         self._steps += 1
 
     def prepare(self):

@@ -8,7 +8,8 @@
  * Conventions: raw device pointers; no allocation, no ownership transfer and no host synchronisation inside;
  * workspaces are passed in; every call takes the HIP stream to launch on and is re-entrant (called from the
  * autograd worker thread); return 0 on success, non-zero error code otherwise (the Python wrapper raises).
- * All tensors are fp32 ("f32" suffix).  "NCHW" tensors are addressed as ptr[b*sb + c*HW + y*W + x] so that a
+ * Tensors are fp32 ("_f32" entry points: the parity mode) or, for activations, bf16 ("_bf16" twins at the end of this header:
+ * the throughput mode).  "NCHW" tensors are addressed as ptr[b*sb + c*HW + y*W + x] so that a
  * channel slice of a larger tensor is (ptr + lo*HW, sb = Ctotal*HW).  "TOK" tensors are [B, N, C] contiguous.
  * Functions whose name ends in _acc ADD into their gradient outputs (the flat gradient arena is zeroed once
  * per step), using float atomics where several workgroups share a destination.
@@ -35,7 +36,7 @@ typedef void* cenet_stream_t;
  *   elem = in-range ? ptr[b*sb + kb*skb + ci*sci + iy*sy + ix*sx] : 0.
  * kfast: 1 if consecutive k are adjacent in memory (picks the coalesced staging pattern). */
 typedef struct {
-  const float* ptr;
+  const void* ptr;           /* fp32 or bf16 elements (the `dtype` argument of cenet_gemm); strides count ELEMENTS */
   long sb, sb2, skb, sr, sc; /* batch z -> (z / nb_inner, z % nb_inner): offset = (z/nb_inner)*sb + (z%nb_inner)*sb2 */
   long sk_outer;             /* mode 0 with kinner > 0: k -> (k / kinner)*sk_outer + (k % kinner)*(sc or sr) */
   int kinner;
@@ -45,16 +46,17 @@ typedef struct {
   long sci, sy, sx;
 } cenet_mat_t;
 
-/* Epilogue: v = alpha*acc; atomic ? C += v : C = bscale[b]*act(v + bias) + R. */
+/* Epilogue: v = alpha*acc; atomic ? C += v : C = bscale[b]*act(v + bias) + R.  C and R have the operands' element type,
+ * except that an ATOMIC epilogue (split-K, scatter-add) always adds into an fp32 C; bias / bscale are always fp32. */
 typedef struct {
-  float* C;
+  void* C;
   long scb, scb2, scr, scc;
   const float* bias;
   int bias_on_row;
   int act;
   float slope;
   const float* bscale;
-  const float* R;
+  const void* R;
   long srb, srb2, srr, src;
   int atomic;
   float alpha;
@@ -72,50 +74,60 @@ typedef struct {
  * nlb.py:106-115,142; blocks.py:178,211,320; dseb.py:164; unet.py:156-197; multihead_diffattn.py:79-81,126. */
 int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K,
                    int nbatch, int nb_inner, int nkb, int splits, cenet_stream_t stream);
+/* The same contraction on bf16 tensors (throughput mode): A, B (and C / R unless E->atomic) hold bf16 elements, products
+ * run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; weights are passed as their bf16 shadow copy (cenet_sgd_step_shadow_f32
+ * / cenet_cast_f32_to_bf16). */
+int cenet_gemm_bf16(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K,
+                    int nbatch, int nb_inner, int nkb, int splits, cenet_stream_t stream);
 
-/* Process-wide operand precision of the GEMM / conv core: 0 = fp32 operands (exact, parity mode, default),
- * 1 = operands rounded to bf16 on their way into LDS, fp32 accumulate (throughput mode). Returns the old value. */
-int cenet_set_compute_bf16(int on);
-int cenet_get_compute_bf16(void);
-
-/* Direct ("LDS halo") stride-1 same-padded convolution for the bf16-operand mode (conv_direct.hip): replaces
+/* Direct ("LDS halo") stride-1 same-padded convolution on bf16 tensors (throughput mode, conv_direct.hip): replaces
  * aten::convolution(+ data-gradient) for out.py:41-49,59 (5x5 32->32, 3x3 64->64, 3x3 64->32 and their dgrads).
- * dgrad = 1: x is dY [B,Cin,H,W], w is the ORIGINAL forward weight [Cin,Cout,k,k], y is dX [B,Cout,H,W]. */
+ * x, y: bf16; w: the fp32 master weight.  dgrad = 1: x is dY [B,Cin,H,W], w is the ORIGINAL forward weight [Cin,Cout,k,k],
+ * y is dX [B,Cout,H,W]. */
 int cenet_conv_direct_supported(int Cin, int Cout, int k, int stride, int pad);
-int cenet_conv_direct_bf16(const float* x, const float* w, float* y, int B, int Cin, int Cout, int H, int W, int k, int dgrad,
-                           cenet_stream_t stream);
+int cenet_conv_direct_bf16(const unsigned short* x, const float* w, unsigned short* y, int B, int Cin, int Cout, int H, int W,
+                           int k, int dgrad, cenet_stream_t stream);
 /* Weight gradient of the same convolutions in the same mode (replaces the implicit-GEMM wgrad of unet.py:156-197,
  * blocks.py:211, out.py:41-49 for 5x5 32->32 and 3x3 64->64 / 64->32): dw_acc[Cout,Cin,k,k] += dY (*) X.
  * ws: cenet_conv_wgrad_direct_ws_floats(Cin, Cout, k) floats of scratch (per-workgroup partial sums). */
 int cenet_conv_wgrad_direct_supported(int Cin, int Cout, int k, int stride, int pad);
 long cenet_conv_wgrad_direct_ws_floats(int Cin, int Cout, int k);
-int cenet_conv_wgrad_direct_bf16(const float* x, const float* dy, float* dw_acc, float* ws, int B, int Cin, int Cout, int H,
-                                 int W, int k, cenet_stream_t stream);
+int cenet_conv_wgrad_direct_bf16(const unsigned short* x, const unsigned short* dy, float* dw_acc, float* ws, int B, int Cin,
+                                 int Cout, int H, int W, int k, cenet_stream_t stream);
 
 /* ---- attention (attn.hip) -------------------------------------------------------------------------------- */
 /* Element (b,h,i,d) of Q = q[b*qsb + h*qsh + i*qsi + d*qsd]; same for K (Nk rows), V (head h / v_head_div,
- * width Dv) and O / dO (strides os*).  lse, delta: [B,H,Nq].  When v_head_div > 1 the backward ADDS into dv
- * with atomics (caller zero-fills dv). */
+ * width Dv) and O / dO (strides os*).  lse, delta: [B,H,Nq] fp32.  q, k, v, o, dout, dq, dk, dv are fp32 (`_f32` entry points)
+ * or bf16 (`_bf16`).  When v_head_div > 1 the backward ADDS into dv with atomics (caller zero-fills dv); with bf16 tensors
+ * atomic accumulation needs `dkv_f32`: dk and dv then point to fp32 buffers laid out like k and v. */
 typedef struct {
-  const float *q, *k, *v;
-  float* o;
+  const void *q, *k, *v;
+  void* o;
   float* lse;
-  const float* dout;
-  float *dq, *dk, *dv, *delta;
+  const void* dout;
+  void *dq, *dk, *dv;
+  float* delta;
   long qsb, qsh, qsi, qsd, ksb, ksh, ksi, ksd, vsb, vsh, vsi, vsd, osb, osh, osi, osd;
   int B, H, Nq, Nk, D, Dv, v_head_div;
   float scale;
   int dkv_zeroed; /* backward only: caller guarantees dk / dv are zero-filled, so the library may slice the query range
                      over workgroups and accumulate dK / dV atomically (few keys under many queries) */
+  int dkv_f32;    /* bf16 entry points only: dk / dv are fp32 accumulators */
 } cenet_attn_t;
 /* Replaces q@k^T -> softmax -> @v (pvtv2.py:101-105; nlb.py:117-138; multihead_diffattn.py:96-116) and backward.
  * Supported head dims: D<=64 with Dv<=128 (cenet_flash_attn_supported). */
 int cenet_flash_attn_supported(int D, int Dv);
 int cenet_flash_attn_fwd_f32(const cenet_attn_t* p, cenet_stream_t stream);
 int cenet_flash_attn_bwd_f32(const cenet_attn_t* p, cenet_stream_t stream);
-/* Row softmax for the materialised path (head dims > 128): aten::_softmax(+_backward_data). */
+int cenet_flash_attn_fwd_bf16(const cenet_attn_t* p, cenet_stream_t stream);
+int cenet_flash_attn_bwd_bf16(const cenet_attn_t* p, cenet_stream_t stream);
+/* Row softmax for the materialised path (head dims > 128): aten::_softmax(+_backward_data).  Scores x and score gradients
+ * dy are fp32 in both forms; the probabilities y and dx have the storage type of the entry point. */
 int cenet_softmax_rows_fwd_f32(const float* x, float* y, long rows, int n, cenet_stream_t stream);
 int cenet_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long rows, int n, cenet_stream_t stream);
+int cenet_softmax_rows_fwd_bf16(const float* x, unsigned short* y, long rows, int n, cenet_stream_t stream);
+int cenet_softmax_rows_bwd_bf16(const unsigned short* y, const float* dy, unsigned short* dx, long rows, int n,
+                                cenet_stream_t stream);
 
 /* ---- normalisation (norm.hip) ----------------------------------------------------------------------------- */
 /* aten::native_layer_norm(+_backward) — pvtv2.py:117,124,166,69,221-245. x,y [rows,C]. */
@@ -266,6 +278,132 @@ int cenet_min_sqdist_i32(const int* a, int na, const int* b, int nb, int* out, c
 /* torch.optim.SGD(momentum, weight_decay) over a flat arena; hyper5 (device) = [lr, momentum, wd, grad_scale, first_step] */
 int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, cenet_stream_t stream);
 int cenet_zero_f32(float* p, long n, cenet_stream_t stream);
+
+/* ---- bf16 twins (throughput mode) ------------------------------------------------------------------------------------
+ * Every `cenet_<op>_f32` entry point above that takes ACTIVATION tensors has a twin `cenet_<op>_bf16` with the same
+ * semantics and argument order in which the activation / activation-gradient pointers are bf16 (`unsigned short`, bf16 bit
+ * patterns) while parameters, statistics (mean / rstd / var / lse / u / z / f ...), workspaces and parameter gradients stay
+ * fp32.  Arithmetic is fp32 in both; the reference sites are those of the fp32 declaration.  (GEMM, attention, direct conv
+ * and row softmax declare their bf16 forms next to the fp32 ones.) */
+/* attn.hip */
+int cenet_softmax_rows_fwd_bf16(const float* x, unsigned short* y, long rows, int n, cenet_stream_t stream);
+int cenet_softmax_rows_bwd_bf16(const unsigned short* y, const float* dy, unsigned short* dx, long rows, int n,
+    cenet_stream_t stream);
+/* dwconv.hip */
+int cenet_dwconv3x3_nchw_bf16(const unsigned short* x, long sxb, const float* w, const float* bias, unsigned short* y, long
+    syb, unsigned short* a, long sab, int B, int C, int H, int W, int dil, int flip, int act, float slope, cenet_stream_t
+    stream);
+int cenet_dwconv3x3_tok_bf16(const unsigned short* x, const float* w, const float* bias, unsigned short* y, unsigned short*
+    a, int B, int C, int H, int W, int flip, int act, float slope, cenet_stream_t stream);
+int cenet_dwconv3x3_wgrad_nchw_acc_bf16(const unsigned short* x, long sxb, const unsigned short* dy, long sgb, float*
+    dw_acc, float* dbias_acc, int B, int C, int H, int W, int dil, cenet_stream_t stream);
+int cenet_dwconv3x3_wgrad_tok_acc_bf16(const unsigned short* x, const unsigned short* dy, float* dw_acc, float* dbias_acc,
+    int B, int C, int H, int W, cenet_stream_t stream);
+/* elementwise.hip */
+int cenet_transpose_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, int R, int Cc,
+    cenet_stream_t stream);
+int cenet_copy_batched_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, long n, int accumulate,
+    cenet_stream_t stream);
+int cenet_patch_tok_bf16(const unsigned short* src, unsigned short* dst, int B, int Ho, int Wo, int C, int S, int inverse,
+    cenet_stream_t stream);
+int cenet_scale_batch_bf16(const unsigned short* x, const float* s, unsigned short* y, int B, long n, cenet_stream_t
+    stream);
+int cenet_act_fwd_bf16(const unsigned short* x, unsigned short* y, long n, int act, float slope, cenet_stream_t stream);
+int cenet_act_bwd_bf16(const unsigned short* pre, const unsigned short* dy, unsigned short* dx, long n, int act, float
+    slope, cenet_stream_t stream);
+int cenet_silu_mul_fwd_bf16(const unsigned short* a, const unsigned short* b, unsigned short* y, long n, cenet_stream_t
+    stream);
+int cenet_silu_mul_bwd_bf16(const unsigned short* a, const unsigned short* b, const unsigned short* dy, unsigned short* da,
+    unsigned short* db, long n, cenet_stream_t stream);
+int cenet_mix_fwd_bf16(const unsigned short* x, const unsigned short* p, const float* w, unsigned short* z, long n,
+    cenet_stream_t stream);
+int cenet_mix_bwd_acc_bf16(const unsigned short* x, const unsigned short* p, const float* w, const unsigned short* dz,
+    unsigned short* dx, unsigned short* dp, float* dw_acc, long n, cenet_stream_t stream);
+int cenet_scale_residual_fwd_bf16(const unsigned short* x, const unsigned short* y, const float* ls, unsigned short* out,
+    int B, int C, int HW, cenet_stream_t stream);
+int cenet_scale_chan_bf16(const unsigned short* g, const float* ls, unsigned short* out, int B, int C, int HW,
+    cenet_stream_t stream);
+int cenet_chan_dot_acc_bf16(const unsigned short* a, long sab, const unsigned short* b, long sbb, float* out_acc, int B, int
+    C, int HW, cenet_stream_t stream);
+int cenet_col_sum_acc_bf16(const unsigned short* a, float* out_acc, long R, int C, cenet_stream_t stream);
+int cenet_add_act_fwd_bf16(const unsigned short* a, const unsigned short* b, unsigned short* out, long n, int act, float
+    slope, cenet_stream_t stream);
+int cenet_lrelu_bwd_from_out_bf16(const unsigned short* out, const unsigned short* dy, unsigned short* dx, long n, float
+    slope, cenet_stream_t stream);
+int cenet_dseb_combine_fwd_bf16(const unsigned short* y, const unsigned short* r0, const unsigned short* r1, const unsigned
+    short* r2, int n, const float* w, const unsigned short* diff, float ycoef, unsigned short* z, int B, int C, int HW,
+    cenet_stream_t stream);
+int cenet_dseb_combine_bwd_acc_bf16(const unsigned short* y, const unsigned short* r0, const unsigned short* r1, const
+    unsigned short* r2, int n, const float* w, const unsigned short* diff, float ycoef, const unsigned short* dz, unsigned
+    short* dy, unsigned short* dr0, unsigned short* dr1, unsigned short* dr2, unsigned short* ddiff, float* dw_acc, int B,
+    int C, int HW, cenet_stream_t stream);
+int cenet_diffattn_combine_fwd_bf16(const unsigned short* U, const float* lam3, unsigned short* out, int B, int H, int N,
+    int dv, float eps, float post, cenet_stream_t stream);
+int cenet_diffattn_combine_bwd_acc_bf16(const unsigned short* U, const float* lam3, const unsigned short* dout, unsigned
+    short* dU, float* dlam_acc, int B, int H, int N, int dv, float eps, float post, cenet_stream_t stream);
+/* loss_optim.hip */
+int cenet_seg_loss_fwd_bf16(const unsigned short* logits, const float* labels, float* acc, float* loss, int B, int K, int H,
+    int W, float w_dice, float w_ce, float w_bd, cenet_stream_t stream);
+int cenet_seg_loss_bwd_bf16(const unsigned short* logits, const float* labels, const float* acc, const float* gout, unsigned
+    short* dlogits, int B, int K, int H, int W, float w_dice, float w_ce, float w_bd, cenet_stream_t stream);
+int cenet_argmax_counts_bf16(const unsigned short* logits, const float* labels, float* pred, unsigned* counts, int B, int K,
+    int HW, cenet_stream_t stream);
+/* norm.hip */
+int cenet_layernorm_fwd_bf16(const unsigned short* x, const float* gamma, const float* beta, unsigned short* y, float* mean,
+    float* rstd, int rows, int C, float eps, cenet_stream_t stream);
+int cenet_layernorm_bwd_add_acc_bf16(const unsigned short* dy, const unsigned short* x, const float* gamma, const float*
+    mean, const float* rstd, const unsigned short* dx_add, unsigned short* dx, float* dgamma_acc, float* dbeta_acc, int
+    rows, int C, cenet_stream_t stream);
+int cenet_layernorm_bwd_acc_bf16(const unsigned short* dy, const unsigned short* x, const float* gamma, const float* mean,
+    const float* rstd, unsigned short* dx, float* dgamma_acc, float* dbeta_acc, int rows, int C, cenet_stream_t stream);
+int cenet_bn_stats_bf16(const unsigned short* x, long sb, int B, int C, int HW, float* ws, float* mean, float* var, float*
+    running_mean, float* running_var, float momentum, long* num_batches_tracked, cenet_stream_t stream);
+int cenet_bn_apply_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, const float* mean, const float* var,
+    float eps, const float* gamma, const float* beta, int act, float slope, int B, int C, int HW, cenet_stream_t stream);
+int cenet_bn_bwd_acc_bf16(const unsigned short* dy, long sgb, const unsigned short* x, long sxb, unsigned short* dx, long
+    sdb, const float* mean, const float* var, float eps, const float* gamma, const float* beta, int act, float slope, int B,
+    int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, cenet_stream_t stream);
+/* resample.hip */
+int cenet_bilinear_fwd_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, int C, int Hi, int Wi,
+    int Ho, int Wo, float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
+int cenet_bilinear_bwd_bf16(const unsigned short* dy, long sgb, unsigned short* dx, long sdb, int B, int C, int Hi, int Wi,
+    int Ho, int Wo, float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
+int cenet_nearest2x_fwd_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, int C, int Hi, int Wi,
+    cenet_stream_t stream);
+int cenet_nearest2x_bwd_bf16(const unsigned short* dy, long sgb, unsigned short* dx, long sdb, int B, int C, int Hi, int Wi,
+    cenet_stream_t stream);
+int cenet_adaptive_avgpool_fwd_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, int C, int Hi,
+    int Wi, int Ho, int Wo, cenet_stream_t stream);
+int cenet_adaptive_avgpool_bwd_bf16(const unsigned short* dy, long sgb, unsigned short* dx, long sdb, int B, int C, int Hi,
+    int Wi, int Ho, int Wo, cenet_stream_t stream);
+int cenet_maxpool2_fwd_bf16(const unsigned short* x, unsigned short* y, long syb, const float* scale, int B, int C, int Hi,
+    int Wi, cenet_stream_t stream);
+int cenet_maxpool2_bwd_acc_bf16(const unsigned short* x, const unsigned short* dy, long sgb, unsigned short* dx, const
+    float* scale, float* dscale_acc, int B, int C, int Hi, int Wi, cenet_stream_t stream);
+/* stats.hip */
+int cenet_ccu_stats_fwd_bf16(const unsigned short* x, const float* fc1, const float* fc2, float* u, int* amax, float* z, int
+    B, int C, int HW, cenet_stream_t stream);
+int cenet_gate_chan_fwd_bf16(const unsigned short* x, const float* g, unsigned short* y, int BC, int HW, cenet_stream_t
+    stream);
+int cenet_gate_chan_bwd_reduce_bf16(const unsigned short* x, const unsigned short* dy, const float* g, float* dg, int BC,
+    int HW, cenet_stream_t stream);
+int cenet_ccu_bwd_apply_acc_bf16(const unsigned short* x, const unsigned short* dy, const float* g, const float* dz, const
+    float* u, const int* amax, const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc, unsigned short* dx, int
+    B, int C, int HW, cenet_stream_t stream);
+int cenet_srm_stats_fwd_bf16(const unsigned short* x, float* u, int* amax, int B, int C, int HW, cenet_stream_t stream);
+int cenet_gate_pix_fwd_bf16(const unsigned short* x, const float* f, unsigned short* y, int B, int C, int HW, cenet_stream_t
+    stream);
+int cenet_gate_pix_bwd_reduce_bf16(const unsigned short* x, const unsigned short* dy, const float* f, float* df, int B, int
+    C, int HW, cenet_stream_t stream);
+int cenet_srm_bwd_apply_bf16(const unsigned short* x, const unsigned short* dy, const float* f, const float* u, const float*
+    du, const int* amax, unsigned short* dx, int B, int C, int HW, cenet_stream_t stream);
+
+/* bf16 shadow of the fp32 master parameters (the weight operand of cenet_gemm_bf16): the fused SGD step can rewrite it in the
+ * same pass (shadow_bf16 may be NULL), and whole buffers can be converted either way. */
+int cenet_sgd_step_shadow_f32(float* p, const float* g, float* buf, const float* hyper5, long n, unsigned short* shadow_bf16,
+                              cenet_stream_t stream);
+int cenet_cast_f32_to_bf16(const float* x, unsigned short* y, long n, cenet_stream_t stream);
+int cenet_cast_bf16_to_f32(const unsigned short* x, float* y, long n, cenet_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
-"""Throughput mode (bf16 MFMA operands, fp32 accumulate / softmax / statistics): the attention and GEMM cores are checked
-against fp32 PyTorch with bf16-level tolerances; whole-model deviation from the fp32 goldens is bounded on the GPU.
-The parity mode (fp32 operands) is the one held to the 1e-3 bar elsewhere."""
+"""Throughput mode (bf16 tensors in HBM and in the MFMA operands; fp32 accumulate / softmax / statistics): the attention,
+GEMM and direct-conv cores on bf16 inputs are checked against fp32 PyTorch evaluated on the same bf16-rounded values, with
+bf16-level tolerances; whole-model deviation from the fp32 goldens is bounded on the GPU.  The parity mode (fp32 tensors)
+is the one held to the 1e-3 bar elsewhere."""
 import os
 
 import numpy as np
@@ -15,70 +16,81 @@ def _rel(a, b):
     return (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
 
 
+BF = torch.bfloat16
+
+
 @pytest.fixture
 def bf16_mode():
-    def on():
-        return kern.set_compute_bf16(True)
-    yield on
-    kern.set_compute_bf16(False)
+    """kept for the tests' shape: the element type of the tensors selects the kernels, nothing is global any more"""
+    yield lambda: None
+
+
+def bft(t, dev):
+    """bf16 leaf tensor on the device"""
+    return t.to(dev).to(BF).requires_grad_(True)
+
+
+def f32(t):
+    """the fp32 values a bf16 tensor holds (reference input)"""
+    return t.detach().float().cpu().clone().requires_grad_(True)
 
 
 # the last case has >= 1024 queries over 49 keys: two query tiles per wave, query-sliced dK/dV with atomics
 @pytest.mark.parametrize("B,N,Nk,C,heads", [(2, 70, 49, 128, 2), (1, 130, 130, 64, 1), (1, 1030, 49, 64, 1)])
 def test_sr_attention_bf16(dev, bf16_mode, B, N, Nk, C, heads):
     g = torch.Generator().manual_seed(0)
-    q = torch.randn(B, N, C, generator=g).to(dev).requires_grad_(True)
-    kv = torch.randn(B, Nk, 2 * C, generator=g).to(dev).requires_grad_(True)
-    go = torch.randn(B, N, C, generator=g).to(dev)
+    q = bft(torch.randn(B, N, C, generator=g), dev)
+    kv = bft(torch.randn(B, Nk, 2 * C, generator=g), dev)
+    go = torch.randn(B, N, C, generator=g).to(dev).to(BF)
     bf16_mode()
     o = ops.sr_attention(q, kv, heads)
     o.backward(go)
     hd = C // heads
-    qr, kvr = q.detach().cpu().clone().requires_grad_(True), kv.detach().cpu().clone().requires_grad_(True)
+    qr, kvr = f32(q), f32(kv)
     qh = qr.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
     kk = kvr.reshape(B, Nk, 2, heads, hd).permute(2, 0, 3, 1, 4)
     ref = (torch.softmax(qh @ kk[0].transpose(-1, -2) * hd ** -0.5, -1) @ kk[1]).transpose(1, 2).reshape(B, N, C)
-    ref.backward(go.cpu())
-    assert _rel(o.detach().cpu(), ref.detach()) < 2e-2
-    assert _rel(q.grad.cpu(), qr.grad) < 4e-2
-    assert _rel(kv.grad.cpu(), kvr.grad) < 4e-2
+    ref.backward(go.float().cpu())
+    assert _rel(o.detach().float().cpu(), ref.detach()) < 2e-2
+    assert _rel(q.grad.float().cpu(), qr.grad) < 4e-2
+    assert _rel(kv.grad.float().cpu(), kvr.grad) < 4e-2
 
 
 @pytest.mark.parametrize("B,N,H,hd", [(2, 96, 2, 16), (1, 1030, 1, 16)])  # second: 128-query / 128-key workgroups
 def test_diff_attention_heads_bf16(dev, bf16_mode, B, N, H, hd):
     E = 2 * H * hd
     g = torch.Generator().manual_seed(1)
-    q, k, v = (torch.randn(B, N, E, generator=g).to(dev).requires_grad_(True) for _ in range(3))
-    go = torch.randn(B, 2 * H, N, 2 * hd, generator=g).to(dev)
+    q, k, v = (bft(torch.randn(B, N, E, generator=g), dev) for _ in range(3))
+    go = torch.randn(B, 2 * H, N, 2 * hd, generator=g).to(dev).to(BF)
     bf16_mode()
     U = ops.diff_attention_heads(q, k, v, H)
     U.backward(go)
-    qr, kr, vr = (t.detach().cpu().clone().requires_grad_(True) for t in (q, k, v))
+    qr, kr, vr = (f32(t) for t in (q, k, v))
     qh = qr.view(B, N, 2 * H, hd).transpose(1, 2)
     kh = kr.view(B, N, 2 * H, hd).transpose(1, 2)
     vh = vr.view(B, N, H, 2 * hd).transpose(1, 2).repeat_interleave(2, dim=1)
     ref = torch.softmax(qh @ kh.transpose(-1, -2) * hd ** -0.5, -1) @ vh
-    ref.backward(go.cpu())
-    assert _rel(U.detach().cpu(), ref.detach()) < 2e-2
+    ref.backward(go.float().cpu())
+    assert _rel(U.detach().float().cpu(), ref.detach()) < 2e-2
     for a, b in ((q, qr), (k, kr), (v, vr)):
-        assert _rel(a.grad.cpu(), b.grad) < 4e-2
+        assert _rel(a.grad.float().cpu(), b.grad) < 4e-2
 
 
 def test_nonlocal_attention_bf16(dev, bf16_mode):
     B, C, N = 2, 64, 100
     g = torch.Generator().manual_seed(2)
-    th, ph, gx = (torch.randn(B, C, N, generator=g).to(dev).requires_grad_(True) for _ in range(3))
-    go = torch.randn(B, C, N, generator=g).to(dev)
+    th, ph, gx = (bft(torch.randn(B, C, N, generator=g), dev) for _ in range(3))
+    go = torch.randn(B, C, N, generator=g).to(dev).to(BF)
     bf16_mode()
     y = ops.nonlocal_attention(th, ph, gx)
     y.backward(go)
-    tr, pr, gr = (t.detach().cpu().clone().requires_grad_(True) for t in (th, ph, gx))
+    tr, pr, gr = (f32(t) for t in (th, ph, gx))
     a = torch.softmax(torch.einsum("nch,ncp->nhp", tr, pr) * C ** -0.5, dim=2)
     ref = torch.einsum("nhg,ncg->nch", a, gr)
-    ref.backward(go.cpu())
-    assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
+    ref.backward(go.float().cpu())
+    assert _rel(y.detach().float().cpu(), ref.detach()) < 2e-2
     for a_, b_ in ((th, tr), (ph, pr), (gx, gr)):
-        assert _rel(a_.grad.cpu(), b_.grad) < 4e-2
+        assert _rel(a_.grad.float().cpu(), b_.grad) < 4e-2
 
 
 @pytest.mark.gpu
@@ -112,19 +124,19 @@ def test_direct_conv_bf16_fwd_and_dgrad(dev, bf16_mode, Cin, Cout, k, H, W):
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(3)
     B = 2
-    x = torch.randn(B, Cin, H, W, generator=g).to(dev).requires_grad_(True)
+    x = bft(torch.randn(B, Cin, H, W, generator=g), dev)
     w = torch.nn.Parameter((torch.randn(Cout, Cin, k, k, generator=g) * 0.05).to(dev))
-    go = torch.randn(B, Cout, H, W, generator=g).to(dev)
+    go = torch.randn(B, Cout, H, W, generator=g).to(dev).to(BF)
     bf16_mode()
     assert kern.conv_direct_supported(Cin, Cout, k, 1, k // 2)
     y = ops.conv2d_nchw(x, w, None, stride=1, pad=k // 2)
     y.backward(go)
-    xr = x.detach().cpu().clone().requires_grad_(True)
+    xr = f32(x)
     wr = w.detach().cpu().clone().requires_grad_(True)
     ref = F.conv2d(xr, wr, None, padding=k // 2)
-    ref.backward(go.cpu())
-    assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
-    assert _rel(x.grad.cpu(), xr.grad) < 2e-2
+    ref.backward(go.float().cpu())
+    assert _rel(y.detach().float().cpu(), ref.detach()) < 2e-2
+    assert _rel(x.grad.float().cpu(), xr.grad) < 2e-2
     assert _rel(w.grad.cpu(), wr.grad) < 2e-2
 
 
@@ -133,18 +145,18 @@ def test_direct_conv_bf16_fwd_and_dgrad(dev, bf16_mode, Cin, Cout, k, H, W):
 @pytest.mark.parametrize("R,K,N", [(150, 192, 70), (70, 200, 130), (300, 128, 64), (33, 320, 320)])
 def test_linear_bf16_k64(dev, bf16_mode, R, K, N):
     g = torch.Generator().manual_seed(R + K + N)
-    x = torch.randn(R, K, generator=g).to(dev).requires_grad_(True)
+    x = bft(torch.randn(R, K, generator=g), dev)
     W = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.1).to(dev))
     b = torch.nn.Parameter(torch.randn(N, generator=g).to(dev))
-    go = torch.randn(R, N, generator=g).to(dev)
+    go = torch.randn(R, N, generator=g).to(dev).to(BF)
     bf16_mode()
     y = ops.linear(x, W, b)
     y.backward(go)
-    xr, Wr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, W, b))
+    xr, Wr, br = (t.detach().float().cpu().clone().requires_grad_(True) for t in (x, W, b))
     ref = torch.nn.functional.linear(xr, Wr, br)
-    ref.backward(go.cpu())
-    assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
-    assert _rel(x.grad.cpu(), xr.grad) < 2e-2
+    ref.backward(go.float().cpu())
+    assert _rel(y.detach().float().cpu(), ref.detach()) < 2e-2
+    assert _rel(x.grad.float().cpu(), xr.grad) < 2e-2
     assert _rel(W.grad.cpu(), Wr.grad) < 2e-2
     assert _rel(b.grad.cpu(), br.grad) < 1e-4
 
@@ -152,17 +164,17 @@ def test_linear_bf16_k64(dev, bf16_mode, R, K, N):
 @pytest.mark.parametrize("B,Cin,Cout,HW", [(2, 136, 72, 100), (1, 256, 130, 49)])
 def test_conv1x1_bf16_k64(dev, bf16_mode, B, Cin, Cout, HW):
     g = torch.Generator().manual_seed(B + Cin + Cout + HW)
-    x = torch.randn(B, Cin, HW, 1, generator=g).to(dev).requires_grad_(True)
+    x = bft(torch.randn(B, Cin, HW, 1, generator=g), dev)
     W = torch.nn.Parameter((torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1).to(dev))
-    go = torch.randn(B, Cout, HW, 1, generator=g).to(dev)
+    go = torch.randn(B, Cout, HW, 1, generator=g).to(dev).to(BF)
     bf16_mode()
     y = ops.conv1x1(x, W)
     y.backward(go)
-    xr, Wr = (t.detach().cpu().clone().requires_grad_(True) for t in (x, W))
+    xr, Wr = (t.detach().float().cpu().clone().requires_grad_(True) for t in (x, W))
     ref = torch.nn.functional.conv2d(xr, Wr)
-    ref.backward(go.cpu())
-    assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
-    assert _rel(x.grad.cpu(), xr.grad) < 2e-2
+    ref.backward(go.float().cpu())
+    assert _rel(y.detach().float().cpu(), ref.detach()) < 2e-2
+    assert _rel(x.grad.float().cpu(), xr.grad) < 2e-2
     assert _rel(W.grad.cpu(), Wr.grad) < 2e-2
 
 
@@ -170,19 +182,19 @@ def test_conv1x1_bf16_k64(dev, bf16_mode, B, Cin, Cout, HW):
 @pytest.mark.parametrize("B,C,Cout,H,W,s", [(2, 64, 40, 8, 8, 4), (1, 16, 24, 16, 8, 8)])
 def test_sr_conv_tok_bf16_split_k(dev, bf16_mode, B, C, Cout, H, W, s):
     g = torch.Generator().manual_seed(C + Cout + s)
-    x = torch.randn(B, H * W, C, generator=g).to(dev).requires_grad_(True)
+    x = bft(torch.randn(B, H * W, C, generator=g), dev)
     Wt = torch.nn.Parameter((torch.randn(Cout, C, s, s, generator=g) * 0.05).to(dev))
     b = torch.nn.Parameter(torch.randn(Cout, generator=g).to(dev))
     Ho, Wo = H // s, W // s
-    go = torch.randn(B, Ho * Wo, Cout, generator=g).to(dev)
+    go = torch.randn(B, Ho * Wo, Cout, generator=g).to(dev).to(BF)
     bf16_mode()
     y = ops.conv2d_tok(x, H, W, Wt, b, stride=s, pad=0, out_layout="tok")
     y.backward(go)
-    xr, Wr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, Wt, b))
+    xr, Wr, br = (t.detach().float().cpu().clone().requires_grad_(True) for t in (x, Wt, b))
     ref = torch.nn.functional.conv2d(xr.transpose(1, 2).reshape(B, C, H, W), Wr, br, stride=s)
     ref = ref.reshape(B, Cout, Ho * Wo).transpose(1, 2)
-    ref.backward(go.cpu())
-    assert _rel(y.detach().cpu(), ref.detach()) < 2e-2
-    assert _rel(x.grad.cpu(), xr.grad) < 2e-2
+    ref.backward(go.float().cpu())
+    assert _rel(y.detach().float().cpu(), ref.detach()) < 2e-2
+    assert _rel(x.grad.float().cpu(), xr.grad) < 2e-2
     assert _rel(Wt.grad.cpu(), Wr.grad) < 2e-2
     assert _rel(b.grad.cpu(), br.grad) < 1e-4

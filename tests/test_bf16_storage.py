@@ -1,0 +1,269 @@
+"""Throughput-mode storage: every operator of cenet_amd.ops run on bf16 tensors (the `_bf16` twins of the C ABI) against the
+SAME operator on fp32 tensors holding the same bf16-rounded values (the parity-mode path, itself pinned on the reference
+goldens).  Forward outputs, input gradients and parameter gradients must agree to bf16 rounding of the results (a few
+2^-8 of the tensor's range; the parameter gradients are fp32 sums in both modes).  Runs on the host SIMT checker (CPU) and,
+with -m gpu, through libcenet_hip.so.  Shapes cover the vector (multiples of 4 / 8) and the scalar fallback forms."""
+import pytest
+import torch
+
+from backend import dev  # noqa: F401
+from cenet_amd import kern, ops
+
+BF = torch.bfloat16
+
+
+def _r(t):
+    return t.bfloat16().float()
+
+
+def _rel(a, b):
+    return (a.float() - b.float()).abs().max().item() / (b.float().abs().max().item() + 1e-12)
+
+
+def compare(fn, acts, params=(), tol=2.5e-2, ptol=3e-2, dev="cpu", out_index=None, extra=()):
+    """fn(*acts, *params, *extra) -> tensor (or tuple; out_index picks).  acts: fp32 activation tensors (rounded to bf16
+    values here); params: fp32 parameter tensors (kept fp32 in both runs)."""
+    acts = [_r(a) for a in acts]
+    res = {}
+    for mode in ("f32", "bf16"):
+        xs = [(a.detach().clone().to(dev).to(BF) if mode == "bf16" else a.detach().clone().to(dev)).requires_grad_(True)
+              for a in acts]
+        ps = [torch.nn.Parameter(p.clone().to(dev)) for p in params]
+        y = fn(*xs, *ps, *extra)
+        if out_index is not None:
+            y = y[out_index]
+        if mode == "f32":
+            go = _r(torch.randn(y.shape, generator=torch.Generator().manual_seed(11)))
+        assert y.dtype == (BF if mode == "bf16" else torch.float32), (mode, y.dtype)
+        y.backward(go.to(dev).to(y.dtype))
+        res[mode] = (y.detach().float().cpu(), [x.grad.float().cpu() if x.grad is not None else None for x in xs],
+                     [p.grad.float().cpu() if p.grad is not None else None for p in ps])
+    (y0, gx0, gp0), (y1, gx1, gp1) = res["f32"], res["bf16"]
+    assert _rel(y1, y0) < tol, ("output", _rel(y1, y0))
+    for i, (a, b) in enumerate(zip(gx1, gx0)):
+        if b is not None:
+            assert a is not None and a.dtype == torch.float32
+            assert _rel(a, b) < tol * 1.6, ("input grad", i, _rel(a, b))
+    for i, (a, b) in enumerate(zip(gp1, gp0)):
+        if b is not None:
+            assert _rel(a, b) < ptol, ("param grad", i, _rel(a, b))
+
+
+def G(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("R,K,N,bias,resid,bscale", [(70, 64, 40, True, True, False), (24, 50, 33, True, False, False),
+                                                     (2 * 30, 128, 64, True, True, True), (150, 192, 70, False, False, False)])
+def test_linear(dev, R, K, N, bias, resid, bscale):
+    g = G(R + K)
+    B = 2
+    x = torch.randn(B, R // B, K, generator=g)
+    W, b = torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    r = torch.randn(B, R // B, N, generator=g)
+    bs = torch.tensor([0.0, 1.25]).to(dev) if bscale else None
+
+    def fn(x, r, W, b):
+        return ops.linear(x, W, b if bias else None, resid=r if resid else None, bscale=bs)
+    compare(fn, [x, r], [W, b], dev=dev)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 40, 24, 8, 8), (1, 64, 130, 7, 7), (2, 136, 72, 10, 10)])
+def test_conv1x1(dev, B, Cin, Cout, H, W):
+    g = G(Cin + Cout)
+    x, r = torch.randn(B, Cin, H, W, generator=g), torch.randn(B, Cout, H, W, generator=g)
+    Wt, b = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1, torch.randn(Cout, generator=g)
+    compare(lambda x, r, Wt, b: ops.conv1x1(x, Wt, b, resid=r), [x, r], [Wt, b], dev=dev)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,s,H,expand,layout", [(1, 16, 7, 4, 32, 3, "tok"), (16, 24, 3, 2, 16, 0, "tok"),
+                                                          (8, 12, 3, 1, 9, 0, "nchw"), (4, 6, 1, 1, 7, 0, "nchw")])
+def test_conv2d_implicit_gemm(dev, Cin, Cout, k, s, H, expand, layout):
+    g = G(Cin * 7 + k)
+    x = torch.randn(2, Cin, H, H, generator=g)
+    Wt = torch.randn(Cout, expand or Cin, k, k, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    compare(lambda x, Wt, b: ops.conv2d_nchw(x, Wt, b, stride=s, pad=k // 2, out_layout=layout, expand_channels=expand),
+            [x], [Wt, b], dev=dev)
+
+
+@pytest.mark.parametrize("B,C,Cout,H,W,s", [(2, 16, 24, 8, 8, 2), (1, 64, 40, 8, 8, 4)])
+def test_sr_conv_tok(dev, B, C, Cout, H, W, s):
+    g = G(C + s)
+    x = torch.randn(B, H * W, C, generator=g)
+    Wt, b = torch.randn(Cout, C, s, s, generator=g) * 0.05, torch.randn(Cout, generator=g)
+    compare(lambda x, Wt, b: ops.conv2d_tok(x, H, W, Wt, b, stride=s, pad=0, out_layout="tok"), [x], [Wt, b], dev=dev)
+
+
+@pytest.mark.parametrize("rows,C", [(37, 64), (33, 320), (21, 50)])
+def test_layernorm_and_residual_form(dev, rows, C):
+    g = G(rows + C)
+    x = torch.randn(rows, C, generator=g) * 2 + 0.5
+    gm, bt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    compare(lambda x, gm, bt: ops.layernorm(x, gm, bt, 1e-6), [x], [gm, bt], dev=dev)
+
+    def res(x, gm, bt):
+        y, xr = ops.layernorm_res(x, gm, bt, 1e-6)
+        return y * 1.0 + xr * 0.5  # torch elementwise glue on the host checker / GPU: both outputs carry gradient
+    compare(res, [x], [gm, bt], dev=dev)
+
+
+@pytest.mark.parametrize("B,C,H,W,act", [(3, 5, 14, 14, "none"), (2, 4, 28, 28, "relu"), (4, 3, 7, 7, "lrelu")])
+def test_batchnorm(dev, B, C, H, W, act):
+    g = G(B + C + H)
+    x = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
+    gm, bt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+
+    def fn(x, gm, bt):
+        rm, rv, nbt = torch.zeros(C, device=x.device), torch.ones(C, device=x.device), torch.zeros((), dtype=torch.long, device=x.device)
+        return ops.batchnorm(x, gm, bt, rm, rv, nbt, True, 1e-5, act, 0.2, 0.1)
+    compare(fn, [x], [gm, bt], dev=dev, tol=3e-2)
+
+
+@pytest.mark.parametrize("B,C,H,W,act", [(2, 8, 6, 6, "gelu"), (1, 6, 30, 9, "none"), (1, 5, 5, 5, "gelu")])
+def test_dwconv_tok(dev, B, C, H, W, act):
+    g = G(C + H)
+    x = torch.randn(B, H * W, C, generator=g)
+    w, b = torch.randn(C, 1, 3, 3, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    compare(lambda x, w, b: ops.dwconv_tok(x, w, b, H, W, act), [x], [w, b], dev=dev)
+
+
+@pytest.mark.parametrize("B,C,H,W,dil,act", [(2, 3, 8, 8, 1, "gelu"), (1, 2, 12, 12, 2, "none"), (2, 3, 7, 7, 3, "none")])
+def test_dwconv_nchw(dev, B, C, H, W, dil, act):
+    g = G(C + H + dil)
+    x = torch.randn(B, C, H, W, generator=g)
+    w, b = torch.randn(C, 1, 3, 3, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    compare(lambda x, w, b: ops.dwconv_nchw(x, w, b, dil=dil, act=act), [x], [w, b], dev=dev)
+
+
+@pytest.mark.parametrize("B,N,Nk,C,heads", [(2, 70, 49, 128, 2), (1, 130, 130, 64, 1)])
+def test_sr_attention(dev, B, N, Nk, C, heads):
+    g = G(N)
+    q, kv = torch.randn(B, N, C, generator=g), torch.randn(B, Nk, 2 * C, generator=g)
+    compare(lambda q, kv: ops.sr_attention(q, kv, heads), [q, kv], dev=dev, tol=3e-2)
+
+
+@pytest.mark.parametrize("B,C,N", [(2, 64, 100), (1, 32, 49)])
+def test_nonlocal_attention(dev, B, C, N):
+    g = G(C + N)
+    th, ph, gx = (torch.randn(B, C, N, generator=g) for _ in range(3))
+    compare(ops.nonlocal_attention, [th, ph, gx], dev=dev, tol=3e-2)
+
+
+# hd 16 / 8: tiled kernels (two softmax heads add into one value head: fp32 accumulators); hd 80: materialised path (fp32 scores)
+@pytest.mark.parametrize("B,N,H,hd", [(2, 96, 2, 16), (1, 70, 2, 8), (1, 49, 1, 80)])
+def test_diff_attention_heads_and_combine(dev, B, N, H, hd):
+    g = G(N + hd)
+    E = 2 * H * hd
+    q, k, v = (torch.randn(B, N, E, generator=g) for _ in range(3))
+    compare(lambda q, k, v: ops.diff_attention_heads(q, k, v, H), [q, k, v], dev=dev, tol=3e-2)
+    U = torch.randn(B, 2 * H, N, 2 * hd, generator=g)
+    lams = [torch.randn(hd, generator=g) * 0.1 for _ in range(4)]
+    compare(lambda U, a, b, c, d: ops.diff_attention_combine(U, a, b, c, d, 0.5), [U], lams, dev=dev)
+
+
+def test_layout_and_glue(dev):
+    g = G(5)
+    x = torch.randn(2, 6 * 6, 10, generator=g)
+    compare(lambda x: ops.tok_to_nchw(x, 6, 6), [x], dev=dev, tol=1e-6)
+    x7 = torch.randn(2, 7 * 7, 5, generator=g)  # odd extents: scalar transpose
+    compare(lambda x: ops.tok_to_nchw(x, 7, 7), [x7], dev=dev, tol=1e-6)
+    a, b = torch.randn(2, 3, 4, 4, generator=g), torch.randn(2, 5, 4, 4, generator=g)
+    compare(ops.concat2, [a, b], dev=dev, tol=1e-6)
+    compare(lambda x: ops.split_channels(x, [2, 3])[1], [b], dev=dev, tol=1e-6)
+    c = torch.randn(2, 3, 4, 4, generator=g)
+    compare(lambda a, c: ops.add_act(a, c, "lrelu", 0.01), [a, c], dev=dev)
+    compare(ops.silu_mul, [a, c], dev=dev)
+    compare(lambda a, c, w: ops.mix(a, c, w), [a, c], [torch.tensor(0.4)], dev=dev)
+    compare(lambda a, c, ls: ops.scale_residual(a, c, ls), [a, c], [torch.rand(1, 3, 1, 1, generator=g)], dev=dev)
+    a7 = torch.randn(2, 3, 7, 7, generator=g)
+    compare(lambda a, c, ls: ops.scale_residual(a, c, ls), [a7, a7 * 0.5 + 1], [torch.rand(1, 3, 1, 1, generator=g)], dev=dev)
+
+
+@pytest.mark.parametrize("kw", [dict(scale_factor=2, align_corners=True), dict(scale_factor=0.5, align_corners=False),
+                                dict(size=(9, 11), align_corners=False)])
+def test_resampling(dev, kw):
+    g = G(9)
+    x = torch.randn(2, 3, 8, 10, generator=g)
+    compare(lambda x: ops.interpolate_bilinear(x, **kw), [x], dev=dev)
+    compare(ops.nearest2x, [x], dev=dev)
+    compare(lambda x: ops.adaptive_avgpool(x, 3, 3), [x], dev=dev)
+    compare(lambda x, w: ops.maxpool2_scale(x, w), [x], [torch.rand(1, 3, 1, 1, generator=g) + 0.5], dev=dev)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 6, 8, 8), (3, 4, 7, 7), (1, 4, 8, 8)])
+def test_ccu_and_srm(dev, B, C, H, W):
+    g = G(B + C + H)
+    x = torch.randn(B, C, H, W, generator=g) + 0.2
+    fc1, fc2 = torch.randn(3 * C, 1, 3, generator=g) * 0.5, torch.randn(C, 3, 1, generator=g) * 0.5
+    bw, bb = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+
+    def ccu(x, fc1, fc2, bw, bb):
+        rm, rv, nbt = torch.zeros(C, device=x.device), torch.ones(C, device=x.device), torch.zeros((), dtype=torch.long, device=x.device)
+        return ops.ccu(x, fc1, fc2, bw, bb, rm, rv, nbt, True)
+    compare(ccu, [x], [fc1, fc2, bw, bb], dev=dev, tol=3e-2, ptol=6e-2)
+    pwc, dwc = torch.randn(1, 3, 1, 1, generator=g) * 0.5, torch.randn(1, 3, 3, 3, generator=g) * 0.3
+    sw, sb = torch.rand(1, generator=g) + 0.5, torch.randn(1, generator=g) * 0.1
+
+    def srm(x, pwc, dwc, sw, sb):
+        rm, rv, nbt = torch.zeros(1, device=x.device), torch.ones(1, device=x.device), torch.zeros((), dtype=torch.long, device=x.device)
+        return ops.srm(x, pwc, dwc, sw, sb, rm, rv, nbt, True)
+    compare(srm, [x], [pwc, dwc, sw, sb], dev=dev, tol=3e-2, ptol=6e-2)
+
+
+@pytest.mark.parametrize("n,HW", [(2, (8, 8)), (3, (7, 7))])
+def test_dseb_combine(dev, n, HW):
+    g = G(n)
+    y = torch.randn(2, 4, *HW, generator=g)
+    diff = torch.randn(2, 4, *HW, generator=g)
+    recs = [y + 0.3 * torch.randn(2, 4, *HW, generator=g) for _ in range(n - 1)]
+    w = torch.randn(1, 4, 1, 1, generator=g)
+
+    def fn(y, diff, *rest):
+        rs, w = rest[:-1], rest[-1]
+        return ops.dseb_combine(y, w, diff, [None] + list(rs))
+    compare(fn, [y, diff] + recs, [w], dev=dev)
+
+
+@pytest.mark.parametrize("K", [4, 9])
+def test_seg_loss(dev, K):
+    g = G(K)
+    logits = torch.randn(2, K, 12, 12, generator=g) * 2
+    labels = torch.randint(0, K, (2, 12, 12), generator=g).float().to(dev)
+    res = {}
+    for mode in ("f32", "bf16"):
+        lg = (_r(logits).to(dev).to(BF) if mode == "bf16" else _r(logits).to(dev)).requires_grad_(True)
+        loss = ops.dice_ce_loss(lg, labels, 0.4, 0.3, 0.3)
+        loss.backward()
+        res[mode] = (loss.item(), lg.grad.float().cpu())
+    assert abs(res["f32"][0] - res["bf16"][0]) < 1e-5 * max(1.0, abs(res["f32"][0]))  # same inputs, fp32 arithmetic
+    assert _rel(res["bf16"][1], res["f32"][1]) < 1e-2
+
+
+def test_weight_shadow_follows_in_place_updates(dev):
+    """kern.wq: the bf16 shadow of a weight is re-cast when the tensor changed through torch, kept when it did not"""
+    W = torch.nn.Parameter(torch.randn(8, 8, generator=G(0)).to(dev))
+    x = torch.zeros(1, 8, device=dev, dtype=BF)
+    s1 = kern.wq(W, x)
+    assert s1.dtype == BF and kern.wq(W, x) is s1
+    torch.testing.assert_close(s1.float().cpu(), W.detach().cpu().bfloat16().float())
+    with torch.no_grad():
+        W.mul_(2.0)
+    s2 = kern.wq(W, x)
+    torch.testing.assert_close(s2.float().cpu(), W.detach().cpu().bfloat16().float())
+    assert kern.wq(W, torch.zeros(1, device=dev)) is W  # fp32 activations read the master weight itself
+
+
+def test_arena_shadow_is_refreshed_by_the_fused_sgd(dev):
+    from cenet_amd import optim
+    m = torch.nn.Module()
+    m.w = torch.nn.Parameter(torch.randn(70, generator=G(1)).to(dev))
+    arena = optim.ParamArena(m)
+    opt = optim.FusedSGD(arena, lr=0.1, momentum=0.0, weight_decay=0.0)
+    sh = kern.wq(m.w, torch.zeros(1, device=dev, dtype=BF))
+    assert sh.data_ptr() == arena.shadow.data_ptr()
+    opt.zero_grad()
+    m.w.grad.fill_(1.0)
+    opt.step()
+    torch.testing.assert_close(kern.wq(m.w, sh).float().cpu(), m.w.detach().cpu().bfloat16().float())
+    torch.testing.assert_close(arena.shadow[:70].float().cpu(), (m.w.detach()).cpu().bfloat16().float())

@@ -98,7 +98,7 @@ def test_conv_igemm_fwd_dgrad_wgrad(dev, k, stride, pad, dil):
     torch.testing.assert_close(dw.cpu(), wr.grad.cpu(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 150, 100), (32, 300, 70), (130, 64, 129)])
+@pytest.mark.parametrize("M,N,K", [(200, 150, 100), (32, 300, 70), (130, 64, 129), (65, 33, 160)])
 def test_gemm_tiles_fp32_and_bf16(dev, M, N, K):
     """larger shapes exercise the 128x128 / 32x256 tiles; bf16-operand mode is checked against bf16-rounded inputs."""
     x, w, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, seed=1), rnd(N, dev=dev, seed=2)
@@ -109,10 +109,22 @@ def test_gemm_tiles_fp32_and_bf16(dev, M, N, K):
     xt = x.t().contiguous()  # [K, M]
     kern.gemm(kern.mat_plain(xt, 1, M, kfast=0), kern.mat_plain(w, 1, K, kfast=1), y, M, N, K, scr=N, scc=1, bias=b)
     torch.testing.assert_close(y.cpu(), F.linear(x, w, b).cpu(), rtol=1e-4, atol=1e-4)
-    old = kern.set_compute_bf16(True)
-    try:
-        kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(w, 1, K, kfast=1), y, M, N, K, scr=N, scc=1, bias=b)
-    finally:
-        kern.set_compute_bf16(old)
-    ref = F.linear(x.bfloat16().float(), w.bfloat16().float(), b)
-    torch.testing.assert_close(y.cpu(), ref.cpu(), rtol=1e-3, atol=1e-3)
+    # bf16 tensors (throughput mode): k-contiguous quads, the row-pair form of a row-contiguous operand (M even) and its
+    # scalar fallback (M odd), bf16 output with bias; then an atomic (fp32) epilogue
+    xb, wb = x.bfloat16(), w.bfloat16()
+    ref = F.linear(xb.float(), wb.float(), b).cpu()
+    yb = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    kern.gemm(kern.mat_plain(xb, K, 1, kfast=1), kern.mat_plain(wb, 1, K, kfast=1), yb, M, N, K, scr=N, scc=1, bias=b)
+    torch.testing.assert_close(yb.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+    xtb = xb.t().contiguous()
+    kern.gemm(kern.mat_plain(xtb, 1, M, kfast=0), kern.mat_plain(wb, 1, K, kfast=1), yb, M, N, K, scr=N, scc=1, bias=b)
+    torch.testing.assert_close(yb.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+    wtb = wb.t().contiguous()  # [K, N]: B row-contiguous
+    kern.gemm(kern.mat_plain(xb, K, 1, kfast=1), kern.mat_plain(wtb, N, 1, kfast=0), yb, M, N, K, scr=N, scc=1, bias=b)
+    torch.testing.assert_close(yb.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+    acc = torch.zeros(M, N, device=dev)
+    kern.gemm(kern.mat_plain(xtb, 1, M, kfast=0), kern.mat_plain(wtb, N, 1, kfast=0), acc, M, N, K, scr=N, scc=1, splits=2,
+              atomic=True)
+    torch.testing.assert_close(acc.cpu(), F.linear(xb.float(), wb.float()).cpu(), rtol=1e-3, atol=1e-3)
+    with pytest.raises(TypeError):  # mixed operand types are refused
+        kern.gemm(kern.mat_plain(xb, K, 1, kfast=1), kern.mat_plain(w, 1, K, kfast=1), yb, M, N, K, scr=N, scc=1)
