@@ -204,34 +204,52 @@ template <int NX>
 __device__ __forceinline__ void plain_fetch(const PlainStage& s, const bf16_t* tile, int klim, int kfast, int vec,
                                             bool interior, StageRegs<NX>& rg) {
   const bf16_t* p = tile + s.toff;
+  // the interior forms are branch-free runs of loads (a per-load runtime condition makes the compiler branch around every
+  // load and wait for each one: cdna_hip_programming.md "Three .s-level traps" (c))
   if (s.pair) {
-    const int lim = interior ? NX / 2 : (klim - s.kk);
+    if (interior) {
+#pragma unroll
+      for (int j = 0; j < NX / 2; ++j, p += s.dj) memcpy(&rg.u[j], p, 4);
+      return;
+    }
+    const int lim = klim - s.kk;
+    const bool both = (s.ok & 3u) == 3u, one = (s.ok & 1u) != 0;
 #pragma unroll
     for (int j = 0; j < NX / 2; ++j, p += s.dj) {
       unsigned w = 0;
       if (j < lim) {
-        if ((s.ok & 3u) == 3u) memcpy(&w, p, 4);
-        else if (s.ok & 1u) w = *p;
+        if (both) memcpy(&w, p, 4);
+        else if (one) w = *p;
       }
       rg.u[j] = w;
     }
     return;
   }
   if (kfast && vec) {
-    const bool kok = interior || s.kk < klim;
+    if (interior) {
+#pragma unroll
+      for (int j = 0; j < NX / 4; ++j, p += s.dj) memcpy(&rg.u[2 * j], p, 8);
+      return;
+    }
+    const bool kok = s.kk < klim;
 #pragma unroll
     for (int j = 0; j < NX / 4; ++j, p += s.dj) {
-      if (kok && (interior || ((s.ok >> j) & 1u))) memcpy(&rg.u[2 * j], p, 8);
+      if (kok && ((s.ok >> j) & 1u)) memcpy(&rg.u[2 * j], p, 8);
       else rg.u[2 * j] = rg.u[2 * j + 1] = 0u;
     }
+    return;
+  }
+  if (interior) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j, p += s.dj) rg.f[j] = cenet_bf2f(*p);
     return;
   }
   if (kfast) {
     const bool kok = s.kk < klim;
 #pragma unroll
-    for (int j = 0; j < NX; ++j, p += s.dj) rg.f[j] = (interior || (kok && ((s.ok >> j) & 1u))) ? cenet_bf2f(*p) : 0.f;
+    for (int j = 0; j < NX; ++j, p += s.dj) rg.f[j] = (kok && ((s.ok >> j) & 1u)) ? cenet_bf2f(*p) : 0.f;
   } else {
-    const int lim = interior ? NX : ((s.ok & 1u) ? klim - s.kk : 0);
+    const int lim = (s.ok & 1u) ? klim - s.kk : 0;
 #pragma unroll
     for (int j = 0; j < NX; ++j, p += s.dj) rg.f[j] = (j < lim) ? cenet_bf2f(*p) : 0.f;
   }

@@ -203,6 +203,21 @@ def flash_bwd(a: AttnT, bf16: bool = False):
     _lib.check(getattr(_lib.lib(), name)(C.byref(a), stream()), name)
 
 
+class DiffAttnT(C.Structure):
+    """cenet_diffattn_t (include/cenet_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "qt", "kt", "vt", "U", "lse", "dU", "dUt", "dq", "dk", "dv", "delta")] + \
+               [(n, C.c_int) for n in ("B", "H", "N", "hd")] + [("scale", C.c_float)]
+
+
+def diffattn_heads_supported(hd: int, N: int) -> bool:
+    return bool(_lib.lib().cenet_diffattn_heads_supported(int(hd), int(N))) and N % 4 == 0
+
+
+def diffattn_heads(a: DiffAttnT, backward: bool):
+    name = "cenet_diffattn_heads_bwd_bf16" if backward else "cenet_diffattn_heads_fwd_bf16"
+    _lib.check(getattr(_lib.lib(), name)(C.byref(a), stream()), name)
+
+
 def softmax_rows_fwd(x, y, rows, n):
     _chk(x, y)
     _call("cenet_softmax_rows_fwd_f32", x, y, L(rows), n)

@@ -198,5 +198,29 @@ static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, 
   return c;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31], j = 0..7;
+// D col = l&31, row = (reg&3) + 8(reg>>2) + 4(l>>5), reg = 0..15  (cdna_hip_programming.md §3)
+static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
+  auto& s = hipsim::st();
+  int w = sim_wave(), l = sim_lane();
+  memcpy(s.xbuf[w][l], &a, 16);
+  memcpy(s.xbuf[w][l] + 16, &b, 16);
+  hipsim::wave_barrier();
+  const int col = l & 31, h = l >> 5;
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    float acc = c[reg];
+    for (int k = 0; k < 16; ++k) {
+      short av, bv;
+      memcpy(&av, s.xbuf[w][(k >> 3) * 32 + row] + 2 * (k & 7), 2);
+      memcpy(&bv, s.xbuf[w][(k >> 3) * 32 + col] + 16 + 2 * (k & 7), 2);
+      acc += sim_bf2f(av) * sim_bf2f(bv);
+    }
+    c[reg] = acc;
+  }
+  hipsim::wave_barrier();
+  return c;
+}
+
 #define CENET_LAUNCH(kernel, grid, block, stream, ...) \
   hipsim::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

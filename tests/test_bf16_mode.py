@@ -105,7 +105,9 @@ def test_whole_model_bf16_mode_stays_close_to_fp32_goldens():
     kern.set_compute_bf16(True)
     try:
         with torch.no_grad():
-            le = net(x).cpu()
+            le = net(x)
+        assert le.dtype == torch.bfloat16
+        le = le.float().cpu()
     finally:
         kern.set_compute_bf16(False)
     ref = z["logits_eval_sub"]
