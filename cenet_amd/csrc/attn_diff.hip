@@ -6,22 +6,29 @@
 // per pass, 96 MFMA FLOP per score — the exponentials and the softmax algebra (VALU), not the matrix cores, bound it.
 //
 // Design (wave64, v_mfma_f32_32x32x16_bf16; C/D: lane = column, 16 registers = rows (r&3) + 8(r>>2) + 4(lane>>5)):
-//   * no LDS, no barriers: a wave owns 32-row tiles of the side that stays fixed (queries in fwd / dQ, keys in dK/dV) for BOTH
-//     softmax heads of a pair, and streams 32-row tiles of the other side as MFMA fragments straight from L2 (a (b, pair)'s
-//     K / V working set is a few hundred KB and every workgroup of the pair — placed on one XCD — re-reads it);
+//   * a wave owns 32-row tiles of the side that stays fixed (queries in fwd / dQ, keys in dK/dV) for BOTH softmax heads of
+//     a pair; the four waves of a workgroup share the streamed side: each 32-row tile is fetched once per workgroup with
+//     16-byte loads (register prefetch one tile ahead) into a double-buffered ROW-MAJOR bf16 image in LDS, one barrier per
+//     tile;
 //   * scores are computed transposed w.r.t. the fixed side (S^T = K Q^T in fwd / dQ, S = Q K^T in dK/dV), so the fixed index is
 //     the MFMA column = the lane: softmax state (max, sum, lse, delta) is one scalar per lane, a row reduction is 15 in-lane
 //     ops + one exchange with lane ^ 32, and the probability registers ARE the B operand of the next product (k-step s takes
-//     registers 8s..8s+7 = rows 16s + 8(j>>2) + 4(lane>>5) + (j&3)); the matching A operand is read with two 8-byte loads
-//     from a TRANSPOSED copy of the streamed tensor ([B, E, N]: the caller passes q^T, k^T, v^T, dU^T next to the row-major
-//     tensors — four small transposes per step instead of scattering 2-byte elements through LDS per tile);
+//     registers 8s..8s+7 = rows 16s + 8(j>>2) + 4(lane>>5) + (j&3));
+//   * the A operand of that next product runs along the token index of the streamed tile: it is read from the same row-major
+//     image with the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group gets a 4-row x 16-column block column-major),
+//     two per fragment — no transposed copy in HBM, no 2-byte scatter into LDS;
 //   * hd = 16 is exactly one K = 16 step of the 32x32x16 MFMA (no zero padding of the contraction as with K = 32 tiles);
 //     hd = 8 runs zero-padded to 16, hd = 32 as two k-steps; value width 2hd = 32 / 64 = one / two 32-row tiles;
 //   * the shared value head: both softmax heads of a pair accumulate dV in the same registers — no atomics anywhere;
-//   * base-2 exponentials with scale*log2(e) folded into one fma per score; the running maximum is rescaled only when some
-//     lane of the wave actually raised it (wave-uniform branch).
+//   * in dK/dV the softmax statistics belong to the ROWS (queries) of the score tile; instead of 2 x 16 loads and subtractions
+//     per lane they ride in the contraction: the dQ kernel leaves lse / scale and delta split into three bf16 terms each
+//     (24 significant bits) per (head, query), and one extra k-step against a constant -1 fragment gives S - lse/scale and
+//     dP - delta straight out of the MFMA;
+//   * base-2 exponentials with scale*log2(e) folded into one multiply per score; the running maximum of the forward pass is
+//     rescaled only when some lane of the wave actually raised it (wave-uniform branch).
 #include "common.h"
 #include "../../include/cenet_hip.h"
+#include <cstdlib>
 
 typedef bf16_t bf;
 #define DA_NEG (-1.0e30f)
@@ -38,45 +45,73 @@ __device__ __forceinline__ bool da_any(bool v) {
 #else
 __device__ __forceinline__ float da_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ bool da_any(bool v) { return __any(v); }
+typedef short da_s4 __attribute__((ext_vector_type(4)));
 #endif
+// max of three without the canonicalising v_max the compiler puts in front of fmaxf on MFMA results
+__device__ __forceinline__ float da_max3(float a, float b, float c3) {
+#ifdef CENET_HOSTSIM_BUILD
+  return fmaxf(fmaxf(a, b), c3);
+#else
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c3));
+  return r;
+#endif
+}
 
 struct DiffArgs {
-  const bf *q, *k, *v;     // row-major: q, k [B, N, 2H*hd] ; v [B, N, H*2hd]
-  const bf *qt, *kt, *vt;  // transposed: [B, 2H*hd, N], [B, 2H*hd, N], [B, H*2hd, N]
-  bf* U;                   // [B, 2H, N, 2hd]
-  float* lse;              // [B, 2H, N]  (natural log)
-  const bf *dU, *dUt;      // [B, 2H, N, 2hd], [B, 2H, 2hd, N]
-  bf *dq, *dk, *dv;        // like q, k, v
-  float* delta;            // [B, 2H, N]
+  const bf *q, *k, *v;  // row-major: q, k [B, N, 2H*hd] ; v [B, N, H*2hd]
+  bf* U;                // [B, 2H, N, 2hd]
+  float* lse;           // [B, 2H, N]  (natural log)
+  const bf* dU;         // [B, 2H, N, 2hd]
+  bf *dq, *dk, *dv;     // like q, k, v
+  bf* aug;              // [B, 2H, N, 16]: lse/scale as 3 bf16 terms at [0..2], delta at [8..10] (written by dQ, read by dK/dV)
   int B, H, N, hd;
   float scale;
 };
 
-// 8 consecutive bf16 of one row as an MFMA fragment; `ok` false -> zeros
+// ---- LDS images -------------------------------------------------------------------------------------------------------------
+// One staged 16-byte chunk of a thread: 8 consecutive elements of one global row -> 8 consecutive elements of one image row.
+struct DaChunk {
+  const bf* g;   // global address of the chunk in tile 0 (nullptr: the chunk lies in the zero padding of the image)
+  int lrow;      // row inside the 32-row tile
+  int loff;      // element offset inside the image
+  unsigned fill; // low word of the 16-byte fill pattern for rows beyond the tensor (rest zero)
+};
+__device__ __forceinline__ void da_fetch(const DaChunk& c, long tile_step, int rows_left, unsigned (&r)[4]) {
+  r[0] = c.fill;
+  r[1] = r[2] = r[3] = 0u;
+  if (c.g && c.lrow < rows_left) memcpy(r, c.g + tile_step, 16);
+  else if (!c.g) r[0] = 0u;
+}
+// row-major fragment: 8 consecutive columns [col + 8hh, +8) of image row `row`
+__device__ __forceinline__ bf16x8 da_rm(const bf* img, int pitch, int row, int col, int hh) {
+  bf16x8 f;
+  memcpy(&f, img + row * pitch + col + 8 * hh, 16);
+  return f;
+}
+// transposed fragment for k-step s2: lane (r = lane & 31, hh) gets column C0 + r of image rows 16 s2 + 4hh + {0..3} and
+// 16 s2 + 8 + 4hh + {0..3} — the accumulator-row order of da_pack8.  Device: two ds_read_b64_tr_b16 (per 16-lane group a
+// 4-row x 16-column block: lane 4q+p supplies the address of row q, columns 4p..4p+3, lane i receives column i).
+__device__ __forceinline__ bf16x8 da_tr(const bf* img, int pitch, int s2, int C0, int lane) {
+  const int hh = lane >> 5;
+  bf16x8 f;
+#ifdef CENET_HOSTSIM_BUILD
+  const int r = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (short)img[(16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3)) * pitch + C0 + r];
+#else
+  const int g2 = (lane >> 4) & 1, i = lane & 15, q = i >> 2, p = i & 3;
+  const bf* a0 = img + (16 * s2 + 4 * hh + q) * pitch + C0 + 16 * g2 + 4 * p;
+  const da_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((da_s4 __attribute__((address_space(3)))*)a0);
+  const da_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((da_s4 __attribute__((address_space(3)))*)(a0 + 8 * pitch));
+  f[0] = lo[0], f[1] = lo[1], f[2] = lo[2], f[3] = lo[3];
+  f[4] = hi[0], f[5] = hi[1], f[6] = hi[2], f[7] = hi[3];
+#endif
+  return f;
+}
 __device__ __forceinline__ bf16x8 da_ld8(const bf* p, bool ok) {
   bf16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
   if (ok) memcpy(&f, p, 16);
-  return f;
-}
-// fragment in the accumulator-row order of k-step s, from a transposed tensor row: elements [4hh .. 4hh+3] and [8 + 4hh .. +3]
-// of the 16 columns that start at p; columns >= lim (counted from p) read as zero (ragged last tile), as does !ok
-__device__ __forceinline__ bf16x8 da_ldperm(const bf* p, int hh, int lim, bool ok) {
-  unsigned long long w0 = 0, w1 = 0;
-  if (ok) {
-    if (lim >= 16) {
-      memcpy(&w0, p + 4 * hh, 8);
-      memcpy(&w1, p + 8 + 4 * hh, 8);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (4 * hh + e < lim) w0 |= (unsigned long long)p[4 * hh + e] << (16 * e);
-        if (8 + 4 * hh + e < lim) w1 |= (unsigned long long)p[8 + 4 * hh + e] << (16 * e);
-      }
-    }
-  }
-  bf16x8 f;
-  memcpy(&f, &w0, 8);
-  memcpy((char*)&f + 8, &w1, 8);
   return f;
 }
 __device__ __forceinline__ bf16x8 da_pack8(const f32x16& x, int s) {  // registers 8s .. 8s+7 -> one B fragment
@@ -94,24 +129,82 @@ __device__ __forceinline__ f32x16 da_zero() {
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
 }
+struct da_true { static constexpr bool value = true; };
+struct da_false { static constexpr bool value = false; };
 #define DA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
+// x as hi + mid + lo with bf16 terms (24 significant bits)
+__device__ __forceinline__ void da_split3(float x, unsigned short* o) {
+  const unsigned h = cenet_f2bf(x);
+  const float r1 = x - cenet_bf2f(h);
+  const unsigned m = cenet_f2bf(r1);
+  const unsigned l = cenet_f2bf(r1 - cenet_bf2f(m));
+  o[0] = (unsigned short)h, o[1] = (unsigned short)m, o[2] = (unsigned short)l;
+}
+
+// image geometry (elements): K / Q image = both heads of the pair side by side, V / dU image = one value head
+template <int HDP>
+struct DaGeo {
+  static constexpr int DVP = 2 * HDP;
+  static constexpr int KP = 2 * HDP + 8;   // pitch of the K / Q image (16-byte row reads conflict-free)
+  static constexpr int VPT = DVP;          // pitch of a value image that is only read transposed (forward)
+  static constexpr int VPR = DVP + 8;      // pitch of a value image that is also read by rows
+  static constexpr int CK = 2 * HDP / 8, CV = DVP / 8;  // 16-byte chunks per row
+};
+
 // ---------------------------------------------------------------------------------------------------------------------------
-// forward: wave = QT tiles of 32 queries x both softmax heads of pair h; grid (ceil(N / (128 QT)), B*H)
+// forward: wave = QT tiles of 32 queries x both softmax heads of pair h; workgroup = 4 waves; grid (ceil(N / (128 QT)), B*H)
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int HDP, int QT>
-__global__ __launch_bounds__(256) void dattn_fwd_kernel(DiffArgs a) {
-  constexpr int NKS = HDP / 16, DVP = 2 * HDP, NDT = DVP / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+template <int HDP, int QT, int MINB>
+__global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
+  typedef DaGeo<HDP> G;
+  constexpr int NKS = HDP / 16, NDT = G::DVP / 32;
+  constexpr int KIMG = 32 * G::KP, VIMG = 32 * G::VPT + 64, IMG = KIMG + VIMG;  // (+64: transposed reads of padded rows)
+  constexpr int NCH = 32 * (G::CK + G::CV), CPT = (NCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf lds[2 * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const cenet_bid bid = cenet_xcd_block();
   const int b = bid.y / a.H, h = bid.y - b * a.H;
   const int q0 = (bid.x * 4 + wave) * (32 * QT);
-  if (q0 >= a.N) return;  // wave-uniform; the kernel has no barriers
   const int N = a.N, hd = a.hd, dv = 2 * hd, E = 2 * a.H * hd;
   const float c = a.scale * DA_LOG2E;
   const bf* qb = a.q + (long)b * N * E;
   const bf* kb = a.k + (long)b * N * E;
-  const bf* vtb = a.vt + ((long)b * a.H + h) * dv * (long)N;  // rows = value features of head h, columns = keys
+  const bf* vb = a.v + (long)b * N * (a.H * dv) + h * dv;
+
+  // this thread's staged chunks (fixed for the whole key loop)
+  DaChunk ch[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int id = tid + 256 * j;
+    ch[j].fill = 0u;
+    if (id >= NCH) {
+      ch[j].g = nullptr;
+      ch[j].lrow = 0;
+      ch[j].loff = -1;
+    } else if (id < 32 * G::CK) {
+      const int row = id / G::CK, cc = id - row * G::CK, s = cc / (HDP / 8), c8 = cc - s * (HDP / 8);
+      ch[j].lrow = row;
+      ch[j].loff = row * G::KP + s * HDP + 8 * c8;
+      ch[j].g = 8 * c8 < hd ? kb + (long)row * E + (2 * h + s) * hd + 8 * c8 : nullptr;
+    } else {
+      const int id2 = id - 32 * G::CK, row = id2 / G::CV, c8 = id2 - row * G::CV;
+      ch[j].lrow = row;
+      ch[j].loff = KIMG + row * G::VPT + 8 * c8;
+      ch[j].g = 8 * c8 < dv ? vb + (long)row * (a.H * dv) + 8 * c8 : nullptr;
+    }
+  }
+  unsigned pre[CPT][4];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+      da_fetch(ch[j], (long)k0 * (ch[j].loff < KIMG ? E : a.H * dv), N - k0, pre[j]);
+  };
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+      if (ch[j].loff >= 0) memcpy(lds + buf * IMG + ch[j].loff, pre[j], 16);
+  };
 
   bf16x8 qf[QT][2][NKS];
   f32x16 O[QT][2][NDT];
@@ -130,63 +223,80 @@ __global__ __launch_bounds__(256) void dattn_fwd_kernel(DiffArgs a) {
       l[t][s] = 0.f;
     }
   }
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int cur = 0;
   for (int k0 = 0; k0 < N; k0 += 32) {
-    const int kr = k0 + r < N ? k0 + r : N - 1;
+    const bool more = k0 + 32 < N;
+    if (more) fetch(k0 + 32);
+    const bf* Kimg = lds + cur * IMG;
+    const bf* Vimg = Kimg + KIMG;
     const int klim = N - k0;  // valid keys of this tile (>= 32 except in the last one)
-    bf16x8 kf[2][NKS], vf[NDT][2];
+    auto tile = [&](auto masked) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked)::value;
+      bf16x8 kf[2][NKS], vf[NDT][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-        kf[s][ks] = da_ld8(kb + (long)kr * E + (2 * h + s) * hd + 16 * ks + 8 * hh, 16 * ks + 8 * hh < hd);
+        for (int ks = 0; ks < NKS; ++ks) kf[s][ks] = da_rm(Kimg, G::KP, r, s * HDP + 16 * ks, hh);
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-        vf[dt][s2] = da_ldperm(vtb + (long)(32 * dt + r) * N + k0 + 16 * s2, hh, klim - 16 * s2, 32 * dt + r < dv);
+        for (int s2 = 0; s2 < 2; ++s2) vf[dt][s2] = da_tr(Vimg, G::VPT, s2, 32 * dt, lane);
 #pragma unroll
-    for (int t = 0; t < QT; ++t)
+      for (int t = 0; t < QT; ++t)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        f32x16 S = da_zero();
+        for (int s = 0; s < 2; ++s) {
+          f32x16 S = da_zero();
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(kf[s][ks], qf[t][s][ks], S);  // S^T[key][query]
-        if (klim < 32) {
+          for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(kf[s][ks], qf[t][s][ks], S);  // S^T[key][query]
+          if (MASKED) {  // ragged last tile only (its own instantiation of the tile body: no per-score selects elsewhere)
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (da_row(i, hh) >= klim) S[i] = DA_NEG;
+            for (int i = 0; i < 16; ++i)
+              if (da_row(i, hh) >= klim) S[i] = DA_NEG;
+          }
+          float mx = da_max3(S[0], S[1], S[2]);
+#pragma unroll
+          for (int i = 3; i < 15; i += 2) mx = da_max3(mx, S[i], S[i + 1]);
+          mx = fmaxf(mx, S[15]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          if (da_any(mx > m[t][s])) {  // some query of the wave raised its maximum: rescale (wave-uniform branch)
+            const float mn = fmaxf(m[t][s], mx);
+            const float alpha = da_exp2((m[t][s] - mn) * c);
+            m[t][s] = mn;
+            l[t][s] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) O[t][s][dt][i] *= alpha;
+          }
+          const float mc = m[t][s] * c;
+          float rs = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float p = da_exp2(S[i] * c - mc);
+            S[i] = p;
+            rs += p;
+          }
+          l[t][s] += rs;
+          const bf16x8 p0 = da_pack8(S, 0), p1 = da_pack8(S, 1);
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {  // O^T[value feature][query] += V^T[feature][key] P^T[key][query]
+            O[t][s][dt] = DA_MFMA(vf[dt][0], p0, O[t][s][dt]);
+            O[t][s][dt] = DA_MFMA(vf[dt][1], p1, O[t][s][dt]);
+          }
         }
-        float mx = S[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, S[i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (da_any(mx > m[t][s])) {  // some query of the wave raised its maximum: rescale (wave-uniform branch)
-          const float mn = fmaxf(m[t][s], mx);
-          const float alpha = da_exp2((m[t][s] - mn) * c);
-          m[t][s] = mn;
-          l[t][s] *= alpha;
-#pragma unroll
-          for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) O[t][s][dt][i] *= alpha;
-        }
-        const float mc = m[t][s] * c;
-        float rs = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = da_exp2(S[i] * c - mc);
-          S[i] = p;
-          rs += p;
-        }
-        l[t][s] += rs;
-        const bf16x8 p0 = da_pack8(S, 0), p1 = da_pack8(S, 1);
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {  // O^T[value feature][query] += V^T[feature][key] P^T[key][query]
-          O[t][s][dt] = DA_MFMA(vf[dt][0], p0, O[t][s][dt]);
-          O[t][s][dt] = DA_MFMA(vf[dt][1], p1, O[t][s][dt]);
-        }
-      }
+    };
+    if (q0 < N) {  // wave-uniform: a wave past the last query only helps with the staging
+      if (klim < 32) tile(da_true());
+      else tile(da_false());
+    }
+    if (more) stage(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
+  if (q0 >= N) return;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int qi = q0 + 32 * t + r;
@@ -215,23 +325,58 @@ __global__ __launch_bounds__(256) void dattn_fwd_kernel(DiffArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// backward, dQ (and delta = rowsum(dU * U)): wave = 32 queries x both softmax heads; streams key tiles
+// backward, dQ (+ delta = rowsum(dU * U) and the bf16 statistics rows for dK/dV): wave = 32 queries x both softmax heads
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int HDP>
-__global__ __launch_bounds__(256) void dattn_bwd_dq_kernel(DiffArgs a) {
-  constexpr int NKS = HDP / 16, DVP = 2 * HDP, NKD = DVP / 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+__global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
+  typedef DaGeo<HDP> G;
+  constexpr int NKS = HDP / 16, NKD = G::DVP / 16;
+  constexpr int KIMG = 32 * G::KP + 64, VIMG = 32 * G::VPR, IMG = KIMG + VIMG;
+  constexpr int NCH = 32 * (G::CK + G::CV), CPT = (NCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf lds[2 * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const cenet_bid bid = cenet_xcd_block();
   const int b = bid.y / a.H, h = bid.y - b * a.H;
   const int q0 = (bid.x * 4 + wave) * 32;
-  if (q0 >= a.N) return;
   const int N = a.N, hd = a.hd, dv = 2 * hd, E = 2 * a.H * hd;
   const float c = a.scale * DA_LOG2E;
   const bf* qb = a.q + (long)b * N * E;
   const bf* kb = a.k + (long)b * N * E;
   const bf* vb = a.v + (long)b * N * (a.H * dv) + h * dv;
-  const bf* ktb = a.kt + (long)b * E * (long)N;
   const int qi = q0 + r < N ? q0 + r : N - 1;
+
+  DaChunk ch[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int id = tid + 256 * j;
+    ch[j].fill = 0u;
+    if (id >= NCH) {
+      ch[j].g = nullptr;
+      ch[j].lrow = 0;
+      ch[j].loff = -1;
+    } else if (id < 32 * G::CK) {
+      const int row = id / G::CK, cc = id - row * G::CK, s = cc / (HDP / 8), c8 = cc - s * (HDP / 8);
+      ch[j].lrow = row;
+      ch[j].loff = row * G::KP + s * HDP + 8 * c8;
+      ch[j].g = 8 * c8 < hd ? kb + (long)row * E + (2 * h + s) * hd + 8 * c8 : nullptr;
+    } else {
+      const int id2 = id - 32 * G::CK, row = id2 / G::CV, c8 = id2 - row * G::CV;
+      ch[j].lrow = row;
+      ch[j].loff = KIMG + row * G::VPR + 8 * c8;
+      ch[j].g = 8 * c8 < dv ? vb + (long)row * (a.H * dv) + 8 * c8 : nullptr;
+    }
+  }
+  unsigned pre[CPT][4];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+      da_fetch(ch[j], (long)k0 * (ch[j].loff < KIMG ? E : a.H * dv), N - k0, pre[j]);
+  };
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+      if (ch[j].loff >= 0) memcpy(lds + buf * IMG + ch[j].loff, pre[j], 16);
+  };
 
   bf16x8 qf[2][NKS], gf[2][NKD];
   float lse2[2], dl[2];
@@ -253,39 +398,56 @@ __global__ __launch_bounds__(256) void dattn_bwd_dq_kernel(DiffArgs a) {
     }
     acc += __shfl_xor(acc, 32);
     dl[s] = acc;
-    lse2[s] = a.lse[hrow] * DA_LOG2E;
-    if (hh == 0 && q0 + r < N) a.delta[hrow] = acc;
+    const float lse = a.lse[hrow];
+    lse2[s] = lse * DA_LOG2E;
+    if (q0 + r < N) {  // statistics rows for the dK/dV kernel: lane half 0 writes lse / scale, half 1 writes delta
+      unsigned short row8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      da_split3(hh == 0 ? lse / a.scale : acc, row8);
+      memcpy(a.aug + hrow * 16 + 8 * hh, row8, 16);
+    }
     dq[s] = da_zero();
   }
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int cur = 0;
   for (int k0 = 0; k0 < N; k0 += 32) {
-    const int kr = k0 + r < N ? k0 + r : N - 1;
+    const bool more = k0 + 32 < N;
+    if (more) fetch(k0 + 32);
+    const bf* Kimg = lds + cur * IMG;
+    const bf* Vimg = Kimg + KIMG;
     const int klim = N - k0;
-    bf16x8 vf[NKD];
+    auto tile = [&](auto masked) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked)::value;
+      bf16x8 vf[NKD];
 #pragma unroll
-    for (int kd = 0; kd < NKD; ++kd) vf[kd] = da_ld8(vb + (long)kr * (a.H * dv) + 16 * kd + 8 * hh, 16 * kd + 8 * hh < dv);
+      for (int kd = 0; kd < NKD; ++kd) vf[kd] = da_rm(Vimg, G::VPR, r, 16 * kd, hh);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f32x16 S = da_zero(), dP = da_zero();
+      for (int s = 0; s < 2; ++s) {
+        f32x16 S = da_zero(), dP = da_zero();
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 kf = da_ld8(kb + (long)kr * E + (2 * h + s) * hd + 16 * ks + 8 * hh, 16 * ks + 8 * hh < hd);
-        S = DA_MFMA(kf, qf[s][ks], S);  // S^T[key][query]
+        for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(da_rm(Kimg, G::KP, r, s * HDP + 16 * ks, hh), qf[s][ks], S);
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd) dP = DA_MFMA(vf[kd], gf[s][kd], dP);  // dP^T[key][query] = V dU^T
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float p = da_exp2(S[i] * c - lse2[s]);
+          if (MASKED && da_row(i, hh) >= klim) p = 0.f;
+          S[i] = p * (dP[i] - dl[s]);
+        }
+        // dQ^T[d][query] += K^T[d][key] dS^T[key][query]; accumulator rows >= hd (the other head's columns, padding) are
+        // never stored
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) dq[s] = DA_MFMA(da_tr(Kimg, G::KP, s2, s * HDP, lane), da_pack8(S, s2), dq[s]);
       }
-#pragma unroll
-      for (int kd = 0; kd < NKD; ++kd) dP = DA_MFMA(vf[kd], gf[s][kd], dP);  // dP^T[key][query] = V dU^T
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float p = da_exp2(S[i] * c - lse2[s]);
-        if (klim < 32 && da_row(i, hh) >= klim) p = 0.f;
-        S[i] = p * (dP[i] - dl[s]);
-      }
-      // dQ^T[d][query] += K^T[d][key] dS^T[key][query]   (rows d >= hd carry zero fragments)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 ktf = da_ldperm(ktb + (long)((2 * h + s) * hd + r) * N + k0 + 16 * s2, hh, klim - 16 * s2, r < hd);
-        dq[s] = DA_MFMA(ktf, da_pack8(S, s2), dq[s]);
-      }
+    };
+    if (q0 < N) {
+      if (klim < 32) tile(da_true());
+      else tile(da_false());
     }
+    if (more) stage(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
   if (q0 + r < N) {
 #pragma unroll
@@ -309,20 +471,68 @@ __global__ __launch_bounds__(256) void dattn_bwd_dq_kernel(DiffArgs a) {
 // backward, dK / dV: wave = 32 keys x both softmax heads (one shared dV accumulator); streams query tiles
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int HDP>
-__global__ __launch_bounds__(256) void dattn_bwd_dkv_kernel(DiffArgs a) {
-  constexpr int NKS = HDP / 16, DVP = 2 * HDP, NKD = DVP / 16, NDT = DVP / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+__global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
+  typedef DaGeo<HDP> G;
+  constexpr int NKS = HDP / 16, NKD = G::DVP / 16, NDT = G::DVP / 32;
+  constexpr int AP = 40;  // statistics image: [query][head s: lse(8) delta(8)] + pad
+  constexpr int QIMG = 32 * G::KP + 64, GIMG = 32 * G::VPR + 64, AIMG = 32 * AP, IMG = QIMG + 2 * GIMG + AIMG;
+  constexpr int NCH = 32 * (G::CK + 2 * G::CV + 4), CPT = (NCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf lds[2 * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const cenet_bid bid = cenet_xcd_block();
   const int b = bid.y / a.H, h = bid.y - b * a.H;
   const int k0 = (bid.x * 4 + wave) * 32;
-  if (k0 >= a.N) return;
   const int N = a.N, hd = a.hd, dv = 2 * hd, E = 2 * a.H * hd;
   const float c = a.scale * DA_LOG2E;
   const bf* qb = a.q + (long)b * N * E;
   const bf* kb = a.k + (long)b * N * E;
   const bf* vb = a.v + (long)b * N * (a.H * dv) + h * dv;
-  const bf* qtb = a.qt + (long)b * E * (long)N;
+  const long hb0 = ((long)b * 2 * a.H + 2 * h) * N;  // (b, head 2h) row base of dU / aug; head 2h+1 is N rows further
   const int ki = k0 + r < N ? k0 + r : N - 1;
+
+  DaChunk ch[CPT];
+  long gstep[CPT];  // elements per 32-row tile step of the chunk's tensor
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    int id = tid + 256 * j;
+    ch[j].fill = 0u;
+    gstep[j] = 0;
+    if (id >= NCH) {
+      ch[j].g = nullptr;
+      ch[j].lrow = 0;
+      ch[j].loff = -1;
+    } else if (id < 32 * G::CK) {  // Q rows, both heads
+      const int row = id / G::CK, cc = id - row * G::CK, s = cc / (HDP / 8), c8 = cc - s * (HDP / 8);
+      ch[j].lrow = row;
+      ch[j].loff = row * G::KP + s * HDP + 8 * c8;
+      ch[j].g = 8 * c8 < hd ? qb + (long)row * E + (2 * h + s) * hd + 8 * c8 : nullptr;
+      gstep[j] = 32L * E;
+    } else if ((id -= 32 * G::CK) < 64 * G::CV) {  // dU rows of head s
+      const int s = id / (32 * G::CV), id2 = id - s * 32 * G::CV, row = id2 / G::CV, c8 = id2 - row * G::CV;
+      ch[j].lrow = row;
+      ch[j].loff = QIMG + s * GIMG + row * G::VPR + 8 * c8;
+      ch[j].g = 8 * c8 < dv ? a.dU + (hb0 + (long)s * N + row) * dv + 8 * c8 : nullptr;
+      gstep[j] = 32L * dv;
+    } else {  // statistics rows: chunk (row, s, kind): kind 0 = lse / scale, 1 = delta
+      id -= 64 * G::CV;
+      const int row = id >> 2, s = (id >> 1) & 1, kind = id & 1;
+      ch[j].lrow = row;
+      ch[j].loff = QIMG + 2 * GIMG + row * AP + s * 16 + 8 * kind;
+      ch[j].g = a.aug + (hb0 + (long)s * N + row) * 16 + 8 * kind;
+      ch[j].fill = kind == 0 ? 0x7149u : 0u;  // rows beyond N: lse / scale = 1e30 -> probability 0
+      gstep[j] = 32L * 16;
+    }
+  }
+  unsigned pre[CPT][4];
+  auto fetch = [&](int q0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) da_fetch(ch[j], (q0 >> 5) * gstep[j], N - q0, pre[j]);
+  };
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j)
+      if (ch[j].loff >= 0) memcpy(lds + buf * IMG + ch[j].loff, pre[j], 16);
+  };
 
   bf16x8 kfB[2][NKS], vfB[NKD];
 #pragma unroll
@@ -332,66 +542,60 @@ __global__ __launch_bounds__(256) void dattn_bwd_dkv_kernel(DiffArgs a) {
       kfB[s][ks] = da_ld8(kb + (long)ki * E + (2 * h + s) * hd + 16 * ks + 8 * hh, 16 * ks + 8 * hh < hd);
 #pragma unroll
   for (int kd = 0; kd < NKD; ++kd) vfB[kd] = da_ld8(vb + (long)ki * (a.H * dv) + 16 * kd + 8 * hh, 16 * kd + 8 * hh < dv);
+  // constant B fragment of the statistics k-step: -1 at k = 0, 1, 2 (lane half 0), zero elsewhere
+  bf16x8 negB = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hh == 0) negB[0] = negB[1] = negB[2] = (short)0xBF80;
   f32x16 dK[2], dV[NDT];
   dK[0] = dK[1] = da_zero();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) dV[dt] = da_zero();
 
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int cur = 0;
   for (int q0 = 0; q0 < N; q0 += 32) {
-    const int qr = q0 + r < N ? q0 + r : N - 1;
-    const int qlim = N - q0;
+    const bool more = q0 + 32 < N;
+    if (more) fetch(q0 + 32);
+    const bf* Qimg = lds + cur * IMG;
+    const bf* Aimg = Qimg + QIMG + 2 * GIMG;
+    if (k0 < N) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const long hbase = ((long)b * 2 * a.H + 2 * h + s) * N;
-      f32x16 S = da_zero(), dP = da_zero();
+      for (int s = 0; s < 2; ++s) {
+        const bf* Gimg = Qimg + QIMG + s * GIMG;
+        f32x16 S = da_zero(), dP = da_zero();
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 qfA = da_ld8(qb + (long)qr * E + (2 * h + s) * hd + 16 * ks + 8 * hh, 16 * ks + 8 * hh < hd);
-        S = DA_MFMA(qfA, kfB[s][ks], S);  // S[query][key]
-      }
+        for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(da_rm(Qimg, G::KP, r, s * HDP + 16 * ks, hh), kfB[s][ks], S);  // S[q][key]
 #pragma unroll
-      for (int kd = 0; kd < NKD; ++kd) {
-        const bf16x8 gfA = da_ld8(a.dU + (hbase + qr) * dv + 16 * kd + 8 * hh, 16 * kd + 8 * hh < dv);
-        dP = DA_MFMA(gfA, vfB[kd], dP);  // dP[query][key] = dU V^T
-      }
-      // per-row (query) softmax statistics: rows 8g + 4hh + 0..3
-      f32x16 dS;
+        for (int kd = 0; kd < NKD; ++kd) dP = DA_MFMA(da_rm(Gimg, G::VPR, r, 16 * kd, hh), vfB[kd], dP);  // dP[q][key] = dU V^T
+        // row (query) statistics through the contraction: S -= lse / scale, dP -= delta
+        bf16x8 al = {0, 0, 0, 0, 0, 0, 0, 0}, ad = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hh == 0) {
+          memcpy(&al, Aimg + r * AP + s * 16, 16);
+          memcpy(&ad, Aimg + r * AP + s * 16 + 8, 16);
+        }
+        S = DA_MFMA(al, negB, S);
+        dP = DA_MFMA(ad, negB, dP);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float l4[4], d4[4];
-        const int qq = q0 + 8 * g + 4 * hh;
-        if (qq + 3 < N) {
-          memcpy(l4, a.lse + hbase + qq, 16);
-          memcpy(d4, a.delta + hbase + qq, 16);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            l4[i] = qq + i < N ? a.lse[hbase + qq + i] : 1.0e30f;  // rows beyond N: p = 0
-            d4[i] = qq + i < N ? a.delta[hbase + qq + i] : 0.f;
-          }
+        for (int i = 0; i < 16; ++i) {
+          const float p = da_exp2(S[i] * c);
+          S[i] = p;
+          dP[i] = p * dP[i];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float p = da_exp2(S[4 * g + i] * c - l4[i] * DA_LOG2E);
-          S[4 * g + i] = p;
-          dS[4 * g + i] = p * (dP[4 * g + i] - d4[i]);
-        }
-      }
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pB = da_pack8(S, s2), dsB = da_pack8(dP, s2);
+          // dV^T[feature][key] += dU^T[feature][query] P[query][key]
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pB = da_pack8(S, s2), dsB = da_pack8(dS, s2);
-        // dV^T[feature][key] += dU^T[feature][query] P[query][key]
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-          const bf16x8 gtf = da_ldperm(a.dUt + (((long)b * 2 * a.H + 2 * h + s) * dv + 32 * dt + r) * N + q0 + 16 * s2, hh,
-                                       qlim - 16 * s2, 32 * dt + r < dv);
-          dV[dt] = DA_MFMA(gtf, pB, dV[dt]);
+          for (int dt = 0; dt < NDT; ++dt) dV[dt] = DA_MFMA(da_tr(Gimg, G::VPR, s2, 32 * dt, lane), pB, dV[dt]);
+          // dK^T[d][key] += Q^T[d][query] dS[query][key]   (accumulator rows >= hd are never stored)
+          dK[s] = DA_MFMA(da_tr(Qimg, G::KP, s2, s * HDP, lane), dsB, dK[s]);
         }
-        // dK^T[d][key] += Q^T[d][query] dS[query][key]
-        const bf16x8 qtf = da_ldperm(qtb + (long)((2 * h + s) * hd + r) * N + q0 + 16 * s2, hh, qlim - 16 * s2, r < hd);
-        dK[s] = DA_MFMA(qtf, dsB, dK[s]);
       }
     }
+    if (more) stage(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
   if (k0 + r < N) {
 #pragma unroll
@@ -424,21 +628,20 @@ __global__ __launch_bounds__(256) void dattn_bwd_dkv_kernel(DiffArgs a) {
   }
 }
 
-// head dims served: 8 and 16 (one k-step), 32 (two); every tensor 8-byte aligned (hd % 4 == 0 makes every row offset so)
+// head dims served: 8 and 16 (one k-step), 32 (two)
 extern "C" int cenet_diffattn_heads_supported(int hd, int N) { return (hd == 8 || hd == 16 || hd == 32) && N >= 1; }
+extern "C" long cenet_diffattn_heads_ws_bytes(int B, int H, int N) { return (long)B * 2 * H * N * 16 * 2; }
 
 static int da_fill(DiffArgs& a, const cenet_diffattn_t* p) {
-  if (!p || !p->q || !p->k || !p->vt || !p->U || !p->lse) return CENET_EINVAL;
+  if (!p || !p->q || !p->k || !p->v || !p->U || !p->lse) return CENET_EINVAL;
   if (p->B <= 0 || p->H <= 0 || p->N <= 0 || !cenet_diffattn_heads_supported(p->hd, p->N)) return CENET_EUNSUPPORTED;
   a.q = (const bf*)p->q; a.k = (const bf*)p->k; a.v = (const bf*)p->v;
-  a.qt = (const bf*)p->qt; a.kt = (const bf*)p->kt; a.vt = (const bf*)p->vt;
-  a.U = (bf*)p->U; a.lse = p->lse; a.dU = (const bf*)p->dU; a.dUt = (const bf*)p->dUt;
-  a.dq = (bf*)p->dq; a.dk = (bf*)p->dk; a.dv = (bf*)p->dv; a.delta = p->delta;
+  a.U = (bf*)p->U; a.lse = p->lse; a.dU = (const bf*)p->dU;
+  a.dq = (bf*)p->dq; a.dk = (bf*)p->dk; a.dv = (bf*)p->dv; a.aug = (bf*)p->ws;
   a.B = p->B; a.H = p->H; a.N = p->N; a.hd = p->hd; a.scale = p->scale;
-  const uintptr_t m = (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.qt | (uintptr_t)a.kt | (uintptr_t)a.vt |
-                      (uintptr_t)a.U | (uintptr_t)a.dU | (uintptr_t)a.dUt | (uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv;
-  if (m & 15) return CENET_EINVAL;  // fragments are 16-byte loads
-  if (a.N & 3) return CENET_EUNSUPPORTED;  // 8-byte runs of the transposed tensors need N % 4 == 0
+  const uintptr_t m = (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.U | (uintptr_t)a.dU | (uintptr_t)a.dq |
+                      (uintptr_t)a.dk | (uintptr_t)a.dv | (uintptr_t)a.aug;
+  if (m & 15) return CENET_EINVAL;  // rows are moved in 16-byte chunks
   return CENET_OK;
 }
 
@@ -446,12 +649,14 @@ extern "C" int cenet_diffattn_heads_fwd_bf16(const cenet_diffattn_t* p, hipStrea
   DiffArgs a;
   const int rc = da_fill(a, p);
   if (rc != CENET_OK) return rc;
-  const dim3 bh(1, a.B * a.H);
+  const int bh = a.B * a.H;
   if (a.hd <= 16) {
-    if (a.N >= 1024) CENET_LAUNCH((dattn_fwd_kernel<16, 2>), dim3(cdiv(a.N, 256), bh.y), dim3(256), stream, a);
-    else CENET_LAUNCH((dattn_fwd_kernel<16, 1>), dim3(cdiv(a.N, 128), bh.y), dim3(256), stream, a);
+    // one 32-query tile per wave at three workgroups per CU (two tiles per wave need 256 registers and still spill)
+    static const int v = getenv("CENET_DATTN_QT2") ? 2 : 1;
+    if (v == 2 && a.N >= 1024) CENET_LAUNCH((dattn_fwd_kernel<16, 2, 2>), dim3(cdiv(a.N, 256), bh), dim3(256), stream, a);
+    else CENET_LAUNCH((dattn_fwd_kernel<16, 1, 3>), dim3(cdiv(a.N, 128), bh), dim3(256), stream, a);
   } else {
-    CENET_LAUNCH((dattn_fwd_kernel<32, 1>), dim3(cdiv(a.N, 128), bh.y), dim3(256), stream, a);
+    CENET_LAUNCH((dattn_fwd_kernel<32, 1, 2>), dim3(cdiv(a.N, 128), bh), dim3(256), stream, a);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
@@ -461,7 +666,7 @@ extern "C" int cenet_diffattn_heads_bwd_bf16(const cenet_diffattn_t* p, hipStrea
   DiffArgs a;
   const int rc = da_fill(a, p);
   if (rc != CENET_OK) return rc;
-  if (!a.v || !a.qt || !a.kt || !a.dU || !a.dUt || !a.dq || !a.dk || !a.dv || !a.delta) return CENET_EINVAL;
+  if (!a.dU || !a.dq || !a.dk || !a.dv || !a.aug) return CENET_EINVAL;
   const dim3 grid(cdiv(a.N, 128), a.B * a.H);
   if (a.hd <= 16) {
     CENET_LAUNCH((dattn_bwd_dq_kernel<16>), grid, dim3(256), stream, a);

@@ -205,12 +205,18 @@ def flash_bwd(a: AttnT, bf16: bool = False):
 
 class DiffAttnT(C.Structure):
     """cenet_diffattn_t (include/cenet_hip.h)."""
-    _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "qt", "kt", "vt", "U", "lse", "dU", "dUt", "dq", "dk", "dv", "delta")] + \
+    _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "U", "lse", "dU", "dq", "dk", "dv", "ws")] + \
                [(n, C.c_int) for n in ("B", "H", "N", "hd")] + [("scale", C.c_float)]
 
 
 def diffattn_heads_supported(hd: int, N: int) -> bool:
-    return bool(_lib.lib().cenet_diffattn_heads_supported(int(hd), int(N))) and N % 4 == 0
+    return bool(_lib.lib().cenet_diffattn_heads_supported(int(hd), int(N)))
+
+
+def diffattn_heads_ws_bytes(B: int, H: int, N: int) -> int:
+    fn = _lib.lib().cenet_diffattn_heads_ws_bytes
+    fn.restype = C.c_long
+    return int(fn(int(B), int(H), int(N)))
 
 
 def diffattn_heads(a: DiffAttnT, backward: bool):

@@ -779,13 +779,10 @@ class DiffAttnHeadsFn(Function):
         U = _act((B, 2 * H, N, dv), q)
         ctx.pairs = _bf(q) and kern.diffattn_heads_supported(hd, N)
         if ctx.pairs:
-            # bf16 tensors: the pair kernels of attn_diff.hip (both softmax heads of a value head per wave, no atomics);
-            # MFMA operands that run along the token index are read from per-image transposes
+            # bf16 tensors: the pair kernels of attn_diff.hip (both softmax heads of a value head per wave, no atomics)
             lse = _empty((B, 2 * H, N), q)
-            vt = _act((B, E, N), v)
-            kern.transpose(v, N * E, vt, N * E, B, N, E)
             a = kern.DiffAttnT()
-            a.q, a.k, a.vt, a.U, a.lse = q.data_ptr(), k.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr()
+            a.q, a.k, a.v, a.U, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), U.data_ptr(), lse.data_ptr()
             a.B, a.H, a.N, a.hd, a.scale = B, H, N, hd, hd ** -0.5
             kern.diffattn_heads(a, backward=False)
             ctx.save_for_backward(q, k, v, U, lse)
@@ -823,17 +820,11 @@ class DiffAttnHeadsFn(Function):
         if ctx.pairs:
             H = ctx.H
             lse = saved_list[0]
-            qt, kt, gt = _act((B, E, N), q), _act((B, E, N), k), _act((B, 2 * H, dv, N), g)
-            kern.transpose(q, N * E, qt, N * E, B, N, E)
-            kern.transpose(k, N * E, kt, N * E, B, N, E)
-            kern.transpose(g, N * dv, gt, N * dv, B * 2 * H, N, dv)
             dq, dk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-            delta = _empty((B, 2 * H, N), q)
+            ws = torch.empty(kern.diffattn_heads_ws_bytes(B, H, N), device=q.device, dtype=torch.uint8)
             a = kern.DiffAttnT()
-            a.q, a.k, a.v, a.qt, a.kt = q.data_ptr(), k.data_ptr(), v.data_ptr(), qt.data_ptr(), kt.data_ptr()
-            a.vt = v.data_ptr()  # not read by the backward (must be non-null)
-            a.U, a.lse, a.dU, a.dUt = U.data_ptr(), lse.data_ptr(), g.data_ptr(), gt.data_ptr()
-            a.dq, a.dk, a.dv, a.delta = dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(), delta.data_ptr()
+            a.q, a.k, a.v, a.U, a.lse, a.dU = q.data_ptr(), k.data_ptr(), v.data_ptr(), U.data_ptr(), lse.data_ptr(), g.data_ptr()
+            a.dq, a.dk, a.dv, a.ws = dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(), ws.data_ptr()
             a.B, a.H, a.N, a.hd, a.scale = B, H, N, hd, hd ** -0.5
             kern.diffattn_heads(a, backward=True)
             return dq, dk, dvv, None

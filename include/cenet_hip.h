@@ -123,21 +123,21 @@ int cenet_flash_attn_fwd_bf16(const cenet_attn_t* p, cenet_stream_t stream);
 int cenet_flash_attn_bwd_bf16(const cenet_attn_t* p, cenet_stream_t stream);
 /* Differential attention of the DSEB skip blocks on bf16 tensors (attn_diff.hip; multihead_diffattn.py:83-109): softmax head
  * 2h+s (s = 0, 1) attends with q_{2h+s}, k_{2h+s} over the SHARED value head h; U[b, 2h+s] = softmax(q k^T * scale) v_h.
- * Row-major operands q, k [B, N, 2H*hd], v [B, N, H*2hd] plus their per-image transposes qt, kt [B, 2H*hd, N], vt [B, H*2hd, N]
- * (the kernels read the transposed copy wherever an MFMA operand runs along the token index); U, dU [B, 2H, N, 2hd],
- * dUt [B, 2H, 2hd, N]; lse, delta [B, 2H, N] fp32 (delta is written by the backward).  Forward needs q, k, vt, U, lse; the
- * backward everything.  hd in {8, 16, 32}, N % 4 == 0, all pointers 16-byte aligned (cenet_diffattn_heads_supported). */
+ * q, k [B, N, 2H*hd], v [B, N, H*2hd] (token-major, as the projections produce them), U, dU [B, 2H, N, 2hd], lse [B, 2H, N]
+ * fp32; dq, dk, dv laid out like q, k, v.  ws: cenet_diffattn_heads_ws_bytes(B, H, N) bytes of scratch the backward uses to
+ * pass the softmax statistics between its two kernels.  hd in {8, 16, 32}; all pointers 16-byte aligned. */
 typedef struct {
-  const void *q, *k, *v, *qt, *kt, *vt;
+  const void *q, *k, *v;
   void* U;
   float* lse;
-  const void *dU, *dUt;
+  const void* dU;
   void *dq, *dk, *dv;
-  float* delta;
+  void* ws;
   int B, H, N, hd;
   float scale;
 } cenet_diffattn_t;
 int cenet_diffattn_heads_supported(int hd, int N);
+long cenet_diffattn_heads_ws_bytes(int B, int H, int N);
 int cenet_diffattn_heads_fwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
 int cenet_diffattn_heads_bwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
 /* Row softmax for the materialised path (head dims > 128): aten::_softmax(+_backward_data).  Scores x and score gradients

@@ -56,15 +56,16 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for key, e0, e1 in log:
     agg[key][0] += 1
     agg[key][1] += e0.elapsed_time(e1)
-peak = 1.0e15 if bf else 1.2e14
+esz = 2.0 if bf else 4.0
+peak = 2.5e15 if bf else 1.57e14
 rows = []
 for key, (n, ms) in agg.items():
     M, N, K, nb, nkb = key[:5]
     flops = 2.0 * M * N * K * nb * nkb
     if key[5] == "im":
-        byt = 4.0 * (M * K * nkb + M * N * nb + N * K * nb * nkb / 9)  # rough: patches re-use the image ~k*k times
+        byt = esz * (M * K * nkb + M * N * nb + N * K * nb * nkb / 9)  # rough: patches re-use the image ~k*k times
     else:
-        byt = 4.0 * nb * (M * K * nkb + K * N * nkb + M * N * (2 if key[7] == "at" else 1))
+        byt = nb * (esz * (M * K * nkb + K * N * nkb) + M * N * (8 if key[7] == "at" else esz))
     ideal = max(byt / 6e12, flops / peak) * 1e3 + 0.004
     rows.append((ms - n * ideal, ms, n, ideal, flops, byt, key))
 rows.sort(reverse=True)

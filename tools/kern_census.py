@@ -35,7 +35,7 @@ orig = kern._call
 
 def wrapped(name, *args):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    byt = sum(a.numel() * 4 for a in args if isinstance(a, torch.Tensor))
+    byt = sum(a.numel() * a.element_size() for a in args if isinstance(a, torch.Tensor))
     e0.record()
     orig(name, *args)
     e1.record()
