@@ -39,9 +39,14 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   g.E = *E;
   g.M = M; g.N = N; g.K = K; g.nkb = nkb; g.splits = splits; g.nb_inner = nb_inner;
   // quad staging: k-contiguous plain operand, every row/batch offset a multiple of 4 elements, K % 4 == 0
-  g.avec = A->kfast && A->kinner == 0 && A->sc == 1 && m4(A->sr) && m4(A->sb) && m4(A->sb2) && m4(A->skb) && m4(K) && alq(A->ptr);
-  g.bvec = B->mode == 0 && B->kfast && B->kinner == 0 && B->sr == 1 && m4(B->sc) && m4(B->sb) && m4(B->sb2) && m4(B->skb) &&
-           m4(K) && alq(B->ptr);
+  g.avec = (A->kfast && A->kinner == 0 && A->sc == 1 && m4(A->sr) && m4(A->sb) && m4(A->sb2) && m4(A->skb) && m4(K) &&
+            alq(A->ptr)) ? 4 : 0;
+  g.bvec = (B->mode == 0 && B->kfast && B->kinner == 0 && B->sr == 1 && m4(B->sc) && m4(B->sb) && m4(B->sb2) && m4(B->skb) &&
+            m4(K) && alq(B->ptr)) ? 4 : 0;
+  // bf16: 16-byte accesses (8 elements) where every offset is a multiple of 8 elements
+  auto m8 = [](long v) { return (v & 7) == 0; };
+  if (bf && g.avec && m8(A->sr) && m8(A->sb) && m8(A->sb2) && m8(A->skb) && m8(K) && (((uintptr_t)A->ptr & 15) == 0)) g.avec = 8;
+  if (bf && g.bvec && m8(B->sc) && m8(B->sb) && m8(B->sb2) && m8(B->skb) && m8(K) && (((uintptr_t)B->ptr & 15) == 0)) g.bvec = 8;
   // bf16 row-contiguous operands: two adjacent rows per 4-byte load (even extents and offsets)
   g.apair = bf && !A->kfast && A->kinner == 0 && A->sr == 1 && m2(A->sc) && m2(A->sb) && m2(A->sb2) && m2(A->skb) && m2(M) &&
             (((uintptr_t)A->ptr & 3) == 0);
@@ -84,7 +89,10 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
     // load -> LDS -> MFMA round trips of the (mostly latency-bound) mid-size contractions
     // (measured: a gain for the 64x64 / 32x64 tiles that these small launches get, a loss for the 128-wide tiles, whose
     // doubled prefetch registers drop them to one workgroup per CU, and for the split-K weight gradients)
-    const bool k64 = !im && K >= 128 && bm <= 64 && bn == 64 && !E->atomic;
+    // with bf16 tensors in HBM every tile but 32x256 has a K-step-64 instance; taken when the chunk a workgroup reduces
+    // is at least two 64-steps long
+    const long kchunk = ((long)nkb * K) / (splits > 0 ? splits : 1);
+    const bool k64 = !im && K >= 128 && kchunk >= 128 && bm <= 64 && bn == 64;  // (the 128-wide K-64 instances spill)
     rc = im ? cenet_gemm_launch_bf16_im2col(g, bm, bn, nbatch, swap, stream)
             : (k64 ? cenet_gemm_launch_bf16_plain_k64(g, bm, bn, nbatch, swap, stream)
                    : cenet_gemm_launch_bf16_plain(g, bm, bn, nbatch, swap, stream));

@@ -179,13 +179,13 @@ __device__ __forceinline__ PlainStage plain_stage(long rs, long ks, int kfast, i
     return s;
   }
   if (kfast) {
-    // 16-byte form: KT/4 lanes per row; scalar form: KT lanes per row
-    const int lpr = vec ? KT / 4 : KT;
+    // vector form (vec = 4 or 8 elements per access): KT/vec lanes per row; scalar form: KT lanes per row
+    const int lpr = vec ? KT / vec : KT;
     const int rstep = 256 / lpr, r0 = tid / lpr;
-    s.kk = vec ? (tid % lpr) * 4 : (tid % lpr);
+    s.kk = vec ? (tid % lpr) * vec : (tid % lpr);
     s.toff = (long)(x0 + r0) * rs + (long)s.kk * ks;
     s.dj = (long)rstep * rs;
-    const int nreg = vec ? NX / 4 : NX;
+    const int nreg = vec ? NX / vec : NX;
     for (int j = 0; j < nreg; ++j)
       if (x0 + r0 + j * rstep < X) s.ok |= 1u << j;
   } else {
@@ -222,6 +222,20 @@ __device__ __forceinline__ void plain_fetch(const PlainStage& s, const bf16_t* t
         else if (one) w = *p;
       }
       rg.u[j] = w;
+    }
+    return;
+  }
+  if (kfast && vec == 8) {  // 16-byte accesses: 8 consecutive k
+    if (interior) {
+#pragma unroll
+      for (int j = 0; j < NX / 8; ++j, p += s.dj) memcpy(&rg.u[4 * j], p, 16);
+      return;
+    }
+    const bool kok = s.kk < klim;
+#pragma unroll
+    for (int j = 0; j < NX / 8; ++j, p += s.dj) {
+      if (kok && ((s.ok >> j) & 1u)) memcpy(&rg.u[4 * j], p, 16);
+      else rg.u[4 * j] = rg.u[4 * j + 1] = rg.u[4 * j + 2] = rg.u[4 * j + 3] = 0u;
     }
     return;
   }
@@ -341,15 +355,17 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
   //   kfast vec    : k4 = tid % 8,   rows r = tid / 8 + 32 j   (4 consecutive k per register quad)
   //   mfast        : row = tid % BMN, kq = tid / BMN ; k = kq * KPT + j  (KPT consecutive k per thread)
   constexpr int A_KPT = KT / (256 / BM), B_KPT = KT / (256 / BN);
-  static_assert(BM <= 256 && BN <= 256 && NA % 4 == 0 && NB % 4 == 0 && NA <= 32 && NB <= 32, "unsupported tile");
+  static_assert(BM <= 256 && BN <= 256 && NA % 4 == 0 && NB % 4 == 0 && NA <= 64 && NB <= 64, "unsupported tile");
   StageRegs<NA> rga;
   StageRegs<NB> rgb;
   float* const ra = rga.f;
   float* const rb = rgb.f;
   // plain operands without the (ko,ki) split of k use hoisted pointer walks; the split form keeps per-element addressing
   const bool a_fast = g.A.kinner == 0, b_fast = !B_IM2COL && g.B.kinner == 0;
-  const PlainStage sa = plain_stage<BM, NA, KT>(g.A.sr, g.A.sc, g.A.kfast, g.avec, m0, g.M, tid, BF && a_fast && g.apair);
-  const PlainStage sb = plain_stage<BN, NB, KT>(g.B.sc, g.B.sr, g.B.kfast, g.bvec, n0, g.N, tid, BF && b_fast && g.bpair);
+  // 16-byte (8-element) staging needs at least 8 elements per thread and operand; else the quad form
+  const int avec = (g.avec == 8 && NA % 8 != 0) ? 4 : g.avec, bvec = (g.bvec == 8 && NB % 8 != 0) ? 4 : g.bvec;
+  const PlainStage sa = plain_stage<BM, NA, KT>(g.A.sr, g.A.sc, g.A.kfast, avec, m0, g.M, tid, BF && a_fast && g.apair);
+  const PlainStage sb = plain_stage<BN, NB, KT>(g.B.sc, g.B.sr, g.B.kfast, bvec, n0, g.N, tid, BF && b_fast && g.bpair);
   const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
 
   KEntry nent;
@@ -368,7 +384,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
     const GT* baseB = (const GT*)g.B.ptr + (long)bo * g.B.sb + (long)bi * g.B.sb2 + (long)kb * g.B.skb;
     const int klim = g.K - k0;
     if (a_fast) {
-      plain_fetch<NA>(sa, baseA + (long)k0 * g.A.sc, klim, g.A.kfast, g.avec, a_in && klim >= KT, rga);
+      plain_fetch<NA>(sa, baseA + (long)k0 * g.A.sc, klim, g.A.kfast, avec, a_in && klim >= KT, rga);
     } else if (g.A.kfast) {
       const int kk = tid % KT, r0 = tid / KT;
 #pragma unroll
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
     }
     if (!B_IM2COL) {
       if (b_fast) {
-        plain_fetch<NB>(sb, baseB + (long)k0 * g.B.sr, klim, g.B.kfast, g.bvec, b_in && klim >= KT, rgb);
+        plain_fetch<NB>(sb, baseB + (long)k0 * g.B.sr, klim, g.B.kfast, bvec, b_in && klim >= KT, rgb);
       } else if (g.B.kfast) {
         const int kk = tid % KT, c0 = tid / KT;
 #pragma unroll
@@ -472,7 +488,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
       memcpy(&As[row * P + kq * (NA / 2)], lo, NA);
       memcpy(&As[(row + 1) * P + kq * (NA / 2)], hi, NA);
     } else if (g.A.kfast) {
-      if (g.avec) {
+      if (BF && avec == 8) {
+        constexpr int L8 = KT / 8, R8 = 256 / L8;
+        const int k8 = (tid % L8) * 8, r0 = tid / L8;
+#pragma unroll
+        for (int j = 0; j < NA / 8; ++j) memcpy(&As[(r0 + j * R8) * P + k8], &rga.u[4 * j], 16);
+      } else if (avec) {
         const int k4 = (tid % LV) * 4, r0 = tid / LV;
         if (BF) {
 #pragma unroll
@@ -501,7 +522,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
       memcpy(&Bs[col * P + kq * (NB / 2)], lo, NB);
       memcpy(&Bs[(col + 1) * P + kq * (NB / 2)], hi, NB);
     } else if (g.B.kfast) {
-      if (!B_IM2COL && g.bvec) {
+      if (BF && !B_IM2COL && bvec == 8) {
+        constexpr int L8 = KT / 8, R8 = 256 / L8;
+        const int k8 = (tid % L8) * 8, c0 = tid / L8;
+#pragma unroll
+        for (int j = 0; j < NB / 8; ++j) memcpy(&Bs[(c0 + j * R8) * P + k8], &rgb.u[4 * j], 16);
+      } else if (!B_IM2COL && bvec) {
         const int k4 = (tid % LV) * 4, c0 = tid / LV;
         if (BF) {
 #pragma unroll
@@ -758,7 +784,8 @@ static int launch_tile(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_
   }
   return CENET_EUNSUPPORTED;
 }
-// K step 64 (plain bf16 operands): only the small tiles, whose doubled prefetch registers keep two workgroups per CU
+// K step 64 (plain bf16 operands; with bf16 tensors the prefetch registers hold packed pairs, so the 128-wide tiles keep
+// two workgroups per CU at K step 64 too)
 template <typename OpT, bool SWAP>
 static int launch_tile_k64(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_t stream) {
   dim3 grid(cdiv(g.N, bn), cdiv(g.M, bm), nbatch * g.splits);
