@@ -11,6 +11,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcenet_hip.so")
 
 
+# per-file flags: the attention kernels never produce or consume NaNs on purpose (masked scores are -1e30), and without
+# NaN semantics fmaxf on MFMA results needs no canonicalising v_max
+EXTRA_FLAGS = {"attn_diff.hip": ["-fno-honor-nans"]}
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -36,7 +41,7 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
         objs.append(obj)
         if force or _stale(obj, [src] + deps[len(sources()):]):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-                   "-Wno-unused-result"]
+                   "-Wno-unused-result"] + EXTRA_FLAGS.get(os.path.basename(src), [])
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

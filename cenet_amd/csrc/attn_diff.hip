@@ -47,16 +47,10 @@ __device__ __forceinline__ float da_exp2(float x) { return __builtin_amdgcn_exp2
 __device__ __forceinline__ bool da_any(bool v) { return __any(v); }
 typedef short da_s4 __attribute__((ext_vector_type(4)));
 #endif
-// max of three without the canonicalising v_max the compiler puts in front of fmaxf on MFMA results
-__device__ __forceinline__ float da_max3(float a, float b, float c3) {
-#ifdef CENET_HOSTSIM_BUILD
-  return fmaxf(fmaxf(a, b), c3);
-#else
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c3));
-  return r;
-#endif
-}
+// max of three; built with -fno-honor-nans (cenet_amd/build.py) the compiler emits v_max3_f32 without the canonicalising
+// v_max it otherwise puts in front of fmaxf on MFMA results.  (NOT inline asm: hipcc pads no MFMA -> VALU wait states for
+// an asm statement that reads accumulator registers, cdna_hip_programming.md §5.7 — the asm form read stale scores.)
+__device__ __forceinline__ float da_max3(float a, float b, float c3) { return fmaxf(fmaxf(a, b), c3); }
 
 struct DiffArgs {
   const bf *q, *k, *v;  // row-major: q, k [B, N, 2H*hd] ; v [B, N, H*2hd]

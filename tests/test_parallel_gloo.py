@@ -124,3 +124,111 @@ def test_arena_views_and_segments():
         assert off % optim.ALIGN == 0
     with pytest.raises(ValueError):
         optim.ParamArena(_make(), [("c", lambda n: n.startswith("c."))])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the REAL CENet (SURVEY §8e known-answer test; reference concept main_acdc.py:178-179): two gloo ranks, kernels on the host
+# SIMT checker at 32x32, batch 2 per rank
+# ---------------------------------------------------------------------------------------------------------------------------
+def _cenet_shard(rank):
+    g = torch.Generator().manual_seed(500 + rank)
+    return torch.randn(2, 1, 32, 32, generator=g), torch.randint(0, 4, (2, 32, 32), generator=g).float()
+
+
+def _cenet_worker(rank, world, port, q):
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from backend import use_sim
+    from cenet_amd import losses, optim, parallel
+    from cenet_amd.networks import CENet
+    from oracle import cenet_oracle as O
+    from oracle.golden_cases import MODEL_CONFIGS, config_from_kwargs
+    torch.set_num_threads(2)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        use_sim()
+        kw = MODEL_CONFIGS["acdc"]["kw"]
+        net = CENet(**kw)
+        net.load_state_dict(O.make_state_dict(config_from_kwargs(kw), seed=7 + 13 * rank), strict=True)  # rank 1 starts elsewhere
+        net.train()
+        net.backbone.reset_drop_path(0.0)
+        arena = optim.ParamArena(net, optim.cenet_segments())
+        red = parallel.GradReducer(arena)
+        red.broadcast_state(net)  # parameters AND buffers of rank 0 everywhere
+        parallel.attach(net, red)
+        # record what each hook sees: the segment's gradient slice at the moment its all-reduce would start
+        seen, order = {}, []
+        orig = red.segment_ready
+
+        def spy(i):
+            if i not in seen:
+                order.append(i)
+                seen[i] = arena.segment_grad(i).clone()
+        red.segment_ready = spy
+        x, lab = _cenet_shard(rank)
+        crit = losses.Criterion(4, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
+        arena.zero_grad()
+        loss = crit(net(x), lab)
+        loss.backward()
+        local = arena.grads.clone()
+        final_when_fired = {i: bool(torch.equal(seen[i], local[arena.segments[i][1]:arena.segments[i][2]])) for i in seen}
+        red.segment_ready = orig
+        red.finish()  # reduces every segment (none was started by the spy)
+        grads = arena.grads.clone() * red.grad_scale
+        bn = {k: v.clone().numpy() for k, v in net.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+        q.put((rank, loss.item(), grads.numpy(), order, final_when_fired, bn, {n: arena.index[n] for n in arena.index}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_cenet_two_ranks_match_the_mean_of_per_shard_oracle_gradients():
+    """n-rank gradient == mean of the single-rank ORACLE gradients on the same shards (rank-0 weights after the broadcast);
+    the tensor hooks CENet.forward places on x4..x1 fire in segment order 0,1,2,3 and each segment's gradient slice is final
+    when its hook fires; BatchNorm buffers stay per rank and equal the oracle's on that rank's shard."""
+    from oracle import cenet_oracle as O
+    from oracle.golden_cases import MODEL_CONFIGS, config_from_kwargs
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cenet_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    kw = MODEL_CONFIGS["acdc"]["kw"]
+    cfg = config_from_kwargs(kw)
+    ref = []
+    for r in range(world):
+        sd = O.make_state_dict(cfg, seed=7)  # rank 0's weights everywhere
+        params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+        x, lab = _cenet_shard(r)
+        loss = O.criterion(O.cenet_forward(sd, x, cfg, training=True), lab, 4)
+        loss.backward()
+        ref.append((loss.item(), {k: v.grad for k, v in params.items()}, sd))
+    for rank, loss, grads, order, final, bn, index in res:
+        assert abs(loss - ref[rank][0]) < 1e-4
+        assert order == [0, 1, 2, 3], f"hooks on x4, x3, x2, x1 must fire in this order, got {order}"
+        assert all(final.values()), f"a segment was still being written when its hook fired: {final}"
+        g = torch.from_numpy(grads)
+        wants = {name: (ref[0][1][name] + ref[1][1][name]).reshape(-1) / world for name in index}
+        gmax = max(w.abs().max().item() for w in wants.values())
+        num = den = 0.0
+        for name, (off, n) in index.items():
+            want, got = wants[name], g[off:off + n]
+            num += float(((got - want) ** 2).sum())
+            den += float((want ** 2).sum())
+            # batch-2 BatchNorm at 1x1 .. 8x8 maps is ill-conditioned (fp32 noise is amplified, most at the 1x1 maps of dec4,
+            # where a batch of two leaves one degree of freedom per channel): per tensor 5 % of its largest entry (15 % inside
+            # dec4) plus 1e-4 of the largest gradient entry of the model, and 1 % for the whole vector in the L2 sense
+            budget = 0.15 if ".dec4." in name else 0.05
+            assert (got - want).abs().max().item() <= budget * want.abs().max().item() + 1e-4 * gmax, name
+        assert (num / den) ** 0.5 < 1e-2, (num / den) ** 0.5
+        for k, v in bn.items():  # per-rank statistics (no SyncBN): the oracle's buffers after ITS shard
+            torch.testing.assert_close(torch.from_numpy(v), ref[rank][2][k], rtol=2e-3, atol=1e-4, msg=k)
+    torch.testing.assert_close(torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2]), rtol=0, atol=0)  # identical after reduce
