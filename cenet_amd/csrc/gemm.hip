@@ -1,6 +1,7 @@
 // gemm.hip — C-ABI entry of the GEMM / implicit-GEMM core: argument checks, tile and split-K selection, dispatch to the
 // per-type instantiations (gemm_inst_*.hip).  The kernel itself is in gemm_core.h.
-#include "gemm_core.h"
+#include "gemm_ring.h"
+#include <cstdlib>
 
 static void pick_tile(int M, int N, int nbatch, int splits, int* bm, int* bn) {
   int m = M >= 96 ? 128 : (M >= 48 ? 64 : 32);
@@ -64,14 +65,30 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   int bm, bn;
   pick_tile(M, N, nbatch, splits, &bm, &bn);
   if (B->mode == 1 && B->kfast && bm == 32) bn = 64;  // weight-gradient view: keep the per-thread gather list short
+  // LDS-DMA ring kernel (gemm_ring.h): bf16, both operands plain with a contiguous, 16-byte aligned fast axis
+  int akf = -1, bkf = -1;
+  if (bf && B->mode == 0) {
+    auto e8 = [](long v) { return (v & 7) == 0; };
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const bool abase = A->kinner == 0 && e8(A->sb) && e8(A->sb2) && e8(A->skb) && al16(A->ptr);
+    const bool bbase = B->kinner == 0 && e8(B->sb) && e8(B->sb2) && e8(B->skb) && al16(B->ptr);
+    akf = (abase && A->sc == 1 && e8(A->sr) && e8(K)) ? 1 : ((abase && A->sr == 1 && e8(A->sc) && e8(M)) ? 0 : -1);
+    bkf = (bbase && B->sr == 1 && e8(B->sc) && e8(K)) ? 1 : ((bbase && B->sc == 1 && e8(B->sr) && e8(N)) ? 0 : -1);
+  }
+  static const bool ring_off = getenv("CENET_GEMM_NO_RING") != nullptr;
+  const bool ring = !ring_off && akf >= 0 && bkf >= 0 && !E->cmode && E->act == ACT_NONE && M >= 48 && N >= 48;
+  if (ring) {
+    bm = bn = (M >= 96 && N >= 96 && (E->atomic || (long)cdiv(M, 128) * cdiv(N, 128) * nbatch >= 256)) ? 128 : 64;
+  }
+  const int kstep = ring ? 64 : BK;
   if (E->atomic && !E->cmode && splits > 1) {
     // split-K: every split adds the whole MxN tile with float atomics (~1.3 TB/s chip-wide), and one workgroup's K loop is a
     // serial chain of ~0.9 us (plain) / ~2 us (gathering) iterations, so with s splits
     //     time ~ iters / s * t_iter  +  s * tiles * tile_bytes / 1.3 TB/s
     // which is least at s = sqrt(iters * t_iter / per-split atomic time); never more workgroups than fit on the chip at once
     const long tiles = (long)cdiv(M, bm) * cdiv(N, bn) * nbatch;
-    const long iters = (long)nkb * cdiv(K, BK);
-    const double t_iter = (B->mode == 1) ? 2.0 : 0.9;
+    const long iters = (long)nkb * cdiv(K, kstep);
+    const double t_iter = ring ? 0.5 : ((B->mode == 1) ? 2.0 : 0.9);
     const double t_atom = (double)tiles * bm * bn * 4.0 / 1.3e6;  // us per split
     long s = (long)(__builtin_sqrt((double)iters * t_iter / t_atom) + 0.5);
     const long slots = (bm * bn >= 128 * 128) ? 512 : 1024;
@@ -84,7 +101,11 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   }
   const bool im = B->mode != 0;
   int rc;
-  if (bf) {
+  if (ring) {
+    if (bm == 128 && (long)cdiv(M, 128) * cdiv(N, 128) * nbatch * splits < 192) bm = bn = 64;
+    rc = akf ? (bkf ? cenet_gemm_launch_ring_kk(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_ring_kr(g, bm, bn, nbatch, swap, stream))
+             : (bkf ? cenet_gemm_launch_ring_rk(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_ring_rr(g, bm, bn, nbatch, swap, stream));
+  } else if (bf) {
     // plain operands with a reduction of at least two 64-steps: K step 64 halves the barriers and the serial
     // load -> LDS -> MFMA round trips of the (mostly latency-bound) mid-size contractions
     // (measured: a gain for the 64x64 / 32x64 tiles that these small launches get, a loss for the 128-wide tiles, whose

@@ -302,6 +302,186 @@ __device__ __forceinline__ void plain_fetch(const PlainStage& s, const float* ti
   }
 }
 
+// Epilogue shared by the GEMM kernels: acc[i][j] is the 16x16 fragment (i, j) of this wave's (BM/2)x(BN/2) quadrant
+// (waves 2x2 over the tile).  cstrip: LDS scratch of 4*16*(BN/2+1) floats, used by the atomic split-K path (!SWAP).
+template <typename GT, int BM, int BN, bool SWAP>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], float* cstrip, int m0, int n0,
+                                              int bo, int bi, int batch, int wave, int lane) {
+  constexpr int MI = BM / 32, NJ = BN / 32;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  // ---- epilogue ----
+  // !SWAP: acc[i][j][r] = C[row = .. + fq*4 + r][col = .. + fr]   (4 consecutive rows per lane)
+  //  SWAP: acc[i][j][r] = C[row = .. + fr][col = .. + fq*4 + r]   (4 consecutive columns per lane)
+  const cenet_epi_t& E = g.E;
+  float* const Cf = (float*)E.C + (long)bo * E.scb + (long)bi * E.scb2;  // atomic epilogues: C is fp32 whatever OpT is
+  GT* const Cb = (GT*)E.C + (long)bo * E.scb + (long)bi * E.scb2;
+  if (!SWAP && E.atomic && !E.cmode && E.scc == 1) {
+    // split-K accumulation into a row-major C: float atomics reach their chip-wide rate only as 256 contiguous bytes per
+    // wave instruction, but an MFMA accumulator register spans 4 rows x 16 floats.  Each wave therefore transposes one
+    // 16-row strip at a time through a private LDS strip and issues the atomics with lane = column.
+    constexpr int WN = BN / 2;
+    float* strip = cstrip + wave * (16 * (WN + 1));
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) strip[(fq * 4 + r) * (WN + 1) + j * 16 + fr] = acc[i][j][r] * E.alpha;
+      __syncthreads();
+      const int row0 = m0 + wm * (BM / 2) + i * 16, col0 = n0 + wn * WN;
+      for (int idx = lane; idx < 16 * WN; idx += 64) {
+        const int r = idx / WN, c = idx - r * WN;
+        if (row0 + r < g.M && col0 + c < g.N) atomicAdd(&Cf[(long)(row0 + r) * E.scr + col0 + c], strip[r * (WN + 1) + c]);
+      }
+    }
+    return;
+  }
+  const GT* Rb = E.R ? (const GT*)E.R + (long)bo * E.srb + (long)bi * E.srb2 : nullptr;
+  const int bsr = E.bscale ? E.bscale_rows : 0;  // > 0: per-sample scale looked up by row (flat batch)
+  const float bs = (E.bscale && bsr == 0) ? E.bscale[batch] : 1.f;
+  const int rwave = m0 + wm * (BM / 2) + (SWAP ? fr : fq * 4);
+  const int cwave = n0 + wn * (BN / 2) + (SWAP ? fq * 4 : fr);
+  if (g.cvec && !E.atomic && !E.cmode && E.act == ACT_NONE && m0 + BM <= g.M && n0 + BN <= g.N) {
+    // interior tile of the common case (plain store, optional bias / per-batch scale / residual): 16 bytes per lane and
+    // fragment, no bounds tests, one 64-bit offset per lane and constant strides per fragment (the general version below
+    // spends ~70 VALU instructions per fragment; on the K <= 128 GEMMs of stages 1-2 that made the epilogue the longest part
+    // of the kernel)
+    const float scale = E.alpha * bs;
+    GT* crow = Cb + (long)rwave * E.scr + (long)cwave * E.scc;
+    const GT* rrow = Rb ? Rb + (long)rwave * E.srr + (long)cwave * E.src : nullptr;
+    const long ci = 16 * E.scr, cj = 16 * E.scc, ri = 16 * E.srr, rj = 16 * E.src;
+    const bool bias_vec = E.bias && (SWAP != (bool)E.bias_on_row) && (((uintptr_t)E.bias & 15) == 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int rbase = rwave + i * 16, cbase = cwave + j * 16;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if (E.bias) {
+          if (bias_vec) {  // the bias index runs along the lane's four elements
+            float bb[4];
+            memcpy(bb, E.bias + (SWAP ? cbase : rbase), 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * E.alpha + bb[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              v[r] = v[r] * E.alpha + E.bias[E.bias_on_row ? (SWAP ? rbase : rbase + r) : (SWAP ? cbase + r : cbase)];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= bs;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= scale;
+        }
+        if (bsr > 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= E.bscale[(SWAP ? rbase : rbase + r) / bsr];
+        }
+        if (rrow) {
+          float rr[4];
+          ld4v(rr, rrow + i * ri + j * rj);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rr[r];
+        }
+        st4v(crow + i * ci + j * cj, v);
+      }
+    return;
+  }
+  if (g.cvec && !E.atomic && !E.cmode && E.act == ACT_NONE) {
+    // common case (plain store, optional bias / per-batch scale / residual), 16 bytes per lane and fragment.  This loop
+    // nest MUST stay small enough to unroll fully: if it does not, acc[][] is indexed dynamically, lives in scratch
+    // memory and is spilled there on every K step.
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int rbase = rwave + i * 16, cbase = cwave + j * 16;
+        const bool full = SWAP ? (rbase < g.M && cbase + 3 < g.N) : (rbase + 3 < g.M && cbase < g.N);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * E.alpha;
+        if (full) {
+          if (E.bias) {
+            if (SWAP != (bool)E.bias_on_row && ((uintptr_t)E.bias & 15) == 0) {  // bias index runs along the lane's 4 elements
+              float bb[4];
+              memcpy(bb, E.bias + (SWAP ? cbase : rbase), 16);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bb[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += E.bias[E.bias_on_row ? (SWAP ? rbase : rbase + r) : (SWAP ? cbase + r : cbase)];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= bsr > 0 ? E.bscale[(SWAP ? rbase : rbase + r) / bsr] : bs;
+          if (Rb) {
+            float rr[4];
+            ld4v(rr, Rb + (long)rbase * E.srr + (long)cbase * E.src);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+          }
+          st4v(Cb + (long)rbase * E.scr + (long)cbase * E.scc, v);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = SWAP ? rbase : rbase + r, col = SWAP ? cbase + r : cbase;
+            if (row < g.M && col < g.N) {
+              float t = v[r];
+              if (E.bias) t += E.bias[E.bias_on_row ? row : col];
+              t *= bsr > 0 ? E.bscale[row / bsr] : bs;
+              if (Rb) t += ldf(Rb + (long)row * E.srr + (long)col * E.src);
+              stf(Cb + (long)row * E.scr + (long)col * E.scc, t);
+            }
+          }
+        }
+      }
+    return;
+  }
+  // everything else (activations, col2im scatter, strided atomics, unaligned C): a RUNTIME loop over the fragments; the
+  // fragment is picked with a chain of selects on static indices so that acc[][] stays in registers
+  for (int f = 0; f < MI * NJ; ++f) {
+    f32x4 t4 = acc[0][0];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (f == i * NJ + j) t4 = acc[i][j];
+    const int rbase = rwave + (f / NJ) * 16, cbase = cwave + (f % NJ) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = SWAP ? rbase : rbase + r, col = SWAP ? cbase + r : cbase;
+      if (row < g.M && col < g.N) {
+        float v = t4[r] * E.alpha;
+        if (E.cmode) {  // col2im scatter: row = (ci,ky,kx), col = (py,px)
+          const int kkw = E.cKH * E.cKW;
+          const int ci = row / kkw, rem = row - ci * kkw;
+          const int ky = rem / E.cKW, kx = rem - ky * E.cKW;
+          const int py = col / E.cPw, px = col - py * E.cPw;
+          const int iy = py * E.cstride - E.cpad + ky, ix = px * E.cstride - E.cpad + kx;
+          if (iy >= 0 && iy < E.cHs && ix >= 0 && ix < E.cWs) {
+            const long o = (long)ci * E.csci + (long)iy * E.csy + (long)ix * E.csx;
+            if (E.atomic) atomicAdd(&Cf[o], v);
+            else stf(&Cb[o], v);
+          }
+        } else if (E.atomic) {
+          atomicAdd(&Cf[(long)row * E.scr + (long)col * E.scc], v);
+        } else {
+          if (E.bias) v += E.bias[E.bias_on_row ? row : col];
+          v = act_fwd(E.act, v, E.slope);
+          v *= bsr > 0 ? E.bscale[row / bsr] : bs;
+          if (Rb) v += ldf(Rb + (long)row * E.srr + (long)col * E.src);
+          stf(&Cb[(long)row * E.scr + (long)col * E.scc], v);
+        }
+      }
+    }
+  }
+}
+
 template <typename OpT, int BM, int BN, bool B_IM2COL, bool SWAP, int KT>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kernel(GemmArgs g) {  // 128x128: keep two workgroups per CU
   static_assert(KT == 32 || (KT == 64 && !B_IM2COL), "K step: 32, or 64 for plain operands");
@@ -593,176 +773,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 1)) void gemm_kern
     __syncthreads();
   }
 
-  // ---- epilogue ----
-  // !SWAP: acc[i][j][r] = C[row = .. + fq*4 + r][col = .. + fr]   (4 consecutive rows per lane)
-  //  SWAP: acc[i][j][r] = C[row = .. + fr][col = .. + fq*4 + r]   (4 consecutive columns per lane)
-  const cenet_epi_t& E = g.E;
-  float* const Cf = (float*)E.C + (long)bo * E.scb + (long)bi * E.scb2;  // atomic epilogues: C is fp32 whatever OpT is
-  GT* const Cb = (GT*)E.C + (long)bo * E.scb + (long)bi * E.scb2;
-  if (!SWAP && E.atomic && !E.cmode && E.scc == 1) {
-    // split-K accumulation into a row-major C: float atomics reach their chip-wide rate only as 256 contiguous bytes per
-    // wave instruction, but an MFMA accumulator register spans 4 rows x 16 floats.  Each wave therefore transposes one
-    // 16-row strip at a time through a private LDS strip and issues the atomics with lane = column.
-    constexpr int WN = BN / 2;
-    float* strip = cstrip + wave * (16 * (WN + 1));
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) strip[(fq * 4 + r) * (WN + 1) + j * 16 + fr] = acc[i][j][r] * E.alpha;
-      __syncthreads();
-      const int row0 = m0 + wm * (BM / 2) + i * 16, col0 = n0 + wn * WN;
-      for (int idx = lane; idx < 16 * WN; idx += 64) {
-        const int r = idx / WN, c = idx - r * WN;
-        if (row0 + r < g.M && col0 + c < g.N) atomicAdd(&Cf[(long)(row0 + r) * E.scr + col0 + c], strip[r * (WN + 1) + c]);
-      }
-    }
-    return;
-  }
-  const GT* Rb = E.R ? (const GT*)E.R + (long)bo * E.srb + (long)bi * E.srb2 : nullptr;
-  const int bsr = E.bscale ? E.bscale_rows : 0;  // > 0: per-sample scale looked up by row (flat batch)
-  const float bs = (E.bscale && bsr == 0) ? E.bscale[batch] : 1.f;
-  const int rwave = m0 + wm * (BM / 2) + (SWAP ? fr : fq * 4);
-  const int cwave = n0 + wn * (BN / 2) + (SWAP ? fq * 4 : fr);
-  if (g.cvec && !E.atomic && !E.cmode && E.act == ACT_NONE && m0 + BM <= g.M && n0 + BN <= g.N) {
-    // interior tile of the common case (plain store, optional bias / per-batch scale / residual): 16 bytes per lane and
-    // fragment, no bounds tests, one 64-bit offset per lane and constant strides per fragment (the general version below
-    // spends ~70 VALU instructions per fragment; on the K <= 128 GEMMs of stages 1-2 that made the epilogue the longest part
-    // of the kernel)
-    const float scale = E.alpha * bs;
-    GT* crow = Cb + (long)rwave * E.scr + (long)cwave * E.scc;
-    const GT* rrow = Rb ? Rb + (long)rwave * E.srr + (long)cwave * E.src : nullptr;
-    const long ci = 16 * E.scr, cj = 16 * E.scc, ri = 16 * E.srr, rj = 16 * E.src;
-    const bool bias_vec = E.bias && (SWAP != (bool)E.bias_on_row) && (((uintptr_t)E.bias & 15) == 0);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int rbase = rwave + i * 16, cbase = cwave + j * 16;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-        if (E.bias) {
-          if (bias_vec) {  // the bias index runs along the lane's four elements
-            float bb[4];
-            memcpy(bb, E.bias + (SWAP ? cbase : rbase), 16);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] * E.alpha + bb[r];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              v[r] = v[r] * E.alpha + E.bias[E.bias_on_row ? (SWAP ? rbase : rbase + r) : (SWAP ? cbase + r : cbase)];
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= bs;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= scale;
-        }
-        if (bsr > 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= E.bscale[(SWAP ? rbase : rbase + r) / bsr];
-        }
-        if (rrow) {
-          float rr[4];
-          ld4v(rr, rrow + i * ri + j * rj);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += rr[r];
-        }
-        st4v(crow + i * ci + j * cj, v);
-      }
-    return;
-  }
-  if (g.cvec && !E.atomic && !E.cmode && E.act == ACT_NONE) {
-    // common case (plain store, optional bias / per-batch scale / residual), 16 bytes per lane and fragment.  This loop
-    // nest MUST stay small enough to unroll fully: if it does not, acc[][] is indexed dynamically, lives in scratch
-    // memory and is spilled there on every K step.
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int rbase = rwave + i * 16, cbase = cwave + j * 16;
-        const bool full = SWAP ? (rbase < g.M && cbase + 3 < g.N) : (rbase + 3 < g.M && cbase < g.N);
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * E.alpha;
-        if (full) {
-          if (E.bias) {
-            if (SWAP != (bool)E.bias_on_row && ((uintptr_t)E.bias & 15) == 0) {  // bias index runs along the lane's 4 elements
-              float bb[4];
-              memcpy(bb, E.bias + (SWAP ? cbase : rbase), 16);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += bb[r];
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += E.bias[E.bias_on_row ? (SWAP ? rbase : rbase + r) : (SWAP ? cbase + r : cbase)];
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= bsr > 0 ? E.bscale[(SWAP ? rbase : rbase + r) / bsr] : bs;
-          if (Rb) {
-            float rr[4];
-            ld4v(rr, Rb + (long)rbase * E.srr + (long)cbase * E.src);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rr[r];
-          }
-          st4v(Cb + (long)rbase * E.scr + (long)cbase * E.scc, v);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = SWAP ? rbase : rbase + r, col = SWAP ? cbase + r : cbase;
-            if (row < g.M && col < g.N) {
-              float t = v[r];
-              if (E.bias) t += E.bias[E.bias_on_row ? row : col];
-              t *= bsr > 0 ? E.bscale[row / bsr] : bs;
-              if (Rb) t += ldf(Rb + (long)row * E.srr + (long)col * E.src);
-              stf(Cb + (long)row * E.scr + (long)col * E.scc, t);
-            }
-          }
-        }
-      }
-    return;
-  }
-  // everything else (activations, col2im scatter, strided atomics, unaligned C): a RUNTIME loop over the fragments; the
-  // fragment is picked with a chain of selects on static indices so that acc[][] stays in registers
-  for (int f = 0; f < MI * NJ; ++f) {
-    f32x4 t4 = acc[0][0];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        if (f == i * NJ + j) t4 = acc[i][j];
-    const int rbase = rwave + (f / NJ) * 16, cbase = cwave + (f % NJ) * 16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = SWAP ? rbase : rbase + r, col = SWAP ? cbase + r : cbase;
-      if (row < g.M && col < g.N) {
-        float v = t4[r] * E.alpha;
-        if (E.cmode) {  // col2im scatter: row = (ci,ky,kx), col = (py,px)
-          const int kkw = E.cKH * E.cKW;
-          const int ci = row / kkw, rem = row - ci * kkw;
-          const int ky = rem / E.cKW, kx = rem - ky * E.cKW;
-          const int py = col / E.cPw, px = col - py * E.cPw;
-          const int iy = py * E.cstride - E.cpad + ky, ix = px * E.cstride - E.cpad + kx;
-          if (iy >= 0 && iy < E.cHs && ix >= 0 && ix < E.cWs) {
-            const long o = (long)ci * E.csci + (long)iy * E.csy + (long)ix * E.csx;
-            if (E.atomic) atomicAdd(&Cf[o], v);
-            else stf(&Cb[o], v);
-          }
-        } else if (E.atomic) {
-          atomicAdd(&Cf[(long)row * E.scr + (long)col * E.scc], v);
-        } else {
-          if (E.bias) v += E.bias[E.bias_on_row ? row : col];
-          v = act_fwd(E.act, v, E.slope);
-          v *= bsr > 0 ? E.bscale[row / bsr] : bs;
-          if (Rb) v += ldf(Rb + (long)row * E.srr + (long)col * E.src);
-          stf(&Cb[(long)row * E.scr + (long)col * E.scc], v);
-        }
-      }
-    }
-  }
+  gemm_epilogue<GT, BM, BN, SWAP>(g, acc, cstrip, m0, n0, bo, bi, batch, wave, lane);
 }
 
 template <typename OpT, bool IM, bool SWAP, int KT>

@@ -1,0 +1,266 @@
+// gemm_ring.h — bf16 GEMM for plain (non-gathering) operands whose fast axis is contiguous and 16-byte aligned: the
+// operand tiles go HBM -> LDS with global_load_lds_dwordx4 (no staging registers) into a ring of NS stage buffers, so a
+// workgroup keeps NS - 1 K-steps of 64 in flight; one raw s_barrier per K-step, counted s_waitcnt vmcnt(N).
+//
+// The contractions of this network are short (K = 64 .. 1280 per workgroup, or split-K chunks of that size), so the
+// register-prefetch kernel of gemm_core.h (one K-step in flight, two barriers per step) spends most of its time waiting
+// for the first bytes; measured in isolation every shape of a training step ran 3 - 30x above its HBM / MFMA bound.
+//
+// Operand orientations (template flags, any combination):
+//   k-fast (KF): element (row, k) at row * ld + k.        LDS image [rows][64 k], 128-byte rows, 16-byte chunk c of
+//                row r stored at chunk c ^ ((r >> 1) & 7): fragment reads (ds_read_b128, 16 rows x 16 bytes) conflict-free.
+//   row-fast (RF): element (row, k) at k * ld + row.      LDS image [64 k][BX rows]; fragments by ds_read_b64_tr_b16
+//                (4 k-rows x 16 columns per 16-lane group), chunk c of k-row k stored at c ^ key(k) (rf_key below).
+// An LDS-DMA writes wave-uniform base + lane * 16, so the images are lane-linear and the swizzle is applied to the
+// per-lane SOURCE address (cdna_hip_programming.md rule 21).
+//
+// Rows beyond M / N are clamped to valid rows (their products land in accumulator rows the epilogue never stores); k
+// beyond K reads a 16-byte zero block.  Everything else (epilogue, split-K, batching, XCD order) is gemm_core.h's.
+#pragma once
+#include "gemm_core.h"
+
+#ifdef CENET_HOSTSIM_BUILD
+static const unsigned ring_zero16[4] = {0, 0, 0, 0};
+#else
+__device__ __attribute__((aligned(16))) const unsigned ring_zero16[4] = {0, 0, 0, 0};
+#endif
+
+typedef short ring_s4 __attribute__((ext_vector_type(4)));
+
+// one 16-byte LDS-DMA: lane L of the wave writes wave_base + 16 L
+__device__ __forceinline__ void ring_glds16(const void* gsrc, unsigned char* wave_base, int lane) {
+#ifdef CENET_HOSTSIM_BUILD
+  memcpy(wave_base + 16 * lane, gsrc, 16);
+#else
+  (void)lane;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned*)gsrc,
+                                   (__attribute__((address_space(3))) unsigned*)wave_base, 16, 0, 0);
+#endif
+}
+
+template <int N>
+__device__ __forceinline__ void ring_wait_vm() {
+#ifndef CENET_HOSTSIM_BUILD
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void ring_barrier() {
+#ifdef CENET_HOSTSIM_BUILD
+  __syncthreads();
+#else
+  asm volatile("s_barrier" ::: "memory");
+#endif
+}
+
+// swizzle keys
+__device__ __forceinline__ int kf_key(int row) { return (row >> 1) & 7; }
+template <int BX>
+__device__ __forceinline__ int rf_key(int k) {
+  // the 32 lanes of one ds_read_b64_tr_b16 pass touch k-rows {0..3, 8..11} (+4 for the second read) x 2 chunks
+  return BX == 128 ? 2 * (k & 3) + 8 * ((k >> 3) & 1) : 2 * ((k >> 1) & 1) + 4 * ((k >> 3) & 1);
+}
+
+// fragment of a k-fast image: rows r0 + (lane & 15), k = 32 kc + 8 (lane >> 4) .. + 7
+__device__ __forceinline__ bf16x8 ring_frag_kf(const unsigned char* img, int r0, int kc, int lane) {
+  const int row = r0 + (lane & 15), c = kc * 4 + (lane >> 4);
+  bf16x8 f;
+  memcpy(&f, img + (row * 8 + (c ^ kf_key(row))) * 16, 16);
+  return f;
+}
+// fragment of a row-fast image [64][BX]: same element set, gathered by two transposing reads
+template <int BX>
+__device__ __forceinline__ bf16x8 ring_frag_rf(const unsigned char* img, int r0, int kc, int lane) {
+  constexpr int CH = BX / 8;
+  const int g = lane >> 4, i = lane & 15;
+  bf16x8 f;
+#ifdef CENET_HOSTSIM_BUILD
+  const int x = r0 + i;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kc * 32 + 8 * g + j;
+    const unsigned short* p = (const unsigned short*)(img + (k * CH + ((x >> 3) ^ rf_key<BX>(k))) * 16) + (x & 7);
+    f[j] = (short)*p;
+  }
+#else
+  const int q = i >> 2, p = i & 3;
+  const int x = r0 + 4 * p;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = kc * 32 + 8 * g + 4 * h + q;
+    const unsigned char* a = img + (k * CH + ((x >> 3) ^ rf_key<BX>(k))) * 16 + (x & 7) * 2;
+    const ring_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ring_s4 __attribute__((address_space(3)))*)a);
+    f[4 * h + 0] = v[0], f[4 * h + 1] = v[1], f[4 * h + 2] = v[2], f[4 * h + 3] = v[3];
+  }
+#endif
+  return f;
+}
+
+// per-thread source description of one operand: NI = BX / 32 LDS-DMA instructions per thread and tile
+template <int NI>
+struct RingSrc {
+  const bf16_t* p[NI];  // source of this lane's chunk at k0 = 0 (row / chunk clamped into the operand)
+  int kofs[NI];         // k of the chunk's first element relative to the tile's k0
+};
+
+template <bool KF, int BX>
+__device__ __forceinline__ RingSrc<BX / 32> ring_src(const bf16_t* base, long ld, int x0, int X, int wave, int lane) {
+  constexpr int NI = BX / 32, CH = BX / 8;
+  RingSrc<NI> s;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int S = (j * 4 + wave) * 64 + lane;  // linear 16-byte slot of the image
+    if (KF) {
+      const int row = S >> 3, c = (S & 7) ^ kf_key(row);
+      int r = x0 + row;
+      r = r < X ? r : X - 1;
+      s.p[j] = base + (long)r * ld + 8 * c;
+      s.kofs[j] = 8 * c;
+    } else {
+      const int k = S / CH, c = (S % CH) ^ rf_key<BX>(k);
+      int x = x0 + 8 * c;
+      x = x < X ? x : x0;  // X % 8 == 0: a chunk is wholly inside or wholly outside
+      s.p[j] = base + (long)k * ld + x;
+      s.kofs[j] = k;
+    }
+  }
+  return s;
+}
+
+template <bool KF, int BX>
+__device__ __forceinline__ void ring_issue(const RingSrc<BX / 32>& s, long koff, int klim, bool tail, unsigned char* img, int wave,
+                                           int lane) {
+  constexpr int NI = BX / 32;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const void* src = s.p[j] + koff;
+    if (tail && s.kofs[j] >= klim) src = ring_zero16;
+    ring_glds16(src, img + (j * 4 + wave) * 1024, lane);
+  }
+}
+
+template <bool AKF, bool BKF, int BM, int BN, int NS, bool SWAP>
+__global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) void gemm_ring_kernel(GemmArgs g) {
+  constexpr int MI = BM / 32, NJ = BN / 32;
+  constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int G = (BM + BN) / 32;  // LDS-DMA instructions per thread and tile
+  static_assert(NS >= 2 && NS <= 4 && G * (NS - 2) <= 63, "ring depth");
+  static_assert(NS * STAGE >= 4 * 16 * (BN / 2 + 1) * 4, "the epilogue strip reuses the ring");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];  // ONE array: stages, then the epilogue strip
+
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef CENET_HOSTSIM_BUILD
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int wm = wave >> 1, wn = wave & 1;
+  int bx, by, bz;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int T = gx * gy * (int)gridDim.z;
+    int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if (T >= 64) {  // XCD-aware order (see gemm_kernel)
+      const int per = T >> 3, rem = T & 7, xcd = L & 7, idx = L >> 3;
+      L = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    }
+    bx = L % gx;
+    const int t = L / gx;
+    by = t % gy;
+    bz = t / gy;
+  }
+  const int batch = bz / g.splits, split = bz - batch * g.splits;
+  const int bo = batch / g.nb_inner, bi = batch - bo * g.nb_inner;
+  const int m0 = by * BM, n0 = bx * BN;
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ktiles = (g.K + 63) / 64;
+  const int total = g.nkb * ktiles;
+  const int chunk = (total + g.splits - 1) / g.splits;
+  const int it0 = split * chunk;
+  const int it1 = (it0 + chunk < total) ? it0 + chunk : total;
+  const int T = it1 - it0;
+
+  const bf16_t* baseA = (const bf16_t*)g.A.ptr + (long)bo * g.A.sb + (long)bi * g.A.sb2;
+  const bf16_t* baseB = (const bf16_t*)g.B.ptr + (long)bo * g.B.sb + (long)bi * g.B.sb2;
+  // A(m, k): KF -> m * sr + k ; RF -> k * sc + m.    B(k, n): KF -> n * sc + k ; RF -> k * sr + n.
+  const long lda = AKF ? g.A.sr : g.A.sc, ldb = BKF ? g.B.sc : g.B.sr;
+  const RingSrc<MI> sa = ring_src<AKF, BM>(baseA, lda, m0, g.M, wave, lane);
+  const RingSrc<NJ> sb = ring_src<BKF, BN>(baseB, ldb, n0, g.N, wave, lane);
+  const long kstepA = AKF ? 1 : lda, kstepB = BKF ? 1 : ldb;
+
+  auto issue = [&](int it, int buf) __attribute__((always_inline)) {
+    const int kb = it / ktiles;
+    const int k0 = (it - kb * ktiles) * 64;
+    const int klim = g.K - k0;
+    const bool tail = klim < 64;
+    unsigned char* img = lds + buf * STAGE;
+    ring_issue<AKF, BM>(sa, (long)kb * g.A.skb + (long)k0 * kstepA, klim, tail, img, wave, lane);
+    ring_issue<BKF, BN>(sb, (long)kb * g.B.skb + (long)k0 * kstepB, klim, tail, img + ABYTES, wave, lane);
+  };
+
+  // prologue: NS - 1 tiles in flight
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < T) issue(it0 + s, s);
+
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    // tile t has landed once at most min(NS - 2, T - 1 - t) younger tiles are still outstanding
+    const int young = T - 1 - t;
+    if (NS >= 4 && young >= 2) ring_wait_vm<G * 2 <= 63 ? G * 2 : 0>();
+    else if (NS >= 3 && young >= 1) ring_wait_vm<G>();
+    else ring_wait_vm<0>();
+    ring_barrier();  // every wave's part of tile t is in LDS; every wave is done reading the buffer refilled below
+    if (t + NS - 1 < T) issue(it0 + t + NS - 1, cur == 0 ? NS - 1 : cur - 1);
+    const unsigned char* Ai = lds + cur * STAGE;
+    const unsigned char* Bi = Ai + ABYTES;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      bf16x8 a[MI], b[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        a[i] = AKF ? ring_frag_kf(Ai, wm * (BM / 2) + i * 16, kc, lane) : ring_frag_rf<BM>(Ai, wm * (BM / 2) + i * 16, kc, lane);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        b[j] = BKF ? ring_frag_kf(Bi, wn * (BN / 2) + j * 16, kc, lane) : ring_frag_rf<BN>(Bi, wn * (BN / 2) + j * 16, kc, lane);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  __syncthreads();  // the ring is free: the atomic epilogue uses it as its transpose strip
+  gemm_epilogue<bf16_t, BM, BN, SWAP>(g, acc, (float*)lds, m0, n0, bo, bi, batch, wave, lane);
+}
+
+template <bool AKF, bool BKF, bool SWAP>
+static int launch_ring(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_t stream) {
+  dim3 grid(cdiv(g.N, bn), cdiv(g.M, bm), nbatch * g.splits);
+  if (grid.y > 65535 || grid.z > 65535) return CENET_EUNSUPPORTED;
+  if (bm == 128 && bn == 128) {
+    CENET_LAUNCH((gemm_ring_kernel<AKF, BKF, 128, 128, 2, SWAP>), grid, dim3(256), stream, g);
+    return CENET_OK;
+  }
+  if (bm == 64 && bn == 64) {
+    CENET_LAUNCH((gemm_ring_kernel<AKF, BKF, 64, 64, 4, SWAP>), grid, dim3(256), stream, g);
+    return CENET_OK;
+  }
+  return CENET_EUNSUPPORTED;
+}
+#define CENET_RING_INSTANCE(NAME, AKF, BKF)                                                       \
+  int NAME(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream) {        \
+    return swap ? launch_ring<AKF, BKF, true>(g, bm, bn, nbatch, stream)                          \
+                : launch_ring<AKF, BKF, false>(g, bm, bn, nbatch, stream);                        \
+  }
+int cenet_gemm_launch_ring_kk(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
+int cenet_gemm_launch_ring_kr(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
+int cenet_gemm_launch_ring_rk(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);
+int cenet_gemm_launch_ring_rr(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream);

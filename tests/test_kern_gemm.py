@@ -128,3 +128,46 @@ def test_gemm_tiles_fp32_and_bf16(dev, M, N, K):
     torch.testing.assert_close(acc.cpu(), F.linear(xb.float(), wb.float()).cpu(), rtol=1e-3, atol=1e-3)
     with pytest.raises(TypeError):  # mixed operand types are refused
         kern.gemm(kern.mat_plain(xb, K, 1, kfast=1), kern.mat_plain(w, 1, K, kfast=1), yb, M, N, K, scr=N, scc=1)
+
+
+# LDS-DMA ring kernel (gemm_ring.h): taken for bf16 operands whose contiguous axis is 16-byte aligned (extents % 8 == 0)
+# and M, N >= 48.  All four operand orientations; ragged tiles in M and N; K tails (K % 64 != 0), single K-step and chains
+# longer than the ring; row-major bf16 store with bias / residual / per-row sample scale, and the fp32 atomic split-K form.
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 152, 72), (136, 264, 320), (56, 48, 8), (264, 136, 456)])
+@pytest.mark.parametrize("akf,bkf", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_ring_orientations(dev, M, N, K, akf, bkf):
+    x, w, b = rnd(M, K, dev=dev).bfloat16(), rnd(N, K, dev=dev, seed=1).bfloat16(), rnd(N, dev=dev, seed=2)
+    R = rnd(M, N, dev=dev, seed=3).bfloat16()
+    xt = x.t().contiguous()
+    wt = w.t().contiguous()
+    A = kern.mat_plain(x, K, 1, kfast=1) if akf else kern.mat_plain(xt, 1, M, kfast=0)
+    Bm = kern.mat_plain(w, 1, K, kfast=1) if bkf else kern.mat_plain(wt, N, 1, kfast=0)
+    ref = F.linear(x.float(), w.float(), b) + R.float()
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    kern.gemm(A, Bm, y, M, N, K, scr=N, scc=1, bias=b, R=R, srr=N, src=1)
+    torch.testing.assert_close(y.float().cpu(), ref.cpu(), rtol=1e-2, atol=2e-2)
+    # transposed store (column-major C: the un-swapped accumulator layout), bias along rows
+    yt = torch.empty(N, M, device=dev, dtype=torch.bfloat16)
+    kern.gemm(A, Bm, yt, M, N, K, scr=1, scc=M)
+    torch.testing.assert_close(yt.float().cpu(), F.linear(x.float(), w.float()).t().cpu(), rtol=1e-2, atol=2e-2)
+    acc = torch.zeros(M, N, device=dev)
+    kern.gemm(A, Bm, acc, M, N, K, scr=N, scc=1, splits=3, atomic=True)
+    torch.testing.assert_close(acc.cpu(), F.linear(x.float(), w.float()).cpu(), rtol=1e-3, atol=1e-3)
+
+
+def test_gemm_ring_batched_kbatch(dev):
+    """per-image batches (grid z) with a per-sample scale, and the K-batch walk of the flat weight gradient"""
+    Bt, Co, Ci, HW = 3, 64, 72, 80
+    w = rnd(Co, Ci, dev=dev).bfloat16()
+    x = rnd(Bt, Ci, HW, dev=dev, seed=1).bfloat16()
+    bs = rnd(Bt, dev=dev, seed=2)
+    y = torch.empty(Bt, Co, HW, device=dev, dtype=torch.bfloat16)
+    kern.gemm(kern.mat_plain(w, Ci, 1, kfast=1), kern.mat_plain(x, HW, 1, sb=Ci * HW), y, Co, HW, Ci, scr=HW, scc=1,
+              scb=Co * HW, nbatch=Bt, bscale=bs)
+    ref = torch.matmul(w.float(), x.float()) * bs[:, None, None]
+    torch.testing.assert_close(y.float().cpu(), ref.cpu(), rtol=1e-2, atol=2e-2)
+    dy = rnd(Bt, Co, HW, dev=dev, seed=3).bfloat16()
+    dw = torch.zeros(Co, Ci, device=dev)
+    kern.gemm(kern.mat_plain(dy, HW, 1, skb=Co * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Ci * HW, kfast=1), dw,
+              Co, Ci, HW, scr=Ci, scc=1, nkb=Bt, splits=2, atomic=True)
+    torch.testing.assert_close(dw.cpu(), torch.einsum("bop,bip->oi", dy.float(), x.float()).cpu(), rtol=1e-3, atol=1e-3)
