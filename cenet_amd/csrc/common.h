@@ -43,6 +43,39 @@ __device__ __forceinline__ cenet_bid cenet_xcd_block() {
   return b;
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4) helpers shared by gemm_ring.h and the tiled depthwise kernels -------------------------
+#ifdef CENET_HOSTSIM_BUILD
+static const unsigned ring_zero16[4] = {0, 0, 0, 0};
+#else
+__device__ __attribute__((aligned(16))) const unsigned ring_zero16[4] = {0, 0, 0, 0};
+#endif
+
+// one 16-byte LDS-DMA: lane L of the wave writes wave_base + 16 L
+__device__ __forceinline__ void ring_glds16(const void* gsrc, unsigned char* wave_base, int lane) {
+#ifdef CENET_HOSTSIM_BUILD
+  memcpy(wave_base + 16 * lane, gsrc, 16);
+#else
+  (void)lane;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned*)gsrc,
+                                   (__attribute__((address_space(3))) unsigned*)wave_base, 16, 0, 0);
+#endif
+}
+
+template <int N>
+__device__ __forceinline__ void ring_wait_vm() {
+#ifndef CENET_HOSTSIM_BUILD
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void ring_barrier() {
+#ifdef CENET_HOSTSIM_BUILD
+  __syncthreads();
+#else
+  asm volatile("s_barrier" ::: "memory");
+#endif
+}
+
+
 // fp32 -> bf16, round to nearest even.  gfx950 converts two floats per instruction (v_cvt_pk_bf16_f32); the host-side
 // checker build uses the equivalent integer rounding.
 #ifdef CENET_HOSTSIM_BUILD

@@ -407,10 +407,258 @@ CENET_TWIN(dwconv3x3_nchw, (const T* x, long sxb, const float* w, const float* b
                             int H, int W, int dil, int flip, int act, float slope, hipStream_t stream),
            (x, sxb, w, bias, y, syb, a, sab, B, C, H, W, dil, flip, act, slope, stream))
 
+// ---- bf16 token layout, LDS-tiled (C % 8 == 0) ----------------------------------------------------------------------------
+// The sliding-window kernels above keep one or two 4-byte loads per lane in flight and reach 1 - 2 TB/s on the 100 MB
+// tensors of stage 1 (the tensor is only ~6x the bandwidth-delay product of the chip, so bytes in flight decide).  Here a
+// workgroup owns a (TH x TW)-pixel tile of a 128-channel slab: the (TH+2) x (TW+2) halo tile goes HBM -> LDS with
+// global_load_lds_dwordx4 (40 KB in flight per workgroup, no staging registers, out-of-image pixels read a zero block),
+// then thread = (8 channels, one of 16 pixel slots) reads its nine taps with ds_read_b128.
+//   MODE 0: out2 = act(conv(x) + bias), out = conv(x) + bias (either may be NULL); FLIP = data gradient (taps mirrored)
+//   MODE 2: backward of act(conv(x) + bias) given g = dL/d(act): recomputes u = conv(x) + bias from the x tile (u is not
+//           stored by the forward pass), writes gu = g * act'(u), and accumulates dw[c][t] += gu * x[tap t], db[c] += gu
+//           in registers over the workgroup's tiles; one LDS reduction and one set of float atomics per workgroup.
+#ifdef CENET_HOSTSIM_BUILD
+typedef unsigned dw_u4 __attribute__((vector_size(16)));
+#else
+typedef unsigned dw_u4 __attribute__((ext_vector_type(4)));
+#endif
+struct DwTileArgs {
+  const bf16_t* x;
+  const bf16_t* g;
+  const float* w;
+  const float* bias;
+  bf16_t* out;
+  bf16_t* out2;
+  float* dw;
+  float* db;
+  int C, H, W, flip, act, tiles_x, ntiles, tpw;
+  float slope;
+};
+
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): the tile kernels are VALU-bound, and libm's
+// erff + expf cost more than the nine taps.  Only the bf16 kernels use it; the fp32 (parity) kernels keep erff.
+__device__ __forceinline__ float dw_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = 1.f / (1.f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.f - poly * fast_exp(-ax * ax);
+  return copysignf(r, x);
+}
+template <int ACT>
+__device__ __forceinline__ float dw_act(float u, int act, float slope) {
+  if (ACT == ACT_NONE) return u;
+  if (ACT == ACT_GELU) return 0.5f * u * (1.f + dw_erf(u * 0.70710678118654752f));
+  return act_fwd(act, u, slope);
+}
+template <int ACT>
+__device__ __forceinline__ float dw_act_grad(float u, int act, float slope) {
+  if (ACT == ACT_NONE) return 1.f;
+  if (ACT == ACT_GELU)
+    return 0.5f * (1.f + dw_erf(u * 0.70710678118654752f)) + u * 0.3989422804014327f * fast_exp(-0.5f * u * u);
+  return act_bwd(act, u, slope);
+}
+
+// ACT: ACT_NONE / ACT_GELU compiled in, -1 = the runtime switch of common.h
+template <int TH, int TW, int MODE, int ACT>
+__global__ __launch_bounds__(256, 2) void dw3x3_tok_tile_kernel(DwTileArgs a) {
+  constexpr int PW = TW + 2, PT = (TH + 2) * PW, NI = (PT + 3) / 4;  // halo tile: pixels, LDS-DMA instructions (4 pixels each)
+  constexpr int NOUT = TH * TW, NPASS = (NOUT + 15) / 16;
+  constexpr int RED = MODE == 2 ? 4 * 16 * 80 * 4 : 0;
+  constexpr int LDSB = NI * 1024 > RED ? NI * 1024 : RED;
+  constexpr bool FLIP = MODE == 1;  // data gradient: tap (ky, kx) reads the mirrored neighbour
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDSB];
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef CENET_HOSTSIM_BUILD
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const cenet_bid bid = cenet_xcd_block();
+  const int grp = tid & 15, slot = tid >> 4;
+  const int c0 = bid.x * 128, c = c0 + grp * 8;
+  const bool cok = c < a.C;
+  const long img = (long)bid.z * a.H * a.W * a.C;
+  float wt[72], bv[8];  // wt[e * 9 + t]: 72 consecutive floats of the weight tensor, 16-byte aligned (c % 8 == 0)
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const f4 v = cok ? ld4(a.w + (long)c * 9 + 4 * i) : f4{{0.f, 0.f, 0.f, 0.f}};
+    wt[4 * i] = v.v[0], wt[4 * i + 1] = v.v[1], wt[4 * i + 2] = v.v[2], wt[4 * i + 3] = v.v[3];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f4 v = (cok && MODE != 1 && a.bias) ? ld4(a.bias + c + 4 * i) : f4{{0.f, 0.f, 0.f, 0.f}};
+    bv[4 * i] = v.v[0], bv[4 * i + 1] = v.v[1], bv[4 * i + 2] = v.v[2], bv[4 * i + 3] = v.v[3];
+  }
+  float acc[MODE == 2 ? 8 : 1][10];
+  if (MODE == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int t = 0; t < 10; ++t) acc[e][t] = 0.f;
+  }
+  const int t_begin = bid.y * a.tpw;
+  const int t_end = t_begin + a.tpw < a.ntiles ? t_begin + a.tpw : a.ntiles;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * TW;
+    if (tile != t_begin) __syncthreads();  // every thread is done reading the previous tile
+    for (int i = wave; i < NI; i += 4) {
+      const int pix = 4 * i + (lane >> 4);
+      const int ty = pix / PW, tx = pix - ty * PW;
+      const int iy = y0 - 1 + ty, ix = x0 - 1 + tx;
+      const int cc = c0 + (lane & 15) * 8;
+      const bool ok = pix < PT && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && cc < a.C;
+      const void* src = ok ? (const void*)(a.x + img + ((long)iy * a.W + ix) * a.C + cc) : (const void*)ring_zero16;
+      ring_glds16(src, lds + i * 1024, lane);
+    }
+    ring_wait_vm<0>();
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < NPASS; ++p) {
+      const int o = p * 16 + slot;
+      const int oy = o / TW, ox = o - oy * TW;
+      const bool ok = cok && o < NOUT && y0 + oy < a.H && x0 + ox < a.W;
+      if (!ok) continue;
+      const unsigned char* tp = lds + ((oy * PW + ox) * 16 + grp) * 16;
+      float u[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u[e] = bv[e];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const dw_u4 r = *(const dw_u4*)(tp + (FLIP ? ((2 - ky) * PW + 2 - kx) : (ky * PW + kx)) * 256);
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            u[2 * h] += wt[(2 * h) * 9 + ky * 3 + kx] * cenet_bf2f(r[h] & 0xFFFFu);
+            u[2 * h + 1] += wt[(2 * h + 1) * 9 + ky * 3 + kx] * cenet_bf2f(r[h] >> 16);
+          }
+        }
+      const long oo = img + ((long)(y0 + oy) * a.W + x0 + ox) * a.C + c;
+      if (MODE != 2) {
+        unsigned q[4];
+        if (a.out) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) q[h] = cenet_pack_bf2(u[2 * h], u[2 * h + 1]);
+          memcpy(a.out + oo, q, 16);
+        }
+        if (MODE == 0 && a.out2) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+            q[h] = cenet_pack_bf2(dw_act<ACT>(u[2 * h], a.act, a.slope), dw_act<ACT>(u[2 * h + 1], a.act, a.slope));
+          memcpy(a.out2 + oo, q, 16);
+        }
+      } else {
+        const dw_u4 gq = *(const dw_u4*)(a.g + oo);
+        unsigned q[4];
+        float gu[8];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          gu[2 * h] = cenet_bf2f(gq[h] & 0xFFFFu) * dw_act_grad<ACT>(u[2 * h], a.act, a.slope);
+          gu[2 * h + 1] = cenet_bf2f(gq[h] >> 16) * dw_act_grad<ACT>(u[2 * h + 1], a.act, a.slope);
+          q[h] = cenet_pack_bf2(gu[2 * h], gu[2 * h + 1]);
+        }
+        memcpy(a.out + oo, q, 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e][9] += gu[e];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const dw_u4 r = *(const dw_u4*)(tp + (ky * PW + kx) * 256);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+              acc[2 * h][ky * 3 + kx] += gu[2 * h] * cenet_bf2f(r[h] & 0xFFFFu);
+              acc[2 * h + 1][ky * 3 + kx] += gu[2 * h + 1] * cenet_bf2f(r[h] >> 16);
+            }
+          }
+      }
+    }
+  }
+  if (MODE == 2) {
+    // lanes l, l+16, l+32, l+48 of a wave hold the same channels: fold them, then the four waves meet in LDS
+    float* red = (float*)lds;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int t = 0; t < 10; ++t) {
+        float v = acc[e][t];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        acc[e][t] = v;
+      }
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) red[(wave * 16 + lane) * 80 + e * 10 + t] = acc[e][t];
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * 80; i += 256) {
+      const int gi = i / 80, r = i - gi * 80, e = r / 10, t = r - e * 10;
+      const int ch = c0 + gi * 8 + e;
+      if (ch < a.C) {
+        const float sm = red[i] + red[16 * 80 + i] + red[2 * 16 * 80 + i] + red[3 * 16 * 80 + i];
+        if (t < 9) atomicAdd(&a.dw[ch * 9 + t], sm);
+        else if (a.db) atomicAdd(&a.db[ch], sm);
+      }
+    }
+  }
+}
+
+template <int MODE>
+static int dw_tile_launch(DwTileArgs a, int B, hipStream_t stream) {
+  const int slabs = cdiv(a.C, 128);
+  // tile shape by map size; tiles per workgroup: 1 (forward / data gradient), up to 4 for the weight gradient (fewer atomics)
+#define DW_TILE_GO(TH_, TW_)                                                                                     \
+  {                                                                                                              \
+    a.tiles_x = cdiv(a.W, TW_);                                                                                  \
+    a.ntiles = a.tiles_x * cdiv(a.H, TH_);                                                                       \
+    a.tpw = 1;                                                                                                   \
+    if (MODE == 2) a.tpw = a.ntiles >= 16 ? 4 : (a.ntiles >= 4 ? 2 : 1);                                         \
+    const dim3 grid(slabs, cdiv(a.ntiles, a.tpw), B);                                                            \
+    if (grid.y > 65535 || grid.z > 65535) return CENET_EUNSUPPORTED;                                             \
+    if (MODE == 1 || a.act == ACT_NONE)                                                                          \
+      CENET_LAUNCH((dw3x3_tok_tile_kernel<TH_, TW_, MODE, ACT_NONE>), grid, dim3(256), stream, a);               \
+    else if (a.act == ACT_GELU)                                                                                  \
+      CENET_LAUNCH((dw3x3_tok_tile_kernel<TH_, TW_, MODE, ACT_GELU>), grid, dim3(256), stream, a);               \
+    else                                                                                                         \
+      CENET_LAUNCH((dw3x3_tok_tile_kernel<TH_, TW_, MODE, -1>), grid, dim3(256), stream, a);                     \
+  }
+  if (a.W % 14 == 0) DW_TILE_GO(8, 14)
+  else if (a.W <= 8 && a.H <= 8) DW_TILE_GO(8, 8)
+  else DW_TILE_GO(8, 16)
+#undef DW_TILE_GO
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+// backward of act(DW3x3(x) + bias) from the saved INPUT: gu = g * act'(conv(x) + bias), dw += gu (*) x, db += sum gu
+extern "C" int cenet_dwconv3x3_tok_bwd_pre_bf16(const bf16_t* x, const bf16_t* g, const float* w, const float* bias, bf16_t* gu,
+                                                float* dw_acc, float* dbias_acc, int B, int C, int H, int W, int act, float slope,
+                                                hipStream_t stream) {
+  if (!x || !g || !w || !gu || !dw_acc || B <= 0 || C <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+  if ((C & 7) != 0 || ((((uintptr_t)x | (uintptr_t)g | (uintptr_t)gu) & 15) != 0)) return CENET_EUNSUPPORTED;
+  DwTileArgs a;
+  a.x = x; a.g = g; a.w = w; a.bias = bias; a.out = gu; a.out2 = nullptr; a.dw = dw_acc; a.db = dbias_acc;
+  a.C = C; a.H = H; a.W = W; a.flip = 0; a.act = act; a.slope = slope;
+  return dw_tile_launch<2>(a, B, stream);
+}
+
 template <typename T>
 static int dwconv3x3_tok_impl(const T* x, const float* w, const float* bias, T* y, T* a, int B, int C, int H, int W, int flip,
                               int act, float slope, hipStream_t stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (!y && !a)) return CENET_EINVAL;
+  if (sizeof(T) == 2 && (C & 7) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)a) & 15) == 0)) {
+    DwTileArgs t;
+    t.x = (const bf16_t*)x; t.g = nullptr; t.w = w; t.bias = bias; t.out = (bf16_t*)y; t.out2 = (bf16_t*)a; t.dw = t.db = nullptr;
+    t.C = C; t.H = H; t.W = W; t.flip = flip; t.act = act; t.slope = slope;
+    if (flip) {
+      if (bias || a) return CENET_EUNSUPPORTED;  // the mirrored form is the data gradient: no bias, no activation
+      return dw_tile_launch<1>(t, B, stream);
+    }
+    return dw_tile_launch<0>(t, B, stream);
+  }
   const int sr = H >= 28 ? 4 : 2;
   const int strips = ((H + sr - 1) / sr) * ((W + DW_SW - 1) / DW_SW);
   if (strips > 65535 || B > 65535) return CENET_EUNSUPPORTED;

@@ -19,38 +19,7 @@
 #pragma once
 #include "gemm_core.h"
 
-#ifdef CENET_HOSTSIM_BUILD
-static const unsigned ring_zero16[4] = {0, 0, 0, 0};
-#else
-__device__ __attribute__((aligned(16))) const unsigned ring_zero16[4] = {0, 0, 0, 0};
-#endif
-
 typedef short ring_s4 __attribute__((ext_vector_type(4)));
-
-// one 16-byte LDS-DMA: lane L of the wave writes wave_base + 16 L
-__device__ __forceinline__ void ring_glds16(const void* gsrc, unsigned char* wave_base, int lane) {
-#ifdef CENET_HOSTSIM_BUILD
-  memcpy(wave_base + 16 * lane, gsrc, 16);
-#else
-  (void)lane;
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned*)gsrc,
-                                   (__attribute__((address_space(3))) unsigned*)wave_base, 16, 0, 0);
-#endif
-}
-
-template <int N>
-__device__ __forceinline__ void ring_wait_vm() {
-#ifndef CENET_HOSTSIM_BUILD
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
-}
-__device__ __forceinline__ void ring_barrier() {
-#ifdef CENET_HOSTSIM_BUILD
-  __syncthreads();
-#else
-  asm volatile("s_barrier" ::: "memory");
-#endif
-}
 
 // swizzle keys
 __device__ __forceinline__ int kf_key(int row) { return (row >> 1) & 7; }

@@ -162,7 +162,7 @@ def _call(name, *args):
             cargs.append(C.c_long(a) if abs(a) > 0x7FFFFFFF else C.c_int(a))
         else:
             cargs.append(a)
-    if bf:
+    if bf and not name.endswith("_bf16"):  # (entries that exist for bf16 tensors only are named so by the caller)
         assert name.endswith("_f32"), name
         name = name[:-4] + "_bf16"
     rc = getattr(_lib.lib(), name)(*cargs, stream())
@@ -271,6 +271,18 @@ def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none",
 def dw_tok(x, w, bias, y, a, B, Cn, H, W, flip, act="none", slope=0.0):
     _chk(x, w, bias, y, a)
     _call("cenet_dwconv3x3_tok_f32", x, w, bias, y, a, B, Cn, H, W, int(flip), ACT[act], float(slope))
+
+
+def dw_tok_bwd_pre(x, g, w, bias, gu, dw, dbias, B, Cn, H, W, act, slope=0.0):
+    """bf16 tokens: gu = g * act'(DW3x3(x) + bias), dw += gu (*) x, dbias += sum gu (pre-activation recomputed from x)."""
+    _chk(x, g, w, bias, gu, dw, dbias)
+    assert is_bf16(x) and is_bf16(g) and is_bf16(gu)
+    _call("cenet_dwconv3x3_tok_bwd_pre_bf16", x, g, w, bias, gu, dw, dbias, B, Cn, H, W, ACT[act], float(slope))
+
+
+def dw_tok_tiled(x):
+    """the LDS-tiled bf16 token-layout depthwise kernels apply (16-byte channel groups)"""
+    return is_bf16(x) and x.shape[-1] % 8 == 0 and x.data_ptr() % 16 == 0
 
 
 def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil):

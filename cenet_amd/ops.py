@@ -540,12 +540,16 @@ class DWConvTokFn(Function):
     def forward(ctx, x, w, b, H, Wd, act):
         x = _c(x)
         B, N, Cn = x.shape
-        u = torch.empty_like(x)
+        # bf16 tokens: the pre-activation is not stored; backward recomputes it from x inside the fused
+        # activation-gradient + weight-gradient kernel (dwconv.hip, MODE 2)
+        recompute = act != "none" and kern.dw_tok_tiled(x)
+        u = torch.empty_like(x) if not recompute else None
         a = torch.empty_like(x) if act != "none" else None
         kern.dw_tok(x, w, b, u, a, B, Cn, H, Wd, 0, act)
-        ctx.save_for_backward(x, w, u if act != "none" else None)
+        ctx.save_for_backward(x, w, u if (act != "none" and not recompute) else None)
         ctx.refs = (w, b)
         ctx.cfg = (H, Wd, act)
+        ctx.recompute = recompute
         return a if a is not None else u
 
     @staticmethod
@@ -555,15 +559,26 @@ class DWConvTokFn(Function):
         H, Wd, act = ctx.cfg
         g = _c(g)
         B, N, Cn = x.shape
+        dw, db = grad_buf(wp), grad_buf(bp)
+        if ctx.recompute and dw is not None and kern.dw_tok_tiled(g):
+            gu = torch.empty_like(g)
+            kern.dw_tok_bwd_pre(x, g, w, bp, gu, dw, db, B, Cn, H, Wd, act)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                kern.dw_tok(gu, w, None, dx, None, B, Cn, H, Wd, 1)
+            return dx, None, None, None, None, None
         gu = g
         if act != "none":
+            if u is None:  # (recompute path without a weight gradient to fuse into: rebuild the pre-activation)
+                u = torch.empty_like(x)
+                kern.dw_tok(x, w, bp, u, None, B, Cn, H, Wd, 0)
             gu = torch.empty_like(g)
             kern.act_bwd(u, g, gu, g.numel(), act)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             kern.dw_tok(gu, w, None, dx, None, B, Cn, H, Wd, 1)
-        dw, db = grad_buf(wp), grad_buf(bp)
         if dw is not None:
             with _wgrad_side(gu, x):
                 kern.dw_wgrad_tok(x, gu, dw, db, B, Cn, H, Wd)

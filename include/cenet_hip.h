@@ -318,6 +318,11 @@ int cenet_dwconv3x3_wgrad_nchw_acc_bf16(const unsigned short* x, long sxb, const
     dw_acc, float* dbias_acc, int B, int C, int H, int W, int dil, cenet_stream_t stream);
 int cenet_dwconv3x3_wgrad_tok_acc_bf16(const unsigned short* x, const unsigned short* dy, float* dw_acc, float* dbias_acc,
     int B, int C, int H, int W, cenet_stream_t stream);
+/* backward of act(DW3x3(x) + bias) on bf16 tokens from the saved INPUT (pvtv2.py:42-43,359-370; the pre-activation is not
+ * stored): gu = g * act'(conv(x) + bias), dw_acc += gu (*) x, dbias_acc += sum gu.  C % 8 == 0, 16-byte aligned tensors. */
+int cenet_dwconv3x3_tok_bwd_pre_bf16(const unsigned short* x, const unsigned short* g, const float* w, const float* bias,
+    unsigned short* gu, float* dw_acc, float* dbias_acc, int B, int C, int H, int W, int act, float slope,
+    cenet_stream_t stream);
 /* elementwise.hip */
 int cenet_transpose_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, int R, int Cc,
     cenet_stream_t stream);

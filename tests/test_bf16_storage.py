@@ -120,7 +120,11 @@ def test_batchnorm(dev, B, C, H, W, act):
     compare(fn, [x], [gm, bt], dev=dev, tol=3e-2)
 
 
-@pytest.mark.parametrize("B,C,H,W,act", [(2, 8, 6, 6, "gelu"), (1, 6, 30, 9, "none"), (1, 5, 5, 5, "gelu")])
+# C % 8 == 0 takes the LDS-tiled kernels (dwconv.hip): the three tile shapes (W % 14 == 0; maps up to 8x8; 8x16), ragged
+# tiles, two channel slabs with a partial one (C = 136), several tiles per workgroup in the fused backward (28x28)
+@pytest.mark.parametrize("B,C,H,W,act", [(2, 8, 6, 6, "gelu"), (1, 6, 30, 9, "none"), (1, 5, 5, 5, "gelu"),
+                                         (2, 16, 7, 7, "gelu"), (1, 136, 14, 14, "gelu"), (1, 8, 11, 19, "gelu"),
+                                         (1, 8, 28, 28, "gelu"), (1, 8, 9, 14, "none")])
 def test_dwconv_tok(dev, B, C, H, W, act):
     g = G(C + H)
     x = torch.randn(B, H * W, C, generator=g)

@@ -1,4 +1,6 @@
-"""Micro-benchmark of the token-layout depthwise 3x3 kernels at the PVT Mlp shapes (B=32)."""
+"""Times the token-layout depthwise 3x3 kernels of the PVTv2 Mlp (forward + GELU, activation backward, data gradient,
+weight gradient) at the four stage shapes of the ACDC preset, B = 32, bf16 tensors; prints time and effective HBM rate
+against the algorithmic bytes.  python tools/dw_bench.py"""
 import os
 import sys
 
@@ -10,8 +12,8 @@ from cenet_amd import kern
 dev = torch.device("cuda:0")
 
 
-def t(fn, reps=10):
-    for _ in range(2):
+def timeit(fn, reps=20):
+    for _ in range(3):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -20,18 +22,25 @@ def t(fn, reps=10):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / reps * 1e3
 
 
 B = 32
-for H, C in [(56, 512), (28, 1024), (14, 1280), (7, 2048)]:
-    x = torch.randn(B, H * H, C, device=dev)
-    w, b = torch.randn(C, 9, device=dev), torch.randn(C, device=dev)
-    y, a = torch.empty_like(x), torch.empty_like(x)
-    dw, db = torch.zeros(C, 9, device=dev), torch.zeros(C, device=dev)
-    mb = x.numel() * 4 / 1e6
-    tf = t(lambda: kern.dw_tok(x, w, b, y, a, B, C, H, H, False, act="gelu"))
-    td = t(lambda: kern.dw_tok(x, w, None, y, None, B, C, H, H, True))
-    tw = t(lambda: kern.dw_wgrad_tok(x, y, dw, db, B, C, H, H))
-    print(f"H={H} C={C} ({mb:.0f} MB/tensor): fwd {tf*1e3:.0f} us ({3*mb/tf/1e3:.2f} TB/s)  dgrad {td*1e3:.0f} us ({2*mb/td/1e3:.2f} TB/s)"
-          f"  wgrad {tw*1e3:.0f} us ({2*mb/tw/1e3:.2f} TB/s)")
+for H, C in ((56, 512), (28, 1024), (14, 1280), (7, 2048)):
+    n = B * H * H * C
+    x = torch.randn(B, H * H, C, device=dev).bfloat16()
+    g = torch.randn_like(x)
+    w = torch.randn(C, 1, 3, 3, device=dev) * 0.2
+    b = torch.randn(C, device=dev) * 0.1
+    u, a, gu, dx = (torch.empty_like(x) for _ in range(4))
+    dw, db = torch.zeros_like(w), torch.zeros_like(b)
+    mb = n * 2 / 1e6
+    rows = [("fwd+gelu (x -> a)", 2 * mb, lambda: kern.dw_tok(x, w, b, None, a, B, C, H, H, 0, "gelu")),
+            ("bwd_pre (x, g -> gu, dw)", 3 * mb, lambda: kern.dw_tok_bwd_pre(x, g, w, b, gu, dw, db, B, C, H, H, "gelu")),
+            ("fwd+gelu (x -> u, a)", 3 * mb, lambda: kern.dw_tok(x, w, b, u, a, B, C, H, H, 0, "gelu")),
+            ("act_bwd (u, g -> gu)", 3 * mb, lambda: kern.act_bwd(u, g, gu, n, "gelu")),
+            ("dgrad (gu -> dx)", 2 * mb, lambda: kern.dw_tok(gu, w, None, dx, None, B, C, H, H, 1)),
+            ("wgrad (x, gu -> dw, db)", 2 * mb, lambda: kern.dw_wgrad_tok(x, gu, dw, db, B, C, H, H))]
+    for name, mbytes, fn in rows:
+        t = timeit(fn)
+        print(f"{H:3d}x{H:<3d} C={C:5d} {name:26s} {t:8.1f} us  {mbytes / t:7.2f} TB/s  (ideal {mbytes / 8.0:6.1f} us)", flush=True)
