@@ -419,8 +419,10 @@ CENET_TWIN(dwconv3x3_nchw, (const T* x, long sxb, const float* w, const float* b
 //           in registers over the workgroup's tiles; one LDS reduction and one set of float atomics per workgroup.
 #ifdef CENET_HOSTSIM_BUILD
 typedef unsigned dw_u4 __attribute__((vector_size(16)));
+typedef unsigned dw_u2 __attribute__((vector_size(8)));
 #else
 typedef unsigned dw_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned dw_u2 __attribute__((ext_vector_type(2)));
 #endif
 struct DwTileArgs {
   const bf16_t* x;
@@ -458,14 +460,48 @@ __device__ __forceinline__ float dw_act_grad(float u, int act, float slope) {
   return act_bwd(act, u, slope);
 }
 
-// ACT: ACT_NONE / ACT_GELU compiled in, -1 = the runtime switch of common.h
+// 16 (CPT = 8) or 8 (CPT = 4) bytes of one pixel's channels from LDS / HBM, as packed bf16 pairs
+template <int CPT>
+struct DwPk {
+  unsigned u[CPT / 2];
+};
+template <int CPT>
+__device__ __forceinline__ DwPk<CPT> dw_ld(const void* p) {
+  DwPk<CPT> r;
+  if (CPT == 8) {
+    const dw_u4 v = *(const dw_u4*)p;
+    r.u[0] = v[0], r.u[1] = v[1], r.u[CPT / 2 - 2] = v[2], r.u[CPT / 2 - 1] = v[3];
+  } else {
+    const dw_u2 v = *(const dw_u2*)p;
+    r.u[0] = v[0], r.u[1] = v[1];
+  }
+  return r;
+}
+template <int CPT>
+__device__ __forceinline__ void dw_st(void* p, const unsigned* q) {
+  if (CPT == 8) {
+    dw_u4 v;
+    v[0] = q[0], v[1] = q[1], v[2] = q[CPT / 2 - 2], v[3] = q[CPT / 2 - 1];
+    *(dw_u4*)p = v;
+  } else {
+    dw_u2 v;
+    v[0] = q[0], v[1] = q[1];
+    *(dw_u2*)p = v;
+  }
+}
+
+// ACT: ACT_NONE / ACT_GELU compiled in, -1 = the runtime switch of common.h.  CPT channels per thread: 8 (16-byte accesses)
+// for the forward / data-gradient modes; 4 for MODE 2, whose 10 accumulators per channel would not fit beside the weights
 template <int TH, int TW, int MODE, int ACT>
-__global__ __launch_bounds__(256, 2) void dw3x3_tok_tile_kernel(DwTileArgs a) {
+__global__ __launch_bounds__(256, 3) void dw3x3_tok_tile_kernel(DwTileArgs a) {
+  constexpr int CPT = MODE == 2 ? 4 : 8, NG = 128 / CPT, SLOTS = 256 / NG, GPW = 64 / NG < 1 ? 1 : 64 / NG;
   constexpr int PW = TW + 2, PT = (TH + 2) * PW, NI = (PT + 3) / 4;  // halo tile: pixels, LDS-DMA instructions (4 pixels each)
-  constexpr int NOUT = TH * TW, NPASS = (NOUT + 15) / 16;
-  constexpr int RED = MODE == 2 ? 4 * 16 * 80 * 4 : 0;
+  constexpr int NOUT = TH * TW, NPASS = (NOUT + SLOTS - 1) / SLOTS;
+  constexpr int NACC = CPT * 10;
+  constexpr int RED = MODE == 2 ? 4 * NG * NACC * 4 : 0;
   constexpr int LDSB = NI * 1024 > RED ? NI * 1024 : RED;
   constexpr bool FLIP = MODE == 1;  // data gradient: tap (ky, kx) reads the mirrored neighbour
+  static_assert(GPW == 4 || GPW == 2, "pixel slots per wave");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDSB];
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef CENET_HOSTSIM_BUILD
@@ -474,25 +510,25 @@ __global__ __launch_bounds__(256, 2) void dw3x3_tok_tile_kernel(DwTileArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
   const cenet_bid bid = cenet_xcd_block();
-  const int grp = tid & 15, slot = tid >> 4;
-  const int c0 = bid.x * 128, c = c0 + grp * 8;
+  const int grp = tid % NG, slot = tid / NG;
+  const int c0 = bid.x * 128, c = c0 + grp * CPT;
   const bool cok = c < a.C;
   const long img = (long)bid.z * a.H * a.W * a.C;
-  float wt[72], bv[8];  // wt[e * 9 + t]: 72 consecutive floats of the weight tensor, 16-byte aligned (c % 8 == 0)
+  float wt[CPT * 9], bv[CPT];  // wt[e * 9 + t]: consecutive floats of the weight tensor, 16-byte aligned (c % 4 == 0)
 #pragma unroll
-  for (int i = 0; i < 18; ++i) {
+  for (int i = 0; i < CPT * 9 / 4; ++i) {
     const f4 v = cok ? ld4(a.w + (long)c * 9 + 4 * i) : f4{{0.f, 0.f, 0.f, 0.f}};
     wt[4 * i] = v.v[0], wt[4 * i + 1] = v.v[1], wt[4 * i + 2] = v.v[2], wt[4 * i + 3] = v.v[3];
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < CPT / 4; ++i) {
     const f4 v = (cok && MODE != 1 && a.bias) ? ld4(a.bias + c + 4 * i) : f4{{0.f, 0.f, 0.f, 0.f}};
     bv[4 * i] = v.v[0], bv[4 * i + 1] = v.v[1], bv[4 * i + 2] = v.v[2], bv[4 * i + 3] = v.v[3];
   }
-  float acc[MODE == 2 ? 8 : 1][10];
+  float acc[MODE == 2 ? CPT : 1][10];
   if (MODE == 2) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < CPT; ++e)
 #pragma unroll
       for (int t = 0; t < 10; ++t) acc[e][t] = 0.f;
   }
@@ -514,91 +550,91 @@ __global__ __launch_bounds__(256, 2) void dw3x3_tok_tile_kernel(DwTileArgs a) {
     __syncthreads();
 #pragma unroll 1
     for (int p = 0; p < NPASS; ++p) {
-      const int o = p * 16 + slot;
+      const int o = p * SLOTS + slot;
       const int oy = o / TW, ox = o - oy * TW;
       const bool ok = cok && o < NOUT && y0 + oy < a.H && x0 + ox < a.W;
       if (!ok) continue;
-      const unsigned char* tp = lds + ((oy * PW + ox) * 16 + grp) * 16;
-      float u[8];
+      const unsigned char* tp = lds + (oy * PW + ox) * 256 + grp * (2 * CPT);
+      float u[CPT];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) u[e] = bv[e];
+      for (int e = 0; e < CPT; ++e) u[e] = bv[e];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const dw_u4 r = *(const dw_u4*)(tp + (FLIP ? ((2 - ky) * PW + 2 - kx) : (ky * PW + kx)) * 256);
+          const DwPk<CPT> r = dw_ld<CPT>(tp + (FLIP ? ((2 - ky) * PW + 2 - kx) : (ky * PW + kx)) * 256);
 #pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            u[2 * h] += wt[(2 * h) * 9 + ky * 3 + kx] * cenet_bf2f(r[h] & 0xFFFFu);
-            u[2 * h + 1] += wt[(2 * h + 1) * 9 + ky * 3 + kx] * cenet_bf2f(r[h] >> 16);
+          for (int h = 0; h < CPT / 2; ++h) {
+            u[2 * h] += wt[(2 * h) * 9 + ky * 3 + kx] * cenet_bf2f(r.u[h] & 0xFFFFu);
+            u[2 * h + 1] += wt[(2 * h + 1) * 9 + ky * 3 + kx] * cenet_bf2f(r.u[h] >> 16);
           }
         }
       const long oo = img + ((long)(y0 + oy) * a.W + x0 + ox) * a.C + c;
       if (MODE != 2) {
-        unsigned q[4];
+        unsigned q[CPT / 2];
         if (a.out) {
 #pragma unroll
-          for (int h = 0; h < 4; ++h) q[h] = cenet_pack_bf2(u[2 * h], u[2 * h + 1]);
-          memcpy(a.out + oo, q, 16);
+          for (int h = 0; h < CPT / 2; ++h) q[h] = cenet_pack_bf2(u[2 * h], u[2 * h + 1]);
+          dw_st<CPT>(a.out + oo, q);
         }
         if (MODE == 0 && a.out2) {
 #pragma unroll
-          for (int h = 0; h < 4; ++h)
+          for (int h = 0; h < CPT / 2; ++h)
             q[h] = cenet_pack_bf2(dw_act<ACT>(u[2 * h], a.act, a.slope), dw_act<ACT>(u[2 * h + 1], a.act, a.slope));
-          memcpy(a.out2 + oo, q, 16);
+          dw_st<CPT>(a.out2 + oo, q);
         }
       } else {
-        const dw_u4 gq = *(const dw_u4*)(a.g + oo);
-        unsigned q[4];
-        float gu[8];
+        const DwPk<CPT> gq = dw_ld<CPT>(a.g + oo);
+        unsigned q[CPT / 2];
+        float gu[CPT];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          gu[2 * h] = cenet_bf2f(gq[h] & 0xFFFFu) * dw_act_grad<ACT>(u[2 * h], a.act, a.slope);
-          gu[2 * h + 1] = cenet_bf2f(gq[h] >> 16) * dw_act_grad<ACT>(u[2 * h + 1], a.act, a.slope);
+        for (int h = 0; h < CPT / 2; ++h) {
+          gu[2 * h] = cenet_bf2f(gq.u[h] & 0xFFFFu) * dw_act_grad<ACT>(u[2 * h], a.act, a.slope);
+          gu[2 * h + 1] = cenet_bf2f(gq.u[h] >> 16) * dw_act_grad<ACT>(u[2 * h + 1], a.act, a.slope);
           q[h] = cenet_pack_bf2(gu[2 * h], gu[2 * h + 1]);
         }
-        memcpy(a.out + oo, q, 16);
+        dw_st<CPT>(a.out + oo, q);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e][9] += gu[e];
+        for (int e = 0; e < CPT; ++e) acc[e][9] += gu[e];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
-            const dw_u4 r = *(const dw_u4*)(tp + (ky * PW + kx) * 256);
+            const DwPk<CPT> r = dw_ld<CPT>(tp + (ky * PW + kx) * 256);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
-              acc[2 * h][ky * 3 + kx] += gu[2 * h] * cenet_bf2f(r[h] & 0xFFFFu);
-              acc[2 * h + 1][ky * 3 + kx] += gu[2 * h + 1] * cenet_bf2f(r[h] >> 16);
+            for (int h = 0; h < CPT / 2; ++h) {
+              acc[2 * h][ky * 3 + kx] += gu[2 * h] * cenet_bf2f(r.u[h] & 0xFFFFu);
+              acc[2 * h + 1][ky * 3 + kx] += gu[2 * h + 1] * cenet_bf2f(r.u[h] >> 16);
             }
           }
       }
     }
   }
   if (MODE == 2) {
-    // lanes l, l+16, l+32, l+48 of a wave hold the same channels: fold them, then the four waves meet in LDS
+    // lanes that differ by a multiple of NG hold the same channels: fold them, then the four waves meet in LDS
     float* red = (float*)lds;
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < CPT; ++e)
 #pragma unroll
       for (int t = 0; t < 10; ++t) {
         float v = acc[e][t];
-        v += __shfl_xor(v, 16);
+        if (GPW == 4) v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
         acc[e][t] = v;
       }
-    if (lane < 16) {
+    if (lane < NG) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
+      for (int e = 0; e < CPT; ++e)
 #pragma unroll
-        for (int t = 0; t < 10; ++t) red[(wave * 16 + lane) * 80 + e * 10 + t] = acc[e][t];
+        for (int t = 0; t < 10; ++t) red[(wave * NG + lane) * NACC + e * 10 + t] = acc[e][t];
     }
     __syncthreads();
-    for (int i = tid; i < 16 * 80; i += 256) {
-      const int gi = i / 80, r = i - gi * 80, e = r / 10, t = r - e * 10;
-      const int ch = c0 + gi * 8 + e;
+    for (int i = tid; i < NG * NACC; i += 256) {
+      const int gi = i / NACC, r = i - gi * NACC, e = r / 10, t = r - e * 10;
+      const int ch = c0 + gi * CPT + e;
       if (ch < a.C) {
-        const float sm = red[i] + red[16 * 80 + i] + red[2 * 16 * 80 + i] + red[3 * 16 * 80 + i];
+        const float sm = red[i] + red[NG * NACC + i] + red[2 * NG * NACC + i] + red[3 * NG * NACC + i];
         if (t < 9) atomicAdd(&a.dw[ch * 9 + t], sm);
         else if (a.db) atomicAdd(&a.db[ch], sm);
       }
