@@ -1,12 +1,25 @@
 """bench.py — training throughput of the CENet hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--config acdc|synapse|ham512]
+                                                   (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" = the reference's train-step body (src/main_acdc.py:237-257) on one synthetic batch already resident in
 HBM: zero_grad -> CENet forward -> Dice+CE (0.5/0.5) -> backward -> gradient all-reduce (RCCL) -> fused SGD.
-Workload = BASELINE.json configs[1]: ACDC 224x224, 4 classes, batch 32 per GPU, random-init PVTv2-b2 CENet.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, timed live with
-HIP events on the launch stream) and `cpu_baseline` (the oracle timed on the host cores, rank 0, N == 1 only).
+Default workload = BASELINE.json configs[1]: ACDC 224x224, 4 classes, batch 32 per GPU, random-init
+PVTv2-b2 CENet.  --config synapse / ham512 run C4 / C5 of the same table.
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  After the timed region, rank 0 (N == 1) re-runs a few
+INSTRUMENTED steps and adds:
+  roofline         the kernel instance with the largest summed duration among the step's launches (every GEMM launch is
+                   bracketed with HIP events on the stream it is launched on and grouped by the instance name the C-ABI
+                   reports, spelled as rocprofv3 prints it; the attention kernels are bracketed per call): algorithmic
+                   bytes and FLOPs of all its launches in one step / their summed duration, against the binding roof.
+                   `traffic` comes from the PMC passes recorded in profiles/r02_traffic.json (null when that file has no
+                   entry for the kernel).
+  roofline_stages  every stage of SURVEY.md §8d (patch_embed1-4, block1-4, dec4..dec1, up3..up1, DSEB3..DSEB1, out.rb /
+                   out.up / out.out): forward + backward time measured with HIP events in module hooks (weight gradients on
+                   the main stream for this pass), against max(3 x fwd FLOPs / MFMA peak, 3 x boundary bytes / HBM peak).
+  cpu_baseline     the oracle timed on the host cores.
 """
 from __future__ import annotations
 
@@ -27,79 +40,63 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 mat
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (same guide)
 PEAK_HBM_GBS = 8000.0
 
+# SURVEY.md §8d C2 / C4 / C5 (the reference's flag presets: acdc.sh:41-77, synapse.sh:42-81, skin.sh:45-100)
+CONFIGS = {
+    "acdc": dict(name="ACDC 224x224 4-class", in_ch=1, classes=4, size=224, batch=32, heads=[4, 4, 4], scales=[1.0, 0.5]),
+    "synapse": dict(name="Synapse 224x224 9-class", in_ch=1, classes=9, size=224, batch=24, heads=[16, 8, 8],
+                    scales=[0.8, 0.4]),
+    "ham512": dict(name="HAM10000 512x512 2-class", in_ch=3, classes=2, size=512, batch=8, heads=[2, 2, 2],
+                   scales=[1.0, 0.75, 0.5]),
+}
+
+# SURVEY.md §8d per-stage algorithmic work per image at 224^2 (forward GFLOP; boundary elements in + out)
+STAGES = {
+    "backbone.patch_embed1": (0.059, 351232), "backbone.patch_embed2": (0.116, 301056),
+    "backbone.patch_embed3": (0.145, 163072), "backbone.patch_embed4": (0.145, 87808),
+    "backbone.block1": (1.671, 3 * 401408), "backbone.block2": (2.102, 4 * 200704),
+    "backbone.block3": (2.871, 6 * 125440), "backbone.block4": (0.945, 3 * 50176),
+    "decoder.dec4": (0.400, 50176), "decoder.up3": (0.066, 87808), "decoder.skip_enhancer3": (0.821, 188160),
+    "decoder.dec3": (0.669, 125440), "decoder.up2": (0.069, 163072), "decoder.skip_enhancer2": (1.092, 301056),
+    "decoder.dec2": (0.717, 200704), "decoder.up1": (0.059, 301056), "decoder.skip_enhancer1": (5.498, 602112),
+    "decoder.dec1": (2.929, 401408), "out.rb": (2.653, 451584), "out.up": (0.462, 602112), "out.out": (1.856, 852992),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU (BASELINE.json configs[1]: 32)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="acdc")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the preset's 32 / 24 / 8)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
-                    help="operand precision of the MFMA contractions (accumulation, softmax and norm statistics stay fp32)")
+                    help="storage type of activations and MFMA operands (accumulation, statistics, parameters stay fp32)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the step as one captured hipGraph (auto: fall back to eager launches if capture fails)")
+                    help="replay the step as one captured hipGraph (auto: N == 1 times a few steps both ways and keeps the faster)")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra fp32 parity-mode measurement (N=1, bf16 runs)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the weight-gradient kernels on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented passes (roofline, roofline_stages)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
 
 
-def make_model(dev):
+def make_model(dev, cfg=None):
     from cenet_amd.networks import CENet
+    cfg = cfg or CONFIGS["acdc"]
     torch.manual_seed(1234)
-    net = CENet(input_channels=1, num_classes=4, scale_factors=[1.0, 0.5], diffatt_num_heads=[4, 4, 4],
-                encoder="pvt_v2_b2", enc_pretrain=False, skip_mode="cat", dec_up_block="eucb", out_merge_mode="cat",
-                out_up_block="upcn", out_up_ks=3)
+    net = CENet(input_channels=cfg["in_ch"], num_classes=cfg["classes"], scale_factors=cfg["scales"],
+                diffatt_num_heads=cfg["heads"], encoder="pvt_v2_b2", enc_pretrain=False, skip_mode="cat", dec_up_block="eucb",
+                out_merge_mode="cat", out_up_block="upcn", out_up_ks=3)  # (the network is size-agnostic: 512^2 needs no flag)
     return net.to(dev).train()
 
 
-def synthetic(B, dev, seed):
+def synthetic(B, dev, seed, cfg=None):
+    cfg = cfg or CONFIGS["acdc"]
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, 1, 224, 224, generator=g)
-    lab = torch.randint(0, 4, (B, 224, 224), generator=g).float()
+    x = torch.randn(B, cfg["in_ch"], cfg["size"], cfg["size"], generator=g)
+    lab = torch.randint(0, cfg["classes"], (B, cfg["size"], cfg["size"]), generator=g).float()
     return x.to(dev), lab.to(dev)
-
-
-def dominant_kernel_probe(dev, B):
-    """Times the single heaviest launch of the step in isolation with HIP events on the launch stream:
-    gemm_f32_kernel<im2col> computing out.rb.0.conv2 forward (5x5, 32->32 channels @224x224, reference out.py:41-44).
-    Algorithmic FLOPs per launch = 2 * B * Cout * Ho*Wo * Cin*k*k."""
-    from cenet_amd import kern, ops
-    dt = torch.bfloat16 if kern.get_compute_bf16() else torch.float32
-    x = torch.randn(B, 32, 224, 224, device=dev).to(dt)
-    w = torch.randn(32, 32, 5, 5, device=dev) * 0.03
-    with torch.no_grad():
-        for _ in range(2):
-            ops.conv2d_nchw(x, w, None, stride=1, pad=2)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
-        e0.record()
-        for _ in range(reps):
-            ops.conv2d_nchw(x, w, None, stride=1, pad=2)
-        e1.record()
-        torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * B * 32 * 224 * 224 * 32 * 25
-    achieved = flops / (ms * 1e-3) / 1e12
-    peak = peak_tflops()
-    # HBM bytes per launch from rocprofv3 PMC passes at B=32 (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/
-    # r01_pmc_roofline_kernel*.csv): fp32 mode = implicit-GEMM gather, bf16 mode = LDS-halo direct conv; algorithmic = 411 MB
-    bf16 = peak != PEAK_F32_MFMA_TFLOPS
-    traffic = (4.2e8 if bf16 else 1.157e9) if B == 32 else None
-    name = ("conv_direct_bf16_kernel<32,32,5>" if bf16 else "gemm_kernel<float,32,256,im2col>") + \
-        " (out.rb.0.conv2 fwd, 5x5 32->32 @224^2)"
-    alg_bytes = 4.0 * (2 * B * 32 * 224 * 224 + 32 * 32 * 25)  # input + output + weights, fp32 in HBM
-    # the binding roof depends on the operand mode: fp32 MFMA (157 TF) binds before HBM; at the bf16 MFMA rate (2.5 PF)
-    # the same launch is HBM-bound (82 GFLOP / 2.5 PF = 33 us < 411 MB / 8 TB/s = 51 us)
-    if flops / (peak * 1e12) >= alg_bytes / (PEAK_HBM_GBS * 1e9):
-        return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic, "avg_launch_ms": round(ms, 4)}
-    gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "avg_launch_ms": round(ms, 4),
-            "mfma_tflops": round(achieved, 2)}
 
 
 def peak_tflops():
@@ -107,53 +104,188 @@ def peak_tflops():
     return PEAK_BF16_MFMA_TFLOPS if kern.get_compute_bf16() else PEAK_F32_MFMA_TFLOPS
 
 
-def _time(fn, reps=5):
-    for _ in range(2):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+# ---------------------------------------------------------------------------------------------------------------------------
+# instrumented passes (after the timed region; never inside it)
+# ---------------------------------------------------------------------------------------------------------------------------
+class _Trace:
+    """brackets every kern.gemm / attention-kernel call of a step with HIP events on the launching stream"""
+
+    def __init__(self):
+        self.rows = []  # (name, e0, e1, flops, bytes)
+
+    def install(self):
+        from cenet_amd import kern
+        self._saved = {n: getattr(kern, n) for n in ("gemm", "diffattn_heads", "flash_fwd", "flash_bwd")}
+        tr = self
+
+        def gemm(A, B, Cout, M, N, K, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tr._saved["gemm"](A, B, Cout, M, N, K, **kw)
+            e1.record()
+            nb, nkb = kw.get("nbatch", 1), kw.get("nkb", 1)
+            es = 2 if A.bf16 else 4
+            ce = 4 if kw.get("atomic") else es
+            by = nb * nkb * (M * K + K * N) * es + nb * M * N * ce * (2 if kw.get("R") is not None else 1)
+            tr.rows.append((kern.last_gemm_kernel(), e0, e1, 2.0 * M * N * K * nb * nkb, float(by)))
+
+        def wrap(name, label):
+            def f(*a, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = tr._saved[name](*a, **kw)
+                e1.record()
+                tr.rows.append((label(*a, **kw), e0, e1, 0.0, 0.0))
+                return r
+            return f
+        kern.gemm = gemm
+        kern.diffattn_heads = wrap("diffattn_heads", lambda a, backward=False: "dattn_bwd_dq+dkv_kernel" if backward else "dattn_fwd_kernel")
+        kern.flash_fwd = wrap("flash_fwd", lambda a, bf=False: "flashc_fwd_kernel" if bf else "flash_fwd_kernel")
+        kern.flash_bwd = wrap("flash_bwd", lambda a, bf=False: "flashc_bwd_dq+dkv_kernel" if bf else "flash_bwd_dq+dkv_kernel")
+
+    def remove(self):
+        from cenet_amd import kern
+        for n, f in self._saved.items():
+            setattr(kern, n, f)
+
+    def groups(self, steps):
+        torch.cuda.synchronize()
+        g = {}
+        for name, e0, e1, fl, by in self.rows:
+            t = g.setdefault(name, [0.0, 0, 0.0, 0.0])
+            t[0] += e0.elapsed_time(e1) / steps
+            t[1] += 1
+            t[2] += fl / steps
+            t[3] += by / steps
+        return g
 
 
-def extra_kernel_probes(dev, B):
-    """Two more live-timed launches: the heaviest single launch of the step (flash backward dK/dV of DSEB-56^2: 8 softmax
-    heads, N=3136, hd=16, dv=32 — fp32 MFMA in every mode this round) and the largest plain GEMM (stage-1 Mlp fc1)."""
-    from cenet_amd import kern, ops
-    out = []
-    N, H, hd = 3136, 4, 16
-    E = 2 * H * hd
-    dt = torch.bfloat16 if kern.get_compute_bf16() else torch.float32
-    q, k, v = (torch.randn(B, N, E, device=dev).to(dt).requires_grad_(True) for _ in range(3))
-    U = ops.diff_attention_heads(q, k, v, H)
-    g = torch.randn_like(U)
-    t_f = _time(lambda: ops.diff_attention_heads(q.detach(), k.detach(), v.detach(), H))
-    t_fb = _time(lambda: ops.diff_attention_heads(q, k, v, H).backward(g))
-    fl_f = 2.0 * B * 2 * H * N * N * (hd + 2 * hd)
-    fl_b = 2.0 * B * 2 * H * N * N * (2 * hd + 2 * 2 * hd) + 2.0 * B * 2 * H * N * N * (2 * hd + 2 * hd)
+def roofline_block(body, steps=3):
+    """dominant kernel instance of the step (largest summed duration among the bracketed launches)"""
+    tr = _Trace()
+    tr.install()
+    try:
+        for _ in range(steps):
+            body()
+        g = tr.groups(steps)
+    finally:
+        tr.remove()
+    # GEMM groups are exact kernel symbols; an attention-backward call launches two symbols (dQ and dK/dV kernels of similar
+    # length) on one entry, so its group competes with half its time
+    def weight(kv):
+        return kv[1][0] * (0.5 if "+" in kv[0] else 1.0)
+    name, (ms, n, fl, by) = max(g.items(), key=weight)
+    n //= steps
     peak = peak_tflops()
-    bf = kern.get_compute_bf16()
-    kf = "flashc_fwd_kernel<32,32,2>" if bf else "flash_fwd_kernel<16,32>"
-    kb = "flashc_bwd_dq+dkv_kernel<32,32,2>" if bf else "flash_bwd_dq+dkv_kernel<16,32>"
-    out.append({"kernel": kf + " (DSEB-56^2 differential attention: 8 heads, N=3136, hd=16, dv=32)", "bound": "mfma",
-                "achieved": round(fl_f / t_f / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(fl_f / t_f / 1e9 / peak, 4), "avg_launch_ms": round(t_f, 3)})
-    out.append({"kernel": kb + " (same problem, both backward launches)", "bound": "mfma",
-                "achieved": round(fl_b / (t_fb - t_f) / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(fl_b / (t_fb - t_f) / 1e9 / peak, 4), "avg_launch_ms": round(t_fb - t_f, 3)})
-    R, K, Nn = B * 3136, 64, 512
-    x = torch.randn(R, K, device=dev).to(dt)
-    W = (torch.randn(Nn, K, device=dev) * 0.05).to(dt)
-    y = torch.empty(R, Nn, device=dev, dtype=dt)
-    t = _time(lambda: kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(W, 1, K, kfast=1), y, R, Nn, K, scr=Nn, scc=1))
-    by = (R * K + Nn * K + R * Nn) * 4.0
-    out.append({"kernel": "gemm_kernel<128,128,plain> (stage-1 Mlp.fc1 fwd: 100352x64 @ 64x512)", "bound": "hbm",
-                "achieved": round(by / t / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / t / 1e6 / PEAK_HBM_GBS, 4),
-                "avg_launch_ms": round(t, 4)})
+    out = {"kernel": name, "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 5), "total_ms_per_step": round(ms, 3)}
+    if fl > 0:
+        t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)
+        if t_mfma >= t_hbm:
+            a = fl / (ms * 1e-3) / 1e12
+            out.update({"bound": "mfma", "achieved": round(a, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(a / peak, 4)})
+        else:
+            a = by / (ms * 1e-3) / 1e9
+            out.update({"bound": "hbm", "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(a / PEAK_HBM_GBS, 4)})
+        out["algorithmic_bytes_per_step"] = int(by)
+        out["algorithmic_flops_per_step"] = int(fl)
+    traffic, src = None, None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        if name in rec:
+            traffic, src = rec[name]["hbm_bytes_per_launch"], rec[name]["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+    out["traffic"] = traffic
+    if src:
+        out["traffic_source"] = src
+    out["method"] = "HIP events around every launch of this instance in %d instrumented steps, on the launching stream" % steps
+    fams = sorted(((k, v[0]) for k, v in g.items()), key=lambda kv: -kv[1])[:6]
+    out["next_kernels_ms_per_step"] = {k: round(v, 3) for k, v in fams[1:]}
+    return out
+
+
+def stage_block(net, body, B, size, steps=3):
+    """forward + backward time of every SURVEY §8d stage (module hooks + HIP events, weight gradients on the main stream)"""
+    from cenet_amd import ops
+    old = ops.set_wgrad_overlap(False)
+    ev = {k: {"f": [], "b": []} for k in STAGES}
+    nograd = {"backbone.patch_embed1": None, "out.rb": None}
+    handles = []
+    mods = dict(net.named_modules())
+
+    def hook(name, m):
+        st = {}
+
+        def fpre(mod, inp):
+            if name in nograd:
+                nograd[name] = (mod, inp)
+            st["f0"] = torch.cuda.Event(enable_timing=True)
+            st["f0"].record()
+
+        def fpost(mod, inp, outp):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev[name]["f"].append((st["f0"], e))
+
+        def bpre(mod, gout):
+            st["b0"] = torch.cuda.Event(enable_timing=True)
+            st["b0"].record()
+
+        def bpost(mod, gin, gout):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev[name]["b"].append((st["b0"], e))
+        handles.extend([m.register_forward_pre_hook(fpre), m.register_forward_hook(fpost),
+                        m.register_full_backward_pre_hook(bpre), m.register_full_backward_hook(bpost)])
+    for name in STAGES:
+        m = mods[name]
+        # ModuleList stages (block1-4) and the Sequential containers of the output head (its forward calls their children
+        # one by one) are hooked per child; a child that is never called (the MaxPool2d folded into ops.maxpool2_scale) adds 0
+        for sub in (list(m) if isinstance(m, (torch.nn.ModuleList, torch.nn.Sequential)) else [m]):
+            hook(name, sub)
+    try:
+        for _ in range(steps):
+            body()
+        torch.cuda.synchronize()
+    finally:
+        for h in handles:
+            h.remove()
+    # the two stages fed by the network input: nothing upstream needs a gradient, so their full-backward hooks fire before
+    # their kernels run.  Their backward is timed stand-alone on the tensors they saw in the step.
+    try:
+        for name, rec in nograd.items():
+            if rec is None:
+                continue
+            mod, inp = rec
+            ev[name]["b"] = []
+            for _ in range(steps):
+                y = mod(*inp)
+                y = y[0] if isinstance(y, (tuple, list)) else y
+                g = torch.ones_like(y)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                y.backward(g)
+                e1.record()
+                ev[name]["b"].append((e0, e1))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_wgrad_overlap(old)
+    peak = peak_tflops()
+    scale_f = (size / 224.0) ** 2
+    out = {}
+    for name, (gf, elems) in STAGES.items():
+        tf = sum(a.elapsed_time(b) for a, b in ev[name]["f"]) / steps
+        tb = sum(a.elapsed_time(b) for a, b in ev[name]["b"]) / steps
+        es = 2 if peak == PEAK_BF16_MFMA_TFLOPS else 4
+        fl = 3.0 * gf * 1e9 * B * scale_f            # fwd + bwd = 3 x fwd (SURVEY §8d); attention terms grow faster at 512^2
+        by = 3.0 * elems * es * B * scale_f
+        t_m, t_h = fl / (peak * 1e12) * 1e3, by / (PEAK_HBM_GBS * 1e9) * 1e3
+        bound_ms = max(t_m, t_h)
+        key = name if name.startswith("out.") else name.split(".", 1)[1].replace("skip_enhancer", "DSEB")
+        out[key] = {
+            "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3), "bound": "mfma" if t_m >= t_h else "hbm",
+            "bound_ms": round(bound_ms, 4), "frac": round(bound_ms / max(tf + tb, 1e-9), 4)}
     return out
 
 
@@ -188,8 +320,19 @@ def cpu_baseline(steps):
             "sample": f"{steps} train steps of ACDC 224x224 4-class batch=4 fp32 (oracle/cenet_oracle.py), {dt:.2f} s/step"}
 
 
+def _time_steps(fn, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
 def main():
     a = parse()
+    cfg = CONFIGS[a.config]
+    B = a.batch or cfg["batch"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,7 +352,7 @@ def main():
     kern.set_compute_bf16(a.dtype == "bf16")
     from cenet_amd import ops
     ops.set_wgrad_overlap(not a.no_overlap)  # weight gradients on a second HIP stream, beside the data-gradient chain
-    net = make_model(dev)
+    net = make_model(dev, cfg)
     arena = optim.ParamArena(net, optim.cenet_segments())
     reducer = parallel.GradReducer(arena, force=use_dist) if use_dist else None
     if reducer is not None:
@@ -217,8 +360,8 @@ def main():
         parallel.attach(net, reducer)
     opt = optim.FusedSGD(arena, lr=0.01, momentum=0.9, weight_decay=1e-4, grad_scale=1.0 / world)
     sched = optim.PolyLR(opt, max_iterations=100000)
-    crit = losses.Criterion(4, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
-    x, lab = synthetic(a.batch, dev, seed=1234 + rank)
+    crit = losses.Criterion(cfg["classes"], argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
+    x, lab = synthetic(B, dev, seed=1234 + rank, cfg=cfg)
 
     def body(sync_hyper=True):
         opt.zero_grad()
@@ -230,12 +373,11 @@ def main():
         return loss
 
     graphed = None
-    # auto: eager launches when the weight gradients overlap on their own stream (measured 45.7 ms eager vs 49.5 ms as a
-    # replayed hipGraph, whose two branches the runtime interleaves less well), and with RCCL collectives inside the step
-    # (N > 1; capture of multi-rank collectives could not be exercised on the 1-GPU development box).  Without the overlap
-    # replay and eager launches are equal (the step is GPU-bound): capture then.
-    if a.graph == "on" or (a.graph == "auto" and not use_dist and a.no_overlap):
-        # the whole step (memset, ~1.8 k kernels, all-reduces, SGD) as ONE hipGraph replay per iteration
+    launch_note = None
+    # N > 1 runs eager launches: RCCL collectives inside a captured graph could not be exercised on the 1-GPU development
+    # box.  N == 1, auto: eager launches are host-bound (~1.9 k launches of ~20 us of Python + ctypes each) and replay is not,
+    # so which one is faster depends on the host; a few steps of each decide.
+    if a.graph == "on" or (a.graph == "auto" and not use_dist):
         from cenet_amd.graph import GraphedStep
         try:
             graphed = GraphedStep(lambda: body(sync_hyper=False), optimizer=opt, warmup=2)
@@ -245,6 +387,14 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             graphed = None
             torch.cuda.synchronize()
+        if graphed is not None and a.graph == "auto":
+            for _ in range(2):
+                body()
+                graphed()
+            t_e, t_g = _time_steps(body, 4), _time_steps(graphed, 4)
+            launch_note = f"auto: eager {t_e * 1e3:.1f} ms vs hipGraph replay {t_g * 1e3:.1f} ms over 4 untimed steps each"
+            if t_e <= t_g:
+                graphed = None
 
     def step():
         loss = graphed() if graphed is not None else body()
@@ -271,33 +421,30 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        out = {"metric": "training images/sec (224x224, 4-class)", "value": round(a.batch * world * a.steps / dt, 3),
+        out = {"metric": "training images/sec (224x224, 4-class)" if a.config == "acdc" else
+               f"training images/sec ({cfg['size']}x{cfg['size']}, {cfg['classes']}-class)",
+               "value": round(B * world * a.steps / dt, 3),
                "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "ACDC 224x224 4-class, batch=32/GPU, random-init PVTv2-b2 CENet, "
+               "config": {"workload": f"{cfg['name']}, batch={B}/GPU, random-init PVTv2-b2 CENet "
+                                      f"(heads {cfg['heads']}, scales {cfg['scales']}), "
                                       "fwd + Dice/CE + bwd + grad all-reduce + SGD(momentum .9, wd 1e-4)",
-                          "batch_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                          "preset": a.config, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                           "launch": "hipGraph replay" if graphed is not None else "eager",
                           "final_loss": round(final_loss, 5)}}
-        out["roofline"] = dominant_kernel_probe(dev, a.batch)
-        out["roofline_extra"] = extra_kernel_probes(dev, a.batch)
+        if launch_note:
+            out["config"]["launch_choice"] = launch_note
+        if world == 1 and not a.no_roofline:
+            out["roofline"] = roofline_block(body)
+            out["roofline_stages"] = stage_block(net, body, B, cfg["size"])
         if world == 1 and a.dtype == "bf16" and not a.no_f32:
-            # the same step in the fp32-operand PARITY mode (the mode the 1e-3 logit / 1e-4 Dice tests are run in)
+            # the same step in the fp32 PARITY mode (fp32 tensors end to end: the mode the 1e-3 logit / 1e-4 Dice tests run in)
             kern.set_compute_bf16(False)
-            g32 = None
-            if graphed is not None:
-                from cenet_amd.graph import GraphedStep
-                g32 = GraphedStep(lambda: body(sync_hyper=False), optimizer=opt, warmup=2)
-            n32 = max(3, a.steps // 2)
+            n32 = max(3, min(10, a.steps // 5))
             for _ in range(2):
-                (g32() if g32 is not None else body())
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n32):
-                (g32() if g32 is not None else body())
-            torch.cuda.synchronize()
-            d32 = (time.perf_counter() - t0) / n32
-            out["parity_mode_f32"] = {"value": round(a.batch / d32, 3), "unit": "images/s", "ms_per_step": round(d32 * 1e3, 3),
+                body()
+            d32 = _time_steps(body, n32)
+            out["parity_mode_f32"] = {"value": round(B / d32, 3), "unit": "images/s", "ms_per_step": round(d32 * 1e3, 3),
                                       "steps": n32}
             kern.set_compute_bf16(True)
         if world == 1 and not a.no_cpu_baseline:

@@ -1,6 +1,7 @@
 // gemm.hip — C-ABI entry of the GEMM / implicit-GEMM core: argument checks, tile and split-K selection, dispatch to the
 // per-type instantiations (gemm_inst_*.hip).  The kernel itself is in gemm_core.h.
 #include "gemm_ring.h"
+#include <cstdio>
 #include <cstdlib>
 
 static void pick_tile(int M, int N, int nbatch, int splits, int* bm, int* bn) {
@@ -19,6 +20,12 @@ static void pick_tile(int M, int N, int nbatch, int splits, int* bm, int* bn) {
   *bm = m;
   *bn = n;
 }
+
+// name of the kernel instance the last cenet_gemm_* call on this thread launched, spelled as rocprofv3 prints it
+// (measurement aid: bench.py groups its live per-launch timings by this name)
+static thread_local char g_last_kernel[96] = "";
+extern "C" const char* cenet_gemm_last_kernel(void) { return g_last_kernel; }
+static inline const char* tf(bool b) { return b ? "true" : "false"; }
 
 static inline bool m4(long v) { return (v & 3) == 0; }
 static inline bool m2(long v) { return (v & 1) == 0; }
@@ -103,6 +110,8 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   int rc;
   if (ring) {
     if (bm == 128 && (long)cdiv(M, 128) * cdiv(N, 128) * nbatch * splits < 192) bm = bn = 64;
+    snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_ring_kernel<%s, %s, %d, %d, %d, %s>", tf(akf), tf(bkf), bm, bn,
+             bm == 128 ? 2 : 4, tf(swap));
     rc = akf ? (bkf ? cenet_gemm_launch_ring_kk(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_ring_kr(g, bm, bn, nbatch, swap, stream))
              : (bkf ? cenet_gemm_launch_ring_rk(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_ring_rr(g, bm, bn, nbatch, swap, stream));
   } else if (bf) {
@@ -114,12 +123,16 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
     // is at least two 64-steps long
     const long kchunk = ((long)nkb * K) / (splits > 0 ? splits : 1);
     const bool k64 = !im && K >= 128 && kchunk >= 128 && bm <= 64 && bn == 64;  // (the 128-wide K-64 instances spill)
+    snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_kernel<unsigned short, %d, %d, %s, %s, %d>", bm, bn, tf(im), tf(swap),
+             k64 ? 64 : 32);
     rc = im ? cenet_gemm_launch_bf16_im2col(g, bm, bn, nbatch, swap, stream)
             : (k64 ? cenet_gemm_launch_bf16_plain_k64(g, bm, bn, nbatch, swap, stream)
                    : cenet_gemm_launch_bf16_plain(g, bm, bn, nbatch, swap, stream));
   }
-  else
+  else {
+    snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_kernel<float, %d, %d, %s, %s, 32>", bm, bn, tf(im), tf(swap));
     rc = im ? cenet_gemm_launch_f32_im2col(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_f32_plain(g, bm, bn, nbatch, swap, stream);
+  }
   if (rc != CENET_OK) return rc;
   CENET_CHECK_LAUNCH();
   return CENET_OK;

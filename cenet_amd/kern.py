@@ -129,6 +129,13 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
     _lib.check(rc, "cenet_gemm_bf16" if A.bf16 else "cenet_gemm_f32")
 
 
+def last_gemm_kernel() -> str:
+    """name of the kernel instance the last gemm() on this thread launched (as rocprofv3 prints it); measurement aid"""
+    f = _lib.lib().cenet_gemm_last_kernel
+    f.restype = C.c_char_p
+    return f().decode()
+
+
 # ------------------------------------------------------------------------------------------------
 # generic call helper
 # ------------------------------------------------------------------------------------------------

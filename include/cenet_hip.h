@@ -79,6 +79,9 @@ int cenet_gemm_f32(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t
  * / cenet_cast_f32_to_bf16). */
 int cenet_gemm_bf16(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_t* E, int M, int N, int K,
                     int nbatch, int nb_inner, int nkb, int splits, cenet_stream_t stream);
+/* Measurement aid: the kernel instance the last cenet_gemm_* call on this thread launched, spelled as rocprofv3 prints it
+ * ("gemm_ring_kernel<false, false, 64, 64, 4, false>").  bench.py groups its live per-launch timings by this name. */
+const char* cenet_gemm_last_kernel(void);
 
 /* Direct ("LDS halo") stride-1 same-padded convolution on bf16 tensors (throughput mode, conv_direct.hip): replaces
  * aten::convolution(+ data-gradient) for out.py:41-49,59 (5x5 32->32, 3x3 64->64, 3x3 64->32 and their dgrads).

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "cenet_hip.h")).read()
-    return sorted(set(re.findall(r"\bint\s+(cenet_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(cenet_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_declares_entry_points():
