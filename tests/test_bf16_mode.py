@@ -200,3 +200,82 @@ def test_sr_conv_tok_bf16_split_k(dev, bf16_mode, B, C, Cout, H, W, s):
     assert _rel(x.grad.float().cpu(), xr.grad) < 2e-2
     assert _rel(Wt.grad.cpu(), Wr.grad) < 2e-2
     assert _rel(b.grad.cpu(), br.grad) < 1e-4
+
+
+def _train_step_grads(build_fn, bf16):
+    """one training step (forward, Dice + CE, backward; deterministic depth) -> loss, logits, flat gradient, arena, buffers"""
+    import argparse
+    from cenet_amd import losses, optim
+    net, K, x, lab = build_fn()
+    net.train()
+    net.backbone.reset_drop_path(0.0)
+    arena = optim.ParamArena(net, optim.cenet_segments())
+    crit = losses.Criterion(K, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
+    kern.set_compute_bf16(bf16)
+    try:
+        lt = net(x)
+        assert lt.dtype == (torch.bfloat16 if bf16 else torch.float32)
+        loss = crit(lt, lab)
+        loss.backward()
+    finally:
+        kern.set_compute_bf16(False)
+    torch.cuda.synchronize()
+    return loss.item(), lt.detach().float().cpu(), arena.grads.clone(), arena, dict(net.named_buffers())
+
+
+def _cos(a, b):
+    return torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=0).item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["acdc", "synapse", "skin"])
+def test_whole_model_bf16_training_step_vs_goldens(name):
+    """The BENCHED mode (bf16 tensors end to end) on the three whole-model goldens of the unmodified reference, one training
+    step.  Pinned against the goldens: loss within 5e-3, train logits mean |d| < 2 % of the logit range, BN running buffers.
+    Pinned against the fp32 product step (itself pinned to the float64 goldens at 1e-3, test_model_parity.py): cosine of the
+    FULL head+decoder gradient >= 0.98, of the whole gradient vector >= 0.80.
+    The golden points (every parameter filled at random, batch 2-4) are ill-conditioned for the encoder gradient: an
+    all-fp32 step whose ONLY perturbation is the network input rounded to bf16 values (2^-9 relative, loss unchanged to five
+    digits) already moves the four encoder segments to cosine 0.988 - 0.997 (tools/bf16_bisect.py --quick), so several
+    hundred bf16 roundings land at 0.85 - 0.96 there.  The well-conditioned pin is the next test."""
+    from oracle.gen_golden_keys import PROBE_BUFFERS
+    from test_model_parity import build
+    d = use_hip()
+
+    def build_fn():
+        net, cfg, z, x, lab = build(name, d)
+        return net, cfg.num_classes, x, lab
+    _, _, z, _, _ = build(name, d)
+    l32, _, g32, arena, _ = _train_step_grads(build_fn, False)
+    l16, lt, g16, _, bufs = _train_step_grads(build_fn, True)
+    assert abs(l32 - float(z["loss"])) < 2e-4
+    assert abs(l16 - float(z["loss"])) < 5e-3, (l16, float(z["loss"]))
+    ref = z["logits_train_sub"]
+    assert np.abs(lt[:, :, ::9, ::9].numpy() - ref).mean() < 0.02 * np.abs(ref).max()
+    seg = {n: (s, e) for n, s, e in arena.segments}
+    s, e = seg["head+decoder"]
+    assert _cos(g32[s:e], g16[s:e]) >= 0.98, _cos(g32[s:e], g16[s:e])
+    assert _cos(g32, g16) >= 0.80, _cos(g32, g16)
+    for k in PROBE_BUFFERS:
+        np.testing.assert_allclose(bufs[k].reshape(-1)[:16].float().cpu().numpy(), z["b." + k], rtol=5e-2, atol=5e-3, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_bf16_training_gradient_tracks_fp32_on_the_benched_model():
+    """The benched workload's own model (default initialisation, ACDC preset, batch 4): the bf16-mode gradient against the
+    fp32-mode gradient of the same step.  Whole vector and head+decoder segment: cosine >= 0.9995; encoder stages >= 0.985
+    (measured 1.00000 / 1.00000 / 0.990 - 0.998); loss within 1e-3."""
+    import bench
+    d = use_hip()
+
+    def build_fn():
+        net = bench.make_model(d)
+        x, lab = bench.synthetic(4, d, 7)
+        return net, 4, x, lab
+    l32, _, g32, arena, _ = _train_step_grads(build_fn, False)
+    l16, _, g16, _, _ = _train_step_grads(build_fn, True)
+    assert abs(l16 - l32) < 1e-3
+    assert _cos(g32, g16) >= 0.9995
+    for n, s, e in arena.segments:
+        c = _cos(g32[s:e], g16[s:e])
+        assert c >= (0.9995 if n == "head+decoder" else 0.985), (n, c)
