@@ -129,19 +129,32 @@ class _Trace:
             by = nb * nkb * (M * K + K * N) * es + nb * M * N * ce * (2 if kw.get("R") is not None else 1)
             tr.rows.append((kern.last_gemm_kernel(), e0, e1, 2.0 * M * N * K * nb * nkb, float(by)))
 
-        def wrap(name, label):
+        def work(a, backward):
+            """algorithmic FLOPs / bytes of one attention call: QK^T and PV (2 MAC each) forward, 2.5x that backward;
+            q, k, v, o once (plus their gradients backward), 2-byte elements"""
+            if hasattr(a, "Nq"):
+                fl = 2.0 * a.B * a.H * a.Nq * a.Nk * (a.D + a.Dv)
+                el = a.B * a.H * (a.Nq * (a.D + a.Dv) + a.Nk * (a.D + a.Dv))
+            else:  # differential pairs: 2H softmax heads of dim hd over H value heads of dim 2 hd
+                fl = 2.0 * a.B * 2 * a.H * a.N * a.N * 3 * a.hd
+                el = a.B * a.N * (2 * a.H * a.hd * 2 + a.H * 2 * a.hd + 2 * a.H * 2 * a.hd)
+            return (2.5 * fl, 2.0 * el * 2) if backward else (fl, el * 2.0)
+
+        def wrap(name, label, backward):
             def f(*a, **kw):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 r = tr._saved[name](*a, **kw)
                 e1.record()
-                tr.rows.append((label(*a, **kw), e0, e1, 0.0, 0.0))
+                bw = backward if backward is not None else bool(kw.get("backward", a[1] if len(a) > 1 else False))
+                fl, by = work(a[0], bw)
+                tr.rows.append((label(*a, **kw), e0, e1, fl, by))
                 return r
             return f
         kern.gemm = gemm
-        kern.diffattn_heads = wrap("diffattn_heads", lambda a, backward=False: "dattn_bwd_dq+dkv_kernel" if backward else "dattn_fwd_kernel")
-        kern.flash_fwd = wrap("flash_fwd", lambda a, bf=False: "flashc_fwd_kernel" if bf else "flash_fwd_kernel")
-        kern.flash_bwd = wrap("flash_bwd", lambda a, bf=False: "flashc_bwd_dq+dkv_kernel" if bf else "flash_bwd_dq+dkv_kernel")
+        kern.diffattn_heads = wrap("diffattn_heads", lambda a, backward=False: "dattn_bwd_dq+dkv_kernel" if backward else "dattn_fwd_kernel", None)
+        kern.flash_fwd = wrap("flash_fwd", lambda a, bf=False: "flashc_fwd_kernel" if bf else "flash_fwd_kernel", False)
+        kern.flash_bwd = wrap("flash_bwd", lambda a, bf=False: "flashc_bwd_dq+dkv_kernel" if bf else "flash_bwd_dq+dkv_kernel", True)
 
     def remove(self):
         from cenet_amd import kern

@@ -49,3 +49,19 @@ def test_bench_under_torchrun_with_rccl_group():
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
     assert d["config"]["final_loss"] == d["config"]["final_loss"]  # not NaN
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,batch,size,classes", [("synapse", 24, 224, 9), ("ham512", 2, 512, 2)])
+def test_bench_other_presets(preset, batch, size, classes):
+    """SURVEY.md §8d C4 (Synapse at its full per-GPU batch) and C5 (HAM10000 at 512x512, three FEA scales; batch 2 here,
+    8 in the preset; no oracle exists at this size: parity unpinned, the step must run and train)"""
+    p = subprocess.run([sys.executable, "bench.py", "--config", preset, "--batch", str(batch), "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-f32"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    assert d["config"]["preset"] == preset and d["config"]["batch_per_gpu"] == batch
+    assert f"{size}x{size}" in d["metric"] and f"{classes}-class" in d["metric"]
+    assert d["value"] > 0 and d["config"]["final_loss"] == d["config"]["final_loss"] and d["config"]["final_loss"] < 5.0
+    assert len(d["roofline_stages"]) == 21 and all(v["fwd_ms"] > 0 for v in d["roofline_stages"].values())
+    assert d["roofline"]["bound"] in ("mfma", "hbm")

@@ -279,3 +279,27 @@ def test_bf16_training_gradient_tracks_fp32_on_the_benched_model():
     for n, s, e in arena.segments:
         c = _cos(g32[s:e], g16[s:e])
         assert c >= (0.9995 if n == "head+decoder" else 0.985), (n, c)
+
+
+@pytest.mark.gpu
+def test_ham512_three_scale_preset_trains_in_both_modes():
+    """SURVEY.md §8d C5 (skin.sh:93-94): 3x512x512 input, 2 classes, heads 2/2/2 (head dims 160 / 64 / 32 at 1024 / 4096 /
+    16384 tokens), THREE FEA scales 1.0 / 0.75 / 0.5, batch 2.  No oracle exists at this size (parity unpinned); the two
+    product modes must agree with each other: loss within 5e-3, head+decoder gradient cosine >= 0.995, logits at full size."""
+    import bench
+    d = use_hip()
+    cfg = bench.CONFIGS["ham512"]
+
+    def build_fn():
+        net = bench.make_model(d, cfg)
+        x, lab = bench.synthetic(2, d, 11, cfg)
+        return net, cfg["classes"], x, lab
+    l32, lt32, g32, arena, _ = _train_step_grads(build_fn, False)
+    l16, lt16, g16, _, _ = _train_step_grads(build_fn, True)
+    assert lt32.shape == (2, 2, 512, 512) and lt16.shape == lt32.shape
+    assert np.isfinite(l32) and abs(l16 - l32) < 5e-3, (l32, l16)
+    assert torch.isfinite(g32).all() and torch.isfinite(g16).all()
+    seg = {n: (s, e) for n, s, e in arena.segments}
+    s, e = seg["head+decoder"]
+    assert _cos(g32[s:e], g16[s:e]) >= 0.995
+    assert (lt16 - lt32).abs().mean() < 0.02 * lt32.abs().max()
