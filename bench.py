@@ -75,6 +75,7 @@ def parse():
                     help="replay the step as one captured hipGraph (auto: N == 1 times a few steps both ways and keeps the faster)")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra fp32 parity-mode measurement (N=1, bf16 runs)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the weight-gradient kernels on the main stream")
+    ap.add_argument("--bf16-buckets", action="store_true", help="N > 1: all-reduce the gradient segments as bf16 (half the bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the instrumented passes (roofline, roofline_stages)")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -367,7 +368,7 @@ def main():
     ops.set_wgrad_overlap(not a.no_overlap)  # weight gradients on a second HIP stream, beside the data-gradient chain
     net = make_model(dev, cfg)
     arena = optim.ParamArena(net, optim.cenet_segments())
-    reducer = parallel.GradReducer(arena, force=use_dist) if use_dist else None
+    reducer = parallel.GradReducer(arena, force=use_dist, bf16_buckets=a.bf16_buckets) if use_dist else None
     if reducer is not None:
         reducer.broadcast_state(net)
         parallel.attach(net, reducer)
@@ -442,7 +443,7 @@ def main():
                "config": {"workload": f"{cfg['name']}, batch={B}/GPU, random-init PVTv2-b2 CENet "
                                       f"(heads {cfg['heads']}, scales {cfg['scales']}), "
                                       "fwd + Dice/CE + bwd + grad all-reduce + SGD(momentum .9, wd 1e-4)",
-                          "preset": a.config, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "preset": a.config, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", **({"grad_buckets": "bf16"} if a.bf16_buckets else {}),
                           "launch": "hipGraph replay" if graphed is not None else "eager",
                           "final_loss": round(final_loss, 5)}}
         if launch_note:

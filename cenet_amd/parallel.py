@@ -20,7 +20,12 @@ from .optim import ParamArena
 
 
 class GradReducer:
-    def __init__(self, arena: ParamArena, group=None, force: bool = False):
+    def __init__(self, arena: ParamArena, group=None, force: bool = False, bf16_buckets: bool = False):
+        """bf16_buckets: all-reduce each segment as bf16 (half the xGMI bytes: 66.8 instead of 133.5 MB per step); the
+        segment is rounded into a staging buffer, summed by RCCL in bf16 and widened back into the fp32 arena.  Off by
+        default: the fp32 sum is the one the known-answer test pins to the mean of the per-shard oracle gradients."""
+        self.bf16_buckets = bool(bf16_buckets)
+        self._stage = {}
         self.arena = arena
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -58,10 +63,26 @@ class GradReducer:
                 self.side.wait_stream(wg)
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
-                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.bf16_buckets:
+                    st = self._stage.get(i)
+                    if st is None:
+                        st = self._stage[i] = torch.empty(buf.shape, dtype=torch.bfloat16, device=buf.device)
+                    st.copy_(buf)
+                    h = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    h.wait()       # orders the COMMUNICATION stream after the collective (no host block)
+                    buf.copy_(st)
+                    h = None
+                else:
+                    h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        elif self.bf16_buckets:
+            st = buf.to(torch.bfloat16)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(st)
+            h = None
         else:
             h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._handles.append(h)
+        if h is not None:
+            self._handles.append(h)
 
     def hook(self, i: int):
         """tensor hook factory: `t.register_hook(reducer.hook(i))`."""
@@ -71,7 +92,11 @@ class GradReducer:
         return _h
 
     def finish(self):
-        """After backward: reduce whatever is left, then make the compute stream wait for all collectives."""
+        """After backward: reduce whatever is left, then order the COMPUTE STREAM after all collectives.  Nothing here
+        blocks the host on a GPU: for RCCL work objects `wait()` inserts a stream-side wait on the process group's internal
+        communication stream (where the collective actually runs; `wait_stream(self.side)` alone would not cover it), so
+        the host returns at once and can issue the next step's zero_grad / forward launches.  (gloo: `wait()` is the host
+        wait, there is no stream.)"""
         for i in range(len(self.arena.segments)):
             self.segment_ready(i)
         for h in self._handles:

@@ -39,11 +39,12 @@ def test_bench_single_process_contract():
 
 
 @pytest.mark.gpu
-def test_bench_under_torchrun_with_rccl_group():
+@pytest.mark.parametrize("extra", [[], ["--bf16-buckets"]])
+def test_bench_under_torchrun_with_rccl_group(extra):
     env = dict(os.environ, CENET_FORCE_DIST="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--no-f32"] + extra
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     d = _last_json(p.stdout)
