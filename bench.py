@@ -116,7 +116,7 @@ class _Trace:
 
     def install(self):
         from cenet_amd import kern
-        self._saved = {n: getattr(kern, n) for n in ("gemm", "diffattn_heads", "flash_fwd", "flash_bwd")}
+        self._saved = {n: getattr(kern, n) for n in ("gemm", "diffattn_heads", "attn64", "flash_fwd", "flash_bwd")}
         tr = self
 
         def gemm(A, B, Cout, M, N, K, **kw):
@@ -136,6 +136,9 @@ class _Trace:
             if hasattr(a, "Nq"):
                 fl = 2.0 * a.B * a.H * a.Nq * a.Nk * (a.D + a.Dv)
                 el = a.B * a.H * (a.Nq * (a.D + a.Dv) + a.Nk * (a.D + a.Dv))
+            elif a.hd == 64:  # single-softmax form: H heads of dimension 64
+                fl = 2.0 * a.B * a.H * a.N * a.N * 128
+                el = a.B * a.H * a.N * 64 * 4
             else:  # differential pairs: 2H softmax heads of dim hd over H value heads of dim 2 hd
                 fl = 2.0 * a.B * 2 * a.H * a.N * a.N * 3 * a.hd
                 el = a.B * a.N * (2 * a.H * a.hd * 2 + a.H * 2 * a.hd + 2 * a.H * 2 * a.hd)
@@ -154,6 +157,7 @@ class _Trace:
             return f
         kern.gemm = gemm
         kern.diffattn_heads = wrap("diffattn_heads", lambda a, backward=False: "dattn_bwd_dq+dkv_kernel" if backward else "dattn_fwd_kernel", None)
+        kern.attn64 = wrap("attn64", lambda a, backward=False: "dattn_bwd_dq+dkv_kernel<32, true>" if backward else "dattn_fwd_kernel<32, 1, 2, true>", None)
         kern.flash_fwd = wrap("flash_fwd", lambda a, bf=False: "flashc_fwd_kernel" if bf else "flash_fwd_kernel", False)
         kern.flash_bwd = wrap("flash_bwd", lambda a, bf=False: "flashc_bwd_dq+dkv_kernel" if bf else "flash_bwd_dq+dkv_kernel", True)
 

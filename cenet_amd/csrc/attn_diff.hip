@@ -149,10 +149,13 @@ struct DaGeo {
 // ---------------------------------------------------------------------------------------------------------------------------
 // forward: wave = QT tiles of 32 queries x both softmax heads of pair h; workgroup = 4 waves; grid (ceil(N / (128 QT)), B*H)
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int HDP, int QT, int MINB>
+// ONE: a single softmax over BOTH halves of the pair's 2*HDP query / key columns (one head of dimension 2*HDP = value width):
+// plain attention with head dimension 64 through the same tiles — the two half-products add into one score tile.  Tensors:
+// q, k, v [B, N, H*2HDP], U [B, H, N, 2HDP], lse / aug rows [B, H, N].
+template <int HDP, int QT, int MINB, bool ONE>
 __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
   typedef DaGeo<HDP> G;
-  constexpr int NKS = HDP / 16, NDT = G::DVP / 32;
+  constexpr int NKS = HDP / 16, NDT = G::DVP / 32, NH = ONE ? 1 : 2;
   constexpr int KIMG = 32 * G::KP, VIMG = 32 * G::VPT + 64, IMG = KIMG + VIMG;  // (+64: transposed reads of padded rows)
   constexpr int NCH = 32 * (G::CK + G::CV), CPT = (NCH + 255) / 256;
   __shared__ __attribute__((aligned(16))) bf lds[2 * IMG];
@@ -201,8 +204,8 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
   };
 
   bf16x8 qf[QT][2][NKS];
-  f32x16 O[QT][2][NDT];
-  float m[QT][2], l[QT][2];
+  f32x16 O[QT][NH][NDT];
+  float m[QT][NH], l[QT][NH];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const int qi = q0 + 32 * t + r < N ? q0 + 32 * t + r : N - 1;
@@ -211,6 +214,9 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
         qf[t][s][ks] = da_ld8(qb + (long)qi * E + (2 * h + s) * hd + 16 * ks + 8 * hh, 16 * ks + 8 * hh < hd);
+    }
+#pragma unroll
+    for (int s = 0; s < NH; ++s) {
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) O[t][s][dt] = da_zero();
       m[t][s] = DA_NEG;
@@ -241,10 +247,12 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
 #pragma unroll
       for (int t = 0; t < QT; ++t)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NH; ++s) {
           f32x16 S = da_zero();
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(kf[s][ks], qf[t][s][ks], S);  // S^T[key][query]
+          for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(kf[sp][ks], qf[t][sp][ks], S);  // S^T[key][query]
           if (MASKED) {  // ragged last tile only (its own instantiation of the tile body: no per-score selects elsewhere)
 #pragma unroll
             for (int i = 0; i < 16; ++i)
@@ -295,11 +303,12 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
   for (int t = 0; t < QT; ++t) {
     const int qi = q0 + 32 * t + r;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NH; ++s) {
       const float lt = l[t][s] + __shfl_xor(l[t][s], 32);
+      const long hrow = ((long)b * NH * a.H + NH * h + s) * N + qi;
       if (qi < N) {
         const float inv = 1.f / lt;
-        bf* up = a.U + (((long)b * 2 * a.H + 2 * h + s) * N + qi) * dv;
+        bf* up = a.U + hrow * dv;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
               st4v(up + f0, o);
             }
           }
-        if (hh == 0) a.lse[((long)b * 2 * a.H + 2 * h + s) * N + qi] = m[t][s] * a.scale + logf(lt);
+        if (hh == 0) a.lse[hrow] = m[t][s] * a.scale + logf(lt);
       }
     }
   }
@@ -321,10 +330,10 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // backward, dQ (+ delta = rowsum(dU * U) and the bf16 statistics rows for dK/dV): wave = 32 queries x both softmax heads
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int HDP>
+template <int HDP, bool ONE>
 __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
   typedef DaGeo<HDP> G;
-  constexpr int NKS = HDP / 16, NKD = G::DVP / 16;
+  constexpr int NKS = HDP / 16, NKD = G::DVP / 16, NH = ONE ? 1 : 2;
   constexpr int KIMG = 32 * G::KP + 64, VIMG = 32 * G::VPR, IMG = KIMG + VIMG;
   constexpr int NCH = 32 * (G::CK + G::CV), CPT = (NCH + 255) / 256;
   __shared__ __attribute__((aligned(16))) bf lds[2 * IMG];
@@ -372,15 +381,19 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
       if (ch[j].loff >= 0) memcpy(lds + buf * IMG + ch[j].loff, pre[j], 16);
   };
 
-  bf16x8 qf[2][NKS], gf[2][NKD];
-  float lse2[2], dl[2];
+  bf16x8 qf[2][NKS], gf[NH][NKD];
+  float lse2[NH], dl[NH];
   f32x16 dq[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const long hrow = ((long)b * 2 * a.H + 2 * h + s) * N + qi;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
       qf[s][ks] = da_ld8(qb + (long)qi * E + (2 * h + s) * hd + 16 * ks + 8 * hh, 16 * ks + 8 * hh < hd);
+    dq[s] = da_zero();
+  }
+#pragma unroll
+  for (int s = 0; s < NH; ++s) {
+    const long hrow = ((long)b * NH * a.H + NH * h + s) * N + qi;
     float acc = 0.f;
 #pragma unroll
     for (int kd = 0; kd < NKD; ++kd) {
@@ -399,7 +412,6 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
       da_split3(hh == 0 ? lse / a.scale : acc, row8);
       memcpy(a.aug + hrow * 16 + 8 * hh, row8, 16);
     }
-    dq[s] = da_zero();
   }
   fetch(0);
   stage(0);
@@ -417,10 +429,12 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
 #pragma unroll
       for (int kd = 0; kd < NKD; ++kd) vf[kd] = da_rm(Vimg, G::VPR, r, 16 * kd, hh);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < NH; ++s) {
         f32x16 S = da_zero(), dP = da_zero();
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(da_rm(Kimg, G::KP, r, s * HDP + 16 * ks, hh), qf[s][ks], S);
+        for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp)
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(da_rm(Kimg, G::KP, r, sp * HDP + 16 * ks, hh), qf[sp][ks], S);
 #pragma unroll
         for (int kd = 0; kd < NKD; ++kd) dP = DA_MFMA(vf[kd], gf[s][kd], dP);  // dP^T[key][query] = V dU^T
 #pragma unroll
@@ -432,7 +446,9 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
         // dQ^T[d][query] += K^T[d][key] dS^T[key][query]; accumulator rows >= hd (the other head's columns, padding) are
         // never stored
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) dq[s] = DA_MFMA(da_tr(Kimg, G::KP, s2, s * HDP, lane), da_pack8(S, s2), dq[s]);
+        for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) dq[sp] = DA_MFMA(da_tr(Kimg, G::KP, s2, sp * HDP, lane), da_pack8(S, s2), dq[sp]);
       }
     };
     if (q0 < N) {
@@ -464,13 +480,13 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // backward, dK / dV: wave = 32 keys x both softmax heads (one shared dV accumulator); streams query tiles
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int HDP>
+template <int HDP, bool ONE>
 __global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
   typedef DaGeo<HDP> G;
-  constexpr int NKS = HDP / 16, NKD = G::DVP / 16, NDT = G::DVP / 32;
+  constexpr int NKS = HDP / 16, NKD = G::DVP / 16, NDT = G::DVP / 32, NH = ONE ? 1 : 2;
   constexpr int AP = 40;  // statistics image: [query][head s: lse(8) delta(8)] + pad
-  constexpr int QIMG = 32 * G::KP + 64, GIMG = 32 * G::VPR + 64, AIMG = 32 * AP, IMG = QIMG + 2 * GIMG + AIMG;
-  constexpr int NCH = 32 * (G::CK + 2 * G::CV + 4), CPT = (NCH + 255) / 256;
+  constexpr int QIMG = 32 * G::KP + 64, GIMG = 32 * G::VPR + 64, AIMG = 32 * AP, IMG = QIMG + NH * GIMG + AIMG;
+  constexpr int NCH = 32 * (G::CK + NH * G::CV + 2 * NH), CPT = (NCH + 255) / 256;
   __shared__ __attribute__((aligned(16))) bf lds[2 * IMG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const cenet_bid bid = cenet_xcd_block();
@@ -481,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
   const bf* qb = a.q + (long)b * N * E;
   const bf* kb = a.k + (long)b * N * E;
   const bf* vb = a.v + (long)b * N * (a.H * dv) + h * dv;
-  const long hb0 = ((long)b * 2 * a.H + 2 * h) * N;  // (b, head 2h) row base of dU / aug; head 2h+1 is N rows further
+  const long hb0 = ((long)b * NH * a.H + NH * h) * N;  // (b, head 2h) row base of dU / aug; head 2h+1 is N rows further
   const int ki = k0 + r < N ? k0 + r : N - 1;
 
   DaChunk ch[CPT];
@@ -501,17 +517,17 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
       ch[j].loff = row * G::KP + s * HDP + 8 * c8;
       ch[j].g = 8 * c8 < hd ? qb + (long)row * E + (2 * h + s) * hd + 8 * c8 : nullptr;
       gstep[j] = 32L * E;
-    } else if ((id -= 32 * G::CK) < 64 * G::CV) {  // dU rows of head s
+    } else if ((id -= 32 * G::CK) < NH * 32 * G::CV) {  // dU rows of head s
       const int s = id / (32 * G::CV), id2 = id - s * 32 * G::CV, row = id2 / G::CV, c8 = id2 - row * G::CV;
       ch[j].lrow = row;
       ch[j].loff = QIMG + s * GIMG + row * G::VPR + 8 * c8;
       ch[j].g = 8 * c8 < dv ? a.dU + (hb0 + (long)s * N + row) * dv + 8 * c8 : nullptr;
       gstep[j] = 32L * dv;
     } else {  // statistics rows: chunk (row, s, kind): kind 0 = lse / scale, 1 = delta
-      id -= 64 * G::CV;
-      const int row = id >> 2, s = (id >> 1) & 1, kind = id & 1;
+      id -= NH * 32 * G::CV;
+      const int row = id / (2 * NH), s = (id - row * 2 * NH) >> 1, kind = id & 1;
       ch[j].lrow = row;
-      ch[j].loff = QIMG + 2 * GIMG + row * AP + s * 16 + 8 * kind;
+      ch[j].loff = QIMG + NH * GIMG + row * AP + s * 16 + 8 * kind;
       ch[j].g = a.aug + (hb0 + (long)s * N + row) * 16 + 8 * kind;
       ch[j].fill = kind == 0 ? 0x7149u : 0u;  // rows beyond N: lse / scale = 1e30 -> probability 0
       gstep[j] = 32L * 16;
@@ -552,14 +568,16 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
     const bool more = q0 + 32 < N;
     if (more) fetch(q0 + 32);
     const bf* Qimg = lds + cur * IMG;
-    const bf* Aimg = Qimg + QIMG + 2 * GIMG;
+    const bf* Aimg = Qimg + QIMG + NH * GIMG;
     if (k0 < N) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < NH; ++s) {
         const bf* Gimg = Qimg + QIMG + s * GIMG;
         f32x16 S = da_zero(), dP = da_zero();
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(da_rm(Qimg, G::KP, r, s * HDP + 16 * ks, hh), kfB[s][ks], S);  // S[q][key]
+        for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp)
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(da_rm(Qimg, G::KP, r, sp * HDP + 16 * ks, hh), kfB[sp][ks], S);  // S[q][key]
 #pragma unroll
         for (int kd = 0; kd < NKD; ++kd) dP = DA_MFMA(da_rm(Gimg, G::VPR, r, 16 * kd, hh), vfB[kd], dP);  // dP[q][key] = dU V^T
         // row (query) statistics through the contraction: S -= lse / scale, dP -= delta
@@ -583,7 +601,8 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt) dV[dt] = DA_MFMA(da_tr(Gimg, G::VPR, s2, 32 * dt, lane), pB, dV[dt]);
           // dK^T[d][key] += Q^T[d][query] dS[query][key]   (accumulator rows >= hd are never stored)
-          dK[s] = DA_MFMA(da_tr(Qimg, G::KP, s2, s * HDP, lane), dsB, dK[s]);
+#pragma unroll
+          for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp) dK[sp] = DA_MFMA(da_tr(Qimg, G::KP, s2, sp * HDP, lane), dsB, dK[sp]);
         }
       }
     }
@@ -647,10 +666,10 @@ extern "C" int cenet_diffattn_heads_fwd_bf16(const cenet_diffattn_t* p, hipStrea
   if (a.hd <= 16) {
     // one 32-query tile per wave at three workgroups per CU (two tiles per wave need 256 registers and still spill)
     static const int v = getenv("CENET_DATTN_QT2") ? 2 : 1;
-    if (v == 2 && a.N >= 1024) CENET_LAUNCH((dattn_fwd_kernel<16, 2, 2>), dim3(cdiv(a.N, 256), bh), dim3(256), stream, a);
-    else CENET_LAUNCH((dattn_fwd_kernel<16, 1, 3>), dim3(cdiv(a.N, 128), bh), dim3(256), stream, a);
+    if (v == 2 && a.N >= 1024) CENET_LAUNCH((dattn_fwd_kernel<16, 2, 2, false>), dim3(cdiv(a.N, 256), bh), dim3(256), stream, a);
+    else CENET_LAUNCH((dattn_fwd_kernel<16, 1, 3, false>), dim3(cdiv(a.N, 128), bh), dim3(256), stream, a);
   } else {
-    CENET_LAUNCH((dattn_fwd_kernel<32, 1, 2>), dim3(cdiv(a.N, 128), bh), dim3(256), stream, a);
+    CENET_LAUNCH((dattn_fwd_kernel<32, 1, 2, false>), dim3(cdiv(a.N, 128), bh), dim3(256), stream, a);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
@@ -663,12 +682,52 @@ extern "C" int cenet_diffattn_heads_bwd_bf16(const cenet_diffattn_t* p, hipStrea
   if (!a.dU || !a.dq || !a.dk || !a.dv || !a.aug) return CENET_EINVAL;
   const dim3 grid(cdiv(a.N, 128), a.B * a.H);
   if (a.hd <= 16) {
-    CENET_LAUNCH((dattn_bwd_dq_kernel<16>), grid, dim3(256), stream, a);
-    CENET_LAUNCH((dattn_bwd_dkv_kernel<16>), grid, dim3(256), stream, a);
+    CENET_LAUNCH((dattn_bwd_dq_kernel<16, false>), grid, dim3(256), stream, a);
+    CENET_LAUNCH((dattn_bwd_dkv_kernel<16, false>), grid, dim3(256), stream, a);
   } else {
-    CENET_LAUNCH((dattn_bwd_dq_kernel<32>), grid, dim3(256), stream, a);
-    CENET_LAUNCH((dattn_bwd_dkv_kernel<32>), grid, dim3(256), stream, a);
+    CENET_LAUNCH((dattn_bwd_dq_kernel<32, false>), grid, dim3(256), stream, a);
+    CENET_LAUNCH((dattn_bwd_dkv_kernel<32, false>), grid, dim3(256), stream, a);
   }
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+// ---- plain self-attention with head dimension 64 through the pair tiles (ONE softmax over both 32-column halves) ------------
+// q, k, v [B, N, H*64] (token-major), U / dU [B, H, N, 64], lse [B, H, N]; ws: cenet_attn64_ws_bytes.  The caller passes
+// hd = 64; inside, a head is a "pair" of two 32-wide halves (DiffArgs.hd = 32).  Used by the Non-local block of the 56x56
+// decoder level (nlb.py:117-138, C = 64, N = 3136).
+extern "C" long cenet_attn64_ws_bytes(int B, int H, int N) { return (long)B * H * N * 16 * 2; }
+
+static int da_fill64(DiffArgs& a, const cenet_diffattn_t* p) {
+  if (!p || !p->q || !p->k || !p->v || !p->U || !p->lse) return CENET_EINVAL;
+  if (p->B <= 0 || p->H <= 0 || p->N <= 0 || p->hd != 64) return CENET_EUNSUPPORTED;
+  a.q = (const bf*)p->q; a.k = (const bf*)p->k; a.v = (const bf*)p->v;
+  a.U = (bf*)p->U; a.lse = p->lse; a.dU = (const bf*)p->dU;
+  a.dq = (bf*)p->dq; a.dk = (bf*)p->dk; a.dv = (bf*)p->dv; a.aug = (bf*)p->ws;
+  a.B = p->B; a.H = p->H; a.N = p->N; a.hd = 32; a.scale = p->scale;
+  const uintptr_t m = (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.U | (uintptr_t)a.dU | (uintptr_t)a.dq |
+                      (uintptr_t)a.dk | (uintptr_t)a.dv | (uintptr_t)a.aug;
+  if (m & 15) return CENET_EINVAL;
+  return CENET_OK;
+}
+
+extern "C" int cenet_attn64_fwd_bf16(const cenet_diffattn_t* p, hipStream_t stream) {
+  DiffArgs a;
+  const int rc = da_fill64(a, p);
+  if (rc != CENET_OK) return rc;
+  CENET_LAUNCH((dattn_fwd_kernel<32, 1, 2, true>), dim3(cdiv(a.N, 128), a.B * a.H), dim3(256), stream, a);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+extern "C" int cenet_attn64_bwd_bf16(const cenet_diffattn_t* p, hipStream_t stream) {
+  DiffArgs a;
+  const int rc = da_fill64(a, p);
+  if (rc != CENET_OK) return rc;
+  if (!a.dU || !a.dq || !a.dk || !a.dv || !a.aug) return CENET_EINVAL;
+  const dim3 grid(cdiv(a.N, 128), a.B * a.H);
+  CENET_LAUNCH((dattn_bwd_dq_kernel<32, true>), grid, dim3(256), stream, a);
+  CENET_LAUNCH((dattn_bwd_dkv_kernel<32, true>), grid, dim3(256), stream, a);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -231,6 +231,18 @@ def diffattn_heads(a: DiffAttnT, backward: bool):
     _lib.check(getattr(_lib.lib(), name)(C.byref(a), stream()), name)
 
 
+def attn64_ws_bytes(B: int, H: int, N: int) -> int:
+    fn = _lib.lib().cenet_attn64_ws_bytes
+    fn.restype = C.c_long
+    return int(fn(int(B), int(H), int(N)))
+
+
+def attn64(a: DiffAttnT, backward: bool):
+    """plain self-attention, head dimension 64, bf16 token-major tensors (attn_diff.hip, single-softmax form)"""
+    name = "cenet_attn64_bwd_bf16" if backward else "cenet_attn64_fwd_bf16"
+    _lib.check(getattr(_lib.lib(), name)(C.byref(a), stream()), name)
+
+
 def softmax_rows_fwd(x, y, rows, n):
     _chk(x, y)
     _call("cenet_softmax_rows_fwd_f32", x, y, L(rows), n)

@@ -765,6 +765,24 @@ class NonlocalAttnFn(Function):
         theta, phi, gx = _c(theta), _c(phi), _c(gx)
         B, Cn = theta.shape[:2]
         N = theta.numel() // (B * Cn)
+        ctx.tok64 = _bf(theta) and Cn == 64 and N >= 256
+        if ctx.tok64:
+            # bf16, C = 64 (the 56x56 level): token-major copies through the single-softmax form of the pair kernels
+            # (attn_diff.hip); three [64, N] -> [N, 64] transposes in, one out (~10 us each against ~2 ms saved)
+            qt, kt, vt = (torch.empty((B, N, Cn), device=theta.device, dtype=theta.dtype) for _ in range(3))
+            for src, dst in ((theta, qt), (phi, kt), (gx, vt)):
+                kern.transpose(src, Cn * N, dst, Cn * N, B, Cn, N)
+            U = torch.empty((B, 1, N, Cn), device=theta.device, dtype=theta.dtype)
+            lse = torch.empty((B, 1, N), device=theta.device, dtype=torch.float32)
+            a = kern.DiffAttnT()
+            a.q, a.k, a.v, a.U, a.lse = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr()
+            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, 64, Cn ** -0.5
+            kern.attn64(a, backward=False)
+            o = torch.empty_like(theta)
+            kern.transpose(U, N * Cn, o, Cn * N, B, N, Cn)
+            ctx.save_for_backward(qt, kt, vt, U, lse)
+            ctx.shape = theta.shape
+            return o
         st = (Cn * N, 0, 1, N)
         d = _AttnDesc(B, 1, N, N, Cn, Cn, Cn ** -0.5, 1, st, st, st, st)
         o = torch.empty_like(theta)
@@ -775,8 +793,26 @@ class NonlocalAttnFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        theta, phi, gx, o, saved = ctx.saved_tensors
         g = _c(g)
+        if ctx.tok64:
+            qt, kt, vt, U, lse = ctx.saved_tensors
+            B, N, Cn = qt.shape
+            gt = torch.empty_like(U)
+            kern.transpose(g, Cn * N, gt, N * Cn, B, Cn, N)
+            dq, dk, dv = torch.empty_like(qt), torch.empty_like(kt), torch.empty_like(vt)
+            ws = torch.empty(kern.attn64_ws_bytes(B, 1, N), device=g.device, dtype=torch.uint8)
+            a = kern.DiffAttnT()
+            a.q, a.k, a.v, a.U, a.lse, a.dU = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr(), gt.data_ptr()
+            a.dq, a.dk, a.dv, a.ws = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr()
+            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, 64, Cn ** -0.5
+            kern.attn64(a, backward=True)
+            outs = []
+            for src in (dq, dk, dv):
+                dst = torch.empty(ctx.shape, device=g.device, dtype=g.dtype)
+                kern.transpose(src, N * Cn, dst, Cn * N, B, N, Cn)
+                outs.append(dst)
+            return tuple(outs)
+        theta, phi, gx, o, saved = ctx.saved_tensors
         dt, dp, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(gx)
         _attn_backward(ctx.d, ctx.kind, saved, theta, phi, gx, o, g, dt, dp, dg)
         return dt, dp, dg

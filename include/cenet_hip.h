@@ -143,6 +143,12 @@ int cenet_diffattn_heads_supported(int hd, int N);
 long cenet_diffattn_heads_ws_bytes(int B, int H, int N);
 int cenet_diffattn_heads_fwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
 int cenet_diffattn_heads_bwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
+/* Plain self-attention with head dimension 64 on bf16 tensors through the same tiles (one softmax over both 32-column
+ * halves): q, k, v [B, N, H*64] token-major, U / dU [B, H, N, 64], lse [B, H, N], hd = 64, ws of cenet_attn64_ws_bytes.
+ * Replaces the score / softmax / value products of the Non-local block at the 56x56 decoder level (nlb.py:117-138). */
+long cenet_attn64_ws_bytes(int B, int H, int N);
+int cenet_attn64_fwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
+int cenet_attn64_bwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
 /* Row softmax for the materialised path (head dims > 128): aten::_softmax(+_backward_data).  Scores x and score gradients
  * dy are fp32 in both forms; the probabilities y and dx have the storage type of the entry point. */
 int cenet_softmax_rows_fwd_f32(const float* x, float* y, long rows, int n, cenet_stream_t stream);
