@@ -74,13 +74,27 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   if (B->mode == 1 && B->kfast && bm == 32) bn = 64;  // weight-gradient view: keep the per-thread gather list short
   // LDS-DMA ring kernel (gemm_ring.h): bf16, both operands plain with a contiguous, 16-byte aligned fast axis
   int akf = -1, bkf = -1;
-  if (bf && B->mode == 0) {
+  g.ring_unal = 0;
+  g.a_end = g.b_end = nullptr;
+  if (bf && B->mode == 0 && A->kinner == 0 && B->kinner == 0) {
     auto e8 = [](long v) { return (v & 7) == 0; };
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    const bool abase = A->kinner == 0 && e8(A->sb) && e8(A->sb2) && e8(A->skb) && al16(A->ptr);
-    const bool bbase = B->kinner == 0 && e8(B->sb) && e8(B->sb2) && e8(B->skb) && al16(B->ptr);
-    akf = (abase && A->sc == 1 && e8(A->sr) && e8(K)) ? 1 : ((abase && A->sr == 1 && e8(A->sc) && e8(M)) ? 0 : -1);
-    bkf = (bbase && B->sr == 1 && e8(B->sc) && e8(K)) ? 1 : ((bbase && B->sc == 1 && e8(B->sr) && e8(N)) ? 0 : -1);
+    akf = A->sc == 1 ? 1 : (A->sr == 1 ? 0 : -1);
+    bkf = B->sr == 1 ? 1 : (B->sc == 1 ? 0 : -1);
+    if (akf >= 0 && bkf >= 0 && A->sb >= 0 && A->sb2 >= 0 && A->skb >= 0 && B->sb >= 0 && B->sb2 >= 0 && B->skb >= 0) {
+      const long lda = akf ? A->sr : A->sc, ldb = bkf ? B->sc : B->sr;
+      const bool a_al = e8(A->sb) && e8(A->sb2) && e8(A->skb) && al16(A->ptr) && e8(lda) && e8(akf ? K : M);
+      const bool b_al = e8(B->sb) && e8(B->sb2) && e8(B->skb) && al16(B->ptr) && e8(ldb) && e8(bkf ? K : N);
+      g.ring_unal = !(a_al && b_al);
+      const long bo = (nbatch - 1) / nb_inner, bi = (nbatch < nb_inner ? nbatch : nb_inner) - 1;
+      const long a_last = bo * A->sb + bi * A->sb2 + (long)(nkb - 1) * A->skb + (akf ? (long)(M - 1) * lda + K : (long)(K - 1) * lda + M);
+      const long b_last = bo * B->sb + bi * B->sb2 + (long)(nkb - 1) * B->skb + (bkf ? (long)(N - 1) * ldb + K : (long)(K - 1) * ldb + N);
+      g.a_end = (const unsigned short*)A->ptr + a_last;
+      g.b_end = (const unsigned short*)B->ptr + b_last;
+      if (lda < 0 || ldb < 0 || a_last < 8 || b_last < 8) akf = bkf = -1;
+    } else {
+      akf = bkf = -1;
+    }
   }
   static const bool ring_off = getenv("CENET_GEMM_NO_RING") != nullptr;
   const bool ring = !ring_off && akf >= 0 && bkf >= 0 && !E->cmode && E->act == ACT_NONE && M >= 48 && N >= 48;

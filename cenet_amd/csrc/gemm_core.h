@@ -35,6 +35,11 @@ struct GemmArgs {
   int M, N, K, nkb, splits, nb_inner;
   int avec, bvec, cvec;  // quad (16-byte fp32 / 8-byte bf16) global access is legal for A / B staging / the epilogue
   int apair, bpair;      // bf16, row-contiguous operand: adjacent rows may be fetched as 4-byte pairs
+  // LDS-DMA ring kernel (gemm_ring.h) on operands whose pitch / extent / base is not a multiple of 8 elements: 16-byte
+  // chunks then start at 2-byte aligned addresses (the hardware takes them) and the last chunk of a row runs into the
+  // next row; a_end / b_end = one past the last element of the operand (a chunk that would cross it is fetched by hand)
+  int ring_unal;
+  const void *a_end, *b_end;
 };
 
 __device__ __forceinline__ unsigned f2bf_bits(float f) { return cenet_f2bf(f); }

@@ -87,7 +87,7 @@ __device__ __forceinline__ RingSrc<BX / 32> ring_src(const bf16_t* base, long ld
     } else {
       const int k = S / CH, c = (S % CH) ^ rf_key<BX>(k);
       int x = x0 + 8 * c;
-      x = x < X ? x : x0;  // X % 8 == 0: a chunk is wholly inside or wholly outside
+      x = x < X ? x : x0;  // a chunk that starts inside may run past X: those columns / rows are never stored
       s.p[j] = base + (long)k * ld + x;
       s.kofs[j] = k;
     }
@@ -95,16 +95,50 @@ __device__ __forceinline__ RingSrc<BX / 32> ring_src(const bf16_t* base, long ld
   return s;
 }
 
+// A chunk whose 16 bytes would cross the end of the operand (unaligned operands only: the last row's last chunk): fetch the
+// 8 elements that END at `end` with ordinary loads, shift the valid ones to the front, zero the rest, store to the slot.
+__device__ __forceinline__ void ring_fix_tail_chunk(const bf16_t* src, const bf16_t* end, unsigned char* slot) {
+  const int d = (int)((src + 8) - end);  // 1 .. 7 elements beyond the end
+  unsigned short in[8], out[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) in[j] = (end - 8)[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    unsigned short v = 0;
+#pragma unroll
+    for (int t = 1; t < 8; ++t)
+      if (t == d && j + t < 8) v = in[j + t];
+    out[j] = v;
+  }
+  memcpy(slot, out, 16);
+}
+
 template <bool KF, int BX>
 __device__ __forceinline__ void ring_issue(const RingSrc<BX / 32>& s, long koff, int klim, bool tail, unsigned char* img, int wave,
-                                           int lane) {
+                                           int lane, bool unal, const bf16_t* end) {
   constexpr int NI = BX / 32;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const void* src = s.p[j] + koff;
-    if (tail && s.kofs[j] >= klim) src = ring_zero16;
-    ring_glds16(src, img + (j * 4 + wave) * 1024, lane);
+    const bf16_t* src = s.p[j] + koff;
+    const bool zero = tail && s.kofs[j] >= klim;
+    unsigned char* dst = img + (j * 4 + wave) * 1024;
+    if (unal) {  // (wave-uniform)
+      const bool cross = !zero && src + 8 > end;
+      if (!cross) ring_glds16(zero ? (const void*)ring_zero16 : (const void*)src, dst, lane);  // other lanes: exec-masked DMA
+      else ring_fix_tail_chunk(src, end, dst + 16 * lane);
+    } else {
+      ring_glds16(zero ? (const void*)ring_zero16 : (const void*)src, dst, lane);
+    }
   }
+}
+
+// k-fast fragment of a K-tail tile whose K is not a multiple of 8: elements k >= klim hold the next row's data -> zero
+__device__ __forceinline__ bf16x8 ring_mask_k(bf16x8 f, int kc, int lane, int klim) {
+  const int nv = klim - (kc * 32 + 8 * (lane >> 4));  // valid elements of this lane's 8
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j >= nv) f[j] = 0;
+  return f;
 }
 
 template <bool AKF, bool BKF, int BM, int BN, int NS, bool SWAP>
@@ -168,9 +202,11 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
     const int klim = g.K - k0;
     const bool tail = klim < 64;
     unsigned char* img = lds + buf * STAGE;
-    ring_issue<AKF, BM>(sa, (long)kb * g.A.skb + (long)k0 * kstepA, klim, tail, img, wave, lane);
-    ring_issue<BKF, BN>(sb, (long)kb * g.B.skb + (long)k0 * kstepB, klim, tail, img + ABYTES, wave, lane);
+    ring_issue<AKF, BM>(sa, (long)kb * g.A.skb + (long)k0 * kstepA, klim, tail, img, wave, lane, g.ring_unal, (const bf16_t*)g.a_end);
+    ring_issue<BKF, BN>(sb, (long)kb * g.B.skb + (long)k0 * kstepB, klim, tail, img + ABYTES, wave, lane, g.ring_unal,
+                        (const bf16_t*)g.b_end);
   };
+  const bool kmask = (AKF || BKF) && (g.K & 7) != 0;  // K tails inside a 16-byte chunk of a k-fast operand
 
   // prologue: NS - 1 tiles in flight
 #pragma unroll
@@ -188,6 +224,11 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
     if (t + NS - 1 < T) issue(it0 + t + NS - 1, cur == 0 ? NS - 1 : cur - 1);
     const unsigned char* Ai = lds + cur * STAGE;
     const unsigned char* Bi = Ai + ABYTES;
+    int klim_t = 64;
+    if (kmask) {
+      const int it = it0 + t;
+      klim_t = g.K - (it - (it / ktiles) * ktiles) * 64;
+    }
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
       bf16x8 a[MI], b[NJ];
@@ -197,6 +238,16 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
         b[j] = BKF ? ring_frag_kf(Bi, wn * (BN / 2) + j * 16, kc, lane) : ring_frag_rf<BN>(Bi, wn * (BN / 2) + j * 16, kc, lane);
+      if (klim_t < 64) {  // (wave-uniform; only the last K tile of an unaligned K)
+        if (AKF) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) a[i] = ring_mask_k(a[i], kc, lane, klim_t);
+        }
+        if (BKF) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) b[j] = ring_mask_k(b[j], kc, lane, klim_t);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll

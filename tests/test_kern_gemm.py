@@ -133,7 +133,10 @@ def test_gemm_tiles_fp32_and_bf16(dev, M, N, K):
 # LDS-DMA ring kernel (gemm_ring.h): taken for bf16 operands whose contiguous axis is 16-byte aligned (extents % 8 == 0)
 # and M, N >= 48.  All four operand orientations; ragged tiles in M and N; K tails (K % 64 != 0), single K-step and chains
 # longer than the ring; row-major bf16 store with bias / residual / per-row sample scale, and the fp32 atomic split-K form.
-@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 152, 72), (136, 264, 320), (56, 48, 8), (264, 136, 456)])
+# (the last four: pitches / extents / K that are NOT multiples of 8 elements — 2-byte aligned LDS-DMA chunks, K tails
+# inside a chunk masked at the fragment, the operand's final chunk fetched by hand instead of reading past its end)
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 152, 72), (136, 264, 320), (56, 48, 8), (264, 136, 456),
+                                   (100, 49, 49), (137, 196, 200), (50, 61, 20), (49, 49, 515)])
 @pytest.mark.parametrize("akf,bkf", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_gemm_ring_orientations(dev, M, N, K, akf, bkf):
     x, w, b = rnd(M, K, dev=dev).bfloat16(), rnd(N, K, dev=dev, seed=1).bfloat16(), rnd(N, dev=dev, seed=2)
@@ -155,9 +158,11 @@ def test_gemm_ring_orientations(dev, M, N, K, akf, bkf):
     torch.testing.assert_close(acc.cpu(), F.linear(x.float(), w.float()).cpu(), rtol=1e-3, atol=1e-3)
 
 
-def test_gemm_ring_batched_kbatch(dev):
-    """per-image batches (grid z) with a per-sample scale, and the K-batch walk of the flat weight gradient"""
-    Bt, Co, Ci, HW = 3, 64, 72, 80
+@pytest.mark.parametrize("Co,Ci,HW", [(64, 72, 80), (64, 72, 49), (56, 50, 196)])
+def test_gemm_ring_batched_kbatch(dev, Co, Ci, HW):
+    """per-image batches (grid z) with a per-sample scale, and the K-batch walk of the flat weight gradient; 7x7 / 14x14
+    planes (49 / 196 pixels) are the unaligned NCHW operands of the two deepest decoder levels"""
+    Bt = 3
     w = rnd(Co, Ci, dev=dev).bfloat16()
     x = rnd(Bt, Ci, HW, dev=dev, seed=1).bfloat16()
     bs = rnd(Bt, dev=dev, seed=2)
