@@ -413,9 +413,11 @@ __global__ __launch_bounds__(256) void gate_pix_bwd_reduce_v4_kernel(const T* __
   const bool ok = p < HW;
   const long base = (long)b * C * HW + (ok ? p : 0);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
+  // gridDim.z > 1 (bf16 tensors, small maps): the channel range is split over workgroups that add into a zero-filled df
+  const int cper = (C + gridDim.z - 1) / gridDim.z, cbeg = blockIdx.z * cper, cend = cbeg + cper < C ? cbeg + cper : C;
   if (ok) {
 #pragma unroll 4
-    for (int c = cg; c < C; c += 16) {
+    for (int c = cbeg + cg; c < cend; c += 16) {
       float xv[4], gv[4];
       ld4v(xv, x + base + (long)c * HW);
       ld4v(gv, dy + base + (long)c * HW);
@@ -433,7 +435,8 @@ __global__ __launch_bounds__(256) void gate_pix_bwd_reduce_v4_kernel(const T* __
 #pragma unroll
       for (int g = 0; g < 16; ++g) t += part[g][pl];
       const float sg = sigmoid_f(f[(long)b * HW + pp]);
-      df[(long)b * HW + pp] = t * sg * (1.f - sg);
+      if (gridDim.z > 1) atomicAdd(&df[(long)b * HW + pp], t * sg * (1.f - sg));
+      else df[(long)b * HW + pp] = t * sg * (1.f - sg);
     }
   }
 }
@@ -450,14 +453,16 @@ __global__ __launch_bounds__(256) void gate_pix_bwd_reduce_kernel(const T* __res
   const bool ok = p < HW;
   const long base = (long)b * C * HW + (ok ? p : 0);
   float s = 0.f;
+  const int cper = (C + gridDim.z - 1) / gridDim.z, cbeg = blockIdx.z * cper, cend = cbeg + cper < C ? cbeg + cper : C;
   if (ok)
-    for (int c = cg; c < C; c += 4) s += ldf(x + base + (long)c * HW) * ldf(dy + base + (long)c * HW);
+    for (int c = cbeg + cg; c < cend; c += 4) s += ldf(x + base + (long)c * HW) * ldf(dy + base + (long)c * HW);
   part[cg][pl] = s;
   __syncthreads();
   if (cg == 0 && ok) {
     const float t = part[0][pl] + part[1][pl] + part[2][pl] + part[3][pl];
     const float sg = sigmoid_f(f[(long)b * HW + p]);
-    df[(long)b * HW + p] = t * sg * (1.f - sg);
+    if (gridDim.z > 1) atomicAdd(&df[(long)b * HW + p], t * sg * (1.f - sg));
+    else df[(long)b * HW + p] = t * sg * (1.f - sg);
   }
 }
 
@@ -596,14 +601,27 @@ static int gate_pix_fwd_impl(const T* x, const float* f, T* y, int B, int C, int
 }
 CENET_TWIN(gate_pix_fwd, (const T* x, const float* f, T* y, int B, int C, int HW, hipStream_t stream), (x, f, y, B, C, HW, stream))
 
+__global__ void stats_zero_kernel(float* p, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 template <typename T>
 static int gate_pix_bwd_reduce_impl(const T* x, const T* dy, const float* f, float* df, int B, int C, int HW,
                                     hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  // small maps leave the chip idle (7x7: 32 workgroups walking 2048 channels each, 206 us): split the channel range over
+  // grid.z and add into a zero-filled df.  bf16 tensors only: the fp32 (parity) mode keeps its fixed summation order.
+  int cs = 1;
+  if (sizeof(T) == 2) {
+    const long wgs = (long)cdiv(HW, 64) * B;
+    while (cs < 32 && wgs * cs < 512 && C / (cs * 2) >= 64) cs *= 2;
+  }
+  if (cs > 1) CENET_LAUNCH(stats_zero_kernel, dim3(cdiv(B * HW, 256)), dim3(256), stream, df, (long)B * HW);
   if ((HW & 3) == 0 && quad_aligned<T>(x) && quad_aligned<T>(dy))
-    CENET_LAUNCH((gate_pix_bwd_reduce_v4_kernel<T>), dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
+    CENET_LAUNCH((gate_pix_bwd_reduce_v4_kernel<T>), dim3(cdiv(HW, 64), B, cs), dim3(256), stream, x, dy, f, df, C, HW);
   else
-    CENET_LAUNCH((gate_pix_bwd_reduce_kernel<T>), dim3(cdiv(HW, 64), B), dim3(256), stream, x, dy, f, df, C, HW);
+    CENET_LAUNCH((gate_pix_bwd_reduce_kernel<T>), dim3(cdiv(HW, 64), B, cs), dim3(256), stream, x, dy, f, df, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -108,7 +108,9 @@ def test_layernorm_and_residual_form(dev, rows, C):
     compare(res, [x], [gm, bt], dev=dev)
 
 
-@pytest.mark.parametrize("B,C,H,W,act", [(3, 5, 14, 14, "none"), (2, 4, 28, 28, "relu"), (4, 3, 7, 7, "lrelu")])
+# (planes of up to 1024 pixels take the flat small-plane kernels in bf16; 40x40 the plane-per-workgroup ones)
+@pytest.mark.parametrize("B,C,H,W,act", [(3, 5, 14, 14, "none"), (2, 4, 28, 28, "relu"), (4, 3, 7, 7, "lrelu"),
+                                         (2, 4, 40, 40, "relu"), (2, 3, 9, 5, "none")])
 def test_batchnorm(dev, B, C, H, W, act):
     g = G(B + C + H)
     x = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
@@ -199,7 +201,8 @@ def test_resampling(dev, kw):
     compare(lambda x, w: ops.maxpool2_scale(x, w), [x], [torch.rand(1, 3, 1, 1, generator=g) + 0.5], dev=dev)
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 6, 8, 8), (3, 4, 7, 7), (1, 4, 8, 8)])
+# (C = 256 on a 7x7 map: the channel-split form of the SRM gate reduction, bf16 only)
+@pytest.mark.parametrize("B,C,H,W", [(2, 6, 8, 8), (3, 4, 7, 7), (1, 4, 8, 8), (2, 256, 7, 7)])
 def test_ccu_and_srm(dev, B, C, H, W):
     g = G(B + C + H)
     x = torch.randn(B, C, H, W, generator=g) + 0.2

@@ -72,6 +72,14 @@ for stage, label, e0, e1 in log:
     st[stage][label][1] += ms
     tot[stage][0] += 1
     tot[stage][1] += ms
+print(f"all bracketed calls: {sum(v[0] for v in tot.values())} calls, {sum(v[1] for v in tot.values()):.3f} ms (single stream)")
+fam = collections.defaultdict(lambda: [0, 0.0])
+for stage, label, e0, e1 in log:
+    k = label.split(" ")[0]
+    fam[k][0] += 1
+    fam[k][1] += e0.elapsed_time(e1)
+for k, (n, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:45]:
+    print(f"   {ms:7.3f} ms {n:4d}x {ms / n * 1e3:7.1f} us  {k}")
 print(f"{'stage':36s} {'calls':>6s} {'ms':>8s}")
 for stage, (n, ms) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print(f"{stage:36s} {n:6d} {ms:8.3f}")
