@@ -33,7 +33,7 @@ class EpiT(C.Structure):
                 ("atomic", C.c_int), ("alpha", C.c_float),
                 ("cmode", C.c_int), ("cKH", C.c_int), ("cKW", C.c_int), ("cPw", C.c_int), ("cHs", C.c_int),
                 ("cWs", C.c_int), ("cstride", C.c_int), ("cpad", C.c_int),
-                ("csci", C.c_long), ("csy", C.c_long), ("csx", C.c_long), ("bscale_rows", C.c_int)]
+                ("csci", C.c_long), ("csy", C.c_long), ("csx", C.c_long), ("bscale_rows", C.c_int), ("asum", C.c_void_p)]
 
 
 def lib():

@@ -27,6 +27,48 @@ static thread_local char g_last_kernel[96] = "";
 extern "C" const char* cenet_gemm_last_kernel(void) { return g_last_kernel; }
 static inline const char* tf(bool b) { return b ? "true" : "false"; }
 
+// asum fallback for contractions the ring kernel does not take: asum[m] += sum over (kb, k) of A[kb*skb + m*sr + k*sc]
+template <typename GT>
+__global__ __launch_bounds__(256) void gemm_asum_kernel(const GT* __restrict__ A, long sr, long sc, long skb, int M, int K, int nkb,
+                                                       float* __restrict__ asum) {
+  __shared__ float red[16];
+  if (sr == 1 && sc != 1) {  // rows contiguous: thread = row, grid.y slices the reduction
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const long total = (long)nkb * K;
+    float s = 0.f;
+    for (long e = blockIdx.y; e < total; e += gridDim.y) {
+      const long kb = e / K, k = e - kb * K;
+      s += ldf(A + kb * skb + k * sc + m);
+    }
+    atomicAdd(&asum[m], s);
+  } else {  // workgroup = row, threads along k
+    const int m = blockIdx.x;
+    const long total = (long)nkb * K;
+    float s = 0.f;
+    for (long e = blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
+      const long kb = e / K, k = e - kb * K;
+      s += ldf(A + kb * skb + (long)m * sr + k * sc);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(&asum[m], s);
+  }
+}
+template <typename GT>
+static void launch_asum(const cenet_mat_t* A, int M, int K, int nkb, float* asum, hipStream_t stream) {
+  const long total = (long)nkb * K;
+  if (A->sr == 1 && A->sc != 1) {
+    int ys = (int)((total + 511) / 512);
+    if (ys > 256) ys = 256;
+    CENET_LAUNCH((gemm_asum_kernel<GT>), dim3(cdiv(M, 256), ys), dim3(256), stream, (const GT*)A->ptr, A->sr, A->sc, A->skb, M, K,
+                 nkb, asum);
+  } else {
+    int ys = (int)((total + 8191) / 8192);
+    if (ys > 64) ys = 64;
+    CENET_LAUNCH((gemm_asum_kernel<GT>), dim3(M, ys), dim3(256), stream, (const GT*)A->ptr, A->sr, A->sc, A->skb, M, K, nkb, asum);
+  }
+}
+
 static inline bool m4(long v) { return (v & 3) == 0; }
 static inline bool m2(long v) { return (v & 1) == 0; }
 
@@ -38,6 +80,7 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   if (A->mode != 0) return CENET_EUNSUPPORTED;
   if (splits > 1 && !E->atomic) return CENET_EINVAL;
   if (E->atomic && (E->bias || E->R || E->act != ACT_NONE || E->bscale)) return CENET_EINVAL;
+  if (E->asum && (!E->atomic || nbatch != 1 || A->kinner != 0)) return CENET_EINVAL;
   const bool bf = esz == 2;
   const uintptr_t qmask = 4 * esz - 1;  // a quad of elements: 16 bytes (fp32) / 8 bytes (bf16)
   auto alq = [&](const void* p) { return ((uintptr_t)p & qmask) == 0; };
@@ -129,6 +172,10 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
     rc = akf ? (bkf ? cenet_gemm_launch_ring_kk(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_ring_kr(g, bm, bn, nbatch, swap, stream))
              : (bkf ? cenet_gemm_launch_ring_rk(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_ring_rr(g, bm, bn, nbatch, swap, stream));
   } else if (bf) {
+    if (E->asum) {
+      launch_asum<unsigned short>(A, M, K, nkb, E->asum, stream);
+      g.E.asum = nullptr;
+    }
     // plain operands with a reduction of at least two 64-steps: K step 64 halves the barriers and the serial
     // load -> LDS -> MFMA round trips of the (mostly latency-bound) mid-size contractions
     // (measured: a gain for the 64x64 / 32x64 tiles that these small launches get, a loss for the 128-wide tiles, whose
@@ -144,6 +191,10 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
                    : cenet_gemm_launch_bf16_plain(g, bm, bn, nbatch, swap, stream));
   }
   else {
+    if (E->asum) {
+      launch_asum<float>(A, M, K, nkb, E->asum, stream);
+      g.E.asum = nullptr;
+    }
     snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_kernel<float, %d, %d, %s, %s, 32>", bm, bn, tf(im), tf(swap));
     rc = im ? cenet_gemm_launch_f32_im2col(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_f32_plain(g, bm, bn, nbatch, swap, stream);
   }

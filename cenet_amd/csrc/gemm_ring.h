@@ -207,6 +207,11 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
                         (const bf16_t*)g.b_end);
   };
   const bool kmask = (AKF || BKF) && (g.K & 7) != 0;  // K tails inside a 16-byte chunk of a k-fast operand
+  // bias gradient riding in the weight-gradient pass: row sums of A, taken from the fragments of the first column of tiles
+  const bool do_asum = g.E.asum != nullptr && bx == 0 && wn == 0;
+  float rsum[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) rsum[i] = 0.f;
 
   // prologue: NS - 1 tiles in flight
 #pragma unroll
@@ -248,6 +253,12 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
           for (int j = 0; j < NJ; ++j) b[j] = ring_mask_k(b[j], kc, lane, klim_t);
         }
       }
+      if (do_asum) {  // (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rsum[i] += cenet_bf2f((unsigned short)a[i][j]);
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -256,6 +267,16 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  if (do_asum) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float v = rsum[i];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int row = m0 + wm * (BM / 2) + i * 16 + lane;
+      if (lane < 16 && row < g.M) atomicAdd(&g.E.asum[row], v);
+    }
   }
   __syncthreads();  // the ring is free: the atomic epilogue uses it as its transpose strip
   gemm_epilogue<bf16_t, BM, BN, SWAP>(g, acc, (float*)lds, m0, n0, bo, bi, batch, wave, lane);

@@ -100,8 +100,10 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
          act: str = "none", slope: float = 0.0, bscale: Optional[torch.Tensor] = None,
          R: Optional[torch.Tensor] = None, srb: int = 0, srr: int = 0, src: int = 0, atomic: bool = False,
          alpha: float = 1.0, c_offset: int = 0, r_offset: int = 0, nb_inner: int = 1, scb2: int = 0, srb2: int = 0,
-         col2im: Optional[dict] = None, bscale_rows: int = 0):
-    _chk(Cout, bias, bscale, R)
+         col2im: Optional[dict] = None, bscale_rows: int = 0, asum: Optional[torch.Tensor] = None):
+    """asum (atomic contractions, nbatch == 1): fp32 vector that receives asum[m] += sum_k A[m, k] — the bias gradient riding
+    in the weight-gradient pass"""
+    _chk(Cout, bias, bscale, R, asum)
     if A.bf16 != B.bf16:
         raise TypeError("cenet_gemm: A and B must have the same element type (fp32 or bf16)")
     want = torch.float32 if (atomic or not A.bf16) else BF16  # atomic epilogues always add into fp32
@@ -116,6 +118,7 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
     e.act, e.slope = ACT[act], slope
     e.bscale = bscale.data_ptr() if bscale is not None else None
     e.bscale_rows = bscale_rows
+    e.asum = asum.data_ptr() if asum is not None else None
     e.R = (R.data_ptr() + esz(R) * r_offset) if R is not None else None
     e.srb, e.srb2, e.srr, e.src = srb, srb2, srr, src
     e.atomic, e.alpha = int(atomic), alpha

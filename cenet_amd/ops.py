@@ -182,10 +182,11 @@ class LinearFn(Function):
         if dW is not None or db is not None:
             with _wgrad_side(gs, x):
                 if dW is not None:
+                    # the bias gradient (column sums of the output gradient) rides in the weight-gradient pass (asum)
                     iters = (R + 31) // 32
                     kern.gemm(kern.mat_plain(gs, 1, N, kfast=0), kern.mat_plain(x, K, 1, kfast=0), dW, N, K, R, scr=K, scc=1,
-                              splits=kern.pick_splits(N, K, 1, iters), atomic=True)
-                if db is not None:
+                              splits=kern.pick_splits(N, K, 1, iters), atomic=True, asum=db)
+                elif db is not None:
                     kern.col_sum(gs, db, R, N)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -235,8 +236,8 @@ class Conv1x1Fn(Function):
                     iters = B * ((HW + 31) // 32)
                     kern.gemm(kern.mat_plain(g, HW, 1, skb=Cout * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Cin * HW, kfast=1),
                               dW, Cout, Cin, HW, scr=Cin, scc=1, nkb=B, splits=kern.pick_splits(Cout, Cin, 1, iters),
-                              atomic=True)
-                if db is not None:
+                              atomic=True, asum=db)
+                elif db is not None:
                     kern.chan_dot(g, Cout * HW, None, 0, db, B, Cout, HW)
         dx = None
         if ctx.needs_input_grad[0]:

@@ -68,6 +68,10 @@ typedef struct {
   /* > 0: bscale is indexed by (row / bscale_rows) instead of by batch -- a [B, n, K] activation run as ONE flat GEMM of
    * B*n rows with the per-sample DropPath scale of pvtv2.py:117-118 still applied per sample (bscale_rows = n). */
   int bscale_rows;
+  /* atomic (weight-gradient) contractions only: asum[m] += sum_k A[m, k] over the whole reduction (all k-batches) -- the
+   * bias gradient that goes with the weight gradient dW = dY^T X (A = dY^T), folded into the pass that already reads dY
+   * instead of a second sweep (aten::sum of the linear / 1x1-convolution backward).  fp32, may be NULL. */
+  float* asum;
 } cenet_epi_t;
 
 /* Replaces aten::addmm/mm/bmm/convolution(+_backward) — pvtv2.py:41,45,90,98,106,164; cfam.py:149,158,299,302;

@@ -57,10 +57,19 @@ def test_gemm_splitk_atomic_kbatch(dev):
     Bt, Co, Ci, HW = 4, 10, 12, 50
     dy, x = rnd(Bt, Co, HW, dev=dev), rnd(Bt, Ci, HW, dev=dev, seed=1)
     dw = torch.zeros(Co, Ci, device=dev)
+    db = torch.zeros(Co, device=dev)
     kern.gemm(kern.mat_plain(dy, HW, 1, skb=Co * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Ci * HW, kfast=1), dw,
-              Co, Ci, HW, scr=Ci, scc=1, nkb=Bt, splits=3, atomic=True)
+              Co, Ci, HW, scr=Ci, scc=1, nkb=Bt, splits=3, atomic=True, asum=db)
     ref = torch.einsum("bop,bip->oi", dy, x)
     torch.testing.assert_close(dw.cpu(), ref.cpu(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), dy.sum((0, 2)).cpu(), rtol=1e-4, atol=1e-4)  # asum through the fallback reduction
+    dbt = torch.zeros(Ci, device=dev)  # and with a row-contiguous A
+    xt = x.permute(0, 2, 1).contiguous()  # [Bt, HW, Ci]
+    d2 = torch.zeros(Ci, Co, device=dev)
+    kern.gemm(kern.mat_plain(xt, 1, Ci, skb=HW * Ci, kfast=0), kern.mat_plain(dy, 1, HW, skb=Co * HW, kfast=1), d2,
+              Ci, Co, HW, scr=Co, scc=1, nkb=Bt, splits=2, atomic=True, asum=dbt)
+    torch.testing.assert_close(d2.cpu(), ref.t().cpu(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dbt.cpu(), x.sum((0, 2)).cpu(), rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("k,stride,pad,dil", [(3, 1, 1, 1), (7, 4, 3, 1), (3, 2, 1, 1), (2, 2, 0, 1), (5, 1, 2, 1)])
@@ -154,8 +163,10 @@ def test_gemm_ring_orientations(dev, M, N, K, akf, bkf):
     kern.gemm(A, Bm, yt, M, N, K, scr=1, scc=M)
     torch.testing.assert_close(yt.float().cpu(), F.linear(x.float(), w.float()).t().cpu(), rtol=1e-2, atol=2e-2)
     acc = torch.zeros(M, N, device=dev)
-    kern.gemm(A, Bm, acc, M, N, K, scr=N, scc=1, splits=3, atomic=True)
+    rs = torch.zeros(M, device=dev)  # asum: row sums of A (the bias gradient of a weight-gradient contraction)
+    kern.gemm(A, Bm, acc, M, N, K, scr=N, scc=1, splits=3, atomic=True, asum=rs)
     torch.testing.assert_close(acc.cpu(), F.linear(x.float(), w.float()).cpu(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(rs.cpu(), x.float().sum(1).cpu(), rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("Co,Ci,HW", [(64, 72, 80), (64, 72, 49), (56, 50, 196)])
@@ -172,7 +183,8 @@ def test_gemm_ring_batched_kbatch(dev, Co, Ci, HW):
     ref = torch.matmul(w.float(), x.float()) * bs[:, None, None]
     torch.testing.assert_close(y.float().cpu(), ref.cpu(), rtol=1e-2, atol=2e-2)
     dy = rnd(Bt, Co, HW, dev=dev, seed=3).bfloat16()
-    dw = torch.zeros(Co, Ci, device=dev)
+    dw, db = torch.zeros(Co, Ci, device=dev), torch.zeros(Co, device=dev)
     kern.gemm(kern.mat_plain(dy, HW, 1, skb=Co * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Ci * HW, kfast=1), dw,
-              Co, Ci, HW, scr=Ci, scc=1, nkb=Bt, splits=2, atomic=True)
+              Co, Ci, HW, scr=Ci, scc=1, nkb=Bt, splits=2, atomic=True, asum=db)
     torch.testing.assert_close(dw.cpu(), torch.einsum("bop,bip->oi", dy.float(), x.float()).cpu(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), dy.float().sum((0, 2)).cpu(), rtol=1e-4, atol=1e-3)
