@@ -634,6 +634,23 @@ def conv_direct(x, w, y, B, Cin, Cout, H, W, k, dgrad):
     _lib.check(rc, "cenet_conv_direct_bf16")
 
 
+def conv_c1_supported(Cin: int, Cout: int, k: int, stride: int, pad: int) -> bool:
+    return bool(_lib.lib().cenet_conv_c1_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
+
+
+def conv_c1_fwd(x, w, y, B, Cout, H, W, k):
+    """one-channel bf16 image -> Cout <= 32 channels, stride 1, same padding (conv_c1.hip)"""
+    _chk(x, w, y)
+    assert x.dtype == BF16 and y.dtype == BF16 and w.dtype == torch.float32
+    _lib.check(_lib.lib().cenet_conv_c1_fwd_bf16(P(x), P(w), P(y), B, Cout, H, W, k, stream()), "cenet_conv_c1_fwd_bf16")
+
+
+def conv_c1_wgrad(x, dy, dw, B, Cout, H, W, k):
+    _chk(x, dy, dw)
+    assert x.dtype == BF16 and dy.dtype == BF16 and dw.dtype == torch.float32
+    _lib.check(_lib.lib().cenet_conv_c1_wgrad_bf16(P(x), P(dy), P(dw), B, Cout, H, W, k, stream()), "cenet_conv_c1_wgrad_bf16")
+
+
 def conv_wgrad_direct_supported(Cin: int, Cout: int, k: int, stride: int, pad: int) -> bool:
     return bool(_lib.lib().cenet_conv_wgrad_direct_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
 

@@ -214,8 +214,14 @@ class Conv1x1Fn(Function):
         Cout = W.shape[0]
         y = _act((B, Cout) + tuple(x.shape[2:]), x)
         resid = _c(resid)
-        kern.gemm(kern.mat_plain(kern.wq(W, x), Cin, 1, kfast=1), kern.mat_plain(x, HW, 1, sb=Cin * HW), y, Cout, HW, Cin, scr=HW,
-                  scc=1, scb=Cout * HW, nbatch=B, bias=b, bias_on_row=True, R=resid, srb=Cout * HW, srr=HW, src=1)
+        # the shortcut 1x1 convolution of the one-channel network input (unet.py conv3): a stencil, not a K = 1 GEMM
+        ctx.c1 = bool(_bf(x) and Cin == 1 and b is None and resid is None and x.dim() == 4
+                      and kern.conv_c1_supported(1, Cout, 1, 1, 0))
+        if ctx.c1:
+            kern.conv_c1_fwd(x, W, y, B, Cout, x.shape[2], x.shape[3], 1)
+        else:
+            kern.gemm(kern.mat_plain(kern.wq(W, x), Cin, 1, kfast=1), kern.mat_plain(x, HW, 1, sb=Cin * HW), y, Cout, HW, Cin,
+                      scr=HW, scc=1, scb=Cout * HW, nbatch=B, bias=b, bias_on_row=True, R=resid, srb=Cout * HW, srr=HW, src=1)
         ctx.save_for_backward(x, W)
         ctx.refs = (W, b)
         ctx.has_resid = resid is not None
@@ -232,7 +238,9 @@ class Conv1x1Fn(Function):
         dW, db = grad_buf(Wp), grad_buf(bp)
         if dW is not None or db is not None:
             with _wgrad_side(g, x):
-                if dW is not None:
+                if dW is not None and ctx.c1:
+                    kern.conv_c1_wgrad(x, g, dW, B, Cout, x.shape[2], x.shape[3], 1)
+                elif dW is not None:
                     iters = B * ((HW + 31) // 32)
                     kern.gemm(kern.mat_plain(g, HW, 1, skb=Cout * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Cin * HW, kfast=1),
                               dW, Cout, Cin, HW, scr=Cin, scc=1, nkb=B, splits=kern.pick_splits(Cout, Cin, 1, iters),
@@ -267,6 +275,15 @@ class Conv2dFn(Function):
         Kd = Cin * k * k
         plain_nchw = (sb == Cin * H * Wd and sc == H * Wd and sy == Wd and sx == 1 and out_layout == "nchw" and b is None)
         ctx.direct = bool(plain_nchw and _bf(x) and kern.conv_direct_supported(Cin, Cout, k, stride, pad))
+        ctx.c1 = bool(plain_nchw and _bf(x) and not ctx.direct and kern.conv_c1_supported(Cin, Cout, k, stride, pad))
+        if ctx.c1:  # bf16, the two convolutions that read the one-channel network input (conv_c1.hip)
+            y = _act((B, Cout, Ho, Wo), x)
+            kern.conv_c1_fwd(x, W, y, B, Cout, H, Wd, k)
+            ctx.save_for_backward(x, W)
+            ctx.refs = (W, b)
+            ctx.geom = geom
+            ctx.out_hw = (Ho, Wo)
+            return y
         if ctx.direct:  # bf16 tensors, output-head convs: LDS-halo direct convolution (conv_direct.hip)
             y = _act((B, Cout, Ho, Wo), x)
             kern.conv_direct(x, W, y, B, Cin, Cout, H, Wd, k, 0)
@@ -347,7 +364,9 @@ class Conv2dFn(Function):
         dW, db = grad_buf(Wp), grad_buf(bp)
         if dW is not None or db is not None:
             with _wgrad_side(g, x):
-                if (dW is not None and getattr(ctx, "direct", False) and _bf(g)
+                if dW is not None and getattr(ctx, "c1", False) and _bf(g):
+                    kern.conv_c1_wgrad(x, g, dW, B, Cout, H, Wd, k)
+                elif (dW is not None and getattr(ctx, "direct", False) and _bf(g)
                         and kern.conv_wgrad_direct_supported(Cin, Cout, k, stride, pad)):
                     kern.conv_wgrad_direct(x, g, dW, B, Cin, Cout, H, Wd, k)  # conv_direct.hip, direct weight gradient
                 elif dW is not None:

@@ -97,6 +97,14 @@ int cenet_conv_direct_bf16(const unsigned short* x, const float* w, unsigned sho
 /* Weight gradient of the same convolutions in the same mode (replaces the implicit-GEMM wgrad of unet.py:156-197,
  * blocks.py:211, out.py:41-49 for 5x5 32->32 and 3x3 64->64 / 64->32): dw_acc[Cout,Cin,k,k] += dY (*) X.
  * ws: cenet_conv_wgrad_direct_ws_floats(Cin, Cout, k) floats of scratch (per-workgroup partial sums). */
+/* One-channel input (the network image) into Cout <= 32 channels, stride 1, pad k/2, k in {1, 3, 5}, bf16 tensors
+ * (conv_c1.hip): the residual block of the output head that reads x (out.py:41-44; unet.py:156-197 conv1 / conv3).
+ * Forward y = w (*) x and the weight gradient dw_acc += dy (*) x; the image itself needs no gradient. */
+int cenet_conv_c1_supported(int Cin, int Cout, int k, int stride, int pad);
+int cenet_conv_c1_fwd_bf16(const unsigned short* x, const float* w, unsigned short* y, int B, int Cout, int H, int W, int k,
+    cenet_stream_t stream);
+int cenet_conv_c1_wgrad_bf16(const unsigned short* x, const unsigned short* dy, float* dw_acc, int B, int Cout, int H, int W,
+    int k, cenet_stream_t stream);
 int cenet_conv_wgrad_direct_supported(int Cin, int Cout, int k, int stride, int pad);
 long cenet_conv_wgrad_direct_ws_floats(int Cin, int Cout, int k);
 int cenet_conv_wgrad_direct_bf16(const unsigned short* x, const unsigned short* dy, float* dw_acc, float* ws, int B, int Cin,

@@ -76,6 +76,14 @@ def test_conv1x1(dev, B, Cin, Cout, H, W):
     compare(lambda x, r, Wt, b: ops.conv1x1(x, Wt, b, resid=r), [x, r], [Wt, b], dev=dev)
 
 
+def test_conv1x1_one_channel_input(dev):
+    """the shortcut 1x1 convolution of the one-channel network input (unet.py conv3): stencil kernels in bf16"""
+    g = G(3)
+    x = torch.randn(2, 1, 9, 140, generator=g)
+    Wt = torch.randn(32, 1, 1, 1, generator=g) * 0.5
+    compare(lambda x, Wt: ops.conv1x1(x, Wt), [x], [Wt], dev=dev)
+
+
 @pytest.mark.parametrize("Cin,Cout,k,s,H,expand,layout", [(1, 16, 7, 4, 32, 3, "tok"), (16, 24, 3, 2, 16, 0, "tok"),
                                                           (8, 12, 3, 1, 9, 0, "nchw"), (4, 6, 1, 1, 7, 0, "nchw")])
 def test_conv2d_implicit_gemm(dev, Cin, Cout, k, s, H, expand, layout):
@@ -87,6 +95,17 @@ def test_conv2d_implicit_gemm(dev, Cin, Cout, k, s, H, expand, layout):
             [x], [Wt, b], dev=dev)
 
 
+# the one-channel stencils of conv_c1.hip (bf16 only; fp32 takes the implicit GEMM): k = 5 / 3 / 1, full 128-column tiles with
+# a ragged last one (W = 140), a width that is not a multiple of 4 (scalar stores), several row groups per workgroup.  The
+# input needs no gradient in the network; here x does, which exercises the generic data-gradient path behind the special forward.
+@pytest.mark.parametrize("Cout,k,H,W", [(32, 5, 20, 140), (32, 1, 9, 132), (12, 3, 11, 30), (32, 5, 7, 9)])
+def test_conv_one_channel_input(dev, Cout, k, H, W):
+    g = G(Cout + k + W)
+    x = torch.randn(2, 1, H, W, generator=g)
+    Wt = torch.randn(Cout, 1, k, k, generator=g) * 0.2
+    compare(lambda x, Wt: ops.conv2d_nchw(x, Wt, None, stride=1, pad=k // 2), [x], [Wt], dev=dev)
+
+
 @pytest.mark.parametrize("B,C,Cout,H,W,s", [(2, 16, 24, 8, 8, 2), (1, 64, 40, 8, 8, 4)])
 def test_sr_conv_tok(dev, B, C, Cout, H, W, s):
     g = G(C + s)
@@ -95,7 +114,8 @@ def test_sr_conv_tok(dev, B, C, Cout, H, W, s):
     compare(lambda x, Wt, b: ops.conv2d_tok(x, H, W, Wt, b, stride=s, pad=0, out_layout="tok"), [x], [Wt, b], dev=dev)
 
 
-@pytest.mark.parametrize("rows,C", [(37, 64), (33, 320), (21, 50)])
+# (C % 8 == 0: the 16-byte backward kernel, one instantiation per width class 64 / 128 / 256 / 512; C = 50: quad-free path)
+@pytest.mark.parametrize("rows,C", [(37, 64), (33, 320), (21, 50), (70, 128), (19, 512), (45, 200)])
 def test_layernorm_and_residual_form(dev, rows, C):
     g = G(rows + C)
     x = torch.randn(rows, C, generator=g) * 2 + 0.5
