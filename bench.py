@@ -178,16 +178,27 @@ class _Trace:
         return g
 
 
+def _hold_stream(ms=60.0):
+    """Parks the stream behind a spin kernel so that the host queues the whole instrumented step before the GPU starts it:
+    the intervals between two events then are kernel durations (as rocprofv3 reports them), not host launch gaps."""
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(ms * 1e-3 * 2.0e9))  # cycles of the ~2 GHz shader clock
+
+
 def roofline_block(body, steps=3):
     """dominant kernel instance of the step (largest summed duration among the bracketed launches)"""
+    from cenet_amd import ops
     tr = _Trace()
     tr.install()
+    old = ops.set_wgrad_overlap(False)  # one stream: an interval then never contains a wait for the other stream
     try:
         for _ in range(steps):
+            _hold_stream()
             body()
         g = tr.groups(steps)
     finally:
         tr.remove()
+        ops.set_wgrad_overlap(old)
     # GEMM groups are exact kernel symbols; an attention-backward call launches two symbols (dQ and dK/dV kernels of similar
     # length) on one entry, so its group competes with half its time
     def weight(kv):
@@ -217,7 +228,8 @@ def roofline_block(body, steps=3):
     out["traffic"] = traffic
     if src:
         out["traffic_source"] = src
-    out["method"] = "HIP events around every launch of this instance in %d instrumented steps, on the launching stream" % steps
+    out["method"] = ("HIP events around every launch of this instance in %d instrumented steps (one stream, the stream parked behind a "
+                     "spin kernel while the host queues the step, so intervals are kernel durations)" % steps)
     fams = sorted(((k, v[0]) for k, v in g.items()), key=lambda kv: -kv[1])[:6]
     out["next_kernels_ms_per_step"] = {k: round(v, 3) for k, v in fams[1:]}
     return out
@@ -228,7 +240,11 @@ def stage_block(net, body, B, size, steps=3):
     from cenet_amd import ops
     old = ops.set_wgrad_overlap(False)
     ev = {k: {"f": [], "b": []} for k in STAGES}
-    nograd = {"backbone.patch_embed1": None, "out.rb": None}
+    # the two stages fed by the network input: nothing upstream needs a gradient, so their full-backward hook fires before
+    # their kernels run.  Their interval is closed by the NEXT backward pre-hook that fires (autograd runs out.rb between
+    # out.up and decoder.dec1) or, for patch_embed1 (last of the pass), by an event recorded when loss.backward() returns.
+    nograd = ("backbone.patch_embed1", "out.rb")
+    order = []  # (stage, start event) of every backward pre-hook, in firing order
     handles = []
     mods = dict(net.named_modules())
 
@@ -236,8 +252,6 @@ def stage_block(net, body, B, size, steps=3):
         st = {}
 
         def fpre(mod, inp):
-            if name in nograd:
-                nograd[name] = (mod, inp)
             st["f0"] = torch.cuda.Event(enable_timing=True)
             st["f0"].record()
 
@@ -249,8 +263,11 @@ def stage_block(net, body, B, size, steps=3):
         def bpre(mod, gout):
             st["b0"] = torch.cuda.Event(enable_timing=True)
             st["b0"].record()
+            order.append((name, st["b0"]))
 
         def bpost(mod, gin, gout):
+            if name in nograd:
+                return
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             ev[name]["b"].append((st["b0"], e))
@@ -262,33 +279,23 @@ def stage_block(net, body, B, size, steps=3):
         # one by one) are hooked per child; a child that is never called (the MaxPool2d folded into ops.maxpool2_scale) adds 0
         for sub in (list(m) if isinstance(m, (torch.nn.ModuleList, torch.nn.Sequential)) else [m]):
             hook(name, sub)
+
+    def after_backward():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        order.append(("<end of backward>", e))
     try:
         for _ in range(steps):
-            body()
+            _hold_stream()
+            body(after_backward=after_backward)
         torch.cuda.synchronize()
     finally:
         for h in handles:
             h.remove()
-    # the two stages fed by the network input: nothing upstream needs a gradient, so their full-backward hooks fire before
-    # their kernels run.  Their backward is timed stand-alone on the tensors they saw in the step.
-    try:
-        for name, rec in nograd.items():
-            if rec is None:
-                continue
-            mod, inp = rec
-            ev[name]["b"] = []
-            for _ in range(steps):
-                y = mod(*inp)
-                y = y[0] if isinstance(y, (tuple, list)) else y
-                g = torch.ones_like(y)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                y.backward(g)
-                e1.record()
-                ev[name]["b"].append((e0, e1))
-        torch.cuda.synchronize()
-    finally:
         ops.set_wgrad_overlap(old)
+    for i, (name, e0) in enumerate(order[:-1]):
+        if name in nograd:
+            ev[name]["b"].append((e0, order[i + 1][1]))
     peak = peak_tflops()
     scale_f = (size / 224.0) ** 2
     out = {}
@@ -381,10 +388,12 @@ def main():
     crit = losses.Criterion(cfg["classes"], argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
     x, lab = synthetic(B, dev, seed=1234 + rank, cfg=cfg)
 
-    def body(sync_hyper=True):
+    def body(sync_hyper=True, after_backward=None):
         opt.zero_grad()
         loss = crit(net(x), lab)
         loss.backward()
+        if after_backward is not None:  # (instrumented passes only)
+            after_backward()
         if reducer is not None:
             reducer.finish()
         opt.step(sync_hyper=sync_hyper)
