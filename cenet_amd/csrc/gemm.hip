@@ -142,7 +142,28 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   static const bool ring_off = getenv("CENET_GEMM_NO_RING") != nullptr;
   const bool ring = !ring_off && akf >= 0 && bkf >= 0 && !E->cmode && E->act == ACT_NONE && M >= 48 && N >= 48;
   if (ring) {
-    bm = bn = (M >= 96 && N >= 96 && (E->atomic || (long)cdiv(M, 128) * cdiv(N, 128) * nbatch >= 256)) ? 128 : 64;
+    // tile choice, from a sweep of every GEMM shape of a training step over the four tiles (tools/gemm_sweep.sh): the
+    // 64x64 tile with its 4-stage ring wins wherever the reduction is long (the step's contractions are latency-bound:
+    // pipeline depth beats tile size); the 2-stage 128x128 tile only pays for short reductions with enough tiles to fill
+    // the chip; big skinny weight gradients take a 3-stage rectangular tile (fewer re-reads of the long operand, half
+    // the atomic traffic).
+    static const char* force = getenv("CENET_RING_TILE");  // "128x64" etc.: measurement aid
+    if (force) {
+      sscanf(force, "%dx%d", &bm, &bn);
+    } else if (E->atomic) {
+      bm = bn = 64;
+      if ((long)K * nkb >= 4096 && (long)M * N >= 131072) {
+        if (N >= 128) bn = 128;
+        else bm = 128;
+      }
+    } else {
+      bm = M >= 96 ? 128 : 64;
+      bn = N >= 96 ? 128 : 64;
+      const long want = K >= 320 ? 400 : 256;
+      auto wgs = [&](int a, int b) { return (long)cdiv(M, a) * cdiv(N, b) * nbatch; };
+      if (wgs(bm, bn) < want && bm == 128 && bn == 128) (M >= N ? bm : bn) = 64;
+      if (wgs(bm, bn) < want && (bm == 128 || bn == 128)) bm = bn = 64;
+    }
   }
   const int kstep = ring ? 64 : BK;
   if (E->atomic && !E->cmode && splits > 1) {
@@ -155,20 +176,25 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
     const double t_iter = ring ? 0.5 : ((B->mode == 1) ? 2.0 : 0.9);
     const double t_atom = (double)tiles * bm * bn * 4.0 / 1.3e6;  // us per split
     long s = (long)(__builtin_sqrt((double)iters * t_iter / t_atom) + 0.5);
-    const long slots = (bm * bn >= 128 * 128) ? 512 : 1024;
+    const long slots = (bm * bn >= 128 * 128) ? 512 : (bm * bn >= 128 * 64 ? 768 : 1024);
     if (s * tiles > slots) s = slots / tiles;
     if (s > iters / 2) s = iters / 2;
     if (s > 256) s = 256;
     if (s < 1) s = 1;
+    static const char* sm = getenv("CENET_RING_SPLIT_MUL");  // measurement aid: scales the split count of the ring kernel
+    if (ring && sm) {
+      s = (long)(s * atof(sm) + 0.5);
+      if (s > iters / 2) s = iters / 2;
+      if (s < 1) s = 1;
+    }
     splits = (int)s;
     g.splits = splits;
   }
   const bool im = B->mode != 0;
   int rc;
   if (ring) {
-    if (bm == 128 && (long)cdiv(M, 128) * cdiv(N, 128) * nbatch * splits < 192) bm = bn = 64;
     snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_ring_kernel<%s, %s, %d, %d, %d, %s>", tf(akf), tf(bkf), bm, bn,
-             bm == 128 ? 2 : 4, tf(swap));
+             bm == 128 && bn == 128 ? 2 : (bm == 64 && bn == 64 ? 4 : 3), tf(swap));
     rc = akf ? (bkf ? cenet_gemm_launch_ring_kk(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_ring_kr(g, bm, bn, nbatch, swap, stream))
              : (bkf ? cenet_gemm_launch_ring_rk(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_ring_rr(g, bm, bn, nbatch, swap, stream));
   } else if (bf) {

@@ -294,6 +294,14 @@ static int launch_ring(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_
     CENET_LAUNCH((gemm_ring_kernel<AKF, BKF, 64, 64, 4, SWAP>), grid, dim3(256), stream, g);
     return CENET_OK;
   }
+  if (bm == 128 && bn == 64) {  // skinny outputs: the long side's operand is re-read once per tile of the short side only
+    CENET_LAUNCH((gemm_ring_kernel<AKF, BKF, 128, 64, 3, SWAP>), grid, dim3(256), stream, g);
+    return CENET_OK;
+  }
+  if (bm == 64 && bn == 128) {
+    CENET_LAUNCH((gemm_ring_kernel<AKF, BKF, 64, 128, 3, SWAP>), grid, dim3(256), stream, g);
+    return CENET_OK;
+  }
   return CENET_EUNSUPPORTED;
 }
 #define CENET_RING_INSTANCE(NAME, AKF, BKF)                                                       \

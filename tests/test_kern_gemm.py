@@ -145,7 +145,7 @@ def test_gemm_tiles_fp32_and_bf16(dev, M, N, K):
 # (the last four: pitches / extents / K that are NOT multiples of 8 elements — 2-byte aligned LDS-DMA chunks, K tails
 # inside a chunk masked at the fragment, the operand's final chunk fetched by hand instead of reading past its end)
 @pytest.mark.parametrize("M,N,K", [(64, 64, 64), (200, 152, 72), (136, 264, 320), (56, 48, 8), (264, 136, 456),
-                                   (100, 49, 49), (137, 196, 200), (50, 61, 20), (49, 49, 515)])
+                                   (100, 49, 49), (137, 196, 200), (50, 61, 20), (49, 49, 515), (56, 200, 72)])
 @pytest.mark.parametrize("akf,bkf", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_gemm_ring_orientations(dev, M, N, K, akf, bkf):
     x, w, b = rnd(M, K, dev=dev).bfloat16(), rnd(N, K, dev=dev, seed=1).bfloat16(), rnd(N, dev=dev, seed=2)
