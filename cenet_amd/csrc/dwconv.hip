@@ -6,6 +6,7 @@
 // token-layout threads run along C.  The data-gradient is the same kernel with the 3x3 taps flipped.
 // Templates over the activation storage type T (float / bf16_t, common.h); weights, bias and their gradients are fp32.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cenet_hip.h"
 
 // grid (B*C, chunks). y_pre = conv(x)+bias ; if a != nullptr: a = act(y_pre)
@@ -645,13 +646,17 @@ __global__ __launch_bounds__(256, 3) void dw3x3_tok_tile_kernel(DwTileArgs a) {
 template <int MODE>
 static int dw_tile_launch(DwTileArgs a, int B, hipStream_t stream) {
   const int slabs = cdiv(a.C, 128);
-  // tile shape by map size; tiles per workgroup: 1 (forward / data gradient), up to 4 for the weight gradient (fewer atomics)
+  // tile shape by map size; tiles per workgroup: 1 (forward / data gradient), 2 on the largest maps for the weight gradient
 #define DW_TILE_GO(TH_, TW_)                                                                                     \
   {                                                                                                              \
     a.tiles_x = cdiv(a.W, TW_);                                                                                  \
     a.ntiles = a.tiles_x * cdiv(a.H, TH_);                                                                       \
     a.tpw = 1;                                                                                                   \
-    if (MODE == 2) a.tpw = a.ntiles >= 16 ? 4 : (a.ntiles >= 4 ? 2 : 1);                                         \
+    if (MODE == 2) {                                                                                             \
+      static const char* e = getenv("CENET_DW_TPW");                                                              \
+      a.tpw = e ? atoi(e) : (a.ntiles >= 16 ? 2 : 1); /* measured: more tiles per workgroup only cost parallelism */                                      \
+      if (a.tpw > a.ntiles) a.tpw = a.ntiles;                                                                    \
+    }                                                                                                            \
     const dim3 grid(slabs, cdiv(a.ntiles, a.tpw), B);                                                            \
     if (grid.y > 65535 || grid.z > 65535) return CENET_EUNSUPPORTED;                                             \
     if (MODE == 1 || a.act == ACT_NONE)                                                                          \
