@@ -731,3 +731,228 @@ extern "C" int cenet_attn64_bwd_bf16(const cenet_diffattn_t* p, hipStream_t stre
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Spatial-reduction attention (pvtv2.py:88-109), backward, bf16: head dimension 64, at most 64 keys (the 7x7 = 49 keys the
+// reduction convs leave at every stage) under 49 ... 3136 queries.  ONE kernel instead of the dQ + dK/dV pair of
+// attn_bf16.hip: the whole key / value set of a (batch, head) sits in LDS, a wave owns 32-query tiles and computes, per tile,
+//   phase A (query = MFMA column, as dattn_bwd_dq):  S^T, dP^T -> dS^T -> dQ^T ; delta and lse as per-lane scalars;
+//   phase B (key = MFMA column, as dattn_bwd_dkv):    S, dP recomputed from the tile's Q / dO images (two MFMA groups:
+//            cheaper than transposing dS through LDS) -> dV^T += dO^T P, dK^T += Q^T dS, accumulated in registers over the wave's
+//            tiles; the four waves meet in LDS and the workgroup adds one 64 x 128 fp32 block into dkv.
+// q, o, dout, dq [B, Nq, C], kv [B, Nk, 2C] (k = columns 0..C, v = C..2C), head h = columns 64h..64h+63, lse [B, H, Nq]
+// (natural log of the scaled scores, as the forward kernel leaves it), dkv [B, Nk, 2C] fp32, zero-filled by the caller.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct SraArgs {
+  const bf *q, *kv, *o, *dout;
+  const float* lse;
+  bf* dq;
+  float* dkv;
+  int B, H, Nq, Nk, C, tiles;  // tiles: 32-query tiles per wave
+  float scale;
+};
+
+__global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
+  constexpr int KP = 72, AP = 40;                     // image pitches (elements)
+  constexpr int KVIMG = 64 * KP, QIMG = 32 * KP + 64, AIMG = 32 * AP;
+  constexpr int WIMG = 2 * QIMG + AIMG;               // per-wave: Q image, dO image, statistics image
+  constexpr int LDS_EL = 2 * KVIMG + 4 * WIMG;
+  static_assert(LDS_EL * 2 >= 64 * 128 * 4, "the dK/dV reduction block reuses the images");
+  __shared__ __attribute__((aligned(16))) bf lds[LDS_EL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const cenet_bid bid = cenet_xcd_block();
+  const int b = bid.y / a.H, h = bid.y - b * a.H;
+  const int C = a.C, Nq = a.Nq, Nk = a.Nk;
+  const float c = a.scale * DA_LOG2E;
+  const bf* qb = a.q + (long)b * Nq * C + h * 64;
+  const bf* ob = a.o + (long)b * Nq * C + h * 64;
+  const bf* gb = a.dout + (long)b * Nq * C + h * 64;
+  const bf* kb = a.kv + (long)b * Nk * 2 * C + h * 64;
+  const bf* vb = kb + C;
+  bf* Kimg = lds;
+  bf* Vimg = lds + KVIMG;
+  bf* Qimg = lds + 2 * KVIMG + wave * WIMG;
+  bf* Gimg = Qimg + QIMG;
+  bf* Aimg = Gimg + QIMG;
+  // K and V of this (batch, head): 64 rows x 8 chunks each, rows >= Nk zero
+  for (int id = tid; id < 2 * 64 * 8; id += 256) {
+    const int which = id >> 9, rem = id & 511, row = rem >> 3, c8 = rem & 7;
+    unsigned v4[4] = {0u, 0u, 0u, 0u};
+    if (row < Nk) memcpy(v4, (which ? vb : kb) + (long)row * 2 * C + 8 * c8, 16);
+    memcpy((which ? Vimg : Kimg) + row * KP + 8 * c8, v4, 16);
+  }
+  // B fragments of K^T / V^T for phase B: key = 32 kt + r
+  bf16x8 kfB[2][4], vfB[2][4];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int key = 32 * kt + r;
+      kfB[kt][ks] = da_ld8(kb + (long)(key < Nk ? key : 0) * 2 * C + 16 * ks + 8 * hh, key < Nk);
+      vfB[kt][ks] = da_ld8(vb + (long)(key < Nk ? key : 0) * 2 * C + 16 * ks + 8 * hh, key < Nk);
+    }
+  bf16x8 negB = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hh == 0) negB[0] = negB[1] = negB[2] = (short)0xBF80;
+  f32x16 dK[2][2], dV[2][2];  // [key tile][feature tile]
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) dK[kt][dt] = dV[kt][dt] = da_zero();
+  __syncthreads();
+
+  const int q00 = (bid.x * 4 + wave) * 32 * a.tiles;
+  for (int t = 0; t < a.tiles; ++t) {
+    const int q0 = q00 + 32 * t;
+    if (q0 >= Nq) break;  // (wave-uniform)
+    const int qi = q0 + r < Nq ? q0 + r : Nq - 1;
+    const bool qok = q0 + r < Nq;
+    // ---- this tile's rows: B fragments for phase A, images for phase B ----
+    bf16x8 qf[4], gf[4];
+    float acc = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = da_ld8(qb + (long)qi * C + 16 * ks + 8 * hh, true);
+      gf[ks] = da_ld8(gb + (long)qi * C + 16 * ks + 8 * hh, true);
+      const bf16x8 uf = da_ld8(ob + (long)qi * C + 16 * ks + 8 * hh, true);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += cenet_bf2f((unsigned short)gf[ks][j]) * cenet_bf2f((unsigned short)uf[j]);
+      bf16x8 qz = qf[ks], gz = gf[ks];
+      if (!qok) qz = gz = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      memcpy(Qimg + r * KP + 16 * ks + 8 * hh, &qz, 16);
+      memcpy(Gimg + r * KP + 16 * ks + 8 * hh, &gz, 16);
+    }
+    acc += __shfl_xor(acc, 32);
+    const float delta = acc;
+    const float lse = a.lse[((long)b * a.H + h) * Nq + qi];
+    const float lse2 = lse * DA_LOG2E;
+    {  // statistics rows: lane half 0 writes lse / scale, half 1 writes delta (rows beyond Nq: lse / scale = 1e30 -> P = 0)
+      unsigned short row8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      da_split3(hh == 0 ? (qok ? lse / a.scale : 1.0e30f) : (qok ? delta : 0.f), row8);
+      memcpy(Aimg + r * AP + 8 * hh, row8, 16);
+    }
+    // ---- phase A: dQ ----
+    f32x16 dq[2] = {da_zero(), da_zero()};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (32 * kt >= Nk) continue;  // (uniform)
+      const bf* Kt = Kimg + 32 * kt * KP;
+      const bf* Vt = Vimg + 32 * kt * KP;
+      f32x16 S = da_zero(), dP = da_zero();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        S = DA_MFMA(da_rm(Kt, KP, r, 16 * ks, hh), qf[ks], S);
+        dP = DA_MFMA(da_rm(Vt, KP, r, 16 * ks, hh), gf[ks], dP);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float pv = da_exp2(S[i] * c - lse2);
+        if (32 * kt + da_row(i, hh) >= Nk) pv = 0.f;
+        S[i] = pv * (dP[i] - delta);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) dq[dt] = DA_MFMA(da_tr(Kt, KP, s2, 32 * dt, lane), da_pack8(S, s2), dq[dt]);
+    }
+    if (qok) {
+      bf* dp = a.dq + ((long)b * Nq + qi) * C + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float o4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o4[i] = dq[dt][4 * g + i] * a.scale;
+          st4v(dp + 32 * dt + 8 * g + 4 * hh, o4);
+        }
+    }
+    // ---- phase B: dK, dV (images written above by this wave only: no workgroup barrier needed) ----
+    bf16x8 al = {0, 0, 0, 0, 0, 0, 0, 0}, ad = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hh == 0) {
+      memcpy(&al, Aimg + r * AP, 16);
+      memcpy(&ad, Aimg + r * AP + 8, 16);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (32 * kt >= Nk) continue;
+      f32x16 S = da_zero(), dP = da_zero();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        S = DA_MFMA(da_rm(Qimg, KP, r, 16 * ks, hh), kfB[kt][ks], S);   // S[query][key]
+        dP = DA_MFMA(da_rm(Gimg, KP, r, 16 * ks, hh), vfB[kt][ks], dP);  // dP[query][key]
+      }
+      S = DA_MFMA(al, negB, S);
+      dP = DA_MFMA(ad, negB, dP);
+      const bool kok = 32 * kt + r < Nk;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = kok ? da_exp2(S[i] * c) : 0.f;
+        S[i] = pv;
+        dP[i] = pv * dP[i];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pB = da_pack8(S, s2), dsB = da_pack8(dP, s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dV[kt][dt] = DA_MFMA(da_tr(Gimg, KP, s2, 32 * dt, lane), pB, dV[kt][dt]);
+          dK[kt][dt] = DA_MFMA(da_tr(Qimg, KP, s2, 32 * dt, lane), dsB, dK[kt][dt]);
+        }
+      }
+    }
+  }
+  // ---- the four waves meet in LDS: red[key][0..63] = dK (unscaled), red[key][64..127] = dV ----
+  // red[feature 0..127][key 0..63] (key fastest: a wave's 32 lanes hit 32 consecutive banks); the waves take turns, so
+  // plain read-modify-writes suffice
+  float* red = (float*)lds;
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = 32 * kt + r, f = 32 * dt + da_row(i, hh);
+            if (w == 0) {
+              red[f * 64 + key] = dK[kt][dt][i];
+              red[(64 + f) * 64 + key] = dV[kt][dt][i];
+            } else {
+              red[f * 64 + key] += dK[kt][dt][i];
+              red[(64 + f) * 64 + key] += dV[kt][dt][i];
+            }
+          }
+    }
+    __syncthreads();
+  }
+  float* dkv = a.dkv + (long)b * Nk * 2 * C + h * 64;
+  for (int i = tid; i < Nk * 128; i += 256) {
+    const int key = i >> 7, f = i & 127;  // 128 consecutive lanes = one key's 64 + 64 features: contiguous runs of 256 B
+    const float v = red[f * 64 + key];
+    if (f < 64) atomicAdd(&dkv[(long)key * 2 * C + f], v * a.scale);
+    else atomicAdd(&dkv[(long)key * 2 * C + C + (f - 64)], v);
+  }
+}
+
+extern "C" int cenet_sra_attn_bwd_supported(int hd, int Nk) { return hd == 64 && Nk >= 1 && Nk <= 64; }
+
+extern "C" int cenet_sra_attn_bwd_bf16(const bf* q, const bf* kv, const bf* o, const bf* dout, const float* lse, bf* dq, float* dkv,
+                                       int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
+  if (!q || !kv || !o || !dout || !lse || !dq || !dkv || B <= 0 || H <= 0 || Nq <= 0) return CENET_EINVAL;
+  if (!cenet_sra_attn_bwd_supported(64, Nk)) return CENET_EUNSUPPORTED;
+  if ((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq) & 15) != 0) return CENET_EINVAL;
+  SraArgs a;
+  a.q = q; a.kv = kv; a.o = o; a.dout = dout; a.lse = lse; a.dq = dq; a.dkv = dkv;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.C = 64 * H; a.scale = scale;
+  // 32-query tiles per wave: the kernel runs one workgroup per CU (484 registers), so more than 256 workgroups is a second
+  // round; measured best (B = 32): 4 tiles at 3136 queries (42 us), 2 at 784 / 196 (31 us), 1 at 49 (25 us)
+  static const char* e = getenv("CENET_SRA_TILES");
+  int tiles = 1;
+  while (tiles < 8 && (long)cdiv(Nq, 128 * tiles) * B * H > 256) ++tiles;
+  if (e) tiles = atoi(e);
+  a.tiles = tiles;
+  CENET_LAUNCH(sra_bwd_kernel, dim3(cdiv(Nq, 128 * tiles), B * H), dim3(256), stream, a);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}

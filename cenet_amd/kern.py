@@ -246,6 +246,19 @@ def attn64(a: DiffAttnT, backward: bool):
     _lib.check(getattr(_lib.lib(), name)(C.byref(a), stream()), name)
 
 
+def sra_attn_bwd_supported(hd: int, Nk: int) -> bool:
+    return bool(_lib.lib().cenet_sra_attn_bwd_supported(int(hd), int(Nk)))
+
+
+def sra_attn_bwd(q, kv, o, dout, lse, dq, dkv, B, H, Nq, Nk, scale):
+    """fused spatial-reduction attention backward (bf16, head dim 64, <= 64 keys); dkv: fp32, zero-filled"""
+    _chk(q, kv, o, dout, lse, dq, dkv)
+    assert q.dtype == BF16 and kv.dtype == BF16 and dq.dtype == BF16 and dkv.dtype == torch.float32
+    rc = _lib.lib().cenet_sra_attn_bwd_bf16(P(q), P(kv), P(o), P(dout), P(lse), P(dq), P(dkv), B, H, Nq, Nk, C.c_float(scale),
+                                            stream())
+    _lib.check(rc, "cenet_sra_attn_bwd_bf16")
+
+
 def softmax_rows_fwd(x, y, rows, n):
     _chk(x, y)
     _call("cenet_softmax_rows_fwd_f32", x, y, L(rows), n)

@@ -770,6 +770,12 @@ class SRAttentionFn(Function):
     def backward(ctx, g):
         q, kv, o, saved = ctx.saved_tensors
         g = _c(g)
+        d = ctx.d
+        if ctx.kind == "flash" and _bf(q) and kern.sra_attn_bwd_supported(d.D, d.Nk) and d.D == d.Dv:
+            # bf16, 64-dim heads, <= 64 keys: one kernel with the key / value set resident (attn_diff.hip, sra_bwd_kernel)
+            dq, dkv = torch.empty_like(q), _zeros(kv.shape, kv)
+            kern.sra_attn_bwd(q, kv, o, g, saved, dq, dkv, d.B, d.H, d.Nq, d.Nk, d.scale)
+            return dq, kern.cast(dkv, kv.dtype), None
         few_keys = ctx.d.Nk <= 128 and ctx.d.Nq >= 1024  # spatial-reduction attention: 49 keys under 784..3136 queries
         # (the query range is then sliced over workgroups and dK / dV are added atomically: fp32 accumulator)
         dq, dkv = torch.empty_like(q), (_zeros(kv.shape, kv) if few_keys else torch.empty_like(kv))

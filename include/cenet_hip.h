@@ -161,6 +161,13 @@ int cenet_diffattn_heads_bwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stre
 long cenet_attn64_ws_bytes(int B, int H, int N);
 int cenet_attn64_fwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
 int cenet_attn64_bwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
+/* Spatial-reduction attention backward (pvtv2.py:88-109) on bf16 tensors in ONE kernel: head dimension 64, Nk <= 64 keys
+ * resident in LDS.  q, o, dout, dq [B, Nq, 64 H]; kv [B, Nk, 128 H] (k | v); lse [B, H, Nq] as the forward kernel left it;
+ * dkv [B, Nk, 128 H] fp32, ZERO-FILLED by the caller (workgroups add their partial sums atomically). */
+int cenet_sra_attn_bwd_supported(int hd, int Nk);
+int cenet_sra_attn_bwd_bf16(const unsigned short* q, const unsigned short* kv, const unsigned short* o,
+    const unsigned short* dout, const float* lse, unsigned short* dq, float* dkv, int B, int H, int Nq, int Nk, float scale,
+    cenet_stream_t stream);
 /* Row softmax for the materialised path (head dims > 128): aten::_softmax(+_backward_data).  Scores x and score gradients
  * dy are fp32 in both forms; the probabilities y and dx have the storage type of the entry point. */
 int cenet_softmax_rows_fwd_f32(const float* x, float* y, long rows, int n, cenet_stream_t stream);

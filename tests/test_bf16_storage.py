@@ -162,7 +162,10 @@ def test_dwconv_nchw(dev, B, C, H, W, dil, act):
     compare(lambda x, w, b: ops.dwconv_nchw(x, w, b, dil=dil, act=act), [x], [w, b], dev=dev)
 
 
-@pytest.mark.parametrize("B,N,Nk,C,heads", [(2, 70, 49, 128, 2), (1, 130, 130, 64, 1)])
+# (<= 64 keys with 64-dim heads: the fused backward kernel sra_bwd_kernel — 49 keys incl. a second, ragged key tile, 20 keys =
+# one key tile, 64 keys, query counts with partial last tiles / idle waves, several tiles per wave)
+@pytest.mark.parametrize("B,N,Nk,C,heads", [(2, 70, 49, 128, 2), (1, 130, 130, 64, 1), (1, 200, 20, 64, 1), (2, 49, 49, 192, 3),
+                                            (1, 300, 64, 64, 1)])
 def test_sr_attention(dev, B, N, Nk, C, heads):
     g = G(N)
     q, kv = torch.randn(B, N, C, generator=g), torch.randn(B, Nk, 2 * C, generator=g)

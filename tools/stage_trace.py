@@ -60,6 +60,7 @@ kern.gemm = bracket(kern.gemm, lambda A, B, C, M, N, K, **kw: f"gemm {kern.last_
 kern.flash_fwd = bracket(kern.flash_fwd, lambda a, bf=False: f"flash_fwd Nq{a.Nq} Nk{a.Nk} D{a.D} H{a.H}")
 kern.flash_bwd = bracket(kern.flash_bwd, lambda a, bf=False: f"flash_bwd Nq{a.Nq} Nk{a.Nk} D{a.D} H{a.H}")
 kern.diffattn_heads = bracket(kern.diffattn_heads, lambda a, backward=False: f"dattn {'bwd' if backward else 'fwd'} N{a.N} hd{a.hd} H{a.H}")
+kern.sra_attn_bwd = bracket(kern.sra_attn_bwd, lambda q, kv, o, g, lse, dq, dkv, B, H, Nq, Nk, sc: f"sra_bwd Nq{Nq} Nk{Nk} H{H}")
 kern.attn64 = bracket(kern.attn64, lambda a, backward=False: f"attn64 {'bwd' if backward else 'fwd'} N{a.N} H{a.H}")
 step()
 torch.cuda.synchronize()
