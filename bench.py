@@ -399,12 +399,17 @@ def main():
         opt.step(sync_hyper=sync_hyper)
         return loss
 
+    def fwd_bwd():
+        opt.zero_grad()
+        loss = crit(net(x), lab)
+        loss.backward()
+        return loss
+
     graphed = None
     launch_note = None
-    # N > 1 runs eager launches: RCCL collectives inside a captured graph could not be exercised on the 1-GPU development
-    # box.  N == 1, auto: eager launches are host-bound (~1.9 k launches of ~20 us of Python + ctypes each) and replay is not,
-    # so which one is faster depends on the host; a few steps of each decide.
-    if a.graph == "on" or (a.graph == "auto" and not use_dist):
+    # N == 1, auto: eager launches are host-bound (~1.3 k C-ABI calls of ~20 us of Python + ctypes each) and replay is not,
+    # so which one is faster depends on the host; a few steps of each decide.  (N > 1: next block.)
+    if not use_dist and a.graph != "off":
         from cenet_amd.graph import GraphedStep
         try:
             graphed = GraphedStep(lambda: body(sync_hyper=False), optimizer=opt, warmup=2)
@@ -422,6 +427,42 @@ def main():
             launch_note = f"auto: eager {t_e * 1e3:.1f} ms vs hipGraph replay {t_g * 1e3:.1f} ms over 4 untimed steps each"
             if t_e <= t_g:
                 graphed = None
+
+    if use_dist and a.graph != "off":
+        # N > 1: forward + backward and the SGD update as two hipGraphs with the all-reduces issued eagerly between them
+        # (cenet_amd.graph.GraphedSplitStep) against eager launches with the all-reduces overlapped from backward hooks.
+        # Every rank times both; the choice is rank 0's (same collective sequence either way, but one mode for all ranks).
+        from cenet_amd.graph import GraphedSplitStep
+        try:
+            parallel.attach(net, None)  # no hooks inside the capture: finish() reduces every segment
+            cand = GraphedSplitStep(fwd_bwd, opt, reducer.finish, warmup=2)
+        except Exception as e:
+            if a.graph == "on":
+                raise
+            print(f"[bench] split hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            cand = None
+            torch.cuda.synchronize()
+        pick = torch.zeros(1, device=dev)
+        if cand is not None:
+            parallel.attach(net, reducer)
+            for _ in range(2):
+                body()
+            dist.barrier()
+            t_e = _time_steps(body, 4)
+            parallel.attach(net, None)
+            for _ in range(2):
+                cand()
+            dist.barrier()
+            t_g = _time_steps(cand, 4)
+            launch_note = (f"auto: eager + overlapped all-reduce {t_e * 1e3:.1f} ms vs two hipGraphs + all-reduce between "
+                           f"{t_g * 1e3:.1f} ms over 4 untimed steps each (rank 0 decides)")
+            pick[0] = 1.0 if (t_g < t_e or a.graph == "on") else 0.0
+        dist.broadcast(pick, 0)
+        if cand is not None and pick.item() > 0:
+            graphed = cand
+            parallel.attach(net, None)
+        else:
+            parallel.attach(net, reducer)
 
     def step():
         loss = graphed() if graphed is not None else body()
@@ -457,7 +498,8 @@ def main():
                                       f"(heads {cfg['heads']}, scales {cfg['scales']}), "
                                       "fwd + Dice/CE + bwd + grad all-reduce + SGD(momentum .9, wd 1e-4)",
                           "preset": a.config, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", **({"grad_buckets": "bf16"} if a.bf16_buckets else {}),
-                          "launch": "hipGraph replay" if graphed is not None else "eager",
+                          "launch": ("eager" if graphed is None else
+                                     ("two hipGraphs + eager all-reduce" if use_dist else "hipGraph replay")),
                           "final_loss": round(final_loss, 5)}}
         if launch_note:
             out["config"]["launch_choice"] = launch_note

@@ -44,3 +44,55 @@ class GraphedStep:
         if self.optimizer is not None:
             self.optimizer._steps += 1
         return self.loss
+
+
+class GraphedSplitStep:
+    """Data-parallel form: the step is captured as TWO hipGraphs with the gradient all-reduce between them, issued eagerly —
+
+        graph A: zero_grad -> forward -> loss -> backward        (all weight gradients joined at its end)
+        eager  : between()   (GradReducer.finish(): one RCCL all-reduce per arena segment, a handful of host calls)
+        graph B: optimizer.step(sync_hyper=False)
+
+    so a rank's host issues ~8 calls per step instead of ~1 300 and the step no longer depends on how fast (or how shared) the
+    host is, at the price of not overlapping the 133 MB all-reduce with the tail of the backward pass (~1.5 ms over xGMI, SURVEY
+    §5).  Collectives stay outside the captured regions: capturing them aborted inside RCCL on this stack."""
+
+    def __init__(self, fwd_bwd_fn: Callable[[], torch.Tensor], optimizer, between: Callable[[], None], warmup: int = 3):
+        from . import ops
+        self.optimizer, self.between = optimizer, between
+
+        def a_fn():
+            loss = fwd_bwd_fn()
+            ops.wgrad_join()  # the side-stream branch must re-join inside the capture
+            return loss
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                optimizer.prepare()
+                a_fn()
+                between()
+                optimizer.step(sync_hyper=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        optimizer.prepare()
+        # (the process group's watchdog thread polls the events of collectives still in flight; an event query from another
+        # thread while a capture is open is an error in the default "global" capture mode: drain first, capture thread-locally)
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
+            self.loss = a_fn()
+        between()
+        torch.cuda.synchronize()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
+            optimizer.step(sync_hyper=False)
+        optimizer._steps -= 1  # the captured call counted itself; replays count below
+        torch.cuda.synchronize()
+
+    def __call__(self) -> torch.Tensor:
+        self.optimizer.prepare()
+        self.graph_a.replay()
+        self.between()
+        self.graph_b.replay()
+        self.optimizer._steps += 1
+        return self.loss
