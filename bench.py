@@ -442,6 +442,10 @@ def main():
             print(f"[bench] split hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             cand = None
             torch.cuda.synchronize()
+        okf = torch.tensor([1.0 if cand is not None else 0.0], device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)  # all ranks or none (the timing loops below contain barriers)
+        if okf.item() < 1.0:
+            cand = None
         pick = torch.zeros(1, device=dev)
         if cand is not None:
             parallel.attach(net, reducer)
