@@ -531,16 +531,58 @@ __global__ void bn_finalize_kernel(const T* __restrict__ x, int HW, const float*
   if (c == 0 && nbt) nbt[0] += 1;
 }
 
+// Train-mode forward in two launches instead of three: when `fin.ws` is set, the normalisation pass derives the batch mean /
+// variance of its channel from the partial sums itself (what bn_finalize_kernel does), and the workgroup (thread) that handles
+// the first elements of image 0's plane publishes mean / var for the backward pass and updates the running statistics.
+struct BnFin {
+  const float* ws;  // partial sums [2][C][S] of the shifted values (nullptr: mean / var are given)
+  int S;
+  float n;          // B * HW
+  float *mean, *var, *rmean, *rvar;
+  float momentum;
+  long* nbt;
+};
+__device__ __forceinline__ void bn_fin_publish(const BnFin& f, int c, float mu, float v) {
+  f.mean[c] = mu;
+  f.var[c] = v;
+  if (f.rmean) {
+    f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * mu;
+    f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * v * (f.n / (f.n - 1.f));
+  }
+  if (c == 0 && f.nbt) f.nbt[0] += 1;
+}
+// plane-per-workgroup kernels: every thread of the workgroup calls (block_sum inside)
+template <typename T>
+__device__ __forceinline__ void bn_fin_plane(const BnFin& f, const T* x, int C, int HW, int c, bool writer, float* red, float& mu,
+                                             float& v) {
+  float p1 = 0.f, p2 = 0.f;
+  for (int i = threadIdx.x; i < f.S; i += blockDim.x) {
+    p1 += f.ws[(long)c * f.S + i];
+    p2 += f.ws[((long)C + c) * f.S + i];
+  }
+  const float a1 = block_sum(p1, red), a2 = block_sum(p2, red);
+  const float m = a1 / f.n;
+  v = a2 / f.n - m * m;
+  if (v < 0.f) v = 0.f;
+  mu = ldf(x + (long)c * HW) + m;
+  if (writer && threadIdx.x == 0) bn_fin_publish(f, c, mu, v);
+}
+
 // y = act(gamma*(x-mean)*rsqrt(var+eps)+beta); grid (B*C, chunks)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y, long syb,
                                                       const float* __restrict__ mean, const float* __restrict__ var,
                                                       float eps, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, int act, float slope, int C, int HW) {
+                                                      const float* __restrict__ beta, int act, float slope, int C, int HW,
+                                                      BnFin fin) {
+  __shared__ float red[16];
   const int bc = blockIdx.x;
   const int b = bc / C, c = bc - b * C;
-  const float sc = gamma[c] * rsqrtf(var[c] + eps);
-  const float sh = beta[c] - mean[c] * sc;
+  float mu, vr;
+  if (fin.ws) bn_fin_plane<T>(fin, x, C, HW, c, b == 0 && blockIdx.y == 0, red, mu, vr);
+  else mu = mean[c], vr = var[c];
+  const float sc = gamma[c] * rsqrtf(vr + eps);
+  const float sh = beta[c] - mu * sc;
   const T* xp = x + (long)b * sxb + (long)c * HW;
   T* yp = y + (long)b * syb + (long)c * HW;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) stf(yp + p, act_fwd(act, ldf(xp + p) * sc + sh, slope));
@@ -655,11 +697,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y, long syb,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          float eps, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, int act, float slope, int C, int HW) {
+                                                         const float* __restrict__ beta, int act, float slope, int C, int HW,
+                                                         BnFin fin) {
+  __shared__ float red[16];
   const int bc = blockIdx.x;
   const int b = bc / C, c = bc - b * C;
-  const float sc = gamma[c] * rsqrtf(var[c] + eps);
-  const float sh = beta[c] - mean[c] * sc;
+  float mu, vr;
+  if (fin.ws) bn_fin_plane<T>(fin, x, C, HW, c, b == 0 && blockIdx.y == 0, red, mu, vr);
+  else mu = mean[c], vr = var[c];
+  const float sc = gamma[c] * rsqrtf(vr + eps);
+  const float sh = beta[c] - mu * sc;
   const T* xp = x + (long)b * sxb + (long)c * HW;
   T* yp = y + (long)b * syb + (long)c * HW;
   const int nq = HW >> 2;
@@ -772,12 +819,28 @@ __global__ __launch_bounds__(256) void bn_apply_flat_kernel(const T* __restrict_
                                                            const float* __restrict__ mean, const float* __restrict__ var,
                                                            float eps, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int act, float slope, int C, int HWv,
-                                                           long nvec) {
+                                                           long nvec, BnFin fin) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
-  const int c = (int)((i / HWv) % C);
-  const float sc = gamma[c] * rsqrtf(var[c] + eps);
-  const float sh = beta[c] - mean[c] * sc;
+  const long plane = i / HWv;
+  const int c = (int)(plane % C);
+  float mu, vr;
+  if (fin.ws) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int k = 0; k < fin.S; ++k) {
+      a1 += fin.ws[(long)c * fin.S + k];
+      a2 += fin.ws[((long)C + c) * fin.S + k];
+    }
+    const float m = a1 / fin.n;
+    vr = a2 / fin.n - m * m;
+    if (vr < 0.f) vr = 0.f;
+    mu = ldf(x + (long)c * HWv * V) + m;
+    if (plane < C && i == plane * HWv) bn_fin_publish(fin, c, mu, vr);
+  } else {
+    mu = mean[c], vr = var[c];
+  }
+  const float sc = gamma[c] * rsqrtf(vr + eps);
+  const float sh = beta[c] - mu * sc;
   float v[V];
   ldv<V>(v, x + i * V);
 #pragma unroll
@@ -910,6 +973,23 @@ static inline int bn_splits(int C, long total) {
 }
 
 template <typename T>
+static int bn_partial_launch(const T* x, long sb, int B, int C, int HW, float* ws, hipStream_t stream) {
+  const long total = (long)B * HW;
+  int S;
+  if (bn_v4_ok<T>(HW, x, sb, x, sb, x, sb)) {
+    S = bn_splits_v4(C, total / 4);
+    CENET_LAUNCH((bn_partial_v4_kernel<T>), dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
+  } else if (sizeof(T) == 2 && HW <= 1024) {
+    S = bn_splits(C, total);
+    CENET_LAUNCH((bn_partial_flat_kernel<T>), dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
+  } else {
+    S = bn_splits(C, total);
+    CENET_LAUNCH((bn_partial_kernel<T>), dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
+  }
+  return S;
+}
+
+template <typename T>
 static int bn_stats_impl(const T* x, long sb, int B, int C, int HW, float* ws, float* mean, float* var, float* running_mean,
                          float* running_var, float momentum, long* num_batches_tracked, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
@@ -935,19 +1015,18 @@ CENET_TWIN(bn_stats, (const T* x, long sb, int B, int C, int HW, float* ws, floa
            (x, sb, B, C, HW, ws, mean, var, running_mean, running_var, momentum, num_batches_tracked, stream))
 
 template <typename T>
-static int bn_apply_impl(const T* x, long sxb, T* y, long syb, const float* mean, const float* var, float eps,
-                         const float* gamma, const float* beta, int act, float slope, int B, int C, int HW,
-                         hipStream_t stream) {
-  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+static int bn_apply_launch(const T* x, long sxb, T* y, long syb, const float* mean, const float* var, float eps,
+                           const float* gamma, const float* beta, int act, float slope, int B, int C, int HW, const BnFin& fin,
+                           hipStream_t stream) {
   if (bn_flat_ok<T>(C, HW, sxb, syb, sxb)) {
     if (bn_v4_ok<T>(HW, x, sxb, y, syb, x, sxb)) {
       const long nvec = (long)B * C * HW / 4;
       CENET_LAUNCH((bn_apply_flat_kernel<T, 4>), dim3(cdiv(nvec, 256)), dim3(256), stream, x, y, mean, var, eps, gamma, beta, act,
-                   slope, C, HW / 4, nvec);
+                   slope, C, HW / 4, nvec, fin);
     } else {
       const long nvec = (long)B * C * HW;
       CENET_LAUNCH((bn_apply_flat_kernel<T, 1>), dim3(cdiv(nvec, 256)), dim3(256), stream, x, y, mean, var, eps, gamma, beta, act,
-                   slope, C, HW, nvec);
+                   slope, C, HW, nvec, fin);
     }
     CENET_CHECK_LAUNCH();
     return CENET_OK;
@@ -956,16 +1035,50 @@ static int bn_apply_impl(const T* x, long sxb, T* y, long syb, const float* mean
     int threads, chunks;
     bn_plane_launch(HW / 4, &threads, &chunks);
     CENET_LAUNCH((bn_apply_v4_kernel<T>), dim3(B * C, chunks), dim3(threads), stream, x, sxb, y, syb, mean, var, eps, gamma,
-                 beta, act, slope, C, HW);
+                 beta, act, slope, C, HW, fin);
   } else {
     int chunks = cdiv(HW, 1024);
     if (chunks > 64) chunks = 64;
     CENET_LAUNCH((bn_apply_kernel<T>), dim3(B * C, chunks), dim3(256), stream, x, sxb, y, syb, mean, var, eps, gamma, beta, act,
-                 slope, C, HW);
+                 slope, C, HW, fin);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+
+template <typename T>
+static int bn_apply_impl(const T* x, long sxb, T* y, long syb, const float* mean, const float* var, float eps,
+                         const float* gamma, const float* beta, int act, float slope, int B, int C, int HW,
+                         hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  BnFin fin;
+  fin.ws = nullptr; fin.S = 0; fin.n = 0.f; fin.mean = fin.var = fin.rmean = fin.rvar = nullptr; fin.momentum = 0.f; fin.nbt = nullptr;
+  return bn_apply_launch<T>(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, fin, stream);
+}
+
+// train-mode forward: partial sums, then ONE pass that finalises the statistics, normalises, and publishes mean / var /
+// running statistics (bf16 tensors; fp32 tensors keep the three-launch form and its summation order)
+template <typename T>
+static int bn_train_fwd_impl(const T* x, long sxb, T* y, long syb, float* ws, float* mean, float* var, float* running_mean,
+                             float* running_var, float momentum, long* num_batches_tracked, float eps, const float* gamma,
+                             const float* beta, int act, float slope, int B, int C, int HW, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  if (sizeof(T) != 2) {
+    const int rc = bn_stats_impl<T>(x, sxb, B, C, HW, ws, mean, var, running_mean, running_var, momentum, num_batches_tracked, stream);
+    if (rc != CENET_OK) return rc;
+    return bn_apply_impl<T>(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, stream);
+  }
+  BnFin fin;
+  fin.S = bn_partial_launch<T>(x, sxb, B, C, HW, ws, stream);
+  fin.ws = ws; fin.n = (float)((long)B * HW); fin.mean = mean; fin.var = var; fin.rmean = running_mean; fin.rvar = running_var;
+  fin.momentum = momentum; fin.nbt = num_batches_tracked;
+  return bn_apply_launch<T>(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, fin, stream);
+}
+CENET_TWIN(bn_train_fwd, (const T* x, long sxb, T* y, long syb, float* ws, float* mean, float* var, float* running_mean,
+                          float* running_var, float momentum, long* num_batches_tracked, float eps, const float* gamma,
+                          const float* beta, int act, float slope, int B, int C, int HW, hipStream_t stream),
+           (x, sxb, y, syb, ws, mean, var, running_mean, running_var, momentum, num_batches_tracked, eps, gamma, beta, act, slope, B,
+            C, HW, stream))
 CENET_TWIN(bn_apply, (const T* x, long sxb, T* y, long syb, const float* mean, const float* var, float eps, const float* gamma,
                       const float* beta, int act, float slope, int B, int C, int HW, hipStream_t stream),
            (x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, stream))

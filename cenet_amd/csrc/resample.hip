@@ -281,10 +281,72 @@ CENET_TWIN(bilinear_fwd, (const T* x, long sxb, T* y, long syb, int B, int C, in
                           float scale_w, int align_corners, hipStream_t stream),
            (x, sxb, y, syb, B, C, Hi, Wi, Ho, Wo, scale_h, scale_w, align_corners, stream))
 
+// ---- exact x2 / x0.5 resizes with align_corners = False (the FEA scale 0.5 of the ACDC preset, dseb.py:27-30, and the final
+// x2 of the output head): fixed tap patterns instead of the general gather with its per-candidate coordinate arithmetic ----
+// x2 up-sampling: output 2i reads (i-1: .25, i: .75), output 2i+1 reads (i: .75, i+1: .25), indices clamped at the borders, so
+//   dx[i] = .25 g[2i-1] + .75 g[2i] + .75 g[2i+1] + .25 g[2i+2]   with g[0] (g[2n-1]) counted in full at i = 0 (i = n-1)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx, long sdb,
+                                                              int C, int Hi, int Wi) {
+  const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
+  const int Wo = 2 * Wi;
+  const T* gp = dy + (long)b * sgb + (long)c * 4 * Hi * Wi;
+  T* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < Hi * Wi; p += gridDim.y * 256) {
+    const int iy = p / Wi, ix = p - iy * Wi;
+    float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    if (iy == 0) wy[0] = 0.f, wy[1] = 1.f;
+    if (iy == Hi - 1) wy[3] = 0.f, wy[2] = 1.f;
+    if (ix == 0) wx[0] = 0.f, wx[1] = 1.f;
+    if (ix == Wi - 1) wx[3] = 0.f, wx[2] = 1.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int oy = 2 * iy - 1 + r;
+      if (wy[r] == 0.f) continue;
+      const T* row = gp + (long)oy * Wo + 2 * ix - 1;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (wx[k] != 0.f) s += wx[k] * ldf(row + k);
+      acc += wy[r] * s;
+    }
+    stf(dp + p, acc);
+  }
+}
+// x0.5 down-sampling: output o reads (2o: .5, 2o+1: .5), so dx[i] = .25 g[i/2][j/2]
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_down2_bwd_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx, long sdb,
+                                                                int C, int Ho, int Wo) {
+  const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
+  const T* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
+  T* dp = dx + (long)b * sdb + (long)c * 4 * Ho * Wo;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < Ho * Wo; p += gridDim.y * 256) {
+    const int oy = p / Wo, ox = p - oy * Wo;
+    const float v = 0.25f * ldf(gp + p);
+    T* o = dp + (long)(2 * oy) * (2 * Wo) + 2 * ox;
+    stf(o, v);
+    stf(o + 1, v);
+    stf(o + 2 * Wo, v);
+    stf(o + 2 * Wo + 1, v);
+  }
+}
+
 template <typename T>
 static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
                              float scale_w, int align_corners, hipStream_t stream) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
+  // (bf16 tensors only: the fp32 parity mode keeps the one summation order of the general kernel)
+  if (sizeof(T) == 2 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && scale_h == 0.5f && scale_w == 0.5f && Hi > 1 && Wi > 1) {
+    CENET_LAUNCH((bilinear_up2_bwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
+  if (sizeof(T) == 2 && !align_corners && Hi == 2 * Ho && Wi == 2 * Wo && scale_h == 2.0f && scale_w == 2.0f) {
+    CENET_LAUNCH((bilinear_down2_bwd_kernel<T>), dim3(B * C, chunks_for(Ho * Wo)), dim3(256), stream, dy, sgb, dx, sdb, C, Ho, Wo);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   if (scale_w >= 0.5f)
     CENET_LAUNCH((bilinear_bwd_kernel<T, 6>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
                  Wo, scale_h, scale_w, align_corners);

@@ -285,6 +285,13 @@ def bn_stats(x, sb, B, Cn, HW, ws, mean, var, rmean, rvar, momentum, nbt):
     _call("cenet_bn_stats_f32", x, L(sb), B, Cn, HW, ws, mean, var, rmean, rvar, float(momentum), nbt)
 
 
+def bn_train_fwd(x, sxb, y, syb, ws, mean, var, rmean, rvar, momentum, nbt, eps, gamma, beta, act, slope, B, Cn, HW):
+    """train-mode BatchNorm forward: statistics + normalisation (+ activation), mean / var / running statistics written"""
+    _chk(x, y, ws, mean, var, rmean, rvar, gamma, beta)
+    _call("cenet_bn_train_fwd_f32", x, L(sxb), y, L(syb), ws, mean, var, rmean, rvar, float(momentum), nbt, float(eps), gamma,
+          beta, ACT[act], float(slope), B, Cn, HW)
+
+
 def bn_apply(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, Cn, HW):
     _chk(x, y, mean, var, gamma, beta)
     _call("cenet_bn_apply_f32", x, L(sxb), y, L(syb), mean, var, float(eps), gamma, beta, ACT[act], float(slope), B, Cn, HW)

@@ -518,10 +518,11 @@ class BatchNormFn(Function):
         if training:
             mean, var = _empty((Cn,), x), _empty((Cn,), x)
             ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
-            kern.bn_stats(x, Cn * HW, B, Cn, HW, ws, mean, var, rmean, rvar, momentum, nbt)
+            kern.bn_train_fwd(x, Cn * HW, y, Cn * HW, ws, mean, var, rmean, rvar, momentum, nbt, eps, weight, bias, act, slope,
+                              B, Cn, HW)
         else:
             mean, var = rmean, rvar
-        kern.bn_apply(x, Cn * HW, y, Cn * HW, mean, var, eps, weight, bias, act, slope, B, Cn, HW)
+            kern.bn_apply(x, Cn * HW, y, Cn * HW, mean, var, eps, weight, bias, act, slope, B, Cn, HW)
         ctx.save_for_backward(x, weight, bias, mean, var)
         ctx.refs = (weight, bias)
         ctx.cfg = (training, eps, act, slope)

@@ -198,6 +198,11 @@ int cenet_bn_stats_f32(const float* x, long sb, int B, int C, int HW, float* ws,
 int cenet_bn_apply_f32(const float* x, long sxb, float* y, long syb, const float* mean, const float* var, float eps,
                        const float* gamma, const float* beta, int act, float slope, int B, int C, int HW,
                        cenet_stream_t stream);
+/* Train-mode BatchNorm forward in one call (two launches): statistics + normalisation (+ activation); writes y, the batch
+ * mean / var the backward pass needs, and the running statistics (nn.BatchNorm2d.forward in training mode). */
+int cenet_bn_train_fwd_f32(const float* x, long sxb, float* y, long syb, float* ws, float* mean, float* var,
+    float* running_mean, float* running_var, float momentum, long* num_batches_tracked, float eps, const float* gamma,
+    const float* beta, int act, float slope, int B, int C, int HW, cenet_stream_t stream);
 int cenet_bn_bwd_acc_f32(const float* dy, long sgb, const float* x, long sxb, float* dx, long sdb, const float* mean,
                          const float* var, float eps, const float* gamma, const float* beta, int act, float slope, int B,
                          int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, cenet_stream_t stream);
@@ -412,6 +417,9 @@ int cenet_bn_stats_bf16(const unsigned short* x, long sb, int B, int C, int HW, 
     running_mean, float* running_var, float momentum, long* num_batches_tracked, cenet_stream_t stream);
 int cenet_bn_apply_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, const float* mean, const float* var,
     float eps, const float* gamma, const float* beta, int act, float slope, int B, int C, int HW, cenet_stream_t stream);
+int cenet_bn_train_fwd_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, float* ws, float* mean, float* var,
+    float* running_mean, float* running_var, float momentum, long* num_batches_tracked, float eps, const float* gamma,
+    const float* beta, int act, float slope, int B, int C, int HW, cenet_stream_t stream);
 int cenet_bn_bwd_acc_bf16(const unsigned short* dy, long sgb, const unsigned short* x, long sxb, unsigned short* dx, long
     sdb, const float* mean, const float* var, float eps, const float* gamma, const float* beta, int act, float slope, int B,
     int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, cenet_stream_t stream);
