@@ -304,10 +304,11 @@ def bn_bwd(dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma, beta, act, slope, B,
 
 
 # ---- depthwise conv ------------------------------------------------------------------------------------
-def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0):
+def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0, x_off=0, y_off=0):
+    """x_off / y_off (elements): read / write a channel slice of a wider tensor in place (batch strides sxb / syb)"""
     _chk(x, w, bias, y, a)
-    _call("cenet_dwconv3x3_nchw_f32", x, L(sxb), w, bias, y, L(syb), a, L(sab), B, Cn, H, W, dil, int(flip), ACT[act],
-          float(slope))
+    _call("cenet_dwconv3x3_nchw_f32", Ptr(x, x_off), L(sxb), w, bias, Ptr(y, y_off) if y is not None else None, L(syb), a, L(sab),
+          B, Cn, H, W, dil, int(flip), ACT[act], float(slope))
 
 
 def dw_tok(x, w, bias, y, a, B, Cn, H, W, flip, act="none", slope=0.0):
@@ -327,9 +328,9 @@ def dw_tok_tiled(x):
     return is_bf16(x) and x.shape[-1] % 8 == 0 and x.data_ptr() % 16 == 0
 
 
-def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil):
+def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil, x_off=0):
     _chk(x, dy, dw, dbias)
-    _call("cenet_dwconv3x3_wgrad_nchw_acc_f32", x, L(sxb), dy, L(sgb), dw, dbias, B, Cn, H, W, dil)
+    _call("cenet_dwconv3x3_wgrad_nchw_acc_f32", Ptr(x, x_off), L(sxb), dy, L(sgb), dw, dbias, B, Cn, H, W, dil)
 
 
 def dw_wgrad_tok(x, dy, dw, dbias, B, Cn, H, W):

@@ -45,7 +45,11 @@ class SepConvBN(nn.Module):
         self.apply(_init_conv)
 
     def forward(self, x):
-        x = ops.dwconv_nchw(x, self.depthwise.weight, None, dil=self.rate)
+        return self.after_depthwise(ops.dwconv_nchw(x, self.depthwise.weight, None, dil=self.rate))
+
+    def after_depthwise(self, x):
+        """the block from its depthwise output on (MultiOrderDWConv runs the depthwise convs of its branches itself,
+        reading their channel slices in place)"""
         x = bn_call(self.depthwise_bn, x, "relu")
         x = ops.conv1x1(x, self.pointwise.weight)
         return bn_call(self.pointwise_bn, x, "relu")

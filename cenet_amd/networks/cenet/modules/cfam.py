@@ -67,17 +67,20 @@ class MultiOrderDWConv(nn.Module):
 
     def forward(self, x):
         H, W = x.shape[2:]
-        parts = ops.split_channels(x, [hi - lo for lo, hi in self.channel_indices])
-        ys = [self.dlps[j](parts[j]) for j in range(3)]
+        # the three dilated branches read their channel slice of x in place (ops.split_dwconv); only the small pooled
+        # branch gets a copy
+        sizes = [hi - lo for lo, hi in self.channel_indices]
+        us = ops.split_dwconv(x, sizes[:3], [m.rate for m in self.dlps[:3]], [m.depthwise.weight for m in self.dlps[:3]])
+        ys = [self.dlps[j].after_depthwise(us[j]) for j in range(3)]
         pool = self.dlps[3]
-        y = ops.adaptive_avgpool(parts[3], 7, 7)
+        y = ops.adaptive_avgpool(us[3], 7, 7)
         y = ops.conv1x1(y, pool[1].weight)
         y = bn_call(pool[2], y, "lrelu", 0.01)
         y = ops.interpolate_bilinear(y, scale_factor=7, align_corners=True)
         if y.shape[2] != H or y.shape[3] != W:
             y = ops.interpolate_bilinear(y, size=(H, W), align_corners=False)
         ys.append(y)
-        x = ops.concat2(ops.concat2(ys[0], ys[1]), ops.concat2(ys[2], ys[3]))
+        x = ops.concat(ys)
         return ops.conv1x1(x, self.PW_conv.weight, self.PW_conv.bias)
 
 

@@ -1080,6 +1080,97 @@ def split_channels(x, sizes):
     return SplitChannelsFn.apply(x, *sizes)
 
 
+class SplitDWFn(Function):
+    """cfam.py:230-236 without the split copies: the first `len(ws)` channel groups of x go straight through their (dilated,
+    bias-free) depthwise 3x3 — each kernel reads its slice of x in place and the data-gradient kernels write their slice of
+    ONE dx — and the remaining channels come back as a contiguous copy.  Returns (u_0, ..., u_{n-1}, rest)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, dils, *ws):
+        x = _c(x)
+        B, Cn, H, Wd = x.shape
+        HW = H * Wd
+        outs, lo = [], 0
+        for c, dil, w in zip(sizes, dils, ws):
+            u = _act((B, c, H, Wd), x)
+            kern.dw_nchw(x, Cn * HW, w, None, u, c * HW, None, 0, B, c, H, Wd, dil, 0, x_off=lo * HW)
+            outs.append(u)
+            lo += c
+        rest = None
+        if lo < Cn:
+            rest = _act((B, Cn - lo, H, Wd), x)
+            kern.copy_batched(x, Cn * HW, rest, (Cn - lo) * HW, B, (Cn - lo) * HW, x_off=lo * HW)
+        ctx.save_for_backward(x, *ws)
+        ctx.refs = ws
+        ctx.cfg = (tuple(sizes), tuple(dils), lo)
+        return tuple(outs) + ((rest,) if rest is not None else ())
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x = ctx.saved_tensors[0]
+        ws = ctx.saved_tensors[1:]
+        sizes, dils, used = ctx.cfg
+        B, Cn, H, Wd = x.shape
+        HW = H * Wd
+        n = len(sizes)
+        full = all(g is not None for g in gs)
+        dx = torch.empty_like(x) if full else kern.zero_(torch.empty_like(x))
+        lo = 0
+        for j, (c, dil, w, wp) in enumerate(zip(sizes, dils, ws, ctx.refs)):
+            g = gs[j]
+            if g is not None:
+                g = _c(g)
+                kern.dw_nchw(g, c * HW, w, None, dx, Cn * HW, None, 0, B, c, H, Wd, dil, 1, y_off=lo * HW)
+                dw = grad_buf(wp)
+                if dw is not None:
+                    with _wgrad_side(g, x):
+                        kern.dw_wgrad_nchw(x, Cn * HW, g, c * HW, dw, None, B, c, H, Wd, dil, x_off=lo * HW)
+            lo += c
+        if used < Cn and len(gs) > n and gs[n] is not None:
+            kern.copy_batched(_c(gs[n]), (Cn - used) * HW, dx, Cn * HW, B, (Cn - used) * HW, y_off=used * HW)
+        return (dx, None, None) + (None,) * n
+
+
+def split_dwconv(x, sizes, dils, ws):
+    return SplitDWFn.apply(x, tuple(sizes), tuple(dils), *ws)
+
+
+class ConcatFn(Function):
+    """torch.cat(xs, dim=1) for NCHW in one pass per input (the nested two-way concats of cfam.py:238 copied twice)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [_c(t) for t in xs]
+        B = xs[0].shape[0]
+        cs = [t.shape[1] for t in xs]
+        HW = xs[0].numel() // (B * cs[0])
+        Ct = sum(cs)
+        y = _act((B, Ct) + tuple(xs[0].shape[2:]), xs[0])
+        lo = 0
+        for t, c in zip(xs, cs):
+            kern.copy_batched(t, c * HW, y, Ct * HW, B, c * HW, y_off=lo * HW)
+            lo += c
+        ctx.dims = (cs, HW)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        cs, HW = ctx.dims
+        B, Ct = g.shape[0], sum(cs)
+        outs, lo = [], 0
+        for c in cs:
+            d = _act((B, c) + tuple(g.shape[2:]), g)
+            kern.copy_batched(g, Ct * HW, d, c * HW, B, c * HW, x_off=lo * HW)
+            outs.append(d)
+            lo += c
+        return tuple(outs)
+
+
+def concat(xs):
+    return ConcatFn.apply(*xs)
+
+
 class AddActFn(Function):
     """out = act(a + b) for act in {none, lrelu, relu} (unet.py:212-213; decoders.py:96)."""
 
