@@ -128,6 +128,67 @@ __global__ __launch_bounds__(256) void patch_tok_kernel(const T* __restrict__ sr
   }
 }
 
+// Overlapping patches (the 3x3 stride-2 pad-1 patch-embedding convs of stages 2-4, pvtv2.py:164): tok [B, H*W, C] ->
+// patch rows [B*Ho*Wo, C*K*K], k = (c, ky, kx) as in the conv weight, zeros outside the map; and the transpose (every input
+// pixel GATHERS the patch entries that cover it: no atomics).  With the rows materialised (2.25x the map, 29 MB at stage 2)
+// forward, weight gradient and data gradient are plain k-contiguous GEMMs for the LDS-DMA ring kernel instead of implicit
+// GEMMs with per-element gathers (64 / 77 / 161 us -> ~12 us each at stage 2) plus these two ~10 us passes.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void im2col_tok_kernel(const T* __restrict__ x, T* __restrict__ xp, int C, int H, int W, int Ho,
+                                                        int Wo, int stride, int pad, long total) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long r = idx / C;
+    const int ox = (int)(r % Wo);
+    const long t = r / Wo;
+    const int oy = (int)(t % Ho);
+    const long b = t / Ho;
+    T v[K * K];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        T e;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) e = x[((b * H + iy) * W + ix) * C + c];
+        else stf(&e, 0.f);
+        v[ky * K + kx] = e;
+      }
+    T* o = xp + (r * C + c) * (K * K);
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) o[i] = v[i];
+  }
+}
+template <typename T, int K>
+__global__ __launch_bounds__(256) void col2im_tok_kernel(const T* __restrict__ gp, T* __restrict__ dx, int C, int H, int W, int Ho,
+                                                        int Wo, int stride, int pad, long total) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    const long r = idx / C;
+    const int ix = (int)(r % W);
+    const long t = r / W;
+    const int iy = (int)(t % H);
+    const long b = t / H;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int ny = iy + pad - ky;
+      if (ny < 0 || ny % stride != 0) continue;
+      const int oy = ny / stride;
+      if (oy >= Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int nx = ix + pad - kx;
+        if (nx < 0 || nx % stride != 0) continue;
+        const int ox = nx / stride;
+        if (ox >= Wo) continue;
+        acc += ldf(gp + (((b * Ho + oy) * Wo + ox) * C + c) * (K * K) + ky * K + kx);
+      }
+    }
+    stf(dx + idx, acc);
+  }
+}
+
 // ---- y[b, i] = s[b] * x[b, i] ------------------------------------------------------------------------------------
 template <typename T, int V>
 __global__ __launch_bounds__(256) void scale_batch_kernel(const T* __restrict__ x, const float* __restrict__ s,
@@ -704,6 +765,25 @@ static int patch_tok_impl(const T* src, T* dst, int B, int Ho, int Wo, int C, in
 }
 CENET_TWIN(patch_tok, (const T* src, T* dst, int B, int Ho, int Wo, int C, int S, int inverse, hipStream_t stream),
            (src, dst, B, Ho, Wo, C, S, inverse, stream))
+
+template <typename T>
+static int im2col_tok_impl(const T* src, T* dst, int B, int H, int W, int C, int K, int stride, int pad, int inverse,
+                           hipStream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K != 3 || stride < 1 || pad < 0) return CENET_EINVAL;
+  const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return CENET_EINVAL;
+  if (inverse) {
+    const long total = (long)B * H * W * C;
+    CENET_LAUNCH((col2im_tok_kernel<T, 3>), EW_GRID(total), dim3(256), stream, src, dst, C, H, W, Ho, Wo, stride, pad, total);
+  } else {
+    const long total = (long)B * Ho * Wo * C;
+    CENET_LAUNCH((im2col_tok_kernel<T, 3>), EW_GRID(total), dim3(256), stream, src, dst, C, H, W, Ho, Wo, stride, pad, total);
+  }
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+CENET_TWIN(im2col_tok, (const T* src, T* dst, int B, int H, int W, int C, int K, int stride, int pad, int inverse,
+                        hipStream_t stream), (src, dst, B, H, W, C, K, stride, pad, inverse, stream))
 
 template <typename T>
 static int scale_batch_impl(const T* x, const float* s, T* y, int B, long n, hipStream_t stream) {

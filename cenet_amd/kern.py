@@ -441,6 +441,11 @@ def copy_batched(x, sxb, y, syb, B, n, accumulate=False, x_off=0, y_off=0):
     _call("cenet_copy_batched_f32", Ptr(x, x_off), L(sxb), Ptr(y, y_off), L(syb), B, L(n), int(accumulate))
 
 
+def im2col_tok(src, dst, B, H, W, C, K, stride, pad, inverse=False):
+    _chk(src, dst)
+    _call("cenet_im2col_tok_f32", src, dst, B, H, W, C, K, stride, pad, int(inverse))
+
+
 def patch_tok(src, dst, B, Ho, Wo, C, S, inverse=False):
     """Space-to-depth of a token map (inverse: patch rows back to tokens); pvtv2.py:93-95 kernel == stride conv."""
     _chk(src, dst)

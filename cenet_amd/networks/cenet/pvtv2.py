@@ -140,10 +140,16 @@ class OverlapPatchEmbed(nn.Module):
         self.norm = nn.LayerNorm(embed_dim)
         self.apply(_init_weights)
 
-    def forward(self, x):
+    def forward(self, x, tokens=None):
+        """tokens: the same map in token layout [B, H*W, C] (the previous stage's normed output, of which x is the NCHW
+        copy made for the decoder): bf16 3x3 embeddings read it instead, as patch rows + plain GEMMs (ops.conv2d_tok)."""
         H, W = x.shape[2:]
         k, s, p = self.patch_size, self.stride, self.patch_size // 2
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        if tokens is not None and k == 3 and tokens.dtype == torch.bfloat16:
+            t = ops.conv2d_tok(tokens, H, W, self.proj.weight, self.proj.bias, stride=s, pad=p, out_layout="tok")
+            t = ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps)
+            return t, Ho, Wo
         expand = self.in_chans if (x.shape[1] == 1 and self.in_chans > 1) else 0  # net.py:55 without materialising cat
         t = ops.conv2d_nchw(x, self.proj.weight, self.proj.bias, stride=s, pad=p, out_layout="tok", expand_channels=expand)
         t = ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps)
@@ -224,8 +230,9 @@ class PyramidVisionTransformerImpr(nn.Module):
         outs = []
         if self.training:
             self._sample_drop_path(x.shape[0], x.device)
+        t = None
         for s in range(4):
-            t, H, W = getattr(self, f"patch_embed{s + 1}")(x)
+            t, H, W = getattr(self, f"patch_embed{s + 1}")(x, tokens=t)
             for blk in getattr(self, f"block{s + 1}"):
                 t = blk(t, H, W)
             n = getattr(self, f"norm{s + 1}")

@@ -417,6 +417,29 @@ class PatchTokFn(Function):
         return dx, None, None, None
 
 
+class Im2colTokFn(Function):
+    """tokens [B, H*W, C] -> overlapping K x K patch rows [B, Ho*Wo, C*K*K] (cenet_im2col_tok); backward = the gathering
+    transpose, so the convolution's data gradient needs no atomics."""
+
+    @staticmethod
+    def forward(ctx, x, H, Wd, K, stride, pad):
+        x = _c(x)
+        B, N, C = x.shape
+        Ho, Wo = (H + 2 * pad - K) // stride + 1, (Wd + 2 * pad - K) // stride + 1
+        xp = _act((B, Ho * Wo, C * K * K), x)
+        kern.im2col_tok(x, xp, B, H, Wd, C, K, stride, pad)
+        ctx.geom = (B, H, Wd, C, K, stride, pad, N)
+        return xp
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, Wd, C, K, stride, pad, N = ctx.geom
+        g = _c(g)
+        dx = _act((B, N, C), g)
+        kern.im2col_tok(g, dx, B, H, Wd, C, K, stride, pad, inverse=True)
+        return dx, None, None, None, None, None
+
+
 def conv2d_tok(x, H, Wd, W, b=None, stride=1, pad=0, out_layout="tok"):
     """x [B, H*W, C] token layout read as an NCHW map (pvtv2.py:93-94)."""
     x = _c(x)
@@ -427,6 +450,10 @@ def conv2d_tok(x, H, Wd, W, b=None, stride=1, pad=0, out_layout="tok"):
         # non-overlapping patches (the spatial-reduction conv): gather the patches once, then it is a Linear layer over
         # rows of C*k*k with the weight in its own [Cout, (c, ky, kx)] order -- both GEMM operands k-contiguous
         return linear(PatchTokFn.apply(x, H, Wd, k), W, b, split_k=True)
+    if (out_layout == "tok" and _bf(x) and k == 3 and W.shape[3] == 3 and N == H * Wd and W.is_contiguous()):
+        # bf16, overlapping 3x3 patches (patch embeddings of stages 2-4): materialise the rows (2.25x the map), then forward,
+        # weight gradient and data gradient are plain GEMMs for the LDS-DMA ring kernel
+        return linear(Im2colTokFn.apply(x, H, Wd, 3, stride, pad), W, b)
     geom = (B, C, H, Wd, N * C, 1, Wd * C, C, stride, pad, out_layout)
     return Conv2dFn.apply(x, W, b, geom)
 

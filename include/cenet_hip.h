@@ -267,6 +267,11 @@ int cenet_copy_batched_f32(const float* x, long sxb, float* y, long syb, int B, 
  * inverse == 0 gathers tok [B, Ho*S, Wo*S, C] into patch rows [B*Ho*Wo, C*S*S] (k = (c, ky, kx), the weight's own order);
  * inverse == 1 scatters patch rows back to the token map (the data gradient). S in {2, 4, 8}. */
 int cenet_patch_tok_f32(const float* src, float* dst, int B, int Ho, int Wo, int C, int S, int inverse, cenet_stream_t stream);
+/* Overlapping K x K patches of a token-layout map (K = 3; the stride-2 pad-1 patch-embedding convs, pvtv2.py:164):
+ * inverse = 0: src tok [B, H*W, C] -> dst rows [B*Ho*Wo, C*K*K] (k = (c, ky, kx), zeros outside the map);
+ * inverse = 1: src rows -> dst tok, every pixel summing the row entries that cover it (the conv's data gradient). */
+int cenet_im2col_tok_f32(const float* src, float* dst, int B, int H, int W, int C, int K, int stride, int pad, int inverse,
+    cenet_stream_t stream);
 int cenet_scale_batch_f32(const float* x, const float* s, float* y, int B, long n, cenet_stream_t stream);
 int cenet_act_fwd_f32(const float* x, float* y, long n, int act, float slope, cenet_stream_t stream);
 int cenet_act_bwd_f32(const float* pre, const float* dy, float* dx, long n, int act, float slope, cenet_stream_t stream);
@@ -363,6 +368,8 @@ int cenet_copy_batched_bf16(const unsigned short* x, long sxb, unsigned short* y
     cenet_stream_t stream);
 int cenet_patch_tok_bf16(const unsigned short* src, unsigned short* dst, int B, int Ho, int Wo, int C, int S, int inverse,
     cenet_stream_t stream);
+int cenet_im2col_tok_bf16(const unsigned short* src, unsigned short* dst, int B, int H, int W, int C, int K, int stride,
+    int pad, int inverse, cenet_stream_t stream);
 int cenet_scale_batch_bf16(const unsigned short* x, const float* s, unsigned short* y, int B, long n, cenet_stream_t
     stream);
 int cenet_act_fwd_bf16(const unsigned short* x, unsigned short* y, long n, int act, float slope, cenet_stream_t stream);

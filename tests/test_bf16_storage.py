@@ -106,6 +106,16 @@ def test_conv_one_channel_input(dev, Cout, k, H, W):
     compare(lambda x, Wt: ops.conv2d_nchw(x, Wt, None, stride=1, pad=k // 2), [x], [Wt], dev=dev)
 
 
+# 3x3 patch-embedding convs on tokens: bf16 materialises the overlapping patch rows (im2col_tok) and runs plain GEMMs, its
+# data gradient is the gathering transpose; fp32 is the implicit GEMM.  Stride 2 (odd and even maps) and stride 1.
+@pytest.mark.parametrize("B,C,Cout,H,W,s", [(2, 16, 24, 8, 8, 2), (1, 8, 12, 7, 9, 2), (1, 8, 16, 6, 6, 1)])
+def test_conv3x3_tok_overlapping_patches(dev, B, C, Cout, H, W, s):
+    g = G(C + H + s)
+    x = torch.randn(B, H * W, C, generator=g)
+    Wt, b = torch.randn(Cout, C, 3, 3, generator=g) * 0.1, torch.randn(Cout, generator=g)
+    compare(lambda x, Wt, b: ops.conv2d_tok(x, H, W, Wt, b, stride=s, pad=1, out_layout="tok"), [x], [Wt, b], dev=dev)
+
+
 @pytest.mark.parametrize("B,C,Cout,H,W,s", [(2, 16, 24, 8, 8, 2), (1, 64, 40, 8, 8, 4)])
 def test_sr_conv_tok(dev, B, C, Cout, H, W, s):
     g = G(C + s)
