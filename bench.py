@@ -178,14 +178,18 @@ class _Trace:
         return g
 
 
-def _hold_stream(ms=60.0):
+HOLD_MS = [60.0]  # set from the measured eager step time (main): long enough for the host to queue a whole step
+
+
+def _hold_stream(ms=None):
     """Parks the stream behind a spin kernel so that the host queues the whole instrumented step before the GPU starts it:
     the intervals between two events then are kernel durations (as rocprofv3 reports them), not host launch gaps."""
     torch.cuda.synchronize()
-    torch.cuda._sleep(int(ms * 1e-3 * 2.0e9))  # cycles of the ~2 GHz shader clock
+    ms = HOLD_MS[0] if ms is None else ms
+    torch.cuda._sleep(int(ms * 1e-3 * 2.0e9))  # cycles of the ~2 GHz shader clock (shows up as `spin_kernel` in a profile)
 
 
-def roofline_block(body, steps=3):
+def roofline_block(body, steps=2):
     """dominant kernel instance of the step (largest summed duration among the bracketed launches)"""
     from cenet_amd import ops
     tr = _Trace()
@@ -235,7 +239,7 @@ def roofline_block(body, steps=3):
     return out
 
 
-def stage_block(net, body, B, size, steps=3):
+def stage_block(net, body, B, size, steps=2):
     """forward + backward time of every SURVEY §8d stage (module hooks + HIP events, weight gradients on the main stream)"""
     from cenet_amd import ops
     old = ops.set_wgrad_overlap(False)
@@ -425,6 +429,7 @@ def main():
                 graphed()
             t_e, t_g = _time_steps(body, 4), _time_steps(graphed, 4)
             launch_note = f"auto: eager {t_e * 1e3:.1f} ms vs hipGraph replay {t_g * 1e3:.1f} ms over 4 untimed steps each"
+            HOLD_MS[0] = min(80.0, max(20.0, 1.25 * t_e * 1e3))
             if t_e <= t_g:
                 graphed = None
 

@@ -54,8 +54,27 @@ __global__ __launch_bounds__(256) void gemm_asum_kernel(const GT* __restrict__ A
     if (threadIdx.x == 0) atomicAdd(&asum[m], s);
   }
 }
+extern "C" int cenet_col_sum_acc_f32(const float* a, float* out_acc, long R, int C, hipStream_t stream);
+extern "C" int cenet_col_sum_acc_bf16(const bf16_t* a, float* out_acc, long R, int C, hipStream_t stream);
+extern "C" int cenet_chan_dot_acc_f32(const float* a, long sab, const float* b, long sbb, float* out_acc, int B, int C, int HW,
+                                      hipStream_t stream);
+extern "C" int cenet_chan_dot_acc_bf16(const bf16_t* a, long sab, const bf16_t* b, long sbb, float* out_acc, int B, int C, int HW,
+                                       hipStream_t stream);
+
 template <typename GT>
 static void launch_asum(const cenet_mat_t* A, int M, int K, int nkb, float* asum, hipStream_t stream) {
+  // the two layouts the network produces have tuned reductions of their own (elementwise.hip): token-major dY [K, M]
+  // (column sums) and per-image channel planes dY [nkb][M][K] (plane sums)
+  if (A->sr == 1 && A->sc == M && nkb == 1) {
+    if (sizeof(GT) == 2) cenet_col_sum_acc_bf16((const bf16_t*)A->ptr, asum, K, M, stream);
+    else cenet_col_sum_acc_f32((const float*)A->ptr, asum, K, M, stream);
+    return;
+  }
+  if (A->sc == 1 && A->sr == K && (nkb == 1 || A->skb >= (long)M * K)) {
+    if (sizeof(GT) == 2) cenet_chan_dot_acc_bf16((const bf16_t*)A->ptr, A->skb, nullptr, 0, asum, nkb, M, K, stream);
+    else cenet_chan_dot_acc_f32((const float*)A->ptr, A->skb, nullptr, 0, asum, nkb, M, K, stream);
+    return;
+  }
   const long total = (long)nkb * K;
   if (A->sr == 1 && A->sc != 1) {
     int ys = (int)((total + 511) / 512);

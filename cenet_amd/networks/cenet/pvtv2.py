@@ -232,7 +232,7 @@ class PyramidVisionTransformerImpr(nn.Module):
             self._sample_drop_path(x.shape[0], x.device)
         t = None
         for s in range(4):
-            t, H, W = getattr(self, f"patch_embed{s + 1}")(x, tokens=t)
+            t, H, W = getattr(self, f"patch_embed{s + 1}")(x, t)  # (positional: module backward hooks only see positional inputs)
             for blk in getattr(self, f"block{s + 1}"):
                 t = blk(t, H, W)
             n = getattr(self, f"norm{s + 1}")
