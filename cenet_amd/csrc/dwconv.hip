@@ -284,6 +284,29 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_tok_v4_kernel(const T* __rest
   }
 }
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): the tile kernels are VALU-bound, and libm's
+// erff + expf cost more than the nine taps.  Only the bf16 kernels use it; the fp32 (parity) kernels keep erff.
+__device__ __forceinline__ float dw_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = 1.f / (1.f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.f - poly * fast_exp(-ax * ax);
+  return copysignf(r, x);
+}
+template <int ACT>
+__device__ __forceinline__ float dw_act(float u, int act, float slope) {
+  if (ACT == ACT_NONE) return u;
+  if (ACT == ACT_GELU) return 0.5f * u * (1.f + dw_erf(u * 0.70710678118654752f));
+  return act_fwd(act, u, slope);
+}
+template <int ACT>
+__device__ __forceinline__ float dw_act_grad(float u, int act, float slope) {
+  if (ACT == ACT_NONE) return 1.f;
+  if (ACT == ACT_GELU)
+    return 0.5f * (1.f + dw_erf(u * 0.70710678118654752f)) + u * 0.3989422804014327f * fast_exp(-0.5f * u * u);
+  return act_bwd(act, u, slope);
+}
+
 // ---- 16-byte NCHW kernels (W % 4 == 0): a thread owns 4 consecutive pixels of one row --------------------------------
 // x window of tap column kx for the quad at (iy, px..px+3): unaligned 16-byte load inside the row, masked scalars at its ends
 template <typename T>
@@ -296,7 +319,8 @@ __device__ __forceinline__ q4 ld_row4(const T* row, int ix0, int W) {
 }
 
 // grid (B*C, chunks), any block size; y_pre = conv(x)+bias ; if a != nullptr: a = act(y_pre)
-template <typename T>
+// ACT: ACT_NONE / ACT_GELU compiled in (GELU with the 1.5e-7 erf above, bf16 tensors only), -1 = run-time switch
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void dw3x3_nchw_v4_kernel(const T* __restrict__ x, long sxb, const float* __restrict__ w,
                                                            const float* __restrict__ bias, T* __restrict__ y, long syb,
                                                            T* __restrict__ a, long sab, int C, int H, int W, int dil,
@@ -326,7 +350,7 @@ __global__ __launch_bounds__(256) void dw3x3_nchw_v4_kernel(const T* __restrict_
     if (y) st4v(y + (long)b * syb + (long)c * HW + 4 * q, acc.v);
     if (a) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc.v[e] = act_fwd(act, acc.v[e], slope);
+      for (int e = 0; e < 4; ++e) acc.v[e] = dw_act<ACT>(acc.v[e], act, slope);
       st4v(a + (long)b * sab + (long)c * HW + 4 * q, acc.v);
     }
   }
@@ -386,17 +410,201 @@ static inline int plane_chunks(int HW) {
 }
 
 // y (pre-activation) may be NULL when only the activated output a is wanted
+// ---- bf16 NCHW, planes resident in LDS (H * W % 4 == 0, (H + 2 dil) * (W + 2 dil) <= DWP_MAX) ------------------------------
+// The quad kernels above read every tap window from L1 with unaligned 8-byte loads and ran the decoder's big depthwise convs
+// (CFAM Mlp: 256 ch @56x56 ... 2048 ch @7x7; EUCB) at ~1.1-1.3 TB/s.  Here a workgroup stages whole (batch, channel) planes —
+// as many as fit — into a zero-bordered fp32 LDS tile with aligned 8-byte loads (everything in flight at once), then every
+// thread computes output quads from LDS; the nine weights of a plane are workgroup data.  Forward (+bias, +activation,
+// optional pre-activation store), data gradient (mirrored taps) and weight gradient (10 partial sums per thread -> LDS atomics
+// per plane -> one global atomic per (channel, tap) and workgroup).
+#define DWP_MAX 4624  // floats of LDS per workgroup: one 64x64 plane with dilation 2, or 57 padded 7x7 planes
+struct DwPlaneArgs {
+  const bf16_t* x;
+  long sxb;
+  const float* w;
+  const float* bias;
+  bf16_t* y;
+  long syb;
+  bf16_t* a;
+  long sab;
+  const bf16_t* dy;  // weight gradient
+  long sgb;
+  float* dw;
+  float* db;
+  int BC, C, H, W, dil, flip, act, ppw;
+  float slope;
+};
+
+template <int MODE>  // 0: forward / data gradient, 2: weight gradient
+__device__ __forceinline__ void dwp_stage(const DwPlaneArgs& a, float* tile, int p0, int np, int PS, int PWd) {
+  const int HW = a.H * a.W, nq = HW >> 2;
+  for (int i = threadIdx.x; i < np * PS; i += 256) tile[i] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < np * nq; i += 256) {
+    const int pl = i / nq, q = i - pl * nq;
+    const int bc = p0 + pl, b = bc / a.C, c = bc - b * a.C;
+    float v[4];
+    ld4v(v, a.x + (long)b * a.sxb + (long)c * HW + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // (a quad may straddle two rows when W % 4 != 0: 14x14 maps)
+      const int p = 4 * q + e, py = p / a.W, px = p - py * a.W;
+      tile[pl * PS + (py + a.dil) * PWd + px + a.dil] = v[e];
+    }
+  }
+  __syncthreads();
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void dw3x3_nchw_plane_kernel(DwPlaneArgs a) {
+  __shared__ float tile[DWP_MAX];
+  __shared__ float wts[64][10];
+  const int HW = a.H * a.W, nq = HW >> 2, d = a.dil;
+  const int PWd = a.W + 2 * d, PS = (a.H + 2 * d) * PWd;
+  const int p0 = blockIdx.x * a.ppw;
+  const int np = p0 + a.ppw <= a.BC ? a.ppw : a.BC - p0;
+  for (int i = threadIdx.x; i < np * 10; i += 256) {
+    const int pl = i / 10, t = i - pl * 10, c = (p0 + pl) % a.C;
+    wts[pl][t] = t < 9 ? a.w[c * 9 + (a.flip ? 8 - t : t)] : (a.bias ? a.bias[c] : 0.f);
+  }
+  dwp_stage<0>(a, tile, p0, np, PS, PWd);
+  for (int i = threadIdx.x; i < np * nq; i += 256) {
+    const int pl = i / nq, q = i - pl * nq;
+    const int bc = p0 + pl, b = bc / a.C, c = bc - b * a.C;
+    int off[4];  // tap (ky, kx) of output element e sits at tile[off[e] + ky*d*PWd + kx*d]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = 4 * q + e, py = p / a.W, px = p - py * a.W;
+      off[e] = pl * PS + py * PWd + px;
+    }
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = wts[pl][9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float wv = wts[pl][ky * 3 + kx];
+        const int ro = ky * d * PWd + kx * d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += wv * tile[off[e] + ro];
+      }
+    const long o = (long)c * HW + 4 * q;
+    if (a.y) st4v(a.y + (long)b * a.syb + o, acc);
+    if (a.a) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = dw_act<ACT>(acc[e], a.act, a.slope);
+      st4v(a.a + (long)b * a.sab + o, acc);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_plane_kernel(DwPlaneArgs a) {
+  __shared__ float tile[DWP_MAX];
+  __shared__ float sums[64][10];
+  const int HW = a.H * a.W, nq = HW >> 2, d = a.dil;
+  const int PWd = a.W + 2 * d, PS = (a.H + 2 * d) * PWd;
+  const int p0 = blockIdx.x * a.ppw;
+  const int np = p0 + a.ppw <= a.BC ? a.ppw : a.BC - p0;
+  for (int i = threadIdx.x; i < np * 10; i += 256) sums[i / 10][i % 10] = 0.f;
+  dwp_stage<2>(a, tile, p0, np, PS, PWd);
+  // work items = (plane, chunk of 64 quads), dealt to the four waves in turn: the plane is wave-uniform, so the ten partial sums
+  // are folded across the wave with shuffles and ONE lane adds them to the plane's LDS slots when the plane changes
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cpp = (nq + 63) >> 6, csz = (nq + cpp - 1) / cpp, items = np * cpp;  // equal chunks (196 quads: 4 x 49, not 3 x 64 + 4)
+  float acc[10];
+  int cur = -1;
+  auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      float v = acc[t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) atomicAdd(&sums[cur][t], v);
+    }
+  };
+  for (int j = wave; j < items; j += 4) {
+    const int pl = j / cpp, q = (j - pl * cpp) * csz + lane;
+    if (pl != cur) {  // (wave-uniform)
+      if (cur >= 0) flush();
+      cur = pl;
+#pragma unroll
+      for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+    }
+    if (lane >= csz || q >= nq) continue;
+    const int bc = p0 + pl, b = bc / a.C, c = bc - b * a.C;
+    float g[4];
+    ld4v(g, a.dy + (long)b * a.sgb + (long)c * HW + 4 * q);
+    int off[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = 4 * q + e, py = p / a.W, px = p - py * a.W;
+      off[e] = pl * PS + py * PWd + px;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[9] += g[e];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ro = ky * d * PWd + kx * d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[ky * 3 + kx] += g[e] * tile[off[e] + ro];
+      }
+  }
+  if (cur >= 0) flush();
+  __syncthreads();
+  for (int i = threadIdx.x; i < np * 10; i += 256) {
+    const int pl = i / 10, t = i - pl * 10, c = (p0 + pl) % a.C;
+    if (t < 9) atomicAdd(&a.dw[c * 9 + t], sums[pl][t]);
+    else if (a.db) atomicAdd(&a.db[c], sums[pl][9]);
+  }
+}
+
+// planes per workgroup: as many padded planes as the tile holds, at most 64, and at least ~1024 workgroups where possible
+static inline int dwp_ppw(int BC, int H, int W, int dil) {
+  const int ps = (H + 2 * dil) * (W + 2 * dil);
+  if (ps > DWP_MAX || ((H * W) & 3)) return 0;
+  int ppw = DWP_MAX / ps;
+  if (ppw > 64) ppw = 64;
+  while (ppw > 1 && cdiv(BC, ppw) < 1024) --ppw;
+  return ppw;
+}
+
 template <typename T>
 static int dwconv3x3_nchw_impl(const T* x, long sxb, const float* w, const float* bias, T* y, long syb, T* a, long sab, int B,
                                int C, int H, int W, int dil, int flip, int act, float slope, hipStream_t stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || dil <= 0 || (!y && !a)) return CENET_EINVAL;
+  static const bool plane_off = getenv("CENET_DW_NO_PLANE") != nullptr;
+  if (sizeof(T) == 2 && !plane_off && ((sxb | syb | sab) & 3) == 0 && quad_aligned<T>(x) && (!y || quad_aligned<T>(y)) &&
+      (!a || quad_aligned<T>(a)) && ((long)H * W) % 4 == 0) {
+    const int ppw = dwp_ppw(B * C, H, W, dil);
+    if (ppw > 0) {
+      DwPlaneArgs p;
+      p.x = (const bf16_t*)x; p.sxb = sxb; p.w = w; p.bias = bias; p.y = (bf16_t*)y; p.syb = syb; p.a = (bf16_t*)a; p.sab = sab;
+      p.dy = nullptr; p.sgb = 0; p.dw = p.db = nullptr;
+      p.BC = B * C; p.C = C; p.H = H; p.W = W; p.dil = dil; p.flip = flip; p.act = act; p.ppw = ppw; p.slope = slope;
+      const dim3 grid(cdiv(B * C, ppw));
+      if (!a || act == ACT_NONE) CENET_LAUNCH((dw3x3_nchw_plane_kernel<ACT_NONE>), grid, dim3(256), stream, p);
+      else if (act == ACT_GELU) CENET_LAUNCH((dw3x3_nchw_plane_kernel<ACT_GELU>), grid, dim3(256), stream, p);
+      else CENET_LAUNCH((dw3x3_nchw_plane_kernel<-1>), grid, dim3(256), stream, p);
+      CENET_CHECK_LAUNCH();
+      return CENET_OK;
+    }
+  }
   if ((W & 3) == 0 && ((sxb | syb | sab) & 3) == 0 && al16p<T>(x, y, a)) {
     const int nq = H * W / 4;
     const int th = nq <= 64 ? 64 : (nq <= 128 ? 128 : 256);
     int ch = cdiv(nq, th * 2);
     if (ch > 16) ch = 16;
-    CENET_LAUNCH((dw3x3_nchw_v4_kernel<T>), dim3(B * C, ch), dim3(th), stream, x, sxb, w, bias, y, syb, a, sab, C, H, W, dil, flip,
-                 act, slope);
+    if (sizeof(T) == 2 && (!a || act == ACT_NONE))
+      CENET_LAUNCH((dw3x3_nchw_v4_kernel<T, ACT_NONE>), dim3(B * C, ch), dim3(th), stream, x, sxb, w, bias, y, syb, a, sab, C, H, W,
+                   dil, flip, act, slope);
+    else if (sizeof(T) == 2 && act == ACT_GELU)
+      CENET_LAUNCH((dw3x3_nchw_v4_kernel<T, ACT_GELU>), dim3(B * C, ch), dim3(th), stream, x, sxb, w, bias, y, syb, a, sab, C, H, W,
+                   dil, flip, act, slope);
+    else
+      CENET_LAUNCH((dw3x3_nchw_v4_kernel<T, -1>), dim3(B * C, ch), dim3(th), stream, x, sxb, w, bias, y, syb, a, sab, C, H, W, dil,
+                   flip, act, slope);
   } else {
     CENET_LAUNCH((dw3x3_nchw_kernel<T>), dim3(B * C, plane_chunks(H * W)), dim3(256), stream, x, sxb, w, bias, y, syb, a, sab, C,
                  H, W, dil, flip, act, slope);
@@ -437,29 +645,6 @@ struct DwTileArgs {
   int C, H, W, flip, act, tiles_x, ntiles, tpw;
   float slope;
 };
-
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): the tile kernels are VALU-bound, and libm's
-// erff + expf cost more than the nine taps.  Only the bf16 kernels use it; the fp32 (parity) kernels keep erff.
-__device__ __forceinline__ float dw_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = 1.f / (1.f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.f - poly * fast_exp(-ax * ax);
-  return copysignf(r, x);
-}
-template <int ACT>
-__device__ __forceinline__ float dw_act(float u, int act, float slope) {
-  if (ACT == ACT_NONE) return u;
-  if (ACT == ACT_GELU) return 0.5f * u * (1.f + dw_erf(u * 0.70710678118654752f));
-  return act_fwd(act, u, slope);
-}
-template <int ACT>
-__device__ __forceinline__ float dw_act_grad(float u, int act, float slope) {
-  if (ACT == ACT_NONE) return 1.f;
-  if (ACT == ACT_GELU)
-    return 0.5f * (1.f + dw_erf(u * 0.70710678118654752f)) + u * 0.3989422804014327f * fast_exp(-0.5f * u * u);
-  return act_bwd(act, u, slope);
-}
 
 // 16 (CPT = 8) or 8 (CPT = 4) bytes of one pixel's channels from LDS / HBM, as packed bf16 pairs
 template <int CPT>
@@ -726,6 +911,19 @@ template <typename T>
 static int dwconv3x3_wgrad_nchw_acc_impl(const T* x, long sxb, const T* dy, long sgb, float* dw_acc, float* dbias_acc, int B,
                                          int C, int H, int W, int dil, hipStream_t stream) {
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+  static const bool plane_off = getenv("CENET_DW_NO_PLANE") != nullptr;
+  if (sizeof(T) == 2 && !plane_off && ((sxb | sgb) & 3) == 0 && quad_aligned<T>(x) && quad_aligned<T>(dy)) {
+    const int ppw = dwp_ppw(B * C, H, W, dil);
+    if (ppw > 0) {
+      DwPlaneArgs p;
+      p.x = (const bf16_t*)x; p.sxb = sxb; p.w = nullptr; p.bias = nullptr; p.y = p.a = nullptr; p.syb = p.sab = 0;
+      p.dy = (const bf16_t*)dy; p.sgb = sgb; p.dw = dw_acc; p.db = dbias_acc;
+      p.BC = B * C; p.C = C; p.H = H; p.W = W; p.dil = dil; p.flip = 0; p.act = 0; p.ppw = ppw; p.slope = 0.f;
+      CENET_LAUNCH(dw3x3_wgrad_nchw_plane_kernel, dim3(cdiv(B * C, ppw)), dim3(256), stream, p);
+      CENET_CHECK_LAUNCH();
+      return CENET_OK;
+    }
+  }
   long total = (long)B * H * W;
   long want = 1024 / C;
   long maxs = (total + 2047) / 2048;

@@ -54,7 +54,14 @@ def bracket(fn, label):
     return f
 
 
-kern._call = bracket(kern._call, lambda name, *a: name.replace("cenet_", "").replace("_f32", ""))
+def _lab(name, *a):
+    n = name.replace("cenet_", "").replace("_f32", "")
+    if os.environ.get("TRACE_SHAPES") and n.startswith(("dwconv3x3", "bn_", "bilinear", "copy_batched", "layernorm")):
+        n += " " + ",".join(str(v) for v in a if isinstance(v, int) and not isinstance(v, bool))
+    return n
+
+
+kern._call = bracket(kern._call, _lab)
 kern.gemm = bracket(kern.gemm, lambda A, B, C, M, N, K, **kw: f"gemm {kern.last_gemm_kernel()} M{M} N{N} K{K} nb{kw.get('nbatch', 1)}"
                     f" nkb{kw.get('nkb', 1)}{' at' if kw.get('atomic') else ''}")
 kern.flash_fwd = bracket(kern.flash_fwd, lambda a, bf=False: f"flash_fwd Nq{a.Nq} Nk{a.Nk} D{a.D} H{a.H}")
