@@ -332,6 +332,48 @@ __global__ __launch_bounds__(256) void bilinear_down2_bwd_kernel(const T* __rest
   }
 }
 
+// Strong up-sampling backward (bf16; the 7x7 -> 49x49 pooled branch of cfam.py:231-236): the gather form above gives one thread
+// per input pixel — 49 busy threads per plane, each walking ~250 candidate outputs (70-80 us for 0.3 M elements).  Here a
+// workgroup owns a plane and its threads take (input pixel, candidate output ROW) pairs: the row's taps are summed with the
+// separable x weights, weighted by wy and added to the pixel's fp32 bin in LDS (~16 adds per bin).
+#define BIL_LDS_MAX 1024
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx, long sdb,
+                                                               int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
+                                                               int align, int maxrows) {
+  __shared__ float bins[BIL_LDS_MAX];
+  const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
+  const T* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
+  T* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
+  for (int i = threadIdx.x; i < Hi * Wi; i += 256) bins[i] = 0.f;
+  __syncthreads();
+  for (int it = threadIdx.x; it < Hi * Wi * maxrows; it += 256) {
+    const int i = it / maxrows, rr = it - i * maxrows;
+    const int iy = i / Wi, ix = i - iy * Wi;
+    int ylo, yhi, xlo, xhi;
+    bil_range(iy, sh, align, Ho, ylo, yhi);
+    const int oy = ylo + rr;
+    if (oy >= yhi) continue;
+    int y0, y1;
+    float ly;
+    bil_coord(oy, sh, align, Hi, y0, y1, ly);
+    const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+    if (wy == 0.f) continue;
+    bil_range(ix, sw, align, Wo, xlo, xhi);
+    float row = 0.f;
+    for (int ox = xlo; ox < xhi; ++ox) {
+      int x0, x1;
+      float lx;
+      bil_coord(ox, sw, align, Wi, x0, x1, lx);
+      const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+      if (wx != 0.f) row += wx * ldf(gp + oy * Wo + ox);
+    }
+    atomicAdd(&bins[i], wy * row);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Hi * Wi; i += 256) stf(dp + i, bins[i]);
+}
+
 template <typename T>
 static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
                              float scale_w, int align_corners, hipStream_t stream) {
@@ -339,6 +381,13 @@ static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int 
   // (bf16 tensors only: the fp32 parity mode keeps the one summation order of the general kernel)
   if (sizeof(T) == 2 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && scale_h == 0.5f && scale_w == 0.5f && Hi > 1 && Wi > 1) {
     CENET_LAUNCH((bilinear_up2_bwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
+  if (sizeof(T) == 2 && Hi * Wi <= BIL_LDS_MAX && scale_h > 1e-6f && scale_h <= 0.3f && scale_w > 1e-6f && scale_w <= 0.3f) {
+    const int maxrows = (int)(2.f / scale_h) + 4;  // bil_range spans (i-1 .. i+1) / scale plus a slack index each side
+    CENET_LAUNCH((bilinear_bwd_rows_kernel<T>), dim3(B * C), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho, Wo, scale_h,
+                 scale_w, align_corners, maxrows);
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }

@@ -226,10 +226,12 @@ def test_layout_and_glue(dev):
     compare(lambda a, c, ls: ops.scale_residual(a, c, ls), [a7, a7 * 0.5 + 1], [torch.rand(1, 3, 1, 1, generator=g)], dev=dev)
 
 
-# (exact x2 / x0.5 with align_corners=False take the fixed-tap backward kernels in bf16; the fp32 run is the general gather)
+# (exact x2 / x0.5 with align_corners=False take the fixed-tap backward kernels in bf16, strong up-sampling (x7, cfam.py:231-236;
+# x4.5-5) the row-parallel one; the fp32 run is the general gather)
 @pytest.mark.parametrize("kw", [dict(scale_factor=2, align_corners=True), dict(scale_factor=0.5, align_corners=False),
                                 dict(size=(9, 11), align_corners=False), dict(scale_factor=2, align_corners=False),
-                                dict(size=(16, 20), align_corners=False)])
+                                dict(size=(16, 20), align_corners=False), dict(scale_factor=7, align_corners=True),
+                                dict(size=(40, 45), align_corners=False)])
 def test_resampling(dev, kw):
     g = G(9)
     x = torch.randn(2, 3, 8, 10, generator=g)
