@@ -932,6 +932,88 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_flat_kernel(const T* __res
     ws[((long)gridDim.x + c) * gridDim.y + blockIdx.y] = s2;
   }
 }
+// ---- one kernel per pass for channels whose whole batch fits a workgroup's registers (bf16, B*HW <= 8192, e.g. the 7x7 and
+// 14x14 decoder levels at B = 32): workgroup = channel; its 256 threads hold up to 32 elements each, so the statistics, the
+// normalisation (or the whole backward formula) and the write happen without a second launch or a partial-sum round trip.
+#define BN1K_EPT 32
+__global__ __launch_bounds__(256) void bn_train_fwd_1k_kernel(const bf16_t* __restrict__ x, long sxb, bf16_t* __restrict__ y, long syb,
+                                                             float eps, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int act, float slope, int B, int HW,
+                                                             BnFin fin) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, total = B * HW;
+  float v[BN1K_EPT];
+  float s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < BN1K_EPT; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    v[k] = 0.f;
+    if (e < total) {
+      const int b = e / HW, p = e - b * HW;
+      v[k] = cenet_bf2f(x[(long)b * sxb + (long)c * HW + p]);
+      s1 += v[k];
+    }
+  }
+  const float n = (float)total;
+  const float mu = block_sum(s1, red) / n;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < BN1K_EPT; ++k)
+    if (threadIdx.x + 256 * k < total) s2 += (v[k] - mu) * (v[k] - mu);
+  const float vr = block_sum(s2, red) / n;
+  if (threadIdx.x == 0) bn_fin_publish(fin, c, mu, vr);
+  const float sc = gamma[c] * rsqrtf(vr + eps), sh = beta[c] - mu * sc;
+#pragma unroll
+  for (int k = 0; k < BN1K_EPT; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    if (e < total) {
+      const int b = e / HW, p = e - b * HW;
+      stf(y + (long)b * syb + (long)c * HW + p, act_fwd(act, v[k] * sc + sh, slope));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_1k_kernel(const bf16_t* __restrict__ dy, long sgb, const bf16_t* __restrict__ x,
+                                                       long sxb, bf16_t* __restrict__ dx, long sdb,
+                                                       const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                       float slope, int B, int HW, float* dgamma, float* dbeta) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, total = B * HW;
+  const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
+  float xh[BN1K_EPT], g[BN1K_EPT];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < BN1K_EPT; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    xh[k] = g[k] = 0.f;
+    if (e < total) {
+      const int b = e / HW, p = e - b * HW;
+      xh[k] = (cenet_bf2f(x[(long)b * sxb + (long)c * HW + p]) - mu) * rs;
+      float gg = cenet_bf2f(dy[(long)b * sgb + (long)c * HW + p]);
+      if (act != ACT_NONE) gg *= act_bwd(act, xh[k] * gm + bt, slope);
+      g[k] = gg;
+      s1 += gg;
+      s2 += gg * xh[k];
+    }
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  const float n = (float)total, m1 = s1 / n, m2 = s2 / n;
+#pragma unroll
+  for (int k = 0; k < BN1K_EPT; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    if (e < total) {
+      const int b = e / HW, p = e - b * HW;
+      stf(dx + (long)b * sdb + (long)c * HW + p, gm * rs * (g[k] - m1 - xh[k] * m2));
+    }
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&dgamma[c], s2);
+    atomicAdd(&dbeta[c], s1);
+  }
+}
+
 // the flat forms apply: bf16 tensors (the fp32 parity mode keeps its summation order), small planes, no batch gaps
 template <typename T>
 static inline bool bn_flat_ok(int C, int HW, long s0, long s1, long s2) {
@@ -1068,6 +1150,15 @@ static int bn_train_fwd_impl(const T* x, long sxb, T* y, long syb, float* ws, fl
     if (rc != CENET_OK) return rc;
     return bn_apply_impl<T>(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, stream);
   }
+  if ((long)B * HW <= 256 * BN1K_EPT && (long)B * HW >= 2) {
+    BnFin f1;
+    f1.ws = nullptr; f1.S = 0; f1.n = (float)((long)B * HW); f1.mean = mean; f1.var = var; f1.rmean = running_mean;
+    f1.rvar = running_var; f1.momentum = momentum; f1.nbt = num_batches_tracked;
+    CENET_LAUNCH(bn_train_fwd_1k_kernel, dim3(C), dim3(256), stream, (const bf16_t*)x, sxb, (bf16_t*)y, syb, eps, gamma, beta, act,
+                 slope, B, HW, f1);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   BnFin fin;
   fin.S = bn_partial_launch<T>(x, sxb, B, C, HW, ws, stream);
   fin.ws = ws; fin.n = (float)((long)B * HW); fin.mean = mean; fin.var = var; fin.rmean = running_mean; fin.rvar = running_var;
@@ -1089,6 +1180,12 @@ static int bn_bwd_acc_impl(const T* dy, long sgb, const T* x, long sxb, T* dx, l
                            float* ws, float* dgamma_acc, float* dbeta_acc, hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   const long total = (long)B * HW;
+  if (sizeof(T) == 2 && total <= 256 * BN1K_EPT) {
+    CENET_LAUNCH(bn_bwd_1k_kernel, dim3(C), dim3(256), stream, (const bf16_t*)dy, sgb, (const bf16_t*)x, sxb, (bf16_t*)dx, sdb, mean,
+                 var, eps, gamma, beta, act, slope, B, HW, dgamma_acc, dbeta_acc);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   if (bn_flat_ok<T>(C, HW, sgb, sxb, sdb)) {
     const bool v4 = bn_v4_ok<T>(HW, dy, sgb, x, sxb, dx, sdb);
     const int S = v4 ? bn_splits_v4(C, total / 4) : bn_splits(C, total);
