@@ -932,10 +932,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_flat_kernel(const T* __res
     ws[((long)gridDim.x + c) * gridDim.y + blockIdx.y] = s2;
   }
 }
-// ---- one kernel per pass for channels whose whole batch fits a workgroup's registers (bf16, B*HW <= 8192, e.g. the 7x7 and
-// 14x14 decoder levels at B = 32): workgroup = channel; its 256 threads hold up to 32 elements each, so the statistics, the
+// ---- one kernel per pass for channels whose whole batch fits a workgroup's registers (bf16, B*HW <= 2048, e.g. the 7x7
+// decoder level at B = 32): workgroup = channel; its 256 threads hold up to 8 elements each, so the statistics, the
 // normalisation (or the whole backward formula) and the write happen without a second launch or a partial-sum round trip.
-#define BN1K_EPT 32
+#define BN1K_EPT 8   // (measured: 32 elements per thread — 14x14 maps at B = 32 — ran slower than the two-kernel flat form)
 __global__ __launch_bounds__(256) void bn_train_fwd_1k_kernel(const bf16_t* __restrict__ x, long sxb, bf16_t* __restrict__ y, long syb,
                                                              float eps, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act, float slope, int B, int HW,

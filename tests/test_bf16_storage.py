@@ -138,7 +138,7 @@ def test_layernorm_and_residual_form(dev, rows, C):
     compare(res, [x], [gm, bt], dev=dev)
 
 
-# bf16: channels of up to 8192 elements (B*H*W) run the one-kernel forms; beyond that planes of up to 1024 pixels take the flat
+# bf16: channels of up to 2048 elements (B*H*W) run the one-kernel forms; beyond that planes of up to 1024 pixels take the flat
 # small-plane kernels (12 x 28x28, 12 x 7x9) and larger planes the plane-per-workgroup ones (6 x 40x40)
 @pytest.mark.parametrize("B,C,H,W,act", [(3, 5, 14, 14, "none"), (2, 4, 28, 28, "relu"), (4, 3, 7, 7, "lrelu"),
                                          (2, 4, 40, 40, "relu"), (2, 3, 9, 5, "none"), (12, 3, 28, 28, "relu"),
