@@ -192,11 +192,13 @@ __global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const T* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 // SRM channel statistics, single pass: workgroup = 64 pixels x 4 channel groups (lanes along pixels: every load is a
 // contiguous 256-byte row segment), shifted sums (shift = channel 0) for mean / unbiased std, groups meet in LDS.
-template <typename T>
-__global__ __launch_bounds__(256) void srm_stats_fwd_kernel(const T* __restrict__ x, float* __restrict__ u,
-                                                           int* __restrict__ amax, int C, int HW) {
-  __shared__ float s1_s[4][64], s2_s[4][64], mx_s[4][64];
-  __shared__ int mi_s[4][64];
+// NG channel groups = NG waves: 4, or 16 for small maps in bf16 mode (7x7: one workgroup per image walked 2048 channels with
+// four groups: 144 us for 6 MB)
+template <typename T, int NG>
+__global__ __launch_bounds__(64 * NG) void srm_stats_fwd_kernel(const T* __restrict__ x, float* __restrict__ u,
+                                                               int* __restrict__ amax, int C, int HW) {
+  __shared__ float s1_s[NG][64], s2_s[NG][64], mx_s[NG][64];
+  __shared__ int mi_s[NG][64];
   const int b = blockIdx.y;
   const int pl = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + pl;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void srm_stats_fwd_kernel(const T* __restrict_
   float s1 = 0.f, s2 = 0.f, mx = -3.4e38f;
   int mi = 0;
   if (ok) {
-    for (int c = cg; c < C; c += 4) {
+    for (int c = cg; c < C; c += NG) {
       const float v = ldf(xb + (long)c * HW);
       const float d = v - shift;
       s1 += d;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void srm_stats_fwd_kernel(const T* __restrict_
     float a1 = 0.f, a2 = 0.f, bm = mx_s[0][pl];
     int bi = mi_s[0][pl];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NG; ++g) {
       a1 += s1_s[g][pl];
       a2 += s2_s[g][pl];
       const float m = mx_s[g][pl];
@@ -274,42 +276,50 @@ __global__ __launch_bounds__(256) void srm_conv_fwd_kernel(const float* __restri
   f[(long)b * HW + p] = acc;
 }
 
-// du[b,ch,p] from df[b,p]; weight grads (3 + 27) accumulated with block partial sums + atomics
+// du[b,ch,p] from df[b,p]; weight grads (3 + 27): per-thread partial sums over the workgroup's pixel chunks, ONE set of 30
+// block sums and 30 float atomics per workgroup.  (All 30 gradients live in one cache line and same-line atomics serialise at
+// ~12 ns each: with a workgroup per 256 pixels the 56x56 level issued 12 480 of them = 150 us; the grid is now (<= 2, B).)
 __global__ __launch_bounds__(256) void srm_conv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ df,
                                                           const float* __restrict__ pwc, const float* __restrict__ dwc,
                                                           float* __restrict__ du, float* __restrict__ dpwc,
                                                           float* __restrict__ ddwc, int H, int W) {
   __shared__ float red[16];
   const int b = blockIdx.y, HW = H * W;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = p < HW;
-  const int py = valid ? p / W : 0, px = valid ? p - py * W : 0;
   const float* ub = u + (long)b * 3 * HW;
   const float* gb = df + (long)b * HW;
-  const float g = valid ? gb[p] : 0.f;
+  float wsum[3][10];  // [channel][9 taps, pointwise]
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int t = 0; t < 10; ++t) wsum[ch][t] = 0.f;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const int py = p / W, px = p - py * W;
+    const float g = gb[p];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float acc = pwc[ch] * g;  // data gradient (correlation with flipped taps)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int t = ky * 3 + kx;
+          // du[p] += dwc[t] * df[p - off_t]  ;  ddwc[t] += df[p] * u[p + off_t]
+          const int qy = py - (ky - 1), qx = px - (kx - 1);
+          if (qy >= 0 && qy < H && qx >= 0 && qx < W) acc += dwc[ch * 9 + t] * gb[qy * W + qx];
+          const int iy = py + ky - 1, ix = px + kx - 1;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) wsum[ch][t] += g * ub[ch * HW + iy * W + ix];
+        }
+      du[(long)b * 3 * HW + ch * HW + p] = acc;
+      wsum[ch][9] += g * ub[ch * HW + p];
+    }
+  }
+#pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
-    // data gradient (correlation with flipped taps)
-    float acc = pwc[ch] * g;
-    float wg[9];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int t = ky * 3 + kx;
-        wg[t] = 0.f;
-        if (!valid) continue;
-        // du[p] += dwc[t] * df[p - off_t]  ;  ddwc[t] += df[p] * u[p + off_t]
-        const int qy = py - (ky - 1), qx = px - (kx - 1);
-        if (qy >= 0 && qy < H && qx >= 0 && qx < W) acc += dwc[ch * 9 + t] * gb[qy * W + qx];
-        const int iy = py + ky - 1, ix = px + kx - 1;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) wg[t] = g * ub[ch * HW + iy * W + ix];
-      }
-    if (valid) du[(long)b * 3 * HW + ch * HW + p] = acc;
-    float sp = block_sum(valid ? g * ub[ch * HW + p] : 0.f, red);
+    const float sp = block_sum(wsum[ch][9], red);
     if (threadIdx.x == 0) atomicAdd(&dpwc[ch], sp);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      float sw = block_sum(wg[t], red);
+      const float sw = block_sum(wsum[ch][t], red);
       if (threadIdx.x == 0) atomicAdd(&ddwc[ch * 9 + t], sw);
     }
   }
@@ -565,8 +575,10 @@ static int srm_stats_fwd_impl(const T* x, float* u, int* amax, int B, int C, int
   if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
   if ((HW & 3) == 0 && quad_aligned<T>(x))
     CENET_LAUNCH((srm_stats_fwd_v4_kernel<T>), dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
+  else if (sizeof(T) == 2 && (long)cdiv(HW, 64) * B < 256 && C >= 256)
+    CENET_LAUNCH((srm_stats_fwd_kernel<T, 16>), dim3(cdiv(HW, 64), B), dim3(1024), stream, x, u, amax, C, HW);
   else
-    CENET_LAUNCH((srm_stats_fwd_kernel<T>), dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
+    CENET_LAUNCH((srm_stats_fwd_kernel<T, 4>), dim3(cdiv(HW, 64), B), dim3(256), stream, x, u, amax, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -583,7 +595,7 @@ extern "C" int cenet_srm_conv_fwd_f32(const float* u, const float* pwc, const fl
 extern "C" int cenet_srm_conv_bwd_acc_f32(const float* u, const float* df, const float* pwc, const float* dwc, float* du,
                                           float* dpwc_acc, float* ddwc_acc, int B, int H, int W, hipStream_t stream) {
   if (B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(srm_conv_bwd_kernel, dim3(cdiv(H * W, 256), B), dim3(256), stream, u, df, pwc, dwc, du, dpwc_acc, ddwc_acc, H,
+  CENET_LAUNCH(srm_conv_bwd_kernel, dim3(H * W > 2048 ? 4 : (H * W > 512 ? 2 : 1), B), dim3(256), stream, u, df, pwc, dwc, du, dpwc_acc, ddwc_acc, H,
                W);
   CENET_CHECK_LAUNCH();
   return CENET_OK;

@@ -56,7 +56,7 @@ def bracket(fn, label):
 
 def _lab(name, *a):
     n = name.replace("cenet_", "").replace("_f32", "")
-    if os.environ.get("TRACE_SHAPES") and n.startswith(("dwconv3x3", "bn_", "bilinear", "copy_batched", "layernorm")):
+    if os.environ.get("TRACE_SHAPES") and n.startswith(("dwconv3x3", "bn_", "bilinear", "copy_batched", "layernorm", "srm", "diffattn", "dseb", "adaptive", "gate", "ccu", "scale", "patch", "mix", "chan")):
         n += " " + ",".join(str(v) for v in a if isinstance(v, int) and not isinstance(v, bool))
     return n
 
