@@ -505,6 +505,50 @@ __global__ __launch_bounds__(256) void srm_bwd_apply_kernel(const T* __restrict_
   }
 }
 
+// bf16 form: a thread owns V consecutive pixels and walks a slice of the channels, so the per-PIXEL terms (sigmoid of the gate,
+// mean / std gradients, arg-max channel) are loaded and evaluated once instead of once per element — the plane-per-workgroup
+// form above spends 7 scalar loads, an exponential and two divisions on every element (156 us for 154 MB at 56x56x256).
+// grid (pixel chunks, B, channel slices)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void srm_bwd_apply_pix_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               const float* __restrict__ f, const float* __restrict__ u,
+                                                               const float* __restrict__ du, const int* __restrict__ amax,
+                                                               T* __restrict__ dx, int C, int HWv) {
+  const int pv = blockIdx.x * 256 + threadIdx.x;
+  if (pv >= HWv) return;
+  const int b = blockIdx.y, HW = HWv * V;
+  const int cper = (C + gridDim.z - 1) / gridDim.z, c0 = blockIdx.z * cper, c1 = c0 + cper < C ? c0 + cper : C;
+  const float* ub = u + (long)b * 3 * HW;
+  const float* db = du + (long)b * 3 * HW;
+  float sg[V], a1[V], kk[V], mean[V], dmax[V];
+  int am[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const int p = pv * V + e;
+    sg[e] = sigmoid_f(f[(long)b * HW + p]);
+    mean[e] = ub[HW + p];
+    const float sd = ub[2 * HW + p];
+    a1[e] = db[HW + p] / C;
+    kk[e] = sd > 0.f ? db[2 * HW + p] / ((C - 1) * sd) : 0.f;
+    dmax[e] = db[p];
+    am[e] = amax[(long)b * HW + p];
+  }
+  const long base = (long)b * C * HW + (long)pv * V;
+#pragma unroll 4
+  for (int c = c0; c < c1; ++c) {
+    float xv[V], gv[V];
+    ldv<V>(xv, x + base + (long)c * HW);
+    ldv<V>(gv, dy + base + (long)c * HW);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float v = gv[e] * sg[e] + a1[e] + kk[e] * (xv[e] - mean[e]);
+      if (c == am[e]) v += dmax[e];
+      gv[e] = v;
+    }
+    stv<V>(dx + base + (long)c * HW, gv);
+  }
+}
+
 static inline int chunks_for(int n) {
   int ch = cdiv(n, 1024);
   return ch > 64 ? 64 : (ch < 1 ? 1 : ch);
@@ -644,6 +688,17 @@ template <typename T>
 static int srm_bwd_apply_impl(const T* x, const T* dy, const float* f, const float* u, const float* du, const int* amax, T* dx,
                               int B, int C, int HW, hipStream_t stream) {
   if (B <= 0 || C <= 1 || HW <= 0) return CENET_EINVAL;
+  if (sizeof(T) == 2) {  // (fp32 keeps the plane form: same expression order as the parity goldens were checked with)
+    const int V = plane_vw<T>(HW, x, dy, dx);
+    const int HWv = HW / V, px = cdiv(HWv, 256);
+    int cs = 1;
+    while (cs < 64 && (long)px * B * cs < 1024 && C / (cs * 2) >= 8) cs *= 2;
+    const dim3 grid(px, B, cs);
+    if (V == 4) CENET_LAUNCH((srm_bwd_apply_pix_kernel<T, 4>), grid, dim3(256), stream, x, dy, f, u, du, amax, dx, C, HWv);
+    else CENET_LAUNCH((srm_bwd_apply_pix_kernel<T, 1>), grid, dim3(256), stream, x, dy, f, u, du, amax, dx, C, HWv);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   if (plane_vw<T>(HW, x, dy, dx) == 4)
     CENET_LAUNCH((srm_bwd_apply_kernel<T, 4>), dim3(B * C, chunks_for(HW / 4)), dim3(256), stream, x, dy, f, u, du, amax, dx, C,
                  HW / 4);
