@@ -748,6 +748,7 @@ struct SraArgs {
   const float* lse;
   bf* dq;
   float* dkv;
+  bf* dkv_bf;  // non-null: ONE workgroup per (batch, head) stores dK/dV as bf16 directly (no zero fill, atomics or cast pass)
   int B, H, Nq, Nk, C, tiles;  // tiles: 32-query tiles per wave
   float scale;
 };
@@ -926,6 +927,16 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
     }
     __syncthreads();
   }
+  if (a.dkv_bf) {  // this workgroup saw every query of its (batch, head)
+    bf* dkvb = a.dkv_bf + (long)b * Nk * 2 * C + h * 64;
+    for (int i = tid; i < Nk * 128; i += 256) {
+      const int key = i >> 7, f = i & 127;
+      const float v = red[f * 64 + key];
+      if (f < 64) stf(dkvb + (long)key * 2 * C + f, v * a.scale);
+      else stf(dkvb + (long)key * 2 * C + C + (f - 64), v);
+    }
+    return;
+  }
   float* dkv = a.dkv + (long)b * Nk * 2 * C + h * 64;
   for (int i = tid; i < Nk * 128; i += 256) {
     const int key = i >> 7, f = i & 127;  // 128 consecutive lanes = one key's 64 + 64 features: contiguous runs of 256 B
@@ -937,22 +948,44 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
 
 extern "C" int cenet_sra_attn_bwd_supported(int hd, int Nk) { return hd == 64 && Nk >= 1 && Nk <= 64; }
 
-extern "C" int cenet_sra_attn_bwd_bf16(const bf* q, const bf* kv, const bf* o, const bf* dout, const float* lse, bf* dq, float* dkv,
-                                       int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
-  if (!q || !kv || !o || !dout || !lse || !dq || !dkv || B <= 0 || H <= 0 || Nq <= 0) return CENET_EINVAL;
-  if (!cenet_sra_attn_bwd_supported(64, Nk)) return CENET_EUNSUPPORTED;
-  if ((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq) & 15) != 0) return CENET_EINVAL;
-  SraArgs a;
-  a.q = q; a.kv = kv; a.o = o; a.dout = dout; a.lse = lse; a.dq = dq; a.dkv = dkv;
-  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.C = 64 * H; a.scale = scale;
-  // 32-query tiles per wave: the kernel runs one workgroup per CU (484 registers), so more than 256 workgroups is a second
-  // round; measured best (B = 32): 4 tiles at 3136 queries (42 us), 2 at 784 / 196 (31 us), 1 at 49 (25 us)
+// 32-query tiles per wave: the kernel runs one workgroup per CU (484 registers), so more than 256 workgroups is a second
+// round; measured best (B = 32): 4 tiles at 3136 queries (42 us), 2 at 784 / 196 (31 us), 1 at 49 (25 us)
+static int sra_tiles(int B, int H, int Nq) {
   static const char* e = getenv("CENET_SRA_TILES");
   int tiles = 1;
   while (tiles < 8 && (long)cdiv(Nq, 128 * tiles) * B * H > 256) ++tiles;
   if (e) tiles = atoi(e);
-  a.tiles = tiles;
-  CENET_LAUNCH(sra_bwd_kernel, dim3(cdiv(Nq, 128 * tiles), B * H), dim3(256), stream, a);
+  return tiles < 1 ? 1 : tiles;
+}
+// 1 when the launch for this problem puts every query of a (batch, head) in ONE workgroup: dK/dV then need no cross-workgroup
+// sum and cenet_sra_attn_bwd_direct_bf16 stores them as bf16 (the 14x14 and 7x7 stages of the ACDC preset)
+extern "C" int cenet_sra_attn_bwd_direct_supported(int B, int H, int Nq, int Nk) {
+  return cenet_sra_attn_bwd_supported(64, Nk) && B > 0 && H > 0 && Nq > 0 && cdiv(Nq, 128 * sra_tiles(B, H, Nq)) == 1;
+}
+
+static int sra_bwd_launch(const bf* q, const bf* kv, const bf* o, const bf* dout, const float* lse, bf* dq, float* dkv, bf* dkv_bf,
+                          int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
+  if (!q || !kv || !o || !dout || !lse || !dq || (!dkv && !dkv_bf) || B <= 0 || H <= 0 || Nq <= 0) return CENET_EINVAL;
+  if (!cenet_sra_attn_bwd_supported(64, Nk)) return CENET_EUNSUPPORTED;
+  if ((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq) & 15) != 0) return CENET_EINVAL;
+  SraArgs a;
+  a.q = q; a.kv = kv; a.o = o; a.dout = dout; a.lse = lse; a.dq = dq; a.dkv = dkv; a.dkv_bf = dkv_bf;
+  a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.C = 64 * H; a.scale = scale;
+  a.tiles = sra_tiles(B, H, Nq);
+  if (dkv_bf && cdiv(Nq, 128 * a.tiles) != 1) return CENET_EUNSUPPORTED;
+  CENET_LAUNCH(sra_bwd_kernel, dim3(cdiv(Nq, 128 * a.tiles), B * H), dim3(256), stream, a);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
+}
+
+extern "C" int cenet_sra_attn_bwd_bf16(const bf* q, const bf* kv, const bf* o, const bf* dout, const float* lse, bf* dq, float* dkv,
+                                       int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
+  if (!dkv) return CENET_EINVAL;
+  return sra_bwd_launch(q, kv, o, dout, lse, dq, dkv, nullptr, B, H, Nq, Nk, scale, stream);
+}
+
+extern "C" int cenet_sra_attn_bwd_direct_bf16(const bf* q, const bf* kv, const bf* o, const bf* dout, const float* lse, bf* dq,
+                                              bf* dkv, int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
+  if (!dkv) return CENET_EINVAL;
+  return sra_bwd_launch(q, kv, o, dout, lse, dq, nullptr, dkv, B, H, Nq, Nk, scale, stream);
 }

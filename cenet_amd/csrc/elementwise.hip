@@ -95,6 +95,29 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(const T* __restrict__
   }
 }
 
+// ---- channel concat / split of up to four NCHW tensors in ONE launch (torch.cat(xs, dim=1) and its backward): part j holds
+// n[j] = C_j * HW contiguous elements per image and sits at element offset off[j] inside an image of the joined tensor.
+// grid (blocks, B, parts).  One launch per part (copy_batched) cost 6-7 us each for a few MB: 57 launches per step.
+template <typename T>
+struct CatArgs {
+  T* part[4];
+  long n[4], off[4];
+  T* joined;
+  long sjb;  // elements per image of the joined tensor
+};
+template <typename T, int V, bool SPLIT>
+__global__ __launch_bounds__(256) void cat_channels_kernel(CatArgs<T> a) {
+  const int j = blockIdx.z, b = blockIdx.y;
+  const long n = a.n[j] / V;
+  T* pb = a.part[j] + (long)b * a.n[j];
+  T* jb = a.joined + (long)b * a.sjb + a.off[j];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v[V];
+    ldv<V>(v, (SPLIT ? jb : pb) + i * V);
+    stv<V>((SPLIT ? pb : jb) + i * V, v);
+  }
+}
+
 // ---- space-to-depth of a token map: the kernel == stride spatial-reduction conv of pvtv2.py:93-95 reads each input
 // pixel exactly once, so gathering the s x s patches into rows turns it into a dense GEMM with both operands k-contiguous.
 // tok [B, Ho*S, Wo*S, C] <-> patch [B*Ho*Wo, C*S*S], k = (c, ky, kx) as in the conv weight [Cout, C, S, S].
@@ -745,6 +768,57 @@ static int copy_batched_impl(const T* x, long sxb, T* y, long syb, int B, long n
 }
 CENET_TWIN(copy_batched, (const T* x, long sxb, T* y, long syb, int B, long n, int accumulate, hipStream_t stream),
            (x, sxb, y, syb, B, n, accumulate, stream))
+
+template <typename T>
+static int cat_channels_impl(T* p0, T* p1, T* p2, T* p3, int c0, int c1, int c2, int c3, T* joined, int B, long HW, int split,
+                             hipStream_t stream) {
+  T* ps[4] = {p0, p1, p2, p3};
+  const int cs[4] = {c0, c1, c2, c3};
+  if (!joined || B <= 0 || HW <= 0) return CENET_EINVAL;
+  CatArgs<T> a;
+  a.joined = joined;
+  int parts = 0;
+  long off = 0, nmax = 0;
+  uintptr_t align = (uintptr_t)joined;
+  long lens = 0;
+  for (int j = 0; j < 4; ++j) {
+    a.part[j] = nullptr;
+    a.n[j] = a.off[j] = 0;
+    if (cs[j] <= 0) continue;
+    if (!ps[j] || parts != j) return CENET_EINVAL;  // parts are given front to back without holes
+    a.part[j] = ps[j];
+    a.n[j] = (long)cs[j] * HW;
+    a.off[j] = off;
+    off += a.n[j];
+    align |= (uintptr_t)ps[j];
+    lens |= a.n[j];
+    if (a.n[j] > nmax) nmax = a.n[j];
+    ++parts;
+  }
+  if (parts == 0) return CENET_EINVAL;
+  a.sjb = off;
+  const int vmax = 16 / (int)sizeof(T);  // 16-byte moves when every part length and pointer allows
+  int vw = 1;
+  if ((lens % vmax) == 0 && (align % 16) == 0) vw = vmax;
+  else if ((lens % 4) == 0 && (align % (4 * sizeof(T))) == 0) vw = 4;
+  long blocks = (nmax / vw + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const dim3 grid((unsigned)blocks, B, parts);
+#define CAT_GO(V_)                                                                                         \
+  do {                                                                                                     \
+    if (split) CENET_LAUNCH((cat_channels_kernel<T, V_, true>), grid, dim3(256), stream, a);               \
+    else CENET_LAUNCH((cat_channels_kernel<T, V_, false>), grid, dim3(256), stream, a);                    \
+  } while (0)
+  if (vw == 8) CAT_GO(8);
+  else if (vw == 4) CAT_GO(4);
+  else CAT_GO(1);
+#undef CAT_GO
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+CENET_TWIN(cat_channels, (T* p0, T* p1, T* p2, T* p3, int c0, int c1, int c2, int c3, T* joined, int B, long HW, int split,
+                          hipStream_t stream),
+           (p0, p1, p2, p3, c0, c1, c2, c3, joined, B, HW, split, stream))
 
 template <typename T>
 static int patch_tok_impl(const T* src, T* dst, int B, int Ho, int Wo, int C, int S, int inverse, hipStream_t stream) {

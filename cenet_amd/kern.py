@@ -259,6 +259,19 @@ def sra_attn_bwd(q, kv, o, dout, lse, dq, dkv, B, H, Nq, Nk, scale):
     _lib.check(rc, "cenet_sra_attn_bwd_bf16")
 
 
+def sra_attn_bwd_direct_supported(B, H, Nq, Nk) -> bool:
+    return bool(_lib.lib().cenet_sra_attn_bwd_direct_supported(int(B), int(H), int(Nq), int(Nk)))
+
+
+def sra_attn_bwd_direct(q, kv, o, dout, lse, dq, dkv, B, H, Nq, Nk, scale):
+    """as sra_attn_bwd where one workgroup owns a (batch, head): dkv bf16, written (not accumulated)"""
+    _chk(q, kv, o, dout, lse, dq, dkv)
+    assert q.dtype == BF16 and kv.dtype == BF16 and dq.dtype == BF16 and dkv.dtype == BF16
+    rc = _lib.lib().cenet_sra_attn_bwd_direct_bf16(P(q), P(kv), P(o), P(dout), P(lse), P(dq), P(dkv), B, H, Nq, Nk,
+                                                   C.c_float(scale), stream())
+    _lib.check(rc, "cenet_sra_attn_bwd_direct_bf16")
+
+
 def softmax_rows_fwd(x, y, rows, n):
     _chk(x, y)
     _call("cenet_softmax_rows_fwd_f32", x, y, L(rows), n)
@@ -439,6 +452,15 @@ def transpose(x, sxb, y, syb, B, R, Cc, x_off=0, y_off=0):
 def copy_batched(x, sxb, y, syb, B, n, accumulate=False, x_off=0, y_off=0):
     _chk(x, y)
     _call("cenet_copy_batched_f32", Ptr(x, x_off), L(sxb), Ptr(y, y_off), L(syb), B, L(n), int(accumulate))
+
+
+def cat_channels(parts, joined, B, HW, split=False):
+    """joined [B, sum c, HW] <- parts [B, c_j, HW] (or the reverse with split=True); at most four parts, one launch"""
+    assert 1 <= len(parts) <= 4
+    _chk(joined, *parts)
+    ps = list(parts) + [None] * (4 - len(parts))
+    cs = [int(t.shape[1]) for t in parts] + [0] * (4 - len(parts))
+    _call("cenet_cat_channels_f32", *ps, *cs, joined, B, L(HW), int(split))
 
 
 def im2col_tok(src, dst, B, H, W, C, K, stride, pad, inverse=False):

@@ -118,7 +118,7 @@ class MCA(nn.Module):
     def forward(self, x):
         shortcut = x
         x = self.ccu(x)
-        g = ops.conv1x1(x, self.gate.weight, self.gate.bias)
+        g, x = ops.conv1x1(x, self.gate.weight, self.gate.bias, tap=True)  # value's gradient joins inside gate's dgrad GEMM
         v = self.value(x)
         x = ops.conv1x1(ops.silu_mul(g, v), self.proj_2.weight, self.proj_2.bias, resid=shortcut)
         return self.denoising_module(x)

@@ -32,8 +32,8 @@ class MultiheadDiffAttn(nn.Module):
     def forward(self, x, rel_pos=None, attn_mask=None):
         if rel_pos is not None or attn_mask is not None:
             raise NotImplementedError
-        q = ops.linear(x, self.q_proj.weight)
-        k = ops.linear(x, self.k_proj.weight)
+        q, x = ops.linear(x, self.q_proj.weight, tap=True)  # (taps: the three data gradients add up inside the GEMMs)
+        k, x = ops.linear(x, self.k_proj.weight, tap=True)
         v = ops.linear(x, self.v_proj.weight)
         U = ops.diff_attention_heads(q, k, v, self.num_heads)  # [B, 2H, N, 2hd], two softmaxes per head, tiled
         a = ops.diff_attention_combine(U, self.lambda_q1, self.lambda_k1, self.lambda_q2, self.lambda_k2, self.lambda_init)

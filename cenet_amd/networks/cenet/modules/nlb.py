@@ -23,9 +23,11 @@ class Nonlocal(nn.Module):
         self.w = nn.Parameter(torch.tensor(0.5))
 
     def forward(self, x):
-        theta = ops.conv1x1(x, self.conv_theta.weight, self.conv_theta.bias)
-        phi = ops.conv1x1(x, self.conv_phi.weight, self.conv_phi.bias)
-        g = ops.conv1x1(x, self.conv_g.weight, self.conv_g.bias)
+        # x has four consumers (theta, phi, g, the residual mix): each 1x1 conv hands x on as a tap, so the four gradients meet
+        # inside the data-gradient GEMMs instead of three aten::add launches
+        theta, x = ops.conv1x1(x, self.conv_theta.weight, self.conv_theta.bias, tap=True)
+        phi, x = ops.conv1x1(x, self.conv_phi.weight, self.conv_phi.bias, tap=True)
+        g, x = ops.conv1x1(x, self.conv_g.weight, self.conv_g.bias, tap=True)
         y = ops.nonlocal_attention(theta, phi, g)  # flash-style: the N x N map is never materialised
         p = ops.conv1x1(y, self.conv_out.weight, self.conv_out.bias)
         p = bn_call(self.bn, p)

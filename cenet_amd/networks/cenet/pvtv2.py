@@ -87,7 +87,7 @@ class Attention(nn.Module):
         self.apply(_init_weights)
 
     def forward(self, x, H, W, resid=None, bscale=None):
-        q = ops.linear(x, self.q.weight, self.q.bias)
+        q, x = ops.linear(x, self.q.weight, self.q.bias, tap=True)  # the kv branch's gradient joins q's inside the dgrad GEMM
         if self.sr_ratio > 1:
             x_ = ops.conv2d_tok(x, H, W, self.sr.weight, self.sr.bias, stride=self.sr_ratio, pad=0, out_layout="tok")
             x_ = ops.layernorm(x_, self.norm.weight, self.norm.bias, self.norm.eps)

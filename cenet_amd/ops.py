@@ -128,10 +128,13 @@ def _c(t: Optional[Tensor]) -> Optional[Tensor]:
 # Linear in token layout (pvtv2.py:41,45,90,98,106; multihead_diffattn.py:79-81,126)
 # =====================================================================================================
 class LinearFn(Function):
-    """y = bscale[b] * (x W^T + b) + resid.  x [..., K] contiguous; bscale [B] needs x [B, n, K]."""
+    """y = bscale[b] * (x W^T + b) + resid.  x [..., K] contiguous; bscale [B] needs x [B, n, K].
+    tap: also return x itself as a second output; a further consumer of x that reads the TAP instead of x sends its gradient
+    through this node, where it rides in the data-gradient GEMM's epilogue (R) instead of an aten::add launched by autograd
+    (q beside the spatial-reduction / kv branch of pvtv2.py:97-107, the q/k/v projections of multihead_diffattn.py:79-81)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, resid, bscale, split_k=False):
+    def forward(ctx, x, W, b, resid, bscale, split_k=False, tap=False):
         x = _c(x)
         K = x.shape[-1]
         N = W.shape[0]
@@ -165,12 +168,14 @@ class LinearFn(Function):
         ctx.save_for_backward(x, W, bscale)
         ctx.refs = (W, b)
         ctx.has_resid = resid is not None
-        return y
+        return (y, x.view_as(x)) if tap else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_tap=None):
         x, W, bscale = ctx.saved_tensors
         Wp, bp = ctx.refs
+        if g is None:  # only the tap carried a gradient
+            return g_tap, None, None, None, None, None, None
         g = _c(g)
         K, N = x.shape[-1], W.shape[0]
         R = x.numel() // K
@@ -191,23 +196,27 @@ class LinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            if g_tap is not None:
+                g_tap = _c(g_tap)
             kern.gemm(kern.mat_plain(gs, N, 1, kfast=1), kern.mat_plain(kern.wq(Wp, x), K, 1, kfast=0), dx, R, K, N, scr=K,
-                      scc=1)
-        return dx, None, None, (g if ctx.has_resid else None), None, None
+                      scc=1, R=g_tap, srr=K, src=1)
+        return dx, None, None, (g if ctx.has_resid else None), None, None, None
 
 
-def linear(x, W, b=None, resid=None, bscale=None, split_k=False):
-    return LinearFn.apply(x, W, b, resid, bscale, split_k)
+def linear(x, W, b=None, resid=None, bscale=None, split_k=False, tap=False):
+    """tap=True returns (y, x_tap): hand x_tap (not x) to the other consumers of x"""
+    return LinearFn.apply(x, W, b, resid, bscale, split_k, tap)
 
 
 # =====================================================================================================
 # 1x1 convolution on NCHW (cfam.py:149,158,299,302; nlb.py:106-115,142; blocks.py:178,320; dseb.py:164)
 # =====================================================================================================
 class Conv1x1Fn(Function):
-    """y[b] = W x[b] + bias + resid ; x [B, Cin, *spatial] contiguous."""
+    """y[b] = W x[b] + bias + resid ; x [B, Cin, *spatial] contiguous.  tap: as in LinearFn (theta / phi / g of nlb.py:117-119
+    and the gate / value / shortcut consumers in cfam.py read one tensor)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, resid):
+    def forward(ctx, x, W, b, resid, tap=False):
         x = _c(x)
         B, Cin = x.shape[:2]
         HW = x.numel() // (B * Cin)
@@ -225,12 +234,14 @@ class Conv1x1Fn(Function):
         ctx.save_for_backward(x, W)
         ctx.refs = (W, b)
         ctx.has_resid = resid is not None
-        return y
+        return (y, x.view_as(x)) if tap else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_tap=None):
         x, W = ctx.saved_tensors
         Wp, bp = ctx.refs
+        if g is None:
+            return g_tap, None, None, None, None
         g = _c(g)
         B, Cin = x.shape[:2]
         HW = x.numel() // (B * Cin)
@@ -250,13 +261,18 @@ class Conv1x1Fn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            if g_tap is not None:
+                g_tap = _c(g_tap)
             kern.gemm(kern.mat_plain(kern.wq(Wp, x), 1, Cin, kfast=0), kern.mat_plain(g, HW, 1, sb=Cout * HW), dx, Cin, HW, Cout,
-                      scr=HW, scc=1, scb=Cin * HW, nbatch=B)
-        return dx, None, None, (g if ctx.has_resid else None)
+                      scr=HW, scc=1, scb=Cin * HW, nbatch=B, R=g_tap, srb=Cin * HW, srr=HW, src=1)
+        elif g_tap is not None:
+            dx = g_tap
+        return dx, None, None, (g if ctx.has_resid else None), None
 
 
-def conv1x1(x, W, b=None, resid=None):
-    return Conv1x1Fn.apply(x, W, b, resid)
+def conv1x1(x, W, b=None, resid=None, tap=False):
+    """tap=True returns (y, x_tap): hand x_tap (not x) to the other consumers of x"""
+    return Conv1x1Fn.apply(x, W, b, resid, tap)
 
 
 # =====================================================================================================
@@ -801,7 +817,12 @@ class SRAttentionFn(Function):
         d = ctx.d
         if ctx.kind == "flash" and _bf(q) and kern.sra_attn_bwd_supported(d.D, d.Nk) and d.D == d.Dv:
             # bf16, 64-dim heads, <= 64 keys: one kernel with the key / value set resident (attn_diff.hip, sra_bwd_kernel)
-            dq, dkv = torch.empty_like(q), _zeros(kv.shape, kv)
+            dq = torch.empty_like(q)
+            if kern.sra_attn_bwd_direct_supported(d.B, d.H, d.Nq, d.Nk):  # one workgroup per (batch, head): bf16 dK/dV directly
+                dkv = torch.empty_like(kv)
+                kern.sra_attn_bwd_direct(q, kv, o, g, saved, dq, dkv, d.B, d.H, d.Nq, d.Nk, d.scale)
+                return dq, dkv, None
+            dkv = _zeros(kv.shape, kv)
             kern.sra_attn_bwd(q, kv, o, g, saved, dq, dkv, d.B, d.H, d.Nq, d.Nk, d.scale)
             return dq, kern.cast(dkv, kv.dtype), None
         few_keys = ctx.d.Nk <= 128 and ctx.d.Nq >= 1024  # spatial-reduction attention: 49 keys under 784..3136 queries
@@ -1050,8 +1071,7 @@ class Concat2Fn(Function):
         Cb = b.shape[1]
         HW = a.numel() // (B * Ca)
         y = _act((B, Ca + Cb) + tuple(a.shape[2:]), a)
-        kern.copy_batched(a, Ca * HW, y, (Ca + Cb) * HW, B, Ca * HW)
-        kern.copy_batched(b, Cb * HW, y, (Ca + Cb) * HW, B, Cb * HW, y_off=Ca * HW)
+        kern.cat_channels([a, b], y, B, HW)
         ctx.dims = (Ca, Cb, HW)
         return y
 
@@ -1062,8 +1082,7 @@ class Concat2Fn(Function):
         B = g.shape[0]
         da = _act((B, Ca) + tuple(g.shape[2:]), g)
         db = _act((B, Cb) + tuple(g.shape[2:]), g)
-        kern.copy_batched(g, (Ca + Cb) * HW, da, Ca * HW, B, Ca * HW)
-        kern.copy_batched(g, (Ca + Cb) * HW, db, Cb * HW, B, Cb * HW, x_off=Ca * HW)
+        kern.cat_channels([da, db], g, B, HW, split=True)
         return da, db
 
 
@@ -1173,10 +1192,13 @@ class ConcatFn(Function):
         HW = xs[0].numel() // (B * cs[0])
         Ct = sum(cs)
         y = _act((B, Ct) + tuple(xs[0].shape[2:]), xs[0])
-        lo = 0
-        for t, c in zip(xs, cs):
-            kern.copy_batched(t, c * HW, y, Ct * HW, B, c * HW, y_off=lo * HW)
-            lo += c
+        if len(xs) <= 4:
+            kern.cat_channels(xs, y, B, HW)  # one launch
+        else:
+            lo = 0
+            for t, c in zip(xs, cs):
+                kern.copy_batched(t, c * HW, y, Ct * HW, B, c * HW, y_off=lo * HW)
+                lo += c
         ctx.dims = (cs, HW)
         return y
 
@@ -1185,12 +1207,14 @@ class ConcatFn(Function):
         g = _c(g)
         cs, HW = ctx.dims
         B, Ct = g.shape[0], sum(cs)
-        outs, lo = [], 0
-        for c in cs:
-            d = _act((B, c) + tuple(g.shape[2:]), g)
-            kern.copy_batched(g, Ct * HW, d, c * HW, B, c * HW, x_off=lo * HW)
-            outs.append(d)
-            lo += c
+        outs = [_act((B, c) + tuple(g.shape[2:]), g) for c in cs]
+        if len(cs) <= 4:
+            kern.cat_channels(outs, g, B, HW, split=True)
+        else:
+            lo = 0
+            for d, c in zip(outs, cs):
+                kern.copy_batched(g, Ct * HW, d, c * HW, B, c * HW, x_off=lo * HW)
+                lo += c
         return tuple(outs)
 
 

@@ -168,6 +168,12 @@ int cenet_sra_attn_bwd_supported(int hd, int Nk);
 int cenet_sra_attn_bwd_bf16(const unsigned short* q, const unsigned short* kv, const unsigned short* o,
     const unsigned short* dout, const float* lse, unsigned short* dq, float* dkv, int B, int H, int Nq, int Nk, float scale,
     cenet_stream_t stream);
+/* The same kernel where its launch puts all queries of a (batch, head) in ONE workgroup (cenet_sra_attn_bwd_direct_supported:
+ * the 14x14 and 7x7 stages at B = 32): dkv [B, Nk, 128 H] is written as bf16 directly — no zero fill, no atomics, no cast. */
+int cenet_sra_attn_bwd_direct_supported(int B, int H, int Nq, int Nk);
+int cenet_sra_attn_bwd_direct_bf16(const unsigned short* q, const unsigned short* kv, const unsigned short* o,
+    const unsigned short* dout, const float* lse, unsigned short* dq, unsigned short* dkv, int B, int H, int Nq, int Nk,
+    float scale, cenet_stream_t stream);
 /* Row softmax for the materialised path (head dims > 128): aten::_softmax(+_backward_data).  Scores x and score gradients
  * dy are fp32 in both forms; the probabilities y and dx have the storage type of the entry point. */
 int cenet_softmax_rows_fwd_f32(const float* x, float* y, long rows, int n, cenet_stream_t stream);
@@ -262,6 +268,12 @@ int cenet_srm_bwd_apply_f32(const float* x, const float* dy, const float* f, con
 /* ---- glue (elementwise.hip) --------------------------------------------------------------------------------- */
 int cenet_transpose_f32(const float* x, long sxb, float* y, long syb, int B, int R, int Cc, cenet_stream_t stream);
 int cenet_copy_batched_f32(const float* x, long sxb, float* y, long syb, int B, long n, int accumulate, cenet_stream_t stream);
+/* torch.cat(parts, dim=1) of up to four contiguous NCHW tensors [B, c_j, HW] into joined [B, sum c_j, HW] (split == 0), or
+ * its backward: the channel slices of joined copied out into the parts (split == 1) — one launch either way.  Unused
+ * trailing parts: pointer NULL, c_j = 0.  Reference call sites: networks/cenet/modules/cfam.py:238 (torch.cat of the four
+ * MultiOrderDWConv branches), modules/dseb.py:156, out.py:63. */
+int cenet_cat_channels_f32(float* p0, float* p1, float* p2, float* p3, int c0, int c1, int c2, int c3, float* joined, int B,
+                           long HW, int split, cenet_stream_t stream);
 /* Space-to-depth of a token map for the kernel == stride spatial-reduction conv (reference networks/cenet/pvtv2.py:93-95,
  * `self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)` applied to x.permute(0,2,1).reshape(B,C,H,W)):
  * inverse == 0 gathers tok [B, Ho*S, Wo*S, C] into patch rows [B*Ho*Wo, C*S*S] (k = (c, ky, kx), the weight's own order);
@@ -366,6 +378,8 @@ int cenet_transpose_bf16(const unsigned short* x, long sxb, unsigned short* y, l
     cenet_stream_t stream);
 int cenet_copy_batched_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, long n, int accumulate,
     cenet_stream_t stream);
+int cenet_cat_channels_bf16(unsigned short* p0, unsigned short* p1, unsigned short* p2, unsigned short* p3, int c0, int c1,
+    int c2, int c3, unsigned short* joined, int B, long HW, int split, cenet_stream_t stream);
 int cenet_patch_tok_bf16(const unsigned short* src, unsigned short* dst, int B, int Ho, int Wo, int C, int S, int inverse,
     cenet_stream_t stream);
 int cenet_im2col_tok_bf16(const unsigned short* src, unsigned short* dst, int B, int H, int W, int C, int K, int stride,

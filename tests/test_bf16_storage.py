@@ -218,6 +218,10 @@ def test_layout_and_glue(dev):
     compare(lambda x: ops.tok_to_nchw(x, 7, 7), [x7], dev=dev, tol=1e-6)
     a, b = torch.randn(2, 3, 4, 4, generator=g), torch.randn(2, 5, 4, 4, generator=g)
     compare(ops.concat2, [a, b], dev=dev, tol=1e-6)
+    # n-way concat in one launch (cenet_cat_channels): 16-byte, 8-byte and scalar part lengths, 2..4 parts, unequal channels
+    for hw, cs in ((8, (8, 8, 8, 4)), (4, (5, 5, 5, 1)), (7, (3, 2)), (3, (1, 2, 3))):
+        parts = [torch.randn(2, c, hw, hw, generator=g) for c in cs]
+        compare(lambda *xs: ops.concat(list(xs)), parts, dev=dev, tol=1e-6)
     compare(lambda x: ops.split_channels(x, [2, 3])[1], [b], dev=dev, tol=1e-6)
     c = torch.randn(2, 3, 4, 4, generator=g)
     compare(lambda a, c: ops.add_act(a, c, "lrelu", 0.01), [a, c], dev=dev)

@@ -23,3 +23,18 @@ print({k: round(v, 2) for k, v in fam.items()})
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 for k, t in sorted(grp.items(), key=lambda kv: -kv[1])[:top]:
     print(f"{t:7.2f}  {k[:100]}")
+
+# gaps between consecutive kernels of the same hardware queue inside the two steps (hipGraph replay: dependency edges
+# between nodes; eager: launch gaps)
+byq = collections.defaultdict(list)
+for r in seg:
+    byq[r.get("Queue_Id", "0")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+for q, iv in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+    iv.sort()
+    gaps = [max(0, iv[i + 1][0] - iv[i][1]) for i in range(len(iv) - 1)]
+    qb = sum(e - s for s, e in iv)
+    gs = sorted(gaps)
+    if not gs:
+        continue
+    print(f"queue {q}: {len(iv) / 2:.0f} kernels/step, busy {qb / 2e6:.2f} ms/step, gaps {sum(gaps) / 2e6:.2f} ms/step "
+          f"(median {gs[len(gs) // 2] / 1e3:.1f} us, p90 {gs[int(len(gs) * .9)] / 1e3:.1f} us, max {gs[-1] / 1e3:.0f} us)")

@@ -56,7 +56,7 @@ def bracket(fn, label):
 
 def _lab(name, *a):
     n = name.replace("cenet_", "").replace("_f32", "")
-    if os.environ.get("TRACE_SHAPES") and n.startswith(("dwconv3x3", "bn_", "bilinear", "copy_batched", "layernorm", "srm", "diffattn", "dseb", "adaptive", "gate", "ccu", "scale", "patch", "mix", "chan")):
+    if os.environ.get("TRACE_SHAPES") and (os.environ.get("TRACE_ALL") or n.startswith(("dwconv3x3", "bn_", "bilinear", "copy_batched", "layernorm", "srm", "diffattn", "dseb", "adaptive", "gate", "ccu", "scale", "patch", "mix", "chan"))):
         n += " " + ",".join(str(v) for v in a if isinstance(v, int) and not isinstance(v, bool))
     return n
 
@@ -88,6 +88,14 @@ for stage, label, e0, e1 in log:
     fam[k][1] += e0.elapsed_time(e1)
 for k, (n, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"   {ms:7.3f} ms {n:4d}x {ms / n * 1e3:7.1f} us  {k}")
+if os.environ.get("TRACE_ALL"):  # every distinct call (with shapes) over the whole step, largest first
+    lab = collections.defaultdict(lambda: [0, 0.0])
+    for stage, label, e0, e1 in log:
+        lab[label][0] += 1
+        lab[label][1] += e0.elapsed_time(e1)
+    print("-- by call and shape")
+    for k, (n, ms) in sorted(lab.items(), key=lambda kv: -kv[1][1])[:int(os.environ["TRACE_ALL"])]:
+        print(f"   {ms:7.3f} ms {n:4d}x {ms / n * 1e3:7.1f} us  {k}")
 print(f"{'stage':36s} {'calls':>6s} {'ms':>8s}")
 for stage, (n, ms) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print(f"{stage:36s} {n:6d} {ms:8.3f}")
