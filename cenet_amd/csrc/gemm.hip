@@ -131,6 +131,11 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   else
     g.cvec = E->scr == 1 && m4(E->scc) && m4(E->scb) && m4(E->scb2) && alq(E->C) &&
              (!E->R || (E->srr == 1 && m4(E->src) && m4(E->srb) && m4(E->srb2) && alq(E->R)));
+  {
+    static const bool no_stage = getenv("CENET_GEMM_NO_STAGE") != nullptr;  // measurement aid
+    const long so = swap ? E->scr : E->scc;
+    g.cvec8 = !no_stage && bf && g.cvec && (so % 8) == 0 && (E->scb % 8) == 0 && (E->scb2 % 8) == 0 && (((uintptr_t)E->C & 15) == 0);
+  }
   int bm, bn;
   pick_tile(M, N, nbatch, splits, &bm, &bn);
   if (B->mode == 1 && B->kfast && bm == 32) bn = 64;  // weight-gradient view: keep the per-thread gather list short
@@ -176,6 +181,8 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
         else bm = 128;
       }
     } else {
+      // (tried: a 2-stage 64x64 instance with 32 KB of LDS — five workgroups per CU — for the reductions of one or two
+      // K-steps, K <= 128: the step got 1 % slower, K <= 64 and K <= 256 likewise)
       bm = M >= 96 ? 128 : 64;
       bn = N >= 96 ? 128 : 64;
       const long want = K >= 320 ? 400 : 256;

@@ -34,6 +34,7 @@ struct GemmArgs {
   cenet_epi_t E;
   int M, N, K, nkb, splits, nb_inner;
   int avec, bvec, cvec;  // quad (16-byte fp32 / 8-byte bf16) global access is legal for A / B staging / the epilogue
+  int cvec8;             // bf16 C: 16-byte stores along its contiguous axis are legal (the staged epilogue of the ring kernel)
   int apair, bpair;      // bf16, row-contiguous operand: adjacent rows may be fetched as 4-byte pairs
   // LDS-DMA ring kernel (gemm_ring.h) on operands whose pitch / extent / base is not a multiple of 8 elements: 16-byte
   // chunks then start at 2-byte aligned addresses (the hardware takes them) and the last chunk of a row runs into the
@@ -309,7 +310,10 @@ __device__ __forceinline__ void plain_fetch(const PlainStage& s, const float* ti
 
 // Epilogue shared by the GEMM kernels: acc[i][j] is the 16x16 fragment (i, j) of this wave's (BM/2)x(BN/2) quadrant
 // (waves 2x2 over the tile).  cstrip: LDS scratch of 4*16*(BN/2+1) floats, used by the atomic split-K path (!SWAP).
-template <typename GT, int BM, int BN, bool SWAP>
+// STAGED (ring kernel, bf16 C): interior tiles go through an LDS image of the whole tile, so that a wave's store instruction
+// writes whole rows (16 bytes per lane, 128 / 256 contiguous bytes per row) instead of 16 rows x 32 bytes; cstrip then holds
+// at least BO * (BI + 8) * 2 bytes.  Same values, same single rounding as the direct path.
+template <typename GT, int BM, int BN, bool SWAP, bool STAGED = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM / 32][BN / 32], float* cstrip, int m0, int n0,
                                               int bo, int bi, int batch, int wave, int lane) {
   constexpr int MI = BM / 32, NJ = BN / 32;
@@ -358,6 +362,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
     const GT* rrow = Rb ? Rb + (long)rwave * E.srr + (long)cwave * E.src : nullptr;
     const long ci = 16 * E.scr, cj = 16 * E.scc, ri = 16 * E.srr, rj = 16 * E.src;
     const bool bias_vec = E.bias && (SWAP != (bool)E.bias_on_row) && (((uintptr_t)E.bias & 15) == 0);
+    constexpr int BI = SWAP ? BN : BM, BO = SWAP ? BM : BN, TP = BI + 8;  // staged image: [BO][BI] + 16-byte row padding
+    const bool staged = STAGED && sizeof(GT) == 2 && g.cvec8;
+    bf16_t* const tile = (bf16_t*)cstrip;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -393,8 +400,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += rr[r];
         }
-        st4v(crow + i * ci + j * cj, v);
+        if (staged) {
+          const int in0 = (SWAP ? wn * (BN / 2) + j * 16 : wm * (BM / 2) + i * 16) + fq * 4;
+          const int out0 = (SWAP ? wm * (BM / 2) + i * 16 : wn * (BN / 2) + j * 16) + fr;
+          st4v(tile + out0 * TP + in0, v);
+        } else {
+          st4v(crow + i * ci + j * cj, v);
+        }
       }
+    if (staged) {
+      __syncthreads();
+      const long so = SWAP ? E.scr : E.scc;
+      bf16_t* cb = (bf16_t*)Cb + (long)(SWAP ? m0 : n0) * so + (SWAP ? n0 : m0);
+      constexpr int CPR = BI / 8;
+      for (int c = wave * 64 + lane; c < BO * CPR; c += 256) {
+        const int out = c / CPR, ch = c - out * CPR;
+        unsigned q[4];
+        memcpy(q, tile + out * TP + 8 * ch, 16);
+        memcpy(cb + (long)out * so + 8 * ch, q, 16);
+      }
+    }
     return;
   }
   if (g.cvec && !E.atomic && !E.cmode && E.act == ACT_NONE) {

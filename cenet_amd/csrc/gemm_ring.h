@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
     }
   }
   __syncthreads();  // the ring is free: the atomic epilogue uses it as its transpose strip
-  gemm_epilogue<bf16_t, BM, BN, SWAP>(g, acc, (float*)lds, m0, n0, bo, bi, batch, wave, lane);
+  static_assert(NS * STAGE >= (BM > BN ? BM : BN) * ((BM > BN ? BN : BM) + 8) * 2 && NS * STAGE >= BM * (BN + 8) * 2,
+                "the staged epilogue image reuses the ring");
+  gemm_epilogue<bf16_t, BM, BN, SWAP, true>(g, acc, (float*)lds, m0, n0, bo, bi, batch, wave, lane);
 }
 
 template <bool AKF, bool BKF, bool SWAP>
