@@ -1,0 +1,36 @@
+#!/bin/bash
+# Regenerates, on the MI355X box, every measured artefact that profiles/README.md cites for the current round:
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'
+# Outputs land in gpurun_out/refresh_<tag>/ (copy the ones to be judged into profiles/).  Order matters: the PMC passes come
+# first, because bench.py reads roofline.traffic from profiles/<tag>_traffic.json by kernel name.
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/refresh_$TAG
+mkdir -p $O
+export PYTHONPATH=$R
+cd /tmp && export TMPDIR=/tmp
+PMC="--steps 2 --warmup 1 --no-cpu-baseline --no-f32 --no-roofline --graph off"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $PMC > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py $PMC > $O/pmc_write.log 2>&1
+F=$(ls $O/pmc_fetch/*/*counter_collection.csv | head -1); W=$(ls $O/pmc_write/*/*counter_collection.csv | head -1)
+python3 $R/tools/pmc_traffic.py $F $W $R/profiles/${TAG}_traffic.json "bench.py $PMC" > $O/pmc_top.txt 2>&1
+cp $R/profiles/${TAG}_traffic.json $O/
+# kernel statistics of the default bench command (instrumented passes included) and of the step alone
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b -- python3 $R/bench.py --no-cpu-baseline --no-f32 > $O/stats_b.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c -- python3 $R/bench.py --no-cpu-baseline --no-f32 --no-roofline > $O/stats_c.log 2>&1
+cp $(ls $O/stats_b/*/*kernel_stats.csv | head -1) $O/${TAG}_b_kernel_stats.csv
+cp $(ls $O/stats_c/*/*kernel_stats.csv | head -1) $O/${TAG}_c_kernel_stats_noroofline.csv
+cd $R
+python3 tools/prof_summary.py $O/stats_c 25 > $O/prof_summary_c.txt 2>&1
+rm -rf $O/stats_b $O/stats_c $O/pmc_fetch/*/*kernel_trace.csv $O/pmc_write/*/*kernel_trace.csv   # (traces: tens of MB)
+# the bench lines
+python3 bench.py > $O/${TAG}_bench_50steps.json 2> $O/bench.err
+python3 bench.py --config synapse --no-f32 --no-cpu-baseline > $O/${TAG}_bench_synapse.json 2>> $O/bench.err
+python3 bench.py --config ham512 --no-f32 --no-cpu-baseline --steps 20 --warmup 5 > $O/${TAG}_bench_ham512.json 2>> $O/bench.err
+# attention kernels: SQ issue / wait counters (one pass of 8 SQ counters)
+cd /tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU \
+  --kernel-trace --output-format csv -d $O/pmc_attn -- python3 $R/tools/dattn_bench.py > $O/pmc_attn.log 2>&1
+rm -f $O/pmc_attn/*/*kernel_trace.csv
+ls -la $O
