@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
 template <typename T>
 __global__ void bn_finalize_kernel(const T* __restrict__ x, int HW, const float* __restrict__ ws, int C, int S, float n,
                                    float* __restrict__ mean, float* __restrict__ var, float* running_mean,
-                                   float* running_var, float momentum, long* nbt) {
+                                   float* running_var, float momentum, long* nbt, int nbt_n) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
     float shift = ldf(x + (long)c * HW);
@@ -528,7 +528,7 @@ __global__ void bn_finalize_kernel(const T* __restrict__ x, int HW, const float*
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * v * (n / (n - 1.f));
     }
   }
-  if (c == 0 && nbt) nbt[0] += 1;
+  if (nbt && c < nbt_n) nbt[c] += 1;
 }
 
 // Train-mode forward in two launches instead of three: when `fin.ws` is set, the normalisation pass derives the batch mean /
@@ -541,6 +541,7 @@ struct BnFin {
   float *mean, *var, *rmean, *rvar;
   float momentum;
   long* nbt;
+  int nbt_n;        // counters at nbt[0 .. nbt_n): one per nn.BatchNorm2d whose channels this launch covers (merged launches)
 };
 __device__ __forceinline__ void bn_fin_publish(const BnFin& f, int c, float mu, float v) {
   f.mean[c] = mu;
@@ -549,7 +550,7 @@ __device__ __forceinline__ void bn_fin_publish(const BnFin& f, int c, float mu, 
     f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * mu;
     f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * v * (f.n / (f.n - 1.f));
   }
-  if (c == 0 && f.nbt) f.nbt[0] += 1;
+  if (f.nbt && c < (f.nbt_n > 1 ? f.nbt_n : 1)) f.nbt[c] += 1;
 }
 // plane-per-workgroup kernels: every thread of the workgroup calls (block_sum inside)
 template <typename T>
@@ -1073,7 +1074,7 @@ static int bn_partial_launch(const T* x, long sb, int B, int C, int HW, float* w
 
 template <typename T>
 static int bn_stats_impl(const T* x, long sb, int B, int C, int HW, float* ws, float* mean, float* var, float* running_mean,
-                         float* running_var, float momentum, long* num_batches_tracked, hipStream_t stream) {
+                         float* running_var, float momentum, long* num_batches_tracked, hipStream_t stream, int nbt_count = 1) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   const long total = (long)B * HW;
   int S;
@@ -1088,7 +1089,7 @@ static int bn_stats_impl(const T* x, long sb, int B, int C, int HW, float* ws, f
     CENET_LAUNCH((bn_partial_kernel<T>), dim3(C, S), dim3(256), stream, x, sb, B, HW, ws);
   }
   CENET_LAUNCH((bn_finalize_kernel<T>), dim3(cdiv(C, 64)), dim3(64), stream, x, HW, (const float*)ws, C, S, (float)total, mean,
-               var, running_mean, running_var, momentum, num_batches_tracked);
+               var, running_mean, running_var, momentum, num_batches_tracked, nbt_count);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -1134,7 +1135,7 @@ static int bn_apply_impl(const T* x, long sxb, T* y, long syb, const float* mean
                          hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   BnFin fin;
-  fin.ws = nullptr; fin.S = 0; fin.n = 0.f; fin.mean = fin.var = fin.rmean = fin.rvar = nullptr; fin.momentum = 0.f; fin.nbt = nullptr;
+  fin.ws = nullptr; fin.S = 0; fin.n = 0.f; fin.mean = fin.var = fin.rmean = fin.rvar = nullptr; fin.momentum = 0.f; fin.nbt = nullptr; fin.nbt_n = 1;
   return bn_apply_launch<T>(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, fin, stream);
 }
 
@@ -1143,17 +1144,18 @@ static int bn_apply_impl(const T* x, long sxb, T* y, long syb, const float* mean
 template <typename T>
 static int bn_train_fwd_impl(const T* x, long sxb, T* y, long syb, float* ws, float* mean, float* var, float* running_mean,
                              float* running_var, float momentum, long* num_batches_tracked, float eps, const float* gamma,
-                             const float* beta, int act, float slope, int B, int C, int HW, hipStream_t stream) {
-  if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+                             const float* beta, int act, float slope, int B, int C, int HW, int nbt_count, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || HW <= 0 || nbt_count < 1 || nbt_count > C) return CENET_EINVAL;
   if (sizeof(T) != 2) {
-    const int rc = bn_stats_impl<T>(x, sxb, B, C, HW, ws, mean, var, running_mean, running_var, momentum, num_batches_tracked, stream);
+    const int rc = bn_stats_impl<T>(x, sxb, B, C, HW, ws, mean, var, running_mean, running_var, momentum, num_batches_tracked,
+                                    stream, nbt_count);
     if (rc != CENET_OK) return rc;
     return bn_apply_impl<T>(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, stream);
   }
   if ((long)B * HW <= 256 * BN1K_EPT && (long)B * HW >= 2) {
     BnFin f1;
     f1.ws = nullptr; f1.S = 0; f1.n = (float)((long)B * HW); f1.mean = mean; f1.var = var; f1.rmean = running_mean;
-    f1.rvar = running_var; f1.momentum = momentum; f1.nbt = num_batches_tracked;
+    f1.rvar = running_var; f1.momentum = momentum; f1.nbt = num_batches_tracked; f1.nbt_n = nbt_count;
     CENET_LAUNCH(bn_train_fwd_1k_kernel, dim3(C), dim3(256), stream, (const bf16_t*)x, sxb, (bf16_t*)y, syb, eps, gamma, beta, act,
                  slope, B, HW, f1);
     CENET_CHECK_LAUNCH();
@@ -1162,14 +1164,14 @@ static int bn_train_fwd_impl(const T* x, long sxb, T* y, long syb, float* ws, fl
   BnFin fin;
   fin.S = bn_partial_launch<T>(x, sxb, B, C, HW, ws, stream);
   fin.ws = ws; fin.n = (float)((long)B * HW); fin.mean = mean; fin.var = var; fin.rmean = running_mean; fin.rvar = running_var;
-  fin.momentum = momentum; fin.nbt = num_batches_tracked;
+  fin.momentum = momentum; fin.nbt = num_batches_tracked; fin.nbt_n = nbt_count;
   return bn_apply_launch<T>(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, fin, stream);
 }
 CENET_TWIN(bn_train_fwd, (const T* x, long sxb, T* y, long syb, float* ws, float* mean, float* var, float* running_mean,
                           float* running_var, float momentum, long* num_batches_tracked, float eps, const float* gamma,
-                          const float* beta, int act, float slope, int B, int C, int HW, hipStream_t stream),
+                          const float* beta, int act, float slope, int B, int C, int HW, int nbt_count, hipStream_t stream),
            (x, sxb, y, syb, ws, mean, var, running_mean, running_var, momentum, num_batches_tracked, eps, gamma, beta, act, slope, B,
-            C, HW, stream))
+            C, HW, nbt_count, stream))
 CENET_TWIN(bn_apply, (const T* x, long sxb, T* y, long syb, const float* mean, const float* var, float eps, const float* gamma,
                       const float* beta, int act, float slope, int B, int C, int HW, hipStream_t stream),
            (x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, C, HW, stream))

@@ -302,7 +302,7 @@ def bn_train_fwd(x, sxb, y, syb, ws, mean, var, rmean, rvar, momentum, nbt, eps,
     """train-mode BatchNorm forward: statistics + normalisation (+ activation), mean / var / running statistics written"""
     _chk(x, y, ws, mean, var, rmean, rvar, gamma, beta)
     _call("cenet_bn_train_fwd_f32", x, L(sxb), y, L(syb), ws, mean, var, rmean, rvar, float(momentum), nbt, float(eps), gamma,
-          beta, ACT[act], float(slope), B, Cn, HW)
+          beta, ACT[act], float(slope), B, Cn, HW, int(nbt.numel()) if nbt is not None else 1)
 
 
 def bn_apply(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, Cn, HW):
@@ -341,9 +341,9 @@ def dw_tok_tiled(x):
     return is_bf16(x) and x.shape[-1] % 8 == 0 and x.data_ptr() % 16 == 0
 
 
-def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil, x_off=0):
+def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil, x_off=0, g_off=0):
     _chk(x, dy, dw, dbias)
-    _call("cenet_dwconv3x3_wgrad_nchw_acc_f32", Ptr(x, x_off), L(sxb), dy, L(sgb), dw, dbias, B, Cn, H, W, dil)
+    _call("cenet_dwconv3x3_wgrad_nchw_acc_f32", Ptr(x, x_off), L(sxb), Ptr(dy, g_off), L(sgb), dw, dbias, B, Cn, H, W, dil)
 
 
 def dw_wgrad_tok(x, dy, dw, dbias, B, Cn, H, W):

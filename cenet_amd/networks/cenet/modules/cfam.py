@@ -65,15 +65,61 @@ class MultiOrderDWConv(nn.Module):
         self.embed_dims = embed_dims
         self.PW_conv = nn.Conv2d(embed_dims, embed_dims, kernel_size=1)
 
+    # ---- the three dilated branches as ONE chain of launches (K11 of SURVEY §3: "CFAM multi-scale conv fusion") ------------
+    # Their BatchNorms and pointwise convs have identical shapes, so with the parameters of equal role back to back in the
+    # ParamArena (arena_groups) one BatchNorm launch covers 3g channels and one batched GEMM the three 1x1 convs; the depthwise
+    # kernels write their slices of one [B, 3g, H, W] tensor, which is also where the concat wants them.
+    _ROLES = (("dbn_w", lambda m: m.depthwise_bn.weight), ("dbn_b", lambda m: m.depthwise_bn.bias),
+              ("pw", lambda m: m.pointwise.weight), ("pbn_w", lambda m: m.pointwise_bn.weight),
+              ("pbn_b", lambda m: m.pointwise_bn.bias))
+
+    def arena_groups(self):
+        return [[get(m) for m in list(self.dlps)[:3]] for _, get in self._ROLES]
+
+    def _merged(self):
+        """joint views of the three branches' parameters / buffers, or None when the parameters are not laid out for it (no
+        ParamArena: eval scripts, the parity tests on bare modules) — the branch-by-branch path runs then"""
+        b = list(self.dlps)[:3]
+        mg = getattr(self, "_mg", None)
+        if mg is None or any(mg[k].data_ptr() != get(b[0]).data_ptr() for k, get in self._ROLES):
+            mg = {k: ops.merged_param([get(m) for m in b]) for k, get in self._ROLES}
+            if any(v is None for v in mg.values()):
+                self._mg = None
+                return None
+            self._mg = mg
+        for key, bn in (("dbn", "depthwise_bn"), ("pbn", "pointwise_bn")):
+            for stat in ("running_mean", "running_var", "num_batches_tracked"):
+                mg[key + "_" + stat] = ops.merged_buffer([getattr(getattr(m, bn), stat) for m in b])
+        return mg
+
+    def _branches_merged(self, x, sizes, mg):
+        b = list(self.dlps)[:3]
+        u, rest = ops.split_dwconv(x, sizes[:3], [m.rate for m in b], [m.depthwise.weight for m in b], joined=True)
+        for key, bn in (("dbn", b[0].depthwise_bn), ("pbn", b[0].pointwise_bn)):
+            if key == "pbn":
+                u = ops.grouped_conv1x1(u, mg["pw"])
+            u = ops.batchnorm(u, mg[key + "_w"], mg[key + "_b"], mg[key + "_running_mean"], mg[key + "_running_var"],
+                              mg[key + "_num_batches_tracked"], bn.training, bn.eps, "relu", 0.0,
+                              bn.momentum if bn.momentum is not None else 0.1)
+        return u, rest
+
     def forward(self, x):
         H, W = x.shape[2:]
         # the three dilated branches read their channel slice of x in place (ops.split_dwconv); only the small pooled
         # branch gets a copy
         sizes = [hi - lo for lo, hi in self.channel_indices]
-        us = ops.split_dwconv(x, sizes[:3], [m.rate for m in self.dlps[:3]], [m.depthwise.weight for m in self.dlps[:3]])
-        ys = [self.dlps[j].after_depthwise(us[j]) for j in range(3)]
+        b = list(self.dlps)[:3]
+        mg = self._merged()
+        if mg is not None:
+            ops.refresh_member_shadows(mg["pw"], x)
+            u, rest = self._branches_merged(x, sizes, mg)
+            ys = [u]
+        else:
+            us = ops.split_dwconv(x, sizes[:3], [m.rate for m in b], [m.depthwise.weight for m in b])
+            ys = [b[j].after_depthwise(us[j]) for j in range(3)]
+            rest = us[3]
         pool = self.dlps[3]
-        y = ops.adaptive_avgpool(us[3], 7, 7)
+        y = ops.adaptive_avgpool(rest, 7, 7)
         y = ops.conv1x1(y, pool[1].weight)
         y = bn_call(pool[2], y, "lrelu", 0.01)
         y = ops.interpolate_bilinear(y, scale_factor=7, align_corners=True)

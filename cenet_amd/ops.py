@@ -61,6 +61,60 @@ def grad_buf(p: Optional[Tensor]) -> Optional[Tensor]:
     return p.grad
 
 
+def merged_param(ps):
+    """[p_0 | p_1 | ...] as ONE tensor of shape [n, *p.shape] if the equally shaped parameters `ps` lie back to back in a
+    ParamArena (its `arena_groups` layout), else None.  The result aliases the parameters' memory, its `.grad` aliases
+    their gradient slots and its bf16 shadow their shadow slots, so the kernels (and ops.grad_buf / kern.wq) treat it like
+    a parameter; nothing is registered anywhere and the optimizer keeps seeing the flat arena."""
+    p0 = ps[0]
+    slot = getattr(p0, "_cenet_arena_slot", None)
+    if slot is None or any(q.shape != p0.shape or not q.requires_grad for q in ps):
+        return None
+    arena, o = slot
+    n = p0.numel()
+    for j, q in enumerate(ps):
+        sj = getattr(q, "_cenet_arena_slot", None)
+        if sj is None or sj[0] is not arena or sj[1] != o + j * n or q.data_ptr() != arena.params.data_ptr() + 4 * (o + j * n):
+            return None
+    shape = (len(ps),) + tuple(p0.shape)
+    m = arena.params[o:o + len(ps) * n].view(shape).detach()
+    m.requires_grad_(True)
+    m.grad = arena.grads[o:o + len(ps) * n].view(shape)
+    m._cenet_grad_home = arena._home(o, len(ps) * n, shape)
+    arena.enable_shadow()  # (its bf16 slots are rewritten by the fused SGD kernel: a private shadow of `m` would go stale)
+    m._cenet_shadow = arena.shadow[o:o + len(ps) * n].view(shape)
+    m._cenet_shadow_ver = m._version
+    m._cenet_members = tuple(ps)
+    return m
+
+
+def refresh_member_shadows(m, like):
+    """bf16 activations: a member of the merged parameter `m` that was modified through torch since its shadow slot was
+    written (load_state_dict, a torch optimizer) gets the slot re-cast — the slots are shared with `m`'s shadow"""
+    if like.dtype == torch.bfloat16:
+        for q in m._cenet_members:
+            if getattr(q, "_cenet_shadow_ver", None) != q._version:
+                kern.wq(q, like)
+
+
+def merged_buffer(bs):
+    """the equally shaped buffers `bs` (BatchNorm running statistics / counters of sibling modules) re-homed into one
+    [n, *shape] tensor; each module keeps its own tensor object, now a view of the joint one (load_state_dict copies in
+    place).  Returns the joint tensor; call again if the buffers were moved since (`.to()` breaks the aliasing)."""
+    b0 = bs[0]
+    n = b0.numel()
+    esz = b0.element_size()
+    if all(q.shape == b0.shape and q.data_ptr() == b0.data_ptr() + j * n * esz for j, q in enumerate(bs)):
+        base = getattr(b0, "_cenet_joint", None)
+        if base is not None and base.data_ptr() == b0.data_ptr() and base.numel() == len(bs) * n:
+            return base
+    joint = torch.stack([q.detach() for q in bs]).contiguous()
+    for j, q in enumerate(bs):
+        q.data = joint[j]
+    b0._cenet_joint = joint
+    return joint
+
+
 class _WgradSide:
     """Weight-gradient kernels can run on a second HIP stream, concurrently with the data-gradient chain of the backward
     pass: they only feed the optimizer, and most of them are short, latency-bound launches that leave the chip half idle.
@@ -1132,53 +1186,109 @@ class SplitDWFn(Function):
     ONE dx — and the remaining channels come back as a contiguous copy.  Returns (u_0, ..., u_{n-1}, rest)."""
 
     @staticmethod
-    def forward(ctx, x, sizes, dils, *ws):
+    def forward(ctx, x, sizes, dils, joined, *ws):
         x = _c(x)
         B, Cn, H, Wd = x.shape
         HW = H * Wd
         outs, lo = [], 0
+        used = sum(sizes)
+        joint = _act((B, used, H, Wd), x) if joined else None  # joined: the groups' outputs as ONE [B, sum sizes, H, W] tensor
         for c, dil, w in zip(sizes, dils, ws):
-            u = _act((B, c, H, Wd), x)
-            kern.dw_nchw(x, Cn * HW, w, None, u, c * HW, None, 0, B, c, H, Wd, dil, 0, x_off=lo * HW)
-            outs.append(u)
+            if joined:
+                kern.dw_nchw(x, Cn * HW, w, None, joint, used * HW, None, 0, B, c, H, Wd, dil, 0, x_off=lo * HW, y_off=lo * HW)
+            else:
+                u = _act((B, c, H, Wd), x)
+                kern.dw_nchw(x, Cn * HW, w, None, u, c * HW, None, 0, B, c, H, Wd, dil, 0, x_off=lo * HW)
+                outs.append(u)
             lo += c
+        if joined:
+            outs = [joint]
         rest = None
         if lo < Cn:
             rest = _act((B, Cn - lo, H, Wd), x)
             kern.copy_batched(x, Cn * HW, rest, (Cn - lo) * HW, B, (Cn - lo) * HW, x_off=lo * HW)
         ctx.save_for_backward(x, *ws)
         ctx.refs = ws
-        ctx.cfg = (tuple(sizes), tuple(dils), lo)
+        ctx.cfg = (tuple(sizes), tuple(dils), lo, bool(joined))
         return tuple(outs) + ((rest,) if rest is not None else ())
 
     @staticmethod
     def backward(ctx, *gs):
         x = ctx.saved_tensors[0]
         ws = ctx.saved_tensors[1:]
-        sizes, dils, used = ctx.cfg
+        sizes, dils, used, joined = ctx.cfg
         B, Cn, H, Wd = x.shape
         HW = H * Wd
         n = len(sizes)
+        nout = 1 if joined else n
         full = all(g is not None for g in gs)
         dx = torch.empty_like(x) if full else kern.zero_(torch.empty_like(x))
+        gj = _c(gs[0]) if joined and gs[0] is not None else None
         lo = 0
         for j, (c, dil, w, wp) in enumerate(zip(sizes, dils, ws, ctx.refs)):
-            g = gs[j]
+            g = gj if joined else gs[j]
             if g is not None:
                 g = _c(g)
-                kern.dw_nchw(g, c * HW, w, None, dx, Cn * HW, None, 0, B, c, H, Wd, dil, 1, y_off=lo * HW)
+                sgb, g_off = (used * HW, lo * HW) if joined else (c * HW, 0)
+                kern.dw_nchw(g, sgb, w, None, dx, Cn * HW, None, 0, B, c, H, Wd, dil, 1, x_off=g_off, y_off=lo * HW)
                 dw = grad_buf(wp)
                 if dw is not None:
                     with _wgrad_side(g, x):
-                        kern.dw_wgrad_nchw(x, Cn * HW, g, c * HW, dw, None, B, c, H, Wd, dil, x_off=lo * HW)
+                        kern.dw_wgrad_nchw(x, Cn * HW, g, sgb, dw, None, B, c, H, Wd, dil, x_off=lo * HW, g_off=g_off)
             lo += c
-        if used < Cn and len(gs) > n and gs[n] is not None:
-            kern.copy_batched(_c(gs[n]), (Cn - used) * HW, dx, Cn * HW, B, (Cn - used) * HW, y_off=used * HW)
-        return (dx, None, None) + (None,) * n
+        if used < Cn and len(gs) > nout and gs[nout] is not None:
+            kern.copy_batched(_c(gs[nout]), (Cn - used) * HW, dx, Cn * HW, B, (Cn - used) * HW, y_off=used * HW)
+        return (dx, None, None, None) + (None,) * n
 
 
-def split_dwconv(x, sizes, dils, ws):
-    return SplitDWFn.apply(x, tuple(sizes), tuple(dils), *ws)
+def split_dwconv(x, sizes, dils, ws, joined=False):
+    """joined=True: (U, rest) with U = the groups' outputs side by side in one [B, sum(sizes), H, W] tensor"""
+    return SplitDWFn.apply(x, tuple(sizes), tuple(dils), bool(joined), *ws)
+
+
+class GroupedConv1x1Fn(Function):
+    """y[b, j*Co + o] = sum_i W[j, o, i] x[b, j*Ci + i]: G independent bias-free 1x1 convolutions on the channel groups of one
+    NCHW tensor in one batched GEMM each way (the pointwise convs of the three dilated SepConvBN branches of cfam.py:208-212,
+    whose weights ops.merged_param joins into W [G, Co, Ci])."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x = _c(x)
+        G, Co, Ci = W.shape[:3]
+        B = x.shape[0]
+        HW = x.numel() // (B * G * Ci)
+        y = _act((B, G * Co) + tuple(x.shape[2:]), x)
+        kern.gemm(kern.mat_plain(kern.wq(W, x), Ci, 1, sb2=Co * Ci, kfast=1), kern.mat_plain(x, HW, 1, sb=G * Ci * HW, sb2=Ci * HW),
+                  y, Co, HW, Ci, scr=HW, scc=1, scb=G * Co * HW, scb2=Co * HW, nbatch=B * G, nb_inner=G)
+        ctx.save_for_backward(x, W)
+        ctx.refs = (W,)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        Wp, = ctx.refs
+        g = _c(g)
+        G, Co, Ci = W.shape[:3]
+        B = x.shape[0]
+        HW = x.numel() // (B * G * Ci)
+        dW = grad_buf(Wp)
+        if dW is not None:
+            with _wgrad_side(g, x):
+                iters = B * ((HW + 31) // 32)
+                kern.gemm(kern.mat_plain(g, HW, 1, sb=Co * HW, skb=G * Co * HW, kfast=1),
+                          kern.mat_plain(x, 1, HW, sb=Ci * HW, skb=G * Ci * HW, kfast=1), dW, Co, Ci, HW, scr=Ci, scc=1,
+                          scb=Co * Ci, nbatch=G, nkb=B, splits=kern.pick_splits(Co, Ci, G, iters), atomic=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            kern.gemm(kern.mat_plain(kern.wq(Wp, x), 1, Ci, sb2=Co * Ci, kfast=0), kern.mat_plain(g, HW, 1, sb=G * Co * HW, sb2=Co * HW),
+                      dx, Ci, HW, Co, scr=HW, scc=1, scb=G * Ci * HW, scb2=Ci * HW, nbatch=B * G, nb_inner=G)
+        return dx, None
+
+
+def grouped_conv1x1(x, W):
+    return GroupedConv1x1Fn.apply(x, W)
 
 
 class ConcatFn(Function):

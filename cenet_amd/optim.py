@@ -33,6 +33,21 @@ class ParamArena:
         dev = named[0][1].device
         if segments is None:
             segments = [("all", lambda n: True)]
+        # parameter groups that a module wants back to back WITHOUT padding between the members (`arena_groups()` on any
+        # sub-module: lists of equally shaped parameters, e.g. the same weight of the three dilated branches of a
+        # MultiOrderDWConv), so that one kernel launch can address them as one [n, ...] tensor (cenet_amd.ops.merged_param)
+        name_of = {id(p): n for n, p in named}
+        group_of = {}
+        for m in model.modules():
+            fn = getattr(m, "arena_groups", None)
+            if fn is None:
+                continue
+            for grp in fn():
+                names = [name_of[id(q)] for q in grp if id(q) in name_of]
+                if len(names) == len(grp) and len(names) > 1:
+                    for n in names:
+                        group_of[n] = names
+        byname = dict(named)
         order, self.segments = [], []
         taken = set()
         off = 0
@@ -41,9 +56,14 @@ class ParamArena:
             for n, p in named:
                 if n in taken or not pred(n):
                     continue
-                taken.add(n)
-                order.append((n, p, off))
-                off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+                members = group_of.get(n, [n])
+                if any(not pred(k) or k in taken for k in members):
+                    members = [n]  # a group never straddles a segment
+                for k in members:
+                    taken.add(k)
+                    order.append((k, byname[k], off))
+                    off += byname[k].numel()
+                off = (off + ALIGN - 1) // ALIGN * ALIGN
             self.segments.append((sname, start, off))
         left = [n for n, _ in named if n not in taken]
         if left:

@@ -208,7 +208,10 @@ int cenet_bn_apply_f32(const float* x, long sxb, float* y, long syb, const float
  * mean / var the backward pass needs, and the running statistics (nn.BatchNorm2d.forward in training mode). */
 int cenet_bn_train_fwd_f32(const float* x, long sxb, float* y, long syb, float* ws, float* mean, float* var,
     float* running_mean, float* running_var, float momentum, long* num_batches_tracked, float eps, const float* gamma,
-    const float* beta, int act, float slope, int B, int C, int HW, cenet_stream_t stream);
+    const float* beta, int act, float slope, int B, int C, int HW, int nbt_count, cenet_stream_t stream);
+/* nbt_count (1 <= nbt_count <= C): the launch covers the channels of that many nn.BatchNorm2d modules whose parameters and
+ * buffers lie back to back (the three dilated SepConvBN branches of cfam.py:208-212 in one launch); num_batches_tracked[0 ..
+ * nbt_count) are each incremented.  1 for a single module. */
 int cenet_bn_bwd_acc_f32(const float* dy, long sgb, const float* x, long sxb, float* dx, long sdb, const float* mean,
                          const float* var, float eps, const float* gamma, const float* beta, int act, float slope, int B,
                          int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, cenet_stream_t stream);
@@ -440,7 +443,7 @@ int cenet_bn_apply_bf16(const unsigned short* x, long sxb, unsigned short* y, lo
     float eps, const float* gamma, const float* beta, int act, float slope, int B, int C, int HW, cenet_stream_t stream);
 int cenet_bn_train_fwd_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, float* ws, float* mean, float* var,
     float* running_mean, float* running_var, float momentum, long* num_batches_tracked, float eps, const float* gamma,
-    const float* beta, int act, float slope, int B, int C, int HW, cenet_stream_t stream);
+    const float* beta, int act, float slope, int B, int C, int HW, int nbt_count, cenet_stream_t stream);
 int cenet_bn_bwd_acc_bf16(const unsigned short* dy, long sgb, const unsigned short* x, long sxb, unsigned short* dx, long
     sdb, const float* mean, const float* var, float eps, const float* gamma, const float* beta, int act, float slope, int B,
     int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, cenet_stream_t stream);
