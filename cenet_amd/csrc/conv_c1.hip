@@ -184,3 +184,84 @@ extern "C" int cenet_conv_c1_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Square 1x1 convolutions over a handful of channels (bf16, no bias): the pointwise convs of the three dilated SepConvBN
+// branches (cfam.py:208-212; g = 5C/16 = 20 / 40 channels at the 56x56 / 28x28 decoder levels, as `groups` independent G x G
+// products on the channel groups of one tensor) and the conv of the pooled branch (cfam.py:213-219; C/16 = 4 ... 32 channels on
+// 7x7 maps).  As GEMMs these are M = K = G <= 40 problems: 21-51 us per launch on 32x256 tiles that are 60-90 % padding, for
+// 6-12 MB of traffic.  Here a thread owns two neighbouring pixels of one (image, group): it keeps their G inputs in registers,
+// walks the G outputs with the weight row read from LDS (every lane the same address: a broadcast), and stores 4 bytes per
+// output plane.  TRANS: the data gradient (the same products with the transposed weights).  HBM-bound: 2 * G * HW * 2 bytes
+// per (image, group).
+//   x, y [B, groups * G, HW] (group j = channels j*G .. j*G+G-1), W [groups, G, G] bf16 (the arena's shadow of the fp32 weights).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int G, bool TRANS>
+__global__ __launch_bounds__(256) void pw_small_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                      bf16_t* __restrict__ y, int groups, int HW) {
+  __shared__ float w[G * G];  // w[o][i]
+  const int bj = blockIdx.y, j = bj % groups;
+  for (int t = threadIdx.x; t < G * G; t += 256) {
+    const int o = t / G, i = t - o * G;
+    w[t] = cenet_bf2f(W[(long)j * G * G + (TRANS ? i * G + o : o * G + i)]);
+  }
+  __syncthreads();
+  const int p = 2 * (blockIdx.x * 256 + threadIdx.x);
+  if (p >= HW) return;
+  const bf16_t* xb = x + (long)bj * G * HW + p;
+  bf16_t* yb = y + (long)bj * G * HW + p;
+  const bool pair = p + 1 < HW && (HW & 1) == 0;  // (odd planes: 2-byte accesses, the last pixel alone)
+  float x0[G], x1[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    if (pair) {
+      unsigned u;
+      memcpy(&u, xb + (long)i * HW, 4);
+      x0[i] = cenet_bf2f(u & 0xFFFFu);
+      x1[i] = cenet_bf2f(u >> 16);
+    } else {
+      x0[i] = cenet_bf2f(xb[(long)i * HW]);
+      x1[i] = p + 1 < HW ? cenet_bf2f(xb[(long)i * HW + 1]) : 0.f;
+    }
+  }
+#pragma unroll 2
+  for (int o = 0; o < G; ++o) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const float wv = w[o * G + i];
+      a0 += wv * x0[i];
+      a1 += wv * x1[i];
+    }
+    if (pair) {
+      const unsigned u = cenet_pack_bf2(a0, a1);
+      memcpy(yb + (long)o * HW, &u, 4);
+    } else {
+      stf(yb + (long)o * HW, a0);
+      if (p + 1 < HW) stf(yb + (long)o * HW + 1, a1);
+    }
+  }
+}
+
+extern "C" int cenet_pw_small_supported(int G) { return G == 4 || G == 8 || G == 20 || G == 32 || G == 40; }
+
+extern "C" int cenet_pw_small_bf16(const bf16_t* x, const bf16_t* W, bf16_t* y, int B, int groups, int G, long HW, int transpose,
+                                   hipStream_t stream) {
+  if (!x || !W || !y || B <= 0 || groups <= 0 || HW <= 0 || HW > 0x7FFFFFFF) return CENET_EINVAL;
+  if (!cenet_pw_small_supported(G) || (long)B * groups > 65535) return CENET_EUNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)y) & 3) != 0) return CENET_EINVAL;
+  const dim3 grid(cdiv((int)((HW + 1) / 2), 256), B * groups);
+#define PW_GO(G_)                                                                                              \
+  do {                                                                                                         \
+    if (transpose) CENET_LAUNCH((pw_small_kernel<G_, true>), grid, dim3(256), stream, x, W, y, groups, (int)HW); \
+    else CENET_LAUNCH((pw_small_kernel<G_, false>), grid, dim3(256), stream, x, W, y, groups, (int)HW);         \
+  } while (0)
+  if (G == 4) PW_GO(4);
+  else if (G == 8) PW_GO(8);
+  else if (G == 20) PW_GO(20);
+  else if (G == 32) PW_GO(32);
+  else PW_GO(40);
+#undef PW_GO
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}

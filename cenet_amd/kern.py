@@ -699,6 +699,18 @@ def conv_c1_wgrad(x, dy, dw, B, Cout, H, W, k):
     _lib.check(_lib.lib().cenet_conv_c1_wgrad_bf16(P(x), P(dy), P(dw), B, Cout, H, W, k, stream()), "cenet_conv_c1_wgrad_bf16")
 
 
+def pw_small_supported(G: int) -> bool:
+    return bool(_lib.lib().cenet_pw_small_supported(int(G)))
+
+
+def pw_small(x, W, y, B, groups, G, HW, transpose=False):
+    """groups x (G x G) bias-free 1x1 convs on bf16 NCHW tensors, G <= 40 (conv_c1.hip); W: bf16 [groups, G, G]"""
+    _chk(x, W, y)
+    assert x.dtype == BF16 and y.dtype == BF16 and W.dtype == BF16
+    _lib.check(_lib.lib().cenet_pw_small_bf16(P(x), P(W), P(y), B, groups, G, L(HW), int(transpose), stream()),
+               "cenet_pw_small_bf16")
+
+
 def conv_wgrad_direct_supported(Cin: int, Cout: int, k: int, stride: int, pad: int) -> bool:
     return bool(_lib.lib().cenet_conv_wgrad_direct_supported(int(Cin), int(Cout), int(k), int(stride), int(pad)))
 

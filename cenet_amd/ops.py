@@ -280,8 +280,12 @@ class Conv1x1Fn(Function):
         # the shortcut 1x1 convolution of the one-channel network input (unet.py conv3): a stencil, not a K = 1 GEMM
         ctx.c1 = bool(_bf(x) and Cin == 1 and b is None and resid is None and x.dim() == 4
                       and kern.conv_c1_supported(1, Cout, 1, 1, 0))
+        # a few channels in, as many out, no bias (the pooled branch of cfam.py:213-219): thread-per-pixel kernel
+        ctx.small = bool(_bf(x) and not ctx.c1 and Cin == Cout and b is None and resid is None and kern.pw_small_supported(Cin))
         if ctx.c1:
             kern.conv_c1_fwd(x, W, y, B, Cout, x.shape[2], x.shape[3], 1)
+        elif ctx.small:
+            kern.pw_small(x, kern.wq(W, x), y, B, 1, Cin, HW)
         else:
             kern.gemm(kern.mat_plain(kern.wq(W, x), Cin, 1, kfast=1), kern.mat_plain(x, HW, 1, sb=Cin * HW), y, Cout, HW, Cin,
                       scr=HW, scc=1, scb=Cout * HW, nbatch=B, bias=b, bias_on_row=True, R=resid, srb=Cout * HW, srr=HW, src=1)
@@ -317,8 +321,11 @@ class Conv1x1Fn(Function):
             dx = torch.empty_like(x)
             if g_tap is not None:
                 g_tap = _c(g_tap)
-            kern.gemm(kern.mat_plain(kern.wq(Wp, x), 1, Cin, kfast=0), kern.mat_plain(g, HW, 1, sb=Cout * HW), dx, Cin, HW, Cout,
-                      scr=HW, scc=1, scb=Cin * HW, nbatch=B, R=g_tap, srb=Cin * HW, srr=HW, src=1)
+            if ctx.small and g_tap is None:
+                kern.pw_small(g, kern.wq(Wp, x), dx, B, 1, Cin, HW, transpose=True)
+            else:
+                kern.gemm(kern.mat_plain(kern.wq(Wp, x), 1, Cin, kfast=0), kern.mat_plain(g, HW, 1, sb=Cout * HW), dx, Cin, HW,
+                          Cout, scr=HW, scc=1, scb=Cin * HW, nbatch=B, R=g_tap, srb=Cin * HW, srr=HW, src=1)
         elif g_tap is not None:
             dx = g_tap
         return dx, None, None, (g if ctx.has_resid else None), None
@@ -1258,8 +1265,13 @@ class GroupedConv1x1Fn(Function):
         B = x.shape[0]
         HW = x.numel() // (B * G * Ci)
         y = _act((B, G * Co) + tuple(x.shape[2:]), x)
-        kern.gemm(kern.mat_plain(kern.wq(W, x), Ci, 1, sb2=Co * Ci, kfast=1), kern.mat_plain(x, HW, 1, sb=G * Ci * HW, sb2=Ci * HW),
-                  y, Co, HW, Ci, scr=HW, scc=1, scb=G * Co * HW, scb2=Co * HW, nbatch=B * G, nb_inner=G)
+        ctx.small = bool(_bf(x) and Co == Ci and kern.pw_small_supported(Ci))
+        if ctx.small:  # a handful of channels per group: thread-per-pixel kernel instead of mostly padded GEMM tiles
+            kern.pw_small(x, kern.wq(W, x), y, B, G, Ci, HW)
+        else:
+            kern.gemm(kern.mat_plain(kern.wq(W, x), Ci, 1, sb2=Co * Ci, kfast=1),
+                      kern.mat_plain(x, HW, 1, sb=G * Ci * HW, sb2=Ci * HW),
+                      y, Co, HW, Ci, scr=HW, scc=1, scb=G * Co * HW, scb2=Co * HW, nbatch=B * G, nb_inner=G)
         ctx.save_for_backward(x, W)
         ctx.refs = (W,)
         return y
@@ -1282,8 +1294,12 @@ class GroupedConv1x1Fn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            kern.gemm(kern.mat_plain(kern.wq(Wp, x), 1, Ci, sb2=Co * Ci, kfast=0), kern.mat_plain(g, HW, 1, sb=G * Co * HW, sb2=Co * HW),
-                      dx, Ci, HW, Co, scr=HW, scc=1, scb=G * Ci * HW, scb2=Ci * HW, nbatch=B * G, nb_inner=G)
+            if ctx.small:
+                kern.pw_small(g, kern.wq(Wp, x), dx, B, G, Ci, HW, transpose=True)
+            else:
+                kern.gemm(kern.mat_plain(kern.wq(Wp, x), 1, Ci, sb2=Co * Ci, kfast=0),
+                          kern.mat_plain(g, HW, 1, sb=G * Co * HW, sb2=Co * HW),
+                          dx, Ci, HW, Co, scr=HW, scc=1, scb=G * Ci * HW, scb2=Ci * HW, nbatch=B * G, nb_inner=G)
         return dx, None
 
 

@@ -101,6 +101,12 @@ int cenet_conv_direct_bf16(const unsigned short* x, const float* w, unsigned sho
  * (conv_c1.hip): the residual block of the output head that reads x (out.py:41-44; unet.py:156-197 conv1 / conv3).
  * Forward y = w (*) x and the weight gradient dw_acc += dy (*) x; the image itself needs no gradient. */
 int cenet_conv_c1_supported(int Cin, int Cout, int k, int stride, int pad);
+/* `groups` independent square bias-free 1x1 convolutions over G <= 40 channels each (conv_c1.hip, bf16): y[b, j*G + o, p] =
+ * sum_i W[j][o][i] x[b, j*G + i, p]  (transpose != 0: W[j][i][o], the data gradient).  The pointwise convs of the dilated
+ * SepConvBN branches and the pooled-branch conv of cfam.py:208-219 at channel counts where a GEMM tile is mostly padding. */
+int cenet_pw_small_supported(int G);
+int cenet_pw_small_bf16(const unsigned short* x, const unsigned short* W, unsigned short* y, int B, int groups, int G, long HW,
+    int transpose, cenet_stream_t stream);
 int cenet_conv_c1_fwd_bf16(const unsigned short* x, const float* w, unsigned short* y, int B, int Cout, int H, int W, int k,
     cenet_stream_t stream);
 int cenet_conv_c1_wgrad_bf16(const unsigned short* x, const unsigned short* dy, float* dw_acc, int B, int Cout, int H, int W,

@@ -76,6 +76,30 @@ def test_conv1x1(dev, B, Cin, Cout, H, W):
     compare(lambda x, r, Wt, b: ops.conv1x1(x, Wt, b, resid=r), [x, r], [Wt, b], dev=dev)
 
 
+# grouped pointwise convs (ops.grouped_conv1x1: the three dilated SepConvBN branches in one launch): G = 20 / 40 channels
+# per group take the thread-per-pixel kernel (conv_c1.hip, pw_small_kernel) with bf16 tensors, 100 the batched ring GEMM;
+# even and odd plane sizes.  The fp32 run (batched GEMM) is itself held against F.conv2d(groups=3).
+@pytest.mark.parametrize("Gc,H,W", [(20, 8, 8), (40, 7, 7), (20, 5, 6), (100, 7, 7), (32, 6, 6)])
+def test_grouped_conv1x1(dev, Gc, H, W):
+    g = G(Gc + H)
+    x = torch.randn(2, 3 * Gc, H, W, generator=g)
+    Wt = torch.randn(3, Gc, Gc, 1, 1, generator=g) * 0.2
+    compare(lambda x, Wt: ops.grouped_conv1x1(x, Wt), [x], [Wt], dev=dev)
+    xr = _r(x)
+    y = ops.grouped_conv1x1(xr.to(dev), Wt.to(dev)).cpu()
+    ref = torch.nn.functional.conv2d(xr, Wt.reshape(3 * Gc, Gc, 1, 1), groups=3)
+    assert _rel(y, ref) < 1e-5
+
+
+# square bias-free 1x1 convs over a few channels (the pooled branch of MultiOrderDWConv at 7x7): pw_small_kernel with bf16
+@pytest.mark.parametrize("Cn,H,W", [(4, 7, 7), (8, 7, 7), (20, 7, 7), (32, 4, 4)])
+def test_conv1x1_few_channels(dev, Cn, H, W):
+    g = G(Cn)
+    x = torch.randn(3, Cn, H, W, generator=g)
+    Wt = torch.randn(Cn, Cn, 1, 1, generator=g) * 0.3
+    compare(lambda x, Wt: ops.conv1x1(x, Wt), [x], [Wt], dev=dev)
+
+
 def test_conv1x1_one_channel_input(dev):
     """the shortcut 1x1 convolution of the one-channel network input (unet.py conv3): stencil kernels in bf16"""
     g = G(3)
