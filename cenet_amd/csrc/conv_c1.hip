@@ -186,6 +186,34 @@ extern "C" int cenet_conv_c1_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Pixel-pair access for the thread-per-pixel 1x1 kernels below: a thread owns pixels p, p + 1 (p even) of a plane of HW bf16
+// elements.  EVEN (HW even: every plane starts 4-byte aligned and p + 1 < HW always): one 4-byte access, no condition — the
+// kernels branch ONCE on the parity of HW (wave-uniform), never per load (per-load conditions serialise the loads).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <bool EVEN>
+__device__ __forceinline__ void pw_ld2(const bf16_t* q, bool has1, float& a, float& b) {
+  if (EVEN) {
+    unsigned u;
+    memcpy(&u, q, 4);
+    a = cenet_bf2f(u & 0xFFFFu);
+    b = cenet_bf2f(u >> 16);
+  } else {
+    a = cenet_bf2f(q[0]);
+    b = has1 ? cenet_bf2f(q[1]) : 0.f;
+  }
+}
+template <bool EVEN>
+__device__ __forceinline__ void pw_st2(bf16_t* q, bool has1, float a, float b) {
+  if (EVEN) {
+    const unsigned u = cenet_pack_bf2(a, b);
+    memcpy(q, &u, 4);
+  } else {
+    stf(q, a);
+    if (has1) stf(q + 1, b);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Square 1x1 convolutions over a handful of channels (bf16, no bias): the pointwise convs of the three dilated SepConvBN
 // branches (cfam.py:208-212; g = 5C/16 = 20 / 40 channels at the 56x56 / 28x28 decoder levels, as `groups` independent G x G
 // products on the channel groups of one tensor) and the conv of the pooled branch (cfam.py:213-219; C/16 = 4 ... 32 channels on
@@ -196,6 +224,23 @@ extern "C" int cenet_conv_c1_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float
 // per (image, group).
 //   x, y [B, groups * G, HW] (group j = channels j*G .. j*G+G-1), W [groups, G, G] bf16 (the arena's shadow of the fp32 weights).
 // ---------------------------------------------------------------------------------------------------------------------------
+template <int G, bool EVEN>
+__device__ __forceinline__ void pw_small_body(const bf16_t* xb, bf16_t* yb, const float* w, int HW, bool has1) {
+  float x0[G], x1[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) pw_ld2<EVEN>(xb + (long)i * HW, has1, x0[i], x1[i]);
+#pragma unroll 2
+  for (int o = 0; o < G; ++o) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const float wv = w[o * G + i];
+      a0 += wv * x0[i];
+      a1 += wv * x1[i];
+    }
+    pw_st2<EVEN>(yb + (long)o * HW, has1, a0, a1);
+  }
+}
 template <int G, bool TRANS>
 __global__ __launch_bounds__(256) void pw_small_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
                                                       bf16_t* __restrict__ y, int groups, int HW) {
@@ -210,37 +255,8 @@ __global__ __launch_bounds__(256) void pw_small_kernel(const bf16_t* __restrict_
   if (p >= HW) return;
   const bf16_t* xb = x + (long)bj * G * HW + p;
   bf16_t* yb = y + (long)bj * G * HW + p;
-  const bool pair = p + 1 < HW && (HW & 1) == 0;  // (odd planes: 2-byte accesses, the last pixel alone)
-  float x0[G], x1[G];
-#pragma unroll
-  for (int i = 0; i < G; ++i) {
-    if (pair) {
-      unsigned u;
-      memcpy(&u, xb + (long)i * HW, 4);
-      x0[i] = cenet_bf2f(u & 0xFFFFu);
-      x1[i] = cenet_bf2f(u >> 16);
-    } else {
-      x0[i] = cenet_bf2f(xb[(long)i * HW]);
-      x1[i] = p + 1 < HW ? cenet_bf2f(xb[(long)i * HW + 1]) : 0.f;
-    }
-  }
-#pragma unroll 2
-  for (int o = 0; o < G; ++o) {
-    float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-      const float wv = w[o * G + i];
-      a0 += wv * x0[i];
-      a1 += wv * x1[i];
-    }
-    if (pair) {
-      const unsigned u = cenet_pack_bf2(a0, a1);
-      memcpy(yb + (long)o * HW, &u, 4);
-    } else {
-      stf(yb + (long)o * HW, a0);
-      if (p + 1 < HW) stf(yb + (long)o * HW + 1, a1);
-    }
-  }
+  if ((HW & 1) == 0) pw_small_body<G, true>(xb, yb, w, HW, true);
+  else pw_small_body<G, false>(xb, yb, w, HW, p + 1 < HW);
 }
 
 extern "C" int cenet_pw_small_supported(int G) { return G == 4 || G == 8 || G == 20 || G == 32 || G == 40; }
@@ -262,6 +278,187 @@ extern "C" int cenet_pw_small_bf16(const bf16_t* x, const bf16_t* W, bf16_t* y, 
   else if (G == 32) PW_GO(32);
   else PW_GO(40);
 #undef PW_GO
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 1x1 convolution from 64 channels to a FEW (<= 16) output channels, bf16, with bias: the segmentation head's last layer
+// (unet.py:200-217 UnetOutBlock; out.py:49: 64 -> num_classes at 112x112).  As a GEMM it is an M = 4 problem on 32-row tiles
+// (80 us forward, 62 us weight gradient, 39 us data gradient at B = 32 for 51 MB of traffic).  Here:
+//   forward : thread = two neighbouring pixels, their 64 inputs in registers, weights [CO][64] broadcast from LDS; reads the
+//             64-channel tensor once (HBM-bound), writes CO planes.
+//   dgrad   : thread = two pixels, their CO output gradients in registers (16 slots, zero weights beyond CO), walks the 64
+//             input channels; writes the 64-channel tensor once.
+//   wgrad   : workgroup = 1024 pixels of one image; wave w owns input channels 16w .. 16w+15, lane = pixel pair: CO x 16
+//             accumulators per thread, xor-shuffle fold over the 64 lanes, one atomic per (o, i) and workgroup; wave 0 also
+//             sums dY into the bias gradient.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define PWF_CI 64
+#define PWF_COMAX 16
+template <bool EVEN>
+__device__ __forceinline__ void pwf_fwd_body(const bf16_t* xb, bf16_t* yb, const float* w, const float* bsh, int CO, int HW,
+                                             bool has1) {
+  float x0[PWF_CI], x1[PWF_CI];
+#pragma unroll
+  for (int i = 0; i < PWF_CI; ++i) pw_ld2<EVEN>(xb + (long)i * HW, has1, x0[i], x1[i]);
+  for (int o = 0; o < CO; ++o) {
+    float a0 = bsh[o], a1 = bsh[o];
+#pragma unroll
+    for (int i = 0; i < PWF_CI; ++i) {
+      const float wv = w[o * PWF_CI + i];
+      a0 += wv * x0[i];
+      a1 += wv * x1[i];
+    }
+    pw_st2<EVEN>(yb + (long)o * HW, has1, a0, a1);
+  }
+}
+__global__ __launch_bounds__(256) void pw_fewout_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ y, int CO, int HW) {
+  __shared__ float w[PWF_COMAX * PWF_CI];
+  __shared__ float bsh[PWF_COMAX];
+  for (int t = threadIdx.x; t < CO * PWF_CI; t += 256) w[t] = cenet_bf2f(W[t]);
+  if (threadIdx.x < CO) bsh[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int b = blockIdx.y, p = 2 * (blockIdx.x * 256 + threadIdx.x);
+  if (p >= HW) return;
+  const bf16_t* xb = x + (long)b * PWF_CI * HW + p;
+  bf16_t* yb = y + (long)b * CO * HW + p;
+  if ((HW & 1) == 0) pwf_fwd_body<true>(xb, yb, w, bsh, CO, HW, true);
+  else pwf_fwd_body<false>(xb, yb, w, bsh, CO, HW, p + 1 < HW);
+}
+
+// COT: compile-time bound of the output-channel loop (2, 4, 9, or 16 for anything else <= 16; rows >= CO hold zero weights)
+template <int COT, bool EVEN>
+__device__ __forceinline__ void pwf_dgrad_body(const bf16_t* gb, bf16_t* db, const float* w, int CO, int HW, bool has1) {
+  float g0[COT], g1[COT];
+#pragma unroll
+  for (int o = 0; o < COT; ++o) {
+    g0[o] = g1[o] = 0.f;
+    if (o < CO) pw_ld2<EVEN>(gb + (long)o * HW, has1, g0[o], g1[o]);  // (CO is wave-uniform)
+  }
+#pragma unroll 4
+  for (int i = 0; i < PWF_CI; ++i) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int o = 0; o < COT; ++o) {
+      const float wv = w[o * PWF_CI + i];
+      a0 += wv * g0[o];
+      a1 += wv * g1[o];
+    }
+    pw_st2<EVEN>(db + (long)i * HW, has1, a0, a1);
+  }
+}
+template <int COT>
+__global__ __launch_bounds__(256) void pw_fewout_dgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ W,
+                                                             bf16_t* __restrict__ dx, int CO, int HW) {
+  __shared__ float w[COT * PWF_CI];  // rows >= CO zero
+  for (int t = threadIdx.x; t < COT * PWF_CI; t += 256) w[t] = t < CO * PWF_CI ? cenet_bf2f(W[t]) : 0.f;
+  __syncthreads();
+  const int b = blockIdx.y, p = 2 * (blockIdx.x * 256 + threadIdx.x);
+  if (p >= HW) return;
+  const bf16_t* gb = dy + (long)b * CO * HW + p;
+  bf16_t* db = dx + (long)b * PWF_CI * HW + p;
+  if ((HW & 1) == 0) pwf_dgrad_body<COT, true>(gb, db, w, CO, HW, true);
+  else pwf_dgrad_body<COT, false>(gb, db, w, CO, HW, p + 1 < HW);
+}
+
+template <int CO, bool EVEN>
+__device__ __forceinline__ void pwf_wgrad_body(const bf16_t* xb, const bf16_t* gb, int HW, int p0, int p1, int lane,
+                                               float (&acc)[CO][16], float (&accb)[CO]) {
+  for (int p = p0 + 2 * lane; p < p1; p += 128) {
+    const bool has1 = p + 1 < p1;
+    float g0[CO], g1[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      pw_ld2<EVEN>(gb + (long)o * HW + p, has1, g0[o], g1[o]);
+      accb[o] += g0[o] + g1[o];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float x0, x1;
+      pw_ld2<EVEN>(xb + (long)i * HW + p, has1, x0, x1);
+#pragma unroll
+      for (int o = 0; o < CO; ++o) acc[o][i] += g0[o] * x0 + g1[o] * x1;
+    }
+  }
+}
+template <int CO>
+__global__ __launch_bounds__(256) void pw_fewout_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                             float* __restrict__ dW, float* __restrict__ dbias, int HW) {
+  __shared__ float red[4][CO * 16 + CO];
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p0 = blockIdx.x * 1024, p1 = p0 + 1024 < HW ? p0 + 1024 : HW;
+  const bf16_t* xb = x + (long)b * PWF_CI * HW + (long)(16 * wave) * HW;
+  const bf16_t* gb = dy + (long)b * CO * HW;
+  float acc[CO][16], accb[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    accb[o] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[o][i] = 0.f;
+  }
+  if ((HW & 1) == 0) pwf_wgrad_body<CO, true>(xb, gb, HW, p0, p1, lane, acc, accb);
+  else pwf_wgrad_body<CO, false>(xb, gb, HW, p0, p1, lane, acc, accb);
+  // fold the 64 lanes of each wave (xor shuffles), meet in LDS, one atomic per (o, i) and workgroup
+  float vals[CO * 16 + CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) vals[o * 16 + i] = acc[o][i];
+    vals[CO * 16 + o] = accb[o];
+  }
+#pragma unroll
+  for (int k = 0; k < CO * 16 + CO; ++k) {
+    float v = vals[k];
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 4 * CO * 16; k += 256) {
+    const int wv = k / (CO * 16), r = k - wv * (CO * 16), o = r / 16, i = r - o * 16;
+    atomicAdd(&dW[o * PWF_CI + 16 * wv + i], red[wv][r]);
+  }
+  if (dbias && threadIdx.x < CO) atomicAdd(&dbias[threadIdx.x], red[0][CO * 16 + threadIdx.x]);
+}
+
+extern "C" int cenet_pw_fewout_supported(int Cin, int Cout) { return Cin == PWF_CI && Cout >= 1 && Cout <= PWF_COMAX; }
+extern "C" int cenet_pw_fewout_wgrad_supported(int Cin, int Cout) { return Cin == PWF_CI && (Cout == 2 || Cout == 4 || Cout == 9); }
+
+extern "C" int cenet_pw_fewout_fwd_bf16(const bf16_t* x, const bf16_t* W, const float* bias, bf16_t* y, int B, int Cin, int Cout,
+                                        long HW, hipStream_t stream) {
+  if (!x || !W || !y || B <= 0 || HW <= 0 || HW > 0x7FFFFFFF || B > 65535) return CENET_EINVAL;
+  if (!cenet_pw_fewout_supported(Cin, Cout)) return CENET_EUNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)y) & 3) != 0) return CENET_EINVAL;
+  CENET_LAUNCH(pw_fewout_fwd_kernel, dim3(cdiv((int)((HW + 1) / 2), 256), B), dim3(256), stream, x, W, bias, y, Cout, (int)HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+extern "C" int cenet_pw_fewout_dgrad_bf16(const bf16_t* dy, const bf16_t* W, bf16_t* dx, int B, int Cin, int Cout, long HW,
+                                          hipStream_t stream) {
+  if (!dy || !W || !dx || B <= 0 || HW <= 0 || HW > 0x7FFFFFFF || B > 65535) return CENET_EINVAL;
+  if (!cenet_pw_fewout_supported(Cin, Cout)) return CENET_EUNSUPPORTED;
+  if ((((uintptr_t)dy | (uintptr_t)dx) & 3) != 0) return CENET_EINVAL;
+  const dim3 grid(cdiv((int)((HW + 1) / 2), 256), B);
+  if (Cout <= 2) CENET_LAUNCH((pw_fewout_dgrad_kernel<2>), grid, dim3(256), stream, dy, W, dx, Cout, (int)HW);
+  else if (Cout <= 4) CENET_LAUNCH((pw_fewout_dgrad_kernel<4>), grid, dim3(256), stream, dy, W, dx, Cout, (int)HW);
+  else if (Cout <= 9) CENET_LAUNCH((pw_fewout_dgrad_kernel<9>), grid, dim3(256), stream, dy, W, dx, Cout, (int)HW);
+  else CENET_LAUNCH((pw_fewout_dgrad_kernel<16>), grid, dim3(256), stream, dy, W, dx, Cout, (int)HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+extern "C" int cenet_pw_fewout_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float* dW_acc, float* dbias_acc, int B, int Cin,
+                                          int Cout, long HW, hipStream_t stream) {
+  if (!x || !dy || !dW_acc || B <= 0 || HW <= 0 || HW > 0x7FFFFFFF || B > 65535) return CENET_EINVAL;
+  if (!cenet_pw_fewout_wgrad_supported(Cin, Cout)) return CENET_EUNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)dy) & 3) != 0) return CENET_EINVAL;
+  const dim3 grid(cdiv((int)HW, 1024), B);
+  if (Cout == 2) CENET_LAUNCH((pw_fewout_wgrad_kernel<2>), grid, dim3(256), stream, x, dy, dW_acc, dbias_acc, (int)HW);
+  else if (Cout == 4) CENET_LAUNCH((pw_fewout_wgrad_kernel<4>), grid, dim3(256), stream, x, dy, dW_acc, dbias_acc, (int)HW);
+  else CENET_LAUNCH((pw_fewout_wgrad_kernel<9>), grid, dim3(256), stream, x, dy, dW_acc, dbias_acc, (int)HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -699,6 +699,35 @@ def conv_c1_wgrad(x, dy, dw, B, Cout, H, W, k):
     _lib.check(_lib.lib().cenet_conv_c1_wgrad_bf16(P(x), P(dy), P(dw), B, Cout, H, W, k, stream()), "cenet_conv_c1_wgrad_bf16")
 
 
+def pw_fewout_supported(Cin: int, Cout: int) -> bool:
+    return bool(_lib.lib().cenet_pw_fewout_supported(int(Cin), int(Cout)))
+
+
+def pw_fewout_wgrad_supported(Cin: int, Cout: int) -> bool:
+    return bool(_lib.lib().cenet_pw_fewout_wgrad_supported(int(Cin), int(Cout)))
+
+
+def pw_fewout_fwd(x, W, bias, y, B, Cin, Cout, HW):
+    """64 -> few channels 1x1 conv with bias on bf16 tensors (conv_c1.hip); W: bf16 [Cout, 64]"""
+    _chk(x, W, bias, y)
+    assert x.dtype == BF16 and y.dtype == BF16 and W.dtype == BF16
+    _lib.check(_lib.lib().cenet_pw_fewout_fwd_bf16(P(x), P(W), P(bias) if bias is not None else None, P(y), B, Cin, Cout, L(HW),
+                                                   stream()), "cenet_pw_fewout_fwd_bf16")
+
+
+def pw_fewout_dgrad(dy, W, dx, B, Cin, Cout, HW):
+    _chk(dy, W, dx)
+    assert dy.dtype == BF16 and dx.dtype == BF16 and W.dtype == BF16
+    _lib.check(_lib.lib().cenet_pw_fewout_dgrad_bf16(P(dy), P(W), P(dx), B, Cin, Cout, L(HW), stream()), "cenet_pw_fewout_dgrad_bf16")
+
+
+def pw_fewout_wgrad(x, dy, dW, dbias, B, Cin, Cout, HW):
+    _chk(x, dy, dW, dbias)
+    assert x.dtype == BF16 and dy.dtype == BF16 and dW.dtype == torch.float32
+    _lib.check(_lib.lib().cenet_pw_fewout_wgrad_bf16(P(x), P(dy), P(dW), P(dbias) if dbias is not None else None, B, Cin, Cout,
+                                                     L(HW), stream()), "cenet_pw_fewout_wgrad_bf16")
+
+
 def pw_small_supported(G: int) -> bool:
     return bool(_lib.lib().cenet_pw_small_supported(int(G)))
 

@@ -282,10 +282,15 @@ class Conv1x1Fn(Function):
                       and kern.conv_c1_supported(1, Cout, 1, 1, 0))
         # a few channels in, as many out, no bias (the pooled branch of cfam.py:213-219): thread-per-pixel kernel
         ctx.small = bool(_bf(x) and not ctx.c1 and Cin == Cout and b is None and resid is None and kern.pw_small_supported(Cin))
+        # 64 -> a few channels with bias (the head's last layer, unet.py:200-217): thread-per-pixel kernels (conv_c1.hip)
+        ctx.fewout = bool(_bf(x) and not ctx.c1 and not ctx.small and resid is None and not tap
+                          and kern.pw_fewout_supported(Cin, Cout))
         if ctx.c1:
             kern.conv_c1_fwd(x, W, y, B, Cout, x.shape[2], x.shape[3], 1)
         elif ctx.small:
             kern.pw_small(x, kern.wq(W, x), y, B, 1, Cin, HW)
+        elif ctx.fewout:
+            kern.pw_fewout_fwd(x, kern.wq(W, x), b, y, B, Cin, Cout, HW)
         else:
             kern.gemm(kern.mat_plain(kern.wq(W, x), Cin, 1, kfast=1), kern.mat_plain(x, HW, 1, sb=Cin * HW), y, Cout, HW, Cin,
                       scr=HW, scc=1, scb=Cout * HW, nbatch=B, bias=b, bias_on_row=True, R=resid, srb=Cout * HW, srr=HW, src=1)
@@ -309,6 +314,8 @@ class Conv1x1Fn(Function):
             with _wgrad_side(g, x):
                 if dW is not None and ctx.c1:
                     kern.conv_c1_wgrad(x, g, dW, B, Cout, x.shape[2], x.shape[3], 1)
+                elif dW is not None and ctx.fewout and kern.pw_fewout_wgrad_supported(Cin, Cout):
+                    kern.pw_fewout_wgrad(x, g, dW, db, B, Cin, Cout, HW)
                 elif dW is not None:
                     iters = B * ((HW + 31) // 32)
                     kern.gemm(kern.mat_plain(g, HW, 1, skb=Cout * HW, kfast=1), kern.mat_plain(x, 1, HW, skb=Cin * HW, kfast=1),
@@ -323,6 +330,8 @@ class Conv1x1Fn(Function):
                 g_tap = _c(g_tap)
             if ctx.small and g_tap is None:
                 kern.pw_small(g, kern.wq(Wp, x), dx, B, 1, Cin, HW, transpose=True)
+            elif ctx.fewout and g_tap is None:
+                kern.pw_fewout_dgrad(g, kern.wq(Wp, x), dx, B, Cin, Cout, HW)
             else:
                 kern.gemm(kern.mat_plain(kern.wq(Wp, x), 1, Cin, kfast=0), kern.mat_plain(g, HW, 1, sb=Cout * HW), dx, Cin, HW,
                           Cout, scr=HW, scc=1, scb=Cin * HW, nbatch=B, R=g_tap, srb=Cin * HW, srr=HW, src=1)

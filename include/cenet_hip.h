@@ -104,6 +104,17 @@ int cenet_conv_c1_supported(int Cin, int Cout, int k, int stride, int pad);
 /* `groups` independent square bias-free 1x1 convolutions over G <= 40 channels each (conv_c1.hip, bf16): y[b, j*G + o, p] =
  * sum_i W[j][o][i] x[b, j*G + i, p]  (transpose != 0: W[j][i][o], the data gradient).  The pointwise convs of the dilated
  * SepConvBN branches and the pooled-branch conv of cfam.py:208-219 at channel counts where a GEMM tile is mostly padding. */
+/* 1x1 convolution from 64 channels to Cout <= 16 channels with bias, bf16 tensors (conv_c1.hip): the last layer of the
+ * segmentation head (unet.py:200-217 UnetOutBlock, out.py:49).  x [B,64,HW], W bf16 [Cout,64] (shadow of the fp32 weight),
+ * y / dy [B,Cout,HW]; the weight-gradient entry adds into fp32 dW [Cout,64] and dbias [Cout] (Cout in {2, 4, 9}). */
+int cenet_pw_fewout_supported(int Cin, int Cout);
+int cenet_pw_fewout_wgrad_supported(int Cin, int Cout);
+int cenet_pw_fewout_fwd_bf16(const unsigned short* x, const unsigned short* W, const float* bias, unsigned short* y, int B, int Cin,
+    int Cout, long HW, cenet_stream_t stream);
+int cenet_pw_fewout_dgrad_bf16(const unsigned short* dy, const unsigned short* W, unsigned short* dx, int B, int Cin, int Cout,
+    long HW, cenet_stream_t stream);
+int cenet_pw_fewout_wgrad_bf16(const unsigned short* x, const unsigned short* dy, float* dW_acc, float* dbias_acc, int B, int Cin,
+    int Cout, long HW, cenet_stream_t stream);
 int cenet_pw_small_supported(int G);
 int cenet_pw_small_bf16(const unsigned short* x, const unsigned short* W, unsigned short* y, int B, int groups, int G, long HW,
     int transpose, cenet_stream_t stream);

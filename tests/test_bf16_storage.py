@@ -100,6 +100,16 @@ def test_conv1x1_few_channels(dev, Cn, H, W):
     compare(lambda x, Wt: ops.conv1x1(x, Wt), [x], [Wt], dev=dev)
 
 
+# 64 -> num_classes with bias (the head's last layer): pw_fewout kernels with bf16 tensors; 4 / 9 / 2 classes have the
+# dedicated weight-gradient kernel, 3 takes the GEMM one; odd plane size
+@pytest.mark.parametrize("Co,H,W", [(4, 12, 12), (9, 10, 14), (2, 40, 40), (3, 8, 8), (4, 7, 7)])
+def test_conv1x1_few_outputs(dev, Co, H, W):
+    g = G(Co)
+    x = torch.randn(2, 64, H, W, generator=g)
+    Wt, b = torch.randn(Co, 64, 1, 1, generator=g) * 0.2, torch.randn(Co, generator=g)
+    compare(lambda x, Wt, b: ops.conv1x1(x, Wt, b), [x], [Wt, b], dev=dev)
+
+
 def test_conv1x1_one_channel_input(dev):
     """the shortcut 1x1 convolution of the one-channel network input (unet.py conv3): stencil kernels in bf16"""
     g = G(3)
