@@ -302,8 +302,15 @@ __device__ __forceinline__ float dw_act(float u, int act, float slope) {
 template <int ACT>
 __device__ __forceinline__ float dw_act_grad(float u, int act, float slope) {
   if (ACT == ACT_NONE) return 1.f;
-  if (ACT == ACT_GELU)
-    return 0.5f * (1.f + dw_erf(u * 0.70710678118654752f)) + u * 0.3989422804014327f * fast_exp(-0.5f * u * u);
+  if (ACT == ACT_GELU) {
+    // Phi(u) + u phi(u): the exponential inside erf(u / sqrt 2) IS exp(-u^2 / 2) — one v_exp_f32 for both terms
+    const float ax = fabsf(u) * 0.70710678118654752f;
+    const float t = 1.f / (1.f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = fast_exp(-0.5f * u * u);
+    const float erfv = copysignf(1.f - poly * e, u);
+    return 0.5f * (1.f + erfv) + u * 0.3989422804014327f * e;
+  }
   return act_bwd(act, u, slope);
 }
 
