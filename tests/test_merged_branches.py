@@ -59,6 +59,11 @@ def test_merged_equals_branchwise(dev, C, hw, bf16):  # noqa: F811
                 assert int(br) == int(bm) == 2, n
             else:
                 assert (br - bm).abs().max() <= 1e-5 + (1e-2 if bf16 else 0.0), n
+        # eval mode: the joint running statistics feed one normalisation launch
+        ref.eval(), mer.eval()
+        with torch.no_grad():
+            yr, ym = ref(x).float(), mer(x).float()
+        assert (yr - ym).abs().max() <= tol * max(1.0, yr.abs().max().item())
     finally:
         kern.set_compute_bf16(old)
 
