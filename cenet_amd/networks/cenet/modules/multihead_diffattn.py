@@ -29,12 +29,28 @@ class MultiheadDiffAttn(nn.Module):
         for n in ("lambda_q1", "lambda_k1", "lambda_q2", "lambda_k2"):
             setattr(self, n, nn.Parameter(torch.zeros(self.head_dim, dtype=torch.float32).normal_(mean=0, std=0.1)))
 
+    def arena_groups(self):
+        return [[self.q_proj.weight, self.k_proj.weight, self.v_proj.weight]]
+
+    def _merged_qkv(self):
+        """[3, E, E] alias of the q / k / v weights when a ParamArena laid them out back to back (arena_groups), else None"""
+        Wm = getattr(self, "_wqkv", None)
+        if Wm is None or Wm.data_ptr() != self.q_proj.weight.data_ptr():
+            Wm = ops.merged_param([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight])
+            self._wqkv = Wm
+        return Wm
+
     def forward(self, x, rel_pos=None, attn_mask=None):
         if rel_pos is not None or attn_mask is not None:
             raise NotImplementedError
-        q, x = ops.linear(x, self.q_proj.weight, tap=True)  # (taps: the three data gradients add up inside the GEMMs)
-        k, x = ops.linear(x, self.k_proj.weight, tap=True)
-        v = ops.linear(x, self.v_proj.weight)
+        Wm = self._merged_qkv()
+        if Wm is not None:  # the three projections as one batched launch per pass (weights back to back in the ParamArena)
+            ops.refresh_member_shadows(Wm, x)
+            q, k, v = ops.multi_linear(x, Wm)
+        else:
+            q, x = ops.linear(x, self.q_proj.weight, tap=True)  # (taps: the three data gradients add up inside the GEMMs)
+            k, x = ops.linear(x, self.k_proj.weight, tap=True)
+            v = ops.linear(x, self.v_proj.weight)
         U = ops.diff_attention_heads(q, k, v, self.num_heads)  # [B, 2H, N, 2hd], two softmaxes per head, tiled
         a = ops.diff_attention_combine(U, self.lambda_q1, self.lambda_k1, self.lambda_q2, self.lambda_k2, self.lambda_init)
         return ops.linear(a, self.out_proj.weight)

@@ -265,6 +265,63 @@ def linear(x, W, b=None, resid=None, bscale=None, split_k=False, tap=False):
 # =====================================================================================================
 # 1x1 convolution on NCHW (cfam.py:149,158,299,302; nlb.py:106-115,142; blocks.py:178,320; dseb.py:164)
 # =====================================================================================================
+class MultiLinearFn(Function):
+    """(x W_0^T, x W_1^T, ...) for n equally shaped bias-free weights joined by ops.merged_param into W [n, N, K]: the q / k / v
+    projections of multihead_diffattn.py:79-81 as ONE launch per pass — forward and weight gradient as a batched GEMM over
+    the n weights, the data gradient as one GEMM with n K-batches (when the incoming gradients sit back to back in memory,
+    as DiffAttnHeadsFn returns them; otherwise n GEMMs chained through the residual operand)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x = _c(x)
+        n, N, K = W.shape[:3]
+        R = x.numel() // K
+        Y = _act((n,) + tuple(x.shape[:-1]) + (N,), x)
+        kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(kern.wq(W, x), 1, K, sb=N * K, kfast=1), Y, R, N, K, scr=N, scc=1,
+                  scb=R * N, nbatch=n)
+        ctx.save_for_backward(x, W)
+        ctx.refs = (W,)
+        return tuple(Y[j] for j in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x, W = ctx.saved_tensors
+        Wp, = ctx.refs
+        n, N, K = W.shape[:3]
+        R = x.numel() // K
+        gs = [_c(g) if g is not None else torch.zeros(x.shape[:-1] + (N,), device=x.device, dtype=x.dtype) for g in gs]
+        esz = gs[0].element_size()
+        joint = all(g.data_ptr() == gs[0].data_ptr() + j * R * N * esz for j, g in enumerate(gs))
+        dW = grad_buf(Wp)
+        if dW is not None:
+            with _wgrad_side(x, *gs):
+                iters = (R + 31) // 32
+                if joint:
+                    kern.gemm(kern.mat_plain(gs[0], 1, N, sb=R * N, kfast=0), kern.mat_plain(x, K, 1, kfast=0), dW, N, K, R,
+                              scr=K, scc=1, scb=N * K, nbatch=n, splits=kern.pick_splits(N, K, n, iters), atomic=True)
+                else:
+                    for j, g in enumerate(gs):
+                        kern.gemm(kern.mat_plain(g, 1, N, kfast=0), kern.mat_plain(x, K, 1, kfast=0), dW, N, K, R, scr=K, scc=1,
+                                  splits=kern.pick_splits(N, K, 1, iters), atomic=True, c_offset=j * N * K)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            Wq = kern.wq(Wp, x)
+            if joint:
+                kern.gemm(kern.mat_plain(gs[0], N, 1, skb=R * N, kfast=1), kern.mat_plain(Wq, K, 1, skb=N * K, kfast=0), dx, R, K, N,
+                          scr=K, scc=1, nkb=n)
+            else:
+                for j, g in enumerate(gs):
+                    kern.gemm(kern.mat_plain(g, N, 1, kfast=1), kern.mat_plain(Wq, K, 1, kfast=0, offset=j * N * K), dx, R, K, N,
+                              scr=K, scc=1, R=(dx if j else None), srr=K, src=1)
+        return dx, None
+
+
+def multi_linear(x, W):
+    """W [n, N, K] (ops.merged_param of n bias-free Linear weights): returns the n products x W_j^T"""
+    return MultiLinearFn.apply(x, W)
+
+
 class Conv1x1Fn(Function):
     """y[b] = W x[b] + bias + resid ; x [B, Cin, *spatial] contiguous.  tap: as in LinearFn (theta / phi / g of nlb.py:117-119
     and the gate / value / shortcut consumers in cfam.py read one tensor)."""
@@ -1016,7 +1073,10 @@ class DiffAttnHeadsFn(Function):
         if ctx.pairs:
             H = ctx.H
             lse = saved_list[0]
-            dq, dk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            # one buffer for the three gradients: MultiLinearFn (the batched q / k / v projection) then runs its data gradient
+            # as ONE GEMM with three K-batches
+            dqkv = torch.empty((3,) + tuple(q.shape), device=q.device, dtype=q.dtype)
+            dq, dk, dvv = dqkv[0], dqkv[1], dqkv[2]
             ws = torch.empty(kern.diffattn_heads_ws_bytes(B, H, N), device=q.device, dtype=torch.uint8)
             a = kern.DiffAttnT()
             a.q, a.k, a.v, a.U, a.lse, a.dU = q.data_ptr(), k.data_ptr(), v.data_ptr(), U.data_ptr(), lse.data_ptr(), g.data_ptr()

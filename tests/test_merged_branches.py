@@ -85,3 +85,34 @@ def test_arena_groups_layout(dev):  # noqa: F811
     mod.load_state_dict(sd)
     assert torch.equal(mg["pw"][1].reshape(-1).cpu(), (sd["dlps.1.pointwise.weight"]).reshape(-1).cpu())
     assert torch.equal(mg["dbn_running_mean"][2].cpu(), sd["dlps.2.depthwise_bn.running_mean"].cpu())
+
+
+@pytest.mark.parametrize("E,H,N,bf16", [(64, 2, 40, False), (64, 2, 40, True), (128, 4, 70, True)])
+def test_merged_qkv_projection(dev, E, H, N, bf16):  # noqa: F811
+    """MultiheadDiffAttn with its q / k / v projections as one batched launch per pass (weights back to back in a ParamArena,
+    ops.multi_linear) against the same module running three Linear ops; reference: modules/multihead_diffattn.py:79-81.
+    fp32 tensors: the attention backward returns separate gradients (the chained data-gradient path); bf16: one buffer (the
+    K-batched GEMM)."""
+    from cenet_amd.networks.cenet.modules.multihead_diffattn import MultiheadDiffAttn
+    torch.manual_seed(E + N)
+    old = kern.set_compute_bf16(bf16)
+    try:
+        ref = MultiheadDiffAttn(E, depth=1, num_heads=H).to(dev).train()
+        mer = copy.deepcopy(ref)
+        ref.arena_groups = lambda: []
+        ref._merged_qkv = lambda: None
+        a_ref, a_mer = optim.ParamArena(ref), optim.ParamArena(mer)
+        assert mer._merged_qkv() is not None
+        dt = torch.bfloat16 if bf16 else torch.float32
+        x = torch.randn(2, N, E, device=dev).to(dt)
+        g = torch.randn(2, N, E, device=dev).to(dt)
+        r, m = _run(ref, a_ref, x, g, steps=1), _run(mer, a_mer, x, g, steps=1)
+        tol = 3e-2 if bf16 else 2e-5
+        (yr, dxr, _), (ym, dxm, _) = r[0], m[0]
+        assert (yr - ym).abs().max() <= tol * max(1.0, yr.abs().max().item())
+        assert (dxr - dxm).abs().max() <= tol * max(1.0, dxr.abs().max().item())
+        for (n, pr), (_, pm) in zip(ref.named_parameters(), mer.named_parameters()):
+            gr, gm = pr.grad.float(), pm.grad.float()
+            assert (gr - gm).abs().max() <= tol * max(1.0, gr.abs().max().item()), n
+    finally:
+        kern.set_compute_bf16(old)
