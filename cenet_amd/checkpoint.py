@@ -31,7 +31,8 @@ def save_training_state(path: str, net: torch.nn.Module, optimizer=None, schedul
     state = {"model": {k: v.detach().cpu() for k, v in net.state_dict().items()}}
     if optimizer is not None:
         osd = optimizer.state_dict()
-        state["optimizer"] = {"buf": osd["buf"].detach().cpu(), "steps": int(osd["steps"]), "lr": float(osd["lr"])}
+        state["optimizer"] = {"momentum": {n: v.detach().cpu() for n, v in osd["momentum"].items()}, "steps": int(osd["steps"]),
+                              "lr": float(osd["lr"])}
     if scheduler is not None:
         state["scheduler"] = {"last_epoch": int(scheduler.last_epoch), "base_lr": float(scheduler.base_lr)}
     if extra:
@@ -45,7 +46,7 @@ def load_training_state(path: str, net: torch.nn.Module, optimizer=None, schedul
     net.load_state_dict(state["model"], strict=True)
     if optimizer is not None and "optimizer" in state:
         o = state["optimizer"]
-        optimizer.load_state_dict({"buf": o["buf"].to(optimizer.buf.device), "steps": o["steps"], "lr": o["lr"]})
+        optimizer.load_state_dict(o)
     if scheduler is not None and "scheduler" in state:
         scheduler.last_epoch = state["scheduler"]["last_epoch"]
         scheduler.base_lr = state["scheduler"]["base_lr"]

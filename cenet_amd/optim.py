@@ -187,10 +187,24 @@ class FusedSGD:
         self._sync_hyper()
 
     def state_dict(self):
-        return {"buf": self.buf, "steps": self._steps, "lr": self.lr}
+        """momentum per parameter NAME (`momentum`: name -> tensor): the flat arena layout (segments, arena groups, padding) is
+        an implementation detail that may differ between the run that saved and the run that loads"""
+        idx = self.arena.index
+        return {"momentum": {n: self.buf[o:o + k].detach().clone() for n, (o, k) in idx.items()}, "steps": self._steps,
+                "lr": self.lr}
 
     def load_state_dict(self, sd):
-        self.buf.copy_(sd["buf"])
+        if "momentum" in sd:
+            idx = self.arena.index
+            missing = [n for n in idx if n not in sd["momentum"]]
+            if missing:
+                raise KeyError(f"momentum missing for parameters {missing[:5]}")
+            for n, (o, k) in idx.items():
+                self.buf[o:o + k].copy_(sd["momentum"][n].reshape(-1).to(self.buf.device))
+        else:  # flat buffer of an older file: only valid for the identical arena layout
+            if sd["buf"].numel() != self.buf.numel():
+                raise ValueError("flat momentum buffer of a different arena layout; re-save the training state")
+            self.buf.copy_(sd["buf"])
         self._steps, self.lr = sd["steps"], sd["lr"]
 
 
