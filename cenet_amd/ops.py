@@ -61,8 +61,9 @@ def grad_buf(p: Optional[Tensor]) -> Optional[Tensor]:
     return p.grad
 
 
-def merged_param(ps):
-    """[p_0 | p_1 | ...] as ONE tensor of shape [n, *p.shape] if the equally shaped parameters `ps` lie back to back in a
+def merged_param(ps, flat=False):
+    """[p_0 | p_1 | ...] as ONE tensor of shape [n, *p.shape] (flat: [n * p.shape[0], *p.shape[1:]], the members stacked along
+    their first axis) if the equally shaped parameters `ps` lie back to back in a
     ParamArena (its `arena_groups` layout), else None.  The result aliases the parameters' memory, its `.grad` aliases
     their gradient slots and its bf16 shadow their shadow slots, so the kernels (and ops.grad_buf / kern.wq) treat it like
     a parameter; nothing is registered anywhere and the optimizer keeps seeing the flat arena."""
@@ -76,7 +77,7 @@ def merged_param(ps):
         sj = getattr(q, "_cenet_arena_slot", None)
         if sj is None or sj[0] is not arena or sj[1] != o + j * n or q.data_ptr() != arena.params.data_ptr() + 4 * (o + j * n):
             return None
-    shape = (len(ps),) + tuple(p0.shape)
+    shape = ((len(ps) * p0.shape[0],) + tuple(p0.shape[1:])) if flat else ((len(ps),) + tuple(p0.shape))
     m = arena.params[o:o + len(ps) * n].view(shape).detach()
     m.requires_grad_(True)
     m.grad = arena.grads[o:o + len(ps) * n].view(shape)
@@ -1122,6 +1123,72 @@ def sr_attention(q, kv, heads):
 
 def nonlocal_attention(theta, phi, g):
     return NonlocalAttnFn.apply(theta, phi, g)
+
+
+class NonlocalAttnJointFn(Function):
+    """NonlocalAttnFn on theta | phi | g as the three channel thirds of ONE tensor [B, 3C, N] (the output of the single 1x1
+    conv that ops.merged_param makes of conv_theta / conv_phi / conv_g, nlb.py:117-119): the kernels read the thirds in
+    place (batch stride 3C N, element offsets 0 / C N / 2 C N) and write the three gradients into one [B, 3C, N] tensor, so
+    that conv's backward is one data-gradient and one weight-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, tpg):
+        tpg = _c(tpg)
+        B, C3 = tpg.shape[:2]
+        Cn = C3 // 3
+        N = tpg.numel() // (B * C3)
+        ctx.tok64 = _bf(tpg) and Cn == 64 and N >= 256
+        ctx.dims = (B, Cn, N, tuple(tpg.shape))
+        oshape = (B, Cn) + tuple(tpg.shape[2:])
+        if ctx.tok64:
+            qt, kt, vt = (torch.empty((B, N, Cn), device=tpg.device, dtype=tpg.dtype) for _ in range(3))
+            for j, dst in enumerate((qt, kt, vt)):
+                kern.transpose(tpg, 3 * Cn * N, dst, Cn * N, B, Cn, N, x_off=j * Cn * N)
+            U = torch.empty((B, 1, N, Cn), device=tpg.device, dtype=tpg.dtype)
+            lse = torch.empty((B, 1, N), device=tpg.device, dtype=torch.float32)
+            a = kern.DiffAttnT()
+            a.q, a.k, a.v, a.U, a.lse = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr()
+            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, 64, Cn ** -0.5
+            kern.attn64(a, backward=False)
+            o = torch.empty(oshape, device=tpg.device, dtype=tpg.dtype)
+            kern.transpose(U, N * Cn, o, Cn * N, B, N, Cn)
+            ctx.save_for_backward(qt, kt, vt, U, lse)
+            return o
+        st, so = (3 * Cn * N, 0, 1, N), (Cn * N, 0, 1, N)
+        d = _AttnDesc(B, 1, N, N, Cn, Cn, Cn ** -0.5, 1, st, st, st, so, qoff=0, koff=Cn * N, voff=2 * Cn * N)
+        o = torch.empty(oshape, device=tpg.device, dtype=tpg.dtype)
+        kind, saved = _attn_forward(d, tpg, tpg, tpg, o)
+        ctx.save_for_backward(tpg, o, saved)
+        ctx.d, ctx.kind = d, kind
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        B, Cn, N, shape = ctx.dims
+        dj = torch.empty(shape, device=g.device, dtype=g.dtype)
+        if ctx.tok64:
+            qt, kt, vt, U, lse = ctx.saved_tensors
+            gt = torch.empty_like(U)
+            kern.transpose(g, Cn * N, gt, N * Cn, B, Cn, N)
+            dq, dk, dv = torch.empty_like(qt), torch.empty_like(kt), torch.empty_like(vt)
+            ws = torch.empty(kern.attn64_ws_bytes(B, 1, N), device=g.device, dtype=torch.uint8)
+            a = kern.DiffAttnT()
+            a.q, a.k, a.v, a.U, a.lse, a.dU = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr(), gt.data_ptr()
+            a.dq, a.dk, a.dv, a.ws = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr()
+            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, 64, Cn ** -0.5
+            kern.attn64(a, backward=True)
+            for j, src in enumerate((dq, dk, dv)):
+                kern.transpose(src, N * Cn, dj, 3 * Cn * N, B, N, Cn, y_off=j * Cn * N)
+            return dj
+        tpg, o, saved = ctx.saved_tensors
+        _attn_backward(ctx.d, ctx.kind, saved, tpg, tpg, tpg, o, g, dj, dj, dj)
+        return dj
+
+
+def nonlocal_attention_joint(tpg):
+    """tpg [B, 3C, ...]: theta | phi | g stacked along the channel axis"""
+    return NonlocalAttnJointFn.apply(tpg)
 
 
 def diff_attention_heads(q, k, v, H):

@@ -116,3 +116,35 @@ def test_merged_qkv_projection(dev, E, H, N, bf16):  # noqa: F811
             assert (gr - gm).abs().max() <= tol * max(1.0, gr.abs().max().item()), n
     finally:
         kern.set_compute_bf16(old)
+
+
+@pytest.mark.parametrize("C,hw,bf16", [(64, 7, False), (64, 16, True), (128, 7, True), (32, 5, False)])
+def test_merged_nonlocal_projections(dev, C, hw, bf16):  # noqa: F811
+    """Nonlocal with conv_theta / conv_phi / conv_g as ONE 1x1 conv whose [B, 3C, N] output the attention reads in place
+    (ops.nonlocal_attention_joint) against the three-conv path; reference: modules/nlb.py:102-148.  C = 64 with 256 tokens
+    takes the token-major pair kernels (bf16), the others the tiled / materialised paths."""
+    from cenet_amd.networks.cenet.modules.nlb import Nonlocal
+    torch.manual_seed(C + hw)
+    old = kern.set_compute_bf16(bf16)
+    try:
+        ref = Nonlocal(C).to(dev).train()
+        with torch.no_grad():
+            ref.bn.weight.uniform_(0.5, 1.5)  # (zero-initialised in the reference: would hide the attention branch)
+        mer = copy.deepcopy(ref)
+        ref.arena_groups = lambda: []
+        ref._merged_tpg = lambda: None
+        a_ref, a_mer = optim.ParamArena(ref), optim.ParamArena(mer)
+        assert mer._merged_tpg() is not None
+        dt = torch.bfloat16 if bf16 else torch.float32
+        x = torch.randn(2, C, hw, hw, device=dev).to(dt)
+        g = torch.randn(2, C, hw, hw, device=dev).to(dt)
+        r, m = _run(ref, a_ref, x, g, steps=1), _run(mer, a_mer, x, g, steps=1)
+        tol = 4e-2 if bf16 else 3e-5
+        (yr, dxr, _), (ym, dxm, _) = r[0], m[0]
+        assert (yr - ym).abs().max() <= tol * max(1.0, yr.abs().max().item())
+        assert (dxr - dxm).abs().max() <= tol * max(1.0, dxr.abs().max().item())
+        for (n, pr), (_, pm) in zip(ref.named_parameters(), mer.named_parameters()):
+            gr, gm = pr.grad.float(), pm.grad.float()
+            assert (gr - gm).abs().max() <= tol * max(1.0, gr.abs().max().item()), n
+    finally:
+        kern.set_compute_bf16(old)
