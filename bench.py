@@ -413,9 +413,15 @@ def main():
     launch_note = None
     # N == 1, auto: eager launches are host-bound (~1.3 k C-ABI calls of ~20 us of Python + ctypes each) and replay is not,
     # so which one is faster depends on the host; a few steps of each decide.  (N > 1: next block.)
+    # The weight-gradient stream pays off for EAGER launches (its kernels fill the gaps the host leaves) and costs under
+    # replay: a captured second stream becomes extra hardware queues whose kernels share the chip with the main chain instead
+    # of filling idle CUs, and the cross-queue dependencies cost ~6 % of the step (measured: 1 198 vs 1 273 images/s).  The
+    # graphs are therefore captured with the weight gradients on the main stream; eager steps keep the second stream.
+    overlap_eager = not a.no_overlap
     if not use_dist and a.graph != "off":
         from cenet_amd.graph import GraphedStep
         try:
+            ops.set_wgrad_overlap(False)
             graphed = GraphedStep(lambda: body(sync_hyper=False), optimizer=opt, warmup=2)
         except Exception as e:  # capture is an optimisation: fall back to eager launches of the same kernels
             if a.graph == "on":
@@ -423,12 +429,15 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             graphed = None
             torch.cuda.synchronize()
+        finally:
+            ops.set_wgrad_overlap(overlap_eager)
         if graphed is not None and a.graph == "auto":
             for _ in range(2):
                 body()
                 graphed()
             t_e, t_g = _time_steps(body, 4), _time_steps(graphed, 4)
-            launch_note = f"auto: eager {t_e * 1e3:.1f} ms vs hipGraph replay {t_g * 1e3:.1f} ms over 4 untimed steps each"
+            launch_note = (f"auto: eager (weight gradients on a second stream) {t_e * 1e3:.1f} ms vs hipGraph replay (one stream) "
+                           f"{t_g * 1e3:.1f} ms over 4 untimed steps each")
             HOLD_MS[0] = min(80.0, max(20.0, 1.25 * t_e * 1e3))
             if t_e <= t_g:
                 graphed = None
@@ -440,6 +449,7 @@ def main():
         from cenet_amd.graph import GraphedSplitStep
         try:
             parallel.attach(net, None)  # no hooks inside the capture: finish() reduces every segment
+            ops.set_wgrad_overlap(False)
             cand = GraphedSplitStep(fwd_bwd, opt, reducer.finish, warmup=2)
         except Exception as e:
             if a.graph == "on":
@@ -447,6 +457,8 @@ def main():
             print(f"[bench] split hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             cand = None
             torch.cuda.synchronize()
+        finally:
+            ops.set_wgrad_overlap(overlap_eager)
         okf = torch.tensor([1.0 if cand is not None else 0.0], device=dev)
         dist.all_reduce(okf, op=dist.ReduceOp.MIN)  # all ranks or none (the timing loops below contain barriers)
         if okf.item() < 1.0:
