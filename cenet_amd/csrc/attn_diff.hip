@@ -946,6 +946,127 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Spatial-reduction attention FORWARD with the key / value set resident (same problem class as sra_bwd_kernel: head dimension
+// 64, at most 64 keys): no key loop and no online softmax — a wave takes 32-query tiles, S^T = K Q^T for both key tiles in one
+// go, the softmax over the <= 64 keys of a query is 32 registers + one exchange with lane ^ 32, and O^T = V^T P^T.  The streamed
+// kernel (attn_bf16.hip, flashc_fwd) spent ~20 us per launch on 13-26 MB; this one is bound by reading q and writing o.
+// q, o [B, Nq, 64 H]; kv [B, Nk, 128 H]; lse [B, H, Nq] = natural log of the sum of exp(scale * scores) (what the backward
+// kernels expect).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct SraFwdArgs {
+  const bf *q, *kv;
+  bf* o;
+  float* lse;
+  int B, H, Nq, Nk, C, tiles;
+  float scale;
+};
+
+__global__ __launch_bounds__(256, 2) void sra_fwd_kernel(SraFwdArgs a) {
+  constexpr int KP = 72, KVIMG = 64 * KP;
+  __shared__ __attribute__((aligned(16))) bf lds[2 * KVIMG + 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const cenet_bid bid = cenet_xcd_block();
+  const int b = bid.y / a.H, h = bid.y - b * a.H;
+  const int C = a.C, Nq = a.Nq, Nk = a.Nk;
+  const float c = a.scale * DA_LOG2E;
+  const bf* qb = a.q + (long)b * Nq * C + h * 64;
+  bf* ob = a.o + (long)b * Nq * C + h * 64;
+  const bf* kb = a.kv + (long)b * Nk * 2 * C + h * 64;
+  const bf* vb = kb + C;
+  bf* Kimg = lds;
+  bf* Vimg = lds + KVIMG;
+  for (int id = tid; id < 2 * 64 * 8; id += 256) {
+    const int which = id >> 9, rem = id & 511, row = rem >> 3, c8 = rem & 7;
+    unsigned v4[4] = {0u, 0u, 0u, 0u};
+    if (row < Nk) memcpy(v4, (which ? vb : kb) + (long)row * 2 * C + 8 * c8, 16);
+    memcpy((which ? Vimg : Kimg) + row * KP + 8 * c8, v4, 16);
+  }
+  __syncthreads();
+  const int q00 = (bid.x * 4 + wave) * 32 * a.tiles;
+  for (int t = 0; t < a.tiles; ++t) {
+    const int q0 = q00 + 32 * t;
+    if (q0 >= Nq) break;  // (wave-uniform)
+    const int qi = q0 + r < Nq ? q0 + r : Nq - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = da_ld8(qb + (long)qi * C + 16 * ks + 8 * hh, true);
+    f32x16 S[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      S[kt] = da_zero();
+      if (32 * kt < Nk) {  // (uniform)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) S[kt] = DA_MFMA(da_rm(Kimg + 32 * kt * KP, KP, r, 16 * ks, hh), qf[ks], S[kt]);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (32 * kt + da_row(i, hh) >= Nk) S[kt][i] = DA_NEG;
+    }
+    float mx = DA_NEG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, S[kt][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mc = mx * c;
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = da_exp2(S[kt][i] * c - mc);  // masked keys: exp2(-huge) = 0
+        S[kt][i] = pv;
+        l += pv;
+      }
+    l += __shfl_xor(l, 32);
+    f32x16 O[2] = {da_zero(), da_zero()};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (32 * kt >= Nk) continue;
+      const bf* Vt = Vimg + 32 * kt * KP;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pB = da_pack8(S[kt], s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) O[dt] = DA_MFMA(da_tr(Vt, KP, s2, 32 * dt, lane), pB, O[dt]);
+      }
+    }
+    if (q0 + r < Nq) {
+      const float inv = 1.f / l;
+      bf* op = ob + (long)qi * C;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float o4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o4[i] = O[dt][4 * g + i] * inv;
+          st4v(op + 32 * dt + 8 * g + 4 * hh, o4);
+        }
+      if (hh == 0) a.lse[((long)b * a.H + h) * Nq + qi] = mx * a.scale + logf(l);
+    }
+  }
+}
+
+extern "C" int cenet_sra_attn_fwd_bf16(const bf* q, const bf* kv, bf* o, float* lse, int B, int H, int Nq, int Nk, float scale,
+                                       hipStream_t stream) {
+  if (!q || !kv || !o || !lse || B <= 0 || H <= 0 || Nq <= 0) return CENET_EINVAL;
+  if (!(Nk >= 1 && Nk <= 64)) return CENET_EUNSUPPORTED;
+  if ((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o) & 15) != 0) return CENET_EINVAL;
+  SraFwdArgs a;
+  a.q = q; a.kv = kv; a.o = o; a.lse = lse; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.C = 64 * H; a.scale = scale;
+  // two workgroups per CU: ~512 workgroups fill the chip once
+  static const char* e = getenv("CENET_SRA_FWD_TILES");  // measurement aid
+  int tiles = 1;
+  while (tiles < 8 && (long)cdiv(Nq, 128 * tiles) * B * H > 1024) ++tiles;
+  if (e) tiles = atoi(e);
+  a.tiles = tiles < 1 ? 1 : tiles;
+  CENET_LAUNCH(sra_fwd_kernel, dim3(cdiv(Nq, 128 * a.tiles), B * H), dim3(256), stream, a);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
 extern "C" int cenet_sra_attn_bwd_supported(int hd, int Nk) { return hd == 64 && Nk >= 1 && Nk <= 64; }
 
 // 32-query tiles per wave: the kernel runs one workgroup per CU (484 registers), so more than 256 workgroups is a second

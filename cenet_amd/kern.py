@@ -250,6 +250,14 @@ def sra_attn_bwd_supported(hd: int, Nk: int) -> bool:
     return bool(_lib.lib().cenet_sra_attn_bwd_supported(int(hd), int(Nk)))
 
 
+def sra_attn_fwd(q, kv, o, lse, B, H, Nq, Nk, scale):
+    """spatial-reduction attention forward with resident keys (bf16, head dim 64, <= 64 keys): o and the natural-log lse"""
+    _chk(q, kv, o, lse)
+    assert q.dtype == BF16 and kv.dtype == BF16 and o.dtype == BF16 and lse.dtype == torch.float32
+    rc = _lib.lib().cenet_sra_attn_fwd_bf16(P(q), P(kv), P(o), P(lse), B, H, Nq, Nk, C.c_float(scale), stream())
+    _lib.check(rc, "cenet_sra_attn_fwd_bf16")
+
+
 def sra_attn_bwd(q, kv, o, dout, lse, dq, dkv, B, H, Nq, Nk, scale):
     """fused spatial-reduction attention backward (bf16, head dim 64, <= 64 keys); dkv: fp32, zero-filled"""
     _chk(q, kv, o, dout, lse, dq, dkv)

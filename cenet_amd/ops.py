@@ -933,7 +933,14 @@ class SRAttentionFn(Function):
         d = _AttnDesc(B, heads, N, Nk, hd, hd, hd ** -0.5, 1, (N * Cn, hd, Cn, 1), (Nk * 2 * Cn, hd, 2 * Cn, 1),
                       (Nk * 2 * Cn, hd, 2 * Cn, 1), (N * Cn, hd, Cn, 1), voff=Cn)
         o = torch.empty_like(q)
-        kind, saved = _attn_forward(d, q, kv, kv, o)
+        if _bf(q) and kern.sra_attn_bwd_supported(hd, Nk):
+            # bf16, 64-dim heads, <= 64 keys: keys / values resident, no key loop (attn_diff.hip, sra_fwd_kernel); the lse it
+            # leaves is the tiled kernels' (kind "flash": the backward below does not care which forward ran)
+            saved = _empty((B, heads, N), q)
+            kern.sra_attn_fwd(q, kv, o, saved, B, heads, N, Nk, d.scale)
+            kind = "flash"
+        else:
+            kind, saved = _attn_forward(d, q, kv, kv, o)
         ctx.save_for_backward(q, kv, o, saved)
         ctx.d, ctx.kind = d, kind
         return o
