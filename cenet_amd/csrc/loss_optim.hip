@@ -14,32 +14,33 @@
 
 // acc layout: [0..K) intersect, [K..2K) z_sum (p^2), [2K..3K) y_sum (t), [3K] ce_sum, [3K+1..4K+1) boundary pixel counts
 // (BoundaryDoULoss, core.py:105-109), and after finalize [4K+1..5K+1) the per-class alpha of core.py:112-119
-template <typename T>
+// KM: compile-time bound of the class loops (4 / 9 / 16: the predicated 16-way loops cost 4x the work at K = 4)
+template <typename T, int KM>
 __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ labels,
                                                          float* __restrict__ acc, int K, int HW, long npix, int W,
                                                          int boundary) {
   __shared__ float red[16];
-  float part[3 * LOSS_MAXK + 1], bnd[LOSS_MAXK];
+  float part[3 * KM + 1], bnd[KM];
 #pragma unroll
-  for (int i = 0; i < 3 * LOSS_MAXK + 1; ++i) part[i] = 0.f;
+  for (int i = 0; i < 3 * KM + 1; ++i) part[i] = 0.f;
 #pragma unroll
-  for (int i = 0; i < LOSS_MAXK; ++i) bnd[i] = 0.f;
+  for (int i = 0; i < KM; ++i) bnd[i] = 0.f;
   const int H = HW / W;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
     const long b = e / HW;
     const int p = (int)(e - b * HW);
     const T* lp = logits + b * (long)K * HW + p;
-    float v[LOSS_MAXK];
+    float v[KM];
     float mx = -3.4e38f;
 #pragma unroll
-    for (int c = 0; c < LOSS_MAXK; ++c)
+    for (int c = 0; c < KM; ++c)
       if (c < K) {
         v[c] = ldf(lp + (long)c * HW);
         mx = fmaxf(mx, v[c]);
       }
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < LOSS_MAXK; ++c)
+    for (int c = 0; c < KM; ++c)
       if (c < K) {
         v[c] = expf(v[c] - mx);
         s += v[c];
@@ -54,23 +55,23 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const T* __restrict__ 
                px + 1 < W && (int)lb[p + 1] == t);
     }
 #pragma unroll
-    for (int c = 0; c < LOSS_MAXK; ++c)
+    for (int c = 0; c < KM; ++c)
       if (c < K) {
         if (c == t && edge) bnd[c] += 1.f;
         const float pc = v[c] * inv;
-        part[LOSS_MAXK + c] += pc * pc;
+        part[KM + c] += pc * pc;
         if (c == t) {
           part[c] += pc;
-          part[2 * LOSS_MAXK + c] += 1.f;
-          part[3 * LOSS_MAXK] -= logf(fmaxf(pc, 1e-37f));
+          part[2 * KM + c] += 1.f;
+          part[3 * KM] -= logf(fmaxf(pc, 1e-37f));
         }
       }
   }
   float* slot = acc + (blockIdx.x % LOSS_SLOTS) * LOSS_SLOT_STRIDE;
 #pragma unroll  // static indices: part[] must stay in registers
-  for (int c = 0; c < LOSS_MAXK; ++c)
+  for (int c = 0; c < KM; ++c)
     if (c < K) {
-      float a0 = block_sum(part[c], red), a1 = block_sum(part[LOSS_MAXK + c], red), a2 = block_sum(part[2 * LOSS_MAXK + c], red);
+      float a0 = block_sum(part[c], red), a1 = block_sum(part[KM + c], red), a2 = block_sum(part[2 * KM + c], red);
       const float a3 = boundary ? block_sum(bnd[c], red) : 0.f;
       if (threadIdx.x == 0) {
         atomicAdd(&slot[c], a0);
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const T* __restrict__ 
         if (boundary) atomicAdd(&slot[3 * K + 1 + c], a3);
       }
     }
-  float ce = block_sum(part[3 * LOSS_MAXK], red);
+  float ce = block_sum(part[3 * KM], red);
   if (threadIdx.x == 0) atomicAdd(&slot[3 * K], ce);
 }
 
@@ -106,15 +107,15 @@ __global__ void dice_ce_finalize_kernel(float* __restrict__ acc, float* __restri
   }
 }
 
-template <typename T>
+template <typename T, int KM>
 __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ labels,
                                                          const float* __restrict__ acc, const float* __restrict__ gout,
                                                          T* __restrict__ dlogits, int K, int HW, long npix, float w_dice,
                                                          float w_ce, float w_bd) {
   const float go = gout[0];
-  float A[LOSS_MAXK], Bc[LOSS_MAXK];  // dL/dp_c = A_c * t_c + Bc_c * p_c
+  float A[KM], Bc[KM];  // dL/dp_c = A_c * t_c + Bc_c * p_c
 #pragma unroll
-  for (int c = 0; c < LOSS_MAXK; ++c)
+  for (int c = 0; c < KM; ++c)
     if (c < K) {
       const float I = acc[c], zy = acc[K + c] + acc[2 * K + c];
       const float D = zy + 1e-5f;
@@ -134,34 +135,34 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const T* __restrict__ 
     const int p = (int)(e - b * HW);
     const T* lp = logits + b * (long)K * HW + p;
     T* dp = dlogits + b * (long)K * HW + p;
-    float v[LOSS_MAXK];
+    float v[KM];
     float mx = -3.4e38f;
 #pragma unroll
-    for (int c = 0; c < LOSS_MAXK; ++c)
+    for (int c = 0; c < KM; ++c)
       if (c < K) {
         v[c] = ldf(lp + (long)c * HW);
         mx = fmaxf(mx, v[c]);
       }
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < LOSS_MAXK; ++c)
+    for (int c = 0; c < KM; ++c)
       if (c < K) {
         v[c] = expf(v[c] - mx);
         s += v[c];
       }
     const float inv = 1.f / s;
     const int t = (int)labels[e];
-    float gp[LOSS_MAXK];
+    float gp[KM];
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < LOSS_MAXK; ++c)
+    for (int c = 0; c < KM; ++c)
       if (c < K) {
         v[c] *= inv;
         gp[c] = Bc[c] * v[c] + (c == t ? A[c] : 0.f);
         dot += gp[c] * v[c];
       }
 #pragma unroll
-    for (int c = 0; c < LOSS_MAXK; ++c)
+    for (int c = 0; c < KM; ++c)
       if (c < K) stf(dp + (long)c * HW, go * (v[c] * (gp[c] - dot) + cew * (v[c] - (c == t ? 1.f : 0.f))));
   }
 }
@@ -214,8 +215,10 @@ static int seg_loss_fwd_impl(const T* logits, const float* labels, float* acc, f
   const long npix = (long)B * HW;
   long blocks = (npix + 2047) / 2048;
   if (blocks > 1024) blocks = 1024;
-  CENET_LAUNCH((dice_ce_fwd_kernel<T>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W,
-               (int)(w_bd != 0.f));
+  const int bnd = (int)(w_bd != 0.f);
+  if (K <= 4) CENET_LAUNCH((dice_ce_fwd_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W, bnd);
+  else if (K <= 9) CENET_LAUNCH((dice_ce_fwd_kernel<T, 9>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W, bnd);
+  else CENET_LAUNCH((dice_ce_fwd_kernel<T, LOSS_MAXK>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W, bnd);
   CENET_LAUNCH(dice_ce_finalize_kernel, dim3(1), dim3(128), stream, acc, loss, K, (float)npix, w_dice, w_ce, w_bd);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
@@ -232,8 +235,9 @@ static int seg_loss_bwd_impl(const T* logits, const float* labels, const float* 
   const long npix = (long)B * HW;
   long blocks = (npix + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  CENET_LAUNCH((dice_ce_bwd_kernel<T>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW,
-               npix, w_dice, w_ce, w_bd);
+  if (K <= 4) CENET_LAUNCH((dice_ce_bwd_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix, w_dice, w_ce, w_bd);
+  else if (K <= 9) CENET_LAUNCH((dice_ce_bwd_kernel<T, 9>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix, w_dice, w_ce, w_bd);
+  else CENET_LAUNCH((dice_ce_bwd_kernel<T, LOSS_MAXK>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix, w_dice, w_ce, w_bd);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
