@@ -14,8 +14,9 @@ INSTRUMENTED steps and adds:
                    bracketed with HIP events on the stream it is launched on and grouped by the instance name the C-ABI
                    reports, spelled as rocprofv3 prints it; the attention kernels are bracketed per call): algorithmic
                    bytes and FLOPs of all its launches in one step / their summed duration, against the binding roof.
-                   `traffic` comes from the PMC passes recorded in profiles/r02_traffic.json (null when that file has no
-                   entry for the kernel).
+                   `traffic` = HBM bytes PER LAUNCH from the PMC passes recorded in profiles/r03_traffic.json (null when
+                   that file has no entry for the kernel); `top_kernels` = the three largest groups, same fields.
+  whole_step       the step's algorithmic FLOPs / bytes over the timed ms_per_step against the MFMA and HBM roofs.
   roofline_stages  every stage of SURVEY.md §8d (patch_embed1-4, block1-4, dec4..dec1, up3..up1, DSEB3..DSEB1, out.rb /
                    out.up / out.out): forward + backward time measured with HIP events in module hooks (weight gradients on
                    the main stream for this pass), against max(3 x fwd FLOPs / MFMA peak, 3 x boundary bytes / HBM peak).
@@ -116,8 +117,26 @@ class _Trace:
 
     def install(self):
         from cenet_amd import kern
-        self._saved = {n: getattr(kern, n) for n in ("gemm", "diffattn_heads", "attn64", "flash_fwd", "flash_bwd")}
+        self._saved = {n: getattr(kern, n) for n in ("gemm", "diffattn_heads", "attn64", "flash_fwd", "flash_bwd", "wgrad_group")}
         tr = self
+
+        def wgrad_group(probs, device, **kw):
+            """the grouped weight gradients, one call per kernel launch: the problems of one orientation in chunks of 56 (the
+            partition the library makes itself), K-slice kernel and fold kernel bracketed separately (phases 1 / 2)"""
+            for kf in (0, 1):
+                sel = [t for t in probs if t[12] == kf]
+                for c in range(0, len(sel), 56):
+                    chunk = sel[c:c + 56]
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    ev[0].record()
+                    need = tr._saved["wgrad_group"](chunk, device, phases=(1, 2), between=lambda: (ev[1].record(), ev[2].record()))
+                    ev[3].record()
+                    fl = sum(2.0 * t[8] * t[9] * t[10] * t[11] for t in chunk)
+                    # operands once (bf16) + the fp32 gradient tile read and written once
+                    by = sum(2.0 * t[10] * t[11] * (t[8] + t[9]) + 8.0 * t[8] * t[9] for t in chunk)
+                    tr.rows.append(("gemm_group_kernel<%s, %s>" % (("true",) * 2 if kf else ("false",) * 2), ev[0], ev[1], fl, by))
+                    if need:
+                        tr.rows.append(("gemm_group_fold_kernel", ev[2], ev[3], 0.0, 2.0 * 4.0 * need))
 
         def gemm(A, B, Cout, M, N, K, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -156,6 +175,7 @@ class _Trace:
                 return r
             return f
         kern.gemm = gemm
+        kern.wgrad_group = wgrad_group
         kern.diffattn_heads = wrap("diffattn_heads", lambda a, backward=False: "dattn_bwd_dq+dkv_kernel" if backward else "dattn_fwd_kernel", None)
         kern.attn64 = wrap("attn64", lambda a, backward=False: "dattn_bwd_dq+dkv_kernel<32, true>" if backward else "dattn_fwd_kernel<32, 1, 2, true>", None)
         kern.flash_fwd = wrap("flash_fwd", lambda a, bf=False: "flashc_fwd_kernel" if bf else "flash_fwd_kernel", False)
@@ -207,35 +227,44 @@ def roofline_block(body, steps=2):
     # length) on one entry, so its group competes with half its time
     def weight(kv):
         return kv[1][0] * (0.5 if "+" in kv[0] else 1.0)
-    name, (ms, n, fl, by) = max(g.items(), key=weight)
-    n //= steps
     peak = peak_tflops()
-    out = {"kernel": name, "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 5), "total_ms_per_step": round(ms, 3)}
-    if fl > 0:
-        t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)
-        if t_mfma >= t_hbm:
-            a = fl / (ms * 1e-3) / 1e12
-            out.update({"bound": "mfma", "achieved": round(a, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(a / peak, 4)})
-        else:
-            a = by / (ms * 1e-3) / 1e9
-            out.update({"bound": "hbm", "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(a / PEAK_HBM_GBS, 4)})
-        out["algorithmic_bytes_per_step"] = int(by)
-        out["algorithmic_flops_per_step"] = int(fl)
-    traffic, src = None, None
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        if name in rec:
-            traffic, src = rec[name]["hbm_bytes_per_launch"], rec[name]["source"]
-    except (OSError, ValueError, KeyError):
-        pass
-    out["traffic"] = traffic
-    if src:
-        out["traffic_source"] = src
+    traffic_rec = {}
+    for f in ("r03_traffic.json", "r02_traffic.json"):
+        try:
+            traffic_rec = json.load(open(os.path.join(ROOT, "profiles", f)))
+            break
+        except (OSError, ValueError):
+            continue
+
+    def entry(name, ms, n, fl, by):
+        n //= steps
+        out = {"kernel": name, "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 5), "total_ms_per_step": round(ms, 3)}
+        if fl > 0 or by > 0:
+            t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)
+            if t_mfma >= t_hbm:
+                a = fl / (ms * 1e-3) / 1e12
+                out.update({"bound": "mfma", "achieved": round(a, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(a / peak, 4)})
+            else:
+                a = by / (ms * 1e-3) / 1e9
+                out.update({"bound": "hbm", "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(a / PEAK_HBM_GBS, 4)})
+            out["algorithmic_bytes_per_launch"] = int(by / max(n, 1))
+            out["algorithmic_flops_per_launch"] = int(fl / max(n, 1))
+        rec = traffic_rec.get(name)
+        # HBM bytes per LAUNCH from the PMC passes of tools/refresh_profiles.sh (2 x FETCH_SIZE + WRITE_SIZE, separate passes);
+        # a committed measurement of this build on another box of the pool, not taken in this run
+        out["traffic"] = rec["hbm_bytes_per_launch"] if rec else None
+        if rec:
+            out["traffic_unit"] = "bytes per launch"
+            out["traffic_source"] = rec.get("source")
+        return out
+    ranked = sorted(g.items(), key=weight, reverse=True)
+    name, (ms, n, fl, by) = ranked[0]
+    out = entry(name, ms, n, fl, by)
     out["method"] = ("HIP events around every launch of this instance in %d instrumented steps (one stream, the stream parked behind a "
                      "spin kernel while the host queues the step, so intervals are kernel durations)" % steps)
-    fams = sorted(((k, v[0]) for k, v in g.items()), key=lambda kv: -kv[1])[:6]
-    out["next_kernels_ms_per_step"] = {k: round(v, 3) for k, v in fams[1:]}
+    out["top_kernels"] = [entry(k, *v) for k, v in ranked[:3]]
+    out["next_kernels_ms_per_step"] = {k: round(v[0], 3) for k, v in ranked[1:6]}
     return out
 
 
@@ -452,17 +481,19 @@ def main():
             ops.set_wgrad_overlap(False)
             cand = GraphedSplitStep(fwd_bwd, opt, reducer.finish, warmup=2)
         except Exception as e:
-            if a.graph == "on":
-                raise
-            print(f"[bench] split hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            print(f"[bench] split hipGraph capture failed on rank {rank} ({type(e).__name__}: {e})", file=sys.stderr)
             cand = None
             torch.cuda.synchronize()
         finally:
             ops.set_wgrad_overlap(overlap_eager)
+        # all ranks or none (the timing loops below contain barriers): EVERY rank reaches this collective, also one whose
+        # capture threw — with --graph on the failure is raised on all ranks only after they have agreed on it
         okf = torch.tensor([1.0 if cand is not None else 0.0], device=dev)
-        dist.all_reduce(okf, op=dist.ReduceOp.MIN)  # all ranks or none (the timing loops below contain barriers)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
         if okf.item() < 1.0:
             cand = None
+            if a.graph == "on":
+                raise SystemExit("--graph on: the split hipGraph capture failed on at least one rank")
         pick = torch.zeros(1, device=dev)
         if cand is not None:
             parallel.attach(net, reducer)
@@ -527,6 +558,17 @@ def main():
         if world == 1 and not a.no_roofline:
             out["roofline"] = roofline_block(body)
             out["roofline_stages"] = stage_block(net, body, B, cfg["size"])
+            # the whole step against both roofs (fwd + bwd = 3 x the forward contractions; stage-boundary tensors
+            # three times, parameters read twice and their gradient written once, the optimizer's three streams)
+            sf = (cfg["size"] / 224.0) ** 2
+            fl = 3.0 * sum(v[0] for v in STAGES.values()) * 1e9 * B * sf
+            es = 2 if a.dtype == "bf16" else 4
+            by = 3.0 * 9.42e6 * es * B * sf + arena.numel * (2 * es + 4 + 5 * 4)
+            t = ms * 1e-3
+            out["whole_step"] = {"flops": int(fl), "bytes": int(by), "tflops": round(fl / t / 1e12, 1),
+                                 "frac_mfma": round(fl / t / (peak_tflops() * 1e12), 4),
+                                 "gbs": round(by / t / 1e9, 1), "frac_hbm": round(by / t / (PEAK_HBM_GBS * 1e9), 4),
+                                 "ideal_ms": round(max(fl / (peak_tflops() * 1e12), by / (PEAK_HBM_GBS * 1e9)) * 1e3, 3)}
         if world == 1 and a.dtype == "bf16" and not a.no_f32:
             # the same step in the fp32 PARITY mode (fp32 tensors end to end: the mode the 1e-3 logit / 1e-4 Dice tests run in)
             kern.set_compute_bf16(False)

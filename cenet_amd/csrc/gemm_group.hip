@@ -1,0 +1,410 @@
+// gemm_group.hip — GROUPED weight-gradient GEMM (bf16 operands, fp32 accumulate into the gradient arena).
+//
+// The weight gradients of a training step, dW_i += dY_i^T X_i (Linear: pvtv2.py:41,45,60-63,90,98,106; 1x1 conv:
+// cfam.py:149,158,299,302, nlb.py:106-115,142, blocks.py:320, dseb.py:164), feed nothing but the optimizer.  Launched one by one
+// (round 2: ~150 launches per step, the `roofline` kernel of bench.py) each of them is a long reduction over few output tiles
+// that has to be split over hundreds of workgroups to fill the chip — every split then adds its whole fp32 tile atomically
+// (4.6x write amplification, profiles/r02_traffic.json) and every launch pays its own ramp and tail.  Here the autograd
+// Functions only RECORD (dY, X, dW) and a whole backward segment is reduced by ONE launch:
+//   * work item = (problem, output tile 64x64, K slice); the problems of a launch share the chip, so a problem is split only
+//     as far as the WHOLE group needs to fill it (slices of >= ~32 K-steps instead of 2 - 6);
+//   * the K loop is gemm_ring.h's LDS-DMA ring (4 stages of 64, one barrier per step);
+//   * unsplit tiles are added to the arena by their only owner with plain read-modify-writes (no atomics, deterministic);
+//   * split tiles go to a workspace in accumulator layout (16-byte stores) and ONE fold launch per group sums the slices in
+//     a fixed order and adds the result — a two-pass reduction, deterministic as well;
+//   * the bias gradient (row sums of dY^T) rides in the same pass (first tile column), as in the ring kernel.
+// The problem table travels in the kernel arguments (64 bytes per problem, <= 56 problems per launch): no device-side
+// table, no host->device copy, nothing for a hipGraph capture to get wrong.
+#include "gemm_ring.h"
+#include <cstdio>
+#include <cstdlib>
+
+#define GRP_MAXP 56
+#define GRP_TILE_FLOATS (64 * 64 + 64)  // a partial tile in accumulator layout + its 64 row sums
+
+struct GroupProb {  // 64 bytes
+  const bf16_t* A;
+  const bf16_t* B;
+  float* C;
+  float* asum;
+  int lda, ldb, skbA, skbB;  // elements
+  int K;                     // | unal << 28 | atomic << 29
+  int ws_tile0;              // first workspace slot of this problem (splits > 1): slot = ws_tile0 + tile * splits + split
+  unsigned short M, N, nkb, splits;
+};
+struct GroupArgs {
+  int nprob, nitems;
+  int item0[GRP_MAXP + 1];  // first work item of problem i (item0[nprob] = nitems)
+  int fold0[GRP_MAXP + 1];  // first fold item (= output tile of a split problem) of problem i
+  GroupProb p[GRP_MAXP];
+};
+static_assert(sizeof(GroupProb) == 64, "problem descriptor");
+static_assert(sizeof(GroupArgs) <= 4096, "the table travels in the kernel arguments");
+
+__device__ __forceinline__ int grp_find(const int* first, int n, int L) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first[mid] <= L) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+// C[m0.., n0..] += the 64x64 tile held as acc[i][j] (fragment (i, j) of the wave's 32x32 quadrant, 4 consecutive rows per lane):
+// each wave transposes one 16-row strip at a time through LDS so that lanes run along a row of C (256 contiguous bytes per
+// wave instruction).  `atomic`: another problem of the launch adds into the same C (a parameter used twice); otherwise this
+// workgroup is the tile's only writer in the launch and the add is a plain load / add / store.
+__device__ __forceinline__ void grp_add_tile(f32x4 (&acc)[2][2], float* cstrip, float* C, int ldc, int M, int N, int m0, int n0,
+                                             int wave, int lane, bool atomic) {
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  constexpr int WN = 32;
+  float* strip = cstrip + wave * (16 * (WN + 1));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) strip[(fq * 4 + r) * (WN + 1) + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    const int row0 = m0 + wm * 32 + i * 16, col0 = n0 + wn * WN;
+    for (int idx = lane; idx < 16 * WN; idx += 64) {
+      const int r = idx / WN, c = idx - r * WN;
+      if (row0 + r < M && col0 + c < N) {
+        float* p = &C[(long)(row0 + r) * ldc + col0 + c];
+        const float v = strip[r * (WN + 1) + c];
+        if (atomic) atomicAdd(p, v);
+        else *p += v;
+      }
+    }
+  }
+}
+
+template <bool AKF, bool BKF>
+__global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs ga, float* __restrict__ ws) {
+  constexpr int BM = 64, BN = 64, NS = 4, MI = 2, NJ = 2;
+  constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int G = (BM + BN) / 32;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef CENET_HOSTSIM_BUILD
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int wm = wave >> 1, wn = wave & 1;
+  int L = blockIdx.x;
+  {
+    const int T = gridDim.x;
+    if (T >= 64) {  // XCD-aware order: consecutive items (the tiles of one K slice, which share operand rows) on one L2
+      const int per = T >> 3, rem = T & 7, xcd = L & 7, idx = L >> 3;
+      L = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    }
+  }
+  const int pi = grp_find(ga.item0, ga.nprob, L);
+  const GroupProb& P = ga.p[pi];
+  const int M = P.M, N = P.N, K = P.K & 0x0FFFFFFF, nkb = P.nkb, splits = P.splits;
+  const bool unal = (P.K >> 28) & 1, atomic = (P.K >> 29) & 1;
+  const int tiles_n = (N + BN - 1) / BN, tiles = ((M + BM - 1) / BM) * tiles_n;
+  const int local = L - ga.item0[pi];
+  const int split = local / tiles, tile = local - split * tiles;
+  const int by = tile / tiles_n, bx = tile - by * tiles_n;
+  const int m0 = by * BM, n0 = bx * BN;
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ktiles = (K + 63) / 64;
+  const int total = nkb * ktiles;
+  const int chunk = (total + splits - 1) / splits;
+  const int it0 = split * chunk;
+  const int it1 = (it0 + chunk < total) ? it0 + chunk : total;
+  const int T = it1 - it0;
+
+  const long lda = P.lda, ldb = P.ldb;
+  const RingSrc<MI> sa = ring_src<AKF, BM>(P.A, lda, m0, M, wave, lane);
+  const RingSrc<NJ> sb = ring_src<BKF, BN>(P.B, ldb, n0, N, wave, lane);
+  const long kstepA = AKF ? 1 : lda, kstepB = BKF ? 1 : ldb;
+  const bf16_t* a_end = P.A + (long)(nkb - 1) * P.skbA + (AKF ? (long)(M - 1) * lda + K : (long)(K - 1) * lda + M);
+  const bf16_t* b_end = P.B + (long)(nkb - 1) * P.skbB + (BKF ? (long)(N - 1) * ldb + K : (long)(K - 1) * ldb + N);
+
+  auto issue = [&](int it, int buf) __attribute__((always_inline)) {
+    const int kb = it / ktiles;
+    const int k0 = (it - kb * ktiles) * 64;
+    const int klim = K - k0;
+    const bool tail = klim < 64;
+    unsigned char* img = lds + buf * STAGE;
+    ring_issue<AKF, BM>(sa, (long)kb * P.skbA + (long)k0 * kstepA, klim, tail, img, wave, lane, unal, a_end);
+    ring_issue<BKF, BN>(sb, (long)kb * P.skbB + (long)k0 * kstepB, klim, tail, img + ABYTES, wave, lane, unal, b_end);
+  };
+  const bool kmask = (AKF || BKF) && (K & 7) != 0;
+  const bool do_asum = P.asum != nullptr && bx == 0 && wn == 0;
+  float rsum[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) rsum[i] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < T) issue(it0 + s, s);
+
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    const int young = T - 1 - t;
+    if (young >= 2) ring_wait_vm<G * 2>();
+    else if (young >= 1) ring_wait_vm<G>();
+    else ring_wait_vm<0>();
+    ring_barrier();
+    if (t + NS - 1 < T) issue(it0 + t + NS - 1, cur == 0 ? NS - 1 : cur - 1);
+    const unsigned char* Ai = lds + cur * STAGE;
+    const unsigned char* Bi = Ai + ABYTES;
+    int klim_t = 64;
+    if (kmask) {
+      const int it = it0 + t;
+      klim_t = K - (it - (it / ktiles) * ktiles) * 64;
+    }
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      bf16x8 a[MI], b[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        a[i] = AKF ? ring_frag_kf(Ai, wm * (BM / 2) + i * 16, kc, lane) : ring_frag_rf<BM>(Ai, wm * (BM / 2) + i * 16, kc, lane);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        b[j] = BKF ? ring_frag_kf(Bi, wn * (BN / 2) + j * 16, kc, lane) : ring_frag_rf<BN>(Bi, wn * (BN / 2) + j * 16, kc, lane);
+      if (klim_t < 64) {
+        if (AKF) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) a[i] = ring_mask_k(a[i], kc, lane, klim_t);
+        }
+        if (BKF) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) b[j] = ring_mask_k(b[j], kc, lane, klim_t);
+        }
+      }
+      if (do_asum) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rsum[i] += cenet_bf2f((unsigned short)a[i][j]);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  if (do_asum) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float v = rsum[i];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      rsum[i] = v;  // lanes 0..15: row m0 + wm*32 + i*16 + lane
+    }
+  }
+  if (splits > 1) {
+    // a K slice: the raw accumulators (and row sums) go to this item's workspace slot; gemm_group_fold_kernel adds them up
+    float* slot = ws + (long)(P.ws_tile0 + tile * splits + split) * GRP_TILE_FLOATS;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) memcpy(slot + ((i * NJ + j) * 256 + tid) * 4, &acc[i][j], 16);
+    if (bx == 0 && wn == 0 && lane < 16) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) slot[64 * 64 + wm * 32 + i * 16 + lane] = rsum[i];
+    }
+    return;
+  }
+  if (do_asum && lane < 16) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = m0 + wm * 32 + i * 16 + lane;
+      if (row < M) {
+        if (atomic) atomicAdd(&P.asum[row], rsum[i]);
+        else P.asum[row] += rsum[i];
+      }
+    }
+  }
+  __syncthreads();  // the ring is free: it becomes the transpose strip
+  grp_add_tile(acc, (float*)lds, P.C, N, M, N, m0, n0, wave, lane, atomic);
+}
+
+// second pass of the split problems: one workgroup per output tile sums the tile's K slices in slice order and adds the result
+__global__ __launch_bounds__(256) void gemm_group_fold_kernel(GroupArgs ga, const float* __restrict__ ws) {
+  __shared__ float strip[4 * 16 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = blockIdx.x;
+  const int pi = grp_find(ga.fold0, ga.nprob, L);
+  const GroupProb& P = ga.p[pi];
+  const int M = P.M, N = P.N, splits = P.splits;
+  const bool atomic = (P.K >> 29) & 1;
+  const int tiles_n = (N + 63) / 64;
+  const int tile = L - ga.fold0[pi];
+  const int by = tile / tiles_n, bx = tile - by * tiles_n;
+  const float* base = ws + (long)(P.ws_tile0 + tile * splits) * GRP_TILE_FLOATS;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float rs = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const float* slot = base + (long)s * GRP_TILE_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 v;
+        memcpy(&v, slot + ((i * 2 + j) * 256 + tid) * 4, 16);
+        acc[i][j] += v;
+      }
+    if (bx == 0 && P.asum && tid < 64) rs += slot[64 * 64 + tid];
+  }
+  if (bx == 0 && P.asum && tid < 64 && by * 64 + tid < M) {
+    if (atomic) atomicAdd(&P.asum[by * 64 + tid], rs);
+    else P.asum[by * 64 + tid] += rs;
+  }
+  grp_add_tile(acc, strip, P.C, N, M, N, by * 64, bx * 64, wave, lane, atomic);
+}
+
+// ---- host side: plan (K slices per problem), table, launches ------------------------------------------------------------
+struct GrpPlan {
+  int splits, tiles, steps;
+};
+static long grp_env(const char* name, long dflt) {
+  const char* v = getenv(name);
+  return v ? atol(v) : dflt;
+}
+// One launch = problems [p0, p1) of one orientation.  Every item should reduce about `depth` K-steps: deep enough to amortise
+// the ring's fill and the epilogue, shallow enough that the launch has a few items per workgroup slot (512 resident workgroups).
+static void grp_plan(const cenet_wgrad_prob_t* p, int n, GrpPlan* out) {
+  const long min_depth = grp_env("CENET_GROUP_DEPTH", 32), slots = grp_env("CENET_GROUP_ITEMS", 1536);  // (tuning aids)
+  long work = 0;
+  for (int i = 0; i < n; ++i) {
+    out[i].tiles = cdiv(p[i].M, 64) * cdiv(p[i].N, 64);
+    out[i].steps = p[i].nkb * cdiv(p[i].K, 64);
+    work += (long)out[i].tiles * out[i].steps;
+  }
+  long depth = (work + slots - 1) / slots;
+  if (depth < min_depth) depth = min_depth;
+  for (int i = 0; i < n; ++i) {
+    long s = (out[i].steps + depth / 2) / depth;
+    if (s > out[i].steps / 8) s = out[i].steps / 8;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    out[i].splits = (int)s;
+  }
+}
+static bool grp_ok(const cenet_wgrad_prob_t& q) {
+  return q.A && q.B && q.C && q.M >= 1 && q.N >= 1 && q.K >= 1 && q.nkb >= 1 && q.M <= 65535 && q.N <= 65535 && q.nkb <= 65535 &&
+         q.K < (1 << 28) && q.lda >= 0 && q.ldb >= 0 && q.skbA >= 0 && q.skbB >= 0 && q.lda < (1L << 31) && q.ldb < (1L << 31) &&
+         q.skbA < (1L << 31) && q.skbB < (1L << 31) && q.akf == q.bkf;
+}
+
+extern "C" long cenet_wgrad_group_ws_floats(const cenet_wgrad_prob_t* p, int n) {
+  if (!p || n <= 0) return 0;
+  long slots = 0;
+  for (int o = 0; o < 2; ++o) {  // same partition into launches as cenet_wgrad_group_bf16
+    cenet_wgrad_prob_t sel[GRP_MAXP];
+    GrpPlan plan[GRP_MAXP];
+    int m = 0;
+    auto flush = [&]() {
+      if (!m) return;
+      grp_plan(sel, m, plan);
+      for (int i = 0; i < m; ++i)
+        if (plan[i].splits > 1) slots += (long)plan[i].tiles * plan[i].splits;
+      m = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      if ((p[i].akf != 0) != (o != 0)) continue;
+      sel[m++] = p[i];
+      if (m == GRP_MAXP) flush();
+    }
+    flush();
+  }
+  return slots * GRP_TILE_FLOATS;
+}
+
+// phase 0: the whole reduction; 1: the K-slice launches only; 2: the fold launches only (1 then 2 on the same arguments = 0;
+// lets a profiler-free measurement bracket the two kernels separately, bench.py)
+static int wgrad_group_impl(const cenet_wgrad_prob_t* p, int n, float* ws, long ws_floats, int phase, hipStream_t stream) {
+  if (!p || n <= 0 || phase < 0 || phase > 2) return CENET_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (!grp_ok(p[i])) return p[i].akf != p[i].bkf ? CENET_EUNSUPPORTED : CENET_EINVAL;
+  long ws_used = 0;
+  for (int o = 0; o < 2; ++o) {
+    cenet_wgrad_prob_t sel[GRP_MAXP];
+    GrpPlan plan[GRP_MAXP];
+    int m = 0;
+    int rc = CENET_OK;
+    auto flush = [&]() {
+      if (!m) return;
+      grp_plan(sel, m, plan);
+      GroupArgs ga;
+      memset(&ga, 0, sizeof ga);
+      ga.nprob = m;
+      int items = 0, folds = 0;
+      for (int i = 0; i < m; ++i) {
+        const cenet_wgrad_prob_t& q = sel[i];
+        GroupProb& d = ga.p[i];
+        d.A = (const bf16_t*)q.A;
+        d.B = (const bf16_t*)q.B;
+        d.C = q.C;
+        d.asum = q.asum;
+        d.lda = (int)q.lda; d.ldb = (int)q.ldb; d.skbA = (int)q.skbA; d.skbB = (int)q.skbB;
+        d.M = (unsigned short)q.M; d.N = (unsigned short)q.N; d.nkb = (unsigned short)q.nkb;
+        d.splits = (unsigned short)plan[i].splits;
+        // 16-byte chunks on 16-byte boundaries, or the 2-byte-aligned LDS-DMA form with hand-fetched final chunks (gemm.hip)
+        auto e8 = [](long v) { return (v & 7) == 0; };
+        const bool a_al = e8(q.skbA) && (((uintptr_t)q.A & 15) == 0) && e8(q.lda) && e8(q.akf ? q.K : q.M);
+        const bool b_al = e8(q.skbB) && (((uintptr_t)q.B & 15) == 0) && e8(q.ldb) && e8(q.bkf ? q.K : q.N);
+        bool dup = false;  // another problem of this launch adds into the same C / asum: atomics
+        for (int j = 0; j < m && !dup; ++j) dup = j != i && (sel[j].C == q.C || (q.asum && sel[j].asum == q.asum));
+        d.K = q.K | ((a_al && b_al) ? 0 : (1 << 28)) | (dup ? (1 << 29) : 0);
+        ga.item0[i] = items;
+        ga.fold0[i] = folds;
+        items += plan[i].tiles * plan[i].splits;
+        if (plan[i].splits > 1) {
+          d.ws_tile0 = (int)(ws_used / GRP_TILE_FLOATS);
+          ws_used += (long)plan[i].tiles * plan[i].splits * GRP_TILE_FLOATS;
+          folds += plan[i].tiles;
+        }
+      }
+      for (int i = m; i <= GRP_MAXP; ++i) ga.item0[i] = items, ga.fold0[i] = folds;
+      ga.nitems = items;
+      if (ws_used > ws_floats || (ws_used && !ws)) {
+        rc = CENET_EINVAL;
+        m = 0;
+        return;
+      }
+      if (phase != 2) {
+        if (o) CENET_LAUNCH((gemm_group_kernel<true, true>), dim3(items), dim3(256), stream, ga, ws);
+        else CENET_LAUNCH((gemm_group_kernel<false, false>), dim3(items), dim3(256), stream, ga, ws);
+      }
+      if (folds && phase != 1) CENET_LAUNCH(gemm_group_fold_kernel, dim3(folds), dim3(256), stream, ga, (const float*)ws);
+      m = 0;
+    };
+    for (int i = 0; i < n && rc == CENET_OK; ++i) {
+      if ((p[i].akf != 0) != (o != 0)) continue;
+      sel[m++] = p[i];
+      if (m == GRP_MAXP) flush();
+    }
+    if (rc == CENET_OK) flush();
+    if (rc != CENET_OK) return rc;
+  }
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+extern "C" int cenet_wgrad_group_bf16(const cenet_wgrad_prob_t* p, int n, float* ws, long ws_floats, hipStream_t stream) {
+  return wgrad_group_impl(p, n, ws, ws_floats, 0, stream);
+}
+extern "C" int cenet_wgrad_group_phase_bf16(const cenet_wgrad_prob_t* p, int n, float* ws, long ws_floats, int phase,
+                                            hipStream_t stream) {
+  return wgrad_group_impl(p, n, ws, ws_floats, phase, stream);
+}

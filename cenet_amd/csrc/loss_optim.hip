@@ -293,6 +293,29 @@ extern "C" int cenet_zero_f32(float* p, long n, hipStream_t stream) {
   if (n <= 0) return CENET_EINVAL;
   return cenet_zero_async(p, n, stream);
 }
+// zero-fill of a byte range that need not be a whole number of aligned 32-bit words (a bf16 tensor with an odd element count,
+// or a contiguous view that starts on an odd element): aligned words by the grid, the <= 3 head / tail bytes by workgroup 0
+__global__ __launch_bounds__(256) void zero_bytes_kernel(unsigned char* __restrict__ p, long n) {
+  long head = (long)((4 - ((uintptr_t)p & 3)) & 3);
+  if (head > n) head = n;
+  const long words = (n - head) >> 2;
+  unsigned* w = (unsigned*)(p + head);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long)gridDim.x * 256) w[i] = 0u;
+  if (blockIdx.x == 0) {
+    const long tail0 = head + 4 * words;
+    if ((long)threadIdx.x < head) p[threadIdx.x] = 0;
+    if (tail0 + (long)threadIdx.x < n && threadIdx.x < 4) p[tail0 + threadIdx.x] = 0;
+  }
+}
+extern "C" int cenet_zero_bytes(void* p, long nbytes, hipStream_t stream) {
+  if (!p || nbytes <= 0) return CENET_EINVAL;
+  long blocks = (nbytes / 4 + 1023) / 1024;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  CENET_LAUNCH(zero_bytes_kernel, dim3((unsigned)blocks), dim3(256), stream, (unsigned char*)p, nbytes);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
 
 // ---- evaluation: argmax mask + overlap counts (main_acdc.py:218-231, metrics_eval.py:24-34,46-49) ---------------------
 // pred[b,p] = argmax_c logits[b,c,p] (first maximum, like torch.argmax; softmax is monotone so it is skipped);

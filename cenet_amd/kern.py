@@ -132,6 +132,43 @@ def gemm(A: MatT, B: MatT, Cout: torch.Tensor, M: int, N: int, K: int, *, scr: i
     _lib.check(rc, "cenet_gemm_bf16" if A.bf16 else "cenet_gemm_f32")
 
 
+class WgradProbT(C.Structure):
+    """cenet_wgrad_prob_t (include/cenet_hip.h)."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("asum", C.c_void_p),
+                ("lda", C.c_long), ("ldb", C.c_long), ("skbA", C.c_long), ("skbB", C.c_long),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("nkb", C.c_int), ("akf", C.c_int), ("bkf", C.c_int)]
+
+
+def _wgrad_array(probs):
+    n = len(probs)
+    arr = (WgradProbT * n)()
+    for d, t in zip(arr, probs):
+        d.A, d.B, d.C, d.asum, d.lda, d.ldb, d.skbA, d.skbB, d.M, d.N, d.K, d.nkb = t[:12]
+        d.akf = d.bkf = t[12]
+    return arr
+
+
+def wgrad_group(probs, device, phases=(0,), between=None):
+    """probs: list of tuples (A_ptr, B_ptr, C_ptr, asum_ptr, lda, ldb, skbA, skbB, M, N, K, nkb, kfast) — all the recorded
+    weight gradients of a backward segment in one call (gemm_group.hip): C_i += A_i^T-style contraction, asum_i += row sums.
+    phases=(1, 2) issues the K-slice launches and the fold launches as two calls (`between()` runs in between): bench.py"""
+    n = len(probs)
+    arr = _wgrad_array(probs)
+    lib = _lib.lib()
+    f = lib.cenet_wgrad_group_ws_floats
+    f.restype = C.c_long
+    need = int(f(arr, n))
+    ws = torch.empty(max(need, 1), device=device, dtype=torch.float32)
+    for i, ph in enumerate(phases):
+        if i and between is not None:
+            between()
+        if ph == 0:
+            _lib.check(lib.cenet_wgrad_group_bf16(arr, n, P(ws), L(need), stream()), "cenet_wgrad_group_bf16")
+        else:
+            _lib.check(lib.cenet_wgrad_group_phase_bf16(arr, n, P(ws), L(need), int(ph), stream()), "cenet_wgrad_group_phase_bf16")
+    return need
+
+
 def last_gemm_kernel() -> str:
     """name of the kernel instance the last gemm() on this thread launched (as rocprofv3 prints it); measurement aid"""
     f = _lib.lib().cenet_gemm_last_kernel
@@ -672,8 +709,13 @@ def zero_(t: torch.Tensor):
     """zero-fill with the library's own kernel (a kernel node replays faithfully in a hipGraph; hipMemsetAsync did not)"""
     _chk(t)
     nbytes = t.numel() * t.element_size()
-    assert t.is_contiguous() and nbytes % 4 == 0, "zero_: contiguous tensor of a whole number of 32-bit words"
-    _lib.check(_lib.lib().cenet_zero_f32(P(t), L(nbytes // 4), stream()), "cenet_zero_f32")
+    assert t.is_contiguous(), "zero_: contiguous tensor"
+    if nbytes == 0:
+        return t
+    if nbytes % 4 == 0 and t.data_ptr() % 4 == 0:
+        _lib.check(_lib.lib().cenet_zero_f32(P(t), L(nbytes // 4), stream()), "cenet_zero_f32")
+    else:  # a bf16 tensor with an odd element count / an odd-element view: head and tail bytes handled by the kernel
+        _lib.check(_lib.lib().cenet_zero_bytes(P(t), L(nbytes), stream()), "cenet_zero_bytes")
     return t
 
 

@@ -27,7 +27,17 @@ class CENet(nn.Module):
     def forward(self, x):
         # throughput mode (kern.set_compute_bf16): the whole network runs on bf16 tensors — the input is rounded once here
         # and every kernel downstream follows the element type of its input; logits come back as bf16
-        if kern.get_compute_bf16() and x.dtype == torch.float32:
+        # The reference's AMP switch (main_acdc.py:192-199,243-249: `with autocast('cuda')` + GradScaler) selects the same
+        # mode: under an enabled CUDA autocast region the forward runs on bf16 tensors (fp32 islands as in
+        # multihead_diffattn.py:108, rms_norm.py:19: softmax / norm statistics / accumulators; parameters stay fp32).  bf16 has
+        # fp32's exponent range, so the GradScaler the caller wraps around the step is harmless but not needed.
+        if torch.compiler.is_compiling():
+            # main_acdc.py:188-191 (--compile): the operators below are ctypes launches of the HIP library inside
+            # autograd.Functions; a tracing compiler cannot see through them and fullgraph=True cannot be honoured
+            raise RuntimeError("cenet_amd.CENet does not support torch.compile: its operators are hand-written HIP kernels "
+                               "launched through a C ABI (capture the step with cenet_amd.graph.GraphedStep instead)")
+        amp = x.is_cuda and torch.is_autocast_enabled("cuda")
+        if (kern.get_compute_bf16() or amp) and x.dtype == torch.float32:
             x = kern.cast(x, torch.bfloat16)
         # grayscale input: the 3-channel replication of net.py:55 is a zero-stride channel read in patch_embed1
         x1, x2, x3, x4 = self.backbone(x)

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -134,8 +135,9 @@ def set_wgrad_overlap(on: bool) -> bool:
 
 
 @contextlib.contextmanager
-def _wgrad_side(*reads):
-    """runs the body on the weight-gradient stream, ordered after everything issued so far on the current stream"""
+def _wgrad_side(*reads, returned=None):
+    """runs the body on the weight-gradient stream, ordered after everything issued so far on the current stream.
+    returned: the one tensor among `reads` that the calling Function also RETURNS as a gradient (see below)"""
     if not _WgradSide.enabled or kern._lib.is_hostsim():
         yield
         return
@@ -154,11 +156,17 @@ def _wgrad_side(*reads):
     for t in reads:
         if isinstance(t, Tensor):
             t.record_stream(side)  # keep the caching allocator from recycling these while the side stream reads them
-            # ... and keep a reference until the streams are joined: a gradient tensor that the Function also RETURNS (the
-            # residual gradient of Conv1x1Fn / LinearFn) would otherwise be accumulated into IN PLACE on the main stream by
-            # autograd when it has a second consumer (use_count == 1 lets the engine steal the buffer), while the side
-            # stream is still reading it.  With the extra reference autograd accumulates out of place.
-            _WgradSide.keep.append(t)
+    if returned is not None:
+        # a gradient tensor that the Function also RETURNS (the residual gradient of Conv1x1Fn / LinearFn) would be accumulated
+        # into IN PLACE on the main stream by autograd when it has a second consumer (use_count == 1 lets the engine steal the
+        # buffer) while the side stream is still reading it: with an extra reference autograd accumulates out of place.  Only
+        # that tensor is held (everything else is covered by record_stream), until the streams are joined (wgrad_join: the
+        # optimizer step, zero_grad, the gradient all-reduce); a caller that never joins (a torch optimizer, autograd.grad
+        # loops) is joined here every 256 entries, so the list cannot grow without bound.
+        if len(_WgradSide.keep) >= 256:
+            cur.wait_stream(side)
+            _WgradSide.keep.clear()
+        _WgradSide.keep.append(returned)
     _WgradSide.pending = True
 
 
@@ -169,10 +177,70 @@ def wgrad_stream():
 
 
 def wgrad_join():
+    wgrad_flush()
     if _WgradSide.pending:
         torch.cuda.current_stream().wait_stream(_WgradSide.stream)
         _WgradSide.pending = False
     _WgradSide.keep.clear()
+
+
+class _WgradQueue:
+    """Deferred, GROUPED weight gradients (bf16 mode): LinearFn / MultiLinearFn / Conv1x1Fn do not launch their dW = dY^T X
+    contraction; they record it here, and `wgrad_flush()` reduces everything recorded so far with one launch per <= 56
+    problems (kern.wgrad_group, gemm_group.hip).  The queue flushes itself at the end of the backward pass (an autograd-engine
+    callback queued with the first record), and earlier wherever somebody needs the gradients: a gradient-arena segment
+    becoming final (GradReducer.segment_ready), wgrad_join() (FusedSGD.step, ParamArena.zero_grad).  The recorded tensors are
+    kept alive until the flush has been issued on the stream their consumers run on."""
+    enabled = os.environ.get("CENET_WGRAD_GROUP", "1") != "0"  # (0: measurement aid, the per-layer launches of round 2)
+    items = []   # descriptor tuples for kern.wgrad_group
+    keep = []    # the dY / X tensors the descriptors point into
+    armed = False
+    device = None
+
+
+def set_wgrad_grouping(on: bool) -> bool:
+    """measurement / test aid: off = every weight gradient is its own launch again (the round-2 path)"""
+    wgrad_flush()
+    old = _WgradQueue.enabled
+    _WgradQueue.enabled = bool(on)
+    return old
+
+
+def _wgrad_deferrable(M: int, N: int, *ts) -> bool:
+    return bool(_WgradQueue.enabled and M >= 48 and N >= 48 and all(t.dtype == torch.bfloat16 for t in ts))
+
+
+def _wgrad_defer(A: Tensor, a_off: int, lda: int, skbA: int, B: Tensor, b_off: int, ldb: int, skbB: int, dW: Tensor, c_off: int,
+                 db: Optional[Tensor], M: int, N: int, K: int, nkb: int, kfast: int):
+    """record dW[c_off:][M, N] += sum_{kb, k} A(m, k) B(k, n), db[m] += sum A(m, k) (offsets in elements)"""
+    q = _WgradQueue
+    q.items.append((A.data_ptr() + 2 * a_off, B.data_ptr() + 2 * b_off, dW.data_ptr() + 4 * c_off,
+                    db.data_ptr() if db is not None else None, lda, ldb, skbA, skbB, M, N, K, nkb, kfast))
+    q.keep.append((A, B))
+    q.device = A.device
+    if not q.armed:
+        q.armed = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_flush_cb)
+        except RuntimeError:  # not inside a backward pass (a Function's backward called by hand): flush right away
+            _wgrad_flush_cb()
+
+
+def _wgrad_flush_cb():
+    _WgradQueue.armed = False
+    wgrad_flush()
+
+
+def wgrad_flush():
+    """launch every recorded weight gradient on the current stream (no-op when nothing is recorded)"""
+    q = _WgradQueue
+    if not q.items:
+        return
+    items, q.items = q.items, []
+    try:
+        kern.wgrad_group(items, q.device)
+    finally:
+        q.keep = []
 
 
 def _c(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -239,8 +307,11 @@ class LinearFn(Function):
             gs = torch.empty_like(g)
             kern.scale_batch(g, bscale, gs, x.shape[0], g.numel() // x.shape[0])
         dW, db = grad_buf(Wp), grad_buf(bp)
-        if dW is not None or db is not None:
-            with _wgrad_side(gs, x):
+        if dW is not None and _wgrad_deferrable(N, K, gs, x):
+            # recorded, not launched: reduced with the other weight gradients of the segment by one grouped launch
+            _wgrad_defer(gs, 0, N, 0, x, 0, K, 0, dW, 0, db, N, K, R, 1, 0)
+        elif dW is not None or db is not None:
+            with _wgrad_side(gs, x, returned=(g if ctx.has_resid and gs is g else None)):
                 if dW is not None:
                     # the bias gradient (column sums of the output gradient) rides in the weight-gradient pass (asum)
                     iters = (R + 31) // 32
@@ -294,7 +365,10 @@ class MultiLinearFn(Function):
         esz = gs[0].element_size()
         joint = all(g.data_ptr() == gs[0].data_ptr() + j * R * N * esz for j, g in enumerate(gs))
         dW = grad_buf(Wp)
-        if dW is not None:
+        if dW is not None and _wgrad_deferrable(N, K, x, *gs):
+            for j, g in enumerate(gs):
+                _wgrad_defer(g, 0, N, 0, x, 0, K, 0, dW, j * N * K, None, N, K, R, 1, 0)
+        elif dW is not None:
             with _wgrad_side(x, *gs):
                 iters = (R + 31) // 32
                 if joint:
@@ -368,8 +442,11 @@ class Conv1x1Fn(Function):
         HW = x.numel() // (B * Cin)
         Cout = W.shape[0]
         dW, db = grad_buf(Wp), grad_buf(bp)
-        if dW is not None or db is not None:
-            with _wgrad_side(g, x):
+        if (dW is not None and not ctx.c1 and not (ctx.fewout and kern.pw_fewout_wgrad_supported(Cin, Cout))
+                and _wgrad_deferrable(Cout, Cin, g, x)):
+            _wgrad_defer(g, 0, HW, Cout * HW, x, 0, HW, Cin * HW, dW, 0, db, Cout, Cin, HW, B, 1)
+        elif dW is not None or db is not None:
+            with _wgrad_side(g, x, returned=(g if ctx.has_resid else None)):
                 if dW is not None and ctx.c1:
                     kern.conv_c1_wgrad(x, g, dW, B, Cout, x.shape[2], x.shape[3], 1)
                 elif dW is not None and ctx.fewout and kern.pw_fewout_wgrad_supported(Cin, Cout):
@@ -1038,7 +1115,9 @@ class DiffAttnHeadsFn(Function):
         hd = E // H // 2
         dv = 2 * hd
         U = _act((B, 2 * H, N, dv), q)
-        ctx.pairs = _bf(q) and kern.diffattn_heads_supported(hd, N)
+        # (the pair kernels read 16-byte chunks: operands that are odd-element views of a larger buffer take the tiled path)
+        ctx.pairs = (_bf(q) and kern.diffattn_heads_supported(hd, N)
+                     and all(t.data_ptr() % 16 == 0 for t in (q, k, v)))
         if ctx.pairs:
             # bf16 tensors: the pair kernels of attn_diff.hip (both softmax heads of a value head per wave, no atomics)
             lse = _empty((B, 2 * H, N), q)

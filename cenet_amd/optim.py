@@ -98,6 +98,16 @@ class ParamArena:
             p._cenet_shadow = self.shadow[o:o + p.numel()].view(p.shape)
             p._cenet_shadow_ver = p._version
 
+    def refresh_shadow(self):
+        """Re-cast the whole bf16 shadow from the fp32 master copy.  Needed after any RAW write to `self.params` (the flat
+        broadcast of `GradReducer.broadcast_state`, a checkpoint restored into the arena): `kern.wq` detects stale shadows by
+        each parameter's own `_version`, which a write through the flat buffer does not bump."""
+        if self.shadow is None:
+            return
+        kern.cast_into(self.params, self.shadow)
+        for p in self._plist:
+            p._cenet_shadow_ver = p._version
+
     def _home(self, o: int, n: int, shape):
         def home():
             g = self.grads[o:o + n]
@@ -201,10 +211,10 @@ class FusedSGD:
                 raise KeyError(f"momentum missing for parameters {missing[:5]}")
             for n, (o, k) in idx.items():
                 self.buf[o:o + k].copy_(sd["momentum"][n].reshape(-1).to(self.buf.device))
-        else:  # flat buffer of an older file: only valid for the identical arena layout
-            if sd["buf"].numel() != self.buf.numel():
-                raise ValueError("flat momentum buffer of a different arena layout; re-save the training state")
-            self.buf.copy_(sd["buf"])
+        else:
+            # (the flat 'buf' of files written before the arena grew groups: the layout is not recorded in the file, and a
+            # same-size buffer of another layout would be silently misassigned)
+            raise ValueError("training state without per-parameter momentum ('momentum': name -> tensor); re-save it")
         self._steps, self.lr = sd["steps"], sd["lr"]
 
 

@@ -41,6 +41,7 @@ class GradReducer:
         if not self.active:
             return
         dist.broadcast(self.arena.params, src, group=self.group)
+        self.arena.refresh_shadow()  # a bf16 shadow cast before the broadcast (an earlier forward / eval) is stale now
         for b in model.buffers():
             dist.broadcast(b, src, group=self.group)
 
@@ -53,8 +54,9 @@ class GradReducer:
         buf = self.arena.segment_grad(i)
         if buf.numel() == 0:
             return
+        from . import ops
+        ops.wgrad_flush()  # the segment's recorded (grouped) weight gradients are launched now, ahead of its collective
         if self.cuda:
-            from . import ops
             # the collective must see the segment's weight gradients, which may still be running on their own stream
             # (ops._WgradSide): the COMMUNICATION stream waits for that stream and for the compute stream; the compute
             # stream itself is not held up

@@ -87,6 +87,31 @@ int cenet_gemm_bf16(const cenet_mat_t* A, const cenet_mat_t* B, const cenet_epi_
  * ("gemm_ring_kernel<false, false, 64, 64, 4, false>").  bench.py groups its live per-launch timings by this name. */
 const char* cenet_gemm_last_kernel(void);
 
+/* GROUPED weight gradients (gemm_group.hip): the parameter gradients that autograd computes one aten::mm / aten::convolution_
+ * backward at a time for every Linear (pvtv2.py:41,45,60-63,90,98,106; multihead_diffattn.py:57-60) and 1x1 convolution
+ * (cfam.py:128-144,283-288; nlb.py:66-92; blocks.py:303-311; dseb.py:111) of a backward segment, as ONE launch per <= 56
+ * problems.  Problem i:  C_i[m, n] += sum over kb < nkb, k < K of A_i(m, k) * B_i(k, n)   and   asum_i[m] += sum of A_i(m, k)
+ * (the bias gradient; may be NULL), with  A(m, k) = akf ? A[kb*skbA + m*lda + k] : A[kb*skbA + k*lda + m],
+ * B(k, n) = bkf ? B[kb*skbB + n*ldb + k] : B[kb*skbB + k*ldb + n];  A, B bf16 (dY and the layer input), C fp32 row-major
+ * [M, N] (a slot of the gradient arena), strides in elements.  akf == bkf is required (token-major Linear: both 0; NCHW 1x1
+ * convolution: both 1), else CENET_EUNSUPPORTED.  Long reductions are cut into K slices whose partial tiles go to `ws`
+ * (cenet_wgrad_group_ws_floats(p, n) floats, may be 0) and are summed in slice order by a second launch: no float atomics
+ * unless two problems of a call share a C, results independent of scheduling. */
+typedef struct {
+  const void* A;
+  const void* B;
+  float* C;
+  float* asum;
+  long lda, ldb, skbA, skbB;
+  int M, N, K, nkb;
+  int akf, bkf;
+} cenet_wgrad_prob_t;
+long cenet_wgrad_group_ws_floats(const cenet_wgrad_prob_t* p, int n);
+int cenet_wgrad_group_bf16(const cenet_wgrad_prob_t* p, int n, float* ws, long ws_floats, cenet_stream_t stream);
+/* Measurement aid: the same reduction issued in two calls — phase 1 launches the K-slice kernels only, phase 2 the fold
+ * kernels only (phase 0 = cenet_wgrad_group_bf16) — so that bench.py can bracket the two kernel symbols with HIP events. */
+int cenet_wgrad_group_phase_bf16(const cenet_wgrad_prob_t* p, int n, float* ws, long ws_floats, int phase, cenet_stream_t stream);
+
 /* Direct ("LDS halo") stride-1 same-padded convolution on bf16 tensors (throughput mode, conv_direct.hip): replaces
  * aten::convolution(+ data-gradient) for out.py:41-49,59 (5x5 32->32, 3x3 64->64, 3x3 64->32 and their dgrads).
  * x, y: bf16; w: the fp32 master weight.  dgrad = 1: x is dY [B,Cin,H,W], w is the ORIGINAL forward weight [Cin,Cout,k,k],
@@ -371,6 +396,9 @@ int cenet_min_sqdist_i32(const int* a, int na, const int* b, int nb, int* out, c
 /* torch.optim.SGD(momentum, weight_decay) over a flat arena; hyper5 (device) = [lr, momentum, wd, grad_scale, first_step] */
 int cenet_sgd_step_f32(float* p, const float* g, float* buf, const float* hyper5, long n, cenet_stream_t stream);
 int cenet_zero_f32(float* p, long n, cenet_stream_t stream);
+/* zero-fill of any byte range (bf16 activations with an odd element count, views starting on an odd element): the buffers
+ * torch.zeros / Tensor.zero_() would give the reference's autograd (e.g. the absent branch of a channel split) */
+int cenet_zero_bytes(void* p, long nbytes, cenet_stream_t stream);
 
 /* ---- bf16 twins (throughput mode) ------------------------------------------------------------------------------------
  * Every `cenet_<op>_f32` entry point above that takes ACTIVATION tensors has a twin `cenet_<op>_bf16` with the same

@@ -206,15 +206,27 @@ def multi_order_dwconv(sd: SD, p: str, x: Tensor, rates: Sequence[int], training
     return F.conv2d(x, sd[p + ".PW_conv.weight"], sd[p + ".PW_conv.bias"])
 
 
+def _query_rows(n: int) -> int:
+    """Attention maps are materialised as the reference does (multihead_diffattn.py:96-116, nlb.py:121-138) up to 4 096
+    positions — every size the reference itself can run.  Beyond (512x512 inputs: 16 384 positions, SURVEY.md §7: the
+    reference fails there) the QUERY rows are processed 2 048 at a time: softmax is row-wise, so each row sees exactly the
+    reference's arithmetic while the host needs 0.5 GB instead of 17 GB."""
+    return n if n <= 4096 else 2048
+
+
 def nonlocal_block(sd: SD, p: str, x: Tensor, training: bool) -> Tensor:
     """nlb.py:102-148 — softmax(theta^T phi / sqrt(C)) g ; conv_out ; BN ; (1-w)x + w p."""
     N, C, H, W = x.shape
     theta = F.conv2d(x, sd[p + ".conv_theta.weight"], sd[p + ".conv_theta.bias"]).view(N, C, -1)
     phi = F.conv2d(x, sd[p + ".conv_phi.weight"], sd[p + ".conv_phi.bias"]).view(N, C, -1)
     g = F.conv2d(x, sd[p + ".conv_g.weight"], sd[p + ".conv_g.bias"]).view(N, C, -1)
-    a = torch.einsum("nch,ncp->nhp", theta, phi) * (C ** -0.5)
-    a = a.softmax(dim=2)
-    y = torch.einsum("nhg,ncg->nch", a, g).view(N, C, H, W)
+    HW = H * W
+    ys = []
+    for h0 in range(0, HW, _query_rows(HW)):  # (one chunk below 4 096 positions: the reference's single product)
+        a = torch.einsum("nch,ncp->nhp", theta[:, :, h0:h0 + _query_rows(HW)], phi) * (C ** -0.5)
+        a = a.softmax(dim=2)
+        ys.append(torch.einsum("nhg,ncg->nch", a, g))
+    y = (ys[0] if len(ys) == 1 else torch.cat(ys, dim=2)).view(N, C, H, W)
     pout = F.conv2d(y, sd[p + ".conv_out.weight"], sd[p + ".conv_out.bias"])
     pout = _bn(sd, p + ".bn", pout, training)
     w = sd[p + ".w"]
@@ -305,14 +317,18 @@ def multihead_diff_attn(sd: SD, p: str, x: Tensor, num_heads: int, depth: int) -
     k = F.linear(x, sd[p + ".k_proj.weight"]).view(B, N, 2 * num_heads, hd).transpose(1, 2)
     v = F.linear(x, sd[p + ".v_proj.weight"]).view(B, N, num_heads, 2 * hd).transpose(1, 2)
     q = q * hd ** -0.5
-    a = torch.nan_to_num(q @ k.transpose(-1, -2))
-    a = F.softmax(a, dim=-1, dtype=torch.float32).type_as(a)
     l1 = torch.exp(torch.sum(sd[p + ".lambda_q1"] * sd[p + ".lambda_k1"], dim=-1).float())
     l2 = torch.exp(torch.sum(sd[p + ".lambda_q2"] * sd[p + ".lambda_k2"], dim=-1).float())
     lam = l1 - l2 + lam0
-    a = a.view(B, num_heads, 2, N, N)
-    a = a[:, :, 0] - lam * a[:, :, 1]
-    o = a @ v
+    os_ = []
+    for n0 in range(0, N, _query_rows(N)):  # (one chunk below 4 096 tokens: the reference's single product)
+        qc = q[:, :, n0:n0 + _query_rows(N)]
+        a = torch.nan_to_num(qc @ k.transpose(-1, -2))
+        a = F.softmax(a, dim=-1, dtype=torch.float32).type_as(a)
+        a = a.view(B, num_heads, 2, qc.shape[2], N)
+        a = a[:, :, 0] - lam * a[:, :, 1]
+        os_.append(a @ v)
+    o = os_[0] if len(os_) == 1 else torch.cat(os_, dim=2)
     o = o * torch.rsqrt(o.pow(2).mean(-1, keepdim=True) + 1e-5)  # RMSNorm(2hd, eps 1e-5, no affine)
     o = o * (1 - lam0)
     o = o.transpose(1, 2).reshape(B, N, E)

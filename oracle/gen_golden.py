@@ -58,8 +58,10 @@ def synthetic_batch(B, cin, K, seed=1234, size=224):
     return x, lab[:, 0]
 
 
-def gen_module_cases():
+def gen_module_cases(only_case=None):
     for idx, c in enumerate(CASES):
+        if only_case and c["name"] not in only_case:
+            continue
         modname, clsname, kw = c["ref"]
         kw = dict(kw)
         if kw.get("norm_layer") == "LN6":
@@ -193,11 +195,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all", choices=["all", "modules", "loss", "models"])
+    ap.add_argument("--case", action="append", help="module cases to (re)generate (default: all)")
     a = ap.parse_args()
     torch.set_num_threads(8)
     core = load_reference_losses()
     if a.only in ("all", "modules"):
-        gen_module_cases()
+        gen_module_cases(a.case)
     if a.only in ("all", "loss"):
         gen_loss_cases(core)
     if a.only in ("all", "models"):

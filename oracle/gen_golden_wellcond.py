@@ -1,0 +1,110 @@
+"""Well-conditioned whole-model golden (TEST INFRASTRUCTURE; runs ONLY in the build container).
+
+The three `model_*.npz` points fill every parameter at random (batch 2): their gradients are dominated by cancellation
+and cannot hold a reduced-precision mode to a tight bound.  This point is the reference AS ITS TRAINING SCRIPT BUILDS IT
+(main_acdc.py:112-126: `torch.manual_seed(seed); CENet(**kw)` = the reference's own initialisers, pvtv2.py:24-38,
+cfam.py / blocks.py / unet.py `_init_weights`), with the CFAM layer scales raised from 1e-6 to 0.5 so the decoder blocks
+are numerically visible, batch 8, stochastic depth off.  The unmodified reference evaluates one training
+step in float32 AND float64; stored per parameter tensor: gradient norm and a 64-entry strided sample (both precisions),
+plus loss, a logits subsample, BatchNorm buffers after the step and per-tensor checksums of the initial state (so that a
+test can prove the product's constructor reproduces the reference's initialisation bit for bit without the reference).
+
+Re-run:  python -m oracle.gen_golden_wellcond
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF_SRC = "/root/reference/src"
+sys.path[:0] = [os.path.join(HERE, "ref_shim"), REF_SRC]
+
+import torch  # noqa: E402
+
+sys.path.insert(0, ROOT)
+from oracle import cenet_oracle as O  # noqa: E402
+from oracle.gen_golden import load_reference_losses  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+SEED = 77
+BATCH = 8
+LAYER_SCALE = 0.5
+NS = 64  # sampled entries per tensor
+KW = dict(input_channels=1, num_classes=4, scale_factors=[1.0, 0.5], diffatt_num_heads=[4, 4, 4], out_up_block="upcn")
+
+
+def sample_index(n: int) -> torch.Tensor:
+    """the strided sample every consumer of this fixture uses: min(NS, n) entries spread over the flat tensor"""
+    m = min(NS, n)
+    return (torch.arange(m, dtype=torch.float64) * ((n - 1) / max(m - 1, 1))).round().long()
+
+
+def prepare(net):
+    """the conditioning step applied to the freshly constructed network (same code runs on the product in the tests)"""
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "layer_scale" in k:
+                p.fill_(LAYER_SCALE)
+    return net
+
+
+def main():
+    from networks import CENet
+    torch.set_num_threads(8)
+    core = load_reference_losses()
+    K = KW["num_classes"]
+    x, lab = O.synthetic_batch(BATCH, KW["input_channels"], K, seed=1234)
+    crit = core.Criterion(K, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
+    rec = {"seed": np.int64(SEED), "batch": np.int64(BATCH), "layer_scale": np.float64(LAYER_SCALE), "x_seed": np.int64(1234)}
+    grads = {}
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        torch.manual_seed(SEED)
+        net = prepare(CENet(**KW))
+        if tag == "32":
+            for k, v in net.state_dict().items():
+                if v.is_floating_point():
+                    rec["init." + k] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+        net = net.to(dt).train()
+        net.backbone.reset_drop_path(0.0)
+        lt = net(x.to(dt))
+        loss = crit(lt, lab.to(dt))
+        loss.backward()
+        rec["loss" + tag] = np.float64(loss.item())
+        rec["logits_sub" + tag] = lt.detach()[:, :, ::9, ::9].double().numpy()
+        g = {}
+        for k, p in net.named_parameters():
+            gk = p.grad.reshape(-1).double()
+            g[k] = gk
+            rec[f"g{tag}.{k}.norm"] = np.float64(gk.norm().item())
+            rec[f"g{tag}.{k}.s"] = gk[sample_index(gk.numel())].numpy().astype(np.float32)
+        grads[tag] = g
+        if tag == "32":
+            for k, b in net.named_buffers():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    rec["b." + k] = b.detach().reshape(-1)[:8].numpy().copy()
+        print(f"[golden] wellcond fp{tag}: loss {loss.item():.8f}")
+    # conditioning report: the reference's own fp32 gradient against its fp64 gradient
+    a = torch.cat([grads["32"][k] for k in grads["32"]])
+    b = torch.cat([grads["64"][k] for k in grads["64"]])
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+    rel = ((a - b).norm() / b.norm()).item()
+    rec["ref32_vs_64_cos"] = np.float64(cos)
+    rec["ref32_vs_64_rel"] = np.float64(rel)
+    print(f"[golden] reference fp32 vs fp64 gradient: cosine {cos:.8f}, relative L2 {rel:.3e}")
+    worst = sorted(((((grads['32'][k] - grads['64'][k]).norm() / (grads['64'][k].norm() + 1e-30)).item(), k) for k in grads["32"]),
+                   reverse=True)[:8]
+    for r, k in worst:
+        print(f"    {r:.3e}  {k}")
+    np.savez_compressed(os.path.join(OUT, "model_acdc_wellcond.npz"), **rec)
+    print(f"[golden] model_acdc_wellcond.npz: {os.path.getsize(os.path.join(OUT, 'model_acdc_wellcond.npz')) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,11 @@ CASES = [
                             up_ks=3)),
           [(2, 16, 8, 8), (2, 1, 32, 32)], lambda sd, ins, tr: O.out_head(sd, P, ins[0], ins[1], tr),
           call=lambda m, ins: m(ins[0], ins[1])),
+    # ---- appended in round 3 (case index = RNG seed: new cases go to the END so the older fixtures stay reproducible) ----
+    _case("mca_14", ("networks.cenet.modules.cfam", "MCA", dict(embed_dims=32, rates=[1, 2, 3])),
+          [(2, 32, 14, 14)], lambda sd, ins, tr: O.mca(sd, P, ins[0], (1, 2, 3), tr)),
+    _case("mca_7", ("networks.cenet.modules.cfam", "MCA", dict(embed_dims=16, rates=[1, 2, 2])),
+          [(3, 16, 7, 7)], lambda sd, ins, tr: O.mca(sd, P, ins[0], (1, 2, 2), tr)),
 ]
 
 CASE_BY_NAME = {c["name"]: c for c in CASES}

@@ -231,14 +231,14 @@ def _cos(a, b):
 @pytest.mark.parametrize("name", ["acdc", "synapse", "skin"])
 def test_whole_model_bf16_training_step_vs_goldens(name):
     """The BENCHED mode (bf16 tensors end to end) on the three whole-model goldens of the unmodified reference, one training
-    step.  Pinned against the goldens: loss within 5e-3, train logits mean |d| < 2 % of the logit range, BN running buffers.
-    Pinned against the fp32 product step (itself pinned to the float64 goldens at 1e-3, test_model_parity.py): cosine of the
-    FULL head+decoder gradient >= 0.90, of the whole gradient vector >= 0.70.
-    The golden points (every parameter filled at random, batch 2-4) are ill-conditioned for the gradient: an all-fp32 step
-    whose ONLY perturbation is the network input rounded to bf16 values (2^-9 relative, loss unchanged to five digits) already
-    moves the four encoder segments to cosine 0.988 - 0.997 (tools/bf16_bisect.py --quick), and three runs of the SAME bf16
-    build differ among themselves through the order of the fp32 split-K atomics alone (head+decoder 0.984 - 0.996, encoder
-    0.83 - 0.98).  The bounds here sit below that spread; the well-conditioned pin is the next test."""
+    step, ONE evaluation.  Pinned against the goldens: loss within 5e-3, train logits mean |d| < 2 % of the logit range, BN
+    running buffers; against the fp32 product step (itself pinned to the float64 goldens at 1e-3, test_model_parity.py):
+    cosine of the FULL head+decoder gradient >= 0.90 (measured 0.984 - 0.996).
+    These golden points (every parameter filled at random, batch 2) are ill-conditioned for the ENCODER gradient: an all-fp32
+    step whose only perturbation is the network input rounded to bf16 values already moves the encoder segments to cosine
+    0.988 - 0.997 (tools/bf16_bisect.py --quick), so no bound on the whole vector is asserted here.  The gradient of the
+    benched mode is held to the reference itself on the well-conditioned golden: tests/test_wellcond.py (cosine >= 0.999 per
+    arena segment against the reference's float64 gradient, plus run-to-run reproducibility)."""
     from oracle.gen_golden_keys import PROBE_BUFFERS
     from test_model_parity import build
     d = use_hip()
@@ -248,13 +248,7 @@ def test_whole_model_bf16_training_step_vs_goldens(name):
         return net, cfg.num_classes, x, lab
     _, _, z, _, _ = build(name, d)
     l32, _, g32, arena, _ = _train_step_grads(build_fn, False)
-    # the whole-vector cosine of one bf16 evaluation ranges over ~0.69 - 0.98 from run to run at these points (order of the
-    # fp32 atomics, see above): the best of up to three evaluations is held to the bound, so that one unlucky ordering does
-    # not fail the suite while a real defect (which moves every evaluation) still does
-    for attempt in range(3):
-        l16, lt, g16, _, bufs = _train_step_grads(build_fn, True)
-        if _cos(g32, g16) >= 0.70:
-            break
+    l16, lt, g16, _, bufs = _train_step_grads(build_fn, True)
     assert abs(l32 - float(z["loss"])) < 2e-4
     assert abs(l16 - float(z["loss"])) < 5e-3, (l16, float(z["loss"]))
     ref = z["logits_train_sub"]
@@ -262,7 +256,6 @@ def test_whole_model_bf16_training_step_vs_goldens(name):
     seg = {n: (s, e) for n, s, e in arena.segments}
     s, e = seg["head+decoder"]
     assert _cos(g32[s:e], g16[s:e]) >= 0.90, _cos(g32[s:e], g16[s:e])
-    assert _cos(g32, g16) >= 0.70, _cos(g32, g16)
     for k in PROBE_BUFFERS:
         np.testing.assert_allclose(bufs[k].reshape(-1)[:16].float().cpu().numpy(), z["b." + k], rtol=5e-2, atol=5e-3, err_msg=k)
 

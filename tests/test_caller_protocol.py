@@ -1,0 +1,177 @@
+"""The reference's CALLER, restated: what src/main_acdc.py does with the model object between construction and the end of a
+training iteration (main_acdc.py:110-132 construction + `.cuda()` + the deepcopy of utils/utils.py:113; :171-180 checkpoint
+load and the `nn.DataParallel` wrap; :185-199 `.train()`, criterion, AMP switch; :237-257 the step body with
+`torch.optim.SGD(net.parameters(), ...)` of utils/core.py:19-21 and the poly `LambdaLR` of core.py:31).  The script itself is
+never shipped or imported; these tests replay its calls on `cenet_amd.networks.CENet`.
+
+* plain-fp32 protocol: three iterations driven by torch.optim.SGD + LambdaLR give the loss trajectory of the fused path
+  (ParamArena + FusedSGD + PolyLR) AND of the oracle trained on the host with the same optimizer;
+* the same under `copy.deepcopy`, `nn.DataParallel` on one device, `state_dict()` -> `load_state_dict(strict=True)`;
+* AMP protocol (`autocast('cuda')` + `GradScaler`): the forward runs in the bf16 mode, the scaler neither skips a step nor
+  changes its scale, the trajectory follows the fp32 one within the bf16 tolerance;
+* `torch.compile(net, fullgraph=True)` (main_acdc.py:188-191) is refused with a clear error."""
+import argparse
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+from backend import use_hip
+from oracle import cenet_oracle as O
+
+ACDC_ARGS = dict(input_channels=1, num_classes=4, scale_factors=[1.0, 0.5], encoder="pvt_v2_b2", enc_pretrain=False,
+                 freeze_bb=False, skip_mode="cat", diffatt_num_heads=[4, 4, 4], dec_up_block="eucb", out_merge_mode="cat",
+                 out_up_block="upcn", out_up_ks=3, base_ptdir=".")
+BASE_LR, WD, MAX_IT = 0.05, 1e-4, 100
+STEPS = 3
+
+
+def _criterion():
+    from cenet_amd import losses
+    return losses.Criterion(4, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
+
+
+def _build(dev):
+    """main_acdc.py:110-126: CENet(**flags).cuda() — with reproducible, non-degenerate weights loaded the way a checkpoint is
+    (main_acdc.py:175)"""
+    from cenet_amd.networks import CENet
+    net = CENet(**ACDC_ARGS).to(dev)
+    sd = O.make_state_dict(O.CENetConfig(), seed=3)
+    net.load_state_dict(sd, strict=True)
+    return net, sd
+
+
+def _drive(net, x, lab, amp=False):
+    """main_acdc.py:185-257 with get_optimizer('sgd') / get_scheduler('poly') of utils/core.py"""
+    net.train()
+    (net.module if isinstance(net, nn.DataParallel) else net).backbone.reset_drop_path(0.0)  # (deterministic trajectory)
+    criterion = _criterion()
+    optimizer = torch.optim.SGD(net.parameters(), lr=BASE_LR, weight_decay=WD, momentum=0.9)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda step: (1 - step / MAX_IT) ** 0.9)
+    scaler = torch.amp.GradScaler() if amp else None
+    losses_, lrs = [], []
+    for _ in range(STEPS):
+        optimizer.zero_grad()
+        if amp:
+            with torch.amp.autocast(device_type="cuda"):
+                outputs = net(x)
+                loss = criterion(outputs, lab[:])
+            scaler.scale(loss).backward()
+            scaler.step(optimizer)
+            scaler.update()
+        else:
+            outputs = net(x)
+            loss = criterion(outputs, lab[:])
+            loss.backward()
+            optimizer.step()
+        lrs.append(scheduler.get_last_lr()[0])
+        scheduler.step()
+        losses_.append(loss.item())
+    return losses_, lrs, outputs, scaler
+
+
+def _oracle_trajectory(sd, x, lab):
+    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+           for k, v in sd.items()}
+    params = [v for v in sdo.values() if v.requires_grad]
+    optimizer = torch.optim.SGD(params, lr=BASE_LR, weight_decay=WD, momentum=0.9)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda step: (1 - step / MAX_IT) ** 0.9)
+    out = []
+    for _ in range(STEPS):
+        optimizer.zero_grad()
+        loss = O.criterion(O.cenet_forward(sdo, x, O.CENetConfig(), training=True), lab, 4)
+        loss.backward()
+        optimizer.step()
+        scheduler.step()
+        out.append(loss.item())
+    return out
+
+
+@pytest.mark.gpu
+def test_fp32_protocol_matches_the_fused_path_and_the_oracle():
+    from cenet_amd import optim
+    dev = use_hip()
+    x, lab = O.synthetic_batch(2, 1, 4, seed=9)
+    xd, labd = x.to(dev), lab.to(dev)
+    net, sd = _build(dev)
+    clone = copy.deepcopy(net)  # utils/utils.py:113 (CalParams) — and an independent replica for the fused path
+    got, lrs, outputs, _ = _drive(net, xd, labd)
+    assert outputs.shape == (2, 4, 224, 224) and outputs.dtype == torch.float32
+    assert lrs == pytest.approx([BASE_LR * (1 - i / MAX_IT) ** 0.9 for i in range(STEPS)])
+    # the fused path (ParamArena + FusedSGD + PolyLR) on the deep copy
+    clone.train()
+    clone.backbone.reset_drop_path(0.0)
+    arena = optim.ParamArena(clone, optim.cenet_segments())
+    opt = optim.FusedSGD(arena, lr=BASE_LR, momentum=0.9, weight_decay=WD)
+    sched = optim.PolyLR(opt, max_iterations=MAX_IT)
+    crit = _criterion()
+    fused = []
+    for _ in range(STEPS):
+        opt.zero_grad()
+        loss = crit(clone(xd), labd)
+        loss.backward()
+        opt.step()
+        sched.step()
+        fused.append(loss.item())
+    ref = _oracle_trajectory(sd, x, lab)
+    for a, b, c in zip(got, fused, ref):
+        assert abs(a - b) < 2e-5, (got, fused)
+        assert abs(a - c) < 2e-4, (got, ref)
+    assert got[-1] < got[0]  # and it trains
+    # the parameters the two optimizers arrive at
+    pa, pb = dict(net.named_parameters()), dict(clone.named_parameters())
+    for k in ("out.out.1.conv.conv.weight", "decoder.dec2.mca.gate.weight", "backbone.block3.2.mlp.fc1.weight",
+              "backbone.patch_embed1.proj.weight"):
+        assert (pa[k] - pb[k]).abs().max().item() < 1e-5 + 1e-3 * pb[k].abs().max().item(), k
+
+
+@pytest.mark.gpu
+def test_dataparallel_wrap_and_state_dict_round_trip():
+    dev = use_hip()
+    x, lab = O.synthetic_batch(2, 1, 4, seed=9)
+    xd, labd = x.to(dev), lab.to(dev)
+    net, sd = _build(dev)
+    plain, _, _, _ = _drive(copy.deepcopy(net), xd, labd)
+    wrapped = nn.DataParallel(net, device_ids=[0]).cuda()  # main_acdc.py:178-180 on a one-GPU box
+    got, _, outputs, _ = _drive(wrapped, xd, labd)
+    assert got == pytest.approx(plain, abs=2e-5)
+    # main_acdc.py:278 saves net.state_dict(); :175 loads it strictly into a freshly built model
+    from cenet_amd.networks import CENet
+    saved = {k: v.detach().cpu().clone() for k, v in wrapped.module.state_dict().items()}
+    assert list(saved) == list(sd)  # the reference's 801 keys, in its order
+    fresh = CENet(**ACDC_ARGS).to(dev)
+    fresh.load_state_dict(saved, strict=True)
+    fresh.eval(), wrapped.eval()
+    with torch.no_grad():
+        assert torch.equal(fresh(xd), wrapped(xd))
+
+
+@pytest.mark.gpu
+def test_amp_protocol_runs_the_bf16_mode_under_the_callers_gradscaler():
+    dev = use_hip()
+    x, lab = O.synthetic_batch(2, 1, 4, seed=9)
+    xd, labd = x.to(dev), lab.to(dev)
+    net, _ = _build(dev)
+    fp32, _, _, _ = _drive(copy.deepcopy(net), xd, labd)
+    before = net.out.out[1].conv.conv.weight.detach().clone()
+    got, _, outputs, scaler = _drive(net, xd, labd, amp=True)
+    assert outputs.dtype == torch.bfloat16  # the autocast region selected the bf16 mode (net.py forward)
+    assert scaler.get_scale() == 65536.0    # no overflow was ever seen: no step skipped, scale never backed off
+    assert not torch.equal(before, net.out.out[1].conv.conv.weight)  # the steps were taken
+    for a, b in zip(got, fp32):
+        assert abs(a - b) < 5e-3, (got, fp32)
+    # outside the region the model is back in fp32 (val(), main_acdc.py:218-231)
+    net.eval()
+    with torch.no_grad():
+        assert net(xd).dtype == torch.float32
+
+
+@pytest.mark.gpu
+def test_torch_compile_is_refused_with_a_clear_error():
+    dev = use_hip()
+    net, _ = _build(dev)
+    x, _ = O.synthetic_batch(1, 1, 4, seed=9)
+    compiled = torch.compile(net, mode="default", fullgraph=True)  # main_acdc.py:190
+    with pytest.raises(Exception, match="does not support torch.compile"):
+        compiled(x.to(dev))

@@ -1,0 +1,138 @@
+"""Grouped weight gradients (cenet_wgrad_group_bf16, gemm_group.hip) and the deferral queue of cenet_amd.ops.
+
+* the C-ABI entry against plain fp32 PyTorch on mixed problem lists: token-major Linear problems (both operands row-fast),
+  NCHW 1x1-conv problems (both k-fast, K batches, unaligned 7x7 / 14x14 planes), ragged M / N / K, bias row sums, K slices
+  (workspace + fold launch), two problems adding into ONE C (atomic path), more problems than one launch holds;
+* results do not depend on scheduling: two runs are bit-identical;
+* LinearFn / MultiLinearFn / Conv1x1Fn with the queue on give the gradients of the one-launch-per-layer path.
+`sim` = the same kernel source on the host SIMT checker (CPU); `hip` = the gfx950 library (marker gpu)."""
+import pytest
+import torch
+
+from backend import dev  # noqa: F401
+from cenet_amd import kern, ops
+
+BF = torch.bfloat16
+
+
+def _lin_problem(g, R, N, K, dev_, bias=True):
+    """token-major Linear: dY [R, N], X [R, K] -> dW [N, K] += dY^T X, db[N] += column sums of dY"""
+    dy = (torch.randn(R, N, generator=g) * 0.5).to(BF)
+    x = torch.randn(R, K, generator=g).to(BF)
+    ref = dy.float().t() @ x.float()
+    rb = dy.float().sum(0)
+    return dict(kind="lin", dy=dy.to(dev_), x=x.to(dev_), M=N, N=K, K=R, nkb=1, ref=ref, rb=rb if bias else None)
+
+
+def _conv_problem(g, B, Cout, Cin, HW, dev_, bias=True):
+    """NCHW 1x1 conv: dY [B, Cout, HW], X [B, Cin, HW] -> dW [Cout, Cin] += sum_b dY_b X_b^T"""
+    dy = (torch.randn(B, Cout, HW, generator=g) * 0.5).to(BF)
+    x = torch.randn(B, Cin, HW, generator=g).to(BF)
+    ref = torch.einsum("bop,bip->oi", dy.float(), x.float())
+    rb = dy.float().sum((0, 2))
+    return dict(kind="conv", dy=dy.to(dev_), x=x.to(dev_), M=Cout, N=Cin, K=HW, nkb=B, ref=ref, rb=rb if bias else None)
+
+
+def _run(probs, dev_, pre=None):
+    items, outs = [], []
+    for i, p in enumerate(probs):
+        dW = torch.zeros(p["M"], p["N"], device=dev_) if pre is None else pre[i][0]
+        db = (torch.zeros(p["M"], device=dev_) if pre is None else pre[i][1]) if p["rb"] is not None else None
+        outs.append((dW, db))
+        if p["kind"] == "lin":
+            items.append((p["dy"].data_ptr(), p["x"].data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else None,
+                          p["M"], p["N"], 0, 0, p["M"], p["N"], p["K"], 1, 0))
+        else:
+            items.append((p["dy"].data_ptr(), p["x"].data_ptr(), dW.data_ptr(), db.data_ptr() if db is not None else None,
+                          p["K"], p["K"], p["M"] * p["K"], p["N"] * p["K"], p["M"], p["N"], p["K"], p["nkb"], 1))
+    kern.wgrad_group(items, dev_)
+    if dev_.type == "cuda":
+        torch.cuda.synchronize()
+    return outs
+
+
+def _check(probs, outs, tol=2e-3):
+    for p, (dW, db) in zip(probs, outs):
+        scale = p["ref"].abs().max().item() + 1e-6
+        assert (dW.cpu() - p["ref"]).abs().max().item() < tol * scale, (p["kind"], p["M"], p["N"], p["K"], p["nkb"])
+        if p["rb"] is not None:
+            assert (db.cpu() - p["rb"]).abs().max().item() < tol * (p["rb"].abs().max().item() + 1e-6)
+
+
+def test_mixed_problem_list(dev):
+    g = torch.Generator().manual_seed(3)
+    probs = [_lin_problem(g, 200, 64, 64, dev), _lin_problem(g, 130, 72, 136, dev), _lin_problem(g, 77, 48, 200, dev, bias=False),
+             _conv_problem(g, 3, 64, 64, 49, dev), _conv_problem(g, 2, 80, 56, 196, dev), _conv_problem(g, 2, 96, 64, 64, dev, bias=False)]
+    outs = _run(probs, dev)
+    _check(probs, outs)
+
+
+def test_long_reductions_are_sliced_and_folded(dev, monkeypatch):
+    """K = 6 000 / 33 x 196 with a small depth target: several K slices per tile, partial tiles through the workspace"""
+    monkeypatch.setenv("CENET_GROUP_DEPTH", "8")
+    g = torch.Generator().manual_seed(4)
+    probs = [_lin_problem(g, 6000, 64, 128, dev), _conv_problem(g, 33, 64, 64, 196, dev), _lin_problem(g, 300, 64, 64, dev)]
+    outs = _run(probs, dev)
+    _check(probs, outs)
+    outs2 = _run(probs, dev)
+    for (a, ab), (b, bb) in zip(outs, outs2):
+        assert torch.equal(a, b) and (ab is None or torch.equal(ab, bb)), "the two-pass reduction is deterministic"
+
+
+def test_accumulates_into_existing_gradient_and_shared_destination(dev):
+    g = torch.Generator().manual_seed(5)
+    p0, p1 = _lin_problem(g, 500, 64, 64, dev), _lin_problem(g, 260, 64, 64, dev)
+    dW = torch.full((64, 64), 0.25, device=dev)
+    db = torch.full((64,), -1.0, device=dev)
+    _run([p0, p1], dev, pre=[(dW, db), (dW, db)])  # one parameter used twice: both problems add into the same C / asum
+    ref = 0.25 + p0["ref"] + p1["ref"]
+    assert (dW.cpu() - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    assert (db.cpu() - (-1.0 + p0["rb"] + p1["rb"])).abs().max().item() < 2e-3 * p0["rb"].abs().max().item()
+
+
+def test_more_problems_than_one_launch(dev):
+    g = torch.Generator().manual_seed(6)
+    probs = [_lin_problem(g, 64 + 8 * i, 48 + 8 * (i % 3), 64, dev, bias=(i % 2 == 0)) for i in range(61)]
+    outs = _run(probs, dev)
+    _check(probs, outs)
+
+
+def _grads(fn, params):
+    for p in params:
+        p.grad = None
+    fn()
+    ops.wgrad_join()
+    return [p.grad.detach().clone() for p in params]
+
+
+def test_deferred_layers_match_the_per_layer_launches(dev):
+    """Linear (bias, residual, tap), the batched q / k / v projection and a 1x1 conv (bias) in one backward pass: the queue
+    on (one grouped launch at the end of the pass) against the queue off (a launch per layer), same bf16 inputs"""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 70, 64, generator=g).to(BF).to(dev).requires_grad_(True)
+    W1 = torch.nn.Parameter((torch.randn(96, 64, generator=g) * 0.1).to(dev))
+    b1 = torch.nn.Parameter(torch.randn(96, generator=g).to(dev))
+    W2 = torch.nn.Parameter((torch.randn(64, 96, generator=g) * 0.1).to(dev))
+    Wq = torch.nn.Parameter((torch.randn(3, 64, 64, generator=g) * 0.1).to(dev))
+    Wc = torch.nn.Parameter((torch.randn(56, 70, 1, 1, generator=g) * 0.1).to(dev))
+    bc = torch.nn.Parameter(torch.randn(56, generator=g).to(dev))
+    cot = torch.randn(2, 56, 64, generator=g).to(BF).to(dev)
+    params = [W1, b1, W2, Wq, Wc, bc]
+
+    def run():
+        h = ops.linear(x, W1, b1)
+        y = ops.linear(h, W2, None, resid=x)
+        q, k, v = ops.multi_linear(y, Wq)
+        z = ops.conv1x1((q + k + v).contiguous(), Wc, bc)  # [2, 70, 64] read as NCHW [B, C=70, HW=64]
+        z.backward(cot)
+
+    old = ops.set_wgrad_grouping(False)
+    try:
+        ref = _grads(run, params)
+        ops.set_wgrad_grouping(True)
+        got = _grads(run, params)
+        assert not ops._WgradQueue.items and not ops._WgradQueue.keep
+    finally:
+        ops.set_wgrad_grouping(old)
+    for r, t, n in zip(ref, got, ["W1", "b1", "W2", "Wq", "Wc", "bc"]):
+        assert (r - t).abs().max().item() <= 2e-3 * r.abs().max().item() + 1e-6, n
