@@ -74,6 +74,8 @@ def parse():
                     help="storage type of activations and MFMA operands (accumulation, statistics, parameters stay fp32)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step as one captured hipGraph (auto: N == 1 times a few steps both ways and keeps the faster)")
+    ap.add_argument("--dist-launch", choices=["auto", "eager", "split", "segmented"], default="auto",
+                    help="N > 1: force one launch form of the step instead of timing the three (see main)")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra fp32 parity-mode measurement (N=1, bf16 runs)")
     ap.add_argument("--no-overlap", action="store_true", help="keep the weight-gradient kernels on the main stream")
     ap.add_argument("--bf16-buckets", action="store_true", help="N > 1: all-reduce the gradient segments as bf16 (half the bytes)")
@@ -440,6 +442,7 @@ def main():
 
     graphed = None
     launch_note = None
+    dist_launch = "eager"
     # N == 1, auto: eager launches are host-bound (~1.3 k C-ABI calls of ~20 us of Python + ctypes each) and replay is not,
     # so which one is faster depends on the host; a few steps of each decide.  (N > 1: next block.)
     # The weight-gradient stream pays off for EAGER launches (its kernels fill the gaps the host leaves) and costs under
@@ -472,49 +475,66 @@ def main():
                 graphed = None
 
     if use_dist and a.graph != "off":
-        # N > 1: forward + backward and the SGD update as two hipGraphs with the all-reduces issued eagerly between them
-        # (cenet_amd.graph.GraphedSplitStep) against eager launches with the all-reduces overlapped from backward hooks.
-        # Every rank times both; the choice is rank 0's (same collective sequence either way, but one mode for all ranks).
-        from cenet_amd.graph import GraphedSplitStep
-        try:
-            parallel.attach(net, None)  # no hooks inside the capture: finish() reduces every segment
-            ops.set_wgrad_overlap(False)
-            cand = GraphedSplitStep(fwd_bwd, opt, reducer.finish, warmup=2)
-        except Exception as e:
-            print(f"[bench] split hipGraph capture failed on rank {rank} ({type(e).__name__}: {e})", file=sys.stderr)
-            cand = None
-            torch.cuda.synchronize()
-        finally:
-            ops.set_wgrad_overlap(overlap_eager)
+        # N > 1: three launch forms of the same step, timed for four untimed steps each on every rank; rank 0's pick is
+        # broadcast (the collective sequence — one all-reduce per arena segment — is the same in all three):
+        #   eager      ~1 300 launches per step, all-reduces started from backward hooks (host-bound; 8 ranks share one host)
+        #   split      forward + backward as ONE hipGraph, the five all-reduces after it, SGD as a second graph
+        #              (cenet_amd.graph.GraphedSplitStep: ~8 host calls, no backward / all-reduce overlap)
+        #   segmented  the backward cut at the encoder stage outputs: graph 0 = forward + head/decoder backward, graphs 1-4 =
+        #              one encoder stage each, segment k's all-reduce issued eagerly behind graph k so that it runs beside
+        #              graphs k+1.. (cenet_amd.graph.SegmentedStep: ~15 host calls, overlap kept)
+        from cenet_amd.graph import GraphedSplitStep, SegmentedStep
+        cands = {}
+        parallel.attach(net, None)  # no hooks inside the captures: the step objects drive the reducer themselves
+        ops.set_wgrad_overlap(False)
+        for name, make in (("split", lambda: GraphedSplitStep(fwd_bwd, opt, reducer.finish, warmup=2)),
+                           ("segmented", lambda: SegmentedStep(net, lambda: crit(net(x), lab), opt, reducer.segment_ready,
+                                                               reducer.finish, warmup=2))):
+            try:
+                cands[name] = make()
+            except Exception as e:
+                print(f"[bench] {name} hipGraph capture failed on rank {rank} ({type(e).__name__}: {e})", file=sys.stderr)
+                torch.cuda.synchronize()
+        ops.set_wgrad_overlap(overlap_eager)
         # all ranks or none (the timing loops below contain barriers): EVERY rank reaches this collective, also one whose
         # capture threw — with --graph on the failure is raised on all ranks only after they have agreed on it
-        okf = torch.tensor([1.0 if cand is not None else 0.0], device=dev)
+        okf = torch.tensor([1.0 if "split" in cands else 0.0, 1.0 if "segmented" in cands else 0.0], device=dev)
         dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-        if okf.item() < 1.0:
-            cand = None
-            if a.graph == "on":
-                raise SystemExit("--graph on: the split hipGraph capture failed on at least one rank")
-        pick = torch.zeros(1, device=dev)
-        if cand is not None:
-            parallel.attach(net, reducer)
+        for i, name in enumerate(("split", "segmented")):
+            if okf[i].item() < 1.0:
+                cands.pop(name, None)
+        if not cands and a.graph == "on":
+            raise SystemExit("--graph on: no hipGraph form of the step could be captured on every rank")
+        times = {}
+        parallel.attach(net, reducer)
+        if a.graph != "on":
             for _ in range(2):
                 body()
             dist.barrier()
-            t_e = _time_steps(body, 4)
-            parallel.attach(net, None)
+            times["eager"] = _time_steps(body, 4)
+        parallel.attach(net, None)
+        for name, cand in cands.items():
             for _ in range(2):
                 cand()
             dist.barrier()
-            t_g = _time_steps(cand, 4)
-            launch_note = (f"auto: eager + overlapped all-reduce {t_e * 1e3:.1f} ms vs two hipGraphs + all-reduce between "
-                           f"{t_g * 1e3:.1f} ms over 4 untimed steps each (rank 0 decides)")
-            pick[0] = 1.0 if (t_g < t_e or a.graph == "on") else 0.0
+            times[name] = _time_steps(cand, 4)
+        order = ["eager", "split", "segmented"]
+        best = min(times, key=times.get) if times else "eager"
+        if a.dist_launch != "auto":
+            if a.dist_launch != "eager" and a.dist_launch not in cands:
+                raise SystemExit(f"--dist-launch {a.dist_launch}: that form could not be captured on every rank")
+            best = a.dist_launch
+        pick = torch.tensor([float(order.index(best))], device=dev)
         dist.broadcast(pick, 0)
-        if cand is not None and pick.item() > 0:
-            graphed = cand
-            parallel.attach(net, None)
-        else:
+        choice = order[int(pick.item())]
+        launch_note = ("auto over 4 untimed steps each (rank 0 decides): " +
+                       ", ".join(f"{k} {v * 1e3:.1f} ms" for k, v in times.items()) + f" -> {choice}")
+        if choice == "eager":
             parallel.attach(net, reducer)
+        else:
+            graphed = cands[choice]
+        dist_launch = {"eager": "eager", "split": "two hipGraphs + eager all-reduce",
+                       "segmented": "six hipGraphs (backward cut per arena segment) + overlapped eager all-reduce"}[choice]
 
     def step():
         loss = graphed() if graphed is not None else body()
@@ -550,8 +570,7 @@ def main():
                                       f"(heads {cfg['heads']}, scales {cfg['scales']}), "
                                       "fwd + Dice/CE + bwd + grad all-reduce + SGD(momentum .9, wd 1e-4)",
                           "preset": a.config, "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", **({"grad_buckets": "bf16"} if a.bf16_buckets else {}),
-                          "launch": ("eager" if graphed is None else
-                                     ("two hipGraphs + eager all-reduce" if use_dist else "hipGraph replay")),
+                          "launch": ("eager" if graphed is None else (dist_launch if use_dist else "hipGraph replay")),
                           "final_loss": round(final_loss, 5)}}
         if launch_note:
             out["config"]["launch_choice"] = launch_note

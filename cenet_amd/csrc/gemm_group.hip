@@ -20,7 +20,6 @@
 #include <cstdlib>
 
 #define GRP_MAXP 56
-#define GRP_TILE_FLOATS (64 * 64 + 64)  // a partial tile in accumulator layout + its 64 row sums
 
 struct GroupProb {  // 64 bytes
   const bf16_t* A;
@@ -51,25 +50,26 @@ __device__ __forceinline__ int grp_find(const int* first, int n, int L) {
   return lo;
 }
 
-// C[m0.., n0..] += the 64x64 tile held as acc[i][j] (fragment (i, j) of the wave's 32x32 quadrant, 4 consecutive rows per lane):
-// each wave transposes one 16-row strip at a time through LDS so that lanes run along a row of C (256 contiguous bytes per
+// C[m0.., n0..] += the BM x BN tile held as acc[i][j] (fragment (i, j) of the wave's quadrant, 4 consecutive rows per lane):
+// each wave transposes one 16-row strip at a time through LDS so that lanes run along a row of C (>= 128 contiguous bytes per
 // wave instruction).  `atomic`: another problem of the launch adds into the same C (a parameter used twice); otherwise this
 // workgroup is the tile's only writer in the launch and the add is a plain load / add / store.
-__device__ __forceinline__ void grp_add_tile(f32x4 (&acc)[2][2], float* cstrip, float* C, int ldc, int M, int N, int m0, int n0,
-                                             int wave, int lane, bool atomic) {
+template <int BM, int BN>
+__device__ __forceinline__ void grp_add_tile(f32x4 (&acc)[BM / 32][BN / 32], float* cstrip, float* C, int ldc, int M, int N, int m0,
+                                             int n0, int wave, int lane, bool atomic) {
+  constexpr int MI = BM / 32, NJ = BN / 32, WN = BN / 2;
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
-  constexpr int WN = 32;
   float* strip = cstrip + wave * (16 * (WN + 1));
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MI; ++i) {
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) strip[(fq * 4 + r) * (WN + 1) + j * 16 + fr] = acc[i][j][r];
     __syncthreads();
-    const int row0 = m0 + wm * 32 + i * 16, col0 = n0 + wn * WN;
+    const int row0 = m0 + wm * (BM / 2) + i * 16, col0 = n0 + wn * WN;
     for (int idx = lane; idx < 16 * WN; idx += 64) {
       const int r = idx / WN, c = idx - r * WN;
       if (row0 + r < M && col0 + c < N) {
@@ -82,11 +82,15 @@ __device__ __forceinline__ void grp_add_tile(f32x4 (&acc)[2][2], float* cstrip, 
   }
 }
 
-template <bool AKF, bool BKF>
-__global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs ga, float* __restrict__ ws) {
-  constexpr int BM = 64, BN = 64, NS = 4, MI = 2, NJ = 2;
+template <bool AKF, bool BKF, int BM, int BN, int NS>
+__global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) void gemm_group_kernel(GroupArgs ga,
+                                                                                                   float* __restrict__ ws) {
+  constexpr int MI = BM / 32, NJ = BN / 32;
   constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int G = (BM + BN) / 32;
+  constexpr int TILE_FLOATS = BM * BN + BM;  // a partial tile in accumulator layout + its row sums
+  static_assert(NS >= 2 && NS <= 4 && G * (NS - 2) <= 63, "ring depth");
+  static_assert(NS * STAGE >= 4 * 16 * (BN / 2 + 1) * 4, "the epilogue strip reuses the ring");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef CENET_HOSTSIM_BUILD
@@ -155,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs ga, float*
   int cur = 0;
   for (int t = 0; t < T; ++t) {
     const int young = T - 1 - t;
-    if (young >= 2) ring_wait_vm<G * 2>();
-    else if (young >= 1) ring_wait_vm<G>();
+    if (NS >= 4 && young >= 2) ring_wait_vm<G * 2 <= 63 ? G * 2 : 0>();
+    else if (NS >= 3 && young >= 1) ring_wait_vm<G>();
     else ring_wait_vm<0>();
     ring_barrier();
     if (t + NS - 1 < T) issue(it0 + t + NS - 1, cur == 0 ? NS - 1 : cur - 1);
@@ -205,26 +209,26 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs ga, float*
       float v = rsum[i];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      rsum[i] = v;  // lanes 0..15: row m0 + wm*32 + i*16 + lane
+      rsum[i] = v;  // lanes 0..15: row m0 + wm * (BM / 2) + i * 16 + lane
     }
   }
   if (splits > 1) {
     // a K slice: the raw accumulators (and row sums) go to this item's workspace slot; gemm_group_fold_kernel adds them up
-    float* slot = ws + (long)(P.ws_tile0 + tile * splits + split) * GRP_TILE_FLOATS;
+    float* slot = ws + (long)(P.ws_tile0 + tile * splits + split) * TILE_FLOATS;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) memcpy(slot + ((i * NJ + j) * 256 + tid) * 4, &acc[i][j], 16);
     if (bx == 0 && wn == 0 && lane < 16) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) slot[64 * 64 + wm * 32 + i * 16 + lane] = rsum[i];
+      for (int i = 0; i < MI; ++i) slot[BM * BN + wm * (BM / 2) + i * 16 + lane] = rsum[i];
     }
     return;
   }
   if (do_asum && lane < 16) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int row = m0 + wm * 32 + i * 16 + lane;
+      const int row = m0 + wm * (BM / 2) + i * 16 + lane;
       if (row < M) {
         if (atomic) atomicAdd(&P.asum[row], rsum[i]);
         else P.asum[row] += rsum[i];
@@ -232,62 +236,78 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs ga, float*
     }
   }
   __syncthreads();  // the ring is free: it becomes the transpose strip
-  grp_add_tile(acc, (float*)lds, P.C, N, M, N, m0, n0, wave, lane, atomic);
+  grp_add_tile<BM, BN>(acc, (float*)lds, P.C, N, M, N, m0, n0, wave, lane, atomic);
 }
 
 // second pass of the split problems: one workgroup per output tile sums the tile's K slices in slice order and adds the result
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_group_fold_kernel(GroupArgs ga, const float* __restrict__ ws) {
-  __shared__ float strip[4 * 16 * 33];
+  constexpr int MI = BM / 32, NJ = BN / 32, TILE_FLOATS = BM * BN + BM;
+  __shared__ float strip[4 * 16 * (BN / 2 + 1)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = blockIdx.x;
   const int pi = grp_find(ga.fold0, ga.nprob, L);
   const GroupProb& P = ga.p[pi];
   const int M = P.M, N = P.N, splits = P.splits;
   const bool atomic = (P.K >> 29) & 1;
-  const int tiles_n = (N + 63) / 64;
+  const int tiles_n = (N + BN - 1) / BN;
   const int tile = L - ga.fold0[pi];
   const int by = tile / tiles_n, bx = tile - by * tiles_n;
-  const float* base = ws + (long)(P.ws_tile0 + tile * splits) * GRP_TILE_FLOATS;
-  f32x4 acc[2][2];
+  const float* base = ws + (long)(P.ws_tile0 + tile * splits) * TILE_FLOATS;
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float rs = 0.f;
   for (int s = 0; s < splits; ++s) {
-    const float* slot = base + (long)s * GRP_TILE_FLOATS;
+    const float* slot = base + (long)s * TILE_FLOATS;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         f32x4 v;
-        memcpy(&v, slot + ((i * 2 + j) * 256 + tid) * 4, 16);
+        memcpy(&v, slot + ((i * NJ + j) * 256 + tid) * 4, 16);
         acc[i][j] += v;
       }
-    if (bx == 0 && P.asum && tid < 64) rs += slot[64 * 64 + tid];
+    if (bx == 0 && P.asum && tid < BM) rs += slot[BM * BN + tid];
   }
-  if (bx == 0 && P.asum && tid < 64 && by * 64 + tid < M) {
-    if (atomic) atomicAdd(&P.asum[by * 64 + tid], rs);
-    else P.asum[by * 64 + tid] += rs;
+  if (bx == 0 && P.asum && tid < BM && by * BM + tid < M) {
+    if (atomic) atomicAdd(&P.asum[by * BM + tid], rs);
+    else P.asum[by * BM + tid] += rs;
   }
-  grp_add_tile(acc, strip, P.C, N, M, N, by * 64, bx * 64, wave, lane, atomic);
+  grp_add_tile<BM, BN>(acc, strip, P.C, N, M, N, by * BM, bx * BN, wave, lane, atomic);
 }
 
-// ---- host side: plan (K slices per problem), table, launches ------------------------------------------------------------
+// ---- host side: tile shape, plan (K slices per problem), table, launches ------------------------------------------------
 struct GrpPlan {
   int splits, tiles, steps;
+};
+struct GrpTile {
+  int bm, bn, ns;
 };
 static long grp_env(const char* name, long dflt) {
   const char* v = getenv(name);
   return v ? atol(v) : dflt;
 }
-// One launch = problems [p0, p1) of one orientation.  Every item should reduce about `depth` K-steps: deep enough to amortise
-// the ring's fill and the epilogue, shallow enough that the launch has a few items per workgroup slot (512 resident workgroups).
-static void grp_plan(const cenet_wgrad_prob_t* p, int n, GrpPlan* out) {
+// Tile shape per problem class, from a sweep over the weight-gradient sets of a training step (tools/wgrad_bench.py, B = 32):
+// outputs with both sides >= 128 (stages 2 - 4, the DSEB projections, the upper decoder levels) run fastest on 128x128 tiles
+// with a 2-stage ring (half the operand bytes through LDS per FLOP: 234 vs 381 us for stage 2, 297 vs 477 us for stage 3);
+// skinny outputs (stage 1: 64 .. 512 x 64) keep the 64x64 tile with its 4-stage ring (304 vs 385 us).
+static GrpTile grp_tile(int cls) {
+  GrpTile t = cls ? GrpTile{128, 128, 2} : GrpTile{64, 64, 4};
+  const char* v = getenv("CENET_GROUP_TILE");  // "128x128x2" etc. for every problem: measurement aid
+  if (v) sscanf(v, "%dx%dx%d", &t.bm, &t.bn, &t.ns);
+  return t;
+}
+static int grp_class(const cenet_wgrad_prob_t& q) { return (q.M >= 128 && q.N >= 128) ? 1 : 0; }
+// One launch = up to GRP_MAXP problems of one orientation and one tile class.  Every item should reduce about `depth` K-steps:
+// deep enough to amortise the ring's fill and the epilogue, shallow enough that the launch has a few items per workgroup slot.
+static void grp_plan(const cenet_wgrad_prob_t* p, int n, GrpTile t, GrpPlan* out) {
   const long min_depth = grp_env("CENET_GROUP_DEPTH", 32), slots = grp_env("CENET_GROUP_ITEMS", 1536);  // (tuning aids)
   long work = 0;
   for (int i = 0; i < n; ++i) {
-    out[i].tiles = cdiv(p[i].M, 64) * cdiv(p[i].N, 64);
+    out[i].tiles = cdiv(p[i].M, t.bm) * cdiv(p[i].N, t.bn);
     out[i].steps = p[i].nkb * cdiv(p[i].K, 64);
     work += (long)out[i].tiles * out[i].steps;
   }
@@ -306,29 +326,53 @@ static bool grp_ok(const cenet_wgrad_prob_t& q) {
          q.K < (1 << 28) && q.lda >= 0 && q.ldb >= 0 && q.skbA >= 0 && q.skbB >= 0 && q.lda < (1L << 31) && q.ldb < (1L << 31) &&
          q.skbA < (1L << 31) && q.skbB < (1L << 31) && q.akf == q.bkf;
 }
+// the partition of a call into launches: orientation (0: row-fast operands, 1: k-fast) x tile class, in chunks of GRP_MAXP
+// problems in their given order; fn(sel, m, orientation, tile) returns false to stop
+template <typename F>
+static void grp_for_each_launch(const cenet_wgrad_prob_t* p, int n, F fn) {
+  for (int o = 0; o < 2; ++o)
+    for (int c = 0; c < 2; ++c) {
+      cenet_wgrad_prob_t sel[GRP_MAXP];
+      int m = 0;
+      for (int i = 0; i < n; ++i) {
+        if ((p[i].akf != 0) != (o != 0) || grp_class(p[i]) != c) continue;
+        sel[m++] = p[i];
+        if (m == GRP_MAXP) {
+          if (!fn(sel, m, o, grp_tile(c))) return;
+          m = 0;
+        }
+      }
+      if (m && !fn(sel, m, o, grp_tile(c))) return;
+    }
+}
+
+template <bool KF, int BM, int BN, int NS>
+static void grp_launch(const GroupArgs& ga, float* ws, int items, int folds, int phase, hipStream_t stream) {
+  if (phase != 2) CENET_LAUNCH((gemm_group_kernel<KF, KF, BM, BN, NS>), dim3(items), dim3(256), stream, ga, ws);
+  if (folds && phase != 1) CENET_LAUNCH((gemm_group_fold_kernel<BM, BN>), dim3(folds), dim3(256), stream, ga, (const float*)ws);
+}
+template <bool KF>
+static int grp_launch_tile(const GroupArgs& ga, GrpTile t, float* ws, int items, int folds, int phase, hipStream_t stream) {
+  if (t.bm == 64 && t.bn == 64 && t.ns == 4) grp_launch<KF, 64, 64, 4>(ga, ws, items, folds, phase, stream);
+  else if (t.bm == 128 && t.bn == 128 && t.ns == 2) grp_launch<KF, 128, 128, 2>(ga, ws, items, folds, phase, stream);
+  else if (t.bm == 128 && t.bn == 128 && t.ns == 3) grp_launch<KF, 128, 128, 3>(ga, ws, items, folds, phase, stream);
+  else if (t.bm == 128 && t.bn == 64 && t.ns == 3) grp_launch<KF, 128, 64, 3>(ga, ws, items, folds, phase, stream);
+  else if (t.bm == 64 && t.bn == 128 && t.ns == 3) grp_launch<KF, 64, 128, 3>(ga, ws, items, folds, phase, stream);
+  else return CENET_EUNSUPPORTED;
+  return CENET_OK;
+}
 
 extern "C" long cenet_wgrad_group_ws_floats(const cenet_wgrad_prob_t* p, int n) {
   if (!p || n <= 0) return 0;
-  long slots = 0;
-  for (int o = 0; o < 2; ++o) {  // same partition into launches as cenet_wgrad_group_bf16
-    cenet_wgrad_prob_t sel[GRP_MAXP];
+  long floats = 0;
+  grp_for_each_launch(p, n, [&](const cenet_wgrad_prob_t* sel, int m, int, GrpTile t) {
     GrpPlan plan[GRP_MAXP];
-    int m = 0;
-    auto flush = [&]() {
-      if (!m) return;
-      grp_plan(sel, m, plan);
-      for (int i = 0; i < m; ++i)
-        if (plan[i].splits > 1) slots += (long)plan[i].tiles * plan[i].splits;
-      m = 0;
-    };
-    for (int i = 0; i < n; ++i) {
-      if ((p[i].akf != 0) != (o != 0)) continue;
-      sel[m++] = p[i];
-      if (m == GRP_MAXP) flush();
-    }
-    flush();
-  }
-  return slots * GRP_TILE_FLOATS;
+    grp_plan(sel, m, t, plan);
+    for (int i = 0; i < m; ++i)
+      if (plan[i].splits > 1) floats += (long)plan[i].tiles * plan[i].splits * ((long)t.bm * t.bn + t.bm);
+    return true;
+  });
+  return floats;
 }
 
 // phase 0: the whole reduction; 1: the K-slice launches only; 2: the fold launches only (1 then 2 on the same arguments = 0;
@@ -337,67 +381,56 @@ static int wgrad_group_impl(const cenet_wgrad_prob_t* p, int n, float* ws, long 
   if (!p || n <= 0 || phase < 0 || phase > 2) return CENET_EINVAL;
   for (int i = 0; i < n; ++i)
     if (!grp_ok(p[i])) return p[i].akf != p[i].bkf ? CENET_EUNSUPPORTED : CENET_EINVAL;
-  long ws_used = 0;
-  for (int o = 0; o < 2; ++o) {
-    cenet_wgrad_prob_t sel[GRP_MAXP];
+  long ws_used = 0;  // floats handed out so far: every launch gets its own stretch of the workspace
+  int rc = CENET_OK;
+  grp_for_each_launch(p, n, [&](const cenet_wgrad_prob_t* sel, int m, int o, GrpTile t) {
+    const long tile_floats = (long)t.bm * t.bn + t.bm;
     GrpPlan plan[GRP_MAXP];
-    int m = 0;
-    int rc = CENET_OK;
-    auto flush = [&]() {
-      if (!m) return;
-      grp_plan(sel, m, plan);
-      GroupArgs ga;
-      memset(&ga, 0, sizeof ga);
-      ga.nprob = m;
-      int items = 0, folds = 0;
-      for (int i = 0; i < m; ++i) {
-        const cenet_wgrad_prob_t& q = sel[i];
-        GroupProb& d = ga.p[i];
-        d.A = (const bf16_t*)q.A;
-        d.B = (const bf16_t*)q.B;
-        d.C = q.C;
-        d.asum = q.asum;
-        d.lda = (int)q.lda; d.ldb = (int)q.ldb; d.skbA = (int)q.skbA; d.skbB = (int)q.skbB;
-        d.M = (unsigned short)q.M; d.N = (unsigned short)q.N; d.nkb = (unsigned short)q.nkb;
-        d.splits = (unsigned short)plan[i].splits;
-        // 16-byte chunks on 16-byte boundaries, or the 2-byte-aligned LDS-DMA form with hand-fetched final chunks (gemm.hip)
-        auto e8 = [](long v) { return (v & 7) == 0; };
-        const bool a_al = e8(q.skbA) && (((uintptr_t)q.A & 15) == 0) && e8(q.lda) && e8(q.akf ? q.K : q.M);
-        const bool b_al = e8(q.skbB) && (((uintptr_t)q.B & 15) == 0) && e8(q.ldb) && e8(q.bkf ? q.K : q.N);
-        bool dup = false;  // another problem of this launch adds into the same C / asum: atomics
-        for (int j = 0; j < m && !dup; ++j) dup = j != i && (sel[j].C == q.C || (q.asum && sel[j].asum == q.asum));
-        d.K = q.K | ((a_al && b_al) ? 0 : (1 << 28)) | (dup ? (1 << 29) : 0);
-        ga.item0[i] = items;
-        ga.fold0[i] = folds;
-        items += plan[i].tiles * plan[i].splits;
-        if (plan[i].splits > 1) {
-          d.ws_tile0 = (int)(ws_used / GRP_TILE_FLOATS);
-          ws_used += (long)plan[i].tiles * plan[i].splits * GRP_TILE_FLOATS;
-          folds += plan[i].tiles;
-        }
+    grp_plan(sel, m, t, plan);
+    GroupArgs ga;
+    memset(&ga, 0, sizeof ga);
+    ga.nprob = m;
+    int items = 0, folds = 0;
+    float* wsl = ws ? ws + ws_used : nullptr;
+    long used = 0;
+    for (int i = 0; i < m; ++i) {
+      const cenet_wgrad_prob_t& q = sel[i];
+      GroupProb& d = ga.p[i];
+      d.A = (const bf16_t*)q.A;
+      d.B = (const bf16_t*)q.B;
+      d.C = q.C;
+      d.asum = q.asum;
+      d.lda = (int)q.lda; d.ldb = (int)q.ldb; d.skbA = (int)q.skbA; d.skbB = (int)q.skbB;
+      d.M = (unsigned short)q.M; d.N = (unsigned short)q.N; d.nkb = (unsigned short)q.nkb;
+      d.splits = (unsigned short)plan[i].splits;
+      // 16-byte chunks on 16-byte boundaries, or the 2-byte-aligned LDS-DMA form with hand-fetched final chunks (gemm.hip)
+      auto e8 = [](long v) { return (v & 7) == 0; };
+      const bool a_al = e8(q.skbA) && (((uintptr_t)q.A & 15) == 0) && e8(q.lda) && e8(q.akf ? q.K : q.M);
+      const bool b_al = e8(q.skbB) && (((uintptr_t)q.B & 15) == 0) && e8(q.ldb) && e8(q.bkf ? q.K : q.N);
+      int same_c = 0, same_s = 0;  // another problem of this call adds into the same C / asum (a parameter used twice): atomics
+      for (int j = 0; j < n; ++j) same_c += p[j].C == q.C, same_s += (q.asum && p[j].asum == q.asum);
+      const bool dup = same_c > 1 || same_s > 1;
+      d.K = q.K | ((a_al && b_al) ? 0 : (1 << 28)) | (dup ? (1 << 29) : 0);
+      ga.item0[i] = items;
+      ga.fold0[i] = folds;
+      items += plan[i].tiles * plan[i].splits;
+      if (plan[i].splits > 1) {
+        d.ws_tile0 = (int)(used / tile_floats);
+        used += (long)plan[i].tiles * plan[i].splits * tile_floats;
+        folds += plan[i].tiles;
       }
-      for (int i = m; i <= GRP_MAXP; ++i) ga.item0[i] = items, ga.fold0[i] = folds;
-      ga.nitems = items;
-      if (ws_used > ws_floats || (ws_used && !ws)) {
-        rc = CENET_EINVAL;
-        m = 0;
-        return;
-      }
-      if (phase != 2) {
-        if (o) CENET_LAUNCH((gemm_group_kernel<true, true>), dim3(items), dim3(256), stream, ga, ws);
-        else CENET_LAUNCH((gemm_group_kernel<false, false>), dim3(items), dim3(256), stream, ga, ws);
-      }
-      if (folds && phase != 1) CENET_LAUNCH(gemm_group_fold_kernel, dim3(folds), dim3(256), stream, ga, (const float*)ws);
-      m = 0;
-    };
-    for (int i = 0; i < n && rc == CENET_OK; ++i) {
-      if ((p[i].akf != 0) != (o != 0)) continue;
-      sel[m++] = p[i];
-      if (m == GRP_MAXP) flush();
     }
-    if (rc == CENET_OK) flush();
-    if (rc != CENET_OK) return rc;
-  }
+    for (int i = m; i <= GRP_MAXP; ++i) ga.item0[i] = items, ga.fold0[i] = folds;
+    ga.nitems = items;
+    ws_used += used;
+    if (ws_used > ws_floats || (used && !ws)) {
+      rc = CENET_EINVAL;
+      return false;
+    }
+    rc = o ? grp_launch_tile<true>(ga, t, wsl, items, folds, phase, stream) : grp_launch_tile<false>(ga, t, wsl, items, folds, phase, stream);
+    return rc == CENET_OK;
+  });
+  if (rc != CENET_OK) return rc;
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -96,3 +96,116 @@ class GraphedSplitStep:
         self.graph_b.replay()
         self.optimizer._steps += 1
         return self.loss
+
+
+def enable_segment_cuts(net):
+    """CENet / DataParallel(CENet): from the next training forward on, the four encoder stage outputs are cut out of the autograd
+    graph (pvtv2.forward_features) and listed in the returned list as (stage output, leaf) pairs, stage 1 first."""
+    net = getattr(net, "module", net)
+    net.backbone.segment_cuts = []
+    return net.backbone.segment_cuts
+
+
+def disable_segment_cuts(net):
+    getattr(net, "module", net).backbone.segment_cuts = None
+
+
+def backward_pieces(loss: torch.Tensor, cuts):
+    """The backward pass of a forward made with segment cuts, as five callables in gradient-arena order
+    (cenet_amd.optim.cenet_segments): piece 0 differentiates the loss down to the cut leaves (head + decoder parameters final),
+    piece k = 1..4 differentiates encoder stage 5 - k from the gradient its leaf has collected (that stage's parameters final;
+    the leaf below it receives its last contribution).  Each piece is its own autograd-engine run, so the recorded (grouped)
+    weight gradients of a segment are launched when its piece ends (ops._WgradQueue)."""
+    def head():
+        loss.backward()
+    pieces = [head]
+    for t, leaf in reversed(cuts):
+        def stage(t=t, leaf=leaf):
+            torch.autograd.backward([t], [leaf.grad])
+        pieces.append(stage)
+    return pieces
+
+
+class SegmentedStep:
+    """Data-parallel step that keeps the backward / all-reduce overlap under hipGraph replay (bench.py, N > 1).
+
+        graph 0 : zero_grad -> forward -> loss -> backward piece 0 (head + decoder)
+        eager   : on_segment(0)      GradReducer.segment_ready(0): the segment's all-reduce starts on the communication stream
+        graph k : backward piece k   (encoder stage 5 - k), k = 1..4, each followed by on_segment(k)
+        eager   : finish()           GradReducer.finish(): the compute stream waits for the five collectives
+        graph 5 : optimizer.step(sync_hyper=False)
+
+    ~15 host calls per step instead of ~1 300 eager launches, and — unlike GraphedSplitStep, which reduces everything after one
+    big backward graph — segment k's collective runs beside graphs k+1..4.  Collectives stay outside the captures (capturing
+    them aborted inside RCCL on this stack).  `graphs=False` runs the same pieces eagerly (CPU tests, gloo)."""
+
+    def __init__(self, net, fwd_loss_fn: Callable[[], torch.Tensor], optimizer, on_segment: Callable[[int], None],
+                 finish: Callable[[], None], graphs: bool = True, warmup: int = 2):
+        self.net, self.fwd_loss_fn, self.optimizer = net, fwd_loss_fn, optimizer
+        self.on_segment, self.finish = on_segment, finish
+        self.graphs = None
+        if not graphs:
+            return
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                optimizer.prepare()
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        optimizer.prepare()
+        self.cuts = enable_segment_cuts(net)
+        # capture: thread-local error mode after a full drain (the process group's watchdog polls events of in-flight
+        # collectives from another thread, see GraphedSplitStep)
+        self.graphs = []
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0, capture_error_mode="thread_local"):
+            optimizer.zero_grad()
+            self.loss = fwd_loss_fn()
+            pieces = backward_pieces(self.loss, self.cuts)
+            pieces[0]()
+        self.graphs.append(g0)
+        on_segment(0)
+        for k in range(1, 5):
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=g0.pool(), capture_error_mode="thread_local"):
+                pieces[k]()
+            self.graphs.append(g)
+            on_segment(k)
+        finish()
+        torch.cuda.synchronize()
+        gs = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gs, pool=g0.pool(), capture_error_mode="thread_local"):
+            optimizer.step(sync_hyper=False)
+        optimizer._steps -= 1
+        self.graphs.append(gs)
+        torch.cuda.synchronize()
+        disable_segment_cuts(net)  # replays run no Python forward; eager forwards of the same model are whole again
+
+    def _eager(self):
+        cuts = enable_segment_cuts(self.net)
+        try:
+            self.optimizer.zero_grad()
+            loss = self.fwd_loss_fn()
+            for k, piece in enumerate(backward_pieces(loss, cuts)):
+                piece()
+                self.on_segment(k)
+        finally:
+            disable_segment_cuts(self.net)
+        self.finish()
+        self.optimizer.step(sync_hyper=False)
+        return loss
+
+    def __call__(self) -> torch.Tensor:
+        self.optimizer.prepare()
+        if self.graphs is None:
+            return self._eager()
+        for k in range(5):
+            self.graphs[k].replay()
+            self.on_segment(k)
+        self.finish()
+        self.graphs[5].replay()
+        self.optimizer._steps += 1
+        return self.loss

@@ -230,6 +230,10 @@ class PyramidVisionTransformerImpr(nn.Module):
         outs = []
         if self.training:
             self._sample_drop_path(x.shape[0], x.device)
+        cuts = None
+        if getattr(self, "segment_cuts", None) is not None and self.training and torch.is_grad_enabled():
+            cuts = self.segment_cuts
+            del cuts[:]
         t = None
         for s in range(4):
             t, H, W = getattr(self, f"patch_embed{s + 1}")(x, t)  # (positional: module backward hooks only see positional inputs)
@@ -237,6 +241,13 @@ class PyramidVisionTransformerImpr(nn.Module):
                 t = blk(t, H, W)
             n = getattr(self, f"norm{s + 1}")
             t = ops.layernorm(t, n.weight, n.bias, n.eps)
+            if cuts is not None and t.requires_grad:
+                # segmented backward (cenet_amd.graph.SegmentedStep): the stage's token output is cut out of the autograd graph;
+                # its consumers (the decoder's NCHW copy, the next stage's patch embedding) read a leaf whose .grad collects
+                # their gradients, and the stage itself is differentiated later by autograd.backward([t], [leaf.grad])
+                leaf = t.detach().requires_grad_(True)
+                cuts.append((t, leaf))
+                t = leaf
             x = ops.tok_to_nchw(t, H, W)
             outs.append(x)
         return outs

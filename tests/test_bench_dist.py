@@ -39,7 +39,8 @@ def test_bench_single_process_contract():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--bf16-buckets"]])
+@pytest.mark.parametrize("extra", [[], ["--bf16-buckets"], ["--dist-launch", "segmented"], ["--dist-launch", "split"],
+                                   ["--dist-launch", "eager"]])
 def test_bench_under_torchrun_with_rccl_group(extra):
     env = dict(os.environ, CENET_FORCE_DIST="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
@@ -50,6 +51,9 @@ def test_bench_under_torchrun_with_rccl_group(extra):
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
     assert d["config"]["final_loss"] == d["config"]["final_loss"]  # not NaN
+    if "--dist-launch" in extra:
+        want = {"segmented": "six hipGraphs", "split": "two hipGraphs", "eager": "eager"}[extra[-1]]
+        assert d["config"]["launch"].startswith(want), d["config"]["launch"]
 
 
 @pytest.mark.gpu

@@ -10,7 +10,7 @@ import torch
 
 import bench
 from cenet_amd import kern, losses, ops, optim
-from cenet_amd.graph import GraphedSplitStep, GraphedStep
+from cenet_amd.graph import GraphedSplitStep, GraphedStep, SegmentedStep
 
 pytestmark = pytest.mark.gpu
 
@@ -47,8 +47,10 @@ def _train(net, dev, mode, steps=4, B=4):
     else:
         if mode == "graph":
             g = GraphedStep(body, optimizer=opt, warmup=1)
-        else:
+        elif mode == "split":
             g = GraphedSplitStep(fwd_bwd, opt, lambda: None, warmup=1)
+        else:  # five backward graphs cut at the encoder stage outputs + the SGD graph (the N > 1 form that keeps the overlap)
+            g = SegmentedStep(net, lambda: crit(net(x), lab), opt, lambda k: None, lambda: None, warmup=1)
         # warm-up + capture already trained 2 steps on this batch
         for _ in range(steps - 2):
             out.append(float(g().detach()))
@@ -58,7 +60,7 @@ def _train(net, dev, mode, steps=4, B=4):
     return out, arena.params.clone()
 
 
-@pytest.mark.parametrize("mode", ["graph", "split"])
+@pytest.mark.parametrize("mode", ["graph", "split", "segmented"])
 def test_replay_trains_like_eager(mode):
     dev = torch.device("cuda:0")
     old_bf, old_ov = kern.set_compute_bf16(True), ops.set_wgrad_overlap(True)

@@ -62,7 +62,9 @@ def _check(probs, outs, tol=2e-3):
 def test_mixed_problem_list(dev):
     g = torch.Generator().manual_seed(3)
     probs = [_lin_problem(g, 200, 64, 64, dev), _lin_problem(g, 130, 72, 136, dev), _lin_problem(g, 77, 48, 200, dev, bias=False),
-             _conv_problem(g, 3, 64, 64, 49, dev), _conv_problem(g, 2, 80, 56, 196, dev), _conv_problem(g, 2, 96, 64, 64, dev, bias=False)]
+             _conv_problem(g, 3, 64, 64, 49, dev), _conv_problem(g, 2, 80, 56, 196, dev), _conv_problem(g, 2, 96, 64, 64, dev, bias=False),
+             # both sides >= 128: the 128x128 tile class (a second launch per orientation inside the same call)
+             _lin_problem(g, 150, 136, 192, dev), _conv_problem(g, 2, 128, 160, 100, dev), _lin_problem(g, 90, 256, 128, dev, bias=False)]
     outs = _run(probs, dev)
     _check(probs, outs)
 
