@@ -101,10 +101,14 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
   const int wm = wave >> 1, wn = wave & 1;
   int L = blockIdx.x;
   {
-    const int T = gridDim.x;
-    if (T >= 64) {  // XCD-aware order: consecutive items (the tiles of one K slice, which share operand rows) on one L2
-      const int per = T >> 3, rem = T & 7, xcd = L & 7, idx = L >> 3;
-      L = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    // XCD-aware order, block-cyclic: workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Runs of 8
+    // consecutive items (tiles of one K slice, which share operand rows) go to ONE XCD, and the runs are dealt over the XCDs
+    // in turn — contiguous eighths of the item list (as in the single-problem GEMM) would hand each XCD a different mix of
+    // problems, and the XCDs of a grouped launch would finish far apart.
+    const int T = gridDim.x, full = T & ~63;
+    if (L < full) {
+      const int q = L >> 6, r = L & 63;
+      L = (q << 6) + ((r & 7) << 3) + (r >> 3);
     }
   }
   const int pi = grp_find(ga.item0, ga.nprob, L);
@@ -239,13 +243,16 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
   grp_add_tile<BM, BN>(acc, (float*)lds, P.C, N, M, N, m0, n0, wave, lane, atomic);
 }
 
-// second pass of the split problems: one workgroup per output tile sums the tile's K slices in slice order and adds the result
+// second pass of the split problems: blockIdx.y = i picks the i-th 16-row strip of each wave's quadrant, so a tile is folded by
+// BM / 32 workgroups (one per output tile left most of the chip idle behind a serial chain of partial-tile reads); each sums
+// its rows of the tile's K slices in slice order and adds the result
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_group_fold_kernel(GroupArgs ga, const float* __restrict__ ws) {
-  constexpr int MI = BM / 32, NJ = BN / 32, TILE_FLOATS = BM * BN + BM;
-  __shared__ float strip[4 * 16 * (BN / 2 + 1)];
+  constexpr int NJ = BN / 32, WN = BN / 2, TILE_FLOATS = BM * BN + BM;
+  __shared__ float strip_all[4 * 16 * (WN + 1)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int L = blockIdx.x;
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+  const int L = blockIdx.x, i = blockIdx.y;
   const int pi = grp_find(ga.fold0, ga.nprob, L);
   const GroupProb& P = ga.p[pi];
   const int M = P.M, N = P.N, splits = P.splits;
@@ -254,29 +261,42 @@ __global__ __launch_bounds__(256) void gemm_group_fold_kernel(GroupArgs ga, cons
   const int tile = L - ga.fold0[pi];
   const int by = tile / tiles_n, bx = tile - by * tiles_n;
   const float* base = ws + (long)(P.ws_tile0 + tile * splits) * TILE_FLOATS;
-  f32x4 acc[MI][NJ];
+  f32x4 acc[NJ];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float rs = 0.f;
+  const bool do_rs = bx == 0 && P.asum && i == 0 && tid < BM;
   for (int s = 0; s < splits; ++s) {
     const float* slot = base + (long)s * TILE_FLOATS;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        f32x4 v;
-        memcpy(&v, slot + ((i * NJ + j) * 256 + tid) * 4, 16);
-        acc[i][j] += v;
-      }
-    if (bx == 0 && P.asum && tid < BM) rs += slot[BM * BN + tid];
+    for (int j = 0; j < NJ; ++j) {
+      f32x4 v;
+      memcpy(&v, slot + ((i * NJ + j) * 256 + tid) * 4, 16);
+      acc[j] += v;
+    }
+    if (do_rs) rs += slot[BM * BN + tid];
   }
-  if (bx == 0 && P.asum && tid < BM && by * BM + tid < M) {
+  if (do_rs && by * BM + tid < M) {
     if (atomic) atomicAdd(&P.asum[by * BM + tid], rs);
     else P.asum[by * BM + tid] += rs;
   }
-  grp_add_tile<BM, BN>(acc, strip, P.C, N, M, N, by * BM, bx * BN, wave, lane, atomic);
+  // the strip transposition of grp_add_tile for this i alone
+  float* strip = strip_all + wave * (16 * (WN + 1));
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) strip[(fq * 4 + r) * (WN + 1) + j * 16 + fr] = acc[j][r];
+  __syncthreads();
+  const int row0 = by * BM + wm * (BM / 2) + i * 16, col0 = bx * BN + wn * WN;
+  for (int idx = lane; idx < 16 * WN; idx += 64) {
+    const int r = idx / WN, c = idx - r * WN;
+    if (row0 + r < M && col0 + c < N) {
+      float* p = &P.C[(long)(row0 + r) * N + col0 + c];
+      const float v = strip[r * (WN + 1) + c];
+      if (atomic) atomicAdd(p, v);
+      else *p += v;
+    }
+  }
 }
 
 // ---- host side: tile shape, plan (K slices per problem), table, launches ------------------------------------------------
@@ -314,7 +334,9 @@ static void grp_plan(const cenet_wgrad_prob_t* p, int n, GrpTile t, GrpPlan* out
   long depth = (work + slots - 1) / slots;
   if (depth < min_depth) depth = min_depth;
   for (int i = 0; i < n; ++i) {
-    long s = (out[i].steps + depth / 2) / depth;
+    // a 2-way split doubles the tile's trips through the workspace for little balance: slice only reductions of >= 3 depths
+    long s = out[i].steps / depth;
+    if (s < 3) s = 1;
     if (s > out[i].steps / 8) s = out[i].steps / 8;
     if (s > 256) s = 256;
     if (s < 1) s = 1;
@@ -349,7 +371,8 @@ static void grp_for_each_launch(const cenet_wgrad_prob_t* p, int n, F fn) {
 template <bool KF, int BM, int BN, int NS>
 static void grp_launch(const GroupArgs& ga, float* ws, int items, int folds, int phase, hipStream_t stream) {
   if (phase != 2) CENET_LAUNCH((gemm_group_kernel<KF, KF, BM, BN, NS>), dim3(items), dim3(256), stream, ga, ws);
-  if (folds && phase != 1) CENET_LAUNCH((gemm_group_fold_kernel<BM, BN>), dim3(folds), dim3(256), stream, ga, (const float*)ws);
+  if (folds && phase != 1)
+    CENET_LAUNCH((gemm_group_fold_kernel<BM, BN>), dim3(folds, BM / 32), dim3(256), stream, ga, (const float*)ws);
 }
 template <bool KF>
 static int grp_launch_tile(const GroupArgs& ga, GrpTile t, float* ws, int items, int folds, int phase, hipStream_t stream) {
@@ -387,6 +410,17 @@ static int wgrad_group_impl(const cenet_wgrad_prob_t* p, int n, float* ws, long 
     const long tile_floats = (long)t.bm * t.bn + t.bm;
     GrpPlan plan[GRP_MAXP];
     grp_plan(sel, m, t, plan);
+    // longest items first: the items of a launch are started in list order, so the deep reductions begin at once and the
+    // shallow ones fill the tail (stable insertion sort on steps per item)
+    int ord[GRP_MAXP];
+    for (int i = 0; i < m; ++i) ord[i] = i;
+    auto depth_of = [&](int i) { return cdiv(plan[i].steps, plan[i].splits); };
+    for (int i = 1; i < m; ++i) {
+      const int v = ord[i];
+      int j = i;
+      while (j > 0 && depth_of(ord[j - 1]) < depth_of(v)) ord[j] = ord[j - 1], --j;
+      ord[j] = v;
+    }
     GroupArgs ga;
     memset(&ga, 0, sizeof ga);
     ga.nprob = m;
@@ -394,7 +428,8 @@ static int wgrad_group_impl(const cenet_wgrad_prob_t* p, int n, float* ws, long 
     float* wsl = ws ? ws + ws_used : nullptr;
     long used = 0;
     for (int i = 0; i < m; ++i) {
-      const cenet_wgrad_prob_t& q = sel[i];
+      const cenet_wgrad_prob_t& q = sel[ord[i]];
+      const GrpPlan& pl = plan[ord[i]];
       GroupProb& d = ga.p[i];
       d.A = (const bf16_t*)q.A;
       d.B = (const bf16_t*)q.B;
@@ -402,7 +437,7 @@ static int wgrad_group_impl(const cenet_wgrad_prob_t* p, int n, float* ws, long 
       d.asum = q.asum;
       d.lda = (int)q.lda; d.ldb = (int)q.ldb; d.skbA = (int)q.skbA; d.skbB = (int)q.skbB;
       d.M = (unsigned short)q.M; d.N = (unsigned short)q.N; d.nkb = (unsigned short)q.nkb;
-      d.splits = (unsigned short)plan[i].splits;
+      d.splits = (unsigned short)pl.splits;
       // 16-byte chunks on 16-byte boundaries, or the 2-byte-aligned LDS-DMA form with hand-fetched final chunks (gemm.hip)
       auto e8 = [](long v) { return (v & 7) == 0; };
       const bool a_al = e8(q.skbA) && (((uintptr_t)q.A & 15) == 0) && e8(q.lda) && e8(q.akf ? q.K : q.M);
@@ -413,11 +448,11 @@ static int wgrad_group_impl(const cenet_wgrad_prob_t* p, int n, float* ws, long 
       d.K = q.K | ((a_al && b_al) ? 0 : (1 << 28)) | (dup ? (1 << 29) : 0);
       ga.item0[i] = items;
       ga.fold0[i] = folds;
-      items += plan[i].tiles * plan[i].splits;
-      if (plan[i].splits > 1) {
+      items += pl.tiles * pl.splits;
+      if (pl.splits > 1) {
         d.ws_tile0 = (int)(used / tile_floats);
-        used += (long)plan[i].tiles * plan[i].splits * tile_floats;
-        folds += plan[i].tiles;
+        used += (long)pl.tiles * pl.splits * tile_floats;
+        folds += pl.tiles;
       }
     }
     for (int i = m; i <= GRP_MAXP; ++i) ga.item0[i] = items, ga.fold0[i] = folds;

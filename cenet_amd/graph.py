@@ -116,12 +116,17 @@ def backward_pieces(loss: torch.Tensor, cuts):
     piece k = 1..4 differentiates encoder stage 5 - k from the gradient its leaf has collected (that stage's parameters final;
     the leaf below it receives its last contribution).  Each piece is its own autograd-engine run, so the recorded (grouped)
     weight gradients of a segment are launched when its piece ends (ops._WgradQueue)."""
+    from . import ops
+
     def head():
         loss.backward()
+        ops.wgrad_join()  # a piece ends with all of ITS weight gradients issued on the compute stream (and, inside a capture,
+                          # with the weight-gradient stream joined: a graph must not end with unjoined work)
     pieces = [head]
     for t, leaf in reversed(cuts):
         def stage(t=t, leaf=leaf):
             torch.autograd.backward([t], [leaf.grad])
+            ops.wgrad_join()
         pieces.append(stage)
     return pieces
 

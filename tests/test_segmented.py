@@ -89,16 +89,18 @@ def test_pieces_leave_the_oracle_gradient_and_each_segment_is_final_after_its_pi
 @pytest.mark.gpu
 @pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
 def test_pieces_equal_one_backward_on_the_gpu(bf16):
-    """the cut backward against the whole backward of the same forward, both storage modes, at 224x224"""
+    """the cut backward against the whole backward of the same forward, both storage modes, at 224x224 — on the
+    well-conditioned point of tests/test_wellcond.py (reference initialisation, batch 8): at the random-filled golden points
+    two bf16 evaluations of the SAME backward differ by ~20 % in relative L2 through the order of fp32 atomics alone"""
     from backend import use_hip
     from cenet_amd import graph, kern, ops, optim
-    from oracle import cenet_oracle as O
+    import test_wellcond as W
     dev_ = use_hip()
-    net = _net().to(dev_)
+    net, x, lab = W.build_product(W.golden(), dev_)
+    net.train()
+    net.backbone.reset_drop_path(0.0)
     arena = optim.ParamArena(net, optim.cenet_segments())
     crit = _crit()
-    x, lab = O.synthetic_batch(2, 1, 4, seed=3)
-    x, lab = x.to(dev_), lab.to(dev_)
     old = kern.set_compute_bf16(bf16)
     try:
         arena.zero_grad()
@@ -120,7 +122,7 @@ def test_pieces_equal_one_backward_on_the_gpu(bf16):
     for k, (name, s, e) in enumerate(arena.segments):
         assert torch.equal(snaps[k], arena.grads[s:e]), f"segment {name} changed after its piece"
     # same kernels on the same values; only the order of float atomics (and, in bf16, of the two-term leaf sums) differs
-    assert ((arena.grads - whole).norm() / whole.norm()).item() < (2e-2 if bf16 else 2e-5)
+    assert ((arena.grads - whole).norm() / whole.norm()).item() < (1e-2 if bf16 else 2e-5)
 
 
 def _worker(rank, world, port, q):
