@@ -51,6 +51,14 @@ typedef short da_s4 __attribute__((ext_vector_type(4)));
 // v_max it otherwise puts in front of fmaxf on MFMA results.  (NOT inline asm: hipcc pads no MFMA -> VALU wait states for
 // an asm statement that reads accumulator registers, cdna_hip_programming.md §5.7 — the asm form read stale scores.)
 __device__ __forceinline__ float da_max3(float a, float b, float c3) { return fmaxf(fmaxf(a, b), c3); }
+// wave-level ordering point between LDS stores and loads of the SAME wave
+__device__ __forceinline__ void da_wave_sync() {
+#ifdef CENET_HOSTSIM_BUILD
+  hipsim::wave_barrier();
+#else
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
 
 struct DiffArgs {
   const bf *q, *k, *v;  // row-major: q, k [B, N, 2H*hd] ; v [B, N, H*2hd]
@@ -753,45 +761,58 @@ struct SraArgs {
   float scale;
 };
 
-__global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
+// NKB = 64-key blocks resident in LDS; DQ / DKV = which gradients this instance produces:
+//   <1, true, true>   the whole backward of a (batch, head) with <= 64 keys (the 224x224 presets: 49 keys);
+//   <4, true, false>  dQ over up to 256 resident keys (512x512 inputs: 256 keys under 4 096 .. 16 384 queries);
+//   <1, false, true>  dK / dV of the 64-key block blockIdx.z (the same 256-key problems, one block of keys per workgroup:
+//                     the softmax statistics come from the saved lse, so a block of keys needs nothing from the others).
+template <int NKB, bool DQ, bool DKV>
+__global__ __launch_bounds__(256, DKV ? 1 : 2) void sra_bwd_kernel(SraArgs a) {
   constexpr int KP = 72, AP = 40;                     // image pitches (elements)
-  constexpr int KVIMG = 64 * KP, QIMG = 32 * KP + 64, AIMG = 32 * AP;
+  constexpr int KVIMG = NKB * 64 * KP, QIMG = 32 * KP + 64, AIMG = 32 * AP;
   constexpr int WIMG = 2 * QIMG + AIMG;               // per-wave: Q image, dO image, statistics image
-  constexpr int LDS_EL = 2 * KVIMG + 4 * WIMG;
-  static_assert(LDS_EL * 2 >= 64 * 128 * 4, "the dK/dV reduction block reuses the images");
+  constexpr int LDS_EL = (DQ ? 2 * KVIMG : 0) + (DKV ? 4 * WIMG : 0);
+  static_assert(!DKV || LDS_EL * 2 >= 64 * 128 * 4, "the dK/dV reduction block reuses the images");
+  static_assert(NKB == 1 || !DKV, "dK / dV accumulators exist for one 64-key block");
   __shared__ __attribute__((aligned(16))) bf lds[LDS_EL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const cenet_bid bid = cenet_xcd_block();
   const int b = bid.y / a.H, h = bid.y - b * a.H;
-  const int C = a.C, Nq = a.Nq, Nk = a.Nk;
+  const int key0 = DQ ? 0 : 64 * bid.z;               // first key of this workgroup's block (dK / dV instances)
+  const int C = a.C, Nq = a.Nq;
+  const int Nk = DQ ? a.Nk : (a.Nk - key0 < 64 ? a.Nk - key0 : 64);  // keys this workgroup holds
   const float c = a.scale * DA_LOG2E;
   const bf* qb = a.q + (long)b * Nq * C + h * 64;
   const bf* ob = a.o + (long)b * Nq * C + h * 64;
   const bf* gb = a.dout + (long)b * Nq * C + h * 64;
-  const bf* kb = a.kv + (long)b * Nk * 2 * C + h * 64;
+  const bf* kb = a.kv + ((long)b * a.Nk + key0) * 2 * C + h * 64;
   const bf* vb = kb + C;
   bf* Kimg = lds;
   bf* Vimg = lds + KVIMG;
-  bf* Qimg = lds + 2 * KVIMG + wave * WIMG;
+  bf* Qimg = lds + (DQ ? 2 * KVIMG : 0) + wave * WIMG;
   bf* Gimg = Qimg + QIMG;
   bf* Aimg = Gimg + QIMG;
-  // K and V of this (batch, head): 64 rows x 8 chunks each, rows >= Nk zero
-  for (int id = tid; id < 2 * 64 * 8; id += 256) {
-    const int which = id >> 9, rem = id & 511, row = rem >> 3, c8 = rem & 7;
-    unsigned v4[4] = {0u, 0u, 0u, 0u};
-    if (row < Nk) memcpy(v4, (which ? vb : kb) + (long)row * 2 * C + 8 * c8, 16);
-    memcpy((which ? Vimg : Kimg) + row * KP + 8 * c8, v4, 16);
+  if (DQ) {
+    // K and V of this (batch, head): NKB * 64 rows x 8 chunks each, rows >= Nk zero
+    for (int id = tid; id < 2 * NKB * 64 * 8; id += 256) {
+      const int which = id / (NKB * 512), rem = id - which * (NKB * 512), row = rem >> 3, c8 = rem & 7;
+      unsigned v4[4] = {0u, 0u, 0u, 0u};
+      if (row < Nk) memcpy(v4, (which ? vb : kb) + (long)row * 2 * C + 8 * c8, 16);
+      memcpy((which ? Vimg : Kimg) + row * KP + 8 * c8, v4, 16);
+    }
   }
   // B fragments of K^T / V^T for phase B: key = 32 kt + r
   bf16x8 kfB[2][4], vfB[2][4];
+  if (DKV) {
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int key = 32 * kt + r;
-      kfB[kt][ks] = da_ld8(kb + (long)(key < Nk ? key : 0) * 2 * C + 16 * ks + 8 * hh, key < Nk);
-      vfB[kt][ks] = da_ld8(vb + (long)(key < Nk ? key : 0) * 2 * C + 16 * ks + 8 * hh, key < Nk);
-    }
+      for (int ks = 0; ks < 4; ++ks) {
+        const int key = 32 * kt + r;
+        kfB[kt][ks] = da_ld8(kb + (long)(key < Nk ? key : 0) * 2 * C + 16 * ks + 8 * hh, key < Nk);
+        vfB[kt][ks] = da_ld8(vb + (long)(key < Nk ? key : 0) * 2 * C + 16 * ks + 8 * hh, key < Nk);
+      }
+  }
   bf16x8 negB = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hh == 0) negB[0] = negB[1] = negB[2] = (short)0xBF80;
   f32x16 dK[2][2], dV[2][2];  // [key tile][feature tile]
@@ -817,16 +838,18 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
       const bf16x8 uf = da_ld8(ob + (long)qi * C + 16 * ks + 8 * hh, true);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += cenet_bf2f((unsigned short)gf[ks][j]) * cenet_bf2f((unsigned short)uf[j]);
-      bf16x8 qz = qf[ks], gz = gf[ks];
-      if (!qok) qz = gz = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      memcpy(Qimg + r * KP + 16 * ks + 8 * hh, &qz, 16);
-      memcpy(Gimg + r * KP + 16 * ks + 8 * hh, &gz, 16);
+      if (DKV) {
+        bf16x8 qz = qf[ks], gz = gf[ks];
+        if (!qok) qz = gz = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        memcpy(Qimg + r * KP + 16 * ks + 8 * hh, &qz, 16);
+        memcpy(Gimg + r * KP + 16 * ks + 8 * hh, &gz, 16);
+      }
     }
     acc += __shfl_xor(acc, 32);
     const float delta = acc;
     const float lse = a.lse[((long)b * a.H + h) * Nq + qi];
     const float lse2 = lse * DA_LOG2E;
-    {  // statistics rows: lane half 0 writes lse / scale, half 1 writes delta (rows beyond Nq: lse / scale = 1e30 -> P = 0)
+    if (DKV) {  // statistics rows: lane half 0 writes lse / scale, half 1 writes delta (rows beyond Nq: lse / scale = 1e30 -> P = 0)
       unsigned short row8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       da_split3(hh == 0 ? (qok ? lse / a.scale : 1.0e30f) : (qok ? delta : 0.f), row8);
       memcpy(Aimg + r * AP + 8 * hh, row8, 16);
@@ -834,7 +857,7 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
     // ---- phase A: dQ ----
     f32x16 dq[2] = {da_zero(), da_zero()};
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < (DQ ? 2 * NKB : 0); ++kt) {
       if (32 * kt >= Nk) continue;  // (uniform)
       const bf* Kt = Kimg + 32 * kt * KP;
       const bf* Vt = Vimg + 32 * kt * KP;
@@ -855,7 +878,7 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) dq[dt] = DA_MFMA(da_tr(Kt, KP, s2, 32 * dt, lane), da_pack8(S, s2), dq[dt]);
     }
-    if (qok) {
+    if (DQ && qok) {
       bf* dp = a.dq + ((long)b * Nq + qi) * C + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -867,7 +890,11 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
           st4v(dp + 32 * dt + 8 * g + 4 * hh, o4);
         }
     }
+    if (!DKV) continue;
     // ---- phase B: dK, dV (images written above by this wave only: no workgroup barrier needed) ----
+    // A wave's LDS instructions execute in program order, so its own stores above are visible to its loads below; the
+    // compiler is told not to move LDS accesses across this point (the host checker runs lanes as fibers: its sync point).
+    da_wave_sync();
     bf16x8 al = {0, 0, 0, 0, 0, 0, 0, 0}, ad = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hh == 0) {
       memcpy(&al, Aimg + r * AP, 16);
@@ -902,6 +929,7 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
       }
     }
   }
+  if (!DKV) return;
   // ---- the four waves meet in LDS: red[key][0..63] = dK (unscaled), red[key][64..127] = dV ----
   // red[feature 0..127][key 0..63] (key fastest: a wave's 32 lanes hit 32 consecutive banks); the waves take turns, so
   // plain read-modify-writes suffice
@@ -928,7 +956,7 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
     __syncthreads();
   }
   if (a.dkv_bf) {  // this workgroup saw every query of its (batch, head)
-    bf* dkvb = a.dkv_bf + (long)b * Nk * 2 * C + h * 64;
+    bf* dkvb = a.dkv_bf + ((long)b * a.Nk + key0) * 2 * C + h * 64;
     for (int i = tid; i < Nk * 128; i += 256) {
       const int key = i >> 7, f = i & 127;
       const float v = red[f * 64 + key];
@@ -937,7 +965,7 @@ __global__ __launch_bounds__(256, 1) void sra_bwd_kernel(SraArgs a) {
     }
     return;
   }
-  float* dkv = a.dkv + (long)b * Nk * 2 * C + h * 64;
+  float* dkv = a.dkv + ((long)b * a.Nk + key0) * 2 * C + h * 64;
   for (int i = tid; i < Nk * 128; i += 256) {
     const int key = i >> 7, f = i & 127;  // 128 consecutive lanes = one key's 64 + 64 features: contiguous runs of 256 B
     const float v = red[f * 64 + key];
@@ -1068,6 +1096,9 @@ extern "C" int cenet_sra_attn_fwd_bf16(const bf* q, const bf* kv, bf* o, float* 
 }
 
 extern "C" int cenet_sra_attn_bwd_supported(int hd, int Nk) { return hd == 64 && Nk >= 1 && Nk <= 64; }
+// 64 < Nk <= 256 (the 512x512 presets: 256 keys): cenet_sra_attn_bwd_bf16 runs as two launches, dQ over all keys resident in
+// LDS and dK / dV per 64-key block; the forward of these problems is the tiled kernel's (same lse convention)
+extern "C" int cenet_sra_attn_bwd_blocks_supported(int hd, int Nk) { return hd == 64 && Nk > 64 && Nk <= 256; }
 
 // 32-query tiles per wave: the kernel runs one workgroup per CU (484 registers), so more than 256 workgroups is a second
 // round; measured best (B = 32): 4 tiles at 3136 queries (42 us), 2 at 784 / 196 (31 us), 1 at 49 (25 us)
@@ -1087,14 +1118,30 @@ extern "C" int cenet_sra_attn_bwd_direct_supported(int B, int H, int Nq, int Nk)
 static int sra_bwd_launch(const bf* q, const bf* kv, const bf* o, const bf* dout, const float* lse, bf* dq, float* dkv, bf* dkv_bf,
                           int B, int H, int Nq, int Nk, float scale, hipStream_t stream) {
   if (!q || !kv || !o || !dout || !lse || !dq || (!dkv && !dkv_bf) || B <= 0 || H <= 0 || Nq <= 0) return CENET_EINVAL;
-  if (!cenet_sra_attn_bwd_supported(64, Nk)) return CENET_EUNSUPPORTED;
+  const bool blocks = cenet_sra_attn_bwd_blocks_supported(64, Nk);
+  if (!cenet_sra_attn_bwd_supported(64, Nk) && !blocks) return CENET_EUNSUPPORTED;
   if ((((uintptr_t)q | (uintptr_t)kv | (uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq) & 15) != 0) return CENET_EINVAL;
   SraArgs a;
   a.q = q; a.kv = kv; a.o = o; a.dout = dout; a.lse = lse; a.dq = dq; a.dkv = dkv; a.dkv_bf = dkv_bf;
   a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.C = 64 * H; a.scale = scale;
   a.tiles = sra_tiles(B, H, Nq);
+  if (blocks) {
+    if (dkv_bf) return CENET_EUNSUPPORTED;  // dK / dV of a key block are summed over the query slices: fp32 accumulator
+    // dQ: two workgroups per CU (no dK / dV accumulators), ~512 workgroups fill the chip once
+    int tq = 1;
+    while (tq < 8 && (long)cdiv(Nq, 128 * tq) * B * H > 512) ++tq;
+    a.tiles = tq;
+    CENET_LAUNCH((sra_bwd_kernel<4, true, false>), dim3(cdiv(Nq, 128 * tq), B * H), dim3(256), stream, a);
+    const int nkb = cdiv(Nk, 64);
+    int tk = 1;
+    while (tk < 16 && (long)cdiv(Nq, 128 * tk) * B * H * nkb > 256) ++tk;
+    a.tiles = tk;
+    CENET_LAUNCH((sra_bwd_kernel<1, false, true>), dim3(cdiv(Nq, 128 * tk), B * H, nkb), dim3(256), stream, a);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   if (dkv_bf && cdiv(Nq, 128 * a.tiles) != 1) return CENET_EUNSUPPORTED;
-  CENET_LAUNCH(sra_bwd_kernel, dim3(cdiv(Nq, 128 * a.tiles), B * H), dim3(256), stream, a);
+  CENET_LAUNCH((sra_bwd_kernel<1, true, true>), dim3(cdiv(Nq, 128 * a.tiles), B * H), dim3(256), stream, a);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -287,6 +287,10 @@ def sra_attn_bwd_supported(hd: int, Nk: int) -> bool:
     return bool(_lib.lib().cenet_sra_attn_bwd_supported(int(hd), int(Nk)))
 
 
+def sra_attn_bwd_blocks_supported(hd: int, Nk: int) -> bool:
+    return bool(_lib.lib().cenet_sra_attn_bwd_blocks_supported(int(hd), int(Nk)))
+
+
 def sra_attn_fwd(q, kv, o, lse, B, H, Nq, Nk, scale):
     """spatial-reduction attention forward with resident keys (bf16, head dim 64, <= 64 keys): o and the natural-log lse"""
     _chk(q, kv, o, lse)

@@ -1037,6 +1037,13 @@ class SRAttentionFn(Function):
             dkv = _zeros(kv.shape, kv)
             kern.sra_attn_bwd(q, kv, o, g, saved, dq, dkv, d.B, d.H, d.Nq, d.Nk, d.scale)
             return dq, kern.cast(dkv, kv.dtype), None
+        if (ctx.kind == "flash" and _bf(q) and kern.sra_attn_bwd_blocks_supported(d.D, d.Nk) and d.D == d.Dv
+                and all(t.data_ptr() % 16 == 0 for t in (q, kv, o, g))):
+            # bf16, 64-dim heads, 65 .. 256 keys (512x512 inputs): dQ with all keys resident + dK / dV per 64-key block
+            dq = torch.empty_like(q)
+            dkv = _zeros(kv.shape, kv)
+            kern.sra_attn_bwd(q, kv, o, g, saved, dq, dkv, d.B, d.H, d.Nq, d.Nk, d.scale)
+            return dq, kern.cast(dkv, kv.dtype), None
         few_keys = ctx.d.Nk <= 128 and ctx.d.Nq >= 1024  # spatial-reduction attention: 49 keys under 784..3136 queries
         # (the query range is then sliced over workgroups and dK / dV are added atomically: fp32 accumulator)
         dq, dkv = torch.empty_like(q), (_zeros(kv.shape, kv) if few_keys else torch.empty_like(kv))

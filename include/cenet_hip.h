@@ -207,6 +207,9 @@ int cenet_attn64_bwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
  * resident in LDS.  q, o, dout, dq [B, Nq, 64 H]; kv [B, Nk, 128 H] (k | v); lse [B, H, Nq] as the forward kernel left it;
  * dkv [B, Nk, 128 H] fp32, ZERO-FILLED by the caller (workgroups add their partial sums atomically). */
 int cenet_sra_attn_bwd_supported(int hd, int Nk);
+/* 64 < Nk <= 256 keys of head dimension 64 (pvtv2.py:92-105 at 512x512 inputs): cenet_sra_attn_bwd_bf16 then runs as two
+ * launches — dQ with all keys resident, dK / dV per 64-key block (the saved lse makes key blocks independent). */
+int cenet_sra_attn_bwd_blocks_supported(int hd, int Nk);
 /* The forward of the same problem class (head dimension 64, Nk <= 64, cenet_sra_attn_bwd_supported) with the keys / values
  * resident: o [B, Nq, 64 H], lse [B, H, Nq] (natural log, as the backward entries expect). */
 int cenet_sra_attn_fwd_bf16(const unsigned short* q, const unsigned short* kv, unsigned short* o, float* lse, int B, int H, int Nq,
