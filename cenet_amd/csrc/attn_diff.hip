@@ -243,15 +243,21 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
     const int klim = N - k0;  // valid keys of this tile (>= 32 except in the last one)
     auto tile = [&](auto masked) __attribute__((always_inline)) {
       constexpr bool MASKED = decltype(masked)::value;
-      bf16x8 kf[2][NKS], vf[NDT][2];
+      // HDP <= 32: the tile's K / V fragments are read once and shared by both heads (and all QT query tiles).  HDP = 64 has
+      // 128 accumulator registers per wave: fragments are read where they are used (LATE) — holding them across the softmax
+      // cost 640 bytes of scratch per lane.
+      constexpr bool LATE = HDP > 32;
+      bf16x8 kf[LATE ? 1 : 2][NKS], vf[LATE ? 1 : NDT][2];
+      if (!LATE) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) kf[s][ks] = da_rm(Kimg, G::KP, r, s * HDP + 16 * ks, hh);
+          for (int ks = 0; ks < NKS; ++ks) kf[LATE ? 0 : s][ks] = da_rm(Kimg, G::KP, r, s * HDP + 16 * ks, hh);
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt)
+        for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) vf[dt][s2] = da_tr(Vimg, G::VPT, s2, 32 * dt, lane);
+          for (int s2 = 0; s2 < 2; ++s2) vf[LATE ? 0 : dt][s2] = da_tr(Vimg, G::VPT, s2, 32 * dt, lane);
+      }
 #pragma unroll
       for (int t = 0; t < QT; ++t)
 #pragma unroll
@@ -260,7 +266,8 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
 #pragma unroll
           for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(kf[sp][ks], qf[t][sp][ks], S);  // S^T[key][query]
+            for (int ks = 0; ks < NKS; ++ks)
+              S = DA_MFMA(LATE ? da_rm(Kimg, G::KP, r, sp * HDP + 16 * ks, hh) : kf[LATE ? 0 : sp][ks], qf[t][sp][ks], S);  // S^T[key][query]
           if (MASKED) {  // ragged last tile only (its own instantiation of the tile body: no per-score selects elsewhere)
 #pragma unroll
             for (int i = 0; i < 16; ++i)
@@ -293,8 +300,8 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
           const bf16x8 p0 = da_pack8(S, 0), p1 = da_pack8(S, 1);
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt) {  // O^T[value feature][query] += V^T[feature][key] P^T[key][query]
-            O[t][s][dt] = DA_MFMA(vf[dt][0], p0, O[t][s][dt]);
-            O[t][s][dt] = DA_MFMA(vf[dt][1], p1, O[t][s][dt]);
+            O[t][s][dt] = DA_MFMA(LATE ? da_tr(Vimg, G::VPT, 0, 32 * dt, lane) : vf[LATE ? 0 : dt][0], p0, O[t][s][dt]);
+            O[t][s][dt] = DA_MFMA(LATE ? da_tr(Vimg, G::VPT, 1, 32 * dt, lane) : vf[LATE ? 0 : dt][1], p1, O[t][s][dt]);
           }
         }
     };
@@ -339,9 +346,10 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
 // backward, dQ (+ delta = rowsum(dU * U) and the bf16 statistics rows for dK/dV): wave = 32 queries x both softmax heads
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int HDP, bool ONE>
-__global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
+__global__ __launch_bounds__(256, HDP > 32 ? 1 : 2) void dattn_bwd_dq_kernel(DiffArgs a) {
   typedef DaGeo<HDP> G;
   constexpr int NKS = HDP / 16, NKD = G::DVP / 16, NH = ONE ? 1 : 2;
+  constexpr int NFT = (HDP + 31) / 32;  // 32-feature accumulator tiles per head (HDP = 64: two)
   constexpr int KIMG = 32 * G::KP + 64, VIMG = 32 * G::VPR, IMG = KIMG + VIMG;
   constexpr int NCH = 32 * (G::CK + G::CV), CPT = (NCH + 255) / 256;
   __shared__ __attribute__((aligned(16))) bf lds[2 * IMG];
@@ -391,13 +399,14 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
 
   bf16x8 qf[2][NKS], gf[NH][NKD];
   float lse2[NH], dl[NH];
-  f32x16 dq[2];
+  f32x16 dq[2][NFT];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
       qf[s][ks] = da_ld8(qb + (long)qi * E + (2 * h + s) * hd + 16 * ks + 8 * hh, 16 * ks + 8 * hh < hd);
-    dq[s] = da_zero();
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) dq[s][ft] = da_zero();
   }
 #pragma unroll
   for (int s = 0; s < NH; ++s) {
@@ -456,7 +465,12 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
 #pragma unroll
         for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp)
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) dq[sp] = DA_MFMA(da_tr(Kimg, G::KP, s2, sp * HDP, lane), da_pack8(S, s2), dq[sp]);
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 dsB = da_pack8(S, s2);
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft)
+              dq[sp][ft] = DA_MFMA(da_tr(Kimg, G::KP, s2, sp * HDP + 32 * ft, lane), dsB, dq[sp][ft]);
+          }
       }
     };
     if (q0 < N) {
@@ -472,15 +486,17 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
     for (int s = 0; s < 2; ++s) {
       bf* dp = a.dq + ((long)b * N + qi) * E + (2 * h + s) * hd;
 #pragma unroll
-      for (int g = 0; g < HDP / 8; ++g) {
-        const int d0 = 8 * g + 4 * hh;
-        if (d0 < hd) {
-          float o[4];
+      for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = dq[s][4 * g + i] * a.scale;
-          st4v(dp + d0, o);
+        for (int g = 0; g < (HDP < 32 ? HDP / 8 : 4); ++g) {
+          const int d0 = 32 * ft + 8 * g + 4 * hh;
+          if (d0 < hd) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = dq[s][ft][4 * g + i] * a.scale;
+            st4v(dp + d0, o);
+          }
         }
-      }
     }
   }
 }
@@ -489,9 +505,10 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dq_kernel(DiffArgs a) {
 // backward, dK / dV: wave = 32 keys x both softmax heads (one shared dV accumulator); streams query tiles
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int HDP, bool ONE>
-__global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
+__global__ __launch_bounds__(256, HDP > 32 ? 1 : 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
   typedef DaGeo<HDP> G;
   constexpr int NKS = HDP / 16, NKD = G::DVP / 16, NDT = G::DVP / 32, NH = ONE ? 1 : 2;
+  constexpr int NFT = (HDP + 31) / 32;  // 32-feature accumulator tiles of dK per head
   constexpr int AP = 40;  // statistics image: [query][head s: lse(8) delta(8)] + pad
   constexpr int QIMG = 32 * G::KP + 64, GIMG = 32 * G::VPR + 64, AIMG = 32 * AP, IMG = QIMG + NH * GIMG + AIMG;
   constexpr int NCH = 32 * (G::CK + NH * G::CV + 2 * NH), CPT = (NCH + 255) / 256;
@@ -563,8 +580,11 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
   // constant B fragment of the statistics k-step: -1 at k = 0, 1, 2 (lane half 0), zero elsewhere
   bf16x8 negB = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hh == 0) negB[0] = negB[1] = negB[2] = (short)0xBF80;
-  f32x16 dK[2], dV[NDT];
-  dK[0] = dK[1] = da_zero();
+  f32x16 dK[2][NFT], dV[NDT];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) dK[s][ft] = da_zero();
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) dV[dt] = da_zero();
 
@@ -610,7 +630,10 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
           for (int dt = 0; dt < NDT; ++dt) dV[dt] = DA_MFMA(da_tr(Gimg, G::VPR, s2, 32 * dt, lane), pB, dV[dt]);
           // dK^T[d][key] += Q^T[d][query] dS[query][key]   (accumulator rows >= hd are never stored)
 #pragma unroll
-          for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp) dK[sp] = DA_MFMA(da_tr(Qimg, G::KP, s2, sp * HDP, lane), dsB, dK[sp]);
+          for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp)
+#pragma unroll
+            for (int ft = 0; ft < NFT; ++ft)
+              dK[sp][ft] = DA_MFMA(da_tr(Qimg, G::KP, s2, sp * HDP + 32 * ft, lane), dsB, dK[sp][ft]);
         }
       }
     }
@@ -623,15 +646,17 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
     for (int s = 0; s < 2; ++s) {
       bf* dp = a.dk + ((long)b * N + ki) * E + (2 * h + s) * hd;
 #pragma unroll
-      for (int g = 0; g < HDP / 8; ++g) {
-        const int d0 = 8 * g + 4 * hh;
-        if (d0 < hd) {
-          float o[4];
+      for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = dK[s][4 * g + i] * a.scale;
-          st4v(dp + d0, o);
+        for (int g = 0; g < (HDP < 32 ? HDP / 8 : 4); ++g) {
+          const int d0 = 32 * ft + 8 * g + 4 * hh;
+          if (d0 < hd) {
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = dK[s][ft][4 * g + i] * a.scale;
+            st4v(dp + d0, o);
+          }
         }
-      }
     }
     bf* dvp = a.dv + ((long)b * N + ki) * (a.H * dv) + h * dv;
 #pragma unroll
@@ -649,8 +674,9 @@ __global__ __launch_bounds__(256, 2) void dattn_bwd_dkv_kernel(DiffArgs a) {
   }
 }
 
-// head dims served: 8 and 16 (one k-step), 32 (two)
-extern "C" int cenet_diffattn_heads_supported(int hd, int N) { return (hd == 8 || hd == 16 || hd == 32) && N >= 1; }
+// head dims served: 8 and 16 (one k-step), 32 (two), 64 (four k-steps, two 32-feature accumulator tiles per head: the
+// 64x64-token level of the 512x512 three-scale preset, skin.sh:93-94)
+extern "C" int cenet_diffattn_heads_supported(int hd, int N) { return (hd == 8 || hd == 16 || hd == 32 || hd == 64) && N >= 1; }
 extern "C" long cenet_diffattn_heads_ws_bytes(int B, int H, int N) { return (long)B * 2 * H * N * 16 * 2; }
 
 static int da_fill(DiffArgs& a, const cenet_diffattn_t* p) {
@@ -676,8 +702,10 @@ extern "C" int cenet_diffattn_heads_fwd_bf16(const cenet_diffattn_t* p, hipStrea
     static const int v = getenv("CENET_DATTN_QT2") ? 2 : 1;
     if (v == 2 && a.N >= 1024) CENET_LAUNCH((dattn_fwd_kernel<16, 2, 2, false>), dim3(cdiv(a.N, 256), bh), dim3(256), stream, a);
     else CENET_LAUNCH((dattn_fwd_kernel<16, 1, 3, false>), dim3(cdiv(a.N, 128), bh), dim3(256), stream, a);
-  } else {
+  } else if (a.hd <= 32) {
     CENET_LAUNCH((dattn_fwd_kernel<32, 1, 2, false>), dim3(cdiv(a.N, 128), bh), dim3(256), stream, a);
+  } else {
+    CENET_LAUNCH((dattn_fwd_kernel<64, 1, 1, false>), dim3(cdiv(a.N, 128), bh), dim3(256), stream, a);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
@@ -692,9 +720,12 @@ extern "C" int cenet_diffattn_heads_bwd_bf16(const cenet_diffattn_t* p, hipStrea
   if (a.hd <= 16) {
     CENET_LAUNCH((dattn_bwd_dq_kernel<16, false>), grid, dim3(256), stream, a);
     CENET_LAUNCH((dattn_bwd_dkv_kernel<16, false>), grid, dim3(256), stream, a);
-  } else {
+  } else if (a.hd <= 32) {
     CENET_LAUNCH((dattn_bwd_dq_kernel<32, false>), grid, dim3(256), stream, a);
     CENET_LAUNCH((dattn_bwd_dkv_kernel<32, false>), grid, dim3(256), stream, a);
+  } else {
+    CENET_LAUNCH((dattn_bwd_dq_kernel<64, false>), grid, dim3(256), stream, a);
+    CENET_LAUNCH((dattn_bwd_dkv_kernel<64, false>), grid, dim3(256), stream, a);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;

@@ -231,9 +231,9 @@ def test_nonlocal_attention(dev, B, C, N):
 
 
 # hd 16 / 8: tiled kernels (two softmax heads add into one value head: fp32 accumulators); hd 80: materialised path (fp32 scores)
-# (N % 4 == 0 and hd in {8, 16, 32}: the pair kernels of attn_diff.hip, incl. ragged last tiles and the 64-query form at 1024+)
+# (N % 4 == 0 and hd in {8, 16, 32, 64}: the pair kernels of attn_diff.hip, incl. ragged last tiles and the 64-query form at 1024+)
 @pytest.mark.parametrize("B,N,H,hd", [(2, 96, 2, 16), (1, 70, 2, 8), (1, 49, 1, 80), (1, 132, 2, 16), (2, 72, 1, 8),
-                                      (1, 100, 2, 32), (1, 1028, 1, 16)])
+                                      (1, 100, 2, 32), (1, 1028, 1, 16), (1, 72, 2, 64), (2, 45, 1, 64)])
 def test_diff_attention_heads_and_combine(dev, B, N, H, hd):
     g = G(N + hd)
     E = 2 * H * hd
