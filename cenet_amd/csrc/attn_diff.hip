@@ -731,19 +731,19 @@ extern "C" int cenet_diffattn_heads_bwd_bf16(const cenet_diffattn_t* p, hipStrea
   return CENET_OK;
 }
 
-// ---- plain self-attention with head dimension 64 through the pair tiles (ONE softmax over both 32-column halves) ------------
-// q, k, v [B, N, H*64] (token-major), U / dU [B, H, N, 64], lse [B, H, N]; ws: cenet_attn64_ws_bytes.  The caller passes
-// hd = 64; inside, a head is a "pair" of two 32-wide halves (DiffArgs.hd = 32).  Used by the Non-local block of the 56x56
-// decoder level (nlb.py:117-138, C = 64, N = 3136).
+// ---- plain self-attention with head dimension 64 or 128 through the pair tiles (ONE softmax over both halves) ----------------
+// q, k, v [B, N, H*hd] (token-major), U / dU [B, H, N, hd], lse [B, H, N]; ws: cenet_attn64_ws_bytes.  The caller passes
+// hd = 64 or 128; inside, a head is a "pair" of two hd/2-wide halves (DiffArgs.hd = 32 / 64).  Used by the Non-local blocks of
+// the 56x56 (C = 64, N = 3136) and 28x28 (C = 128, N = 784) decoder levels (nlb.py:117-138).
 extern "C" long cenet_attn64_ws_bytes(int B, int H, int N) { return (long)B * H * N * 16 * 2; }
 
 static int da_fill64(DiffArgs& a, const cenet_diffattn_t* p) {
   if (!p || !p->q || !p->k || !p->v || !p->U || !p->lse) return CENET_EINVAL;
-  if (p->B <= 0 || p->H <= 0 || p->N <= 0 || p->hd != 64) return CENET_EUNSUPPORTED;
+  if (p->B <= 0 || p->H <= 0 || p->N <= 0 || (p->hd != 64 && p->hd != 128)) return CENET_EUNSUPPORTED;
   a.q = (const bf*)p->q; a.k = (const bf*)p->k; a.v = (const bf*)p->v;
   a.U = (bf*)p->U; a.lse = p->lse; a.dU = (const bf*)p->dU;
   a.dq = (bf*)p->dq; a.dk = (bf*)p->dk; a.dv = (bf*)p->dv; a.aug = (bf*)p->ws;
-  a.B = p->B; a.H = p->H; a.N = p->N; a.hd = 32; a.scale = p->scale;
+  a.B = p->B; a.H = p->H; a.N = p->N; a.hd = p->hd / 2; a.scale = p->scale;  // a head = a "pair" of two hd/2-wide halves
   const uintptr_t m = (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.U | (uintptr_t)a.dU | (uintptr_t)a.dq |
                       (uintptr_t)a.dk | (uintptr_t)a.dv | (uintptr_t)a.aug;
   if (m & 15) return CENET_EINVAL;
@@ -754,7 +754,8 @@ extern "C" int cenet_attn64_fwd_bf16(const cenet_diffattn_t* p, hipStream_t stre
   DiffArgs a;
   const int rc = da_fill64(a, p);
   if (rc != CENET_OK) return rc;
-  CENET_LAUNCH((dattn_fwd_kernel<32, 1, 2, true>), dim3(cdiv(a.N, 128), a.B * a.H), dim3(256), stream, a);
+  if (a.hd == 32) CENET_LAUNCH((dattn_fwd_kernel<32, 1, 2, true>), dim3(cdiv(a.N, 128), a.B * a.H), dim3(256), stream, a);
+  else CENET_LAUNCH((dattn_fwd_kernel<64, 1, 1, true>), dim3(cdiv(a.N, 128), a.B * a.H), dim3(256), stream, a);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -765,8 +766,13 @@ extern "C" int cenet_attn64_bwd_bf16(const cenet_diffattn_t* p, hipStream_t stre
   if (rc != CENET_OK) return rc;
   if (!a.dU || !a.dq || !a.dk || !a.dv || !a.aug) return CENET_EINVAL;
   const dim3 grid(cdiv(a.N, 128), a.B * a.H);
-  CENET_LAUNCH((dattn_bwd_dq_kernel<32, true>), grid, dim3(256), stream, a);
-  CENET_LAUNCH((dattn_bwd_dkv_kernel<32, true>), grid, dim3(256), stream, a);
+  if (a.hd == 32) {
+    CENET_LAUNCH((dattn_bwd_dq_kernel<32, true>), grid, dim3(256), stream, a);
+    CENET_LAUNCH((dattn_bwd_dkv_kernel<32, true>), grid, dim3(256), stream, a);
+  } else {
+    CENET_LAUNCH((dattn_bwd_dq_kernel<64, true>), grid, dim3(256), stream, a);
+    CENET_LAUNCH((dattn_bwd_dkv_kernel<64, true>), grid, dim3(256), stream, a);
+  }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -1059,9 +1059,9 @@ class NonlocalAttnFn(Function):
         theta, phi, gx = _c(theta), _c(phi), _c(gx)
         B, Cn = theta.shape[:2]
         N = theta.numel() // (B * Cn)
-        ctx.tok64 = _bf(theta) and Cn == 64 and N >= 256
+        ctx.tok64 = _bf(theta) and Cn in (64, 128) and N >= 256
         if ctx.tok64:
-            # bf16, C = 64 (the 56x56 level): token-major copies through the single-softmax form of the pair kernels
+            # bf16, C = 64 / 128 (the 56x56 / 28x28 levels): token-major copies through the single-softmax form of the pair kernels
             # (attn_diff.hip); three [64, N] -> [N, 64] transposes in, one out (~10 us each against ~2 ms saved)
             qt, kt, vt = (torch.empty((B, N, Cn), device=theta.device, dtype=theta.dtype) for _ in range(3))
             for src, dst in ((theta, qt), (phi, kt), (gx, vt)):
@@ -1070,7 +1070,7 @@ class NonlocalAttnFn(Function):
             lse = torch.empty((B, 1, N), device=theta.device, dtype=torch.float32)
             a = kern.DiffAttnT()
             a.q, a.k, a.v, a.U, a.lse = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr()
-            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, 64, Cn ** -0.5
+            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, Cn, Cn ** -0.5
             kern.attn64(a, backward=False)
             o = torch.empty_like(theta)
             kern.transpose(U, N * Cn, o, Cn * N, B, N, Cn)
@@ -1098,7 +1098,7 @@ class NonlocalAttnFn(Function):
             a = kern.DiffAttnT()
             a.q, a.k, a.v, a.U, a.lse, a.dU = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr(), gt.data_ptr()
             a.dq, a.dk, a.dv, a.ws = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr()
-            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, 64, Cn ** -0.5
+            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, Cn, Cn ** -0.5
             kern.attn64(a, backward=True)
             outs = []
             for src in (dq, dk, dv):
@@ -1230,7 +1230,7 @@ class NonlocalAttnJointFn(Function):
         B, C3 = tpg.shape[:2]
         Cn = C3 // 3
         N = tpg.numel() // (B * C3)
-        ctx.tok64 = _bf(tpg) and Cn == 64 and N >= 256
+        ctx.tok64 = _bf(tpg) and Cn in (64, 128) and N >= 256
         ctx.dims = (B, Cn, N, tuple(tpg.shape))
         oshape = (B, Cn) + tuple(tpg.shape[2:])
         if ctx.tok64:
@@ -1241,7 +1241,7 @@ class NonlocalAttnJointFn(Function):
             lse = torch.empty((B, 1, N), device=tpg.device, dtype=torch.float32)
             a = kern.DiffAttnT()
             a.q, a.k, a.v, a.U, a.lse = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr()
-            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, 64, Cn ** -0.5
+            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, Cn, Cn ** -0.5
             kern.attn64(a, backward=False)
             o = torch.empty(oshape, device=tpg.device, dtype=tpg.dtype)
             kern.transpose(U, N * Cn, o, Cn * N, B, N, Cn)
@@ -1269,7 +1269,7 @@ class NonlocalAttnJointFn(Function):
             a = kern.DiffAttnT()
             a.q, a.k, a.v, a.U, a.lse, a.dU = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr(), gt.data_ptr()
             a.dq, a.dk, a.dv, a.ws = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr()
-            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, 64, Cn ** -0.5
+            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, Cn, Cn ** -0.5
             kern.attn64(a, backward=True)
             for j, src in enumerate((dq, dk, dv)):
                 kern.transpose(src, N * Cn, dj, 3 * Cn * N, B, N, Cn, y_off=j * Cn * N)

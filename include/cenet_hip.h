@@ -197,9 +197,10 @@ int cenet_diffattn_heads_supported(int hd, int N);
 long cenet_diffattn_heads_ws_bytes(int B, int H, int N);
 int cenet_diffattn_heads_fwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
 int cenet_diffattn_heads_bwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
-/* Plain self-attention with head dimension 64 on bf16 tensors through the same tiles (one softmax over both 32-column
- * halves): q, k, v [B, N, H*64] token-major, U / dU [B, H, N, 64], lse [B, H, N], hd = 64, ws of cenet_attn64_ws_bytes.
- * Replaces the score / softmax / value products of the Non-local block at the 56x56 decoder level (nlb.py:117-138). */
+/* Plain self-attention with head dimension 64 or 128 on bf16 tensors through the same tiles (one softmax over both hd/2-column
+ * halves): q, k, v [B, N, H*hd] token-major, U / dU [B, H, N, hd], lse [B, H, N], hd = 64 | 128, ws of cenet_attn64_ws_bytes.
+ * Replaces the score / softmax / value products of the Non-local block at the 56x56 (C = 64) and 28x28 (C = 128) decoder
+ * levels (nlb.py:117-138). */
 long cenet_attn64_ws_bytes(int B, int H, int N);
 int cenet_attn64_fwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);
 int cenet_attn64_bwd_bf16(const cenet_diffattn_t* p, cenet_stream_t stream);

@@ -223,7 +223,8 @@ def test_sr_attention(dev, B, N, Nk, C, heads):
 
 # C = 64 with N >= 256 takes the single-softmax form of the pair kernels (attn_diff.hip) on token-major copies; N = 300 has a
 # ragged last key tile and a partial last query wave
-@pytest.mark.parametrize("B,C,N", [(2, 64, 100), (1, 32, 49), (2, 64, 256), (1, 64, 300)])
+# C = 128 (the 28x28 level): the same form with 64-wide halves
+@pytest.mark.parametrize("B,C,N", [(2, 64, 100), (1, 32, 49), (2, 64, 256), (1, 64, 300), (1, 128, 260), (2, 128, 256)])
 def test_nonlocal_attention(dev, B, C, N):
     g = G(C + N)
     th, ph, gx = (torch.randn(B, C, N, generator=g) for _ in range(3))
