@@ -270,6 +270,8 @@ def roofline_block(body, steps=2):
     out["method"] = ("HIP events around every launch of this instance in %d instrumented steps (one stream, the stream parked behind a "
                      "spin kernel while the host queues the step, so intervals are kernel durations)" % steps)
     out["top_kernels"] = [entry(k, *v) for k, v in ranked[:3]]
+    # the grouped weight-gradient launches (round 2's dominant kernel family, now ~10 launches per step), whatever their rank
+    out["weight_gradient_kernels"] = [entry(k, *v) for k, v in ranked if k.startswith("gemm_group")]
     out["next_kernels_ms_per_step"] = {k: round(v[0], 3) for k, v in ranked[1:6]}
     return out
 
@@ -319,16 +321,25 @@ def stage_block(net, body, B, size, steps=2):
         for sub in (list(m) if isinstance(m, (torch.nn.ModuleList, torch.nn.Sequential)) else [m]):
             hook(name, sub)
 
+    wg_ev = []  # the grouped weight-gradient launches (recorded during backward, issued when it ends): their own line
+
     def after_backward():
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         order.append(("<end of backward>", e))
+        ops.wgrad_flush()
+        ops._WgradQueue.armed = False
+        e2 = torch.cuda.Event(enable_timing=True)
+        e2.record()
+        wg_ev.append((e, e2))
     try:
         for _ in range(steps):
             _hold_stream()
+            ops._WgradQueue.armed = True  # no end-of-backward callback in this pass: after_backward() issues the flush itself
             body(after_backward=after_backward)
         torch.cuda.synchronize()
     finally:
+        ops._WgradQueue.armed = False
         for h in handles:
             h.remove()
         ops.set_wgrad_overlap(old)
@@ -350,6 +361,10 @@ def stage_block(net, body, B, size, steps=2):
         out[key] = {
             "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3), "bound": "mfma" if t_m >= t_h else "hbm",
             "bound_ms": round(bound_ms, 4), "frac": round(bound_ms / max(tf + tb, 1e-9), 4)}
+    if wg_ev:
+        # not a SURVEY stage: the Linear / 1x1-conv weight gradients of ALL stages, reduced by the grouped launches after the
+        # backward pass (their time is therefore in none of the per-stage bwd_ms above)
+        out["grouped_weight_gradients"] = {"ms": round(sum(a.elapsed_time(b) for a, b in wg_ev) / steps, 3)}
     return out
 
 

@@ -189,6 +189,8 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
       auto wgs = [&](int a, int b) { return (long)cdiv(M, a) * cdiv(N, b) * nbatch; };
       if (wgs(bm, bn) < want && bm == 128 && bn == 128) (M >= N ? bm : bn) = 64;
       if (wgs(bm, bn) < want && (bm == 128 || bn == 128)) bm = bn = 64;
+      static const char* fb = getenv("CENET_RING_TILE_BATCHED");  // measurement aid: per-image (nbatch >= 8) launches only
+      if (fb && nbatch >= 8) sscanf(fb, "%dx%d", &bm, &bn);
     }
   }
   const int kstep = ring ? 64 : BK;

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates, on the MI355X box, every measured artefact that profiles/README.md cites for the current round:
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'
 # Outputs land in gpurun_out/refresh_<tag>/ (copy the ones to be judged into profiles/).  Order matters: the PMC passes come
 # first, because bench.py reads roofline.traffic from profiles/<tag>_traffic.json by kernel name.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/refresh_$TAG
 mkdir -p $O
