@@ -25,6 +25,22 @@ class CENet(nn.Module):
                            up_block=out_up_block, up_ks=out_up_ks)
 
     def forward(self, x):
+        if torch.jit.is_tracing():
+            # utils/utils.py:171-185 (print_param_flops, called on the model at main_acdc.py:128) runs fvcore's FlopCountAnalysis,
+            # a torch.jit.trace of the model.  A tracer turns tensor sizes into traced values (which cannot be passed to the C
+            # ABI) and could only record the custom kernels as opaque calls anyway: the forward runs with tracing suspended and
+            # the result is tied to the input by a zero-valued traced term, so the trace completes (the parameter count it
+            # reports is right, its FLOP count is ~0 — INTEGRATION.md).
+            state = torch._C._get_tracing_state()
+            torch._C._set_tracing_state(None)
+            try:
+                out = self._forward(x.detach())
+            finally:
+                torch._C._set_tracing_state(state)
+            return out + torch.zeros_like(x).sum().to(out.dtype)
+        return self._forward(x)
+
+    def _forward(self, x):
         # throughput mode (kern.set_compute_bf16): the whole network runs on bf16 tensors — the input is rounded once here
         # and every kernel downstream follows the element type of its input; logits come back as bf16
         # The reference's AMP switch (main_acdc.py:192-199,243-249: `with autocast('cuda')` + GradScaler) selects the same

@@ -180,3 +180,20 @@ def test_torch_compile_is_refused_with_a_clear_error():
     compiled = torch.compile(net, mode="default", fullgraph=True)  # main_acdc.py:190
     with pytest.raises(Exception, match="does not support torch.compile"):
         compiled(x.to(dev))
+
+
+@pytest.mark.gpu
+def test_jit_trace_of_the_model_completes():
+    """utils/utils.py:171-185 (`print_param_flops`, main_acdc.py:128): fvcore's FlopCountAnalysis is a `torch.jit.trace` of the
+    model followed by `parameter_count`.  fvcore is absent from this image; its mechanism is exercised directly: the trace
+    completes, the traced module reproduces the eager output, and the parameter count is the reference's 33.38 M."""
+    dev = use_hip()
+    net, _ = _build(dev)
+    net.eval()
+    x, _ = O.synthetic_batch(1, 1, 4, seed=9)
+    xd = x.to(dev)
+    with torch.no_grad():
+        traced = torch.jit.trace(net, xd, check_trace=False, strict=False)
+        assert torch.equal(traced(xd), net(xd))
+    assert sum(p.numel() for p in net.parameters()) == 33384872  # SURVEY.md §6 (ACDC preset)
+
