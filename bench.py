@@ -417,6 +417,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # (test aids: CENET_DEVICE pins every rank to one device and CENET_DIST_BACKEND=gloo carries the collectives, so that the
+    # N > 1 code path can run with two ranks on a one-GPU box — RCCL refuses two ranks on one device; tests/test_bench_dist.py)
+    local = int(os.environ.get("CENET_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # CENET_FORCE_DIST=1 runs the whole RCCL path (process group, hooks, side stream) even with a single rank, so the
@@ -425,7 +428,7 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("CENET_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from cenet_amd import kern, losses, optim, parallel
     kern.set_compute_bf16(a.dtype == "bf16")

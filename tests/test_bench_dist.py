@@ -72,3 +72,28 @@ def test_bench_other_presets(preset, batch, size, classes):
     assert st.pop("grouped_weight_gradients")["ms"] > 0  # (all stages' weight gradients, issued after the backward pass)
     assert len(st) == 21 and all(v["fwd_ms"] > 0 for v in st.values())
     assert d["roofline"]["bound"] in ("mfma", "hbm")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--dist-launch", "segmented"]])
+def test_bench_with_two_ranks_on_one_gpu(extra):
+    """`--gpus 2` exactly as the driver launches it (torch.distributed.run, two processes), with both ranks pinned to cuda:0 and
+    the collectives over gloo (RCCL refuses two ranks on one device; only a one-GPU box is available to the tests): the whole
+    N > 1 control flow of bench.py — broadcast, capture of the split / segmented graph forms on every rank, the agreement
+    all-reduce, the timing loops with their barriers, rank 0's pick and its broadcast, max-over-ranks timing — with world 2."""
+    env = dict(os.environ, CENET_DIST_BACKEND="gloo", CENET_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29633", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-f32", "--batch", "8"] + extra
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1200, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 16
+    assert d["value"] > 0 and abs(d["value"] - 16 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]
+    assert "roofline" not in d  # the instrumented passes are a single-GPU extra
+    if extra:
+        assert d["config"]["launch"].startswith("six hipGraphs"), d["config"]["launch"]
+    else:
+        assert "->" in d["config"]["launch_choice"]
+
