@@ -19,7 +19,8 @@ def use_sim():
     global _SIM
     if _SIM is None:
         from build_sim import build_sim
-        _SIM = ctypes.CDLL(build_sim())
+        # CENET_SIM_SANITIZE=1: the UndefinedBehaviorSanitizer build of the same sources (sanitizers run on the CPU build only)
+        _SIM = ctypes.CDLL(build_sim(sanitize=os.environ.get("CENET_SIM_SANITIZE") == "1"))
     _lib._LIB = _SIM
     _lib._HOSTSIM = True
     return torch.device("cpu")
