@@ -239,3 +239,17 @@ def test_sr_conv_tok_patch_path(dev, B, C, Cout, H, W, s):
     torch.testing.assert_close(xq.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(wq.grad.cpu(), wr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(bq.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,off", [(7, 0), (9, 1), (1, 0), (1031, 3), (4096, 0)])
+def test_zero_fill_of_odd_sized_bf16_buffers(dev, n, off):
+    """kern.zero_ on bf16 tensors with an odd element count / starting on an odd element (a channel-split branch without a
+    consumer, a non-overlapping strided-conv gradient): whole words by the grid, head / tail bytes by one workgroup, nothing
+    outside the range touched"""
+    buf = torch.full((n + off + 5,), 3.0, dtype=torch.bfloat16, device=dev)
+    view = buf[off:off + n]
+    assert view.is_contiguous()
+    kern.zero_(view)
+    out = buf.float().cpu()
+    assert torch.all(out[off:off + n] == 0)
+    assert torch.all(out[:off] == 3.0) and torch.all(out[off + n:] == 3.0)
