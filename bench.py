@@ -192,8 +192,23 @@ class _Trace:
         for n, f in self._saved.items():
             setattr(kern, n, f)
 
+    @staticmethod
+    def bracket_overhead_ms(n=200):
+        """what an EMPTY event bracket reads on the parked stream (marker-to-marker dispatch latency).  Reported, NOT subtracted:
+        a bracketed kernel hides part of it (the live average of the 17.6 us dominant kernel reads 20.7 us, the empty bracket
+        4.6 us), so the live averages bound the profiler's kernel durations from above by at most this much"""
+        _hold_stream(5.0)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in ev:
+            a.record()
+            b.record()
+        torch.cuda.synchronize()
+        v = sorted(a.elapsed_time(b) for a, b in ev)
+        return v[len(v) // 2]
+
     def groups(self, steps):
         torch.cuda.synchronize()
+        self.overhead_ms = self.bracket_overhead_ms()
         g = {}
         for name, e0, e1, fl, by in self.rows:
             t = g.setdefault(name, [0.0, 0, 0.0, 0.0])
@@ -268,7 +283,9 @@ def roofline_block(body, steps=2):
     name, (ms, n, fl, by) = ranked[0]
     out = entry(name, ms, n, fl, by)
     out["method"] = ("HIP events around every launch of this instance in %d instrumented steps (one stream, the stream parked behind a "
-                     "spin kernel while the host queues the step, so intervals are kernel durations)" % steps)
+                     "spin kernel while the host queues the step, so intervals are kernel durations plus at most the "
+                     "marker-to-marker latency an empty bracket reads: %.4f ms)" % (steps, tr.overhead_ms))
+    out["empty_bracket_ms"] = round(tr.overhead_ms, 5)
     out["top_kernels"] = [entry(k, *v) for k, v in ranked[:3]]
     # the grouped weight-gradient launches (round 2's dominant kernel family, now ~10 launches per step), whatever their rank
     out["weight_gradient_kernels"] = [entry(k, *v) for k, v in ranked if k.startswith("gemm_group")]
