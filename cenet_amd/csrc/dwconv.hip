@@ -126,10 +126,7 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_kernel(const T* __restri
   float acc[10];
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t] = 0.f;
-  for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
-  for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
-           pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
-       p < pend__; p += 256) {
+  auto pixel = [&](int b, int p) __attribute__((always_inline)) {
     const int py = p / W, px = p - py * W;
     const float g = ldf(dy + (long)b * sgb + (long)c * HW + p);
     const T* xp = x + (long)b * sxb + (long)c * HW;
@@ -145,6 +142,20 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_kernel(const T* __restri
         acc[ky * 3 + kx] += g * ldf(xp + iy * W + ix);
       }
     }
+  };
+  if (HW < 256) {
+    // small planes (7x7: 49 pixels): the (image, pixel) pairs of the channel flat over the threads — a pass per image left 49
+    // of 256 lanes busy and B dependent load rounds per workgroup (94 us for 2048 channels x 7 x 7 x 32 images)
+    for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
+      const int b = (int)(e / HW);
+      pixel(b, (int)(e - (long)b * HW));
+    }
+  } else {
+    for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
+      for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
+               pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
+           p < pend__; p += 256)
+        pixel(b, p);
   }
 #pragma unroll
   for (int t = 0; t < 10; ++t) {

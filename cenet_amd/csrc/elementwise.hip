@@ -361,12 +361,23 @@ __global__ __launch_bounds__(256) void chan_dot_kernel(const T* __restrict__ a, 
   __shared__ float red[16];
   const int c = blockIdx.x;
   float s = 0.f;
-  for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
-  for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
-           pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
-       p < pend__; p += 256) {
-    const float av = ldf(a + (long)b * sab + (long)c * HW + p);
-    s += bb ? av * ldf(bb + (long)b * sbb + (long)c * HW + p) : av;
+  if (HW < 256) {
+    // small planes (7x7): the channel's (image, pixel) pairs flat over the threads (a pass per image left 49 of 256 lanes busy
+    // and B dependent load rounds per workgroup)
+    const long total = (long)B * HW;
+    for (long e = (long)blockIdx.y * 256 + threadIdx.x; e < total; e += (long)gridDim.y * 256) {
+      const int b = (int)(e / HW), p = (int)(e - (long)b * HW);
+      const float av = ldf(a + (long)b * sab + (long)c * HW + p);
+      s += bb ? av * ldf(bb + (long)b * sbb + (long)c * HW + p) : av;
+    }
+  } else {
+    for (int w__ = blockIdx.y; w__ < B * ((HW + 1023) / 1024); w__ += gridDim.y)  // (image, 1024-pixel chunk) items: no per-element division
+      for (int b = w__ / ((HW + 1023) / 1024), p = (w__ - b * ((HW + 1023) / 1024)) * 1024 + threadIdx.x,
+               pend__ = ((w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 < HW) ? (w__ - b * ((HW + 1023) / 1024)) * 1024 + 1024 : HW;
+           p < pend__; p += 256) {
+        const float av = ldf(a + (long)b * sab + (long)c * HW + p);
+        s += bb ? av * ldf(bb + (long)b * sbb + (long)c * HW + p) : av;
+      }
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) atomicAdd(&out[c], s);

@@ -88,6 +88,72 @@ __global__ __launch_bounds__(256) void ccu_stats_fwd_kernel(const T* __restrict_
   }
 }
 
+// The same statistics for SMALL planes (HWv <= 64 vector elements: 7x7 as 49 scalars, 14x14 as 49 quads), bf16 mode: one WAVE
+// per plane, four planes per workgroup, every reduction a shuffle tree and no workgroup barrier — the 256-thread form left
+// 49 lanes busy behind three barriers per plane (34 us for 32 x 512 planes of 7x7).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void ccu_stats_fwd_wave_kernel(const T* __restrict__ x, const float* __restrict__ fc1,
+                                                                const float* __restrict__ fc2, float* __restrict__ u,
+                                                                int* __restrict__ amax, float* __restrict__ z, int C, int HWv,
+                                                                int BC) {
+  const int lane = threadIdx.x & 63, bc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bc >= BC) return;  // (wave-uniform)
+  const int c = bc % C, HW = HWv * V;
+  const T* xp = x + (long)bc * HW;
+  float v[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) v[e] = 0.f;
+  if (lane < HWv) ldv<V>(v, xp + lane * V);
+  float s = 0.f, mx = -3.4e38f;
+  int mi = 0;
+  if (lane < HWv) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      s += v[e];
+      if (v[e] > mx) {
+        mx = v[e];
+        mi = lane * V + e;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / HW;
+  float q = 0.f;
+  if (lane < HWv) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float d = v[e] - mean;
+      q += d * d;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    q += __shfl_xor(q, o);
+    const float ov = __shfl_xor(mx, o);
+    const int oi = __shfl_xor(mi, o);
+    if (ov > mx || (ov == mx && oi < mi)) {
+      mx = ov;
+      mi = oi;
+    }
+  }
+  if (lane == 0) {
+    const float sd = sqrtf(q / HW);
+    u[bc * 3 + 0] = mx;
+    u[bc * 3 + 1] = mean;
+    u[bc * 3 + 2] = sd;
+    amax[bc] = mi;
+    float zz = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float* w1 = fc1 + (c * 3 + j) * 3;
+      const float hdn = w1[0] * mx + w1[1] * mean + w1[2] * sd;
+      if (hdn > 0.f) zz += fc2[c * 3 + j] * hdn;
+    }
+    z[bc] = zz;
+  }
+}
+
 // y = x * sigmoid(g[bc])
 template <typename T, int V>
 __global__ __launch_bounds__(256) void gate_chan_fwd_kernel(const T* __restrict__ x, const float* __restrict__ g,
@@ -208,7 +274,25 @@ __global__ __launch_bounds__(64 * NG) void srm_stats_fwd_kernel(const T* __restr
   float s1 = 0.f, s2 = 0.f, mx = -3.4e38f;
   int mi = 0;
   if (ok) {
-    for (int c = cg; c < C; c += NG) {
+    // eight channel rows in flight per thread: at 7x7 / 14x14 a workgroup walks 80 - 128 rows per thread and the launch has
+    // only 32 - 128 workgroups, so the walk is a latency chain unless the loads are issued ahead of the (ordered) compares
+    int c = cg;
+    for (; c + 7 * NG < C; c += 8 * NG) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ldf(xb + (long)(c + j * NG) * HW);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[j] - shift;
+        s1 += d;
+        s2 += d * d;
+        if (v[j] > mx) {
+          mx = v[j];
+          mi = c + j * NG;
+        }
+      }
+    }
+    for (; c < C; c += NG) {
       const float v = ldf(xb + (long)c * HW);
       const float d = v - shift;
       s1 += d;
@@ -566,7 +650,11 @@ static int ccu_stats_fwd_impl(const T* x, const float* fc1, const float* fc2, fl
                               hipStream_t stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   // fp32 keeps the one-element-per-thread walk: the summation order of the parity mode is pinned
-  if (sizeof(T) == 2 && plane_vw<T>(HW, x) == 4) CENET_LAUNCH((ccu_stats_fwd_kernel<T, 4>), dim3(B * C), dim3(256), stream, x, fc1, fc2, u, amax, z, C, HW / 4);
+  const int vw = sizeof(T) == 2 ? plane_vw<T>(HW, x) : 1;
+  if (sizeof(T) == 2 && HW / vw <= 64) {  // small planes, bf16 mode: one wave per plane
+    if (vw == 4) CENET_LAUNCH((ccu_stats_fwd_wave_kernel<T, 4>), dim3(cdiv(B * C, 4)), dim3(256), stream, x, fc1, fc2, u, amax, z, C, HW / 4, B * C);
+    else CENET_LAUNCH((ccu_stats_fwd_wave_kernel<T, 1>), dim3(cdiv(B * C, 4)), dim3(256), stream, x, fc1, fc2, u, amax, z, C, HW, B * C);
+  } else if (vw == 4) CENET_LAUNCH((ccu_stats_fwd_kernel<T, 4>), dim3(B * C), dim3(256), stream, x, fc1, fc2, u, amax, z, C, HW / 4);
   else CENET_LAUNCH((ccu_stats_fwd_kernel<T, 1>), dim3(B * C), dim3(256), stream, x, fc1, fc2, u, amax, z, C, HW);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
