@@ -4,12 +4,13 @@ The three `model_*.npz` points fill every parameter at random (batch 2): their g
 and cannot hold a reduced-precision mode to a tight bound.  This point is the reference AS ITS TRAINING SCRIPT BUILDS IT
 (main_acdc.py:112-126: `torch.manual_seed(seed); CENet(**kw)` = the reference's own initialisers, pvtv2.py:24-38,
 cfam.py / blocks.py / unet.py `_init_weights`), with the CFAM layer scales raised from 1e-6 to 0.5 so the decoder blocks
-are numerically visible, batch 8, stochastic depth off.  The unmodified reference evaluates one training
+are numerically visible, batch 8, stochastic depth off — for each of the three presets (ACDC; Synapse: 9 classes,
+heads 16/8/8, scales 0.8/0.4; skin: 3-channel input, 2 classes, heads 2/2/2 = head dimensions 160 / 64 / 32, three scales).  The unmodified reference evaluates one training
 step in float32 AND float64; stored per parameter tensor: gradient norm and a 64-entry strided sample (both precisions),
 plus loss, a logits subsample, BatchNorm buffers after the step and per-tensor checksums of the initial state (so that a
 test can prove the product's constructor reproduces the reference's initialisation bit for bit without the reference).
 
-Re-run:  python -m oracle.gen_golden_wellcond
+Re-run:  python -m oracle.gen_golden_wellcond [--preset acdc|synapse|skin]
 """
 from __future__ import annotations
 
@@ -37,7 +38,7 @@ SEED = 77
 BATCH = 8
 LAYER_SCALE = 0.5
 NS = 64  # sampled entries per tensor
-KW = dict(input_channels=1, num_classes=4, scale_factors=[1.0, 0.5], diffatt_num_heads=[4, 4, 4], out_up_block="upcn")
+from oracle.golden_cases import MODEL_CONFIGS  # noqa: E402  (the three presets: acdc / synapse / skin)
 
 
 def sample_index(n: int) -> torch.Tensor:
@@ -56,9 +57,18 @@ def prepare(net):
 
 
 def main():
-    from networks import CENet
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", action="append", choices=sorted(MODEL_CONFIGS), help="default: all three")
+    a = ap.parse_args()
     torch.set_num_threads(8)
     core = load_reference_losses()
+    for name in (a.preset or sorted(MODEL_CONFIGS)):
+        generate(name, core)
+
+
+def generate(name, core):
+    from networks import CENet
+    KW = MODEL_CONFIGS[name]["kw"]
     K = KW["num_classes"]
     x, lab = O.synthetic_batch(BATCH, KW["input_channels"], K, seed=1234)
     crit = core.Criterion(K, argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
@@ -89,7 +99,7 @@ def main():
             for k, b in net.named_buffers():
                 if k.endswith("running_mean") or k.endswith("running_var"):
                     rec["b." + k] = b.detach().reshape(-1)[:8].numpy().copy()
-        print(f"[golden] wellcond fp{tag}: loss {loss.item():.8f}")
+        print(f"[golden] wellcond {name} fp{tag}: loss {loss.item():.8f}")
     # conditioning report: the reference's own fp32 gradient against its fp64 gradient
     a = torch.cat([grads["32"][k] for k in grads["32"]])
     b = torch.cat([grads["64"][k] for k in grads["64"]])
@@ -102,8 +112,8 @@ def main():
                    reverse=True)[:8]
     for r, k in worst:
         print(f"    {r:.3e}  {k}")
-    np.savez_compressed(os.path.join(OUT, "model_acdc_wellcond.npz"), **rec)
-    print(f"[golden] model_acdc_wellcond.npz: {os.path.getsize(os.path.join(OUT, 'model_acdc_wellcond.npz')) / 1024:.0f} KiB")
+    np.savez_compressed(os.path.join(OUT, f"model_{name}_wellcond.npz"), **rec)
+    print(f"[golden] model_{name}_wellcond.npz: {os.path.getsize(os.path.join(OUT, f'model_{name}_wellcond.npz')) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":
