@@ -257,6 +257,9 @@ def roofline_block(body, steps=2):
         except (OSError, ValueError):
             continue
 
+    meta = traffic_rec.pop("_meta", None) or {}
+    from cenet_amd.build import source_sha16
+
     def entry(name, ms, n, fl, by):
         n //= steps
         out = {"kernel": name, "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 5), "total_ms_per_step": round(ms, 3)}
@@ -286,6 +289,8 @@ def roofline_block(body, steps=2):
                      "spin kernel while the host queues the step, so intervals are kernel durations plus at most the "
                      "marker-to-marker latency an empty bracket reads: %.4f ms)" % (steps, tr.overhead_ms))
     out["empty_bracket_ms"] = round(tr.overhead_ms, 5)
+    # the PMC passes were taken on the kernel sources that hash to traffic_src_sha16; kernel_src_sha16 = the sources benched now
+    out["kernel_src_sha16"], out["traffic_src_sha16"] = source_sha16(), meta.get("kernel_src_sha16")
     out["top_kernels"] = [entry(k, *v) for k, v in ranked[:3]]
     # the grouped weight-gradient launches (round 2's dominant kernel family, now ~10 launches per step), whatever their rank
     out["weight_gradient_kernels"] = [entry(k, *v) for k, v in ranked if k.startswith("gemm_group")]

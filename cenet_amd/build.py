@@ -20,6 +20,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_sha16() -> str:
+    """hash of the kernel sources (csrc/*.hip, csrc/*.h, include/cenet_hip.h): identifies the BUILD a measurement belongs to
+    independently of where and when hipcc ran (profiles/*_traffic.json, bench.py roofline.kernel_src_sha16)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "cenet_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -32,7 +32,14 @@ for k in f:
     out[k] = {"hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024), "fetch_kb_raw_per_launch": round(fk, 1),
               "write_kb_per_launch": round(wk, 1), "launches_in_pass": nf[k],
               "source": ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, 2 x FETCH + WRITE (gfx950 correction); " + note).strip()}
+# which build these counters belong to: the hash of the kernel sources (bench.py reports the same hash of the sources it runs
+# on, so a reader can tell whether `roofline.traffic` was measured on the build being benched)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cenet_amd.build import source_sha16  # noqa: E402
+out["_meta"] = {"kernel_src_sha16": source_sha16()}
 json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+out.pop("_meta")
 top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_in_pass"])[:12]
 for k, v in top:
     print(f"{v['hbm_bytes_per_launch'] / 1e6:9.2f} MB/launch x {v['launches_in_pass']:5d}  {k}")
