@@ -13,7 +13,9 @@ LIB = os.path.join(HERE, "libcenet_hip.so")
 
 # per-file flags: the attention kernels never produce or consume NaNs on purpose (masked scores are -1e30), and without
 # NaN semantics fmaxf on MFMA results needs no canonicalising v_max
-EXTRA_FLAGS = {"attn_diff.hip": ["-fno-honor-nans"]}
+# pvt_mlp.hip: its depthwise phase is bound by vector-instruction issue; SLP-packing scalar f32 math into v_pk_fma_f32 (two issue
+# slots each) costs ~300 and/or/shift instructions per slab to assemble the 64-bit operands
+EXTRA_FLAGS = {"attn_diff.hip": ["-fno-honor-nans"], "pvt_mlp.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

@@ -1,0 +1,356 @@
+// pvt_mlp.hip — the MLP half of a PVTv2 block (reference pvtv2.py:40-47, 145-149, 364-370) as ONE kernel per pass on bf16
+// token tensors:
+//     y = x + s_b * ( fc2( GELU( DW3x3( fc1( LN(x) ) ) + bd ) ) + b2 )          (s_b: per-sample DropPath scale or 1)
+// The hidden tensor ([tokens, 8C]: 102 MB per block at 56x56 / batch 32) and the LayerNorm output never reach HBM in the
+// forward pass; the backward pass recomputes them tile by tile and writes only what the grouped weight-gradient launch reads.
+//
+// Workgroup (512 threads) = one (TH x TW)-token tile of one image.  The (TH+2) x (TW+2) halo tile of x is normalised into a
+// k-fast bf16 LDS image (the layout of gemm_ring.h: 128-byte rows, 16-byte chunks XOR-swizzled); the hidden dimension is then
+// walked in slabs of 64 channels:
+//   P1 (MFMA)  h^T[64 ch, halo tokens] = W1_slab . xn^T + b1     -> bf16 LDS plane, rows of out-of-image tokens forced to 0
+//                                                                    (the depthwise conv zero-pads h, not x)
+//   P2 (VALU)  a = GELU(DW3x3(h) + bd) on the interior tokens     -> k-fast bf16 LDS image (thread = channel pair x strip)
+//   P3 (MFMA)  acc^T[C, interior tokens] += W2[:, slab] . a^T     (fp32 registers across the slabs)
+// and the epilogue adds bias, DropPath scale and the residual.  Weight slabs arrive by LDS-DMA one phase ahead of their use.
+// Every rounding point of the unfused chain (LN output, h, GELU output: bf16) is kept, so the fused result equals the
+// chain of launches it replaces up to the order of fp32 additions.
+#include "gemm_ring.h"
+
+struct PvtMlpArgs {
+  const bf16_t* x;
+  const float* ln_g;
+  const float* ln_b;
+  const bf16_t* w1;   // [HD, C]
+  const float* b1;    // [HD]
+  const float* wd;    // [HD, 9]
+  const float* bd;    // [HD]
+  const bf16_t* w2;   // [C, HD]
+  const float* b2;    // [C]
+  const float* bscale;  // [B] or null
+  bf16_t* y;
+  // backward only
+  const bf16_t* dy;   // [B, H*W, C] gradient of y
+  bf16_t* dx;         // [B, H*W, C] gradient of x (residual path included)
+  bf16_t* xn_out;     // [B, H*W, C]  LN(x)            (operand of the fc1 weight gradient)
+  bf16_t* dys_out;    // [B, H*W, C]  s_b * dy          (operand of the fc2 weight gradient; null when bscale is null)
+  bf16_t* a_out;      // [B, H*W, HD] GELU output       (operand of the fc2 weight gradient)
+  bf16_t* dh_out;     // [B, H*W, HD] gradient of fc1's output (operand of the fc1 weight gradient)
+  float* dwd;         // [HD, 9] +=
+  float* dbd;         // [HD] +=
+  float* dln_g;       // [C] +=
+  float* dln_b;       // [C] +=
+  int H, W, HD, tiles_x, tiles_per_img;
+  float eps;
+};
+
+#ifdef CENET_HOSTSIM_BUILD
+#define PVT_WAVE_ID(tid) ((tid) >> 6)
+#else
+#define PVT_WAVE_ID(tid) __builtin_amdgcn_readfirstlane((tid) >> 6)
+#endif
+
+// 1 / x by v_rcp_f32 (1 ulp): a full-precision division is ten instructions, and the P2 phase is bound by instruction issue
+__device__ __forceinline__ float pvt_rcp(float x) {
+#ifdef CENET_HOSTSIM_BUILD
+  return 1.f / x;
+#else
+  return __builtin_amdgcn_rcpf(x);
+#endif
+}
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, as in dwconv.hip's tiled kernels)
+__device__ __forceinline__ float pvt_gelu(float u) {
+  const float ax = fabsf(u) * 0.70710678118654752f;
+  const float t = pvt_rcp(1.f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.f - poly * fast_exp(-ax * ax);
+  return 0.5f * u * (1.f + copysignf(r, u));
+}
+// GELU(u) and GELU'(u) = Phi(u) + u phi(u) from one exponential
+__device__ __forceinline__ void pvt_gelu2(float u, float& act, float& grad) {
+  const float ax = fabsf(u) * 0.70710678118654752f;
+  const float t = pvt_rcp(1.f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = fast_exp(-0.5f * u * u);
+  const float cdf = 0.5f * (1.f + copysignf(1.f - poly * e, u));
+  act = u * cdf;
+  grad = cdf + u * 0.3989422804014327f * e;
+}
+
+template <int LPT>
+__device__ __forceinline__ float pvt_subrow_sum(float v) {
+#pragma unroll
+  for (int o = LPT / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// 64 rows x 64 k of a k-contiguous bf16 matrix (row pitch ld elements) -> k-fast LDS image, one LDS-DMA per wave (8 waves)
+__device__ __forceinline__ void pvt_load_kf64(const bf16_t* src, long ld, unsigned char* img, int wave, int lane) {
+  const int S = wave * 64 + lane, row = S >> 3, c = (S & 7) ^ kf_key(row);
+  ring_glds16(src + (long)row * ld + 8 * c, img + wave * 1024, lane);
+}
+
+// LayerNorm of the halo tile into the k-fast image(s) XN[C / 64][PTP][64]; tokens outside the image (or beyond PT) become 0.
+// mean / rstd of every halo token go to `stat` (2 floats per token) when it is non-null.
+template <int C, int PW, int PT, int PTP>
+__device__ __forceinline__ void pvt_ln_tile(const bf16_t* ximg, const float* ln_g, const float* ln_b, float eps, int H, int W,
+                                            int y0, int x0, int halo, unsigned char* XN, float* stat, int tid) {
+  constexpr int LPT = C / 8, TPP = 512 / LPT;
+  const int j = tid % LPT, tsub = tid / LPT;
+  float gm[8], bt[8];
+  {
+    const f4 g0 = ld4(ln_g + 8 * j), g1 = ld4(ln_g + 8 * j + 4), b0 = ld4(ln_b + 8 * j), b1 = ld4(ln_b + 8 * j + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gm[e] = g0.v[e], gm[4 + e] = g1.v[e], bt[e] = b0.v[e], bt[4 + e] = b1.v[e];
+  }
+  const float invC = 1.f / C;
+  for (int p0 = 0; p0 < PTP; p0 += TPP) {
+    const int p = p0 + tsub;
+    const int ty = p / PW, tx = p - ty * PW;
+    const int iy = y0 - halo + ty, ix = x0 - halo + tx;
+    const bool ok = p < PT && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    float v[8];
+    if (ok) ldv<8>(v, ximg + ((long)iy * W + ix) * C + 8 * j);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    const float mu = pvt_subrow_sum<LPT>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = v[e] - mu;
+      q += d * d;
+    }
+    const float rs = rsqrtf(pvt_subrow_sum<LPT>(q) * invC + eps);
+    unsigned o[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float a0 = ok ? (v[2 * h] - mu) * rs * gm[2 * h] + bt[2 * h] : 0.f;
+      const float a1 = ok ? (v[2 * h + 1] - mu) * rs * gm[2 * h + 1] + bt[2 * h + 1] : 0.f;
+      o[h] = cenet_pack_bf2(a0, a1);
+    }
+    if (p < PTP) {
+      *(uint4*)(XN + (j >> 3) * (PTP * 128) + p * 128 + ((j & 7) ^ kf_key(p)) * 16) = uint4{o[0], o[1], o[2], o[3]};
+      if (stat && j == 0) stat[2 * p] = mu, stat[2 * p + 1] = rs;
+    }
+  }
+}
+
+// ============================================================================================================================
+// forward
+// ============================================================================================================================
+template <int C, int TH, int TW>
+struct PvtFwdGeo {
+  static constexpr int PW = TW + 2, PH = TH + 2, PT = PH * PW, PTP = (PT + 15) / 16 * 16, MTH = PTP / 16;
+  static constexpr int NT = TH * TW, MTI = (NT + 15) / 16, SL = TW / 2;
+  static constexpr int KB = C / 64, HS = 136;
+  static constexpr int XN_B = KB * PTP * 128, A_B = MTI * 16 * 128, W1_B = KB * 8192, W2_B = C * 128, H_B = PTP * HS;
+  static constexpr int O_XN = 0, O_A = XN_B, O_W1 = O_A + A_B, O_W2 = O_W1 + W1_B, O_H = O_W2 + W2_B, LDS = O_H + H_B;
+};
+
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(512, 2) void pvt_mlp_fwd_kernel(PvtMlpArgs a) {
+  typedef PvtFwdGeo<C, TH, TW> G;
+  constexpr int PW = G::PW, PT = G::PT, PTP = G::PTP, MTH = G::MTH, NT = G::NT, MTI = G::MTI, SL = G::SL, KB = G::KB, HS = G::HS;
+  static_assert(C == 64 || C == 128, "channels");
+  static_assert(MTI <= 8 && 2 * TH <= 16 && TW % 2 == 0, "tile shape");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS];
+  unsigned char* const XN = lds + G::O_XN;
+  unsigned char* const AI = lds + G::O_A;
+  unsigned char* const W1I = lds + G::O_W1;
+  unsigned char* const W2I = lds + G::O_W2;
+  unsigned char* const HI = lds + G::O_H;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = PVT_WAVE_ID(tid);
+  const cenet_bid bid = cenet_xcd_block();
+  const int b = bid.x / a.tiles_per_img, t = bid.x - b * a.tiles_per_img;
+  const int y0 = (t / a.tiles_x) * TH, x0 = (t % a.tiles_x) * TW;
+  const long img = (long)b * a.H * a.W;  // first token of the image
+  const bf16_t* ximg = a.x + img * C;
+  const int nslab = a.HD / 64;
+
+  // weight slabs of slab 0 (in flight under the LayerNorm phase)
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) pvt_load_kf64(a.w1 + kb * 64, C, W1I + kb * 8192, wave, lane);
+#pragma unroll
+  for (int r = 0; r < C / 64; ++r) pvt_load_kf64(a.w2 + (long)(r * 64) * a.HD, a.HD, W2I + r * 8192, wave, lane);
+
+  pvt_ln_tile<C, PW, PT, PTP>(ximg, a.ln_g, a.ln_b, a.eps, a.H, a.W, y0, x0, 1, XN, nullptr, tid);
+
+  f32x4 acc[C / 16];
+#pragma unroll
+  for (int i = 0; i < C / 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // P2 geometry of this thread: channel pair cp of the slab, strip of SL outputs in row oy
+  const int cp = tid & 31, strip = tid >> 5;
+  const int oy = strip >> 1, ox0 = (strip & 1) * SL;
+  const bool p2_on = strip < 2 * TH;
+  // P1 geometry: channel tile ct of the slab, token tiles (wave >> 2), +2, ...
+  const int ct = wave & 3;
+
+  ring_wait_vm<0>();
+  __syncthreads();
+
+  for (int s = 0; s < nslab; ++s) {
+    // depthwise weights / biases of this thread's channel pair: 18 + 2 floats, issued before P1, used in P2
+    float wdv[18], bdv[2], b1v[4];
+    {
+      const float* wp = a.wd + (long)(s * 64 + 2 * cp) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float2 v = *(const float2*)(wp + 2 * i);  // (typed accesses: byte-wise memcpy made hipcc reassemble every value from bytes)
+        wdv[2 * i] = v.x, wdv[2 * i + 1] = v.y;
+      }
+      bdv[0] = a.bd[s * 64 + 2 * cp], bdv[1] = a.bd[s * 64 + 2 * cp + 1];
+      const f4 bb = ld4(a.b1 + s * 64 + ct * 16 + (lane >> 4) * 4);
+      b1v[0] = bb.v[0], b1v[1] = bb.v[1], b1v[2] = bb.v[2], b1v[3] = bb.v[3];
+    }
+    // ---- P1: h^T = W1_slab . xn^T + b1 ------------------------------------------------------------------------------------
+    {
+      bf16x8 wf[KB * 2];
+#pragma unroll
+      for (int k = 0; k < KB * 2; ++k) wf[k] = ring_frag_kf(W1I + (k >> 1) * 8192, ct * 16, k & 1, lane);
+      for (int tt = wave >> 2; tt < MTH; tt += 2) {
+        f32x4 h = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KB * 2; ++k) {
+          const bf16x8 xf = ring_frag_kf(XN + (k >> 1) * (PTP * 128), tt * 16, k & 1, lane);
+          h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, h, 0, 0, 0);
+        }
+        const int p = tt * 16 + (lane & 15);
+        const int ty = p / PW, tx = p - ty * PW;
+        const int iy = y0 - 1 + ty, ix = x0 - 1 + tx;
+        const bool ok = p < PT && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        unsigned o[2];
+        o[0] = ok ? cenet_pack_bf2(h[0] + b1v[0], h[1] + b1v[1]) : 0u;
+        o[1] = ok ? cenet_pack_bf2(h[2] + b1v[2], h[3] + b1v[3]) : 0u;
+        *(uint2*)(HI + p * HS + (ct * 16 + (lane >> 4) * 4) * 2) = uint2{o[0], o[1]};
+      }
+    }
+    __syncthreads();  // h complete; the W1 image is free
+    if (s + 1 < nslab) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) pvt_load_kf64(a.w1 + (long)(s + 1) * 64 * C + kb * 64, C, W1I + kb * 8192, wave, lane);
+    }
+    // ---- P2: a = GELU(DW3x3(h) + bd) on the interior tokens ---------------------------------------------------------------
+    if (p2_on) {
+      float u[SL][2];
+#pragma unroll
+      for (int i = 0; i < SL; ++i) u[i][0] = bdv[0], u[i][1] = bdv[1];
+      const unsigned char* hp = HI + (oy * PW + ox0) * HS + cp * 4;
+#pragma unroll
+      for (int kxx = 0; kxx < SL + 2; ++kxx) {
+        float h0[3], h1[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned v = *(const unsigned*)(hp + (ky * PW + kxx) * HS);
+          h0[ky] = __uint_as_float(v << 16);
+          h1[ky] = __uint_as_float(v & 0xFFFF0000u);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int i = kxx - kx;
+          if (i >= 0 && i < SL) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              u[i][0] += wdv[ky * 3 + kx] * h0[ky];
+              u[i][1] += wdv[9 + ky * 3 + kx] * h1[ky];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < SL; ++i) {
+        const int row = oy * TW + ox0 + i;
+        const unsigned v = cenet_pack_bf2(pvt_gelu(u[i][0]), pvt_gelu(u[i][1]));
+        *(unsigned*)(AI + row * 128 + (((cp >> 2) ^ kf_key(row)) * 16) + (cp & 3) * 4) = v;
+      }
+    }
+    ring_wait_vm<0>();  // this wave's part of the next W1 slab (and of this slab's W2, issued one slab ago) has landed
+    __syncthreads();    // a complete; h free
+    // ---- P3: acc^T += W2[:, slab] . a^T -----------------------------------------------------------------------------------
+    if (wave < MTI) {
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        const bf16x8 af = ring_frag_kf(AI, wave * 16, kc, lane);
+#pragma unroll
+        for (int nt = 0; nt < C / 16; ++nt) {
+          const bf16x8 wf = ring_frag_kf(W2I + (nt >> 2) * 8192, (nt & 3) * 16, kc, lane);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // a and the W2 image are free
+    if (s + 1 < nslab) {
+#pragma unroll
+      for (int r = 0; r < C / 64; ++r)
+        pvt_load_kf64(a.w2 + (long)(r * 64) * a.HD + (s + 1) * 64, a.HD, W2I + r * 8192, wave, lane);
+    }
+  }
+  // ---- epilogue: y = x + s_b (acc + b2) -------------------------------------------------------------------------------------
+  if (wave < MTI) {
+    const int ti = wave * 16 + (lane & 15);
+    const int ry = ti / TW, rx = ti - ry * TW;
+    const int gy = y0 + ry, gx = x0 + rx;
+    if (ti < NT && gy < a.H && gx < a.W) {
+      const float sc = a.bscale ? a.bscale[b] : 1.f;
+      const long tok = img + (long)gy * a.W + gx;
+#pragma unroll
+      for (int nt = 0; nt < C / 16; ++nt) {
+        const int n0 = nt * 16 + (lane >> 4) * 4;
+        const f4 xr = ld4(a.x + tok * C + n0);
+        const f4 bb = ld4(a.b2 + n0);
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.v[e] = xr.v[e] + sc * (acc[nt][e] + bb.v[e]);
+        st4(a.y + tok * C + n0, o);
+      }
+    }
+  }
+}
+
+static bool pvt_mlp_geo(int H, int W, int& TH, int& TW) {
+  if (W % 14 != 0) return false;
+  TW = 14;
+  if (H % 8 == 0) TH = 8;
+  else if (H % 7 == 0) TH = 7;
+  else return false;
+  return true;
+}
+
+/* 1 when (C, HD, H, W) has a fused instance */
+extern "C" int cenet_pvt_mlp_supported(int C, int HD, int H, int W) {
+  int TH, TW;
+  return (C == 64 || C == 128) && HD % 64 == 0 && HD >= 64 && pvt_mlp_geo(H, W, TH, TW) ? 1 : 0;
+}
+
+extern "C" int cenet_pvt_mlp_fwd_bf16(const bf16_t* x, const float* ln_g, const float* ln_b, float eps, const bf16_t* w1,
+                                      const float* b1, const float* wd, const float* bd, const bf16_t* w2, const float* b2,
+                                      const float* bscale, bf16_t* y, int B, int H, int W, int C, int HD, hipStream_t stream) {
+  if (!x || !ln_g || !ln_b || !w1 || !b1 || !wd || !bd || !w2 || !b2 || !y || B <= 0) return CENET_EINVAL;
+  int TH, TW;
+  if (!cenet_pvt_mlp_supported(C, HD, H, W) || !pvt_mlp_geo(H, W, TH, TW)) return CENET_EUNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)ln_g | (uintptr_t)ln_b | (uintptr_t)b1 |
+        (uintptr_t)b2) & 15) != 0 || (((uintptr_t)wd | (uintptr_t)bd) & 7) != 0)
+    return CENET_EUNSUPPORTED;
+  PvtMlpArgs a = {};
+  a.x = x; a.ln_g = ln_g; a.ln_b = ln_b; a.w1 = w1; a.b1 = b1; a.wd = wd; a.bd = bd; a.w2 = w2; a.b2 = b2; a.bscale = bscale;
+  a.y = y; a.H = H; a.W = W; a.HD = HD; a.eps = eps;
+  a.tiles_x = W / TW;
+  a.tiles_per_img = a.tiles_x * (H / TH);
+  const dim3 grid(B * a.tiles_per_img);
+#define PVT_FWD_GO(C_, TH_)                                                                  \
+  if (C == C_ && TH == TH_) {                                                                 \
+    CENET_LAUNCH((pvt_mlp_fwd_kernel<C_, TH_, 14>), grid, dim3(512), stream, a);              \
+    CENET_CHECK_LAUNCH();                                                                     \
+    return CENET_OK;                                                                          \
+  }
+  PVT_FWD_GO(64, 8)
+  PVT_FWD_GO(64, 7)
+  PVT_FWD_GO(128, 8)
+  PVT_FWD_GO(128, 7)
+#undef PVT_FWD_GO
+  return CENET_EUNSUPPORTED;
+}

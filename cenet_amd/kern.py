@@ -390,6 +390,19 @@ def dw_tok_tiled(x):
     return is_bf16(x) and x.shape[-1] % 8 == 0 and x.data_ptr() % 16 == 0
 
 
+
+def pvt_mlp_supported(x, Cn, HD, H, W) -> bool:
+    """the fused PVT-MLP kernels (pvt_mlp.hip) have an instance for these bf16 tokens"""
+    return bool(is_bf16(x) and x.data_ptr() % 16 == 0 and _lib.lib().cenet_pvt_mlp_supported(Cn, HD, H, W))
+
+
+def pvt_mlp_fwd(x, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, Cn, HD):
+    """y = x + s_b (fc2(GELU(DW3x3(fc1(LN(x))) + bd)) + b2), one launch (bf16 tokens; w1 / w2 are the bf16 shadows)"""
+    _chk(x, ln_g, ln_b, w1, b1, wd, bd, w2, b2, bscale, y)
+    assert is_bf16(x) and is_bf16(y) and is_bf16(w1) and is_bf16(w2)
+    _call("cenet_pvt_mlp_fwd_bf16", x, ln_g, ln_b, float(eps), w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, Cn, HD)
+
+
 def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil, x_off=0, g_off=0):
     _chk(x, dy, dw, dbias)
     _call("cenet_dwconv3x3_wgrad_nchw_acc_f32", Ptr(x, x_off), L(sxb), Ptr(dy, g_off), L(sgb), dw, dbias, B, Cn, H, W, dil)

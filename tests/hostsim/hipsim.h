@@ -144,6 +144,10 @@ typedef short bf16x8 __attribute__((vector_size(16)));
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 
 static inline float sim_bf2f(short h) {
   uint32_t u = ((uint32_t)(uint16_t)h) << 16;
