@@ -403,6 +403,22 @@ def pvt_mlp_fwd(x, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, 
     _call("cenet_pvt_mlp_fwd_bf16", x, ln_g, ln_b, float(eps), w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, Cn, HD)
 
 
+
+def pvt_mlp_bwd(x, dy, ln_g, ln_b, eps, w1, b1, wd, bd, w2, bscale, dx, xn, dys, a, dh, dwd, dbd, dln_g, dln_b, ws, B, H, W, Cn, HD):
+    """backward of pvt_mlp_fwd in one launch (+ a fold): dx (residual path included); xn = LN(x), dys = s_b dy, a = GELU output
+    and dh = dL/d(fc1 output) are written once in bf16 as the operands of the grouped fc1 / fc2 weight gradients; the
+    depthwise-conv and LayerNorm parameter gradients are ADDED into dwd / dbd / dln_g / dln_b."""
+    _chk(x, dy, ln_g, ln_b, w1, b1, wd, bd, w2, bscale, dx, xn, dys, a, dh, dwd, dbd, dln_g, dln_b, ws)
+    _call("cenet_pvt_mlp_bwd_bf16", x, dy, ln_g, ln_b, float(eps), w1, b1, wd, bd, w2, bscale, dx, xn, dys, a, dh, dwd, dbd,
+          dln_g, dln_b, ws, B, H, W, Cn, HD)
+
+
+def pvt_mlp_bwd_ws_floats(Cn, HD) -> int:
+    f = _lib.lib().cenet_pvt_mlp_bwd_ws_floats
+    f.restype = C.c_long
+    return int(f(Cn, HD))
+
+
 def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil, x_off=0, g_off=0):
     _chk(x, dy, dw, dbias)
     _call("cenet_dwconv3x3_wgrad_nchw_acc_f32", Ptr(x, x_off), L(sxb), Ptr(dy, g_off), L(sgb), dw, dbias, B, Cn, H, W, dil)

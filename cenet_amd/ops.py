@@ -854,6 +854,71 @@ class DWConvTokFn(Function):
         return dx, None, None, None, None, None
 
 
+class PvtMlpFn(Function):
+    """pvtv2.py:145-149 (second half) as one kernel per pass on bf16 tokens: x + s_b * Mlp(LayerNorm(x)) with
+    Mlp = fc2(GELU(DW3x3(fc1(.)))) (pvtv2.py:40-47, 364-370).  Nothing but x is saved: the backward kernel recomputes the hidden
+    tensor tile by tile and writes the four bf16 operands of the fc1 / fc2 weight gradients, which are recorded for the grouped
+    launch like every other Linear's (csrc/pvt_mlp.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, H, Wd, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale):
+        x = _c(x)
+        B, N, Cn = x.shape
+        HD = w1.shape[0]
+        y = torch.empty_like(x)
+        kern.pvt_mlp_fwd(x, ln_g, ln_b, eps, kern.wq(w1, x), b1, wd, bd, kern.wq(w2, x), b2, bscale, y, B, H, Wd, Cn, HD)
+        ctx.save_for_backward(x, bscale)
+        ctx.refs = (ln_g, ln_b, w1, b1, wd, bd, w2, b2)
+        ctx.cfg = (H, Wd, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bscale = ctx.saved_tensors
+        ln_g, ln_b, w1, b1, wd, bd, w2, b2 = ctx.refs
+        H, Wd, eps = ctx.cfg
+        g = _c(g)
+        B, N, Cn = x.shape
+        HD = w1.shape[0]
+        R = B * N
+        dx = torch.empty_like(x)
+        xn = torch.empty_like(x)
+        dys = torch.empty_like(x) if bscale is not None else g
+        a = torch.empty((B, N, HD), device=x.device, dtype=x.dtype)
+        dh = torch.empty((B, N, HD), device=x.device, dtype=x.dtype)
+        ws = _empty((kern.pvt_mlp_bwd_ws_floats(Cn, HD),), x)
+        dwd, dbd, dlg, dlb = grad_buf(wd), grad_buf(bd), grad_buf(ln_g), grad_buf(ln_b)
+        scratch = [t is None for t in (dwd, dbd, dlg, dlb)]
+        if scratch[0]:
+            dwd = _zeros(wd.shape, x)
+        if scratch[1]:
+            dbd = _zeros(bd.shape, x)
+        if scratch[2]:
+            dlg = _zeros(ln_g.shape, x)
+        if scratch[3]:
+            dlb = _zeros(ln_b.shape, x)
+        kern.pvt_mlp_bwd(x, g, ln_g, ln_b, eps, kern.wq(w1, x), b1, wd, bd, kern.wq(w2, x), bscale, dx, xn,
+                         dys if bscale is not None else None, a, dh, dwd, dbd, dlg, dlb, ws, B, H, Wd, Cn, HD)
+        dW1, db1, dW2, db2 = grad_buf(w1), grad_buf(b1), grad_buf(w2), grad_buf(b2)
+        for (gy, xin, dW, db, Nn, K) in ((dh, xn, dW1, db1, HD, Cn), (dys, a, dW2, db2, Cn, HD)):
+            if dW is not None and _wgrad_deferrable(Nn, K, gy, xin):
+                _wgrad_defer(gy, 0, Nn, 0, xin, 0, K, 0, dW, 0, db, Nn, K, R, 1, 0)
+            elif dW is not None:
+                kern.gemm(kern.mat_plain(gy, 1, Nn, kfast=0), kern.mat_plain(xin, K, 1, kfast=0), dW, Nn, K, R, scr=K, scc=1,
+                          splits=kern.pick_splits(Nn, K, 1, (R + 31) // 32), atomic=True, asum=db)
+            elif db is not None:
+                kern.col_sum(gy, db, R, Nn)
+        return (dx,) + (None,) * 12
+
+
+def pvt_mlp_supported(x, HD, H, Wd) -> bool:
+    return x.dim() == 3 and kern.pvt_mlp_supported(x, x.shape[-1], HD, H, Wd) and os.environ.get("CENET_PVT_MLP_FUSED", "1") != "0"
+
+
+def pvt_mlp(x, H, Wd, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale=None):
+    return PvtMlpFn.apply(x, H, Wd, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale)
+
+
 class DWConvNCHWFn(Function):
     """cfam.py:150-151 (bias+GELU), blocks.py:173 (dilated, no bias), blocks.py:305."""
 

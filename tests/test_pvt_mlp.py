@@ -41,3 +41,30 @@ def test_fused_forward_equals_chain(dev, C, HD, H, W, B, drop):
     # identical rounding points; only the order of fp32 additions differs -> a few bf16 ulps on isolated elements
     assert d.max().item() <= 0.05 * ref.float().abs().max().item(), d.max().item()
     assert d.mean().item() <= 2e-3 * ref.float().abs().mean().item(), (d.mean().item(), ref.float().abs().mean().item())
+
+
+def _grads(fn, x, p, gy):
+    xg = x.clone().requires_grad_(True)
+    for v in p.values():
+        v.grad = None
+    fn(xg).backward(gy)
+    ops.wgrad_flush()
+    return [xg.grad.float()] + [p[k].grad.clone().float() for k in ("ln_g", "ln_b", "w1", "b1", "wd", "bd", "w2", "b2")]
+
+
+@pytest.mark.parametrize("C,HD,H,W,B,drop", [(64, 128, 16, 14, 2, True), (64, 64, 7, 14, 1, False), (128, 128, 14, 28, 2, True),
+                                              (128, 192, 8, 14, 1, False)])
+def test_fused_backward_equals_chain(dev, C, HD, H, W, B, drop):
+    p = _params(C, HD, dev)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, H * W, C, generator=g) * 1.5).to(BF).to(dev)
+    gy = torch.randn(B, H * W, C, generator=g).to(BF).to(dev)
+    bscale = torch.tensor([0.0, 1.25][:B] if B > 1 else [1.25], dtype=torch.float32, device=dev) if drop else None
+    ref = _grads(lambda t: _chain(t, p, H, W, bscale), x, p, gy)
+    got = _grads(lambda t: ops.pvt_mlp(t, H, W, p["ln_g"], p["ln_b"], 1e-6, p["w1"], p["b1"], p["wd"], p["bd"], p["w2"], p["b2"],
+                                       bscale), x, p, gy)
+    names = ["dx", "ln_g", "ln_b", "w1", "b1", "wd", "bd", "w2", "b2"]
+    for n, r, o in zip(names, ref, got):
+        assert o.shape == r.shape, n
+        err = (o - r).norm().item() / max(r.norm().item(), 1e-12)
+        assert err < 1e-2, (n, err)

@@ -27,7 +27,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for C, HD, H, W in [(64, 512, 56, 56), (128, 1024, 28, 28)]:
+for C, HD, H, W in [(64, 512, 56, 56), (128, 1024, 28, 28)][:int(os.environ.get("MLP_NCFG", "2"))]:
     B = 32
     p = _params(C, HD, dev)
     x = (torch.randn(B, H * W, C, device=dev) * 1.5).to(BF)
@@ -47,6 +47,21 @@ for C, HD, H, W in [(64, 512, 56, 56), (128, 1024, 28, 28)]:
     d = (y.float() - ref.float()).abs()
     print(f"C{C} HD{HD} {H}x{W}: max|d| {d.max().item():.4f} mean|d| {d.mean().item():.2e} (|ref| mean {ref.float().abs().mean().item():.3f})")
     print(f"   forward: fused {timeit(fused):8.1f} us   chain {timeit(chain):8.1f} us")
+    if hasattr(kern, "pvt_mlp_bwd"):
+        gy0 = torch.randn_like(x)
+        dx, xn, dys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        aa = torch.empty(B, H * W, HD, device=dev, dtype=BF)
+        dh = torch.empty_like(aa)
+        ws = torch.empty(kern.pvt_mlp_bwd_ws_floats(C, HD), device=dev)
+        gr = [torch.zeros_like(p[k]) for k in ("wd", "bd", "ln_g", "ln_b")]
+
+        def bwd_raw():
+            kern.pvt_mlp_bwd(x, gy0, p["ln_g"], p["ln_b"], 1e-6, w1, p["b1"], p["wd"], p["bd"], w2, bscale, dx, xn, dys, aa, dh,
+                             gr[0], gr[1], gr[2], gr[3], ws, B, H, W, C, HD)
+
+        print(f"   backward kernel + fold alone: {timeit(bwd_raw):8.1f} us")
+    if os.environ.get("MLP_RAW_ONLY"):
+        continue
     if hasattr(ops, "pvt_mlp"):
         xg = x.clone().requires_grad_(True)
         gy = torch.randn_like(x)
