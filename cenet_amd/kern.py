@@ -396,27 +396,15 @@ def pvt_mlp_supported(x, Cn, HD, H, W) -> bool:
     return bool(is_bf16(x) and x.data_ptr() % 16 == 0 and _lib.lib().cenet_pvt_mlp_supported(Cn, HD, H, W))
 
 
-def pvt_mlp_fwd(x, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, Cn, HD):
-    """y = x + s_b (fc2(GELU(DW3x3(fc1(LN(x))) + bd)) + b2), one launch (bf16 tokens; w1 / w2 are the bf16 shadows)"""
-    _chk(x, ln_g, ln_b, w1, b1, wd, bd, w2, b2, bscale, y)
+def pvt_mlp_fwd(x, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, Cn, HD, saved=None):
+    """y = x + s_b (fc2(GELU(DW3x3(fc1(LN(x))) + bd)) + b2), one launch (bf16 tokens; w1 / w2 are the bf16 shadows).
+    saved = (xn, mean, rstd, h, a): also store the LayerNorm output and statistics, the fc1 output and the GELU output (what the
+    backward chain reads)."""
+    xn, mean, rstd, h, a = saved if saved is not None else (None,) * 5
+    _chk(x, ln_g, ln_b, w1, b1, wd, bd, w2, b2, bscale, y, xn, mean, rstd, h, a)
     assert is_bf16(x) and is_bf16(y) and is_bf16(w1) and is_bf16(w2)
-    _call("cenet_pvt_mlp_fwd_bf16", x, ln_g, ln_b, float(eps), w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, Cn, HD)
-
-
-
-def pvt_mlp_bwd(x, dy, ln_g, ln_b, eps, w1, b1, wd, bd, w2, bscale, dx, xn, dys, a, dh, dwd, dbd, dln_g, dln_b, ws, B, H, W, Cn, HD):
-    """backward of pvt_mlp_fwd in one launch (+ a fold): dx (residual path included); xn = LN(x), dys = s_b dy, a = GELU output
-    and dh = dL/d(fc1 output) are written once in bf16 as the operands of the grouped fc1 / fc2 weight gradients; the
-    depthwise-conv and LayerNorm parameter gradients are ADDED into dwd / dbd / dln_g / dln_b."""
-    _chk(x, dy, ln_g, ln_b, w1, b1, wd, bd, w2, bscale, dx, xn, dys, a, dh, dwd, dbd, dln_g, dln_b, ws)
-    _call("cenet_pvt_mlp_bwd_bf16", x, dy, ln_g, ln_b, float(eps), w1, b1, wd, bd, w2, bscale, dx, xn, dys, a, dh, dwd, dbd,
-          dln_g, dln_b, ws, B, H, W, Cn, HD)
-
-
-def pvt_mlp_bwd_ws_floats(Cn, HD) -> int:
-    f = _lib.lib().cenet_pvt_mlp_bwd_ws_floats
-    f.restype = C.c_long
-    return int(f(Cn, HD))
+    _call("cenet_pvt_mlp_fwd_bf16", x, ln_g, ln_b, float(eps), w1, b1, wd, bd, w2, b2, bscale, y, xn, mean, rstd, h, a, B, H, W,
+          Cn, HD)
 
 
 def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil, x_off=0, g_off=0):

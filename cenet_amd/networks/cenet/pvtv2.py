@@ -124,6 +124,11 @@ class Block(nn.Module):
         # layernorm_res hands x back for the skip connection so that both gradients meet inside the LN backward kernel
         y, xr = ops.layernorm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x = self.attn(y, H, W, resid=xr, bscale=self._scale(x))
+        m = self.mlp
+        if ops.pvt_mlp_supported(x, m.fc1.out_features, H, W):
+            # bf16 tokens at 56x56 / 28x28 (C = 64 / 128): norm2 + Mlp + DropPath + residual as ONE forward kernel (csrc/pvt_mlp.hip)
+            return ops.pvt_mlp(x, H, W, self.norm2.weight, self.norm2.bias, self.norm2.eps, m.fc1.weight, m.fc1.bias,
+                               m.dwconv.dwconv.weight, m.dwconv.dwconv.bias, m.fc2.weight, m.fc2.bias, self._scale(x))
         y, xr = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         x = self.mlp(y, H, W, resid=xr, bscale=self._scale(x))
         return x

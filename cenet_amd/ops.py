@@ -855,10 +855,10 @@ class DWConvTokFn(Function):
 
 
 class PvtMlpFn(Function):
-    """pvtv2.py:145-149 (second half) as one kernel per pass on bf16 tokens: x + s_b * Mlp(LayerNorm(x)) with
-    Mlp = fc2(GELU(DW3x3(fc1(.)))) (pvtv2.py:40-47, 364-370).  Nothing but x is saved: the backward kernel recomputes the hidden
-    tensor tile by tile and writes the four bf16 operands of the fc1 / fc2 weight gradients, which are recorded for the grouped
-    launch like every other Linear's (csrc/pvt_mlp.hip)."""
+    """pvtv2.py:145-149 (second half) with ONE forward kernel on bf16 tokens: x + s_b * Mlp(LayerNorm(x)), Mlp =
+    fc2(GELU(DW3x3(fc1(.)))) (pvtv2.py:40-47, 364-370; csrc/pvt_mlp.hip).  The kernel stores what the backward pass reads (LN
+    output + statistics, fc1 output, GELU output) as it goes; the backward pass is the chain of LayerNormResFn / LinearFn /
+    DWConvTokFn backward launches, on those tensors."""
 
     @staticmethod
     def forward(ctx, x, H, Wd, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale):
@@ -866,48 +866,65 @@ class PvtMlpFn(Function):
         B, N, Cn = x.shape
         HD = w1.shape[0]
         y = torch.empty_like(x)
-        kern.pvt_mlp_fwd(x, ln_g, ln_b, eps, kern.wq(w1, x), b1, wd, bd, kern.wq(w2, x), b2, bscale, y, B, H, Wd, Cn, HD)
-        ctx.save_for_backward(x, bscale)
+        saved = None
+        if any(ctx.needs_input_grad):
+            saved = (torch.empty_like(x), _empty((B * N,), x), _empty((B * N,), x),
+                     torch.empty((B, N, HD), device=x.device, dtype=x.dtype), torch.empty((B, N, HD), device=x.device, dtype=x.dtype))
+        kern.pvt_mlp_fwd(x, ln_g, ln_b, eps, kern.wq(w1, x), b1, wd, bd, kern.wq(w2, x), b2, bscale, y, B, H, Wd, Cn, HD, saved)
+        if saved is not None:
+            ctx.save_for_backward(x, bscale, *saved)
         ctx.refs = (ln_g, ln_b, w1, b1, wd, bd, w2, b2)
-        ctx.cfg = (H, Wd, eps)
+        ctx.cfg = (H, Wd)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, bscale = ctx.saved_tensors
+        x, bscale, xn, mean, rstd, h, a = ctx.saved_tensors
         ln_g, ln_b, w1, b1, wd, bd, w2, b2 = ctx.refs
-        H, Wd, eps = ctx.cfg
+        H, Wd = ctx.cfg
         g = _c(g)
         B, N, Cn = x.shape
         HD = w1.shape[0]
         R = B * N
-        dx = torch.empty_like(x)
-        xn = torch.empty_like(x)
-        dys = torch.empty_like(x) if bscale is not None else g
-        a = torch.empty((B, N, HD), device=x.device, dtype=x.dtype)
-        dh = torch.empty((B, N, HD), device=x.device, dtype=x.dtype)
-        ws = _empty((kern.pvt_mlp_bwd_ws_floats(Cn, HD),), x)
-        dwd, dbd, dlg, dlb = grad_buf(wd), grad_buf(bd), grad_buf(ln_g), grad_buf(ln_b)
-        scratch = [t is None for t in (dwd, dbd, dlg, dlb)]
-        if scratch[0]:
-            dwd = _zeros(wd.shape, x)
-        if scratch[1]:
-            dbd = _zeros(bd.shape, x)
-        if scratch[2]:
-            dlg = _zeros(ln_g.shape, x)
-        if scratch[3]:
-            dlb = _zeros(ln_b.shape, x)
-        kern.pvt_mlp_bwd(x, g, ln_g, ln_b, eps, kern.wq(w1, x), b1, wd, bd, kern.wq(w2, x), bscale, dx, xn,
-                         dys if bscale is not None else None, a, dh, dwd, dbd, dlg, dlb, ws, B, H, Wd, Cn, HD)
-        dW1, db1, dW2, db2 = grad_buf(w1), grad_buf(b1), grad_buf(w2), grad_buf(b2)
-        for (gy, xin, dW, db, Nn, K) in ((dh, xn, dW1, db1, HD, Cn), (dys, a, dW2, db2, Cn, HD)):
+        # fc2 (LinearFn.backward with the DropPath scale)
+        gs = g
+        if bscale is not None:
+            gs = torch.empty_like(g)
+            kern.scale_batch(g, bscale, gs, B, g.numel() // B)
+
+        def wgrad(gy, xin, Wp, bp, Nn, K):
+            dW, db = grad_buf(Wp), grad_buf(bp)
             if dW is not None and _wgrad_deferrable(Nn, K, gy, xin):
                 _wgrad_defer(gy, 0, Nn, 0, xin, 0, K, 0, dW, 0, db, Nn, K, R, 1, 0)
-            elif dW is not None:
-                kern.gemm(kern.mat_plain(gy, 1, Nn, kfast=0), kern.mat_plain(xin, K, 1, kfast=0), dW, Nn, K, R, scr=K, scc=1,
-                          splits=kern.pick_splits(Nn, K, 1, (R + 31) // 32), atomic=True, asum=db)
-            elif db is not None:
-                kern.col_sum(gy, db, R, Nn)
+            elif dW is not None or db is not None:
+                with _wgrad_side(gy, xin):
+                    if dW is not None:
+                        kern.gemm(kern.mat_plain(gy, 1, Nn, kfast=0), kern.mat_plain(xin, K, 1, kfast=0), dW, Nn, K, R, scr=K,
+                                  scc=1, splits=kern.pick_splits(Nn, K, 1, (R + 31) // 32), atomic=True, asum=db)
+                    else:
+                        kern.col_sum(gy, db, R, Nn)
+
+        wgrad(gs, a, w2, b2, Cn, HD)
+        da = torch.empty_like(a)
+        kern.gemm(kern.mat_plain(gs, Cn, 1, kfast=1), kern.mat_plain(kern.wq(w2, x), HD, 1, kfast=0), da, R, HD, Cn, scr=HD, scc=1)
+        # depthwise conv + GELU (DWConvTokFn.backward, pre-activation recomputed from h)
+        dwd, dbd = grad_buf(wd), grad_buf(bd)
+        if dwd is None:
+            dwd, dbd = _zeros(wd.shape, x), _zeros(bd.shape, x)
+        gu = torch.empty_like(da)
+        kern.dw_tok_bwd_pre(h, da, wd, bd, gu, dwd, dbd, B, HD, H, Wd, "gelu")
+        dh = da  # (its buffer is free again)
+        kern.dw_tok(gu, wd, None, dh, None, B, HD, H, Wd, 1)
+        # fc1
+        wgrad(dh, xn, w1, b1, HD, Cn)
+        dxn = torch.empty_like(x)
+        kern.gemm(kern.mat_plain(dh, HD, 1, kfast=1), kern.mat_plain(kern.wq(w1, x), Cn, 1, kfast=0), dxn, R, Cn, HD, scr=Cn, scc=1)
+        # LayerNorm + the residual connection (LayerNormResFn.backward)
+        dx = torch.empty_like(x)
+        dg, db = grad_buf(ln_g), grad_buf(ln_b)
+        if dg is None:
+            dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
+        kern.layernorm_bwd(dxn, x, ln_g, mean, rstd, dx, dg, db, R, Cn, dx_add=g)
         return (dx,) + (None,) * 12
 
 

@@ -278,6 +278,18 @@ int cenet_dwconv3x3_wgrad_nchw_acc_f32(const float* x, long sxb, const float* dy
 int cenet_dwconv3x3_wgrad_tok_acc_f32(const float* x, const float* dy, float* dw_acc, float* dbias_acc, int B, int C, int H,
                                       int W, cenet_stream_t stream);
 
+/* ---- fused PVTv2 MLP half (pvt_mlp.hip) — pvtv2.py:40-47,145-149,364-370 on bf16 tokens [B, H*W, C] --------------------- */
+/* y = x + s_b (fc2(GELU(DW3x3(fc1(LayerNorm(x))) + bd)) + b2) in ONE launch: replaces aten::native_layer_norm + addmm +
+ * convolution(groups) + gelu + addmm + mul + add.  w1 [HD, C] / w2 [C, HD] are bf16, everything else fp32; bscale [B] (DropPath
+ * keep / keep_prob per sample) may be NULL.  xn_out / mean_out / rstd_out / h_out / a_out (all or none): the LayerNorm output
+ * and statistics, the fc1 output and the GELU output, stored for the backward chain.  CENET_EUNSUPPORTED unless
+ * cenet_pvt_mlp_supported(C, HD, H, W) (C in {64, 128}, HD % 64 == 0, W % 14 == 0, H % 7 == 0 or H % 8 == 0). */
+int cenet_pvt_mlp_supported(int C, int HD, int H, int W);
+int cenet_pvt_mlp_fwd_bf16(const unsigned short* x, const float* ln_g, const float* ln_b, float eps, const unsigned short* w1,
+                           const float* b1, const float* wd, const float* bd, const unsigned short* w2, const float* b2,
+                           const float* bscale, unsigned short* y, unsigned short* xn_out, float* mean_out, float* rstd_out,
+                           unsigned short* h_out, unsigned short* a_out, int B, int H, int W, int C, int HD, cenet_stream_t stream);
+
 /* ---- resampling (resample.hip) ---------------------------------------------------------------------------- */
 /* aten::upsample_bilinear2d(+_backward) — dseb.py:67-68; cfam.py:217,232; blocks.py:210; out.py:74 */
 int cenet_bilinear_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo,

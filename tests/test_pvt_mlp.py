@@ -35,8 +35,27 @@ def test_fused_forward_equals_chain(dev, C, HD, H, W, B, drop):
     with torch.no_grad():
         ref = _chain(x, p, H, W, bscale)
         y = torch.empty_like(x)
+        saved = (torch.empty_like(x), torch.empty(B * H * W, device=dev), torch.empty(B * H * W, device=dev),
+                 torch.empty(B, H * W, HD, dtype=BF, device=dev), torch.empty(B, H * W, HD, dtype=BF, device=dev))
         kern.pvt_mlp_fwd(x, p["ln_g"], p["ln_b"], 1e-6, kern.wq(p["w1"], x), p["b1"], p["wd"], p["bd"], kern.wq(p["w2"], x),
-                         p["b2"], bscale, y, B, H, W, C, HD)
+                         p["b2"], bscale, y, B, H, W, C, HD, saved)
+        y2 = torch.empty_like(x)  # inference form: nothing saved, same result
+        kern.pvt_mlp_fwd(x, p["ln_g"], p["ln_b"], 1e-6, kern.wq(p["w1"], x), p["b1"], p["wd"], p["bd"], kern.wq(p["w2"], x),
+                         p["b2"], bscale, y2, B, H, W, C, HD)
+        assert torch.equal(y, y2)
+        # the saved tensors against the chain's own
+        xn_ref = torch.empty_like(x)
+        mean_ref, rstd_ref = torch.empty(B * H * W, device=dev), torch.empty(B * H * W, device=dev)
+        kern.layernorm_fwd(x, p["ln_g"], p["ln_b"], xn_ref, mean_ref, rstd_ref, B * H * W, C, 1e-6)
+        h_ref = ops.linear(xn_ref, p["w1"], p["b1"])
+        a_ref = ops.dwconv_tok(h_ref, p["wd"], p["bd"], H, W, act="gelu")
+    for got, want, name in ((saved[0], xn_ref, "xn"), (saved[1], mean_ref, "mean"), (saved[2], rstd_ref, "rstd"),
+                            (saved[3], h_ref, "h"), (saved[4], a_ref, "a")):
+        dd = (got.float() - want.float()).abs()
+        assert dd.max().item() <= 0.04 * max(want.float().abs().max().item(), 1e-6), (name, dd.max().item())
+        assert dd.mean().item() <= 1e-3 * max(want.float().abs().mean().item(), 1e-6), (name, dd.mean().item())
+    with torch.no_grad():
+        pass
     d = (y.float() - ref.float()).abs()
     # identical rounding points; only the order of fp32 additions differs -> a few bf16 ulps on isolated elements
     assert d.max().item() <= 0.05 * ref.float().abs().max().item(), d.max().item()

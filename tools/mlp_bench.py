@@ -35,8 +35,14 @@ for C, HD, H, W in [(64, 512, 56, 56), (128, 1024, 28, 28)][:int(os.environ.get(
     y = torch.empty_like(x)
     w1, w2 = kern.wq(p["w1"], x), kern.wq(p["w2"], x)
 
+    saved = (torch.empty_like(x), torch.empty(B * H * W, device=dev), torch.empty(B * H * W, device=dev),
+             torch.empty(B, H * W, HD, dtype=BF, device=dev), torch.empty(B, H * W, HD, dtype=BF, device=dev))
+
     def fused():
         kern.pvt_mlp_fwd(x, p["ln_g"], p["ln_b"], 1e-6, w1, p["b1"], p["wd"], p["bd"], w2, p["b2"], bscale, y, B, H, W, C, HD)
+
+    def fused_saving():
+        kern.pvt_mlp_fwd(x, p["ln_g"], p["ln_b"], 1e-6, w1, p["b1"], p["wd"], p["bd"], w2, p["b2"], bscale, y, B, H, W, C, HD, saved)
 
     def chain():
         with torch.no_grad():
@@ -46,20 +52,7 @@ for C, HD, H, W in [(64, 512, 56, 56), (128, 1024, 28, 28)][:int(os.environ.get(
     fused()
     d = (y.float() - ref.float()).abs()
     print(f"C{C} HD{HD} {H}x{W}: max|d| {d.max().item():.4f} mean|d| {d.mean().item():.2e} (|ref| mean {ref.float().abs().mean().item():.3f})")
-    print(f"   forward: fused {timeit(fused):8.1f} us   chain {timeit(chain):8.1f} us")
-    if hasattr(kern, "pvt_mlp_bwd"):
-        gy0 = torch.randn_like(x)
-        dx, xn, dys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-        aa = torch.empty(B, H * W, HD, device=dev, dtype=BF)
-        dh = torch.empty_like(aa)
-        ws = torch.empty(kern.pvt_mlp_bwd_ws_floats(C, HD), device=dev)
-        gr = [torch.zeros_like(p[k]) for k in ("wd", "bd", "ln_g", "ln_b")]
-
-        def bwd_raw():
-            kern.pvt_mlp_bwd(x, gy0, p["ln_g"], p["ln_b"], 1e-6, w1, p["b1"], p["wd"], p["bd"], w2, bscale, dx, xn, dys, aa, dh,
-                             gr[0], gr[1], gr[2], gr[3], ws, B, H, W, C, HD)
-
-        print(f"   backward kernel + fold alone: {timeit(bwd_raw):8.1f} us")
+    print(f"   forward: fused {timeit(fused):8.1f} us   fused + saved tensors {timeit(fused_saving):8.1f} us   chain {timeit(chain):8.1f} us")
     if os.environ.get("MLP_RAW_ONLY"):
         continue
     if hasattr(ops, "pvt_mlp"):
