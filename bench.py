@@ -350,18 +350,17 @@ def stage_block(net, body, B, size, steps=2):
         e.record()
         order.append(("<end of backward>", e))
         ops.wgrad_flush()
-        ops._WgradQueue.armed = False
         e2 = torch.cuda.Event(enable_timing=True)
         e2.record()
         wg_ev.append((e, e2))
     try:
         for _ in range(steps):
             _hold_stream()
-            ops._WgradQueue.armed = True  # no end-of-backward callback in this pass: after_backward() issues the flush itself
+            ops.wgrad_hold(True)  # no end-of-backward callback in this pass: after_backward() issues the flush itself
             body(after_backward=after_backward)
         torch.cuda.synchronize()
     finally:
-        ops._WgradQueue.armed = False
+        ops.wgrad_hold(False)
         for h in handles:
             h.remove()
         ops.set_wgrad_overlap(old)

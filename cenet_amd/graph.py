@@ -115,7 +115,7 @@ def backward_pieces(loss: torch.Tensor, cuts):
     (cenet_amd.optim.cenet_segments): piece 0 differentiates the loss down to the cut leaves (head + decoder parameters final),
     piece k = 1..4 differentiates encoder stage 5 - k from the gradient its leaf has collected (that stage's parameters final;
     the leaf below it receives its last contribution).  Each piece is its own autograd-engine run, so the recorded (grouped)
-    weight gradients of a segment are launched when its piece ends (ops._WgradQueue)."""
+    weight gradients of a segment are launched when its piece ends (ops._WgradState)."""
     from . import ops
 
     def head():
@@ -149,6 +149,12 @@ class SegmentedStep:
         self.net, self.fwd_loss_fn, self.optimizer = net, fwd_loss_fn, optimizer
         self.on_segment, self.finish = on_segment, finish
         self.graphs = None
+        # the stage-output hooks of an attached GradReducer would fire inside piece 0 on decoder-only partial gradients and start
+        # the stage segments' all-reduces before their backward has run: the segmented step drives the reducer itself
+        core = getattr(net, "module", net)
+        if getattr(core, "_grad_sync", None) is not None:
+            raise RuntimeError("SegmentedStep: detach the GradReducer's backward hooks (net._grad_sync) first; pass "
+                               "reducer.segment_ready / reducer.finish as on_segment / finish instead")
         if not graphs:
             return
         side = torch.cuda.Stream()
@@ -161,6 +167,15 @@ class SegmentedStep:
         torch.cuda.synchronize()
         optimizer.prepare()
         self.cuts = enable_segment_cuts(net)
+        try:  # whatever a capture raises, the model must not stay cut (its encoder would silently stop receiving gradients)
+            self._capture(net, fwd_loss_fn, optimizer, on_segment, finish)
+        except BaseException:
+            self.graphs = None
+            raise
+        finally:
+            disable_segment_cuts(net)  # replays run no Python forward; eager forwards of the same model are whole again
+
+    def _capture(self, net, fwd_loss_fn, optimizer, on_segment, finish):
         # capture: thread-local error mode after a full drain (the process group's watchdog polls events of in-flight
         # collectives from another thread, see GraphedSplitStep)
         self.graphs = []
@@ -168,6 +183,9 @@ class SegmentedStep:
         with torch.cuda.graph(g0, capture_error_mode="thread_local"):
             optimizer.zero_grad()
             self.loss = fwd_loss_fn()
+            if len(self.cuts) != 4:
+                raise RuntimeError(f"SegmentedStep: expected the four encoder stage outputs to be cut, got {len(self.cuts)} "
+                                   "(the forward must run CENet.backbone.forward_features in training mode with grad enabled)")
             pieces = backward_pieces(self.loss, self.cuts)
             pieces[0]()
         self.graphs.append(g0)
@@ -187,7 +205,6 @@ class SegmentedStep:
         optimizer._steps -= 1
         self.graphs.append(gs)
         torch.cuda.synchronize()
-        disable_segment_cuts(net)  # replays run no Python forward; eager forwards of the same model are whole again
 
     def _eager(self):
         cuts = enable_segment_cuts(self.net)

@@ -23,22 +23,26 @@ class CENet(nn.Module):
         self.out = OutHead(dec_in_spatial=56, dec_in_channels=channels[-1], x_in_spatial=224,
                            x_in_channels=input_channels, out_channels=num_classes, merge_mode=out_merge_mode,
                            up_block=out_up_block, up_ks=out_up_ks)
+        from ... import opaque
+        opaque.register(self)
+
+    def __setstate__(self, state):  # (deepcopy / unpickling: the copy is its own module for cenet_amd::forward)
+        super().__setstate__(state)
+        from ... import opaque
+        opaque.register(self)
 
     def forward(self, x):
-        if torch.jit.is_tracing():
-            # utils/utils.py:171-185 (print_param_flops, called on the model at main_acdc.py:128) runs fvcore's FlopCountAnalysis,
-            # a torch.jit.trace of the model.  A tracer turns tensor sizes into traced values (which cannot be passed to the C
-            # ABI) and could only record the custom kernels as opaque calls anyway: the forward runs with tracing suspended and
-            # the result is tied to the input by a zero-valued traced term, so the trace completes (the parameter count it
-            # reports is right, its FLOP count is ~0 — INTEGRATION.md).
-            state = torch._C._get_tracing_state()
-            torch._C._set_tracing_state(None)
-            try:
-                out = self._forward(x.detach())
-            finally:
-                torch._C._set_tracing_state(state)
-            return out + torch.zeros_like(x).sum().to(out.dtype)
+        if torch.jit.is_tracing() or torch.compiler.is_compiling():
+            # Tracing callers — utils/utils.py:171-185 (print_param_flops -> fvcore FlopCountAnalysis = torch.jit.trace, called at
+            # main_acdc.py:128) and main_acdc.py:188-191 (torch.compile(net, mode='default', fullgraph=True)) — see the forward as ONE
+            # opaque operator with a shape function and an autograd formula (cenet_amd/opaque.py): a tracer cannot look inside
+            # ctypes launches of hand-written kernels, and has nothing to optimise there
+            from ... import opaque
+            return opaque.forward(self, x, self._bf16_mode(x))
         return self._forward(x)
+
+    def _bf16_mode(self, x) -> bool:
+        return bool(x.dtype == torch.bfloat16 or kern.get_compute_bf16() or (x.is_cuda and torch.is_autocast_enabled("cuda")))
 
     def _forward(self, x):
         # throughput mode (kern.set_compute_bf16): the whole network runs on bf16 tensors — the input is rounded once here
@@ -47,11 +51,6 @@ class CENet(nn.Module):
         # mode: under an enabled CUDA autocast region the forward runs on bf16 tensors (fp32 islands as in
         # multihead_diffattn.py:108, rms_norm.py:19: softmax / norm statistics / accumulators; parameters stay fp32).  bf16 has
         # fp32's exponent range, so the GradScaler the caller wraps around the step is harmless but not needed.
-        if torch.compiler.is_compiling():
-            # main_acdc.py:188-191 (--compile): the operators below are ctypes launches of the HIP library inside
-            # autograd.Functions; a tracing compiler cannot see through them and fullgraph=True cannot be honoured
-            raise RuntimeError("cenet_amd.CENet does not support torch.compile: its operators are hand-written HIP kernels "
-                               "launched through a C ABI (capture the step with cenet_amd.graph.GraphedStep instead)")
         amp = x.is_cuda and torch.is_autocast_enabled("cuda")
         if (kern.get_compute_bf16() or amp) and x.dtype == torch.float32:
             x = kern.cast(x, torch.bfloat16)

@@ -117,20 +117,71 @@ def merged_buffer(bs):
     return joint
 
 
-class _WgradSide:
-    """Weight-gradient kernels can run on a second HIP stream, concurrently with the data-gradient chain of the backward
-    pass: they only feed the optimizer, and most of them are short, latency-bound launches that leave the chip half idle.
-    Off by default; `set_wgrad_overlap(True)` turns it on (bench.py does); `wgrad_join()` makes the current stream wait
-    for them and must run before anything reads the gradients (FusedSGD.step and the gradient all-reduce call it)."""
-    enabled = False
-    stream = None
-    pending = False
-    keep = []  # tensors the side stream still reads (see _wgrad_side): released in wgrad_join()
+class _WgradCfg:
+    """process-wide SWITCHES of the weight-gradient machinery (configuration, not per-pass state)"""
+    overlap = False  # weight-gradient kernels on a second HIP stream (set_wgrad_overlap)
+    grouping = os.environ.get("CENET_WGRAD_GROUP", "1") != "0"  # record + one grouped launch (0: the per-layer launches of round 2)
+    hold_bytes = int(float(os.environ.get("CENET_WGRAD_HOLD_MB", "3072")) * (1 << 20))  # recorded operands kept alive at most
+    hold = False  # measurement aid (wgrad_hold): no automatic flush, the caller flushes
+
+
+class _WgradState:
+    """Per-DEVICE state of the weight-gradient machinery: the recorded (deferred) problems of the grouped launch and the
+    weight-gradient stream.  One object per device index (`_wg`), created on first use: two models, or the replicas of a
+    multi-device nn.DataParallel (one autograd thread per device), never share a queue, a stream or an event ring."""
+
+    def __init__(self, device):
+        self.device = device
+        # --- deferred, GROUPED weight gradients (bf16 mode): LinearFn / MultiLinearFn / Conv1x1Fn / PvtMlpFn do not launch their
+        # dW = dY^T X contraction; they record it here, and flush() reduces everything recorded so far with one launch per <= 56
+        # problems (kern.wgrad_group, gemm_group.hip).  The queue flushes itself at the end of the backward pass (an autograd-engine
+        # callback queued with the first record OF THAT PASS), and earlier wherever somebody needs the gradients: a gradient-arena
+        # segment becoming final (GradReducer.segment_ready), wgrad_join() (FusedSGD.step, ParamArena.zero_grad), or when the
+        # recorded operands exceed _WgradCfg.hold_bytes.  The recorded tensors are kept alive until the flush has been issued.
+        self.items = []    # descriptor tuples for kern.wgrad_group
+        self.keep = []     # the dY / X tensors the descriptors point into
+        self.held = 0      # their bytes
+        self.task = None   # autograd graph task whose end-of-backward callback is queued
+        # --- the weight-gradient stream
+        self.stream = None
+        self.events = None
+        self.next_event = 0
+        self.pending = False
+        self.side_keep = []  # tensors the side stream still reads (see _wgrad_side): released in wgrad_join()
+
+    def flush(self):
+        if not self.items:
+            return
+        items, self.items = self.items, []
+        self.held = 0
+        try:
+            if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
+                with torch.cuda.device(self.device):
+                    kern.wgrad_group(items, self.device)
+            else:
+                kern.wgrad_group(items, self.device)
+        finally:
+            self.keep = []
+
+
+_WG = {}
+
+
+def _wg(device) -> _WgradState:
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0))
+    st = _WG.get(key)
+    if st is None:
+        st = _WG[key] = _WgradState(torch.device(*key) if key[0] == "cuda" else torch.device(key[0]))
+    return st
 
 
 def set_wgrad_overlap(on: bool) -> bool:
-    old = _WgradSide.enabled
-    _WgradSide.enabled = bool(on)
+    """Weight-gradient kernels can run on a second HIP stream, concurrently with the data-gradient chain of the backward
+    pass: they only feed the optimizer, and most of them are short, latency-bound launches that leave the chip half idle.
+    Off by default (bench.py turns it on for eager launches); `wgrad_join()` makes the current stream wait for them and must
+    run before anything reads the gradients (FusedSGD.step and the gradient all-reduce call it)."""
+    old = _WgradCfg.overlap
+    _WgradCfg.overlap = bool(on)
     return old
 
 
@@ -138,17 +189,17 @@ def set_wgrad_overlap(on: bool) -> bool:
 def _wgrad_side(*reads, returned=None):
     """runs the body on the weight-gradient stream, ordered after everything issued so far on the current stream.
     returned: the one tensor among `reads` that the calling Function also RETURNS as a gradient (see below)"""
-    if not _WgradSide.enabled or kern._lib.is_hostsim():
+    if not _WgradCfg.overlap or kern._lib.is_hostsim():
         yield
         return
-    cur = torch.cuda.current_stream()
-    if _WgradSide.stream is None:
-        _WgradSide.stream = torch.cuda.Stream()
-        _WgradSide.events = [torch.cuda.Event() for _ in range(64)]  # reused round-robin: creating one per op costs more
-        _WgradSide.next_event = 0
-    side = _WgradSide.stream
-    ev = _WgradSide.events[_WgradSide.next_event & 63]
-    _WgradSide.next_event += 1
+    st = _wg(next(t for t in reads if isinstance(t, Tensor)).device)
+    cur = torch.cuda.current_stream(st.device)
+    if st.stream is None:
+        st.stream = torch.cuda.Stream(st.device)
+        st.events = [torch.cuda.Event() for _ in range(64)]  # reused round-robin: creating one per op costs more
+    side = st.stream
+    ev = st.events[st.next_event & 63]
+    st.next_event += 1
     ev.record(cur)
     side.wait_event(ev)
     with torch.cuda.stream(side):
@@ -163,84 +214,98 @@ def _wgrad_side(*reads, returned=None):
         # that tensor is held (everything else is covered by record_stream), until the streams are joined (wgrad_join: the
         # optimizer step, zero_grad, the gradient all-reduce); a caller that never joins (a torch optimizer, autograd.grad
         # loops) is joined here every 256 entries, so the list cannot grow without bound.
-        if len(_WgradSide.keep) >= 256:
+        if len(st.side_keep) >= 256:
             cur.wait_stream(side)
-            _WgradSide.keep.clear()
-        _WgradSide.keep.append(returned)
-    _WgradSide.pending = True
+            st.side_keep.clear()
+        st.side_keep.append(returned)
+    st.pending = True
 
 
-def wgrad_stream():
-    """the weight-gradient stream if kernels may be pending on it, else None (for consumers that order another stream
-    after it without stalling the compute stream, e.g. the gradient all-reduce)"""
-    return _WgradSide.stream if _WgradSide.pending else None
+def wgrad_stream(device=None):
+    """the weight-gradient stream of `device` (default: the current one) if kernels may be pending on it, else None (for
+    consumers that order another stream after it without stalling the compute stream, e.g. the gradient all-reduce)"""
+    if kern._lib.is_hostsim() or not torch.cuda.is_available():
+        return None
+    st = _wg(torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
+    return st.stream if st.pending else None
 
 
 def wgrad_join():
-    wgrad_flush()
-    if _WgradSide.pending:
-        torch.cuda.current_stream().wait_stream(_WgradSide.stream)
-        _WgradSide.pending = False
-    _WgradSide.keep.clear()
-
-
-class _WgradQueue:
-    """Deferred, GROUPED weight gradients (bf16 mode): LinearFn / MultiLinearFn / Conv1x1Fn do not launch their dW = dY^T X
-    contraction; they record it here, and `wgrad_flush()` reduces everything recorded so far with one launch per <= 56
-    problems (kern.wgrad_group, gemm_group.hip).  The queue flushes itself at the end of the backward pass (an autograd-engine
-    callback queued with the first record), and earlier wherever somebody needs the gradients: a gradient-arena segment
-    becoming final (GradReducer.segment_ready), wgrad_join() (FusedSGD.step, ParamArena.zero_grad).  The recorded tensors are
-    kept alive until the flush has been issued on the stream their consumers run on."""
-    enabled = os.environ.get("CENET_WGRAD_GROUP", "1") != "0"  # (0: measurement aid, the per-layer launches of round 2)
-    items = []   # descriptor tuples for kern.wgrad_group
-    keep = []    # the dY / X tensors the descriptors point into
-    armed = False
-    device = None
+    """every recorded weight gradient is launched and every device's compute stream waits for its weight-gradient stream"""
+    for st in list(_WG.values()):
+        st.flush()
+        if st.pending:
+            torch.cuda.current_stream(st.device).wait_stream(st.stream)
+            st.pending = False
+        st.side_keep.clear()
 
 
 def set_wgrad_grouping(on: bool) -> bool:
     """measurement / test aid: off = every weight gradient is its own launch again (the round-2 path)"""
     wgrad_flush()
-    old = _WgradQueue.enabled
-    _WgradQueue.enabled = bool(on)
+    old = _WgradCfg.grouping
+    _WgradCfg.grouping = bool(on)
     return old
 
 
+def wgrad_hold(on: bool):
+    """measurement aid (bench.py's instrumented passes): while on, recorded weight gradients are launched only by an explicit
+    wgrad_flush() / wgrad_join(), never by the end-of-backward callback"""
+    _WgradCfg.hold = bool(on)
+
+
+def wgrad_pending() -> int:
+    """recorded, not yet launched weight-gradient problems over all devices"""
+    return sum(len(st.items) + len(st.keep) for st in _WG.values())
+
+
 def _wgrad_deferrable(M: int, N: int, *ts) -> bool:
-    return bool(_WgradQueue.enabled and M >= 48 and N >= 48 and all(t.dtype == torch.bfloat16 for t in ts))
+    return bool(_WgradCfg.grouping and M >= 48 and N >= 48 and all(t.dtype == torch.bfloat16 for t in ts))
+
+
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
 
 
 def _wgrad_defer(A: Tensor, a_off: int, lda: int, skbA: int, B: Tensor, b_off: int, ldb: int, skbB: int, dW: Tensor, c_off: int,
                  db: Optional[Tensor], M: int, N: int, K: int, nkb: int, kfast: int):
     """record dW[c_off:][M, N] += sum_{kb, k} A(m, k) B(k, n), db[m] += sum A(m, k) (offsets in elements)"""
-    q = _WgradQueue
-    q.items.append((A.data_ptr() + 2 * a_off, B.data_ptr() + 2 * b_off, dW.data_ptr() + 4 * c_off,
-                    db.data_ptr() if db is not None else None, lda, ldb, skbA, skbB, M, N, K, nkb, kfast))
-    q.keep.append((A, B))
-    q.device = A.device
-    if not q.armed:
-        q.armed = True
+    st = _wg(A.device)
+    tid = _graph_task_id() if _graph_task_id is not None else 0
+    if not _WgradCfg.hold and st.items and st.task is not None and tid != st.task:
+        # records of a backward pass that never reached its end (it raised: the engine runs no callbacks then).  Their
+        # gradients are void; adding them into a later pass's would be wrong, and they must not block that pass's own callback.
+        st.items, st.keep, st.held, st.task = [], [], 0, None
+    st.items.append((A.data_ptr() + 2 * a_off, B.data_ptr() + 2 * b_off, dW.data_ptr() + 4 * c_off,
+                     db.data_ptr() if db is not None else None, lda, ldb, skbA, skbB, M, N, K, nkb, kfast))
+    st.keep.append((A, B))
+    st.held += A.numel() * A.element_size() + B.numel() * B.element_size()
+    if _WgradCfg.hold:
+        return
+    if tid < 0:  # not inside a backward pass (a Function's backward called by hand): flush right away
+        st.flush()
+        return
+    if st.task != tid:
+        st.task = tid
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_flush_cb)
-        except RuntimeError:  # not inside a backward pass (a Function's backward called by hand): flush right away
-            _wgrad_flush_cb()
+            torch.autograd.Variable._execution_engine.queue_callback(lambda st=st, tid=tid: _wgrad_flush_cb(st, tid))
+        except RuntimeError:
+            st.task = None
+            st.flush()
+            return
+    if st.held > _WgradCfg.hold_bytes:  # bound the operands kept alive (a full launch costs nothing extra)
+        st.flush()
 
 
-def _wgrad_flush_cb():
-    _WgradQueue.armed = False
-    wgrad_flush()
+def _wgrad_flush_cb(st, tid):
+    if st.task == tid:
+        st.task = None
+    st.flush()
 
 
 def wgrad_flush():
-    """launch every recorded weight gradient on the current stream (no-op when nothing is recorded)"""
-    q = _WgradQueue
-    if not q.items:
-        return
-    items, q.items = q.items, []
-    try:
-        kern.wgrad_group(items, q.device)
-    finally:
-        q.keep = []
+    """launch every recorded weight gradient on the current stream of its device (no-op when nothing is recorded)"""
+    for st in list(_WG.values()):
+        st.flush()
 
 
 def _c(t: Optional[Tensor]) -> Optional[Tensor]:

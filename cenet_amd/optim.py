@@ -188,7 +188,7 @@ class FusedSGD:
         if sync_hyper:
             self._sync_hyper()
         from . import ops
-        ops.wgrad_join()  # weight gradients issued on the side stream (ops._WgradSide) must have landed
+        ops.wgrad_join()  # weight gradients issued on the side stream (ops._wgrad_side) must have landed
         kern.sgd_step(self.arena.params, self.arena.grads, self.buf, self.hyper, self.arena.numel, self.arena.shadow)
         self._steps += 1
 

@@ -58,7 +58,7 @@ class GradReducer:
         ops.wgrad_flush()  # the segment's recorded (grouped) weight gradients are launched now, ahead of its collective
         if self.cuda:
             # the collective must see the segment's weight gradients, which may still be running on their own stream
-            # (ops._WgradSide): the COMMUNICATION stream waits for that stream and for the compute stream; the compute
+            # (ops._wgrad_side): the COMMUNICATION stream waits for that stream and for the compute stream; the compute
             # stream itself is not held up
             wg = ops.wgrad_stream()
             if wg is not None:

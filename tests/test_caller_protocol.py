@@ -9,7 +9,10 @@ never shipped or imported; these tests replay its calls on `cenet_amd.networks.C
 * the same under `copy.deepcopy`, `nn.DataParallel` on one device, `state_dict()` -> `load_state_dict(strict=True)`;
 * AMP protocol (`autocast('cuda')` + `GradScaler`): the forward runs in the bf16 mode, the scaler neither skips a step nor
   changes its scale, the trajectory follows the fp32 one within the bf16 tolerance;
-* `torch.compile(net, fullgraph=True)` (main_acdc.py:188-191) is refused with a clear error."""
+* `torch.compile(net, mode='default', fullgraph=True)` + `torch.compile(criterion)` (main_acdc.py:188-191): the forward is one
+  opaque `cenet_amd::forward` operator for the tracer (cenet_amd/opaque.py); the compiled model trains like the eager one;
+* `print_param_flops` (utils/utils.py:171-181): the FLOP table entry of that operator reproduces the reference's 12.76 G;
+* two models trained alternately in one process (no process-global state in the weight-gradient machinery)."""
 import argparse
 import copy
 
@@ -172,14 +175,140 @@ def test_amp_protocol_runs_the_bf16_mode_under_the_callers_gradscaler():
         assert net(xd).dtype == torch.float32
 
 
+def _one_step(model, net, x, lab, criterion):
+    for p in net.parameters():
+        p.grad = None
+    out = model(x)
+    loss = criterion(out, lab)
+    loss.backward()
+    return loss.item(), out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+
 @pytest.mark.gpu
-def test_torch_compile_is_refused_with_a_clear_error():
+def test_torch_compile_fullgraph_trains_like_eager():
+    """main_acdc.py:188-191: `net = torch.compile(net, mode='default', fullgraph=True); criterion = torch.compile(criterion)`,
+    then the step body of :237-257.  One training step of the compiled pair against the eager pair from the same state (fp32
+    mode, DropPath off): loss and logits equal, every parameter gradient present and equal up to the order of fp32 atomics."""
     dev = use_hip()
     net, _ = _build(dev)
-    x, _ = O.synthetic_batch(1, 1, 4, seed=9)
-    compiled = torch.compile(net, mode="default", fullgraph=True)  # main_acdc.py:190
-    with pytest.raises(Exception, match="does not support torch.compile"):
-        compiled(x.to(dev))
+    net.train()
+    net.backbone.reset_drop_path(0.0)
+    ref = copy.deepcopy(net)
+    x, lab = O.synthetic_batch(2, 1, 4, seed=9)
+    xd, labd = x.to(dev), lab.to(dev)
+    crit = _criterion()
+    l0, o0, g0 = _one_step(ref, ref, xd, labd, crit)
+    cnet = torch.compile(net, mode="default", fullgraph=True)
+    ccrit = torch.compile(_criterion())
+    l1, o1, g1 = _one_step(cnet, net, xd, labd, ccrit)
+    assert abs(l0 - l1) < 1e-5 and torch.allclose(o0, o1, rtol=0, atol=1e-5)
+    assert set(g0) == set(g1) and len(g1) == 630
+    for n in g0:
+        d = (g0[n] - g1[n]).norm().item()
+        assert d <= 2e-3 * g0[n].norm().item() + 1e-7, (n, d, g0[n].norm().item())
+    # a second call replays the compiled graph (no recompilation per step), eval mode is its own graph
+    l2, _, _ = _one_step(cnet, net, xd, labd, ccrit)
+    assert abs(l2 - l1) < 1e-5
+    net.eval(), ref.eval()
+    with torch.no_grad():
+        assert torch.allclose(cnet(xd), ref(xd), rtol=0, atol=1e-5)
+
+
+def test_torch_compile_fullgraph_on_the_host_checker():
+    """the tracing protocol itself needs no GPU: the same check at 32x32 on the host SIMT checker (aot_eager backend: the
+    tracer, functionalisation and the joint forward / backward graph are the real ones, only code generation is skipped)"""
+    from backend import use_sim
+    import test_segmented as TS
+    from test_parallel_gloo import _cenet_shard
+    from cenet_amd import _lib
+    use_sim()
+    try:
+        net = TS._net(seed=7)
+        ref = copy.deepcopy(net)
+        crit = TS._crit()
+        x, lab = _cenet_shard(0)
+        l0, o0, g0 = _one_step(ref, ref, x, lab, crit)
+        cnet = torch.compile(net, mode="default", fullgraph=True, backend="aot_eager")
+        l1, o1, g1 = _one_step(cnet, net, x, lab, crit)
+        assert l0 == l1 and torch.equal(o0, o1) and set(g0) == set(g1)
+        for n in g0:
+            assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-7), n
+        with torch.no_grad():
+            net.eval(), ref.eval()
+            traced = torch.jit.trace(net, x, check_trace=False, strict=False)
+            assert [n.kind() for n in traced.graph.nodes() if n.kind().startswith("cenet_amd")] == ["cenet_amd::forward"]
+            assert torch.equal(traced(x), ref(x))
+    finally:
+        _lib._LIB, _lib._HOSTSIM = None, False
+
+
+def test_flop_count_of_the_opaque_operator_is_the_references():
+    """utils/utils.py:171-181 prints `FlopCountAnalysis(net, x).total() / 1e9` = 12.76 G for the ACDC preset (SURVEY.md section 6,
+    the paper's figure).  fvcore is absent here; cenet_amd.flops prices the operator by fvcore's rules on a dry run (no kernel
+    is launched, no GPU needed) and registers itself in fvcore's table when fvcore is importable."""
+    from cenet_amd import flops
+    from cenet_amd.networks import CENet
+    net = CENet(**ACDC_ARGS)
+    total = flops.count(net, (1, 1, 224, 224))
+    assert abs(total / 1e9 - 12.76) < 0.01 * 12.76, total
+    by = flops.count(net, (1, 1, 224, 224), by_op=True)
+    assert by["gemm"] > 0.95 * total  # convolutions, linears and attention products dominate
+    assert abs(flops.count(net, (2, 1, 224, 224)) - 2 * total) < 1e-6 * total  # (B == 1 skips the CCU's BatchNorm1d, cfam.py:258)
+    assert net.training  # the mode is restored
+
+
+@pytest.mark.gpu
+def test_two_models_in_one_process_train_independently():
+    """SURVEY section 8b "no global mutable state": two models built in one process, trained in alternation (bf16 mode, recorded
+    weight gradients, the weight-gradient stream on), end where each ends when trained alone."""
+    from cenet_amd import kern, ops, optim
+    dev = use_hip()
+    x, lab = O.synthetic_batch(2, 1, 4, seed=9)
+    xd, labd = x.to(dev), lab.to(dev)
+    crit = _criterion()
+
+    def fresh(seed):
+        from cenet_amd.networks import CENet
+        net = CENet(**ACDC_ARGS).to(dev)
+        net.load_state_dict(O.make_state_dict(O.CENetConfig(), seed=seed), strict=True)
+        net.train()
+        net.backbone.reset_drop_path(0.0)
+        arena = optim.ParamArena(net, optim.cenet_segments())
+        return net, optim.FusedSGD(arena, lr=0.01, momentum=0.9, weight_decay=1e-4), arena
+
+    def step(net, opt):
+        opt.zero_grad()
+        loss = crit(net(xd), labd)
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    kern.set_compute_bf16(True)
+    old = ops.set_wgrad_overlap(True)
+    try:
+        alone = []
+        for seed in (3, 4):
+            net, opt, arena = fresh(seed)
+            alone.append(([step(net, opt) for _ in range(2)], arena.params.clone()))
+        a, b = fresh(3), fresh(4)
+        la, lb = [], []
+        for _ in range(2):
+            # interleaved: both forwards first, then both backwards (recorded weight gradients of two models in flight)
+            a[1].zero_grad(), b[1].zero_grad()
+            loss_a, loss_b = crit(a[0](xd), labd), crit(b[0](xd), labd)
+            loss_a.backward()
+            loss_b.backward()
+            a[1].step(), b[1].step()
+            la.append(loss_a.item()), lb.append(loss_b.item())
+        torch.cuda.synchronize()
+        for (l_ref, p_ref), l_got, arena in ((alone[0], la, a[2]), (alone[1], lb, b[2])):
+            assert all(abs(u - v) < 2e-3 for u, v in zip(l_ref, l_got)), (l_ref, l_got)
+            cos = torch.nn.functional.cosine_similarity(arena.params - p_ref * 0, p_ref, dim=0).item()
+            assert cos > 0.999999, cos
+            assert (arena.params - p_ref).norm().item() < 1e-3 * p_ref.norm().item()
+    finally:
+        ops.set_wgrad_overlap(old)
+        kern.set_compute_bf16(False)
 
 
 @pytest.mark.gpu

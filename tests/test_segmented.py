@@ -119,7 +119,7 @@ def _worker(rank, world, port, q):
         step = graph.SegmentedStep(net, lambda: crit(net(x), lab), opt, on_segment, finish, graphs=False)
         loss = step().item()
         from cenet_amd import ops
-        assert not ops._WgradQueue.items
+        assert not ops.wgrad_pending()
         q.put((rank, loss, arena.params.clone().numpy(), started, {n: arena.index[n] for n in arena.index}, final))
     finally:
         dist.destroy_process_group()

@@ -133,8 +133,45 @@ def test_deferred_layers_match_the_per_layer_launches(dev):
         ref = _grads(run, params)
         ops.set_wgrad_grouping(True)
         got = _grads(run, params)
-        assert not ops._WgradQueue.items and not ops._WgradQueue.keep
+        assert not ops.wgrad_pending()
     finally:
         ops.set_wgrad_grouping(old)
     for r, t, n in zip(ref, got, ["W1", "b1", "W2", "Wq", "Wc", "bc"]):
         assert (r - t).abs().max().item() <= 2e-3 * r.abs().max().item() + 1e-6, n
+
+
+def test_a_backward_that_raises_does_not_poison_the_next_one(dev):
+    """a backward pass that raises after its first record never runs the end-of-backward callback; the NEXT pass must
+    still flush by itself (a caller with a torch optimizer never calls wgrad_join) and must not add the failed pass's records."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 64, generator=g).to(BF).to(dev)
+    W1 = torch.nn.Parameter((torch.randn(64, 64, generator=g) * 0.1).to(dev))
+    W2 = torch.nn.Parameter((torch.randn(64, 64, generator=g) * 0.1).to(dev))
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            raise RuntimeError("boom")
+
+    def run(fail):
+        h = ops.linear(x, W1)
+        if fail:
+            h = Boom.apply(h)
+        ops.linear(h, W2).float().sum().backward()
+
+    run(False)
+    ref = [W1.grad.clone(), W2.grad.clone()]
+    W1.grad.zero_(), W2.grad.zero_()
+    with pytest.raises(RuntimeError, match="boom"):
+        run(True)  # W2's weight gradient is recorded, then the pass dies
+    W1.grad.zero_(), W2.grad.zero_()
+    run(False)  # no wgrad_join / wgrad_flush by the caller
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert not ops.wgrad_pending()
+    for r, p in zip(ref, (W1, W2)):
+        assert torch.equal(r, p.grad)
