@@ -429,6 +429,27 @@ def _time_steps(fn, n):
     return (time.perf_counter() - t0) / n
 
 
+def dist_identity(dev, world):
+    """What makes an N > 1 line self-proving: the collective backend, its version, and how many DISTINCT GPUs the ranks really
+    sit on (every rank contributes its device's PCI identity / UUID; a launch that put two ranks on one device, or one that fell
+    back to another backend, shows here).  Collective: every rank calls it."""
+    pr = torch.cuda.get_device_properties(dev)
+    ident = str(getattr(pr, "uuid", "")) or "-"
+    pci = tuple(getattr(pr, k, -1) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    mine = (os.uname().nodename, ident, pci, pr.name)
+    allv = [None] * world
+    dist.all_gather_object(allv, mine)
+    backend = dist.get_backend()
+    rec = {"backend": backend, "world_size": world, "distinct_devices": len({(v[0], v[1], v[2]) for v in allv}),
+           "hosts": len({v[0] for v in allv}), "device_names": sorted({v[3] for v in allv})}
+    if backend == "nccl":
+        try:
+            rec["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())  # (RCCL reports its NCCL API level)
+        except Exception as e:  # pragma: no cover
+            rec["nccl_version"] = f"unavailable ({type(e).__name__})"
+    return rec
+
+
 def main():
     a = parse()
     cfg = CONFIGS[a.config]
@@ -450,6 +471,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(os.environ.get("CENET_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    dist_record = dist_identity(dev, world) if use_dist else None
 
     from cenet_amd import kern, losses, optim, parallel
     kern.set_compute_bf16(a.dtype == "bf16")
@@ -517,6 +539,7 @@ def main():
             if t_e <= t_g:
                 graphed = None
 
+    dist_times = {}
     if use_dist and a.graph != "off":
         # N > 1: three launch forms of the same step, timed for four untimed steps each on every rank; rank 0's pick is
         # broadcast (the collective sequence — one all-reduce per arena segment — is the same in all three):
@@ -561,6 +584,7 @@ def main():
                 cand()
             dist.barrier()
             times[name] = _time_steps(cand, 4)
+        dist_times = dict(times)
         order = ["eager", "split", "segmented"]
         best = min(times, key=times.get) if times else "eager"
         if a.dist_launch != "auto":
@@ -617,6 +641,8 @@ def main():
                           "final_loss": round(final_loss, 5)}}
         if launch_note:
             out["config"]["launch_choice"] = launch_note
+        if dist_record is not None:
+            out["config"]["rccl"] = dict(dist_record, launch_forms_ms={k: round(v * 1e3, 3) for k, v in dist_times.items()})
         if world == 1 and not a.no_roofline:
             out["roofline"] = roofline_block(body)
             out["roofline_stages"] = stage_block(net, body, B, cfg["size"])

@@ -77,6 +77,18 @@ __device__ __forceinline__ void pvt_load_kf64(const bf16_t* src, long ld, unsign
   ring_glds16(src + (long)row * ld + 8 * c, img + wave * 1024, lane);
 }
 
+// 64 k-rows x BX columns of a row-major bf16 matrix (pitch ld) -> row-fast LDS image [64][BX] (gemm_ring.h layout; 8 waves)
+template <int BX>
+__device__ __forceinline__ void pvt_load_rf(const bf16_t* src, long ld, unsigned char* img, int wave, int lane) {
+  constexpr int CH = BX / 8;
+#pragma unroll
+  for (int j = 0; j < BX / 64; ++j) {
+    const int S = (j * 8 + wave) * 64 + lane;
+    const int k = S / CH, c = (S % CH) ^ rf_key<BX>(k);
+    ring_glds16(src + (long)k * ld + 8 * c, img + (j * 8 + wave) * 1024, lane);
+  }
+}
+
 // LayerNorm of the halo tile into the k-fast image(s) XN[C / 64][PTP][64]; tokens outside the image (or beyond PT) become 0.
 // Interior tokens (halo <= ty < halo + TH, halo <= tx < halo + TW) also go to xn_out / mean_out / rstd_out when those are set
 // (pointers to the IMAGE's first token).
@@ -320,6 +332,417 @@ __global__ __launch_bounds__(512, 2) void pvt_mlp_fwd_kernel(PvtMlpArgs a) {
   }
 }
 
+// ============================================================================================================================
+// backward: two kernels instead of scale_batch + fc2 dgrad GEMM + depthwise/GELU backward + depthwise dgrad + fc1 dgrad GEMM +
+// LayerNorm backward.  (One kernel for everything was built and measured first — see the header.  What these two keep from it:
+// no halo RECOMPUTATION — the halo tiles of h and gu are read from memory — and two workgroups per CU.)
+//   K1  gu = (s_b g . W2[:, slab]) * GELU'(DW3x3(h) + bd)      workgroup = (slab of 64 hidden channels, run of tiles, image):
+//       the depthwise weight / bias gradients of the slab stay in registers over the workgroup's tiles
+//   K2  dh = DW3x3^T(gu) -> HBM (operand of the fc1 weight gradient);  dxn += dh . W1_slab over the slabs (registers);
+//       dx = g + LayerNormBackward(dxn)                        workgroup = tile, slabs walked inside
+// ============================================================================================================================
+__device__ __forceinline__ float pvt_gelu_grad(float u) {
+  const float ax = fabsf(u) * 0.70710678118654752f;
+  const float t = pvt_rcp(1.f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = fast_exp(-0.5f * u * u);
+  const float cdf = 0.5f * (1.f + copysignf(1.f - poly * e, u));
+  return cdf + u * 0.3989422804014327f * e;
+}
+
+struct PvtBwdArgs {
+  const bf16_t* g;       // [B, N, C]  gradient of the block output y
+  const float* bscale;   // [B] or null
+  const bf16_t* w1;      // [HD, C]
+  const bf16_t* w2;      // [C, HD]
+  const float* wd;       // [HD, 9]
+  const float* bd;       // [HD]
+  const bf16_t* h;       // [B, N, HD] fc1 output (saved by the forward kernel)
+  bf16_t* gu;            // [B, N, HD] gradient of the depthwise conv's output
+  bf16_t* gs;            // [B, N, C]  s_b g (operand of the fc2 weight gradient; written when bscale is set)
+  bf16_t* dh;            // [B, N, HD] gradient of fc1's output
+  float* dwd;            // [HD, 9] +=
+  float* dbd;            // [HD] +=
+  const bf16_t* x;       // [B, N, C]  block input (LayerNorm input)
+  const float* ln_g;
+  const float* mean;     // [B * N]
+  const float* rstd;
+  bf16_t* dx;            // [B, N, C]
+  float* ws;             // K2: [tiles][2 C] LayerNorm affine gradient partials
+  int H, W, HD, tiles_x, tiles_per_img, tpw;
+};
+
+// (rows x 64 channels) of a token-major bf16 tensor (pitch ld elements) -> LDS plane with 128-byte rows by LDS-DMA; `tok(p)`
+// gives the source token of plane row p or -1 for a zero row.  NI = ceil(rows * 8 / 512) instructions per wave.
+template <int ROWS, typename F>
+__device__ __forceinline__ void pvt_dma_plane(const bf16_t* base, long ld, unsigned char* plane, int wave, int lane, F tok) {
+  constexpr int NI = (ROWS * 8 + 511) / 512;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int S = (j * 8 + wave) * 64 + lane, p = S >> 3, c = S & 7;
+    if ((j * 8 + wave) * 64 < ROWS * 8) {  // (wave-uniform)
+      const long t = p < ROWS ? tok(p) : -1;
+      ring_glds16(t >= 0 ? (const void*)(base + t * ld + 8 * c) : (const void*)ring_zero16, plane + (j * 8 + wave) * 1024, lane);
+    }
+  }
+}
+
+template <int C, int TH, int TW>
+struct PvtB1Geo {
+  static constexpr int PW = TW + 2, PH = TH + 2, PT = PH * PW, NT = TH * TW, MTI = (NT + 15) / 16, SL = TW / 2;
+  static constexpr int KB = C / 64, KS = C / 32, HS = 136;
+  static constexpr int HP_B = (PT * 128 + 1023) / 1024 * 1024, GS_B = KB * MTI * 16 * 128, W2_B = KB * 8192, DA_B = MTI * 16 * HS;
+  static constexpr int O_HP = 0, O_GS = 2 * HP_B, O_W2 = O_GS + GS_B, O_DA = O_W2 + W2_B, LDS = O_DA + DA_B;
+};
+
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(512, 4) void pvt_mlp_bwd1_kernel(PvtBwdArgs a) {
+  typedef PvtB1Geo<C, TH, TW> G;
+  constexpr int PW = G::PW, PT = G::PT, NT = G::NT, MTI = G::MTI, SL = G::SL, KB = G::KB, KS = G::KS, HS = G::HS;
+  static_assert(G::LDS >= 8 * 32 * 20 * 4, "the end-of-kernel reduction reuses the buffers");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS];
+  unsigned char* const GS = lds + G::O_GS;
+  unsigned char* const W2R = lds + G::O_W2;
+  unsigned char* const DA = lds + G::O_DA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = PVT_WAVE_ID(tid);
+  const cenet_bid bid = cenet_xcd_block();
+  const int s = bid.x, b = bid.z;
+  const long img = (long)b * a.H * a.W;
+  const float sc = a.bscale ? a.bscale[b] : 1.f;
+  const int cp = tid & 31, strip = tid >> 5;
+  const int oy = strip >> 1, ox0 = (strip & 1) * SL;
+  const bool on = strip < 2 * TH;
+  const int ct = wave & 3;
+
+  // once per workgroup: the W2 slab (row-fast: k = output channel n, columns = the slab's hidden channels), depthwise weights
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) pvt_load_rf<64>(a.w2 + (long)(kb * 64) * a.HD + s * 64, a.HD, W2R + kb * 8192, wave, lane);
+  float wdv[18], wacc[2][10];
+  {
+    const float* wp = a.wd + (long)(s * 64 + 2 * cp) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float2 v = *(const float2*)(wp + 2 * i);
+      wdv[2 * i] = v.x, wdv[2 * i + 1] = v.y;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int k = 0; k < 10; ++k) wacc[e][k] = 0.f;
+  }
+  const float bd0 = a.bd[s * 64 + 2 * cp], bd1 = a.bd[s * 64 + 2 * cp + 1];
+
+  const int t_begin = bid.y * a.tpw;
+  const int t_end = t_begin + a.tpw < a.tiles_per_img ? t_begin + a.tpw : a.tiles_per_img;
+  auto issue_h = [&](int tile, int buf) __attribute__((always_inline)) {
+    const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * TW;
+    pvt_dma_plane<PT>(a.h + img * a.HD + s * 64, a.HD, lds + G::O_HP + buf * G::HP_B, wave, lane, [&](int p) -> long {
+      const int ty = p / PW, tx = p - ty * PW;
+      const int iy = y0 - 1 + ty, ix = x0 - 1 + tx;
+      return (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (long)iy * a.W + ix : -1;
+    });
+  };
+  issue_h(t_begin, 0);
+  int buf = 0;
+  for (int tile = t_begin; tile < t_end; ++tile, buf ^= 1) {
+    const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * TW;
+    // ---- s_b g of the tile -> k-fast image (B operand of the dgrad product); slab 0 also writes it out -------------------------
+    for (int i = tid; i < MTI * 16 * (C / 8); i += 512) {
+      const int ti = i / (C / 8), j = i - ti * (C / 8);
+      const int ry = ti / TW, rx = ti - ry * TW;
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (ti < NT && y0 + ry < a.H && x0 + rx < a.W) {
+        const long off = (img + (long)(y0 + ry) * a.W + x0 + rx) * C + 8 * j;
+        v = *(const uint4*)(a.g + off);
+        if (a.bscale) {
+          float f[8];
+          ldv<8>(f, (const bf16_t*)&v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= sc;
+          v = uint4{cenet_pack_bf2(f[0], f[1]), cenet_pack_bf2(f[2], f[3]), cenet_pack_bf2(f[4], f[5]), cenet_pack_bf2(f[6], f[7])};
+          if (s == 0) *(uint4*)(a.gs + off) = v;
+        }
+      }
+      *(uint4*)(GS + (j >> 3) * (MTI * 16 * 128) + ti * 128 + ((j & 7) ^ kf_key(ti)) * 16) = v;
+    }
+    ring_wait_vm<0>();
+    __syncthreads();  // this tile's h plane and g image (and, first time, the W2 slab) are in LDS
+    if (tile + 1 < t_end) issue_h(tile + 1, buf ^ 1);
+    // ---- da^T[slab channels, tokens] = W2[:, slab]^T . (s g)^T --------------------------------------------------------------
+    for (int tt = wave >> 2; tt < MTI; tt += 2) {
+      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        const bf16x8 wf = ring_frag_rf<64>(W2R + (k >> 1) * 8192, ct * 16, k & 1, lane);
+        const bf16x8 gf = ring_frag_kf(GS + (k >> 1) * (MTI * 16 * 128), tt * 16, k & 1, lane);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf, d, 0, 0, 0);
+      }
+      const int p = tt * 16 + (lane & 15);
+      *(uint2*)(DA + p * HS + (ct * 16 + (lane >> 4) * 4) * 2) = uint2{cenet_pack_bf2(d[0], d[1]), cenet_pack_bf2(d[2], d[3])};
+    }
+    __syncthreads();
+    // ---- gu = da * GELU'(DW3x3(h) + bd); depthwise weight / bias gradient -------------------------------------------------------
+    if (on) {
+      const unsigned char* hp = lds + G::O_HP + buf * G::HP_B + (oy * PW + ox0) * 128 + cp * 4;
+      float win[3][3][2];
+#pragma unroll
+      for (int kxx = 0; kxx < 2; ++kxx)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned v = *(const unsigned*)(hp + (ky * PW + kxx) * 128);
+          win[ky][kxx][0] = __uint_as_float(v << 16);
+          win[ky][kxx][1] = __uint_as_float(v & 0xFFFF0000u);
+        }
+      const int gy = y0 + oy;
+#pragma unroll
+      for (int i = 0; i < SL; ++i) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned v = *(const unsigned*)(hp + (ky * PW + i + 2) * 128);
+          win[ky][2][0] = __uint_as_float(v << 16);
+          win[ky][2][1] = __uint_as_float(v & 0xFFFF0000u);
+        }
+        float u0 = bd0, u1 = bd1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            u0 += wdv[ky * 3 + kx] * win[ky][kx][0];
+            u1 += wdv[9 + ky * 3 + kx] * win[ky][kx][1];
+          }
+        const int row = oy * TW + ox0 + i;
+        const unsigned dv = *(const unsigned*)(DA + row * HS + cp * 4);
+        const int gx = x0 + ox0 + i;
+        const bool in = gy < a.H && gx < a.W;
+        const float g0 = in ? __uint_as_float(dv << 16) * pvt_gelu_grad(u0) : 0.f;
+        const float g1 = in ? __uint_as_float(dv & 0xFFFF0000u) * pvt_gelu_grad(u1) : 0.f;
+        if (in) *(unsigned*)(a.gu + (img + (long)gy * a.W + gx) * a.HD + s * 64 + 2 * cp) = cenet_pack_bf2(g0, g1);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            wacc[0][ky * 3 + kx] += g0 * win[ky][kx][0];
+            wacc[1][ky * 3 + kx] += g1 * win[ky][kx][1];
+          }
+        wacc[0][9] += g0;
+        wacc[1][9] += g1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          win[ky][0][0] = win[ky][1][0], win[ky][0][1] = win[ky][1][1];
+          win[ky][1][0] = win[ky][2][0], win[ky][1][1] = win[ky][2][1];
+        }
+      }
+    }
+    __syncthreads();  // the g image, the da plane and this h plane are free
+  }
+  // ---- the slab's depthwise gradients: two strips per wave fold by a shuffle, the eight waves meet in LDS, one atomic each ------
+  float* red = (float*)lds;
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) wacc[e][k] += __shfl_xor(wacc[e][k], 32);
+  if (lane < 32) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int k = 0; k < 10; ++k) red[(wave * 32 + cp) * 20 + e * 10 + k] = wacc[e][k];
+  }
+  __syncthreads();
+  for (int i = tid; i < 640; i += 512) {
+    const int ch = i / 10, k = i - ch * 10;  // channel 0..63 of the slab, tap 0..8 or 9 = bias
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[(w * 32 + (ch >> 1)) * 20 + (ch & 1) * 10 + k];
+    if (k < 9) atomicAdd(&a.dwd[(long)(s * 64 + ch) * 9 + k], v);
+    else atomicAdd(&a.dbd[s * 64 + ch], v);
+  }
+}
+
+template <int C, int TH, int TW>
+struct PvtB2Geo {
+  static constexpr int PW = TW + 2, PH = TH + 2, PT = PH * PW, NT = TH * TW, MTI = (NT + 15) / 16, SL = TW / 2;
+  static constexpr int GU_B = (PT * 128 + 1023) / 1024 * 1024, W1_B = 64 * C * 2, DH_B = MTI * 16 * 128;
+  static constexpr int O_GU = 0, O_W1 = 2 * GU_B, O_DH = O_W1 + 2 * W1_B, O_LN = O_DH + DH_B, LDS = O_LN + 2 * C * 4;
+};
+
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(512, C == 64 ? 4 : 2) void pvt_mlp_bwd2_kernel(PvtBwdArgs a) {
+  typedef PvtB2Geo<C, TH, TW> G;
+  constexpr int PW = G::PW, PT = G::PT, NT = G::NT, MTI = G::MTI, SL = G::SL;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS];
+  unsigned char* const DH = lds + G::O_DH;
+  float* const LNS = (float*)(lds + G::O_LN);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = PVT_WAVE_ID(tid);
+  const cenet_bid bid = cenet_xcd_block();
+  const int b = bid.x / a.tiles_per_img, t = bid.x - b * a.tiles_per_img;
+  const int y0 = (t / a.tiles_x) * TH, x0 = (t % a.tiles_x) * TW;
+  const long img = (long)b * a.H * a.W;
+  const int nslab = a.HD / 64;
+  const int cp = tid & 31, strip = tid >> 5;
+  const int oy = strip >> 1, ox0 = (strip & 1) * SL;
+  const bool on = strip < 2 * TH;
+  for (int i = tid; i < 2 * C; i += 512) LNS[i] = 0.f;
+
+  auto issue = [&](int s, int buf) __attribute__((always_inline)) {
+    pvt_dma_plane<PT>(a.gu + img * a.HD + s * 64, a.HD, lds + G::O_GU + buf * G::GU_B, wave, lane, [&](int p) -> long {
+      const int ty = p / PW, tx = p - ty * PW;
+      const int iy = y0 - 1 + ty, ix = x0 - 1 + tx;
+      return (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (long)iy * a.W + ix : -1;
+    });
+    pvt_load_rf<C>(a.w1 + (long)s * 64 * C, C, lds + G::O_W1 + buf * G::W1_B, wave, lane);
+  };
+  f32x4 acc[C / 16];
+#pragma unroll
+  for (int i = 0; i < C / 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  issue(0, 0);
+  float wdv[18];
+  {
+    const float* wp = a.wd + (long)(2 * cp) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const float2 v = *(const float2*)(wp + 2 * i);
+      wdv[2 * i] = v.x, wdv[2 * i + 1] = v.y;
+    }
+  }
+  for (int s = 0, buf = 0; s < nslab; ++s, buf ^= 1) {
+    ring_wait_vm<0>();
+    __syncthreads();  // slab s (gu plane, W1 image) has landed; everybody is done with the other buffer and with DH
+    if (s + 1 < nslab) issue(s + 1, buf ^ 1);
+    float wdn[18];  // depthwise weights of the next slab (one slab ahead)
+    {
+      const float* wp = a.wd + (long)((s + 1 < nslab ? s + 1 : s) * 64 + 2 * cp) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float2 v = *(const float2*)(wp + 2 * i);
+        wdn[2 * i] = v.x, wdn[2 * i + 1] = v.y;
+      }
+    }
+    // ---- dh = DW3x3^T(gu): the mirrored taps ---------------------------------------------------------------------------------
+    if (on) {
+      float dhv[SL][2];
+#pragma unroll
+      for (int i = 0; i < SL; ++i) dhv[i][0] = 0.f, dhv[i][1] = 0.f;
+      const unsigned char* gp = lds + G::O_GU + buf * G::GU_B + (oy * PW + ox0) * 128 + cp * 4;
+#pragma unroll
+      for (int kxx = 0; kxx < SL + 2; ++kxx) {
+        float d0[3], d1[3];
+#pragma unroll
+        for (int jy = 0; jy < 3; ++jy) {
+          const unsigned v = *(const unsigned*)(gp + (jy * PW + kxx) * 128);
+          d0[jy] = __uint_as_float(v << 16);
+          d1[jy] = __uint_as_float(v & 0xFFFF0000u);
+        }
+#pragma unroll
+        for (int jx = 0; jx < 3; ++jx) {
+          const int i = kxx - jx;
+          if (i >= 0 && i < SL) {
+#pragma unroll
+            for (int jy = 0; jy < 3; ++jy) {
+              dhv[i][0] += wdv[(2 - jy) * 3 + (2 - jx)] * d0[jy];
+              dhv[i][1] += wdv[9 + (2 - jy) * 3 + (2 - jx)] * d1[jy];
+            }
+          }
+        }
+      }
+      const int gy = y0 + oy;
+#pragma unroll
+      for (int i = 0; i < SL; ++i) {
+        const int row = oy * TW + ox0 + i;
+        const unsigned v = cenet_pack_bf2(dhv[i][0], dhv[i][1]);
+        *(unsigned*)(DH + row * 128 + (((cp >> 2) ^ kf_key(row)) * 16) + (cp & 3) * 4) = v;
+        const int gx = x0 + ox0 + i;
+        if (gy < a.H && gx < a.W) *(unsigned*)(a.dh + (img + (long)gy * a.W + gx) * a.HD + s * 64 + 2 * cp) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 18; ++i) wdv[i] = wdn[i];
+    __syncthreads();  // dh image complete
+    // ---- dxn^T[C, tokens] += W1_slab^T . dh^T ------------------------------------------------------------------------------------
+    if (wave < MTI) {
+      const unsigned char* W1R = lds + G::O_W1 + buf * G::W1_B;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        const bf16x8 hf = ring_frag_kf(DH, wave * 16, kc, lane);
+#pragma unroll
+        for (int nt = 0; nt < C / 16; ++nt) {
+          const bf16x8 wf = ring_frag_rf<C>(W1R, nt * 16, kc, lane);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hf, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- LayerNorm backward + the residual connection: dx = g + rstd (q - mean(q) - xhat mean(q xhat)), q = dxn gamma -----------
+  if (wave < MTI) {
+    const int ti = wave * 16 + (lane & 15);
+    const int ry = ti / TW, rx = ti - ry * TW;
+    const int gy = y0 + ry, gx = x0 + rx;
+    const bool in = ti < NT && gy < a.H && gx < a.W;
+    const long tok = img + (long)(in ? gy : y0) * a.W + (in ? gx : x0);
+    const float mu = a.mean[tok], rs = a.rstd[tok];
+    float xh[C / 16][4], qv[C / 16][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < C / 16; ++nt) {
+      const int n0 = nt * 16 + (lane >> 4) * 4;
+      const f4 xr = ld4(a.x + tok * C + n0);
+      const f4 gm = ld4(a.ln_g + n0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dxn = in ? acc[nt][e] : 0.f;
+        xh[nt][e] = (xr.v[e] - mu) * rs;
+        qv[nt][e] = dxn * gm.v[e];
+        s1 += qv[nt][e];
+        s2 += qv[nt][e] * xh[nt][e];
+        // affine gradients: sums over the 16 tokens of this lane group, then over the workgroup in LDS
+        float dg = dxn * xh[nt][e], db = dxn;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dg += __shfl_xor(dg, o), db += __shfl_xor(db, o);
+        if ((lane & 15) == 0) {
+          atomicAdd(&LNS[n0 + e], dg);
+          atomicAdd(&LNS[C + n0 + e], db);
+        }
+      }
+    }
+    s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+    const float m1 = s1 * (1.f / C), m2 = s2 * (1.f / C);
+    if (in) {
+#pragma unroll
+      for (int nt = 0; nt < C / 16; ++nt) {
+        const int n0 = nt * 16 + (lane >> 4) * 4;
+        const f4 gr = ld4(a.g + tok * C + n0);
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.v[e] = gr.v[e] + rs * (qv[nt][e] - m1 - xh[nt][e] * m2);
+        st4(a.dx + tok * C + n0, o);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 512) a.ws[(long)bid.x * 2 * C + i] = LNS[i];
+}
+
+// dln_g[c] += sum_rows ws[row][c], dln_b[c] += sum_rows ws[row][C + c]
+__global__ __launch_bounds__(256) void pvt_mlp_lnfold_kernel(const float* __restrict__ ws, int rows, int C2, float* __restrict__ dg,
+                                                            float* __restrict__ db) {
+  __shared__ float red[256];
+  const int c = blockIdx.x, tid = threadIdx.x;  // one workgroup per output
+  float s = 0.f;
+  for (int r = tid; r < rows; r += 256) s += ws[(long)r * C2 + c];
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (c < C2 / 2) dg[c] += red[0];
+    else db[c - C2 / 2] += red[0];
+  }
+}
+
 static bool pvt_mlp_geo(int H, int W, int& TH, int& TW) {
   if (W % 14 != 0) return false;
   TW = 14;
@@ -369,3 +792,58 @@ extern "C" int cenet_pvt_mlp_fwd_bf16(const bf16_t* x, const float* ln_g, const 
   return CENET_EUNSUPPORTED;
 }
 
+
+/* floats of workspace cenet_pvt_mlp_bwd_bf16 needs */
+extern "C" long cenet_pvt_mlp_bwd_ws_floats(int B, int H, int W, int C) {
+  int TH, TW;
+  if (!pvt_mlp_geo(H, W, TH, TW)) return 0;
+  return (long)B * (W / TW) * (H / TH) * 2 * C;
+}
+
+/* backward of cenet_pvt_mlp_fwd_bf16 from its saved tensors, two launches (+ a fold of the LayerNorm affine gradients):
+ * gu, dh: [B, H*W, HD] outputs (dh: the operand of the fc1 weight gradient); gs = s_b g [B, H*W, C] (written when bscale is set:
+ * the operand of the fc2 weight gradient); dx = g + dLayerNorm; dwd / dbd / dln_g / dln_b are ADDED into. */
+extern "C" int cenet_pvt_mlp_bwd_bf16(const bf16_t* g, const float* bscale, const bf16_t* w1, const bf16_t* w2, const float* wd,
+                                      const float* bd, const bf16_t* h, const bf16_t* x, const float* ln_g, const float* mean,
+                                      const float* rstd, bf16_t* gu, bf16_t* gs, bf16_t* dh, bf16_t* dx, float* dwd_acc,
+                                      float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* ws, int B, int H, int W, int C,
+                                      int HD, hipStream_t stream) {
+  if (!g || !w1 || !w2 || !wd || !bd || !h || !x || !ln_g || !mean || !rstd || !gu || !dh || !dx || !dwd_acc || !dbd_acc ||
+      !dln_g_acc || !dln_b_acc || !ws || B <= 0 || (bscale && !gs))
+    return CENET_EINVAL;
+  int TH, TW;
+  if (!cenet_pvt_mlp_supported(C, HD, H, W) || !pvt_mlp_geo(H, W, TH, TW)) return CENET_EUNSUPPORTED;
+  if ((((uintptr_t)g | (uintptr_t)h | (uintptr_t)x | (uintptr_t)gu | (uintptr_t)gs | (uintptr_t)dh | (uintptr_t)dx |
+        (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)ln_g) & 15) != 0 || (((uintptr_t)wd | (uintptr_t)bd) & 7) != 0)
+    return CENET_EUNSUPPORTED;
+  PvtBwdArgs a = {};
+  a.g = g; a.bscale = bscale; a.w1 = w1; a.w2 = w2; a.wd = wd; a.bd = bd; a.h = h; a.gu = gu; a.gs = gs; a.dh = dh;
+  a.dwd = dwd_acc; a.dbd = dbd_acc; a.x = x; a.ln_g = ln_g; a.mean = mean; a.rstd = rstd; a.dx = dx; a.ws = ws;
+  a.H = H; a.W = W; a.HD = HD;
+  a.tiles_x = W / TW;
+  a.tiles_per_img = a.tiles_x * (H / TH);
+  {
+    static const char* e = getenv("CENET_PVT_TPW");
+    a.tpw = e ? atoi(e) : (a.tiles_per_img >= 16 ? 4 : 2);
+    if (a.tpw < 1) a.tpw = 1;
+    if (a.tpw > a.tiles_per_img) a.tpw = a.tiles_per_img;
+  }
+  const dim3 g1(HD / 64, cdiv(a.tiles_per_img, a.tpw), B), g2(B * a.tiles_per_img);
+  if (g1.y > 65535 || g1.z > 65535) return CENET_EUNSUPPORTED;
+  static const char* only_e = getenv("CENET_PVT_ONLY");  // measurement aid: 1 / 2 = launch only that kernel
+  const int only = only_e ? atoi(only_e) : 0;
+#define PVT_BWD_GO(C_, TH_)                                                                              \
+  if (C == C_ && TH == TH_) {                                                                             \
+    if (only != 2) CENET_LAUNCH((pvt_mlp_bwd1_kernel<C_, TH_, 14>), g1, dim3(512), stream, a);            \
+    if (only != 1) CENET_LAUNCH((pvt_mlp_bwd2_kernel<C_, TH_, 14>), g2, dim3(512), stream, a);            \
+  } else
+  PVT_BWD_GO(64, 8)
+  PVT_BWD_GO(64, 7)
+  PVT_BWD_GO(128, 8)
+  PVT_BWD_GO(128, 7)
+  return CENET_EUNSUPPORTED;
+#undef PVT_BWD_GO
+  CENET_LAUNCH(pvt_mlp_lnfold_kernel, dim3(2 * C), dim3(256), stream, (const float*)ws, (int)g2.x, 2 * C, dln_g_acc, dln_b_acc);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}

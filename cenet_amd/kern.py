@@ -407,6 +407,19 @@ def pvt_mlp_fwd(x, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, 
           Cn, HD)
 
 
+
+def pvt_mlp_bwd(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, gs, dh, dx, dwd, dbd, dln_g, dln_b, B, H, W, Cn, HD):
+    """backward of pvt_mlp_fwd from its saved tensors in two launches (+ a fold): gu = (s_b g . W2) * GELU'(DW(h) + bd) with the
+    depthwise weight / bias gradients ADDED into dwd / dbd; dh = DW^T(gu) (the operand of the fc1 weight gradient), dx = g +
+    LayerNormBackward(dh . W1) with the affine gradients ADDED into dln_g / dln_b.  gs = s_b g is written when bscale is set."""
+    _chk(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, gs, dh, dx, dwd, dbd, dln_g, dln_b)
+    f = _lib.lib().cenet_pvt_mlp_bwd_ws_floats
+    f.restype = C.c_long
+    ws = torch.empty(int(f(B, H, W, Cn)), device=g.device, dtype=torch.float32)
+    _call("cenet_pvt_mlp_bwd_bf16", g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, gs, dh, dx, dwd, dbd, dln_g, dln_b, ws,
+          B, H, W, Cn, HD)
+
+
 def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil, x_off=0, g_off=0):
     _chk(x, dy, dw, dbias)
     _call("cenet_dwconv3x3_wgrad_nchw_acc_f32", Ptr(x, x_off), L(sxb), Ptr(dy, g_off), L(sgb), dw, dbias, B, Cn, H, W, dil)

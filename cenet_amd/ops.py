@@ -952,10 +952,7 @@ class PvtMlpFn(Function):
         HD = w1.shape[0]
         R = B * N
         # fc2 (LinearFn.backward with the DropPath scale)
-        gs = g
-        if bscale is not None:
-            gs = torch.empty_like(g)
-            kern.scale_batch(g, bscale, gs, B, g.numel() // B)
+        gs = torch.empty_like(g) if bscale is not None else g  # (s_b g: written by the first backward kernel)
 
         def wgrad(gy, xin, Wp, bp, Nn, K):
             dW, db = grad_buf(Wp), grad_buf(bp)
@@ -969,27 +966,19 @@ class PvtMlpFn(Function):
                     else:
                         kern.col_sum(gy, db, R, Nn)
 
-        wgrad(gs, a, w2, b2, Cn, HD)
-        da = torch.empty_like(a)
-        kern.gemm(kern.mat_plain(gs, Cn, 1, kfast=1), kern.mat_plain(kern.wq(w2, x), HD, 1, kfast=0), da, R, HD, Cn, scr=HD, scc=1)
-        # depthwise conv + GELU (DWConvTokFn.backward, pre-activation recomputed from h)
+        # two kernels: (scale + fc2 data gradient + depthwise / GELU backward) and (depthwise data gradient + fc1 data gradient +
+        # LayerNorm backward with the residual connection), csrc/pvt_mlp.hip
         dwd, dbd = grad_buf(wd), grad_buf(bd)
         if dwd is None:
             dwd, dbd = _zeros(wd.shape, x), _zeros(bd.shape, x)
-        gu = torch.empty_like(da)
-        kern.dw_tok_bwd_pre(h, da, wd, bd, gu, dwd, dbd, B, HD, H, Wd, "gelu")
-        dh = da  # (its buffer is free again)
-        kern.dw_tok(gu, wd, None, dh, None, B, HD, H, Wd, 1)
-        # fc1
-        wgrad(dh, xn, w1, b1, HD, Cn)
-        dxn = torch.empty_like(x)
-        kern.gemm(kern.mat_plain(dh, HD, 1, kfast=1), kern.mat_plain(kern.wq(w1, x), Cn, 1, kfast=0), dxn, R, Cn, HD, scr=Cn, scc=1)
-        # LayerNorm + the residual connection (LayerNormResFn.backward)
-        dx = torch.empty_like(x)
         dg, db = grad_buf(ln_g), grad_buf(ln_b)
         if dg is None:
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
-        kern.layernorm_bwd(dxn, x, ln_g, mean, rstd, dx, dg, db, R, Cn, dx_add=g)
+        gu, dh, dx = torch.empty_like(a), torch.empty_like(a), torch.empty_like(x)
+        kern.pvt_mlp_bwd(g, bscale, kern.wq(w1, x), kern.wq(w2, x), wd, bd, h, x, ln_g, mean, rstd, gu,
+                         gs if bscale is not None else None, dh, dx, dwd, dbd, dg, db, B, H, Wd, Cn, HD)
+        wgrad(gs, a, w2, b2, Cn, HD)
+        wgrad(dh, xn, w1, b1, HD, Cn)
         return (dx,) + (None,) * 12
 
 

@@ -290,6 +290,19 @@ int cenet_pvt_mlp_fwd_bf16(const unsigned short* x, const float* ln_g, const flo
                            const float* bscale, unsigned short* y, unsigned short* xn_out, float* mean_out, float* rstd_out,
                            unsigned short* h_out, unsigned short* a_out, int B, int H, int W, int C, int HD, cenet_stream_t stream);
 
+/* backward of cenet_pvt_mlp_fwd_bf16 from its saved tensors in two launches (+ a fold of the LayerNorm affine gradients): replaces
+ * mul (DropPath scale) + mm (fc2 data gradient) + gelu_backward + convolution_backward(groups) + mm (fc1 data gradient) +
+ * native_layer_norm_backward + add (residual).  gu, dh [B, H*W, HD]: the gradient of the depthwise conv's output (scratch) and of
+ * fc1's output (operand of the fc1 weight gradient dW1 = dh^T xn); gs = s_b g [B, H*W, C] is written when bscale is set (operand of
+ * the fc2 weight gradient dW2 = gs^T a); dx = g + LayerNormBackward(dh . W1); dwd / dbd / dln_g / dln_b are ADDED into.
+ * ws: cenet_pvt_mlp_bwd_ws_floats(B, H, W, C) floats. */
+long cenet_pvt_mlp_bwd_ws_floats(int B, int H, int W, int C);
+int cenet_pvt_mlp_bwd_bf16(const unsigned short* g, const float* bscale, const unsigned short* w1, const unsigned short* w2,
+                           const float* wd, const float* bd, const unsigned short* h, const unsigned short* x, const float* ln_g,
+                           const float* mean, const float* rstd, unsigned short* gu, unsigned short* gs, unsigned short* dh,
+                           unsigned short* dx, float* dwd_acc, float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* ws,
+                           int B, int H, int W, int C, int HD, cenet_stream_t stream);
+
 /* ---- resampling (resample.hip) ---------------------------------------------------------------------------- */
 /* aten::upsample_bilinear2d(+_backward) — dseb.py:67-68; cfam.py:217,232; blocks.py:210; out.py:74 */
 int cenet_bilinear_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo,

@@ -51,6 +51,9 @@ def test_bench_under_torchrun_with_rccl_group(extra):
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
     assert d["config"]["final_loss"] == d["config"]["final_loss"]  # not NaN
+    r = d["config"]["rccl"]  # the record that makes an N > 1 line self-proving (here: one rank, the real RCCL backend)
+    assert r["backend"] == "nccl" and r["world_size"] == 1 and r["distinct_devices"] == 1 and r["hosts"] == 1
+    assert r["nccl_version"][0].isdigit() and set(r["launch_forms_ms"]) <= {"eager", "split", "segmented"}
     if "--dist-launch" in extra:
         want = {"segmented": "six hipGraphs", "split": "two hipGraphs", "eager": "eager"}[extra[-1]]
         assert d["config"]["launch"].startswith(want), d["config"]["launch"]
@@ -92,6 +95,10 @@ def test_bench_with_two_ranks_on_one_gpu(extra):
     assert d["value"] > 0 and abs(d["value"] - 16 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
     assert d["config"]["final_loss"] == d["config"]["final_loss"]
     assert "roofline" not in d  # the instrumented passes are a single-GPU extra
+    r = d["config"]["rccl"]
+    # both ranks were pinned to cuda:0 on purpose: the record must SAY that the two ranks share one device, over gloo
+    assert r["backend"] == "gloo" and r["world_size"] == 2 and r["distinct_devices"] == 1 and r["hosts"] == 1
+    assert "nccl_version" not in r and all(v > 0 for v in r["launch_forms_ms"].values())
     if extra:
         assert d["config"]["launch"].startswith("six hipGraphs"), d["config"]["launch"]
     else:

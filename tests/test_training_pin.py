@@ -1,0 +1,146 @@
+"""The BENCHED mode's training, not just one gradient (metric: "Dice vs ref"; step body main_acdc.py:237-257 with the SGD + poly
+schedule of utils/core.py:12-41).  The reference-initialised ACDC model of tests/test_wellcond.py (seed 77, CFAM layer scales
+0.5, batch 8, blocky synthetic labels) is trained for 30 steps on two alternating batches with stochastic depth ACTIVE and its
+keep masks injected identically into every run:
+
+* bf16 product vs fp32 product: per-step loss, final mean class Dice, parameter update direction per gradient-arena segment;
+* both against the ORACLE's fp32 trajectory (host) for the first five steps;
+* "noise, not bias" (tests/test_wellcond.py): the bf16 one-step gradient against the reference's float64 samples has no
+  additive and no multiplicative bias per segment."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from backend import use_hip
+from oracle import cenet_oracle as O
+
+import test_wellcond as W
+
+STEPS, ORACLE_STEPS = 30, 5
+LR, WD, MAX_IT = 0.01, 1e-4, 100
+
+
+def _drop_masks(step, cfg, B):
+    """keep masks of one forward, {(stage, i): (attn[B], mlp[B])}, for the blocks whose drop rate is > 0 (pvtv2.py:228-236)"""
+    rates = O.drop_path_rates(cfg)
+    g = torch.Generator().manual_seed(1000 + step)
+    out, cur = {}, 0
+    for s in range(4):
+        for i in range(cfg.depths[s]):
+            r = rates[cur + i]
+            if r > 0:
+                out[(s, i)] = tuple((torch.rand(B, generator=g) >= r).float() for _ in range(2))
+        cur += cfg.depths[s]
+    return out
+
+
+def _batches(z):
+    kw = z.kw
+    return [O.synthetic_batch(int(z["batch"]), kw["input_channels"], kw["num_classes"], seed=int(z["x_seed"]) + j) for j in range(2)]
+
+
+def _product_run(z, dev, bf16, steps):
+    from cenet_amd import evaluate, kern, losses, optim
+    net, _, _ = W.build_product(z, dev)
+    net.train()
+    data = [(x.to(dev), lab.to(dev)) for x, lab in _batches(z)]
+    arena = optim.ParamArena(net, optim.cenet_segments())
+    p0 = arena.params.detach().clone()
+    opt = optim.FusedSGD(arena, lr=LR, momentum=0.9, weight_decay=WD)
+    sched = optim.PolyLR(opt, max_iterations=MAX_IT)
+    crit = losses.Criterion(z.kw["num_classes"], argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
+    B = int(z["batch"])
+    out = []
+    kern.set_compute_bf16(bf16)
+    try:
+        for t in range(steps):
+            x, lab = data[t % 2]
+            net.backbone.set_drop_path_masks(_drop_masks(t, z.cfg, B))
+            opt.zero_grad()
+            loss = crit(net(x), lab)
+            loss.backward()
+            opt.step()
+            sched.step()
+            out.append(loss.item())
+        net.eval()
+        with torch.no_grad():
+            dice = float(np.mean(evaluate.class_dice(evaluate.predict_counts(net(data[0][0]), data[0][1])[1])))
+    finally:
+        kern.set_compute_bf16(False)
+    torch.cuda.synchronize()
+    return out, dice, (arena.params.detach() - p0).cpu(), arena
+
+
+def _oracle_run(z, steps):
+    net, _, _ = W.build_product(z, torch.device("cpu"))
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+          for k, v in net.state_dict().items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.SGD(params, lr=LR, momentum=0.9, weight_decay=WD)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: (1 - s / MAX_IT) ** 0.9)
+    data, B, out = _batches(z), int(z["batch"]), []
+    for t in range(steps):
+        x, lab = data[t % 2]
+        opt.zero_grad()
+        loss = O.criterion(O.cenet_forward(sd, x, z.cfg, training=True, drop_masks=_drop_masks(t, z.cfg, B)), lab,
+                           z.kw["num_classes"])
+        loss.backward()
+        opt.step()
+        sched.step()
+        out.append(loss.item())
+    return out
+
+
+@pytest.mark.gpu
+def test_bf16_training_follows_the_fp32_and_the_oracle_trajectories():
+    """Measured on MI355X: see the assertion messages' operands in DESIGN.md section 4 (round 4)."""
+    z = W.golden("acdc")
+    dev = use_hip()
+    l32, d32, dp32, arena = _product_run(z, dev, False, STEPS)
+    l16, d16, dp16, _ = _product_run(z, dev, True, STEPS)
+    lo = _oracle_run(z, ORACLE_STEPS)
+    assert np.mean(l32[-4:]) < np.mean(l32[:4]) - 0.01, l32  # it trains (reference learning rate: a few per cent in 30 steps)
+    for t in range(ORACLE_STEPS):  # the fp32 product IS the oracle's trajectory; the bf16 product follows it
+        assert abs(l32[t] - lo[t]) < 2e-4 * max(1.0, abs(lo[t])), (t, l32[t], lo[t])
+        assert abs(l16[t] - lo[t]) < 0.02 * abs(lo[t]), (t, l16[t], lo[t])
+    worst = max(abs(a - b) / abs(b) for a, b in zip(l16, l32))
+    assert worst < 0.02, (worst, l16, l32)
+    assert abs(d16 - d32) < 2e-3, (d16, d32)
+    # direction of the accumulated parameter update, per gradient-arena segment
+    for name, s, e in arena.segments:
+        cos = torch.nn.functional.cosine_similarity(dp16[s:e].double(), dp32[s:e].double(), dim=0).item()
+        assert cos >= 0.99, (name, cos)
+
+
+@pytest.mark.gpu
+def test_bf16_gradient_error_is_noise_not_bias():
+    """tests/test_wellcond.py holds the bf16 gradient to the reference's float64 one by cosine and norm; here the SIGN of the
+    error: per segment, over the 64-entry samples of every tensor (each scaled by its tensor's rms so that tensors of different
+    magnitude weigh alike), the mean signed error is within three standard errors of zero (no additive bias; one datum per
+    tensor, since the samples of a tensor share their upstream rounding noise) and the regression slope of the bf16 samples on the float64 ones is 1 within 1 % (no multiplicative bias: a kernel that, say,
+    truncated instead of rounding would shrink every gradient by ~0.4 %... per stored tensor)."""
+    z = W.golden("acdc")
+    dev = use_hip()
+    _, _, grads, _, _ = W._train_step(z, dev, True)
+    segs = {}
+    for k, g in grads.items():
+        g = g.reshape(-1).double()
+        ref = torch.from_numpy(z[f"g64.{k}.s"].astype(np.float64))
+        got = g[W.sample_index(g.numel())]
+        rms = float(z[f"g64.{k}.norm"]) / np.sqrt(g.numel())
+        if rms < 1e-7:  # (gradients that are zero up to rounding in the reference's float64 run carry no sign information)
+            continue
+        s = segs.setdefault(W.segment_of(k), dict(m=[], a=[], b=[]))
+        s["m"].append(((got - ref) / rms).mean().item())  # (the 64 samples of one tensor share their upstream noise: one datum)
+        s["a"].append(got / rms)
+        s["b"].append(ref / rms)
+    for name, s in segs.items():
+        m, a, b = np.array(s["m"]), torch.cat(s["a"]), torch.cat(s["b"])
+        se = m.std() / np.sqrt(len(m))
+        # additive bias: the mean over the segment's tensors of the per-tensor mean signed error (in units of the tensor's rms)
+        # is zero within three standard errors (+ 0.5 % of an rms: measured |mean| <= 0.25 %)
+        assert abs(m.mean()) < 3 * se + 5e-3, (name, m.mean(), se, len(m))
+        slope = (a @ b / (b @ b)).item()
+        assert abs(slope - 1.0) < 0.01, (name, slope)
