@@ -185,3 +185,113 @@ def test_single_volume(image, label, net, classes: int, patch_size: Sequence[int
     pred_d = torch.from_numpy(np.ascontiguousarray(prediction)).to(device)
     lab_d = torch.from_numpy(np.ascontiguousarray(label)).to(device)
     return [metric_percase(pred_d == c, lab_d == c) for c in range(1, classes)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Synapse (utils/utils_synapse.py:12-100) and skin (utils/utils_skin.py:97-170) evaluation wrappers
+# ---------------------------------------------------------------------------------------------------------------------------
+def synapse_metric_percase(pred: torch.Tensor, gt: torch.Tensor) -> Tuple[float, float]:
+    """calculate_metric_percase of utils_synapse.py:12-21: (dice, hd95) of two binary volumes; (1, 0) for a prediction without
+    ground truth, (0, 0) otherwise."""
+    p, g = pred != 0, gt != 0
+    np_, ng = int(p.sum()), int(g.sum())
+    if np_ > 0 and ng > 0:
+        inter = int((p & g).sum())
+        d1, d2 = surface_distances(p, g)
+        return 2.0 * inter / float(np_ + ng), float(np.percentile(np.hstack((d1, d2)), 95))
+    if np_ > 0 and ng == 0:
+        return 1, 0
+    return 0, 0
+
+
+@torch.no_grad()
+def synapse_test_single_volume(image, label, net, classes: int, patch_size: Sequence[int] = (256, 256), test_save_path=None,
+                               case=None, z_spacing: float = 1.0, batch_slices: int = 32, device=None):
+    """test_single_volume of utils_synapse.py:49-97: every slice of the volume [1, D, H, W] is resized to `patch_size` (cubic
+    zoom), normalised with Normalize([0.5], [0.5]) (`ToTensor` leaves float arrays unscaled), classified, and the prediction
+    resized back with order 0; returns [(dice, hd95)] for classes 1..classes-1.  A 2-D input takes the reference's second branch
+    (one forward, no normalisation).  The slices go through the network in batches (with the reference's batch-1 semantics),
+    the metrics run on the device.  `test_save_path` (NIfTI files through SimpleITK, which is absent here) writes .npy volumes
+    with the spacing (1, 1, z_spacing) in a side-car text file instead."""
+    from scipy.ndimage import zoom
+    image = image.squeeze(0).cpu().numpy() if torch.is_tensor(image) else np.asarray(image)
+    label = label.squeeze(0).cpu().numpy() if torch.is_tensor(label) else np.asarray(label)
+    device = device or next(net.parameters()).device
+    net.eval()
+    if image.ndim == 3:
+        D, x, y = image.shape
+        resize = (x != patch_size[0] or y != patch_size[1])
+        prediction = np.zeros_like(label)
+        for s in range(0, D, batch_slices):
+            sl = image[s:s + batch_slices]
+            if resize:
+                sl = np.stack([zoom(a, (patch_size[0] / x, patch_size[1] / y), order=3) for a in sl])
+            inp = torch.from_numpy(np.ascontiguousarray(sl)).unsqueeze(1).float()
+            inp = ((inp - 0.5) / 0.5).to(device)
+            with ops.batch1_semantics():
+                logits = net(inp)
+            pred, _ = predict_counts(logits)
+            out = pred.reshape(-1, patch_size[0], patch_size[1]).cpu().numpy()
+            for i in range(out.shape[0]):
+                prediction[s + i] = zoom(out[i], (x / patch_size[0], y / patch_size[1]), order=0) if resize else out[i]
+    else:
+        inp = torch.from_numpy(np.ascontiguousarray(image)).unsqueeze(0).unsqueeze(0).float().to(device)
+        pred, _ = predict_counts(net(inp))
+        prediction = pred.squeeze(0).cpu().numpy().astype(label.dtype)
+    pred_d = torch.from_numpy(np.ascontiguousarray(prediction)).to(device)
+    lab_d = torch.from_numpy(np.ascontiguousarray(label)).to(device)
+    metric_list = [synapse_metric_percase(pred_d == c, lab_d == c) for c in range(1, classes)]
+    if test_save_path is not None:
+        import os
+        os.makedirs(test_save_path, exist_ok=True)
+        for tag, vol in (("pred", prediction), ("img", image), ("gt", label)):
+            np.save(os.path.join(test_save_path, f"{case}_{tag}.npy"), np.asarray(vol, dtype=np.float32))
+        with open(os.path.join(test_save_path, f"{case}_spacing.txt"), "w") as f:
+            f.write(f"1 1 {z_spacing}\n")
+    return metric_list
+
+
+def _binary_dc(result: torch.Tensor, reference: torch.Tensor) -> float:
+    """medpy.metric.binary.dc as the skin scripts call it — on arrays of DIFFERENT rank (argmax output [B, H, W] or [H, W]
+    against the label batch [B, 1, H, W]): the intersection is counted on the numpy-broadcast of the two boolean arrays, the
+    sizes on each array alone; 0.0 when both are empty"""
+    a, b = result != 0, reference != 0
+    sa, sb = int(a.sum()), int(b.sum())
+    return 2.0 * int((a & b).sum()) / float(sa + sb) if (sa + sb) else 0.0
+
+
+@torch.no_grad()
+def skin_val(net, vl_loader, device=None) -> float:
+    """val of utils_skin.py:97-113: mean over the loader's batches of dc(argmax(softmax(logits), 1).squeeze(0), label batch)"""
+    device = device or next(net.parameters()).device
+    net.eval()
+    dc_sum, n = 0.0, 0
+    for batch in vl_loader:
+        img, lab = batch["image"].to(device), batch["label"].to(device)
+        pred, _ = predict_counts(net(img.float()))
+        dc_sum += _binary_dc(pred.squeeze(0), lab)
+        n += 1
+    return dc_sum / max(n, 1)
+
+
+@torch.no_grad()
+def skin_test(net, te_loader, device=None) -> Tuple[float, float, float]:
+    """test of utils_skin.py:131-170 (batch size 1, as the reference's test loader): (mean dice, pixel accuracy, mean IoU) with
+    the ground truth read as `label[0, 0]` and calc_iou(pd > 0.5, gt > 0.5) = |A & B| / |A or B| (0.0 for an empty union,
+    utils_skin.py:13-27)"""
+    device = device or next(net.parameters()).device
+    net.eval()
+    dc_sum, correct, total, ious, n = 0.0, 0, 0, [], 0
+    for batch in te_loader:
+        img, lab = batch["image"].float().to(device), batch["label"].float().to(device)
+        pred, _ = predict_counts(net(img))
+        pd = pred.squeeze(0)
+        gt = lab[0, 0]
+        correct += int((pd == gt).sum())
+        total += gt.numel()
+        a, b = pd > 0.5, gt > 0.5
+        union = int((a | b).sum())
+        ious.append(int((a & b).sum()) / union if union else 0.0)
+        dc_sum += _binary_dc(pd, lab)
+        n += 1
+    return dc_sum / max(n, 1), correct / max(total, 1), float(np.mean(ious)) if ious else 0.0

@@ -181,3 +181,77 @@ def test_batched_eval_equals_slice_by_slice_on_real_cenet():
         plain = net(x)
     torch.testing.assert_close(batched, single, rtol=1e-4, atol=1e-4)
     assert (plain - single).abs().max().item() > 1e-3  # the B > 1 branch really is a different function
+
+
+class _Proj(torch.nn.Module):
+    """a stand-in network: fixed 1x1 projection of the (normalised) slice to K logit maps"""
+
+    def __init__(self, K, cin=1):
+        super().__init__()
+        g = torch.Generator().manual_seed(2)
+        self.w = torch.nn.Parameter(torch.randn(K, cin, generator=g) * 3)
+        self.b = torch.nn.Parameter(torch.randn(K, generator=g))
+
+    def forward(self, x):
+        return torch.einsum("kc,bchw->bkhw", self.w.to(x.dtype), x) + self.b.view(1, -1, 1, 1)
+
+
+def test_synapse_volume_wrapper_follows_utils_synapse(dev):
+    """utils_synapse.py:49-97 restated on the host (zoom order 3 in, Normalize([0.5],[0.5]), argmax, zoom order 0 out, then
+    (dice, hd95) per class with the 1,0 / 0,0 rules) against evaluate.synapse_test_single_volume; medpy absent: the oracle's
+    scipy restatement of its surface distances is the checker (parity unpinned, as for the ACDC wrapper)."""
+    import numpy as np
+    from scipy.ndimage import zoom
+    K, D, H, W, P = 4, 5, 20, 24, 16
+    g = torch.Generator().manual_seed(1)
+    vol = torch.rand(1, D, H, W, generator=g)
+    lab = torch.randint(0, K, (1, D, H, W), generator=g).float()
+    lab[lab == 3] = 0  # class 3 absent from the ground truth
+    net = _Proj(K).to(dev)
+    got = evaluate.synapse_test_single_volume(vol, lab, net, K, patch_size=(P, P), batch_slices=2, device=dev)
+    pred = np.zeros((D, H, W), dtype=np.float32)
+    for i in range(D):
+        sl = zoom(vol[0, i].numpy(), (P / H, P / W), order=3)
+        x = ((torch.from_numpy(sl).float() - 0.5) / 0.5)[None, None]
+        out = torch.argmax(torch.softmax(net.cpu()(x), dim=1), dim=1)[0].numpy()
+        pred[i] = zoom(out, (H / P, W / P), order=0)
+    net.to(dev)
+    for c in range(1, K):
+        p, t = pred == c, lab[0].numpy() == c
+        if p.sum() > 0 and t.sum() > 0:
+            want = (O.dice_metric(torch.from_numpy(p), torch.from_numpy(t)), O.hd95_metric(p, t))
+        elif p.sum() > 0:
+            want = (1, 0)
+        else:
+            want = (0, 0)
+        assert abs(got[c - 1][0] - want[0]) < 1e-12 and abs(got[c - 1][1] - want[1]) < 1e-9, (c, got[c - 1], want)
+
+
+def test_skin_wrappers_follow_utils_skin(dev):
+    """utils_skin.py:97-113 (val) and :131-170 (test) restated with numpy on the host: dc on the broadcast of the argmax output
+    against the label batch, pixel accuracy against label[0, 0], calc_iou with its 0.0 for an empty union."""
+    import numpy as np
+    g = torch.Generator().manual_seed(4)
+    net = _Proj(2, cin=3).to(dev)
+    loader = [{"image": torch.rand(1, 3, 12, 10, generator=g), "label": torch.randint(0, 2, (1, 1, 12, 10), generator=g).float(),
+               "id": torch.tensor([i])} for i in range(3)]
+    loader.append({"image": torch.zeros(1, 3, 12, 10), "label": torch.zeros(1, 1, 12, 10), "id": torch.tensor([3])})
+
+    def np_dc(a, b):
+        a, b = a.astype(bool), b.astype(bool)
+        s = np.count_nonzero(a) + np.count_nonzero(b)
+        return 2.0 * np.count_nonzero(a & b) / s if s else 0.0
+
+    dcs, corr, tot, ious = [], 0, 0, []
+    cpu = _Proj(2, cin=3)
+    for b in loader:
+        pd = torch.argmax(torch.softmax(cpu(b["image"]), dim=1), dim=1).squeeze(0).numpy()
+        gt = b["label"][0, 0].numpy()
+        dcs.append(np_dc(pd, b["label"].numpy()))
+        corr += (pd == gt).sum()
+        tot += gt.size
+        u = np.logical_or(pd > 0.5, gt > 0.5).sum()
+        ious.append(np.logical_and(pd > 0.5, gt > 0.5).sum() / u if u > 0 else 0.0)
+    d, acc, iou = evaluate.skin_test(net, loader, device=dev)
+    assert abs(d - np.mean(dcs)) < 1e-12 and abs(acc - corr / tot) < 1e-12 and abs(iou - np.mean(ious)) < 1e-12
+    assert abs(evaluate.skin_val(net, loader, device=dev) - np.mean(dcs)) < 1e-12
