@@ -37,7 +37,7 @@ struct PvtMlpArgs {
   float* mean_out;    // [B * H*W]
   float* rstd_out;    // [B * H*W]
   bf16_t* h_out;      // [B, H*W, HD] fc1 output
-  bf16_t* a_out;      // [B, H*W, HD] GELU output
+  bf16_t* a_out;      // [B, H*W, HD] s_b * GELU output (the DropPath scale rides on the operand of the fc2 weight gradient)
   int H, W, HD, tiles_x, tiles_per_img;
   float eps;
 };
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void pvt_mlp_fwd_kernel(PvtMlpArgs a) {
 #pragma unroll
   for (int i = 0; i < C / 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const float sc_b = a.bscale ? a.bscale[b] : 1.f;
   // P2 geometry of this thread: channel pair cp of the slab, strip of SL outputs in row oy
   const int cp = tid & 31, strip = tid >> 5;
   const int oy = strip >> 1, ox0 = (strip & 1) * SL;
@@ -272,23 +273,21 @@ __global__ __launch_bounds__(512, 2) void pvt_mlp_fwd_kernel(PvtMlpArgs a) {
 #pragma unroll
       for (int i = 0; i < SL; ++i) {
         const int row = oy * TW + ox0 + i;
-        const unsigned v = cenet_pack_bf2(pvt_gelu(u[i][0]), pvt_gelu(u[i][1]));
+        const float a0 = pvt_gelu(u[i][0]), a1 = pvt_gelu(u[i][1]);
+        const unsigned v = cenet_pack_bf2(a0, a1);
         *(unsigned*)(AI + row * 128 + (((cp >> 2) ^ kf_key(row)) * 16) + (cp & 3) * 4) = v;
-        akeep[i] = v;
+        // saved for the fc2 weight gradient dW2 = (s_b g)^T a = g^T (s_b a): the scale rides on a, so no scaled copy of g is needed
+        akeep[i] = a.bscale ? cenet_pack_bf2(a0 * sc_b, a1 * sc_b) : v;
       }
     }
     ring_wait_vm<0>();  // this wave's part of the next W1 slab (and of this slab's W2, issued one slab ago) has landed
     __syncthreads();    // a complete; h free
     if (a.h_out && p2_on) {  // (after the wait above: the stores' acknowledgements are not waited for before the next slab's)
-      const int gy = y0 + oy;
+      const long o = (img + (long)(y0 + oy) * a.W + x0 + ox0) * a.HD + s * 64 + 2 * cp;  // (exact tiles: inside the image)
 #pragma unroll
       for (int i = 0; i < SL; ++i) {
-        const int gx = x0 + ox0 + i;
-        if (gy < a.H && gx < a.W) {
-          const long o = (img + (long)gy * a.W + gx) * a.HD + s * 64 + 2 * cp;
-          *(unsigned*)(a.h_out + o) = hkeep[i];
-          *(unsigned*)(a.a_out + o) = akeep[i];
-        }
+        *(unsigned*)(a.h_out + o + (long)i * a.HD) = hkeep[i];
+        *(unsigned*)(a.a_out + o + (long)i * a.HD) = akeep[i];
       }
     }
     // ---- P3: acc^T += W2[:, slab] . a^T -----------------------------------------------------------------------------------
@@ -316,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void pvt_mlp_fwd_kernel(PvtMlpArgs a) {
     const int ry = ti / TW, rx = ti - ry * TW;
     const int gy = y0 + ry, gx = x0 + rx;
     if (ti < NT && gy < a.H && gx < a.W) {
-      const float sc = a.bscale ? a.bscale[b] : 1.f;
+      const float sc = sc_b;
       const long tok = img + (long)gy * a.W + gx;
 #pragma unroll
       for (int nt = 0; nt < C / 16; ++nt) {
@@ -336,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void pvt_mlp_fwd_kernel(PvtMlpArgs a) {
 // backward: two kernels instead of scale_batch + fc2 dgrad GEMM + depthwise/GELU backward + depthwise dgrad + fc1 dgrad GEMM +
 // LayerNorm backward.  (One kernel for everything was built and measured first — see the header.  What these two keep from it:
 // no halo RECOMPUTATION — the halo tiles of h and gu are read from memory — and two workgroups per CU.)
-//   K1  gu = (s_b g . W2[:, slab]) * GELU'(DW3x3(h) + bd)      workgroup = (slab of 64 hidden channels, run of tiles, image):
+//   K1  gu = s_b (g . W2[:, slab]) * GELU'(DW3x3(h) + bd)      workgroup = (slab of 64 hidden channels, run of tiles, image):
 //       the depthwise weight / bias gradients of the slab stay in registers over the workgroup's tiles
 //   K2  dh = DW3x3^T(gu) -> HBM (operand of the fc1 weight gradient);  dxn += dh . W1_slab over the slabs (registers);
 //       dx = g + LayerNormBackward(dxn)                        workgroup = tile, slabs walked inside
@@ -359,7 +358,6 @@ struct PvtBwdArgs {
   const float* bd;       // [HD]
   const bf16_t* h;       // [B, N, HD] fc1 output (saved by the forward kernel)
   bf16_t* gu;            // [B, N, HD] gradient of the depthwise conv's output
-  bf16_t* gs;            // [B, N, C]  s_b g (operand of the fc2 weight gradient; written when bscale is set)
   bf16_t* dh;            // [B, N, HD] gradient of fc1's output
   float* dwd;            // [HD, 9] +=
   float* dbd;            // [HD] +=
@@ -368,7 +366,7 @@ struct PvtBwdArgs {
   const float* mean;     // [B * N]
   const float* rstd;
   bf16_t* dx;            // [B, N, C]
-  float* ws;             // K2: [tiles][2 C] LayerNorm affine gradient partials
+  float* ws;             // K2: [tiles][3 C] partials: LayerNorm gamma / beta gradients, fc2 bias gradient
   int H, W, HD, tiles_x, tiles_per_img, tpw;
 };
 
@@ -443,29 +441,29 @@ __global__ __launch_bounds__(512, 4) void pvt_mlp_bwd1_kernel(PvtBwdArgs a) {
       return (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (long)iy * a.W + ix : -1;
     });
   };
+  // g of a tile -> k-fast image (B operand of the dgrad product) by LDS-DMA: row ti of the image = interior token ti
+  auto issue_g = [&](int tile) __attribute__((always_inline)) {
+    const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * TW;
+    constexpr int NI = (MTI * 16 * 8 + 511) / 512;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if ((j * 8 + wave) * 64 < MTI * 16 * 8) {  // (wave-uniform)
+          const int S = (j * 8 + wave) * 64 + lane, ti = S >> 3, c = (S & 7) ^ kf_key(ti);
+          const int ry = ti / TW, rx = ti - ry * TW;
+          const bool ok = ti < NT && y0 + ry < a.H && x0 + rx < a.W;
+          const void* src = ok ? (const void*)(a.g + (img + (long)(y0 + ry) * a.W + x0 + rx) * C + kb * 64 + 8 * c)
+                               : (const void*)ring_zero16;
+          ring_glds16(src, GS + kb * (MTI * 16 * 128) + (j * 8 + wave) * 1024, lane);
+        }
+      }
+  };
   issue_h(t_begin, 0);
+  issue_g(t_begin);
   int buf = 0;
   for (int tile = t_begin; tile < t_end; ++tile, buf ^= 1) {
     const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * TW;
-    // ---- s_b g of the tile -> k-fast image (B operand of the dgrad product); slab 0 also writes it out -------------------------
-    for (int i = tid; i < MTI * 16 * (C / 8); i += 512) {
-      const int ti = i / (C / 8), j = i - ti * (C / 8);
-      const int ry = ti / TW, rx = ti - ry * TW;
-      uint4 v = uint4{0u, 0u, 0u, 0u};
-      if (ti < NT && y0 + ry < a.H && x0 + rx < a.W) {
-        const long off = (img + (long)(y0 + ry) * a.W + x0 + rx) * C + 8 * j;
-        v = *(const uint4*)(a.g + off);
-        if (a.bscale) {
-          float f[8];
-          ldv<8>(f, (const bf16_t*)&v);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] *= sc;
-          v = uint4{cenet_pack_bf2(f[0], f[1]), cenet_pack_bf2(f[2], f[3]), cenet_pack_bf2(f[4], f[5]), cenet_pack_bf2(f[6], f[7])};
-          if (s == 0) *(uint4*)(a.gs + off) = v;
-        }
-      }
-      *(uint4*)(GS + (j >> 3) * (MTI * 16 * 128) + ti * 128 + ((j & 7) ^ kf_key(ti)) * 16) = v;
-    }
     ring_wait_vm<0>();
     __syncthreads();  // this tile's h plane and g image (and, first time, the W2 slab) are in LDS
     if (tile + 1 < t_end) issue_h(tile + 1, buf ^ 1);
@@ -479,9 +477,11 @@ __global__ __launch_bounds__(512, 4) void pvt_mlp_bwd1_kernel(PvtBwdArgs a) {
         d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf, d, 0, 0, 0);
       }
       const int p = tt * 16 + (lane & 15);
-      *(uint2*)(DA + p * HS + (ct * 16 + (lane >> 4) * 4) * 2) = uint2{cenet_pack_bf2(d[0], d[1]), cenet_pack_bf2(d[2], d[3])};
+      *(uint2*)(DA + p * HS + (ct * 16 + (lane >> 4) * 4) * 2) =
+          uint2{cenet_pack_bf2(sc * d[0], sc * d[1]), cenet_pack_bf2(sc * d[2], sc * d[3])};
     }
     __syncthreads();
+    if (tile + 1 < t_end) issue_g(tile + 1);  // (the image is free; lands under the depthwise phase)
     // ---- gu = da * GELU'(DW3x3(h) + bd); depthwise weight / bias gradient -------------------------------------------------------
     if (on) {
       const unsigned char* hp = lds + G::O_HP + buf * G::HP_B + (oy * PW + ox0) * 128 + cp * 4;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(512, 4) void pvt_mlp_bwd1_kernel(PvtBwdArgs a) {
           win[ky][kxx][0] = __uint_as_float(v << 16);
           win[ky][kxx][1] = __uint_as_float(v & 0xFFFF0000u);
         }
-      const int gy = y0 + oy;
+      bf16_t* const gup = a.gu + (img + (long)(y0 + oy) * a.W + x0 + ox0) * a.HD + s * 64 + 2 * cp;
 #pragma unroll
       for (int i = 0; i < SL; ++i) {
 #pragma unroll
@@ -513,11 +513,10 @@ __global__ __launch_bounds__(512, 4) void pvt_mlp_bwd1_kernel(PvtBwdArgs a) {
           }
         const int row = oy * TW + ox0 + i;
         const unsigned dv = *(const unsigned*)(DA + row * HS + cp * 4);
-        const int gx = x0 + ox0 + i;
-        const bool in = gy < a.H && gx < a.W;
-        const float g0 = in ? __uint_as_float(dv << 16) * pvt_gelu_grad(u0) : 0.f;
-        const float g1 = in ? __uint_as_float(dv & 0xFFFF0000u) * pvt_gelu_grad(u1) : 0.f;
-        if (in) *(unsigned*)(a.gu + (img + (long)gy * a.W + gx) * a.HD + s * 64 + 2 * cp) = cenet_pack_bf2(g0, g1);
+        // (tiles are exact — pvt_mlp_geo: H % TH == 0, W % TW == 0 — so interior tokens are always inside the image)
+        const float g0 = __uint_as_float(dv << 16) * pvt_gelu_grad(u0);
+        const float g1 = __uint_as_float(dv & 0xFFFF0000u) * pvt_gelu_grad(u1);
+        *(unsigned*)(gup + (long)i * a.HD) = cenet_pack_bf2(g0, g1);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -563,7 +562,7 @@ template <int C, int TH, int TW>
 struct PvtB2Geo {
   static constexpr int PW = TW + 2, PH = TH + 2, PT = PH * PW, NT = TH * TW, MTI = (NT + 15) / 16, SL = TW / 2;
   static constexpr int GU_B = (PT * 128 + 1023) / 1024 * 1024, W1_B = 64 * C * 2, DH_B = MTI * 16 * 128;
-  static constexpr int O_GU = 0, O_W1 = 2 * GU_B, O_DH = O_W1 + 2 * W1_B, O_LN = O_DH + DH_B, LDS = O_LN + 2 * C * 4;
+  static constexpr int O_GU = 0, O_W1 = 2 * GU_B, O_DH = O_W1 + 2 * W1_B, O_LN = O_DH + DH_B, LDS = O_LN + 3 * C * 4;
 };
 
 template <int C, int TH, int TW>
@@ -583,7 +582,8 @@ __global__ __launch_bounds__(512, C == 64 ? 4 : 2) void pvt_mlp_bwd2_kernel(PvtB
   const int cp = tid & 31, strip = tid >> 5;
   const int oy = strip >> 1, ox0 = (strip & 1) * SL;
   const bool on = strip < 2 * TH;
-  for (int i = tid; i < 2 * C; i += 512) LNS[i] = 0.f;
+  for (int i = tid; i < 3 * C; i += 512) LNS[i] = 0.f;
+  const float sc = a.bscale ? a.bscale[b] : 1.f;
 
   auto issue = [&](int s, int buf) __attribute__((always_inline)) {
     pvt_dma_plane<PT>(a.gu + img * a.HD + s * 64, a.HD, lds + G::O_GU + buf * G::GU_B, wave, lane, [&](int p) -> long {
@@ -646,14 +646,13 @@ __global__ __launch_bounds__(512, C == 64 ? 4 : 2) void pvt_mlp_bwd2_kernel(PvtB
           }
         }
       }
-      const int gy = y0 + oy;
+      bf16_t* const dhp = a.dh + (img + (long)(y0 + oy) * a.W + x0 + ox0) * a.HD + s * 64 + 2 * cp;
 #pragma unroll
       for (int i = 0; i < SL; ++i) {
         const int row = oy * TW + ox0 + i;
         const unsigned v = cenet_pack_bf2(dhv[i][0], dhv[i][1]);
         *(unsigned*)(DH + row * 128 + (((cp >> 2) ^ kf_key(row)) * 16) + (cp & 3) * 4) = v;
-        const int gx = x0 + ox0 + i;
-        if (gy < a.H && gx < a.W) *(unsigned*)(a.dh + (img + (long)gy * a.W + gx) * a.HD + s * 64 + 2 * cp) = v;
+        *(unsigned*)(dhp + (long)i * a.HD) = v;  // (exact tiles: always inside the image)
       }
     }
 #pragma unroll
@@ -708,29 +707,38 @@ __global__ __launch_bounds__(512, C == 64 ? 4 : 2) void pvt_mlp_bwd2_kernel(PvtB
     s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
     s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
     const float m1 = s1 * (1.f / C), m2 = s2 * (1.f / C);
-    if (in) {
 #pragma unroll
-      for (int nt = 0; nt < C / 16; ++nt) {
-        const int n0 = nt * 16 + (lane >> 4) * 4;
-        const f4 gr = ld4(a.g + tok * C + n0);
+    for (int nt = 0; nt < C / 16; ++nt) {
+      const int n0 = nt * 16 + (lane >> 4) * 4;
+      const f4 gr = ld4(a.g + tok * C + n0);
+      if (in) {
         f4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o.v[e] = gr.v[e] + rs * (qv[nt][e] - m1 - xh[nt][e] * m2);
         st4(a.dx + tok * C + n0, o);
       }
+      // fc2 bias gradient: column sums of s_b g (the grouped weight-gradient launch gets the UNscaled g, whose row sums
+      // would miss the DropPath scale)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = in ? sc * gr.v[e] : 0.f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((lane & 15) == 0) atomicAdd(&LNS[2 * C + n0 + e], v);
+      }
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * C; i += 512) a.ws[(long)bid.x * 2 * C + i] = LNS[i];
+  for (int i = tid; i < 3 * C; i += 512) a.ws[(long)bid.x * 3 * C + i] = LNS[i];
 }
 
-// dln_g[c] += sum_rows ws[row][c], dln_b[c] += sum_rows ws[row][C + c]
-__global__ __launch_bounds__(256) void pvt_mlp_lnfold_kernel(const float* __restrict__ ws, int rows, int C2, float* __restrict__ dg,
-                                                            float* __restrict__ db) {
+// dln_g[c] += sum_rows ws[row][c], dln_b[c] += sum_rows ws[row][C + c], db2[c] += sum_rows ws[row][2 C + c]
+__global__ __launch_bounds__(256) void pvt_mlp_lnfold_kernel(const float* __restrict__ ws, int rows, int C, float* __restrict__ dg,
+                                                            float* __restrict__ db, float* __restrict__ db2) {
   __shared__ float red[256];
   const int c = blockIdx.x, tid = threadIdx.x;  // one workgroup per output
   float s = 0.f;
-  for (int r = tid; r < rows; r += 256) s += ws[(long)r * C2 + c];
+  for (int r = tid; r < rows; r += 256) s += ws[(long)r * 3 * C + c];
   red[tid] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -738,8 +746,9 @@ __global__ __launch_bounds__(256) void pvt_mlp_lnfold_kernel(const float* __rest
     __syncthreads();
   }
   if (tid == 0) {
-    if (c < C2 / 2) dg[c] += red[0];
-    else db[c - C2 / 2] += red[0];
+    if (c < C) dg[c] += red[0];
+    else if (c < 2 * C) db[c - C] += red[0];
+    else if (db2) db2[c - 2 * C] += red[0];
   }
 }
 
@@ -797,27 +806,28 @@ extern "C" int cenet_pvt_mlp_fwd_bf16(const bf16_t* x, const float* ln_g, const 
 extern "C" long cenet_pvt_mlp_bwd_ws_floats(int B, int H, int W, int C) {
   int TH, TW;
   if (!pvt_mlp_geo(H, W, TH, TW)) return 0;
-  return (long)B * (W / TW) * (H / TH) * 2 * C;
+  return (long)B * (W / TW) * (H / TH) * 3 * C;
 }
 
 /* backward of cenet_pvt_mlp_fwd_bf16 from its saved tensors, two launches (+ a fold of the LayerNorm affine gradients):
- * gu, dh: [B, H*W, HD] outputs (dh: the operand of the fc1 weight gradient); gs = s_b g [B, H*W, C] (written when bscale is set:
- * the operand of the fc2 weight gradient); dx = g + dLayerNorm; dwd / dbd / dln_g / dln_b are ADDED into. */
+ * gu, dh: [B, H*W, HD] outputs (dh: the operand of the fc1 weight gradient; the fc2 weight gradient is g^T a with the saved,
+ * already scaled a); dx = g + dLayerNorm; dwd / dbd / dln_g / dln_b and db2 (fc2 bias: column sums of s_b g; may be NULL) are
+ * ADDED into. */
 extern "C" int cenet_pvt_mlp_bwd_bf16(const bf16_t* g, const float* bscale, const bf16_t* w1, const bf16_t* w2, const float* wd,
                                       const float* bd, const bf16_t* h, const bf16_t* x, const float* ln_g, const float* mean,
-                                      const float* rstd, bf16_t* gu, bf16_t* gs, bf16_t* dh, bf16_t* dx, float* dwd_acc,
-                                      float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* ws, int B, int H, int W, int C,
-                                      int HD, hipStream_t stream) {
+                                      const float* rstd, bf16_t* gu, bf16_t* dh, bf16_t* dx, float* dwd_acc,
+                                      float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* db2_acc, float* ws, int B, int H,
+                                      int W, int C, int HD, hipStream_t stream) {
   if (!g || !w1 || !w2 || !wd || !bd || !h || !x || !ln_g || !mean || !rstd || !gu || !dh || !dx || !dwd_acc || !dbd_acc ||
-      !dln_g_acc || !dln_b_acc || !ws || B <= 0 || (bscale && !gs))
+      !dln_g_acc || !dln_b_acc || !ws || B <= 0)
     return CENET_EINVAL;
   int TH, TW;
   if (!cenet_pvt_mlp_supported(C, HD, H, W) || !pvt_mlp_geo(H, W, TH, TW)) return CENET_EUNSUPPORTED;
-  if ((((uintptr_t)g | (uintptr_t)h | (uintptr_t)x | (uintptr_t)gu | (uintptr_t)gs | (uintptr_t)dh | (uintptr_t)dx |
+  if ((((uintptr_t)g | (uintptr_t)h | (uintptr_t)x | (uintptr_t)gu | (uintptr_t)dh | (uintptr_t)dx |
         (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)ln_g) & 15) != 0 || (((uintptr_t)wd | (uintptr_t)bd) & 7) != 0)
     return CENET_EUNSUPPORTED;
   PvtBwdArgs a = {};
-  a.g = g; a.bscale = bscale; a.w1 = w1; a.w2 = w2; a.wd = wd; a.bd = bd; a.h = h; a.gu = gu; a.gs = gs; a.dh = dh;
+  a.g = g; a.bscale = bscale; a.w1 = w1; a.w2 = w2; a.wd = wd; a.bd = bd; a.h = h; a.gu = gu; a.dh = dh;
   a.dwd = dwd_acc; a.dbd = dbd_acc; a.x = x; a.ln_g = ln_g; a.mean = mean; a.rstd = rstd; a.dx = dx; a.ws = ws;
   a.H = H; a.W = W; a.HD = HD;
   a.tiles_x = W / TW;
@@ -843,7 +853,7 @@ extern "C" int cenet_pvt_mlp_bwd_bf16(const bf16_t* g, const float* bscale, cons
   PVT_BWD_GO(128, 7)
   return CENET_EUNSUPPORTED;
 #undef PVT_BWD_GO
-  CENET_LAUNCH(pvt_mlp_lnfold_kernel, dim3(2 * C), dim3(256), stream, (const float*)ws, (int)g2.x, 2 * C, dln_g_acc, dln_b_acc);
+  CENET_LAUNCH(pvt_mlp_lnfold_kernel, dim3(3 * C), dim3(256), stream, (const float*)ws, (int)g2.x, C, dln_g_acc, dln_b_acc, db2_acc);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -398,8 +398,8 @@ def pvt_mlp_supported(x, Cn, HD, H, W) -> bool:
 
 def pvt_mlp_fwd(x, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, Cn, HD, saved=None):
     """y = x + s_b (fc2(GELU(DW3x3(fc1(LN(x))) + bd)) + b2), one launch (bf16 tokens; w1 / w2 are the bf16 shadows).
-    saved = (xn, mean, rstd, h, a): also store the LayerNorm output and statistics, the fc1 output and the GELU output (what the
-    backward chain reads)."""
+    saved = (xn, mean, rstd, h, a): also store the LayerNorm output and statistics, the fc1 output and s_b * the GELU output (what
+    the backward kernels and the fc1 / fc2 weight gradients read)."""
     xn, mean, rstd, h, a = saved if saved is not None else (None,) * 5
     _chk(x, ln_g, ln_b, w1, b1, wd, bd, w2, b2, bscale, y, xn, mean, rstd, h, a)
     assert is_bf16(x) and is_bf16(y) and is_bf16(w1) and is_bf16(w2)
@@ -408,15 +408,16 @@ def pvt_mlp_fwd(x, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, 
 
 
 
-def pvt_mlp_bwd(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, gs, dh, dx, dwd, dbd, dln_g, dln_b, B, H, W, Cn, HD):
+def pvt_mlp_bwd(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dln_g, dln_b, db2, B, H, W, Cn, HD):
     """backward of pvt_mlp_fwd from its saved tensors in two launches (+ a fold): gu = (s_b g . W2) * GELU'(DW(h) + bd) with the
     depthwise weight / bias gradients ADDED into dwd / dbd; dh = DW^T(gu) (the operand of the fc1 weight gradient), dx = g +
-    LayerNormBackward(dh . W1) with the affine gradients ADDED into dln_g / dln_b.  gs = s_b g is written when bscale is set."""
-    _chk(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, gs, dh, dx, dwd, dbd, dln_g, dln_b)
+    LayerNormBackward(dh . W1) with the affine gradients ADDED into dln_g / dln_b and the fc2 bias gradient (column sums of s_b g)
+    into db2 (None: not wanted)."""
+    _chk(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dln_g, dln_b, db2)
     f = _lib.lib().cenet_pvt_mlp_bwd_ws_floats
     f.restype = C.c_long
     ws = torch.empty(int(f(B, H, W, Cn)), device=g.device, dtype=torch.float32)
-    _call("cenet_pvt_mlp_bwd_bf16", g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, gs, dh, dx, dwd, dbd, dln_g, dln_b, ws,
+    _call("cenet_pvt_mlp_bwd_bf16", g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dln_g, dln_b, db2, ws,
           B, H, W, Cn, HD)
 
 

@@ -951,8 +951,6 @@ class PvtMlpFn(Function):
         B, N, Cn = x.shape
         HD = w1.shape[0]
         R = B * N
-        # fc2 (LinearFn.backward with the DropPath scale)
-        gs = torch.empty_like(g) if bscale is not None else g  # (s_b g: written by the first backward kernel)
 
         def wgrad(gy, xin, Wp, bp, Nn, K):
             dW, db = grad_buf(Wp), grad_buf(bp)
@@ -975,9 +973,11 @@ class PvtMlpFn(Function):
         if dg is None:
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
         gu, dh, dx = torch.empty_like(a), torch.empty_like(a), torch.empty_like(x)
-        kern.pvt_mlp_bwd(g, bscale, kern.wq(w1, x), kern.wq(w2, x), wd, bd, h, x, ln_g, mean, rstd, gu,
-                         gs if bscale is not None else None, dh, dx, dwd, dbd, dg, db, B, H, Wd, Cn, HD)
-        wgrad(gs, a, w2, b2, Cn, HD)
+        kern.pvt_mlp_bwd(g, bscale, kern.wq(w1, x), kern.wq(w2, x), wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dg, db,
+                         grad_buf(b2), B, H, Wd, Cn, HD)
+        # a was saved as s_b * GELU(.): dW2 = (s_b g)^T a = g^T (s_b a), no scaled copy of g; the bias gradient (column sums of
+        # s_b g) comes from the second kernel, so the recorded problem carries no bias
+        wgrad(g, a, w2, None, Cn, HD)
         wgrad(dh, xn, w1, b1, HD, Cn)
         return (dx,) + (None,) * 12
 

@@ -282,7 +282,7 @@ int cenet_dwconv3x3_wgrad_tok_acc_f32(const float* x, const float* dy, float* dw
 /* y = x + s_b (fc2(GELU(DW3x3(fc1(LayerNorm(x))) + bd)) + b2) in ONE launch: replaces aten::native_layer_norm + addmm +
  * convolution(groups) + gelu + addmm + mul + add.  w1 [HD, C] / w2 [C, HD] are bf16, everything else fp32; bscale [B] (DropPath
  * keep / keep_prob per sample) may be NULL.  xn_out / mean_out / rstd_out / h_out / a_out (all or none): the LayerNorm output
- * and statistics, the fc1 output and the GELU output, stored for the backward chain.  CENET_EUNSUPPORTED unless
+ * and statistics, the fc1 output and s_b * the GELU output, stored for the backward kernels.  CENET_EUNSUPPORTED unless
  * cenet_pvt_mlp_supported(C, HD, H, W) (C in {64, 128}, HD % 64 == 0, W % 14 == 0, H % 7 == 0 or H % 8 == 0). */
 int cenet_pvt_mlp_supported(int C, int HD, int H, int W);
 int cenet_pvt_mlp_fwd_bf16(const unsigned short* x, const float* ln_g, const float* ln_b, float eps, const unsigned short* w1,
@@ -293,15 +293,16 @@ int cenet_pvt_mlp_fwd_bf16(const unsigned short* x, const float* ln_g, const flo
 /* backward of cenet_pvt_mlp_fwd_bf16 from its saved tensors in two launches (+ a fold of the LayerNorm affine gradients): replaces
  * mul (DropPath scale) + mm (fc2 data gradient) + gelu_backward + convolution_backward(groups) + mm (fc1 data gradient) +
  * native_layer_norm_backward + add (residual).  gu, dh [B, H*W, HD]: the gradient of the depthwise conv's output (scratch) and of
- * fc1's output (operand of the fc1 weight gradient dW1 = dh^T xn); gs = s_b g [B, H*W, C] is written when bscale is set (operand of
- * the fc2 weight gradient dW2 = gs^T a); dx = g + LayerNormBackward(dh . W1); dwd / dbd / dln_g / dln_b are ADDED into.
+ * fc1's output (operand of the fc1 weight gradient dW1 = dh^T xn; the fc2 weight gradient is dW2 = g^T a with the forward's saved a,
+ * which already carries s_b); dx = g + LayerNormBackward(dh . W1); dwd / dbd / dln_g / dln_b and db2 (fc2 bias gradient =
+ * column sums of s_b g; may be NULL) are ADDED into.
  * ws: cenet_pvt_mlp_bwd_ws_floats(B, H, W, C) floats. */
 long cenet_pvt_mlp_bwd_ws_floats(int B, int H, int W, int C);
 int cenet_pvt_mlp_bwd_bf16(const unsigned short* g, const float* bscale, const unsigned short* w1, const unsigned short* w2,
                            const float* wd, const float* bd, const unsigned short* h, const unsigned short* x, const float* ln_g,
-                           const float* mean, const float* rstd, unsigned short* gu, unsigned short* gs, unsigned short* dh,
-                           unsigned short* dx, float* dwd_acc, float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* ws,
-                           int B, int H, int W, int C, int HD, cenet_stream_t stream);
+                           const float* mean, const float* rstd, unsigned short* gu, unsigned short* dh, unsigned short* dx,
+                           float* dwd_acc, float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* db2_acc,
+                           float* ws, int B, int H, int W, int C, int HD, cenet_stream_t stream);
 
 /* ---- resampling (resample.hip) ---------------------------------------------------------------------------- */
 /* aten::upsample_bilinear2d(+_backward) — dseb.py:67-68; cfam.py:217,232; blocks.py:210; out.py:74 */

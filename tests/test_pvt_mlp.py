@@ -49,11 +49,15 @@ def test_fused_forward_equals_chain(dev, C, HD, H, W, B, drop):
         kern.layernorm_fwd(x, p["ln_g"], p["ln_b"], xn_ref, mean_ref, rstd_ref, B * H * W, C, 1e-6)
         h_ref = ops.linear(xn_ref, p["w1"], p["b1"])
         a_ref = ops.dwconv_tok(h_ref, p["wd"], p["bd"], H, W, act="gelu")
+        if bscale is not None:  # the saved GELU output carries the DropPath scale (it only feeds the fc2 weight gradient)
+            a_ref = (a_ref.float() * bscale.view(-1, 1, 1)).to(BF)
     for got, want, name in ((saved[0], xn_ref, "xn"), (saved[1], mean_ref, "mean"), (saved[2], rstd_ref, "rstd"),
                             (saved[3], h_ref, "h"), (saved[4], a_ref, "a")):
         dd = (got.float() - want.float()).abs()
         assert dd.max().item() <= 0.04 * max(want.float().abs().max().item(), 1e-6), (name, dd.max().item())
-        assert dd.mean().item() <= 1e-3 * max(want.float().abs().mean().item(), 1e-6), (name, dd.mean().item())
+        # (a with a DropPath scale: the kernel scales in fp32 and rounds once, the restatement above rounds twice)
+        rel = 3e-3 if (name == "a" and bscale is not None) else 1e-3
+        assert dd.mean().item() <= rel * max(want.float().abs().mean().item(), 1e-6), (name, dd.mean().item())
     with torch.no_grad():
         pass
     d = (y.float() - ref.float()).abs()

@@ -54,13 +54,14 @@ for C, HD, H, W in [(64, 512, 56, 56), (128, 1024, 28, 28)][:int(os.environ.get(
     print(f"C{C} HD{HD} {H}x{W}: max|d| {d.max().item():.4f} mean|d| {d.mean().item():.2e} (|ref| mean {ref.float().abs().mean().item():.3f})")
     print(f"   forward: fused {timeit(fused):8.1f} us   fused + saved tensors {timeit(fused_saving):8.1f} us   chain {timeit(chain):8.1f} us")
     gy0 = torch.randn_like(x)
-    gu, dh, dx, gs = torch.empty_like(saved[3]), torch.empty_like(saved[3]), torch.empty_like(x), torch.empty_like(x)
+    gu, dh, dx = torch.empty_like(saved[3]), torch.empty_like(saved[3]), torch.empty_like(x)
     gr = [torch.zeros_like(p[k]) for k in ("wd", "bd", "ln_g", "ln_b")]
+    db2 = torch.zeros_like(p["b2"])
     fused_saving()
 
     def bwd_raw():
-        kern.pvt_mlp_bwd(gy0, bscale, w1, w2, p["wd"], p["bd"], saved[3], x, p["ln_g"], saved[1], saved[2], gu, gs, dh, dx,
-                         gr[0], gr[1], gr[2], gr[3], B, H, W, C, HD)
+        kern.pvt_mlp_bwd(gy0, bscale, w1, w2, p["wd"], p["bd"], saved[3], x, p["ln_g"], saved[1], saved[2], gu, dh, dx,
+                         gr[0], gr[1], gr[2], gr[3], db2, B, H, W, C, HD)
 
     print(f"   backward kernels (K1 + K2 + fold) alone: {timeit(bwd_raw):8.1f} us")
     if os.environ.get("MLP_RAW_ONLY"):
