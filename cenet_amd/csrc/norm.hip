@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void ln_bwd_v8_kernel(const bf16_t* __restrict
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dx,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                       int steps, const bf16_t* __restrict__ dx_add) {
+                                                       int steps, const bf16_t* __restrict__ dx_add, float* __restrict__ part) {
   constexpr int RPW = 64 / LPR;
   __shared__ float red[2][4][NP * LPR * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, l = lane % LPR;
@@ -366,9 +366,103 @@ __global__ __launch_bounds__(256) void ln_bwd_v8_kernel(const bf16_t* __restrict
     }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {  // column c sits at octet c/8 = l + LPR*p -> index (p*LPR + l)*8 + e == c
-    atomicAdd(&dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(&dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    const float vg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float vb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    if (part) {  // deferred: this workgroup's row of the partial buffer (folded later by ln_fold_group_kernel, no atomics)
+      part[(long)blockIdx.x * 2 * C + c] = vg;
+      part[(long)blockIdx.x * 2 * C + C + c] = vb;
+    } else {
+      atomicAdd(&dgamma[c], vg);
+      atomicAdd(&dbeta[c], vb);
+    }
   }
+}
+
+// ---- deferred fold of LayerNorm affine-gradient partials (round 4) ----------------------------------------------------------
+// With float atomics every LayerNorm backward ended in 2 C same-address adds per workgroup, which capped the grid at ~256
+// workgroups x 6 - 8 dependent steps (14 - 18 us per call on 4 - 13 MB of data).  Writing one partial ROW per workgroup instead
+// lets the grid be ~1 000 single-step workgroups; the rows of ALL LayerNorms of a backward segment are folded by ONE launch.
+struct LnFoldDesc {
+  const float* part;  // [nrows][2 C]
+  float* dg;          // [C] +=
+  float* db;          // [C] +=
+  int nrows, C;
+};
+#define LN_FOLD_MAX 48
+struct LnFoldArgs {
+  LnFoldDesc d[LN_FOLD_MAX];
+};
+// grid (chunks of 32 columns, layers), 1024 threads = 32 columns x 32 row lanes
+__global__ __launch_bounds__(1024) void ln_fold_group_kernel(LnFoldArgs a) {
+  __shared__ float red[32][33];
+  const LnFoldDesc d = a.d[blockIdx.y];
+  const int C2 = 2 * d.C;
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  if (blockIdx.x * 32 >= C2) return;
+  float s = 0.f;
+  if (col < C2)
+    for (int r = rl; r < d.nrows; r += 32) s += d.part[(long)r * C2 + col];
+  red[rl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rl == 0 && col < C2) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i][threadIdx.x & 31];
+    if (col < d.C) d.dg[col] += t;
+    else d.db[col - d.C] += t;
+  }
+}
+
+static inline int ln_steps(int rows, int rows_per_step, long target);
+/* rows of the partial buffer cenet_layernorm_bwd_add_part_bf16 writes for (rows, C): [that many][2 C] floats */
+extern "C" int cenet_layernorm_bwd_part_rows(int rows, int C) {
+  const int lpr = C <= 64 ? 8 : C <= 128 ? 16 : C <= 256 ? 32 : 64;
+  const int rps = 4 * 64 / lpr, st = ln_steps(rows, rps, 1024);
+  return cdiv(rows, rps * st);
+}
+
+/* LayerNorm backward (+ residual gradient dx_add) on bf16 rows whose affine gradients go to a partial buffer instead of float
+ * atomics: part[cenet_layernorm_bwd_part_rows(rows, C)][2 C]; fold with cenet_ln_fold_group. */
+extern "C" int cenet_layernorm_bwd_add_part_bf16(const bf16_t* dy, const bf16_t* x, const float* gamma, const float* mean,
+                                                 const float* rstd, const bf16_t* dx_add, bf16_t* dx, float* part, int rows, int C,
+                                                 hipStream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !part || rows <= 0 || C <= 0) return CENET_EINVAL;
+  if (C > 512 || (C & 7) != 0 ||
+      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)gamma) & 15) != 0))
+    return CENET_EUNSUPPORTED;
+#define CENET_LNP8(LPRv)                                                                                               \
+  {                                                                                                                   \
+    const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps, 1024);                                                    \
+    CENET_LAUNCH((ln_bwd_v8_kernel<LPRv, 1>), dim3(cdiv(rows, rps * st)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, \
+                 (float*)nullptr, (float*)nullptr, rows, C, st, dx_add, part);                                        \
+  }
+  if (C <= 64) CENET_LNP8(8)
+  else if (C <= 128) CENET_LNP8(16)
+  else if (C <= 256) CENET_LNP8(32)
+  else CENET_LNP8(64)
+#undef CENET_LNP8
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+/* n <= 48 per launch (more: several launches): dg / db += column sums of the partial buffers */
+extern "C" int cenet_ln_fold_group(const void* const* part, float* const* dg, float* const* db, const int* nrows, const int* C,
+                                   int n, hipStream_t stream) {
+  if (n < 0 || (n > 0 && (!part || !dg || !db || !nrows || !C))) return CENET_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += LN_FOLD_MAX) {
+    LnFoldArgs a;
+    const int m = n - i0 < LN_FOLD_MAX ? n - i0 : LN_FOLD_MAX;
+    int cmax = 0;
+    for (int i = 0; i < m; ++i) {
+      if (!part[i0 + i] || !dg[i0 + i] || !db[i0 + i] || nrows[i0 + i] <= 0 || C[i0 + i] <= 0) return CENET_EINVAL;
+      a.d[i].part = (const float*)part[i0 + i]; a.d[i].dg = dg[i0 + i]; a.d[i].db = db[i0 + i];
+      a.d[i].nrows = nrows[i0 + i]; a.d[i].C = C[i0 + i];
+      if (C[i0 + i] > cmax) cmax = C[i0 + i];
+    }
+    CENET_LAUNCH(ln_fold_group_kernel, dim3(cdiv(2 * cmax, 32), m), dim3(1024), stream, a);
+    CENET_CHECK_LAUNCH();
+  }
+  return CENET_OK;
 }
 
 // activation pointers a, b (quads of T) and parameter pointers c, d (quads of float)
@@ -382,7 +476,7 @@ static inline bool ln_v4_ok(const void* a, const void* b, const void* c, const v
 // `target`: workgroups wanted.  Forward: ~1024 (latency hiding).  Backward: ~256 — every workgroup ends with 2*C float atomics
 // onto the SAME 2*C addresses, and same-row atomics run at ~0.09 TB/s (MI355X_MICROARCH.md, Global float atomics): at C = 320
 // and 1568 workgroups that was 4 MB of contended adds = 44 us per LayerNorm; measured 31 -> 17 us per call with 256.
-static inline int ln_steps(int rows, int rows_per_step, long target = 1024) {
+static inline int ln_steps(int rows, int rows_per_step, long target) {
   long st = rows / ((long)rows_per_step * target);
   if (st < 1) st = 1;
   if (st > 8) st = 8;
@@ -396,7 +490,7 @@ static int layernorm_fwd_impl(const T* x, const float* gamma, const float* beta,
   if (ln_v4_ok<T>(x, y, gamma, beta, C)) {
 #define CENET_LNF(LPRv, NPv)                                                                                          \
   {                                                                                                                   \
-    const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps);                                                          \
+    const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps, 1024);                                                          \
     CENET_LAUNCH((ln_fwd_v4_kernel<T, LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, x, gamma, beta, y, mean, rstd, \
                  rows, C, eps, st);                                                                                   \
   }
@@ -426,7 +520,7 @@ static int layernorm_bwd_add_acc_impl(const T* dy, const T* x, const float* gamm
   {                                                                                                                   \
     const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps, 256);                                                     \
     CENET_LAUNCH((ln_bwd_v8_kernel<LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, (const bf16_t*)dy,      \
-                 (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma_acc, dbeta_acc, rows, C, st, (const bf16_t*)dx_add); \
+                 (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma_acc, dbeta_acc, rows, C, st, (const bf16_t*)dx_add, (float*)nullptr); \
   }
     if (C <= 64) CENET_LNB8(8, 1)
     else if (C <= 128) CENET_LNB8(16, 1)

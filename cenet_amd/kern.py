@@ -342,6 +342,34 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, Cn, dx_add=
     _call("cenet_layernorm_bwd_add_acc_f32", dy, x, gamma, mean, rstd, dx_add, dx, dgamma, dbeta, rows, Cn)
 
 
+def layernorm_bwd_part_supported(dy, x, Cn) -> bool:
+    return bool(is_bf16(dy) and is_bf16(x) and Cn % 8 == 0 and Cn <= 512 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def layernorm_bwd_part(dy, x, gamma, mean, rstd, dx, rows, Cn, dx_add=None):
+    """LayerNorm backward whose affine gradients go to a partial buffer [workgroups, 2 C] (returned) instead of float atomics;
+    ln_fold_group adds the column sums of many such buffers into their gradients with one launch."""
+    _chk(dy, x, gamma, mean, rstd, dx, dx_add)
+    nrows = int(_lib.lib().cenet_layernorm_bwd_part_rows(rows, Cn))
+    part = torch.empty((nrows, 2 * Cn), device=dy.device, dtype=torch.float32)
+    _call("cenet_layernorm_bwd_add_part_bf16", dy, x, gamma, mean, rstd, dx_add, dx, part, rows, Cn)
+    return part
+
+
+def ln_fold_group(items):
+    """items: [(part [nrows, 2 C], dgamma [C], dbeta [C])]: dgamma / dbeta += column sums, one launch per 48 items"""
+    n = len(items)
+    if n == 0:
+        return
+    parts = (C.c_void_p * n)(*[t[0].data_ptr() for t in items])
+    dgs = (C.c_void_p * n)(*[t[1].data_ptr() for t in items])
+    dbs = (C.c_void_p * n)(*[t[2].data_ptr() for t in items])
+    nr = (C.c_int * n)(*[t[0].shape[0] for t in items])
+    cs = (C.c_int * n)(*[t[0].shape[1] // 2 for t in items])
+    rc = _lib.lib().cenet_ln_fold_group(parts, dgs, dbs, nr, cs, n, stream())
+    _lib.check(rc, "cenet_ln_fold_group")
+
+
 def bn_stats(x, sb, B, Cn, HW, ws, mean, var, rmean, rvar, momentum, nbt):
     _chk(x, ws, mean, var, rmean, rvar)
     _call("cenet_bn_stats_f32", x, L(sb), B, Cn, HW, ws, mean, var, rmean, rvar, float(momentum), nbt)

@@ -142,6 +142,7 @@ class _WgradState:
         self.keep = []     # the dY / X tensors the descriptors point into
         self.held = 0      # their bytes
         self.task = None   # autograd graph task whose end-of-backward callback is queued
+        self.ln_items = []  # (partial buffer, dgamma, dbeta) of LayerNorm backward launches: folded by ONE launch at the flush
         # --- the weight-gradient stream
         self.stream = None
         self.events = None
@@ -150,16 +151,23 @@ class _WgradState:
         self.side_keep = []  # tensors the side stream still reads (see _wgrad_side): released in wgrad_join()
 
     def flush(self):
-        if not self.items:
+        if not self.items and not self.ln_items:
             return
         items, self.items = self.items, []
+        ln, self.ln_items = self.ln_items, []
         self.held = 0
+
+        def go():
+            if ln:
+                kern.ln_fold_group(ln)
+            if items:
+                kern.wgrad_group(items, self.device)
         try:
             if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
                 with torch.cuda.device(self.device):
-                    kern.wgrad_group(items, self.device)
+                    go()
             else:
-                kern.wgrad_group(items, self.device)
+                go()
         finally:
             self.keep = []
 
@@ -256,7 +264,7 @@ def wgrad_hold(on: bool):
 
 def wgrad_pending() -> int:
     """recorded, not yet launched weight-gradient problems over all devices"""
-    return sum(len(st.items) + len(st.keep) for st in _WG.values())
+    return sum(len(st.items) + len(st.keep) + len(st.ln_items) for st in _WG.values())
 
 
 def _wgrad_deferrable(M: int, N: int, *ts) -> bool:
@@ -270,15 +278,26 @@ def _wgrad_defer(A: Tensor, a_off: int, lda: int, skbA: int, B: Tensor, b_off: i
                  db: Optional[Tensor], M: int, N: int, K: int, nkb: int, kfast: int):
     """record dW[c_off:][M, N] += sum_{kb, k} A(m, k) B(k, n), db[m] += sum A(m, k) (offsets in elements)"""
     st = _wg(A.device)
-    tid = _graph_task_id() if _graph_task_id is not None else 0
-    if not _WgradCfg.hold and st.items and st.task is not None and tid != st.task:
-        # records of a backward pass that never reached its end (it raised: the engine runs no callbacks then).  Their
-        # gradients are void; adding them into a later pass's would be wrong, and they must not block that pass's own callback.
-        st.items, st.keep, st.held, st.task = [], [], 0, None
+    tid = _defer_begin(st)
     st.items.append((A.data_ptr() + 2 * a_off, B.data_ptr() + 2 * b_off, dW.data_ptr() + 4 * c_off,
                      db.data_ptr() if db is not None else None, lda, ldb, skbA, skbB, M, N, K, nkb, kfast))
     st.keep.append((A, B))
     st.held += A.numel() * A.element_size() + B.numel() * B.element_size()
+    _defer_end(st, tid)
+
+
+def _defer_begin(st) -> int:
+    """before a record: the current autograd graph task; drops the records of a pass that never reached its end"""
+    tid = _graph_task_id() if _graph_task_id is not None else 0
+    if not _WgradCfg.hold and (st.items or st.ln_items) and st.task is not None and tid != st.task:
+        # records of a backward pass that never reached its end (it raised: the engine runs no callbacks then).  Their
+        # gradients are void; adding them into a later pass's would be wrong, and they must not block that pass's own callback.
+        st.items, st.ln_items, st.keep, st.held, st.task = [], [], [], 0, None
+    return tid
+
+
+def _defer_end(st, tid: int):
+    """after a record: make sure the end-of-backward flush of THIS pass is queued (or flush now when there is no pass)"""
     if _WgradCfg.hold:
         return
     if tid < 0:  # not inside a backward pass (a Function's backward called by hand): flush right away
@@ -294,6 +313,21 @@ def _wgrad_defer(A: Tensor, a_off: int, lda: int, skbA: int, B: Tensor, b_off: i
             return
     if st.held > _WgradCfg.hold_bytes:  # bound the operands kept alive (a full launch costs nothing extra)
         st.flush()
+
+
+def _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, dx_add=None):
+    """LayerNorm backward; bf16 rows with grouping on: the affine gradients go to a partial buffer that is folded, together with
+    those of every other LayerNorm of the backward segment, by one launch at the flush (no float atomics, ~1 000 single-step
+    workgroups instead of ~256 x 6 - 8 dependent steps)"""
+    if _WgradCfg.grouping and kern.layernorm_bwd_part_supported(g, x, Cn) and (dx_add is None or dx_add.dtype == g.dtype):
+        st = _wg(g.device)
+        tid = _defer_begin(st)
+        part = kern.layernorm_bwd_part(g, x, gamma, mean, rstd, dx, rows, Cn, dx_add=dx_add)
+        st.ln_items.append((part, dg, db))
+        st.held += part.numel() * 4
+        _defer_end(st, tid)
+    else:
+        kern.layernorm_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, dx_add=dx_add)
 
 
 def _wgrad_flush_cb(st, tid):
@@ -771,7 +805,7 @@ class LayerNormFn(Function):
         dg, db = grad_buf(gp), grad_buf(bp)
         if dg is None:  # frozen affine: accumulate into scratch
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
-        kern.layernorm_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn)
+        _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn)
         return dx, None, None, None
 
 
@@ -809,7 +843,7 @@ class LayerNormResFn(Function):
         dg, db = grad_buf(gp), grad_buf(bp)
         if dg is None:
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
-        kern.layernorm_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, dx_add=_c(g_res))
+        _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, dx_add=_c(g_res))
         return dx, None, None, None
 
 

@@ -278,6 +278,16 @@ int cenet_dwconv3x3_wgrad_nchw_acc_f32(const float* x, long sxb, const float* dy
 int cenet_dwconv3x3_wgrad_tok_acc_f32(const float* x, const float* dy, float* dw_acc, float* dbias_acc, int B, int C, int H,
                                       int W, cenet_stream_t stream);
 
+/* LayerNorm backward on bf16 rows with DEFERRED affine gradients (round 4): instead of 2 C float atomics per workgroup, each
+ * workgroup writes one row of part[cenet_layernorm_bwd_part_rows(rows, C)][2 C]; cenet_ln_fold_group adds the column sums of up to
+ * any number of such buffers (all LayerNorms of a backward segment) into their dgamma / dbeta with one launch per 48. */
+int cenet_layernorm_bwd_part_rows(int rows, int C);
+int cenet_layernorm_bwd_add_part_bf16(const unsigned short* dy, const unsigned short* x, const float* gamma, const float* mean,
+                                      const float* rstd, const unsigned short* dx_add, unsigned short* dx, float* part, int rows,
+                                      int C, cenet_stream_t stream);
+int cenet_ln_fold_group(const void* const* part, float* const* dgamma_acc, float* const* dbeta_acc, const int* nrows, const int* C,
+                        int n, cenet_stream_t stream);
+
 /* ---- fused PVTv2 MLP half (pvt_mlp.hip) — pvtv2.py:40-47,145-149,364-370 on bf16 tokens [B, H*W, C] --------------------- */
 /* y = x + s_b (fc2(GELU(DW3x3(fc1(LayerNorm(x))) + bd)) + b2) in ONE launch: replaces aten::native_layer_norm + addmm +
  * convolution(groups) + gelu + addmm + mul + add.  w1 [HD, C] / w2 [C, HD] are bf16, everything else fp32; bscale [B] (DropPath
