@@ -200,7 +200,8 @@ def _wgrad_side(*reads, returned=None):
     if not _WgradCfg.overlap or kern._lib.is_hostsim():
         yield
         return
-    st = _wg(next(t for t in reads if isinstance(t, Tensor)).device)
+    dev_of = next((t.device for t in reads if isinstance(t, Tensor)), None)
+    st = _wg(dev_of if dev_of is not None else torch.device("cuda", torch.cuda.current_device()))
     cur = torch.cuda.current_stream(st.device)
     if st.stream is None:
         st.stream = torch.cuda.Stream(st.device)
