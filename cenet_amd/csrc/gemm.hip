@@ -220,7 +220,15 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   }
   const bool im = B->mode != 0;
   int rc;
-  if (ring) {
+  // one or two K-steps, nothing to pipeline inside a tile: persistent workgroups with the ring over TILES (gemm_ring.h)
+  static const bool stream_off = getenv("CENET_GEMM_NO_STREAM") != nullptr;
+  const bool rstream = ring && !stream_off && !E->atomic && nkb == 1 && splits <= 1 && !g.ring_unal && (K == 64 || K == 128) &&
+                       (long)cdiv(M, 64) * cdiv(N, 64) * nbatch >= 768;
+  if (rstream) {
+    snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_ring_stream_kernel<%s, %s, %s, %d>", tf(akf), tf(bkf), tf(swap), K / 64);
+    rc = akf ? (bkf ? cenet_gemm_launch_ring_kk(g, 0, 0, nbatch, swap, stream) : cenet_gemm_launch_ring_kr(g, 0, 0, nbatch, swap, stream))
+             : (bkf ? cenet_gemm_launch_ring_rk(g, 0, 0, nbatch, swap, stream) : cenet_gemm_launch_ring_rr(g, 0, 0, nbatch, swap, stream));
+  } else if (ring) {
     snprintf(g_last_kernel, sizeof g_last_kernel, "gemm_ring_kernel<%s, %s, %d, %d, %d, %s>", tf(akf), tf(bkf), bm, bn,
              bm == 128 && bn == 128 ? 2 : (bm == 64 && bn == 64 ? 4 : 3), tf(swap));
     rc = akf ? (bkf ? cenet_gemm_launch_ring_kk(g, bm, bn, nbatch, swap, stream) : cenet_gemm_launch_ring_kr(g, bm, bn, nbatch, swap, stream))

@@ -284,6 +284,119 @@ __global__ __launch_bounds__(256, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1)) v
   gemm_epilogue<bf16_t, BM, BN, SWAP, true>(g, acc, (float*)lds, m0, n0, bo, bi, batch, wave, lane);
 }
 
+// ---- streaming variant (round 4): reductions of ONE or TWO K-steps (K = 64 / 128, aligned operands, no split) -----------------
+// For K <= 128 the ring above has nothing to pipeline: a workgroup issues its tile's loads, waits out the whole first-byte
+// latency, does 1 - 2 MFMA steps, stores and exits; a launch is then ~3 rounds of (launch ramp + latency + store) whatever the
+// byte count (16 us for 26 MB: 1.6 TB/s).  Here workgroups are PERSISTENT over 64x64 output tiles and the ring runs over TILES:
+// while tile i is multiplied and stored, the operands of tile i + 1 are already in flight into the other buffer set.  One
+// barrier per tile; the wait for the next tile's loads sits BEFORE the current tile's stores are issued, so a store's
+// acknowledgement is never waited for (vmcnt counts loads and stores in issue order).  Epilogue = the direct (unstaged) one.
+template <bool AKF, bool BKF, bool SWAP, int T>
+__global__ __launch_bounds__(256, 2) void gemm_ring_stream_kernel(GemmArgs g, int tiles_x, int tiles_y, int total_tiles) {
+  constexpr int BM = 64, BN = 64, MI = 2, NJ = 2;
+  constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * T * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef CENET_HOSTSIM_BUILD
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int wm = wave >> 1, wn = wave & 1;
+  const long lda = AKF ? g.A.sr : g.A.sc, ldb = BKF ? g.B.sc : g.B.sr;
+  const long kstepA = AKF ? 1 : lda, kstepB = BKF ? 1 : ldb;
+  // virtual tile index -> tile: each XCD owns a contiguous range of the tile list (workgroups are dealt round-robin over the XCDs)
+  auto tile_of = [&](int vt) -> int {
+    if ((gridDim.x & 7) == 0 && total_tiles >= 64) {
+      const int per = total_tiles >> 3, rem = total_tiles & 7, xcd = vt & 7, idx = vt >> 3;
+      return xcd * per + (xcd < rem ? xcd : rem) + idx;
+    }
+    return vt;
+  };
+  struct Where { int m0, n0, bo, bi, batch; };
+  auto where = [&](int L) -> Where {
+    Where w;
+    const int bx = L % tiles_x, t = L / tiles_x, by = t % tiles_y;
+    w.batch = t / tiles_y;
+    w.bo = w.batch / g.nb_inner;
+    w.bi = w.batch - w.bo * g.nb_inner;
+    w.m0 = by * BM;
+    w.n0 = bx * BN;
+    return w;
+  };
+  auto issue = [&](const Where& w, int set) __attribute__((always_inline)) {
+    const bf16_t* baseA = (const bf16_t*)g.A.ptr + (long)w.bo * g.A.sb + (long)w.bi * g.A.sb2;
+    const bf16_t* baseB = (const bf16_t*)g.B.ptr + (long)w.bo * g.B.sb + (long)w.bi * g.B.sb2;
+    const RingSrc<MI> sa = ring_src<AKF, BM>(baseA, lda, w.m0, g.M, wave, lane);
+    const RingSrc<NJ> sb = ring_src<BKF, BN>(baseB, ldb, w.n0, g.N, wave, lane);
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+      unsigned char* img = lds + (set * T + kt) * STAGE;
+      ring_issue<AKF, BM>(sa, (long)kt * 64 * kstepA, 64, false, img, wave, lane, false, nullptr);
+      ring_issue<BKF, BN>(sb, (long)kt * 64 * kstepB, 64, false, img + ABYTES, wave, lane, false, nullptr);
+    }
+  };
+  int vt = blockIdx.x;
+  if (vt >= total_tiles) return;
+  Where cur = where(tile_of(vt));
+  issue(cur, 0);
+  ring_wait_vm<0>();
+  int set = 0;
+  for (; vt < total_tiles; vt += gridDim.x, set ^= 1) {
+    ring_barrier();  // every wave's part of this tile has landed (each waited for its own); everybody is done with the other set
+    const int nvt = vt + gridDim.x;
+    Where nxt = cur;
+    if (nvt < total_tiles) {
+      nxt = where(tile_of(nvt));
+      issue(nxt, set ^ 1);
+    }
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+      const unsigned char* Ai = lds + (set * T + kt) * STAGE;
+      const unsigned char* Bi = Ai + ABYTES;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        bf16x8 a[MI], b[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          a[i] = AKF ? ring_frag_kf(Ai, wm * 32 + i * 16, kc, lane) : ring_frag_rf<BM>(Ai, wm * 32 + i * 16, kc, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          b[j] = BKF ? ring_frag_kf(Bi, wn * 32 + j * 16, kc, lane) : ring_frag_rf<BN>(Bi, wn * 32 + j * 16, kc, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    ring_wait_vm<0>();  // the next tile's loads (issued a whole tile ago) and the PREVIOUS tile's stores; not this tile's stores
+    gemm_epilogue<bf16_t, BM, BN, SWAP, false>(g, acc, (float*)nullptr, cur.m0, cur.n0, cur.bo, cur.bi, cur.batch, wave, lane);
+    cur = nxt;
+  }
+}
+
+template <bool AKF, bool BKF, bool SWAP>
+static int launch_ring_stream(const GemmArgs& g, int nbatch, hipStream_t stream) {
+  const int tx = cdiv(g.N, 64), ty = cdiv(g.M, 64);
+  const long total = (long)tx * ty * nbatch;
+  if (total > (1L << 30)) return CENET_EUNSUPPORTED;
+  static const char* ge = getenv("CENET_STREAM_WGS");  // measurement aid
+  long wgs = ge ? atol(ge) : 1024;  // (measured on the whole step: 256 / 512 / 768 / 1024 / 2048 -> 21.6 / 21.55 / 21.50 / 21.46 / 21.47 ms)
+  if (wgs > total) wgs = total;
+  if (wgs >= 8) wgs &= ~7L;
+  if (g.K == 64) CENET_LAUNCH((gemm_ring_stream_kernel<AKF, BKF, SWAP, 1>), dim3((unsigned)wgs), dim3(256), stream, g, tx, ty, (int)total);
+  else if (g.K == 128) CENET_LAUNCH((gemm_ring_stream_kernel<AKF, BKF, SWAP, 2>), dim3((unsigned)wgs), dim3(256), stream, g, tx, ty, (int)total);
+  else return CENET_EUNSUPPORTED;
+  return CENET_OK;
+}
+
 template <bool AKF, bool BKF, bool SWAP>
 static int launch_ring(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_t stream) {
   dim3 grid(cdiv(g.N, bn), cdiv(g.M, bm), nbatch * g.splits);
@@ -306,8 +419,12 @@ static int launch_ring(const GemmArgs& g, int bm, int bn, int nbatch, hipStream_
   }
   return CENET_EUNSUPPORTED;
 }
+// bm == 0: the streaming variant (K = 64 / 128, 64x64 tiles)
 #define CENET_RING_INSTANCE(NAME, AKF, BKF)                                                       \
   int NAME(const GemmArgs& g, int bm, int bn, int nbatch, bool swap, hipStream_t stream) {        \
+    if (bm == 0)                                                                                  \
+      return swap ? launch_ring_stream<AKF, BKF, true>(g, nbatch, stream)                         \
+                  : launch_ring_stream<AKF, BKF, false>(g, nbatch, stream);                       \
     return swap ? launch_ring<AKF, BKF, true>(g, bm, bn, nbatch, stream)                          \
                 : launch_ring<AKF, BKF, false>(g, bm, bn, nbatch, stream);                        \
   }

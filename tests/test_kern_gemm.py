@@ -188,3 +188,47 @@ def test_gemm_ring_batched_kbatch(dev, Co, Ci, HW):
               Co, Ci, HW, scr=Ci, scc=1, nkb=Bt, splits=2, atomic=True, asum=db)
     torch.testing.assert_close(dw.cpu(), torch.einsum("bop,bip->oi", dy.float(), x.float()).cpu(), rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(db.cpu(), dy.float().sum((0, 2)).cpu(), rtol=1e-4, atol=1e-3)
+
+
+# K = 64 / 128 with >= 768 output tiles: the persistent streaming variant of the ring GEMM (gemm_ring.h, round 4) — all four
+# operand orientations, ragged edge tiles, the per-image batched form with bias / residual, and the flat form with the
+# per-row DropPath scale
+@pytest.mark.parametrize("akf,bkf", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("K", [64, 128])
+def test_ring_stream_orientations(dev, akf, bkf, K):
+    BF = torch.bfloat16
+    M, N = 1656, 1912  # 26 x 30 = 780 tiles, both edges ragged, every pitch a multiple of 8
+    a = rnd(M, K, dev=dev).to(BF)
+    b = rnd(K, N, dev=dev, seed=1).to(BF)
+    at, bt = a.t().contiguous(), b.t().contiguous()  # (kept alive: a MatT holds a raw pointer)
+    A = kern.mat_plain(a, K, 1, kfast=1) if akf else kern.mat_plain(at, 1, M, kfast=0)
+    B = kern.mat_plain(bt, 1, K, kfast=1) if bkf else kern.mat_plain(b, N, 1, kfast=0)
+    y = torch.empty(M, N, device=dev, dtype=BF)
+    kern.gemm(A, B, y, M, N, K, scr=N, scc=1)
+    if not kern._lib.is_hostsim():
+        assert kern.last_gemm_kernel().startswith("gemm_ring_stream_kernel"), kern.last_gemm_kernel()
+    ref = a.float() @ b.float()
+    torch.testing.assert_close(y.float().cpu(), ref.cpu(), rtol=2e-2, atol=2e-2 * ref.abs().max().item())
+    assert (y.float() - ref).abs().mean().item() < 4e-3 * ref.abs().mean().item()
+
+
+def test_ring_stream_batched_and_scaled_epilogues(dev):
+    BF = torch.bfloat16
+    # per-image 1x1 conv: W [M, K] . X_b [K, HW], bias on rows, residual
+    nb, M, K, HW = 16, 64, 64, 3136
+    w, x = rnd(M, K, dev=dev).to(BF), rnd(nb, K, HW, dev=dev, seed=1).to(BF)
+    bias, R = rnd(M, dev=dev, seed=2), rnd(nb, M, HW, dev=dev, seed=3).to(BF)
+    y = torch.empty(nb, M, HW, device=dev, dtype=BF)
+    kern.gemm(kern.mat_plain(w, K, 1, kfast=1), kern.mat_plain(x, HW, 1, sb=K * HW), y, M, HW, K, scr=HW, scc=1, scb=M * HW,
+              nbatch=nb, bias=bias, bias_on_row=True, R=R, srb=M * HW, srr=HW, src=1)
+    ref = torch.matmul(w.float(), x.float()) + bias[None, :, None] + R.float()
+    assert (y.float() - ref).abs().mean().item() < 4e-3 * ref.abs().mean().item()
+    # flat Linear with the per-sample scale looked up by row
+    Bt, n, N2, K2 = 8, 784, 128, 128
+    xt, w2 = rnd(Bt, n, K2, dev=dev).to(BF), rnd(N2, K2, dev=dev, seed=1).to(BF)
+    b2, R2, bs = rnd(N2, dev=dev, seed=2), rnd(Bt, n, N2, dev=dev, seed=3).to(BF), rnd(Bt, dev=dev, seed=4)
+    y2 = torch.empty(Bt, n, N2, device=dev, dtype=BF)
+    kern.gemm(kern.mat_plain(xt, K2, 1, kfast=1), kern.mat_plain(w2, 1, K2, kfast=1), y2, Bt * n, N2, K2, scr=N2, scc=1, bias=b2,
+              bscale=bs, bscale_rows=n, R=R2, srr=N2, src=1)
+    ref2 = (F.linear(xt.float(), w2.float(), b2)) * bs[:, None, None] + R2.float()
+    assert (y2.float() - ref2).abs().mean().item() < 4e-3 * ref2.abs().mean().item()
