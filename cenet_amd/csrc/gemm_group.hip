@@ -404,6 +404,12 @@ static int wgrad_group_impl(const cenet_wgrad_prob_t* p, int n, float* ws, long 
   if (!p || n <= 0 || phase < 0 || phase > 2) return CENET_EINVAL;
   for (int i = 0; i < n; ++i)
     if (!grp_ok(p[i])) return p[i].akf != p[i].bkf ? CENET_EUNSUPPORTED : CENET_EINVAL;
+  {
+    // dry pass: the whole call is planned and its workspace need checked BEFORE the first launch (the launches add into the
+    // gradient arena: an error after some of them would leave the gradients half-updated)
+    const long need = cenet_wgrad_group_ws_floats(p, n);
+    if (need > ws_floats || (need > 0 && !ws)) return CENET_EINVAL;
+  }
   long ws_used = 0;  // floats handed out so far: every launch gets its own stretch of the workspace
   int rc = CENET_OK;
   grp_for_each_launch(p, n, [&](const cenet_wgrad_prob_t* sel, int m, int o, GrpTile t) {

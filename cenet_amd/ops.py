@@ -268,8 +268,11 @@ def wgrad_pending() -> int:
     return sum(len(st.items) + len(st.keep) + len(st.ln_items) for st in _WG.values())
 
 
-def _wgrad_deferrable(M: int, N: int, *ts) -> bool:
-    return bool(_WgradCfg.grouping and M >= 48 and N >= 48 and all(t.dtype == torch.bfloat16 for t in ts))
+def _wgrad_deferrable(M: int, N: int, *ts, K: int = 1, nkb: int = 1) -> bool:
+    """the grouped launch takes this problem (the limits of gemm_group.hip's grp_ok: 16-bit M / N / K-batch counts, K < 2^28;
+    anything else keeps its own per-layer GEMM launch instead of failing the whole end-of-backward flush)"""
+    return bool(_WgradCfg.grouping and 48 <= M <= 65535 and 48 <= N <= 65535 and 1 <= nkb <= 65535 and K < (1 << 28)
+                and all(t.dtype == torch.bfloat16 and t.numel() < (1 << 31) for t in ts))
 
 
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
@@ -407,7 +410,7 @@ class LinearFn(Function):
             gs = torch.empty_like(g)
             kern.scale_batch(g, bscale, gs, x.shape[0], g.numel() // x.shape[0])
         dW, db = grad_buf(Wp), grad_buf(bp)
-        if dW is not None and _wgrad_deferrable(N, K, gs, x):
+        if dW is not None and _wgrad_deferrable(N, K, gs, x, K=R):
             # recorded, not launched: reduced with the other weight gradients of the segment by one grouped launch
             _wgrad_defer(gs, 0, N, 0, x, 0, K, 0, dW, 0, db, N, K, R, 1, 0)
         elif dW is not None or db is not None:
@@ -465,7 +468,7 @@ class MultiLinearFn(Function):
         esz = gs[0].element_size()
         joint = all(g.data_ptr() == gs[0].data_ptr() + j * R * N * esz for j, g in enumerate(gs))
         dW = grad_buf(Wp)
-        if dW is not None and _wgrad_deferrable(N, K, x, *gs):
+        if dW is not None and _wgrad_deferrable(N, K, x, *gs, K=R):
             for j, g in enumerate(gs):
                 _wgrad_defer(g, 0, N, 0, x, 0, K, 0, dW, j * N * K, None, N, K, R, 1, 0)
         elif dW is not None:
@@ -543,7 +546,7 @@ class Conv1x1Fn(Function):
         Cout = W.shape[0]
         dW, db = grad_buf(Wp), grad_buf(bp)
         if (dW is not None and not ctx.c1 and not (ctx.fewout and kern.pw_fewout_wgrad_supported(Cin, Cout))
-                and _wgrad_deferrable(Cout, Cin, g, x)):
+                and _wgrad_deferrable(Cout, Cin, g, x, K=HW, nkb=B)):
             _wgrad_defer(g, 0, HW, Cout * HW, x, 0, HW, Cin * HW, dW, 0, db, Cout, Cin, HW, B, 1)
         elif dW is not None or db is not None:
             with _wgrad_side(g, x, returned=(g if ctx.has_resid else None)):
@@ -989,7 +992,7 @@ class PvtMlpFn(Function):
 
         def wgrad(gy, xin, Wp, bp, Nn, K):
             dW, db = grad_buf(Wp), grad_buf(bp)
-            if dW is not None and _wgrad_deferrable(Nn, K, gy, xin):
+            if dW is not None and _wgrad_deferrable(Nn, K, gy, xin, K=R):
                 _wgrad_defer(gy, 0, Nn, 0, xin, 0, K, 0, dW, 0, db, Nn, K, R, 1, 0)
             elif dW is not None or db is not None:
                 with _wgrad_side(gy, xin):
