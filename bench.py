@@ -123,26 +123,24 @@ class _Trace:
         tr = self
 
         def wgrad_group(probs, device, **kw):
-            """the grouped weight gradients, one call per kernel launch: the problems of one orientation and tile class in chunks
-            of 56 (the partition the library makes itself, gemm_group.hip grp_for_each_launch), K-slice kernel and fold kernel
-            bracketed separately (phases 1 / 2)"""
-            for kf in (0, 1):
-                for cls, tile in ((0, "64, 64, 4"), (1, "128, 128, 2")):
-                    sel = [t for t in probs if t[12] == kf and int(t[8] >= 128 and t[9] >= 128) == cls]
-                    for c in range(0, len(sel), 56):
-                        chunk = sel[c:c + 56]
-                        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-                        ev[0].record()
-                        need = tr._saved["wgrad_group"](chunk, device, phases=(1, 2),
-                                                        between=lambda: (ev[1].record(), ev[2].record()))
-                        ev[3].record()
-                        fl = sum(2.0 * t[8] * t[9] * t[10] * t[11] for t in chunk)
-                        # operands once (bf16) + the fp32 gradient tile read and written once
-                        by = sum(2.0 * t[10] * t[11] * (t[8] + t[9]) + 8.0 * t[8] * t[9] for t in chunk)
-                        b = "true" if kf else "false"
-                        tr.rows.append((f"gemm_group_kernel<{b}, {b}, {tile}>", ev[0], ev[1], fl, by))
-                        if need:  # partial tiles written by the slices and read back by the fold
-                            tr.rows.append((f"gemm_group_fold_kernel<{tile.rsplit(',', 1)[0]}>", ev[2], ev[3], 0.0, 2.0 * 4.0 * need))
+            """the grouped weight gradients, one call per kernel launch — the partition is the LIBRARY's (kern.wgrad_group_plan:
+            launch index and tile per problem), K-slice kernel and fold kernel bracketed separately (phases 1 / 2)"""
+            plan = kern.wgrad_group_plan(probs)
+            for li in sorted({p[0] for p in plan}):
+                chunk = [t for t, p in zip(probs, plan) if p[0] == li]
+                _, bm, bn, ns = next(p for p in plan if p[0] == li)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                ev[0].record()
+                need = tr._saved["wgrad_group"](chunk, device, phases=(1, 2),
+                                                between=lambda: (ev[1].record(), ev[2].record()))
+                ev[3].record()
+                fl = sum(2.0 * t[8] * t[9] * t[10] * t[11] for t in chunk)
+                # operands once (bf16) + the fp32 gradient tile read and written once
+                by = sum(2.0 * t[10] * t[11] * (t[8] + t[9]) + 8.0 * t[8] * t[9] for t in chunk)
+                b = "true" if chunk[0][12] else "false"
+                tr.rows.append((f"gemm_group_kernel<{b}, {b}, {bm}, {bn}, {ns}>", ev[0], ev[1], fl, by))
+                if need:  # partial tiles written by the slices and read back by the fold
+                    tr.rows.append((f"gemm_group_fold_kernel<{bm}, {bn}>", ev[2], ev[3], 0.0, 2.0 * 4.0 * need))
 
         def gemm(A, B, Cout, M, N, K, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -398,6 +398,30 @@ extern "C" long cenet_wgrad_group_ws_floats(const cenet_wgrad_prob_t* p, int n) 
   return floats;
 }
 
+/* The partition a cenet_wgrad_group_bf16 call makes of its problems: launch[i] = index of the grouped launch problem i goes to (in
+ * the order the launches are issued), bm / bn / ns [i] = that launch's tile and ring depth (kernel instance
+ * gemm_group_kernel<akf, akf, bm, bn, ns>).  For measurement code that brackets the launches one by one (bench.py). */
+extern "C" int cenet_wgrad_group_plan(const cenet_wgrad_prob_t* p, int n, int* launch, int* bm, int* bn, int* ns) {
+  if (!p || n <= 0 || !launch || !bm || !bn || !ns) return CENET_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    if (!grp_ok(p[i])) return CENET_EUNSUPPORTED;
+    launch[i] = -1;
+  }
+  int li = 0;
+  for (int o = 0; o < 2; ++o)
+    for (int c = 0; c < 2; ++c) {
+      int m = 0;
+      const GrpTile t = grp_tile(c);
+      for (int i = 0; i < n; ++i) {
+        if ((p[i].akf != 0) != (o != 0) || grp_class(p[i]) != c) continue;
+        launch[i] = li, bm[i] = t.bm, bn[i] = t.bn, ns[i] = t.ns;
+        if (++m == GRP_MAXP) ++li, m = 0;
+      }
+      if (m) ++li;
+    }
+  return CENET_OK;
+}
+
 // phase 0: the whole reduction; 1: the K-slice launches only; 2: the fold launches only (1 then 2 on the same arguments = 0;
 // lets a profiler-free measurement bracket the two kernels separately, bench.py)
 static int wgrad_group_impl(const cenet_wgrad_prob_t* p, int n, float* ws, long ws_floats, int phase, hipStream_t stream) {

@@ -169,6 +169,15 @@ def wgrad_group(probs, device, phases=(0,), between=None):
     return need
 
 
+def wgrad_group_plan(probs):
+    """[(launch index, bm, bn, ns)] per problem: the partition kern.wgrad_group makes (the library's own, gemm_group.hip)"""
+    n = len(probs)
+    arr = _wgrad_array(probs)
+    out = [(C.c_int * n)() for _ in range(4)]
+    _lib.check(_lib.lib().cenet_wgrad_group_plan(arr, n, *out), "cenet_wgrad_group_plan")
+    return [tuple(int(o[i]) for o in out) for i in range(n)]
+
+
 def last_gemm_kernel() -> str:
     """name of the kernel instance the last gemm() on this thread launched (as rocprofv3 prints it); measurement aid"""
     f = _lib.lib().cenet_gemm_last_kernel

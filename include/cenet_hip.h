@@ -110,6 +110,9 @@ long cenet_wgrad_group_ws_floats(const cenet_wgrad_prob_t* p, int n);
 int cenet_wgrad_group_bf16(const cenet_wgrad_prob_t* p, int n, float* ws, long ws_floats, cenet_stream_t stream);
 /* Measurement aid: the same reduction issued in two calls — phase 1 launches the K-slice kernels only, phase 2 the fold
  * kernels only (phase 0 = cenet_wgrad_group_bf16) — so that bench.py can bracket the two kernel symbols with HIP events. */
+/* the partition cenet_wgrad_group_bf16 makes of its problems: launch[i] = index of the grouped launch problem i goes to (issue
+ * order), bm / bn / ns [i] = that launch's tile and ring depth (gemm_group_kernel<akf, akf, bm, bn, ns>) */
+int cenet_wgrad_group_plan(const cenet_wgrad_prob_t* p, int n, int* launch, int* bm, int* bn, int* ns);
 int cenet_wgrad_group_phase_bf16(const cenet_wgrad_prob_t* p, int n, float* ws, long ws_floats, int phase, cenet_stream_t stream);
 
 /* Direct ("LDS halo") stride-1 same-padded convolution on bf16 tensors (throughput mode, conv_direct.hip): replaces

@@ -175,3 +175,25 @@ def test_a_backward_that_raises_does_not_poison_the_next_one(dev):
     assert not ops.wgrad_pending()
     for r, p in zip(ref, (W1, W2)):
         assert torch.equal(r, p.grad)
+
+
+def test_group_plan_is_the_librarys_partition(dev):
+    """bench.py brackets the grouped launches one by one: the partition comes from the library (cenet_wgrad_group_plan), not from
+    constants copied into the bench — problems of one launch share orientation and tile, no launch exceeds 56 problems, launch
+    indices are dense and ordered like the library issues them (row-fast before k-fast, skinny tiles before 128 x 128)."""
+    t = torch.zeros(8, dtype=BF, device=dev)
+    w = torch.zeros(8, device=dev)
+    probs = []
+    for i in range(130):
+        M, N = (64, 320) if i % 3 == 0 else (256, 512)
+        probs.append((t.data_ptr(), t.data_ptr(), w.data_ptr(), None, N, M, 0, 0, M, N, 64, 1, i % 2))
+    plan = kern.wgrad_group_plan(probs)
+    assert sorted({p[0] for p in plan}) == list(range(max(p[0] for p in plan) + 1))
+    for li in {p[0] for p in plan}:
+        members = [(pr, pl) for pr, pl in zip(probs, plan) if pl[0] == li]
+        assert len(members) <= 56
+        assert len({pr[12] for pr, _ in members}) == 1 and len({pl[1:] for _, pl in members}) == 1
+        bm, bn, _ = members[0][1][1:]
+        assert all((min(pr[8], pr[9]) >= 128) == (bm == 128 and bn == 128) for pr, _ in members)
+    order = [(probs[i][12], plan[i][1]) for i in sorted(range(len(plan)), key=lambda i: plan[i][0])]
+    assert order == sorted(order)
