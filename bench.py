@@ -116,6 +116,8 @@ class _Trace:
 
     def __init__(self):
         self.rows = []  # (name, e0, e1, flops, bytes)
+        self.valu = {}  # attention kernels: vector-issue cycles (per SIMD-lane-group, see work()) summed over the bracketed calls
+        self.valu_cycles_last = 0.0
 
     def install(self):
         from cenet_amd import kern
@@ -165,6 +167,12 @@ class _Trace:
             else:  # differential pairs: 2H softmax heads of dim hd over H value heads of dim 2 hd
                 fl = 2.0 * a.B * 2 * a.H * a.N * a.N * 3 * a.hd
                 el = a.B * a.N * (2 * a.H * a.hd * 2 + a.H * 2 * a.hd + 2 * a.H * 2 * a.hd)
+            # vector-instruction ISSUE cycles per softmax score (MI355X_MICROARCH.md issue costs: 4 per wave64 VALU instruction, 8
+            # per transcendental; 64 scores per instruction).  Forward: scale / subtract (fma 4) + exp (8) + row-sum add (4) + half
+            # a max3 (2) + half a cvt_pk (2) = 20.  Backward, per kernel (dQ and dK/dV each recompute p): fma + exp (12) +
+            # dS = p (dP - delta) (8) + two half cvt_pk (4) = 24, two kernels = 48.
+            scores = a.B * a.H * a.Nq * a.Nk if hasattr(a, "Nq") else a.B * a.H * a.N * a.N * (1 if a.hd == 64 else 2)
+            tr.valu_cycles_last = scores * (48.0 if backward else 20.0) / 64.0
             return (2.5 * fl, 2.0 * el * 2) if backward else (fl, el * 2.0)
 
         def wrap(name, label, backward):
@@ -175,7 +183,9 @@ class _Trace:
                 e1.record()
                 bw = backward if backward is not None else bool(kw.get("backward", a[1] if len(a) > 1 else False))
                 fl, by = work(a[0], bw)
-                tr.rows.append((label(*a, **kw), e0, e1, fl, by))
+                lab = label(*a, **kw)
+                tr.rows.append((lab, e0, e1, fl, by))
+                tr.valu[lab] = tr.valu.get(lab, 0.0) + tr.valu_cycles_last
                 return r
             return f
         kern.gemm = gemm
@@ -248,9 +258,10 @@ def roofline_block(body, steps=2):
         return kv[1][0] * (0.5 if "+" in kv[0] else 1.0)
     peak = peak_tflops()
     traffic_rec = {}
-    for f in ("r03_traffic.json", "r02_traffic.json"):
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):  # the latest round's PMC passes
         try:
-            traffic_rec = json.load(open(os.path.join(ROOT, "profiles", f)))
+            traffic_rec = json.load(open(f))
             break
         except (OSError, ValueError):
             continue
@@ -272,6 +283,13 @@ def roofline_block(body, steps=2):
                             "frac": round(a / PEAK_HBM_GBS, 4)})
             out["algorithmic_bytes_per_launch"] = int(by / max(n, 1))
             out["algorithmic_flops_per_launch"] = int(fl / max(n, 1))
+        if name in tr.valu:
+            # the pair / flash attention kernels are bound by vector-instruction ISSUE, not by the matrix pipe (DESIGN.md section 8,
+            # profiles/r04_attn_sq_counters.txt): graded against that roof too — issue cycles of the softmax algebra alone over
+            # 1024 SIMDs at the 2.4 GHz maximum clock
+            roof_ms = tr.valu[name] / steps / (1024 * 2.4e9) * 1e3
+            out["valu_issue"] = {"bound": "valu", "roof_ms_per_step": round(roof_ms, 4), "frac": round(roof_ms / ms, 4),
+                                 "peak": "1024 SIMDs x 1 wave64 vector instruction per 4 cycles (8 per transcendental) x 2.4 GHz"}
         rec = traffic_rec.get(name)
         # HBM bytes per LAUNCH from the PMC passes of tools/refresh_profiles.sh (2 x FETCH_SIZE + WRITE_SIZE, separate passes);
         # a committed measurement of this build on another box of the pool, not taken in this run
@@ -293,6 +311,7 @@ def roofline_block(body, steps=2):
     # the grouped weight-gradient launches (round 2's dominant kernel family, now ~10 launches per step), whatever their rank
     out["weight_gradient_kernels"] = [entry(k, *v) for k, v in ranked if k.startswith("gemm_group")]
     out["next_kernels_ms_per_step"] = {k: round(v[0], 3) for k, v in ranked[1:6]}
+    out["attention_kernels"] = [entry(k, *v) for k, v in ranked if k in tr.valu]
     return out
 
 
