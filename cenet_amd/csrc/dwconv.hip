@@ -473,12 +473,12 @@ __device__ __forceinline__ void dwp_stage(const DwPlaneArgs& a, float* tile, int
 }
 
 template <int ACT>
-__global__ __launch_bounds__(256) void dw3x3_nchw_plane_kernel(DwPlaneArgs a) {
+__device__ __forceinline__ void dwp_fwd_body(const DwPlaneArgs& a, int bx) {
   __shared__ float tile[DWP_MAX];
   __shared__ float wts[64][10];
   const int HW = a.H * a.W, nq = HW >> 2, d = a.dil;
   const int PWd = a.W + 2 * d, PS = (a.H + 2 * d) * PWd;
-  const int p0 = blockIdx.x * a.ppw;
+  const int p0 = bx * a.ppw;
   const int np = p0 + a.ppw <= a.BC ? a.ppw : a.BC - p0;
   for (int i = threadIdx.x; i < np * 10; i += 256) {
     const int pl = i / 10, t = i - pl * 10, c = (p0 + pl) % a.C;
@@ -516,12 +516,17 @@ __global__ __launch_bounds__(256) void dw3x3_nchw_plane_kernel(DwPlaneArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_plane_kernel(DwPlaneArgs a) {
+template <int ACT>
+__global__ __launch_bounds__(256) void dw3x3_nchw_plane_kernel(DwPlaneArgs a) {
+  dwp_fwd_body<ACT>(a, blockIdx.x);
+}
+
+__device__ __forceinline__ void dwp_wgrad_body(const DwPlaneArgs& a, int bx) {
   __shared__ float tile[DWP_MAX];
   __shared__ float sums[64][10];
   const int HW = a.H * a.W, nq = HW >> 2, d = a.dil;
   const int PWd = a.W + 2 * d, PS = (a.H + 2 * d) * PWd;
-  const int p0 = blockIdx.x * a.ppw;
+  const int p0 = bx * a.ppw;
   const int np = p0 + a.ppw <= a.BC ? a.ppw : a.BC - p0;
   for (int i = threadIdx.x; i < np * 10; i += 256) sums[i / 10][i % 10] = 0.f;
   dwp_stage<2>(a, tile, p0, np, PS, PWd);
@@ -576,6 +581,27 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_plane_kernel(DwPlaneArgs
     if (t < 9) atomicAdd(&a.dw[c * 9 + t], sums[pl][t]);
     else if (a.db) atomicAdd(&a.db[c], sums[pl][9]);
   }
+}
+
+__global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_plane_kernel(DwPlaneArgs a) { dwp_wgrad_body(a, blockIdx.x); }
+
+// ---- several depthwise convs in ONE launch (round 4): the three dilated SepConvBN branches of a CFAM block (cfam.py:208-212) read
+// channel slices of one tensor with different dilations; as three launches of 2 - 25 MB each they sat at their fill / drain
+// latency (15 - 17 us apiece, forward, data gradient and weight gradient alike).  blockIdx.y selects the branch's argument set;
+// workgroups beyond a branch's own plane count leave at once.
+#define DWP_MULTI_MAX 4
+struct DwPlaneMulti {
+  DwPlaneArgs a[DWP_MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void dw3x3_nchw_plane_multi_kernel(DwPlaneMulti m) {
+  const DwPlaneArgs& a = m.a[blockIdx.y];
+  if ((int)blockIdx.x * a.ppw >= a.BC) return;
+  dwp_fwd_body<ACT_NONE>(a, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_plane_multi_kernel(DwPlaneMulti m) {
+  const DwPlaneArgs& a = m.a[blockIdx.y];
+  if ((int)blockIdx.x * a.ppw >= a.BC) return;
+  dwp_wgrad_body(a, blockIdx.x);
 }
 
 // planes per workgroup: as many padded planes as the tile holds, at most 64, and at least ~1024 workgroups where possible
@@ -965,6 +991,60 @@ static int dwconv3x3_wgrad_nchw_acc_impl(const T* x, long sxb, const T* dy, long
 CENET_TWIN(dwconv3x3_wgrad_nchw_acc, (const T* x, long sxb, const T* dy, long sgb, float* dw_acc, float* dbias_acc, int B, int C,
                                       int H, int W, int dil, hipStream_t stream),
            (x, sxb, dy, sgb, dw_acc, dbias_acc, B, C, H, W, dil, stream))
+
+/* n <= 4 bias-free, activation-free depthwise 3x3 convs (forward, or data gradient with flip = 1) of bf16 NCHW channel slices in ONE
+ * launch: branch i reads x[i] (batch stride sxb[i]), writes y[i] (syb[i]), C[i] channels, dilation dil[i]; all on H x W maps of B
+ * images.  CENET_EUNSUPPORTED unless every branch takes the plane-in-LDS path (H W % 4 == 0, the padded plane fits the tile). */
+extern "C" int cenet_dwconv3x3_nchw_multi_bf16(const bf16_t* const* x, const long* sxb, const float* const* w, bf16_t* const* y,
+                                               const long* syb, const int* C, const int* dil, int n, int B, int H, int W, int flip,
+                                               hipStream_t stream) {
+  if (n < 1 || n > DWP_MULTI_MAX || !x || !sxb || !w || !y || !syb || !C || !dil || B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+  if (((long)H * W) % 4 != 0) return CENET_EUNSUPPORTED;
+  DwPlaneMulti m;
+  unsigned gx = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!x[i] || !w[i] || !y[i] || C[i] <= 0 || dil[i] <= 0) return CENET_EINVAL;
+    if (((sxb[i] | syb[i]) & 3) != 0 || !quad_aligned<bf16_t>(x[i]) || !quad_aligned<bf16_t>(y[i])) return CENET_EUNSUPPORTED;
+    const int ppw = dwp_ppw(B * C[i], H, W, dil[i]);
+    if (ppw <= 0) return CENET_EUNSUPPORTED;
+    DwPlaneArgs& p = m.a[i];
+    p.x = x[i]; p.sxb = sxb[i]; p.w = w[i]; p.bias = nullptr; p.y = y[i]; p.syb = syb[i]; p.a = nullptr; p.sab = 0;
+    p.dy = nullptr; p.sgb = 0; p.dw = p.db = nullptr;
+    p.BC = B * C[i]; p.C = C[i]; p.H = H; p.W = W; p.dil = dil[i]; p.flip = flip; p.act = ACT_NONE; p.ppw = ppw; p.slope = 0.f;
+    const unsigned g = (unsigned)cdiv(B * C[i], ppw);
+    if (g > gx) gx = g;
+  }
+  for (int i = n; i < DWP_MULTI_MAX; ++i) m.a[i] = m.a[0];
+  CENET_LAUNCH(dw3x3_nchw_plane_multi_kernel, dim3(gx, n), dim3(256), stream, m);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+/* the weight gradients of the same n branches in ONE launch: dw[i][C[i], 9] += dy[i] (*) x[i] */
+extern "C" int cenet_dwconv3x3_wgrad_nchw_multi_bf16(const bf16_t* const* x, const long* sxb, const bf16_t* const* dy, const long* sgb,
+                                                     float* const* dw_acc, const int* C, const int* dil, int n, int B, int H, int W,
+                                                     hipStream_t stream) {
+  if (n < 1 || n > DWP_MULTI_MAX || !x || !sxb || !dy || !sgb || !dw_acc || !C || !dil || B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+  if (((long)H * W) % 4 != 0) return CENET_EUNSUPPORTED;
+  DwPlaneMulti m;
+  unsigned gx = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!x[i] || !dy[i] || !dw_acc[i] || C[i] <= 0 || dil[i] <= 0) return CENET_EINVAL;
+    if (((sxb[i] | sgb[i]) & 3) != 0 || !quad_aligned<bf16_t>(x[i]) || !quad_aligned<bf16_t>(dy[i])) return CENET_EUNSUPPORTED;
+    const int ppw = dwp_ppw(B * C[i], H, W, dil[i]);
+    if (ppw <= 0) return CENET_EUNSUPPORTED;
+    DwPlaneArgs& p = m.a[i];
+    p.x = x[i]; p.sxb = sxb[i]; p.w = nullptr; p.bias = nullptr; p.y = p.a = nullptr; p.syb = p.sab = 0;
+    p.dy = dy[i]; p.sgb = sgb[i]; p.dw = dw_acc[i]; p.db = nullptr;
+    p.BC = B * C[i]; p.C = C[i]; p.H = H; p.W = W; p.dil = dil[i]; p.flip = 0; p.act = 0; p.ppw = ppw; p.slope = 0.f;
+    const unsigned g = (unsigned)cdiv(B * C[i], ppw);
+    if (g > gx) gx = g;
+  }
+  for (int i = n; i < DWP_MULTI_MAX; ++i) m.a[i] = m.a[0];
+  CENET_LAUNCH(dw3x3_wgrad_nchw_plane_multi_kernel, dim3(gx, n), dim3(256), stream, m);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
 
 template <typename T>
 static int dwconv3x3_wgrad_tok_acc_impl(const T* x, const T* dy, float* dw_acc, float* dbias_acc, int B, int C, int H, int W,

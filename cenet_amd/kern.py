@@ -410,6 +410,56 @@ def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none",
           B, Cn, H, W, dil, int(flip), ACT[act], float(slope))
 
 
+
+_NO_DW_MULTI = __import__("os").environ.get("CENET_DW_NO_MULTI") is not None  # measurement aid: the branches one launch each
+
+
+def _ptr_arr(vals):
+    return (C.c_void_p * len(vals))(*vals)
+
+
+def dw_nchw_multi(branches, B, H, W, flip):
+    """branches: [(x, x_off, sxb, w, y, y_off, syb, C, dil)] — up to 4 bias-free depthwise 3x3 convs (or their data gradients, flip)
+    of bf16 NCHW channel slices in ONE launch.  Returns False when the library has no single-launch form for them (the caller
+    then launches them one by one)."""
+    n = len(branches)
+    if n < 1 or n > 4 or _NO_DW_MULTI or any(not is_bf16(b[0]) or not is_bf16(b[4]) for b in branches):
+        return False
+    _chk(*[b[0] for b in branches], *[b[3] for b in branches], *[b[4] for b in branches])
+    xs = _ptr_arr([b[0].data_ptr() + 2 * b[1] for b in branches])
+    ws = _ptr_arr([b[3].data_ptr() for b in branches])
+    ys = _ptr_arr([b[4].data_ptr() + 2 * b[5] for b in branches])
+    sx = (C.c_long * n)(*[b[2] for b in branches])
+    sy = (C.c_long * n)(*[b[6] for b in branches])
+    cs = (C.c_int * n)(*[b[7] for b in branches])
+    ds = (C.c_int * n)(*[b[8] for b in branches])
+    rc = _lib.lib().cenet_dwconv3x3_nchw_multi_bf16(xs, sx, ws, ys, sy, cs, ds, n, B, H, W, int(flip), stream())
+    if rc == 2:  # CENET_EUNSUPPORTED
+        return False
+    _lib.check(rc, "cenet_dwconv3x3_nchw_multi_bf16")
+    return True
+
+
+def dw_wgrad_nchw_multi(branches, B, H, W):
+    """branches: [(x, x_off, sxb, dy, g_off, sgb, dw, C, dil)]: dw[i] += dy[i] (*) x[i] for up to 4 branches in ONE launch; False
+    when unsupported"""
+    n = len(branches)
+    if n < 1 or n > 4 or _NO_DW_MULTI or any(not is_bf16(b[0]) or not is_bf16(b[3]) for b in branches):
+        return False
+    _chk(*[b[0] for b in branches], *[b[3] for b in branches], *[b[6] for b in branches])
+    xs = _ptr_arr([b[0].data_ptr() + 2 * b[1] for b in branches])
+    gs = _ptr_arr([b[3].data_ptr() + 2 * b[4] for b in branches])
+    dws = _ptr_arr([b[6].data_ptr() for b in branches])
+    sx = (C.c_long * n)(*[b[2] for b in branches])
+    sg = (C.c_long * n)(*[b[5] for b in branches])
+    cs = (C.c_int * n)(*[b[7] for b in branches])
+    ds = (C.c_int * n)(*[b[8] for b in branches])
+    rc = _lib.lib().cenet_dwconv3x3_wgrad_nchw_multi_bf16(xs, sx, gs, sg, dws, cs, ds, n, B, H, W, stream())
+    if rc == 2:
+        return False
+    _lib.check(rc, "cenet_dwconv3x3_wgrad_nchw_multi_bf16")
+    return True
+
 def dw_tok(x, w, bias, y, a, B, Cn, H, W, flip, act="none", slope=0.0):
     _chk(x, w, bias, y, a)
     _call("cenet_dwconv3x3_tok_f32", x, w, bias, y, a, B, Cn, H, W, int(flip), ACT[act], float(slope))

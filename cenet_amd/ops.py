@@ -1603,14 +1603,19 @@ class SplitDWFn(Function):
         outs, lo = [], 0
         used = sum(sizes)
         joint = _act((B, used, H, Wd), x) if joined else None  # joined: the groups' outputs as ONE [B, sum sizes, H, W] tensor
+        plan = []  # (x, x_off, sxb, w, y, y_off, syb, C, dil) per branch
         for c, dil, w in zip(sizes, dils, ws):
             if joined:
-                kern.dw_nchw(x, Cn * HW, w, None, joint, used * HW, None, 0, B, c, H, Wd, dil, 0, x_off=lo * HW, y_off=lo * HW)
+                plan.append((x, lo * HW, Cn * HW, w, joint, lo * HW, used * HW, c, dil))
             else:
                 u = _act((B, c, H, Wd), x)
-                kern.dw_nchw(x, Cn * HW, w, None, u, c * HW, None, 0, B, c, H, Wd, dil, 0, x_off=lo * HW)
+                plan.append((x, lo * HW, Cn * HW, w, u, 0, c * HW, c, dil))
                 outs.append(u)
             lo += c
+        # the branches in ONE launch where the library has that form (bf16 planes that fit its LDS tile), else one by one
+        if not (_bf(x) and kern.dw_nchw_multi(plan, B, H, Wd, 0)):
+            for (xx, xo, sxb, w, y, yo, syb, c, dil) in plan:
+                kern.dw_nchw(xx, sxb, w, None, y, syb, None, 0, B, c, H, Wd, dil, 0, x_off=xo, y_off=yo)
         if joined:
             outs = [joint]
         rest = None
@@ -1635,17 +1640,25 @@ class SplitDWFn(Function):
         dx = torch.empty_like(x) if full else kern.zero_(torch.empty_like(x))
         gj = _c(gs[0]) if joined and gs[0] is not None else None
         lo = 0
+        dplan, wplan = [], []
         for j, (c, dil, w, wp) in enumerate(zip(sizes, dils, ws, ctx.refs)):
             g = gj if joined else gs[j]
             if g is not None:
                 g = _c(g)
                 sgb, g_off = (used * HW, lo * HW) if joined else (c * HW, 0)
-                kern.dw_nchw(g, sgb, w, None, dx, Cn * HW, None, 0, B, c, H, Wd, dil, 1, x_off=g_off, y_off=lo * HW)
+                dplan.append((g, g_off, sgb, w, dx, lo * HW, Cn * HW, c, dil))
                 dw = grad_buf(wp)
                 if dw is not None:
-                    with _wgrad_side(g, x):
-                        kern.dw_wgrad_nchw(x, Cn * HW, g, sgb, dw, None, B, c, H, Wd, dil, x_off=lo * HW, g_off=g_off)
+                    wplan.append((x, lo * HW, Cn * HW, g, g_off, sgb, dw, c, dil))
             lo += c
+        if dplan and not (_bf(x) and kern.dw_nchw_multi(dplan, B, H, Wd, 1)):
+            for (g, go, sgb, w, y, yo, syb, c, dil) in dplan:
+                kern.dw_nchw(g, sgb, w, None, y, syb, None, 0, B, c, H, Wd, dil, 1, x_off=go, y_off=yo)
+        if wplan:
+            with _wgrad_side(x, *[b[3] for b in wplan]):
+                if not (_bf(x) and kern.dw_wgrad_nchw_multi(wplan, B, H, Wd)):
+                    for (xx, xo, sxb, g, go, sgb, dw, c, dil) in wplan:
+                        kern.dw_wgrad_nchw(xx, sxb, g, sgb, dw, None, B, c, H, Wd, dil, x_off=xo, g_off=go)
         if used < Cn and len(gs) > nout and gs[nout] is not None:
             kern.copy_batched(_c(gs[nout]), (Cn - used) * HW, dx, Cn * HW, B, (Cn - used) * HW, y_off=used * HW)
         return (dx, None, None, None) + (None,) * n

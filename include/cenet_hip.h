@@ -317,6 +317,17 @@ int cenet_pvt_mlp_bwd_bf16(const unsigned short* g, const float* bscale, const u
                            float* dwd_acc, float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* db2_acc,
                            float* ws, int B, int H, int W, int C, int HD, cenet_stream_t stream);
 
+/* n <= 4 bias-free, activation-free depthwise 3x3 convs (flip = 1: their data gradients) / weight gradients of bf16 NCHW channel slices
+ * in ONE launch — the three dilated SepConvBN branches of a CFAM block (cfam.py:208-212, blocks.py:142-150).  Branch i: x[i] (batch
+ * stride sxb[i]) -> y[i] (syb[i]), C[i] channels, dilation dil[i], all on H x W maps of B images.  CENET_EUNSUPPORTED unless every
+ * branch takes the plane-in-LDS path (H W % 4 == 0 and the padded plane fits): the caller then launches the branches one by one. */
+int cenet_dwconv3x3_nchw_multi_bf16(const unsigned short* const* x, const long* sxb, const float* const* w, unsigned short* const* y,
+                                    const long* syb, const int* C, const int* dil, int n, int B, int H, int W, int flip,
+                                    cenet_stream_t stream);
+int cenet_dwconv3x3_wgrad_nchw_multi_bf16(const unsigned short* const* x, const long* sxb, const unsigned short* const* dy,
+                                          const long* sgb, float* const* dw_acc, const int* C, const int* dil, int n, int B, int H,
+                                          int W, cenet_stream_t stream);
+
 /* ---- resampling (resample.hip) ---------------------------------------------------------------------------- */
 /* aten::upsample_bilinear2d(+_backward) — dseb.py:67-68; cfam.py:217,232; blocks.py:210; out.py:74 */
 int cenet_bilinear_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, int Ho, int Wo,
