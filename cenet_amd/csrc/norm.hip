@@ -286,7 +286,9 @@ __global__ __launch_bounds__(256) void ln_bwd_v8_kernel(const bf16_t* __restrict
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dx,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C,
-                                                       int steps, const bf16_t* __restrict__ dx_add, float* __restrict__ part) {
+                                                       int steps, const bf16_t* __restrict__ dx_add, float* __restrict__ part,
+                                                       const float* __restrict__ bscale, int rows_per_sample,
+                                                       bf16_t* __restrict__ dxs) {
   constexpr int RPW = 64 / LPR;
   __shared__ float red[2][4][NP * LPR * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, l = lane % LPR;
@@ -346,6 +348,12 @@ __global__ __launch_bounds__(256) void ln_bwd_v8_kernel(const bf16_t* __restrict
             for (int e = 0; e < 8; ++e) o[e] += ad[e];
           }
           stv<8>(dx + row * C + c, o);
+          if (dxs) {  // the same rows times the per-sample (stochastic-depth) scale of the branch that produced this tensor
+            const float sc = bscale[row / rows_per_sample];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = sc * cenet_bf2f(cenet_f2bf(o[e]));
+            stv<8>(dxs + row * C + c, o);
+          }
         }
       }
     }
@@ -423,18 +431,23 @@ extern "C" int cenet_layernorm_bwd_part_rows(int rows, int C) {
 
 /* LayerNorm backward (+ residual gradient dx_add) on bf16 rows whose affine gradients go to a partial buffer instead of float
  * atomics: part[cenet_layernorm_bwd_part_rows(rows, C)][2 C]; fold with cenet_ln_fold_group. */
-extern "C" int cenet_layernorm_bwd_add_part_bf16(const bf16_t* dy, const bf16_t* x, const float* gamma, const float* mean,
-                                                 const float* rstd, const bf16_t* dx_add, bf16_t* dx, float* part, int rows, int C,
-                                                 hipStream_t stream) {
+/* ... and optionally dxs = bscale[row / rows_per_sample] * dx (bf16, rounded from the stored dx): the tensor this LayerNorm read was
+ * x + bscale_b * branch(...) (pvtv2.py:141-149 DropPath), so the branch's backward wants the scaled gradient — written here by the
+ * kernel that produces dx instead of a scale pass of its own.  bscale == NULL / dxs == NULL: plain. */
+extern "C" int cenet_layernorm_bwd_add_part_scaled_bf16(const bf16_t* dy, const bf16_t* x, const float* gamma, const float* mean,
+                                                        const float* rstd, const bf16_t* dx_add, bf16_t* dx, float* part,
+                                                        const float* bscale, int rows_per_sample, bf16_t* dxs, int rows, int C,
+                                                        hipStream_t stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !part || rows <= 0 || C <= 0) return CENET_EINVAL;
+  if ((bscale != nullptr) != (dxs != nullptr) || (bscale && rows_per_sample <= 0)) return CENET_EINVAL;
   if (C > 512 || (C & 7) != 0 ||
-      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)gamma) & 15) != 0))
+      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dx_add | (uintptr_t)gamma | (uintptr_t)dxs) & 15) != 0))
     return CENET_EUNSUPPORTED;
 #define CENET_LNP8(LPRv)                                                                                               \
   {                                                                                                                   \
     const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps, 1024);                                                    \
     CENET_LAUNCH((ln_bwd_v8_kernel<LPRv, 1>), dim3(cdiv(rows, rps * st)), dim3(256), stream, dy, x, gamma, mean, rstd, dx, \
-                 (float*)nullptr, (float*)nullptr, rows, C, st, dx_add, part);                                        \
+                 (float*)nullptr, (float*)nullptr, rows, C, st, dx_add, part, bscale, rows_per_sample, dxs);            \
   }
   if (C <= 64) CENET_LNP8(8)
   else if (C <= 128) CENET_LNP8(16)
@@ -443,6 +456,11 @@ extern "C" int cenet_layernorm_bwd_add_part_bf16(const bf16_t* dy, const bf16_t*
 #undef CENET_LNP8
   CENET_CHECK_LAUNCH();
   return CENET_OK;
+}
+extern "C" int cenet_layernorm_bwd_add_part_bf16(const bf16_t* dy, const bf16_t* x, const float* gamma, const float* mean,
+                                                 const float* rstd, const bf16_t* dx_add, bf16_t* dx, float* part, int rows, int C,
+                                                 hipStream_t stream) {
+  return cenet_layernorm_bwd_add_part_scaled_bf16(dy, x, gamma, mean, rstd, dx_add, dx, part, nullptr, 1, nullptr, rows, C, stream);
 }
 
 /* n <= 48 per launch (more: several launches): dg / db += column sums of the partial buffers */
@@ -520,7 +538,8 @@ static int layernorm_bwd_add_acc_impl(const T* dy, const T* x, const float* gamm
   {                                                                                                                   \
     const int rps = 4 * 64 / LPRv, st = ln_steps(rows, rps, 256);                                                     \
     CENET_LAUNCH((ln_bwd_v8_kernel<LPRv, NPv>), dim3(cdiv(rows, rps * st)), dim3(256), stream, (const bf16_t*)dy,      \
-                 (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma_acc, dbeta_acc, rows, C, st, (const bf16_t*)dx_add, (float*)nullptr); \
+                 (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma_acc, dbeta_acc, rows, C, st, (const bf16_t*)dx_add, (float*)nullptr, \
+                 (const float*)nullptr, 1, (bf16_t*)nullptr); \
   }
     if (C <= 64) CENET_LNB8(8, 1)
     else if (C <= 128) CENET_LNB8(16, 1)

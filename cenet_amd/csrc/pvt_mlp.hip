@@ -366,6 +366,8 @@ struct PvtBwdArgs {
   const float* mean;     // [B * N]
   const float* rstd;
   bf16_t* dx;            // [B, N, C]
+  const float* up_scale; // [B] or null: DropPath scale of the branch that produced x ...
+  bf16_t* dxs;           // ... and where K2 leaves up_scale_b * dx for that branch's backward (both null: not wanted)
   float* ws;             // K2: [tiles][3 C] partials: LayerNorm gamma / beta gradients, fc2 bias gradient
   int H, W, HD, tiles_x, tiles_per_img, tpw;
 };
@@ -716,6 +718,12 @@ __global__ __launch_bounds__(512, C == 64 ? 4 : 2) void pvt_mlp_bwd2_kernel(PvtB
 #pragma unroll
         for (int e = 0; e < 4; ++e) o.v[e] = gr.v[e] + rs * (qv[nt][e] - m1 - xh[nt][e] * m2);
         st4(a.dx + tok * C + n0, o);
+        if (a.dxs) {  // (what scale_batch(dx, up_scale) would write: the rounded dx times the scale)
+          const float us = a.up_scale[b];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o.v[e] = us * cenet_bf2f(cenet_f2bf(o.v[e]));
+          st4(a.dxs + tok * C + n0, o);
+        }
       }
       // fc2 bias gradient: column sums of s_b g (the grouped weight-gradient launch gets the UNscaled g, whose row sums
       // would miss the DropPath scale)
@@ -811,24 +819,26 @@ extern "C" long cenet_pvt_mlp_bwd_ws_floats(int B, int H, int W, int C) {
 
 /* backward of cenet_pvt_mlp_fwd_bf16 from its saved tensors, two launches (+ a fold of the LayerNorm affine gradients):
  * gu, dh: [B, H*W, HD] outputs (dh: the operand of the fc1 weight gradient; the fc2 weight gradient is g^T a with the saved,
- * already scaled a); dx = g + dLayerNorm; dwd / dbd / dln_g / dln_b and db2 (fc2 bias: column sums of s_b g; may be NULL) are
+ * already scaled a); dx = g + dLayerNorm (and, with up_scale [B] + dxs, dxs = up_scale_b * dx: x was itself residual +
+ * up_scale_b * branch, and that branch's backward starts from the scaled gradient); dwd / dbd / dln_g / dln_b and db2 (fc2 bias: column sums of s_b g; may be NULL) are
  * ADDED into. */
 extern "C" int cenet_pvt_mlp_bwd_bf16(const bf16_t* g, const float* bscale, const bf16_t* w1, const bf16_t* w2, const float* wd,
                                       const float* bd, const bf16_t* h, const bf16_t* x, const float* ln_g, const float* mean,
-                                      const float* rstd, bf16_t* gu, bf16_t* dh, bf16_t* dx, float* dwd_acc,
-                                      float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* db2_acc, float* ws, int B, int H,
-                                      int W, int C, int HD, hipStream_t stream) {
+                                      const float* rstd, bf16_t* gu, bf16_t* dh, bf16_t* dx, const float* up_scale, bf16_t* dxs,
+                                      float* dwd_acc, float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* db2_acc,
+                                      float* ws, int B, int H, int W, int C, int HD, hipStream_t stream) {
   if (!g || !w1 || !w2 || !wd || !bd || !h || !x || !ln_g || !mean || !rstd || !gu || !dh || !dx || !dwd_acc || !dbd_acc ||
-      !dln_g_acc || !dln_b_acc || !ws || B <= 0)
+      !dln_g_acc || !dln_b_acc || !ws || B <= 0 || (up_scale != nullptr) != (dxs != nullptr))
     return CENET_EINVAL;
   int TH, TW;
   if (!cenet_pvt_mlp_supported(C, HD, H, W) || !pvt_mlp_geo(H, W, TH, TW)) return CENET_EUNSUPPORTED;
-  if ((((uintptr_t)g | (uintptr_t)h | (uintptr_t)x | (uintptr_t)gu | (uintptr_t)dh | (uintptr_t)dx |
+  if ((((uintptr_t)g | (uintptr_t)h | (uintptr_t)x | (uintptr_t)gu | (uintptr_t)dh | (uintptr_t)dx | (uintptr_t)dxs |
         (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)ln_g) & 15) != 0 || (((uintptr_t)wd | (uintptr_t)bd) & 7) != 0)
     return CENET_EUNSUPPORTED;
   PvtBwdArgs a = {};
   a.g = g; a.bscale = bscale; a.w1 = w1; a.w2 = w2; a.wd = wd; a.bd = bd; a.h = h; a.gu = gu; a.dh = dh;
   a.dwd = dwd_acc; a.dbd = dbd_acc; a.x = x; a.ln_g = ln_g; a.mean = mean; a.rstd = rstd; a.dx = dx; a.ws = ws;
+  a.up_scale = up_scale; a.dxs = dxs;
   a.H = H; a.W = W; a.HD = HD;
   a.tiles_x = W / TW;
   a.tiles_per_img = a.tiles_x * (H / TH);

@@ -355,13 +355,18 @@ def layernorm_bwd_part_supported(dy, x, Cn) -> bool:
     return bool(is_bf16(dy) and is_bf16(x) and Cn % 8 == 0 and Cn <= 512 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def layernorm_bwd_part(dy, x, gamma, mean, rstd, dx, rows, Cn, dx_add=None):
+def layernorm_bwd_part(dy, x, gamma, mean, rstd, dx, rows, Cn, dx_add=None, bscale=None, dxs=None):
     """LayerNorm backward whose affine gradients go to a partial buffer [workgroups, 2 C] (returned) instead of float atomics;
-    ln_fold_group adds the column sums of many such buffers into their gradients with one launch."""
-    _chk(dy, x, gamma, mean, rstd, dx, dx_add)
+    ln_fold_group adds the column sums of many such buffers into their gradients with one launch.
+    bscale [B] + dxs (like dx): also write dxs = bscale[sample] * dx (what scale_batch(dx, bscale) would)."""
+    _chk(dy, x, gamma, mean, rstd, dx, dx_add, bscale, dxs)
     nrows = int(_lib.lib().cenet_layernorm_bwd_part_rows(rows, Cn))
     part = torch.empty((nrows, 2 * Cn), device=dy.device, dtype=torch.float32)
-    _call("cenet_layernorm_bwd_add_part_bf16", dy, x, gamma, mean, rstd, dx_add, dx, part, rows, Cn)
+    if bscale is None:
+        _call("cenet_layernorm_bwd_add_part_bf16", dy, x, gamma, mean, rstd, dx_add, dx, part, rows, Cn)
+    else:
+        _call("cenet_layernorm_bwd_add_part_scaled_bf16", dy, x, gamma, mean, rstd, dx_add, dx, part, bscale,
+              rows // bscale.numel(), dxs, rows, Cn)
     return part
 
 
@@ -495,17 +500,18 @@ def pvt_mlp_fwd(x, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, y, B, H, W, 
 
 
 
-def pvt_mlp_bwd(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dln_g, dln_b, db2, B, H, W, Cn, HD):
+def pvt_mlp_bwd(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dln_g, dln_b, db2, B, H, W, Cn, HD,
+                up_scale=None, dxs=None):
     """backward of pvt_mlp_fwd from its saved tensors in two launches (+ a fold): gu = (s_b g . W2) * GELU'(DW(h) + bd) with the
     depthwise weight / bias gradients ADDED into dwd / dbd; dh = DW^T(gu) (the operand of the fc1 weight gradient), dx = g +
     LayerNormBackward(dh . W1) with the affine gradients ADDED into dln_g / dln_b and the fc2 bias gradient (column sums of s_b g)
-    into db2 (None: not wanted)."""
-    _chk(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dln_g, dln_b, db2)
+    into db2 (None: not wanted).  up_scale [B] + dxs: also dxs = up_scale_b * dx (see ops._prescaled_put)."""
+    _chk(g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dln_g, dln_b, db2, up_scale, dxs)
     f = _lib.lib().cenet_pvt_mlp_bwd_ws_floats
     f.restype = C.c_long
     ws = torch.empty(int(f(B, H, W, Cn)), device=g.device, dtype=torch.float32)
-    _call("cenet_pvt_mlp_bwd_bf16", g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dln_g, dln_b, db2, ws,
-          B, H, W, Cn, HD)
+    _call("cenet_pvt_mlp_bwd_bf16", g, bscale, w1, w2, wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, up_scale, dxs, dwd, dbd, dln_g,
+          dln_b, db2, ws, B, H, W, Cn, HD)
 
 
 def dw_wgrad_nchw(x, sxb, dy, sgb, dw, dbias, B, Cn, H, W, dil, x_off=0, g_off=0):

@@ -123,6 +123,7 @@ class _WgradCfg:
     grouping = os.environ.get("CENET_WGRAD_GROUP", "1") != "0"  # record + one grouped launch (0: the per-layer launches of round 2)
     hold_bytes = int(float(os.environ.get("CENET_WGRAD_HOLD_MB", "3072")) * (1 << 20))  # recorded operands kept alive at most
     hold = False  # measurement aid (wgrad_hold): no automatic flush, the caller flushes
+    prescale = os.environ.get("CENET_LN_PRESCALE", "1") != "0"  # LayerNorm backward also writes the DropPath-scaled gradient
 
 
 class _WgradState:
@@ -319,14 +320,20 @@ def _defer_end(st, tid: int):
         st.flush()
 
 
-def _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, dx_add=None):
+def _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, dx_add=None, up_scale=None):
     """LayerNorm backward; bf16 rows with grouping on: the affine gradients go to a partial buffer that is folded, together with
     those of every other LayerNorm of the backward segment, by one launch at the flush (no float atomics, ~1 000 single-step
-    workgroups instead of ~256 x 6 - 8 dependent steps)"""
+    workgroups instead of ~256 x 6 - 8 dependent steps).
+    up_scale: the DropPath scale of the branch that produced x (see _prescaled_put): the same kernel also leaves up_scale * dx"""
     if _WgradCfg.grouping and kern.layernorm_bwd_part_supported(g, x, Cn) and (dx_add is None or dx_add.dtype == g.dtype):
         st = _wg(g.device)
         tid = _defer_begin(st)
-        part = kern.layernorm_bwd_part(g, x, gamma, mean, rstd, dx, rows, Cn, dx_add=dx_add)
+        dxs = None
+        if up_scale is not None and _WgradCfg.prescale and rows % up_scale.numel() == 0:
+            dxs = torch.empty_like(dx)
+            _prescaled_put(dx, up_scale, dxs)
+        part = kern.layernorm_bwd_part(g, x, gamma, mean, rstd, dx, rows, Cn, dx_add=dx_add,
+                                       bscale=up_scale if dxs is not None else None, dxs=dxs)
         st.ln_items.append((part, dg, db))
         st.held += part.numel() * 4
         _defer_end(st, tid)
@@ -338,6 +345,41 @@ def _wgrad_flush_cb(st, tid):
     if st.task == tid:
         st.task = None
     st.flush()
+    for k in [k for k in _PRESCALED if k[0] == st.device.index]:  # (records nobody asked for)
+        del _PRESCALED[k]
+
+
+# ---- gradients that their producer already scaled ---------------------------------------------------------------------------
+# A PVT block is x + s_b * branch(LN(x)) (pvtv2.py:141-149, s_b the DropPath scale fused into the proj / fc2 epilogue): the
+# branch's backward starts from s_b * g, where g is the gradient of the block output — which the LayerNorm backward of the NEXT
+# half block produces.  That kernel writes the scaled copy as a second output (one more store, no launch, no extra read) and
+# leaves it here; LinearFn.backward picks it up instead of launching scale_batch.  Keyed by the storage of g; the entry holds g
+# itself, so its memory cannot be handed to another tensor while the entry exists, and a pointer match means the same tensor.
+# Nothing found (fp32 mode, autograd summed two gradients into a new tensor, a hook replaced it): the scale pass runs as before.
+_PRESCALED: dict = {}
+
+
+def _prescaled_put(g: Tensor, bscale: Tensor, gs: Tensor):
+    if len(_PRESCALED) > 64:  # (records nobody asked for: a backward pass that raised)
+        _PRESCALED.clear()
+    _PRESCALED[(g.device.index, g.data_ptr())] = (g, bscale, gs)
+
+
+def _prescaled_take(g: Tensor, bscale: Tensor) -> Optional[Tensor]:
+    e = _PRESCALED.pop((g.device.index, g.data_ptr()), None)
+    if e is None or e[0].shape != g.shape or e[0].dtype != g.dtype or e[0].stride() != g.stride():
+        return None
+    if e[1].data_ptr() != bscale.data_ptr() or e[1].numel() != bscale.numel():
+        return None
+    return e[2]
+
+
+def tag_bscale(y: Tensor, bscale: Optional[Tensor]) -> Tensor:
+    """y = x + bscale_b * branch: remember the scale on the tensor object so that the LayerNorm that reads y next can hand the
+    branch its scaled gradient (layernorm / layernorm_res look for the tag)"""
+    if bscale is not None:
+        y._cenet_bscale = bscale
+    return y
 
 
 def wgrad_flush():
@@ -407,8 +449,10 @@ class LinearFn(Function):
         R = x.numel() // K
         gs = g
         if bscale is not None:
-            gs = torch.empty_like(g)
-            kern.scale_batch(g, bscale, gs, x.shape[0], g.numel() // x.shape[0])
+            gs = _prescaled_take(g, bscale)  # (the LayerNorm backward that produced g wrote bscale * g beside it)
+            if gs is None:
+                gs = torch.empty_like(g)
+                kern.scale_batch(g, bscale, gs, x.shape[0], g.numel() // x.shape[0])
         dW, db = grad_buf(Wp), grad_buf(bp)
         if dW is not None and _wgrad_deferrable(N, K, gs, x, K=R):
             # recorded, not launched: reduced with the other weight gradients of the segment by one grouped launch
@@ -434,7 +478,10 @@ class LinearFn(Function):
 
 def linear(x, W, b=None, resid=None, bscale=None, split_k=False, tap=False):
     """tap=True returns (y, x_tap): hand x_tap (not x) to the other consumers of x"""
-    return LinearFn.apply(x, W, b, resid, bscale, split_k, tap)
+    out = LinearFn.apply(x, W, b, resid, bscale, split_k, tap)
+    if bscale is not None and resid is not None:
+        tag_bscale(out[0] if tap else out, bscale)
+    return out
 
 
 # =====================================================================================================
@@ -787,7 +834,8 @@ def conv2d_tok(x, H, Wd, W, b=None, stride=1, pad=0, out_layout="tok"):
 # =====================================================================================================
 class LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, up_scale=None):
+        ctx.up_scale = up_scale
         x = _c(x)
         Cn = x.shape[-1]
         rows = x.numel() // Cn
@@ -809,12 +857,12 @@ class LayerNormFn(Function):
         dg, db = grad_buf(gp), grad_buf(bp)
         if dg is None:  # frozen affine: accumulate into scratch
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
-        _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn)
-        return dx, None, None, None
+        _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, up_scale=ctx.up_scale)
+        return dx, None, None, None, None
 
 
 def layernorm(x, gamma, beta, eps):
-    return LayerNormFn.apply(x, gamma, beta, eps)
+    return LayerNormFn.apply(x, gamma, beta, eps, getattr(x, "_cenet_bscale", None))
 
 
 class LayerNormResFn(Function):
@@ -823,7 +871,8 @@ class LayerNormResFn(Function):
     LN-backward followed by autograd's aten::add."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, up_scale=None):
+        ctx.up_scale = up_scale
         x = _c(x)
         Cn = x.shape[-1]
         rows = x.numel() // Cn
@@ -841,19 +890,19 @@ class LayerNormResFn(Function):
         Cn = x.shape[-1]
         rows = x.numel() // Cn
         if g is None:  # only the residual path carried a gradient
-            return g_res, None, None, None
+            return g_res, None, None, None, None
         g = _c(g)
         dx = torch.empty_like(x)
         dg, db = grad_buf(gp), grad_buf(bp)
         if dg is None:
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
-        _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, dx_add=_c(g_res))
-        return dx, None, None, None
+        _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, dx_add=_c(g_res), up_scale=ctx.up_scale)
+        return dx, None, None, None, None
 
 
 def layernorm_res(x, gamma, beta, eps):
     """returns (LN(x), x_residual): use x_residual (not x) for the skip connection around the normalised branch"""
-    return LayerNormResFn.apply(x, gamma, beta, eps)
+    return LayerNormResFn.apply(x, gamma, beta, eps, getattr(x, "_cenet_bscale", None))
 
 
 # =====================================================================================================
@@ -964,7 +1013,8 @@ class PvtMlpFn(Function):
     DWConvTokFn backward launches, on those tensors."""
 
     @staticmethod
-    def forward(ctx, x, H, Wd, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale):
+    def forward(ctx, x, H, Wd, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, up_scale=None):
+        ctx.up_scale = up_scale
         x = _c(x)
         B, N, Cn = x.shape
         HD = w1.shape[0]
@@ -1011,13 +1061,18 @@ class PvtMlpFn(Function):
         if dg is None:
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
         gu, dh, dx = torch.empty_like(a), torch.empty_like(a), torch.empty_like(x)
+        dxs = None
+        if ctx.up_scale is not None and _WgradCfg.prescale and ctx.up_scale.numel() == B:
+            # x = residual + up_scale_b * proj(...) (the attention half): its backward wants up_scale_b * dx (_prescaled_put)
+            dxs = torch.empty_like(x)
+            _prescaled_put(dx, ctx.up_scale, dxs)
         kern.pvt_mlp_bwd(g, bscale, kern.wq(w1, x), kern.wq(w2, x), wd, bd, h, x, ln_g, mean, rstd, gu, dh, dx, dwd, dbd, dg, db,
-                         grad_buf(b2), B, H, Wd, Cn, HD)
+                         grad_buf(b2), B, H, Wd, Cn, HD, up_scale=ctx.up_scale if dxs is not None else None, dxs=dxs)
         # a was saved as s_b * GELU(.): dW2 = (s_b g)^T a = g^T (s_b a), no scaled copy of g; the bias gradient (column sums of
         # s_b g) comes from the second kernel, so the recorded problem carries no bias
         wgrad(g, a, w2, None, Cn, HD)
         wgrad(dh, xn, w1, b1, HD, Cn)
-        return (dx,) + (None,) * 12
+        return (dx,) + (None,) * 13
 
 
 def pvt_mlp_supported(x, HD, H, Wd) -> bool:
@@ -1025,7 +1080,7 @@ def pvt_mlp_supported(x, HD, H, Wd) -> bool:
 
 
 def pvt_mlp(x, H, Wd, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale=None):
-    return PvtMlpFn.apply(x, H, Wd, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale)
+    return PvtMlpFn.apply(x, H, Wd, ln_g, ln_b, eps, w1, b1, wd, bd, w2, b2, bscale, getattr(x, "_cenet_bscale", None))
 
 
 class DWConvNCHWFn(Function):

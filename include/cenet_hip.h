@@ -288,6 +288,12 @@ int cenet_layernorm_bwd_part_rows(int rows, int C);
 int cenet_layernorm_bwd_add_part_bf16(const unsigned short* dy, const unsigned short* x, const float* gamma, const float* mean,
                                       const float* rstd, const unsigned short* dx_add, unsigned short* dx, float* part, int rows,
                                       int C, cenet_stream_t stream);
+/* the same, also writing dxs = bscale[row / rows_per_sample] * dx: the gradient the DropPath-scaled branch upstream wants
+ * (pvtv2.py:141-149) comes out of the kernel that produces dx instead of a scale pass (both NULL: plain) */
+int cenet_layernorm_bwd_add_part_scaled_bf16(const unsigned short* dy, const unsigned short* x, const float* gamma,
+                                             const float* mean, const float* rstd, const unsigned short* dx_add,
+                                             unsigned short* dx, float* part, const float* bscale, int rows_per_sample,
+                                             unsigned short* dxs, int rows, int C, cenet_stream_t stream);
 int cenet_ln_fold_group(const void* const* part, float* const* dgamma_acc, float* const* dbeta_acc, const int* nrows, const int* C,
                         int n, cenet_stream_t stream);
 
@@ -314,8 +320,8 @@ long cenet_pvt_mlp_bwd_ws_floats(int B, int H, int W, int C);
 int cenet_pvt_mlp_bwd_bf16(const unsigned short* g, const float* bscale, const unsigned short* w1, const unsigned short* w2,
                            const float* wd, const float* bd, const unsigned short* h, const unsigned short* x, const float* ln_g,
                            const float* mean, const float* rstd, unsigned short* gu, unsigned short* dh, unsigned short* dx,
-                           float* dwd_acc, float* dbd_acc, float* dln_g_acc, float* dln_b_acc, float* db2_acc,
-                           float* ws, int B, int H, int W, int C, int HD, cenet_stream_t stream);
+                           const float* up_scale, unsigned short* dxs, float* dwd_acc, float* dbd_acc, float* dln_g_acc,
+                           float* dln_b_acc, float* db2_acc, float* ws, int B, int H, int W, int C, int HD, cenet_stream_t stream);
 
 /* n <= 4 bias-free, activation-free depthwise 3x3 convs (flip = 1: their data gradients) / weight gradients of bf16 NCHW channel slices
  * in ONE launch — the three dilated SepConvBN branches of a CFAM block (cfam.py:208-212, blocks.py:142-150).  Branch i: x[i] (batch

@@ -1,0 +1,119 @@
+"""Glue launches folded into their producers (round 4).
+
+* LayerNorm backward also writes the DropPath-scaled gradient the branch upstream wants (cenet_layernorm_bwd_add_part_scaled_bf16):
+  bit-identical to scale_batch of its dx; a PVT block chain with per-sample scales gives the SAME gradients with the second output
+  on and off, and LinearFn.backward launches no scale pass when it finds the pre-scaled copy.
+`sim` = the same kernel source on the host SIMT checker (CPU); `hip` = the gfx950 library (marker gpu)."""
+import pytest
+import torch
+
+from backend import dev  # noqa: F401
+from cenet_amd import kern, ops
+
+BF = torch.bfloat16
+
+
+@pytest.mark.parametrize("B,N,Cn", [(4, 49, 64), (3, 50, 128), (2, 196, 320), (5, 21, 512)])
+def test_ln_backward_second_output_is_the_scale_pass(dev, B, N, Cn):
+    g = torch.Generator().manual_seed(B * 1000 + Cn)
+    rows = B * N
+    x = torch.randn(B, N, Cn, generator=g).to(BF).to(dev)
+    dy = torch.randn(B, N, Cn, generator=g).to(BF).to(dev)
+    add = torch.randn(B, N, Cn, generator=g).to(BF).to(dev)
+    gamma = (1 + 0.1 * torch.randn(Cn, generator=g)).to(dev)
+    beta = torch.zeros(Cn).to(dev)
+    s = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25][:B]).to(dev)
+    y, mean, rstd = torch.empty_like(x), torch.empty(rows).to(dev), torch.empty(rows).to(dev)
+    kern.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, Cn, 1e-5)
+    dx0, dx1, dxs = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    p0 = kern.layernorm_bwd_part(dy, x, gamma, mean, rstd, dx0, rows, Cn, dx_add=add)
+    p1 = kern.layernorm_bwd_part(dy, x, gamma, mean, rstd, dx1, rows, Cn, dx_add=add, bscale=s, dxs=dxs)
+    assert torch.equal(dx0, dx1) and torch.equal(p0, p1)
+    want = torch.empty_like(x)
+    kern.scale_batch(dx0, s, want, B, N * Cn)
+    assert torch.equal(dxs, want)
+
+
+def _chain(dev_, masks, seed=0):
+    """two PVT-style half blocks on tokens: x1 = x + s1 * Linear(LN(x)); x2 = x1 + s2 * Linear(LN(x1)); out = LN(x2)"""
+    g = torch.Generator().manual_seed(seed)
+    B, N, Cn = 4, 49, 64
+    x = torch.randn(B, N, Cn, generator=g).to(BF).to(dev_).requires_grad_(True)
+    ps = []
+    for _ in range(3):
+        ps += [(1 + 0.1 * torch.randn(Cn, generator=g)).to(dev_).requires_grad_(True), (0.1 * torch.randn(Cn, generator=g)).to(dev_).requires_grad_(True)]
+    Ws = [(0.1 * torch.randn(Cn, Cn, generator=g)).to(dev_).requires_grad_(True) for _ in range(2)]
+    bs = [(0.1 * torch.randn(Cn, generator=g)).to(dev_).requires_grad_(True) for _ in range(2)]
+    t = x
+    for i in range(2):
+        y, tr = ops.layernorm_res(t, ps[2 * i], ps[2 * i + 1], 1e-5)
+        t = ops.linear(y, Ws[i], bs[i], resid=tr, bscale=masks[i].to(dev_))
+    out = ops.layernorm(t, ps[4], ps[5], 1e-5)
+    w = torch.randn(B, N, Cn, generator=g).to(BF).to(dev_)
+    for p in ps + Ws + bs:
+        p.grad = torch.zeros_like(p)
+    (out.float() * w.float()).sum().backward()
+    ops.wgrad_flush()
+    return [x.grad] + [p.grad for p in ps + Ws + bs]
+
+
+def test_block_chain_gradients_do_not_depend_on_where_the_scale_is_applied(dev, monkeypatch):
+    masks = [torch.tensor([1.25, 0.0, 1.25, 1.25]), torch.tensor([0.0, 1.25, 1.25, 0.0])]
+    calls = []
+    orig = kern.scale_batch
+    monkeypatch.setattr(kern, "scale_batch", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    monkeypatch.setattr(ops._WgradCfg, "prescale", True)
+    on = _chain(dev, masks)
+    n_on = len(calls)
+    monkeypatch.setattr(ops._WgradCfg, "prescale", False)
+    off = _chain(dev, masks)
+    n_off = len(calls) - n_on
+    assert n_off == 2 and n_on == (0 if ops._WgradCfg.grouping else 2)
+    for a, b in zip(on, off):
+        assert torch.equal(a, b)
+    assert not ops._PRESCALED
+
+
+def _attn_then_fused_mlp(dev_, s1, s2, seed=3):
+    """x1 = x + s1 * Linear(LN(x)) (the attention half's tail), then the fused MLP half reads x1: its second backward kernel is the
+    producer of the gradient the Linear wants scaled"""
+    from test_pvt_mlp import _params
+    B, H, W, Cn, HD = 2, 8, 14, 64, 128
+    g = torch.Generator().manual_seed(seed)
+    p = _params(Cn, HD, dev_, seed)
+    x = torch.randn(B, H * W, Cn, generator=g).to(BF).to(dev_).requires_grad_(True)
+    ng = (1 + 0.1 * torch.randn(Cn, generator=g)).to(dev_).requires_grad_(True)
+    nb = (0.1 * torch.randn(Cn, generator=g)).to(dev_).requires_grad_(True)
+    Wp = (0.1 * torch.randn(Cn, Cn, generator=g)).to(dev_).requires_grad_(True)
+    bp = (0.1 * torch.randn(Cn, generator=g)).to(dev_).requires_grad_(True)
+    y, xr = ops.layernorm_res(x, ng, nb, 1e-6)
+    x1 = ops.linear(y, Wp, bp, resid=xr, bscale=s1.to(dev_))
+    assert ops.pvt_mlp_supported(x1, HD, H, W)
+    out = ops.pvt_mlp(x1, H, W, p["ln_g"], p["ln_b"], 1e-6, p["w1"], p["b1"], p["wd"], p["bd"], p["w2"], p["b2"], s2.to(dev_))
+    w = torch.randn(B, H * W, Cn, generator=g).to(BF).to(dev_)
+    leaves = [ng, nb, Wp, bp] + list(p.values())
+    for q in leaves:
+        q.grad = torch.zeros_like(q)
+    (out.float() * w.float()).sum().backward()
+    ops.wgrad_flush()
+    return [x.grad] + [q.grad for q in leaves]
+
+
+def test_fused_mlp_backward_hands_the_attention_half_its_scaled_gradient(dev, monkeypatch):
+    s1, s2 = torch.tensor([1.25, 0.0]), torch.tensor([1.25, 1.25])
+    calls = []
+    orig = kern.scale_batch
+    monkeypatch.setattr(kern, "scale_batch", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    monkeypatch.setattr(ops._WgradCfg, "prescale", True)
+    on = _attn_then_fused_mlp(dev, s1, s2)
+    n_on = len(calls)
+    monkeypatch.setattr(ops._WgradCfg, "prescale", False)
+    off = _attn_then_fused_mlp(dev, s1, s2)
+    assert n_on == 0 and len(calls) == 1
+    for i, (a, b) in enumerate(zip(on, off)):
+        # (the fused kernels' affine / depthwise gradient sums use LDS float atomics: their order varies from run to run on the GPU)
+        if a.dtype == BF or str(dev) == "cpu":
+            assert torch.equal(a, b), i
+        else:
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * max(b.abs().max().item(), 1.0)), i
+    assert not ops._PRESCALED
