@@ -345,8 +345,10 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // backward, dQ (+ delta = rowsum(dU * U) and the bf16 statistics rows for dK/dV): wave = 32 queries x both softmax heads
 // ---------------------------------------------------------------------------------------------------------------------------
+// (HDP <= 16: three workgroups per CU — 168 registers, nothing spilled; the kernel waits on dependent MFMA / exponential chains, a
+// third wave per SIMD covers more of them: 0.78 -> 0.74 ms at DSEB-56x56, same box)
 template <int HDP, bool ONE>
-__global__ __launch_bounds__(256, HDP > 32 ? 1 : 2) void dattn_bwd_dq_kernel(DiffArgs a) {
+__global__ __launch_bounds__(256, HDP > 32 ? 1 : (HDP <= 16 ? 3 : 2)) void dattn_bwd_dq_kernel(DiffArgs a) {
   typedef DaGeo<HDP> G;
   constexpr int NKS = HDP / 16, NKD = G::DVP / 16, NH = ONE ? 1 : 2;
   constexpr int NFT = (HDP + 31) / 32;  // 32-feature accumulator tiles per head (HDP = 64: two)

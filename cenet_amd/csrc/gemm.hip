@@ -98,6 +98,7 @@ static int gemm_dispatch(const cenet_mat_t* A, const cenet_mat_t* B, const cenet
   if (M <= 0 || N <= 0 || K <= 0 || nbatch <= 0 || nb_inner <= 0 || nkb <= 0 || splits <= 0) return CENET_EINVAL;
   if (A->mode != 0) return CENET_EUNSUPPORTED;
   if (splits > 1 && !E->atomic) return CENET_EINVAL;
+  if (E->atomic == 2 && (splits > 1 || E->cmode || E->asum)) return CENET_EINVAL;  // fp32 STORE of an unsplit product
   if (E->atomic && (E->bias || E->R || E->act != ACT_NONE || E->bscale)) return CENET_EINVAL;
   if (E->asum && (!E->atomic || nbatch != 1 || A->kinner != 0)) return CENET_EINVAL;
   const bool bf = esz == 2;

@@ -342,7 +342,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
       const int row0 = m0 + wm * (BM / 2) + i * 16, col0 = n0 + wn * WN;
       for (int idx = lane; idx < 16 * WN; idx += 64) {
         const int r = idx / WN, c = idx - r * WN;
-        if (row0 + r < g.M && col0 + c < g.N) atomicAdd(&Cf[(long)(row0 + r) * E.scr + col0 + c], strip[r * (WN + 1) + c]);
+        if (row0 + r < g.M && col0 + c < g.N) {
+          // atomic == 2: the only contribution to this element (no split): a plain fp32 store, C needs no zero fill
+          if (E.atomic == 2) Cf[(long)(row0 + r) * E.scr + col0 + c] = strip[r * (WN + 1) + c];
+          else atomicAdd(&Cf[(long)(row0 + r) * E.scr + col0 + c], strip[r * (WN + 1) + c]);
+        }
       }
     }
     return;
@@ -498,6 +502,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[BM
             if (E.atomic) atomicAdd(&Cf[o], v);
             else stf(&Cb[o], v);
           }
+        } else if (E.atomic == 2) {
+          Cf[(long)row * E.scr + (long)col * E.scc] = v;
         } else if (E.atomic) {
           atomicAdd(&Cf[(long)row * E.scr + (long)col * E.scc], v);
         } else {

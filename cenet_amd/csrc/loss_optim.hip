@@ -286,6 +286,36 @@ static int cast_launch(const TI* x, TO* y, long n, hipStream_t stream) {
 extern "C" int cenet_cast_f32_to_bf16(const float* x, unsigned short* y, long n, hipStream_t stream) {
   return cast_launch<float, bf16_t>(x, y, n, stream);
 }
+// y = bf16(x); x = 0: the fp32 accumulator a kernel added into atomically is rounded to the gradient's storage type AND left zero
+// for its next user in one pass (the accumulator is a persistent workspace: no zero fill in front of every use)
+__global__ __launch_bounds__(256) void cast_clear_kernel(float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    stf(y + i, x[i]);
+    x[i] = 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void cast_clear4_kernel(float* __restrict__ x, bf16_t* __restrict__ y, long nq) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long)gridDim.x * 256) {
+    st4(y + 4 * i, ld4(x + 4 * i));
+    f4 z;
+    z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0.f;
+    st4(x + 4 * i, z);
+  }
+}
+extern "C" int cenet_cast_clear_f32_to_bf16(float* x, unsigned short* y, long n, hipStream_t stream) {
+  if (!x || !y || n <= 0) return CENET_EINVAL;
+  if ((n & 3) == 0 && quad_aligned<float>(x) && quad_aligned<bf16_t>((const bf16_t*)y)) {
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    CENET_LAUNCH(cast_clear4_kernel, dim3((unsigned)blocks), dim3(256), stream, x, (bf16_t*)y, n / 4);
+  } else {
+    long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    CENET_LAUNCH(cast_clear_kernel, dim3((unsigned)blocks), dim3(256), stream, x, (bf16_t*)y, n);
+  }
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
 extern "C" int cenet_cast_bf16_to_f32(const unsigned short* x, float* y, long n, hipStream_t stream) {
   return cast_launch<bf16_t, float>(x, y, n, stream);
 }

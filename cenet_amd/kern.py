@@ -804,6 +804,13 @@ def cast(x: torch.Tensor, dtype) -> torch.Tensor:
     return y
 
 
+def cast_clear(x: torch.Tensor, y: torch.Tensor):
+    """y (bf16) = x (fp32, contiguous); x = 0 afterwards (see ops._zero_ws)"""
+    _chk(x, y)
+    assert x.dtype == torch.float32 and y.dtype == BF16 and x.numel() == y.numel()
+    _lib.check(_lib.lib().cenet_cast_clear_f32_to_bf16(P(x), P(y), L(x.numel()), stream()), "cenet_cast_clear_f32_to_bf16")
+
+
 def cast_into(x: torch.Tensor, y: torch.Tensor):
     name = "cenet_cast_f32_to_bf16" if y.dtype == BF16 else "cenet_cast_bf16_to_f32"
     assert x.dtype != y.dtype and x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous()

@@ -50,6 +50,36 @@ def _zeros(shape, ref: Tensor) -> Tensor:
     return kern.zero_(t)
 
 
+class _ZeroWs:
+    """Persistent fp32 accumulators that are ZERO at rest, one per (device, element count): a kernel adds into one atomically and
+    kern.cast_clear rounds it to the gradient's type and zeroes it again in the same pass — instead of a zero-fill launch in
+    front of every use (the dK / dV accumulator of the spatial-reduction attention backward: 7 fills per step).  `dirty` covers a
+    pass that raised between the two launches: the next taker fills it again."""
+    bufs: dict = {}
+
+    @staticmethod
+    def take(shape, ref: Tensor) -> Tensor:
+        n = 1
+        for v in shape:
+            n *= int(v)
+        key = (ref.device.type, ref.device.index, n)
+        e = _ZeroWs.bufs.get(key)
+        if e is None:
+            e = _ZeroWs.bufs[key] = [kern.zero_(torch.empty(n, device=ref.device, dtype=torch.float32)), False]
+        elif e[1]:
+            kern.zero_(e[0])
+        e[1] = True
+        return e[0].view(shape)
+
+    @staticmethod
+    def give_back_as(ws: Tensor, like: Tensor) -> Tensor:
+        """-> a tensor of like's dtype (bf16) holding ws; ws is zero again"""
+        out = torch.empty(ws.shape, device=ws.device, dtype=like.dtype)
+        kern.cast_clear(ws, out)
+        _ZeroWs.bufs[(ws.device.type, ws.device.index, ws.numel())][1] = False
+        return out
+
+
 def grad_buf(p: Optional[Tensor]) -> Optional[Tensor]:
     """fp32 buffer that gradient kernels ADD into for parameter `p` (None if p is frozen / absent)."""
     if p is None or not p.requires_grad:
@@ -1165,11 +1195,11 @@ def _attn_forward(d: _AttnDesc, q, k, v, o):
     # materialised path (large head dims, small N): S = scale QK^T ; P = softmax ; O = P V.  The scores stay fp32 in both
     # modes (bf16 operands: the GEMM adds atomically into a zero-filled fp32 S); P has the operand type.
     BH = d.B * d.H
-    S = _zeros((BH, d.Nq, d.Nk), q) if bf else _empty((BH, d.Nq, d.Nk), q)
+    S = _empty((BH, d.Nq, d.Nk), q)  # (bf16 operands: the GEMM STORES its fp32 accumulators, atomic=2 — no zero fill)
     kern.gemm(kern.mat_plain(q, d.qs[2], d.qs[3], sb=d.qs[0], sb2=d.qs[1], kfast=int(d.qs[3] == 1), offset=d.qoff),
               kern.mat_plain(k, d.ks[3], d.ks[2], sb=d.ks[0], sb2=d.ks[1], kfast=int(d.ks[3] == 1), offset=d.koff),
               S, d.Nq, d.Nk, d.D, scr=d.Nk, scc=1, scb=d.H * d.Nq * d.Nk, scb2=d.Nq * d.Nk, nbatch=BH, nb_inner=d.H,
-              alpha=d.scale, atomic=bf)
+              alpha=d.scale, atomic=2 if bf else False)
     P = _act(S.shape, q)
     kern.softmax_rows_fwd(S, P, BH * d.Nq, d.Nk)
     vh = d.vdiv
@@ -1207,10 +1237,10 @@ def _attn_backward(d: _AttnDesc, kind, saved, q, k, v, o, g, dq, dk, dv, dkv_zer
     BH = d.B * d.H
     HN = d.H * d.Nq * d.Nk
     NN = d.Nq * d.Nk
-    dP = _zeros(P.shape, P) if bf else torch.empty_like(P)  # fp32 in both modes (see _attn_forward)
+    dP = torch.empty(P.shape, device=P.device, dtype=torch.float32)  # fp32 in both modes (see _attn_forward)
     kern.gemm(kern.mat_plain(g, d.os[2], d.os[3], sb=d.os[0], sb2=d.os[1], kfast=int(d.os[3] == 1)),
               kern.mat_plain(v, d.vs[3], d.vs[2], sb=d.vs[0], sb2=d.vs[1], kfast=int(d.vs[3] == 1), offset=d.voff),
-              dP, d.Nq, d.Nk, d.Dv, scr=d.Nk, scc=1, scb=HN, scb2=NN, nbatch=BH, nb_inner=d.H, atomic=bf)
+              dP, d.Nq, d.Nk, d.Dv, scr=d.Nk, scc=1, scb=HN, scb2=NN, nbatch=BH, nb_inner=d.H, atomic=2 if bf else False)
     dS = torch.empty_like(P)
     kern.softmax_rows_bwd(P, dP, dS, BH * d.Nq, d.Nk)
     kern.gemm(kern.mat_plain(dS, d.Nk, 1, sb=HN, sb2=NN, kfast=1),
@@ -1263,9 +1293,9 @@ class SRAttentionFn(Function):
                 dkv = torch.empty_like(kv)
                 kern.sra_attn_bwd_direct(q, kv, o, g, saved, dq, dkv, d.B, d.H, d.Nq, d.Nk, d.scale)
                 return dq, dkv, None
-            dkv = _zeros(kv.shape, kv)
+            dkv = _ZeroWs.take(kv.shape, kv)  # (zero at rest: no fill launch; cast_clear leaves it zero again)
             kern.sra_attn_bwd(q, kv, o, g, saved, dq, dkv, d.B, d.H, d.Nq, d.Nk, d.scale)
-            return dq, kern.cast(dkv, kv.dtype), None
+            return dq, _ZeroWs.give_back_as(dkv, kv), None
         if (ctx.kind == "flash" and _bf(q) and kern.sra_attn_bwd_blocks_supported(d.D, d.Nk) and d.D == d.Dv
                 and all(t.data_ptr() % 16 == 0 for t in (q, kv, o, g))):
             # bf16, 64-dim heads, 65 .. 256 keys (512x512 inputs): dQ with all keys resident + dK / dV per 64-key block

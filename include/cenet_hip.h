@@ -597,6 +597,9 @@ int cenet_sgd_step_shadow_f32(float* p, const float* g, float* buf, const float*
                               cenet_stream_t stream);
 int cenet_cast_f32_to_bf16(const float* x, unsigned short* y, long n, cenet_stream_t stream);
 int cenet_cast_bf16_to_f32(const unsigned short* x, float* y, long n, cenet_stream_t stream);
+/* y = bf16(x) and x = 0 in one pass: x is a persistent fp32 accumulator that kernels add into atomically (the dK / dV of the
+ * spatial-reduction attention backward, pvtv2.py:88-109), left zero for its next use instead of a fill before every use */
+int cenet_cast_clear_f32_to_bf16(float* x, unsigned short* y, long n, cenet_stream_t stream);
 
 #ifdef __cplusplus
 }

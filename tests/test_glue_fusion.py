@@ -117,3 +117,43 @@ def test_fused_mlp_backward_hands_the_attention_half_its_scaled_gradient(dev, mo
         else:
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * max(b.abs().max().item(), 1.0)), i
     assert not ops._PRESCALED
+
+
+def test_sra_backward_accumulator_is_zero_at_rest(dev, monkeypatch):
+    """dK / dV of the multi-workgroup spatial-reduction attention backward: a persistent accumulator + cast_clear instead of a zero
+    fill before and a cast after every use — same bits as the filled form, also on the second use and after an interrupted one"""
+    B, H, Nq, Nk, hd = 1, 1, 1024, 49, 64
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, Nq, H * hd, generator=g).to(BF).to(dev).requires_grad_(True)
+    kv = torch.randn(B, Nk, 2 * H * hd, generator=g).to(BF).to(dev).requires_grad_(True)
+    w = torch.randn(B, Nq, H * hd, generator=g).to(BF).to(dev)
+    if kern.sra_attn_bwd_direct_supported(B, H, Nq, Nk):
+        pytest.skip("one workgroup per (batch, head) here: no accumulator")
+
+    def run():
+        q.grad = kv.grad = None
+        ops.sr_attention(q, kv, H).backward(w)
+        return q.grad.clone(), kv.grad.clone()
+
+    takes = []
+    orig_take = ops._ZeroWs.take
+    monkeypatch.setattr(ops._ZeroWs, "take", staticmethod(lambda shape, ref: (takes.append(1), orig_take(shape, ref))[1]))
+    a = run()
+    b = run()
+    assert len(takes) == 2
+    key = (dev.type, dev.index, kv.numel())
+    assert ops._ZeroWs.bufs[key][1] is False and float(ops._ZeroWs.bufs[key][0].abs().max()) == 0.0
+    # an interrupted use (dirty accumulator) is filled again by the next taker
+    ops._ZeroWs.take(kv.shape, kv).fill_(3.0)
+    c = run()
+    # the filled form
+    monkeypatch.setattr(ops._ZeroWs, "take", staticmethod(lambda shape, ref: ops._zeros(shape, ref)))
+    monkeypatch.setattr(ops._ZeroWs, "give_back_as", staticmethod(lambda ws, like: kern.cast(ws, like.dtype)))
+    ref = run()
+    for x in (a, b, c):
+        assert torch.equal(x[0], ref[0])
+        # (fp32 atomics from several workgroups: the order of the adds is not fixed on the GPU)
+        if dev.type == "cpu":
+            assert torch.equal(x[1], ref[1])
+        else:
+            torch.testing.assert_close(x[1].float(), ref[1].float(), rtol=2e-2, atol=2e-2)

@@ -167,6 +167,15 @@ def test_gemm_ring_orientations(dev, M, N, K, akf, bkf):
     kern.gemm(A, Bm, acc, M, N, K, scr=N, scc=1, splits=3, atomic=True, asum=rs)
     torch.testing.assert_close(acc.cpu(), F.linear(x.float(), w.float()).cpu(), rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(rs.cpu(), x.float().sum(1).cpu(), rtol=1e-4, atol=1e-3)
+    # atomic=2: the unsplit product STORED as fp32 (no zero fill: the destination starts as garbage), row-major and strided C
+    st = torch.full((M, N), 7.5e8, device=dev)
+    kern.gemm(A, Bm, st, M, N, K, scr=N, scc=1, alpha=0.5, atomic=2)
+    torch.testing.assert_close(st.cpu(), 0.5 * F.linear(x.float(), w.float()).cpu(), rtol=1e-3, atol=1e-3)
+    stt = torch.full((N, M), -3.0e9, device=dev)
+    kern.gemm(A, Bm, stt, M, N, K, scr=1, scc=M, atomic=2)
+    torch.testing.assert_close(stt.cpu(), F.linear(x.float(), w.float()).t().cpu(), rtol=1e-3, atol=1e-3)
+    with pytest.raises(Exception):
+        kern.gemm(A, Bm, st, M, N, K, scr=N, scc=1, splits=2, atomic=2)
 
 
 @pytest.mark.parametrize("Co,Ci,HW", [(64, 72, 80), (64, 72, 49), (56, 50, 196)])
