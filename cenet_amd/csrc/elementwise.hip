@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(const T* __restrict__
 template <typename T>
 struct CatArgs {
   T* part[4];
+  const T* add[4];  // SPLIT only: part[j] = slice + add[j] (nullptr: plain copy) — the gradient that reached the part by another path
   long n[4], off[4];
   T* joined;
   long sjb;  // elements per image of the joined tensor
@@ -114,6 +115,12 @@ __global__ __launch_bounds__(256) void cat_channels_kernel(CatArgs<T> a) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float v[V];
     ldv<V>(v, (SPLIT ? jb : pb) + i * V);
+    if (SPLIT && a.add[j]) {
+      float w[V];
+      ldv<V>(w, a.add[j] + (long)b * a.n[j] + i * V);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] += w[e];
+    }
     stv<V>((SPLIT ? pb : jb) + i * V, v);
   }
 }
@@ -877,8 +884,11 @@ CENET_TWIN(copy_batched, (const T* x, long sxb, T* y, long syb, int B, long n, i
 
 template <typename T>
 static int cat_channels_impl(T* p0, T* p1, T* p2, T* p3, int c0, int c1, int c2, int c3, T* joined, int B, long HW, int split,
-                             hipStream_t stream) {
+                             hipStream_t stream, const T* a0 = nullptr, const T* a1 = nullptr, const T* a2 = nullptr,
+                             const T* a3 = nullptr) {
   T* ps[4] = {p0, p1, p2, p3};
+  const T* as[4] = {a0, a1, a2, a3};
+  if (!split && (a0 || a1 || a2 || a3)) return CENET_EINVAL;
   const int cs[4] = {c0, c1, c2, c3};
   if (!joined || B <= 0 || HW <= 0) return CENET_EINVAL;
   CatArgs<T> a;
@@ -889,10 +899,13 @@ static int cat_channels_impl(T* p0, T* p1, T* p2, T* p3, int c0, int c1, int c2,
   long lens = 0;
   for (int j = 0; j < 4; ++j) {
     a.part[j] = nullptr;
+    a.add[j] = nullptr;
     a.n[j] = a.off[j] = 0;
     if (cs[j] <= 0) continue;
     if (!ps[j] || parts != j) return CENET_EINVAL;  // parts are given front to back without holes
     a.part[j] = ps[j];
+    a.add[j] = as[j];
+    align |= (uintptr_t)as[j];
     a.n[j] = (long)cs[j] * HW;
     a.off[j] = off;
     off += a.n[j];
@@ -925,6 +938,17 @@ static int cat_channels_impl(T* p0, T* p1, T* p2, T* p3, int c0, int c1, int c2,
 CENET_TWIN(cat_channels, (T* p0, T* p1, T* p2, T* p3, int c0, int c1, int c2, int c3, T* joined, int B, long HW, int split,
                           hipStream_t stream),
            (p0, p1, p2, p3, c0, c1, c2, c3, joined, B, HW, split, stream))
+// the split with addends: part j = its channel slice of `joined` + a_j (a_j == NULL: the slice alone) — the backward of a channel
+// concat whose inputs have further consumers (dseb.py:156: `dec` also feeds the level's residual add, `skip` the mixer's): the
+// gradients that reached them by those paths are added here instead of by an elementwise add each
+template <typename T>
+static int split_channels_add_impl(T* p0, T* p1, T* p2, T* p3, const T* a0, const T* a1, const T* a2, const T* a3, int c0, int c1,
+                                   int c2, int c3, const T* joined, int B, long HW, hipStream_t stream) {
+  return cat_channels_impl<T>(p0, p1, p2, p3, c0, c1, c2, c3, const_cast<T*>(joined), B, HW, 1, stream, a0, a1, a2, a3);
+}
+CENET_TWIN(split_channels_add, (T* p0, T* p1, T* p2, T* p3, const T* a0, const T* a1, const T* a2, const T* a3, int c0, int c1,
+                                int c2, int c3, const T* joined, int B, long HW, hipStream_t stream),
+           (p0, p1, p2, p3, a0, a1, a2, a3, c0, c1, c2, c3, joined, B, HW, stream))
 
 template <typename T>
 static int patch_tok_impl(const T* src, T* dst, int B, int Ho, int Wo, int C, int S, int inverse, hipStream_t stream) {

@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                           float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int act, float slope, int C, int HW,
                                                           float n, const float* __restrict__ ws, int S, float* dgamma,
-                                                          float* dbeta) {
+                                                          float* dbeta, const T* __restrict__ dx_add, long sab) {
   const int bc = blockIdx.x;
   const int b = bc / C, c = bc - b * C;
   const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
@@ -754,12 +754,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const float m1 = s1 / n, m2 = s2 / n;
   const T* xp = x + (long)b * sxb + (long)c * HW;
   const T* gp = dy + (long)b * sgb + (long)c * HW;
+  const T* ap = dx_add ? dx_add + (long)b * sab + (long)c * HW : nullptr;  // gradient that by-passed the BatchNorm (residual path)
   T* dp = dx + (long)b * sdb + (long)c * HW;
   for (int p = blockIdx.y * 256 + threadIdx.x; p < HW; p += gridDim.y * 256) {
     float xh = (ldf(xp + p) - mu) * rs;
     float g = ldf(gp + p);
     if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
-    stf(dp + p, gm * rs * (g - m1 - xh * m2));
+    stf(dp + p, gm * rs * (g - m1 - xh * m2) + (ap ? ldf(ap + p) : 0.f));
   }
   if (b == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     atomicAdd(&dgamma[c], s2);
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* __restric
                                                              float eps, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act, float slope, int C,
                                                              int HW, float n, const float* __restrict__ ws, int S, float* dgamma,
-                                                             float* dbeta) {
+                                                             float* dbeta, const T* __restrict__ dx_add, long sab) {
   const int bc = blockIdx.x;
   const int b = bc / C, c = bc - b * C;
   const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
@@ -903,17 +904,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const T* __restric
   const T* xp = x + (long)b * sxb + (long)c * HW;
   const T* gp = dy + (long)b * sgb + (long)c * HW;
   T* dp = dx + (long)b * sdb + (long)c * HW;
+  const T* ap = dx_add ? dx_add + (long)b * sab + (long)c * HW : nullptr;
   const int nq = HW >> 2;
   for (int q = blockIdx.y * blockDim.x + threadIdx.x; q < nq; q += gridDim.y * blockDim.x) {
-    float xv[4], gv[4];
+    float xv[4], gv[4], av[4] = {0.f, 0.f, 0.f, 0.f};
     ld4v(xv, xp + 4 * q);
     ld4v(gv, gp + 4 * q);
+    if (ap) ld4v(av, ap + 4 * q);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float xh = (xv[e] - mu) * rs;
       float g = gv[e];
       if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
-      gv[e] = gm * rs * (g - m1 - xh * m2);
+      gv[e] = gm * rs * (g - m1 - xh * m2) + av[e];
     }
     st4v(dp + 4 * q, gv);
   }
@@ -968,7 +971,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restr
                                                                const float* __restrict__ var, float eps,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                int act, float slope, int C, int HWv, long nvec, float n,
-                                                               const float* __restrict__ ws, int S, float* dgamma, float* dbeta) {
+                                                               const float* __restrict__ ws, int S, float* dgamma, float* dbeta,
+                                                               const T* __restrict__ dx_add) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
   const long plane = i / HWv;
@@ -980,15 +984,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restr
     s2 += ws[((long)C + c) * S + k];
   }
   const float m1 = s1 / n, m2 = s2 / n;
-  float xv[V], gv[V];
+  float xv[V], gv[V], av[V];
   ldv<V>(xv, x + i * V);
   ldv<V>(gv, dy + i * V);
+#pragma unroll
+  for (int e = 0; e < V; ++e) av[e] = 0.f;
+  if (dx_add) ldv<V>(av, dx_add + i * V);
 #pragma unroll
   for (int e = 0; e < V; ++e) {
     const float xh = (xv[e] - mu) * rs;
     float g = gv[e];
     if (act != ACT_NONE) g *= act_bwd(act, xh * gm + bt, slope);
-    gv[e] = gm * rs * (g - m1 - xh * m2);
+    gv[e] = gm * rs * (g - m1 - xh * m2) + av[e];
   }
   stv<V>(dx + i * V, gv);
   if (plane < C && i == plane * HWv) {  // first vector of image 0's plane of channel c
@@ -1091,7 +1098,8 @@ __global__ __launch_bounds__(256) void bn_bwd_1k_kernel(const bf16_t* __restrict
                                                        long sxb, bf16_t* __restrict__ dx, long sdb,
                                                        const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                       float slope, int B, int HW, float* dgamma, float* dbeta) {
+                                                       float slope, int B, int HW, float* dgamma, float* dbeta,
+                                                       const bf16_t* __restrict__ dx_add, long sab) {
   __shared__ float red[16];
   const int c = blockIdx.x, total = B * HW;
   const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
@@ -1119,7 +1127,8 @@ __global__ __launch_bounds__(256) void bn_bwd_1k_kernel(const bf16_t* __restrict
     const int e = threadIdx.x + 256 * k;
     if (e < total) {
       const int b = e / HW, p = e - b * HW;
-      stf(dx + (long)b * sdb + (long)c * HW + p, gm * rs * (g[k] - m1 - xh[k] * m2));
+      stf(dx + (long)b * sdb + (long)c * HW + p,
+          gm * rs * (g[k] - m1 - xh[k] * m2) + (dx_add ? cenet_bf2f(dx_add[(long)b * sab + (long)c * HW + p]) : 0.f));
     }
   }
   if (threadIdx.x == 0) {
@@ -1292,17 +1301,18 @@ CENET_TWIN(bn_apply, (const T* x, long sxb, T* y, long syb, const float* mean, c
 template <typename T>
 static int bn_bwd_acc_impl(const T* dy, long sgb, const T* x, long sxb, T* dx, long sdb, const float* mean, const float* var,
                            float eps, const float* gamma, const float* beta, int act, float slope, int B, int C, int HW,
-                           float* ws, float* dgamma_acc, float* dbeta_acc, hipStream_t stream) {
+                           float* ws, float* dgamma_acc, float* dbeta_acc, hipStream_t stream, const T* dx_add = nullptr,
+                           long sab = 0) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
   const long total = (long)B * HW;
   if (sizeof(T) == 2 && total <= 256 * BN1K_EPT) {
     CENET_LAUNCH(bn_bwd_1k_kernel, dim3(C), dim3(256), stream, (const bf16_t*)dy, sgb, (const bf16_t*)x, sxb, (bf16_t*)dx, sdb, mean,
-                 var, eps, gamma, beta, act, slope, B, HW, dgamma_acc, dbeta_acc);
+                 var, eps, gamma, beta, act, slope, B, HW, dgamma_acc, dbeta_acc, (const bf16_t*)dx_add, sab);
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }
-  if (bn_flat_ok<T>(C, HW, sgb, sxb, sdb)) {
-    const bool v4 = bn_v4_ok<T>(HW, dy, sgb, x, sxb, dx, sdb);
+  if (bn_flat_ok<T>(C, HW, sgb, sxb, sdb) && (!dx_add || sab == (long)C * HW)) {
+    const bool v4 = bn_v4_ok<T>(HW, dy, sgb, x, sxb, dx, sdb) && bn_v4_ok<T>(HW, dx_add, sab, x, sxb, dx, sdb);
     const int S = v4 ? bn_splits_v4(C, total / 4) : bn_splits(C, total);
     if (v4)
       CENET_LAUNCH((bn_bwd_partial_v4_kernel<T>), dim3(C, S), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma, beta, act,
@@ -1313,23 +1323,23 @@ static int bn_bwd_acc_impl(const T* dy, long sgb, const T* x, long sxb, T* dx, l
     if (v4) {
       const long nvec = (long)B * C * HW / 4;
       CENET_LAUNCH((bn_bwd_apply_flat_kernel<T, 4>), dim3(cdiv(nvec, 256)), dim3(256), stream, dy, x, dx, mean, var, eps, gamma,
-                   beta, act, slope, C, HW / 4, nvec, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc);
+                   beta, act, slope, C, HW / 4, nvec, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc, dx_add);
     } else {
       const long nvec = (long)B * C * HW;
       CENET_LAUNCH((bn_bwd_apply_flat_kernel<T, 1>), dim3(cdiv(nvec, 256)), dim3(256), stream, dy, x, dx, mean, var, eps, gamma,
-                   beta, act, slope, C, HW, nvec, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc);
+                   beta, act, slope, C, HW, nvec, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc, dx_add);
     }
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }
-  if (bn_v4_ok<T>(HW, dy, sgb, x, sxb, dx, sdb)) {
+  if (bn_v4_ok<T>(HW, dy, sgb, x, sxb, dx, sdb) && bn_v4_ok<T>(HW, dx_add, sab, x, sxb, dx, sdb)) {
     const int S = bn_splits_v4(C, total / 4);
     CENET_LAUNCH((bn_bwd_partial_v4_kernel<T>), dim3(C, S), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma, beta, act,
                  slope, B, HW, ws);
     int threads, chunks;
     bn_plane_launch(HW / 4, &threads, &chunks);
     CENET_LAUNCH((bn_bwd_apply_v4_kernel<T>), dim3(B * C, chunks), dim3(threads), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps,
-                 gamma, beta, act, slope, C, HW, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc);
+                 gamma, beta, act, slope, C, HW, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc, dx_add, sab);
   } else {
     const int S = bn_splits(C, total);
     CENET_LAUNCH((bn_bwd_partial_kernel<T>), dim3(C, S), dim3(256), stream, dy, sgb, x, sxb, mean, var, eps, gamma, beta, act, slope,
@@ -1337,7 +1347,7 @@ static int bn_bwd_acc_impl(const T* dy, long sgb, const T* x, long sxb, T* dx, l
     int chunks = cdiv(HW, 1024);
     if (chunks > 64) chunks = 64;
     CENET_LAUNCH((bn_bwd_apply_kernel<T>), dim3(B * C, chunks), dim3(256), stream, dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma,
-                 beta, act, slope, C, HW, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc);
+                 beta, act, slope, C, HW, (float)total, (const float*)ws, S, dgamma_acc, dbeta_acc, dx_add, sab);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
@@ -1346,3 +1356,18 @@ CENET_TWIN(bn_bwd_acc, (const T* dy, long sgb, const T* x, long sxb, T* dx, long
                         float eps, const float* gamma, const float* beta, int act, float slope, int B, int C, int HW, float* ws,
                         float* dgamma_acc, float* dbeta_acc, hipStream_t stream),
            (dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma, beta, act, slope, B, C, HW, ws, dgamma_acc, dbeta_acc, stream))
+// ... + dx_add (batch stride sab): the gradient of a residual connection that by-passed this BatchNorm (cfam.py:365-374: x +
+// ls * branch(BN(x))) added by the kernel that writes dx, instead of an aten::add behind it
+template <typename T>
+static int bn_bwd_add_acc_impl(const T* dy, long sgb, const T* x, long sxb, T* dx, long sdb, const T* dx_add, long sab,
+                               const float* mean, const float* var, float eps, const float* gamma, const float* beta, int act,
+                               float slope, int B, int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc,
+                               hipStream_t stream) {
+  return bn_bwd_acc_impl<T>(dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma, beta, act, slope, B, C, HW, ws, dgamma_acc, dbeta_acc,
+                            stream, dx_add, sab);
+}
+CENET_TWIN(bn_bwd_add_acc, (const T* dy, long sgb, const T* x, long sxb, T* dx, long sdb, const T* dx_add, long sab,
+                            const float* mean, const float* var, float eps, const float* gamma, const float* beta, int act,
+                            float slope, int B, int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, hipStream_t stream),
+           (dy, sgb, x, sxb, dx, sdb, dx_add, sab, mean, var, eps, gamma, beta, act, slope, B, C, HW, ws, dgamma_acc, dbeta_acc,
+            stream))

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const T* __restrict_
                                                            const float* __restrict__ u, const int* __restrict__ amax,
                                                            const float* __restrict__ fc1, const float* __restrict__ fc2,
                                                            float* __restrict__ dfc1, float* __restrict__ dfc2,
-                                                           T* __restrict__ dx, int C, int HWv) {
+                                                           T* __restrict__ dx, int C, int HWv, const T* __restrict__ dx_add) {
   __shared__ float du_s[3];
   const int bc = blockIdx.x, c = bc % C, HW = HWv * V;
   if (threadIdx.x == 0) {
@@ -239,15 +239,19 @@ __global__ __launch_bounds__(256) void ccu_bwd_apply_kernel(const T* __restrict_
   const T* xp = x + (long)bc * HW;
   const T* gp = dy + (long)bc * HW;
   T* dp = dx + (long)bc * HW;
+  const T* ap = dx_add ? dx_add + (long)bc * HW : nullptr;  // gradient of x's other consumer (cfam.py:298-303: the shortcut)
   for (int p = threadIdx.x; p < HWv; p += 256) {
-    float xv[V], gv[V];
+    float xv[V], gv[V], av[V];
     ldv<V>(xv, xp + p * V);
     ldv<V>(gv, gp + p * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) av[e] = 0.f;
+    if (ap) ldv<V>(av, ap + p * V);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       float v = gv[e] * sg + dmean + dstd * (xv[e] - mean);
       if (p * V + e == am) v += dmax;
-      gv[e] = v;
+      gv[e] = v + av[e];
     }
     stv<V>(dp + p * V, gv);
   }
@@ -686,14 +690,14 @@ CENET_TWIN(gate_chan_bwd_reduce, (const T* x, const T* dy, const float* g, float
 template <typename T>
 static int ccu_bwd_apply_acc_impl(const T* x, const T* dy, const float* g, const float* dz, const float* u, const int* amax,
                                   const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc, T* dx, int B, int C,
-                                  int HW, hipStream_t stream) {
+                                  int HW, hipStream_t stream, const T* dx_add = nullptr) {
   if (B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
-  if (plane_vw<T>(HW, x, dy, dx) == 4)
+  if (plane_vw<T>(HW, x, dy, dx) == 4 && (!dx_add || plane_vw<T>(HW, dx_add, dy, dx) == 4))
     CENET_LAUNCH((ccu_bwd_apply_kernel<T, 4>), dim3(B * C), dim3(256), stream, x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc,
-                 dx, C, HW / 4);
+                 dx, C, HW / 4, dx_add);
   else
     CENET_LAUNCH((ccu_bwd_apply_kernel<T, 1>), dim3(B * C), dim3(256), stream, x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc,
-                 dx, C, HW);
+                 dx, C, HW, dx_add);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -701,6 +705,17 @@ CENET_TWIN(ccu_bwd_apply_acc, (const T* x, const T* dy, const float* g, const fl
                                const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc, T* dx, int B, int C, int HW,
                                hipStream_t stream),
            (x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc, dx, B, C, HW, stream))
+// ... + dx_add (contiguous, like x): the gradient of x's other consumer (the MCA shortcut, cfam.py:298-303) added by this kernel
+template <typename T>
+static int ccu_bwd_apply_add_acc_impl(const T* x, const T* dy, const float* g, const float* dz, const float* u, const int* amax,
+                                      const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc, T* dx, const T* dx_add,
+                                      int B, int C, int HW, hipStream_t stream) {
+  return ccu_bwd_apply_acc_impl<T>(x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc, dx, B, C, HW, stream, dx_add);
+}
+CENET_TWIN(ccu_bwd_apply_add_acc, (const T* x, const T* dy, const float* g, const float* dz, const float* u, const int* amax,
+                                   const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc, T* dx, const T* dx_add,
+                                   int B, int C, int HW, hipStream_t stream),
+           (x, dy, g, dz, u, amax, fc1, fc2, dfc1_acc, dfc2_acc, dx, dx_add, B, C, HW, stream))
 
 template <typename T>
 static int srm_stats_fwd_impl(const T* x, float* u, int* amax, int B, int C, int HW, hipStream_t stream) {

@@ -401,10 +401,16 @@ def bn_apply(x, sxb, y, syb, mean, var, eps, gamma, beta, act, slope, B, Cn, HW)
     _call("cenet_bn_apply_f32", x, L(sxb), y, L(syb), mean, var, float(eps), gamma, beta, ACT[act], float(slope), B, Cn, HW)
 
 
-def bn_bwd(dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma, beta, act, slope, B, Cn, HW, ws, dgamma, dbeta):
-    _chk(dy, x, dx, mean, var, gamma, beta, ws, dgamma, dbeta)
-    _call("cenet_bn_bwd_acc_f32", dy, L(sgb), x, L(sxb), dx, L(sdb), mean, var, float(eps), gamma, beta, ACT[act],
-          float(slope), B, Cn, HW, ws, dgamma, dbeta)
+def bn_bwd(dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma, beta, act, slope, B, Cn, HW, ws, dgamma, dbeta, dx_add=None):
+    """dx_add (contiguous [B, C, HW], optional): added to dx by the kernel that writes it (the gradient of a residual connection
+    around the BatchNorm)"""
+    _chk(dy, x, dx, mean, var, gamma, beta, ws, dgamma, dbeta, dx_add)
+    if dx_add is None:
+        _call("cenet_bn_bwd_acc_f32", dy, L(sgb), x, L(sxb), dx, L(sdb), mean, var, float(eps), gamma, beta, ACT[act],
+              float(slope), B, Cn, HW, ws, dgamma, dbeta)
+    else:
+        _call("cenet_bn_bwd_add_acc_f32", dy, L(sgb), x, L(sxb), dx, L(sdb), dx_add, L(Cn * HW), mean, var, float(eps), gamma, beta,
+              ACT[act], float(slope), B, Cn, HW, ws, dgamma, dbeta)
 
 
 # ---- depthwise conv ------------------------------------------------------------------------------------
@@ -581,9 +587,12 @@ def gate_chan_bwd_reduce(x, dy, g, dg, BC, HW):
     _call("cenet_gate_chan_bwd_reduce_f32", x, dy, g, dg, BC, HW)
 
 
-def ccu_bwd_apply(x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx, B, Cn, HW):
-    _chk(x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx)
-    _call("cenet_ccu_bwd_apply_acc_f32", x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx, B, Cn, HW)
+def ccu_bwd_apply(x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx, B, Cn, HW, dx_add=None):
+    _chk(x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx, dx_add)
+    if dx_add is None:
+        _call("cenet_ccu_bwd_apply_acc_f32", x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx, B, Cn, HW)
+    else:
+        _call("cenet_ccu_bwd_apply_add_acc_f32", x, dy, g, dz, u, amax, fc1, fc2, dfc1, dfc2, dx, dx_add, B, Cn, HW)
 
 
 def srm_stats_fwd(x, u, amax, B, Cn, HW):
@@ -634,6 +643,16 @@ def cat_channels(parts, joined, B, HW, split=False):
     ps = list(parts) + [None] * (4 - len(parts))
     cs = [int(t.shape[1]) for t in parts] + [0] * (4 - len(parts))
     _call("cenet_cat_channels_f32", *ps, *cs, joined, B, L(HW), int(split))
+
+
+def split_channels_add(parts, adds, joined, B, HW):
+    """parts[j] [B, c_j, HW] = channel slice j of joined + adds[j] (None: the slice alone); at most four parts, one launch"""
+    assert 1 <= len(parts) <= 4 and len(adds) == len(parts)
+    _chk(joined, *parts, *adds)
+    ps = list(parts) + [None] * (4 - len(parts))
+    ads = list(adds) + [None] * (4 - len(adds))
+    cs = [int(t.shape[1]) for t in parts] + [0] * (4 - len(parts))
+    _call("cenet_split_channels_add_f32", *ps, *ads, *cs, joined, B, L(HW))
 
 
 def im2col_tok(src, dst, B, H, W, C, K, stride, pad, inverse=False):

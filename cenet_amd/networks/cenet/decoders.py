@@ -39,6 +39,8 @@ class Decoder(nn.Module):
         d = self.dec4(x)
         for lvl, s in zip((3, 2, 1), skips):
             d = getattr(self, f"up{lvl}")(d)
-            e = getattr(self, f"skip_enhancer{lvl}")(s, d)
+            se = getattr(self, f"skip_enhancer{lvl}")
+            e = se(s, d)
+            d, se.dec_tap = se.dec_tap, None  # (d itself, routed through the block's concat node: see DSEBlock.forward)
             d = getattr(self, f"dec{lvl}")(ops.add_act(d, e))
         return d

@@ -8,10 +8,11 @@ import torch.nn as nn
 from .... import ops
 
 
-def bn_call(bn: nn.BatchNorm2d, x, act="none", slope=0.0):
-    """Train/eval BatchNorm (+fused activation) through the HIP kernels using the container's tensors."""
+def bn_call(bn: nn.BatchNorm2d, x, act="none", slope=0.0, tap=False):
+    """Train/eval BatchNorm (+fused activation) through the HIP kernels using the container's tensors.
+    tap=True: returns (y, x_tap) — x itself routed through the BatchNorm's autograd node, for the residual connection around it"""
     return ops.batchnorm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training,
-                         bn.eps, act, slope, bn.momentum if bn.momentum is not None else 0.1)
+                         bn.eps, act, slope, bn.momentum if bn.momentum is not None else 0.1, tap)
 
 
 def _init_conv(m, scheme="normal"):

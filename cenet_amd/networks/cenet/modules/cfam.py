@@ -141,10 +141,10 @@ class CCU(nn.Module):
         self.fc2 = nn.Conv1d(3 * channel, channel, kernel_size=1, groups=channel, bias=False)
         self.bn = nn.BatchNorm1d(channel)
 
-    def forward(self, x):
+    def forward(self, x, tap=False):
         b = self.bn
         return ops.ccu(x, self.fc1.weight, self.fc2.weight, b.weight, b.bias, b.running_mean, b.running_var,
-                       b.num_batches_tracked, b.training)
+                       b.num_batches_tracked, b.training, tap)
 
 
 class MCA(nn.Module):
@@ -162,8 +162,7 @@ class MCA(nn.Module):
         self.ccu = CCU(embed_dims)
 
     def forward(self, x):
-        shortcut = x
-        x = self.ccu(x)
+        x, shortcut = self.ccu(x, True)  # (shortcut = x itself, through the CCU's autograd node: its gradient joins in that kernel)
         g, x = ops.conv1x1(x, self.gate.weight, self.gate.bias, tap=True)  # value's gradient joins inside gate's dgrad GEMM
         v = self.value(x)
         x = ops.conv1x1(ops.silu_mul(g, v), self.proj_2.weight, self.proj_2.bias, resid=shortcut)
@@ -187,6 +186,10 @@ class CFAModule(nn.Module):
         self.layer_scale_2 = nn.Parameter(init_value * torch.ones((1, embed_dims, 1, 1)), requires_grad=True)
 
     def forward(self, x):
-        x = ops.scale_residual(x, self.mca(bn_call(self.norm1, x)), self.layer_scale_1)
-        x = ops.scale_residual(x, self.mlp(bn_call(self.norm2, x)), self.layer_scale_2)
+        # (taps: the residual connection reads x through the BatchNorm's autograd node, whose backward kernel then writes the sum
+        # of both gradients of x — no aten::add behind it)
+        y, x = bn_call(self.norm1, x, tap=True)
+        x = ops.scale_residual(x, self.mca(y), self.layer_scale_1)
+        y, x = bn_call(self.norm2, x, tap=True)
+        x = ops.scale_residual(x, self.mlp(y), self.layer_scale_2)
         return x

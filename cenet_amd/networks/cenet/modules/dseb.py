@@ -45,9 +45,14 @@ class DSEBlock(nn.Module):
         self.boundary = FEA(dim=_dim, scale_factors=scale_factors, label=label, writer=writer)
         self.diffattn = MultiheadDiffAttn(embed_dim=_dim, depth=depth, num_heads=num_heads)
         self.mixer = nn.Conv2d(_dim, dim, kernel_size=1, stride=1, bias=False)
+        self.dec_tap = None  # (set by forward, taken by Decoder.forward)
 
     def forward(self, skip, dec):
-        y = ops.concat2(dec, skip)
+        # dec has a second consumer in the decoder (decoders.py:96, the residual add).  It reads `self.dec_tap` (dec itself, routed
+        # through the concat's autograd node) so that both of dec's gradients — and both of skip's — meet in the concat's backward
+        # kernel (ops.Concat2Fn) instead of two aten::add launches per level
+        y, dec, skip = ops.concat2(dec, skip, tap=True)
+        self.dec_tap = dec
         B, C2, H, W = y.shape
         # dseb.py:115: the flat NCHW buffer re-read as [B, HW, 2C] tokens (a view, not a permute)
         diff = self.diffattn(y.view(B, H * W, C2)).view(B, C2, H, W)

@@ -939,8 +939,12 @@ def layernorm_res(x, gamma, beta, eps):
 # BatchNorm (+ fused activation) on NCHW or [B,C]  (cfam.py:22-32; blocks.py; nlb.py:81; unet.py:175-197)
 # =====================================================================================================
 class BatchNormFn(Function):
+    """tap: also returns x itself (x_tap).  The residual connection around the normalised branch (cfam.py:365-374: x + ls *
+    branch(BN(x))) reads the TAP, so its gradient arrives here and the kernel that writes dx adds it (as LayerNormResFn does for
+    the encoder blocks) instead of an aten::add launched by autograd."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, rmean, rvar, nbt, training, eps, act, slope, momentum):
+    def forward(ctx, x, weight, bias, rmean, rvar, nbt, training, eps, act, slope, momentum, tap=False):
         x = _c(x)
         B, Cn = x.shape[:2]
         HW = x.numel() // (B * Cn)
@@ -956,16 +960,20 @@ class BatchNormFn(Function):
         ctx.save_for_backward(x, weight, bias, mean, var)
         ctx.refs = (weight, bias)
         ctx.cfg = (training, eps, act, slope)
-        return y
+        return (y, x.view_as(x)) if tap else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_tap=None):
         x, weight, bias, mean, var = ctx.saved_tensors
         wp, bp = ctx.refs
         training, eps, act, slope = ctx.cfg
+        if g is None:  # only the tap carried a gradient
+            return (g_tap,) + (None,) * 11
         if not training:
             raise RuntimeError("cenet_amd BatchNorm backward is implemented for training mode only")
         g = _c(g)
+        if g_tap is not None:
+            g_tap = _c(g_tap) if g_tap.dtype == g.dtype else _c(g_tap.to(g.dtype))
         B, Cn = x.shape[:2]
         HW = x.numel() // (B * Cn)
         dx = torch.empty_like(x)
@@ -973,12 +981,14 @@ class BatchNormFn(Function):
         dg, db = grad_buf(wp), grad_buf(bp)
         if dg is None:
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
-        kern.bn_bwd(g, Cn * HW, x, Cn * HW, dx, Cn * HW, mean, var, eps, weight, bias, act, slope, B, Cn, HW, ws, dg, db)
-        return (dx,) + (None,) * 10
+        kern.bn_bwd(g, Cn * HW, x, Cn * HW, dx, Cn * HW, mean, var, eps, weight, bias, act, slope, B, Cn, HW, ws, dg, db,
+                    dx_add=g_tap)
+        return (dx,) + (None,) * 11
 
 
-def batchnorm(x, weight, bias, rmean, rvar, nbt, training, eps=1e-5, act="none", slope=0.0, momentum=0.1):
-    return BatchNormFn.apply(x, weight, bias, rmean, rvar, nbt, training, eps, act, slope, momentum)
+def batchnorm(x, weight, bias, rmean, rvar, nbt, training, eps=1e-5, act="none", slope=0.0, momentum=0.1, tap=False):
+    """tap=True returns (y, x_tap): hand x_tap (not x) to the residual connection around the normalised branch"""
+    return BatchNormFn.apply(x, weight, bias, rmean, rvar, nbt, training, eps, act, slope, momentum, tap)
 
 
 # =====================================================================================================
@@ -1611,32 +1621,43 @@ def tok_to_nchw(x, H, Wd):
 
 
 class Concat2Fn(Function):
-    """torch.cat([a, b], dim=1) for NCHW (dseb.py:156, out.py:63)."""
+    """torch.cat([a, b], dim=1) for NCHW (dseb.py:156, out.py:63).
+    tap: also returns a and b themselves (a_tap, b_tap); further consumers of a / b that read the TAPS send their gradients through
+    this node, where the split kernel adds them to the slices (dseb.py:156-164 + decoders.py:96: `dec` and `skip` each have a
+    second consumer) instead of one aten::add per input."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, tap=False):
         a, b = _c(a), _c(b)
         B, Ca = a.shape[:2]
         Cb = b.shape[1]
         HW = a.numel() // (B * Ca)
         y = _act((B, Ca + Cb) + tuple(a.shape[2:]), a)
         kern.cat_channels([a, b], y, B, HW)
-        ctx.dims = (Ca, Cb, HW)
-        return y
+        ctx.dims = (Ca, Cb, HW, tuple(a.shape), tuple(b.shape))
+        return (y, a.view_as(a), b.view_as(b)) if tap else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, ga=None, gb=None):
+        Ca, Cb, HW, sa, sb = ctx.dims
+        if g is None:  # only the taps carried gradients
+            return ga, gb, None
         g = _c(g)
-        Ca, Cb, HW = ctx.dims
         B = g.shape[0]
-        da = _act((B, Ca) + tuple(g.shape[2:]), g)
-        db = _act((B, Cb) + tuple(g.shape[2:]), g)
-        kern.cat_channels([da, db], g, B, HW, split=True)
-        return da, db
+        da = _act(sa, g)
+        db = _act(sb, g)
+        ga = _c(ga) if ga is not None and ga.dtype == g.dtype else (None if ga is None else ga.to(g.dtype))
+        gb = _c(gb) if gb is not None and gb.dtype == g.dtype else (None if gb is None else gb.to(g.dtype))
+        if ga is None and gb is None:
+            kern.cat_channels([da, db], g, B, HW, split=True)
+        else:
+            kern.split_channels_add([da, db], [ga, gb], g, B, HW)
+        return da, db, None
 
 
-def concat2(a, b):
-    return Concat2Fn.apply(a, b)
+def concat2(a, b, tap=False):
+    """tap=True returns (cat, a_tap, b_tap): hand the taps (not a / b) to the other consumers of a and b"""
+    return Concat2Fn.apply(a, b, tap)
 
 
 class SplitChannelsFn(Function):
@@ -2102,8 +2123,11 @@ def batch1_semantics(on: bool = True):
 
 
 class CCUFn(Function):
+    """tap: also returns x itself; x's other consumer (the MCA shortcut, cfam.py:298-303) reads the tap and its gradient is added by
+    this node's data-gradient kernel"""
+
     @staticmethod
-    def forward(ctx, x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training):
+    def forward(ctx, x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training, tap=False):
         x = _c(x)
         B, Cn, H, Wd = x.shape
         HW = H * Wd
@@ -2129,13 +2153,17 @@ class CCUFn(Function):
         ctx.save_for_backward(x, fc1, fc2, u, amax, z, zn, mean, var, bn_w, bn_b)
         ctx.refs = (fc1, fc2, bn_w, bn_b)
         ctx.cfg = (use_bn, training)
-        return y
+        return (y, x.view_as(x)) if tap else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_tap=None):
         x, fc1, fc2, u, amax, z, zn, mean, var, bn_w, bn_b = ctx.saved_tensors
         use_bn, training = ctx.cfg
+        if g is None:
+            return (g_tap,) + (None,) * 9
         g = _c(g)
+        if g_tap is not None:
+            g_tap = _c(g_tap) if g_tap.dtype == g.dtype else _c(g_tap.to(g.dtype))
         B, Cn, H, Wd = x.shape
         HW = H * Wd
         dzn = _empty((B, Cn), x)
@@ -2155,12 +2183,13 @@ class CCUFn(Function):
         if d1 is None:
             d1, d2 = _zeros(fc1.shape, x), _zeros(fc2.shape, x)
         dx = torch.empty_like(x)
-        kern.ccu_bwd_apply(x, g, zn, dz, u, amax, fc1, fc2, d1, d2, dx, B, Cn, HW)
-        return (dx,) + (None,) * 8
+        kern.ccu_bwd_apply(x, g, zn, dz, u, amax, fc1, fc2, d1, d2, dx, B, Cn, HW, dx_add=g_tap)
+        return (dx,) + (None,) * 9
 
 
-def ccu(x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training):
-    return CCUFn.apply(x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training)
+def ccu(x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training, tap=False):
+    """tap=True returns (y, x_tap): hand x_tap (not x) to x's other consumer"""
+    return CCUFn.apply(x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training, tap)
 
 
 class SRMFn(Function):

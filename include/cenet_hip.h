@@ -268,6 +268,12 @@ int cenet_bn_train_fwd_f32(const float* x, long sxb, float* y, long syb, float* 
 int cenet_bn_bwd_acc_f32(const float* dy, long sgb, const float* x, long sxb, float* dx, long sdb, const float* mean,
                          const float* var, float eps, const float* gamma, const float* beta, int act, float slope, int B,
                          int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, cenet_stream_t stream);
+/* ... + dx_add (batch stride sab, may be NULL): dx = BatchNormBackward(dy) + dx_add — the gradient of the residual connection
+ * around the normalised branch (cfam.py:365-374) added by the kernel that writes dx (round 4) */
+int cenet_bn_bwd_add_acc_f32(const float* dy, long sgb, const float* x, long sxb, float* dx, long sdb, const float* dx_add,
+                             long sab, const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                             int act, float slope, int B, int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc,
+                             cenet_stream_t stream);
 
 /* ---- depthwise 3x3 conv (dwconv.hip) — aten::convolution(groups=C)(+_backward) ------------------------------ */
 /* pvtv2.py:359-370 (token layout), cfam.py:132-140, blocks.py:142-150,305 (NCHW). y = conv(x)+bias; a = act(y) if a. */
@@ -363,6 +369,11 @@ int cenet_gate_chan_bwd_reduce_f32(const float* x, const float* dy, const float*
 int cenet_ccu_bwd_apply_acc_f32(const float* x, const float* dy, const float* g, const float* dz, const float* u,
                                 const int* amax, const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc,
                                 float* dx, int B, int C, int HW, cenet_stream_t stream);
+/* ... + dx_add (like x, may be NULL): the gradient of x's other consumer (the MCA shortcut, cfam.py:298-303), added by the kernel
+ * that writes dx (round 4) */
+int cenet_ccu_bwd_apply_add_acc_f32(const float* x, const float* dy, const float* g, const float* dz, const float* u,
+                                    const int* amax, const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc,
+                                    float* dx, const float* dx_add, int B, int C, int HW, cenet_stream_t stream);
 int cenet_srm_stats_fwd_f32(const float* x, float* u, int* amax, int B, int C, int HW, cenet_stream_t stream);
 int cenet_srm_conv_fwd_f32(const float* u, const float* pwc, const float* dwc, float* f, int B, int H, int W,
                            cenet_stream_t stream);
@@ -383,6 +394,12 @@ int cenet_copy_batched_f32(const float* x, long sxb, float* y, long syb, int B, 
  * MultiOrderDWConv branches), modules/dseb.py:156, out.py:63. */
 int cenet_cat_channels_f32(float* p0, float* p1, float* p2, float* p3, int c0, int c1, int c2, int c3, float* joined, int B,
                            long HW, int split, cenet_stream_t stream);
+/* The split with addends (round 4): p_j = channel slice j of joined + a_j (a_j NULL: the slice alone).  Backward of a concat whose
+ * inputs have further consumers (dseb.py:156-164: `dec` also feeds decoders.py:96's residual add, `skip` the mixer's residual):
+ * the gradients that reached the inputs along those paths are added by this launch instead of one aten::add each. */
+int cenet_split_channels_add_f32(float* p0, float* p1, float* p2, float* p3, const float* a0, const float* a1, const float* a2,
+                                 const float* a3, int c0, int c1, int c2, int c3, const float* joined, int B, long HW,
+                                 cenet_stream_t stream);
 /* Space-to-depth of a token map for the kernel == stride spatial-reduction conv (reference networks/cenet/pvtv2.py:93-95,
  * `self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)` applied to x.permute(0,2,1).reshape(B,C,H,W)):
  * inverse == 0 gathers tok [B, Ho*S, Wo*S, C] into patch rows [B*Ho*Wo, C*S*S] (k = (c, ky, kx), the weight's own order);
@@ -492,6 +509,9 @@ int cenet_copy_batched_bf16(const unsigned short* x, long sxb, unsigned short* y
     cenet_stream_t stream);
 int cenet_cat_channels_bf16(unsigned short* p0, unsigned short* p1, unsigned short* p2, unsigned short* p3, int c0, int c1,
     int c2, int c3, unsigned short* joined, int B, long HW, int split, cenet_stream_t stream);
+int cenet_split_channels_add_bf16(unsigned short* p0, unsigned short* p1, unsigned short* p2, unsigned short* p3,
+    const unsigned short* a0, const unsigned short* a1, const unsigned short* a2, const unsigned short* a3, int c0, int c1, int c2,
+    int c3, const unsigned short* joined, int B, long HW, cenet_stream_t stream);
 int cenet_patch_tok_bf16(const unsigned short* src, unsigned short* dst, int B, int Ho, int Wo, int C, int S, int inverse,
     cenet_stream_t stream);
 int cenet_im2col_tok_bf16(const unsigned short* src, unsigned short* dst, int B, int H, int W, int C, int K, int stride,
@@ -556,6 +576,9 @@ int cenet_bn_train_fwd_bf16(const unsigned short* x, long sxb, unsigned short* y
 int cenet_bn_bwd_acc_bf16(const unsigned short* dy, long sgb, const unsigned short* x, long sxb, unsigned short* dx, long
     sdb, const float* mean, const float* var, float eps, const float* gamma, const float* beta, int act, float slope, int B,
     int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, cenet_stream_t stream);
+int cenet_bn_bwd_add_acc_bf16(const unsigned short* dy, long sgb, const unsigned short* x, long sxb, unsigned short* dx, long sdb,
+    const unsigned short* dx_add, long sab, const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+    int act, float slope, int B, int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc, cenet_stream_t stream);
 /* resample.hip */
 int cenet_bilinear_fwd_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, int C, int Hi, int Wi,
     int Ho, int Wo, float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
@@ -583,6 +606,9 @@ int cenet_gate_chan_bwd_reduce_bf16(const unsigned short* x, const unsigned shor
 int cenet_ccu_bwd_apply_acc_bf16(const unsigned short* x, const unsigned short* dy, const float* g, const float* dz, const
     float* u, const int* amax, const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc, unsigned short* dx, int
     B, int C, int HW, cenet_stream_t stream);
+int cenet_ccu_bwd_apply_add_acc_bf16(const unsigned short* x, const unsigned short* dy, const float* g, const float* dz, const
+    float* u, const int* amax, const float* fc1, const float* fc2, float* dfc1_acc, float* dfc2_acc, unsigned short* dx, const
+    unsigned short* dx_add, int B, int C, int HW, cenet_stream_t stream);
 int cenet_srm_stats_fwd_bf16(const unsigned short* x, float* u, int* amax, int B, int C, int HW, cenet_stream_t stream);
 int cenet_gate_pix_fwd_bf16(const unsigned short* x, const float* f, unsigned short* y, int B, int C, int HW, cenet_stream_t
     stream);

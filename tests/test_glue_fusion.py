@@ -157,3 +157,62 @@ def test_sra_backward_accumulator_is_zero_at_rest(dev, monkeypatch):
             assert torch.equal(x[1], ref[1])
         else:
             torch.testing.assert_close(x[1].float(), ref[1].float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+def test_concat_backward_adds_the_gradients_of_its_inputs_other_consumers(dev, dt):
+    """y = cat(a, b); a and b each have a second consumer reading the tap: one split launch writes slice + other gradient"""
+    g = torch.Generator().manual_seed(4)
+    B, Ca, Cb, H, W = 2, 8, 24, 7, 7
+    a0 = torch.randn(B, Ca, H, W, generator=g).to(dt).to(dev)
+    b0 = torch.randn(B, Cb, H, W, generator=g).to(dt).to(dev)
+    wy = torch.randn(B, Ca + Cb, H, W, generator=g).to(dt).to(dev)
+    wa = torch.randn(B, Ca, H, W, generator=g).to(dt).to(dev)
+    wb = torch.randn(B, Cb, H, W, generator=g).to(dt).to(dev)
+    res = []
+    for tap in (True, False):
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        if tap:
+            y, at, bt = ops.concat2(a, b, tap=True)
+        else:
+            y, at, bt = ops.concat2(a, b), a, b
+        ((y.float() * wy.float()).sum() + (at.float() * wa.float()).sum() + (bt.float() * wb.float()).sum()).backward()
+        res.append((y.detach(), a.grad, b.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    tol = dict(rtol=0, atol=0) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)  # (bf16: one rounding instead of two)
+    torch.testing.assert_close(res[0][1].float(), res[1][1].float(), **tol)
+    torch.testing.assert_close(res[0][2].float(), res[1][2].float(), **tol)
+    # only one of the taps used / none used
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    y, at, bt = ops.concat2(a, b, tap=True)
+    ((y.float() * wy.float()).sum() + (bt.float() * wb.float()).sum()).backward()
+    torch.testing.assert_close(a.grad.float(), wy[:, :Ca].float(), **tol)
+    torch.testing.assert_close(b.grad.float(), (wy[:, Ca:].float() + wb.float()), **tol)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+@pytest.mark.parametrize("B,Cn,H,W", [(2, 16, 7, 7), (3, 8, 14, 14), (2, 8, 40, 36), (1, 24, 5, 3), (2, 4, 64, 66)])
+def test_batchnorm_backward_adds_the_residual_gradient(dev, dt, B, Cn, H, W):
+    """x + f(BN(x)) with the residual reading the tap: same gradients as the untapped form (every plane-size class of the backward)"""
+    g = torch.Generator().manual_seed(B * 100 + Cn)
+    x0 = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    wy = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    wr = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    res = []
+    for tap in (True, False):
+        x = x0.clone().requires_grad_(True)
+        gam = (1 + 0.1 * torch.arange(Cn, dtype=torch.float32)).to(dev).requires_grad_(True)
+        bet = (0.05 * torch.arange(Cn, dtype=torch.float32)).to(dev).requires_grad_(True)
+        rm, rv, nbt = torch.zeros(Cn).to(dev), torch.ones(Cn).to(dev), torch.zeros((), dtype=torch.long).to(dev)
+        gam.grad, bet.grad = torch.zeros_like(gam), torch.zeros_like(bet)
+        if tap:
+            y, xt = ops.batchnorm(x, gam, bet, rm, rv, nbt, True, 1e-5, "lrelu", 0.01, 0.1, tap=True)
+        else:
+            y, xt = ops.batchnorm(x, gam, bet, rm, rv, nbt, True, 1e-5, "lrelu", 0.01, 0.1), x
+        ((y.float() * wy.float()).sum() + (xt.float() * wr.float()).sum()).backward()
+        res.append((y.detach(), x.grad, gam.grad, bet.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    tol = dict(rtol=1e-6, atol=1e-6) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(res[0][1].float(), res[1][1].float(), **tol)
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(res[0][3], res[1][3], rtol=1e-4, atol=1e-4)
