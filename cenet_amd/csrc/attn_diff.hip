@@ -69,6 +69,7 @@ struct DiffArgs {
   bf* aug;              // [B, 2H, N, 16]: lse/scale as 3 bf16 terms at [0..2], delta at [8..10] (written by dQ, read by dK/dV)
   int B, H, N, hd;
   float scale;
+  int bmul;             // batch stride of q / k / v / dq / dk / dv in units of their own [N, row] block (1: dense)
 };
 
 // ---- LDS images -------------------------------------------------------------------------------------------------------------
@@ -173,9 +174,9 @@ __global__ __launch_bounds__(256, MINB) void dattn_fwd_kernel(DiffArgs a) {
   const int q0 = (bid.x * 4 + wave) * (32 * QT);
   const int N = a.N, hd = a.hd, dv = 2 * hd, E = 2 * a.H * hd;
   const float c = a.scale * DA_LOG2E;
-  const bf* qb = a.q + (long)b * N * E;
-  const bf* kb = a.k + (long)b * N * E;
-  const bf* vb = a.v + (long)b * N * (a.H * dv) + h * dv;
+  const bf* qb = a.q + (long)b * a.bmul * N * E;
+  const bf* kb = a.k + (long)b * a.bmul * N * E;
+  const bf* vb = a.v + (long)b * a.bmul * N * (a.H * dv) + h * dv;
 
   // this thread's staged chunks (fixed for the whole key loop)
   DaChunk ch[CPT];
@@ -361,9 +362,9 @@ __global__ __launch_bounds__(256, HDP > 32 ? 1 : (HDP <= 16 ? 3 : 2)) void dattn
   const int q0 = (bid.x * 4 + wave) * 32;
   const int N = a.N, hd = a.hd, dv = 2 * hd, E = 2 * a.H * hd;
   const float c = a.scale * DA_LOG2E;
-  const bf* qb = a.q + (long)b * N * E;
-  const bf* kb = a.k + (long)b * N * E;
-  const bf* vb = a.v + (long)b * N * (a.H * dv) + h * dv;
+  const bf* qb = a.q + (long)b * a.bmul * N * E;
+  const bf* kb = a.k + (long)b * a.bmul * N * E;
+  const bf* vb = a.v + (long)b * a.bmul * N * (a.H * dv) + h * dv;
   const int qi = q0 + r < N ? q0 + r : N - 1;
 
   DaChunk ch[CPT];
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256, HDP > 32 ? 1 : (HDP <= 16 ? 3 : 2)) void dattn
   if (q0 + r < N) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf* dp = a.dq + ((long)b * N + qi) * E + (2 * h + s) * hd;
+      bf* dp = a.dq + ((long)b * a.bmul * N + qi) * E + (2 * h + s) * hd;
 #pragma unroll
       for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
@@ -521,9 +522,9 @@ __global__ __launch_bounds__(256, HDP > 32 ? 1 : 2) void dattn_bwd_dkv_kernel(Di
   const int k0 = (bid.x * 4 + wave) * 32;
   const int N = a.N, hd = a.hd, dv = 2 * hd, E = 2 * a.H * hd;
   const float c = a.scale * DA_LOG2E;
-  const bf* qb = a.q + (long)b * N * E;
-  const bf* kb = a.k + (long)b * N * E;
-  const bf* vb = a.v + (long)b * N * (a.H * dv) + h * dv;
+  const bf* qb = a.q + (long)b * a.bmul * N * E;
+  const bf* kb = a.k + (long)b * a.bmul * N * E;
+  const bf* vb = a.v + (long)b * a.bmul * N * (a.H * dv) + h * dv;
   const long hb0 = ((long)b * NH * a.H + NH * h) * N;  // (b, head 2h) row base of dU / aug; head 2h+1 is N rows further
   const int ki = k0 + r < N ? k0 + r : N - 1;
 
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(256, HDP > 32 ? 1 : 2) void dattn_bwd_dkv_kernel(Di
   if (k0 + r < N) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf* dp = a.dk + ((long)b * N + ki) * E + (2 * h + s) * hd;
+      bf* dp = a.dk + ((long)b * a.bmul * N + ki) * E + (2 * h + s) * hd;
 #pragma unroll
       for (int ft = 0; ft < NFT; ++ft)
 #pragma unroll
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(256, HDP > 32 ? 1 : 2) void dattn_bwd_dkv_kernel(Di
           }
         }
     }
-    bf* dvp = a.dv + ((long)b * N + ki) * (a.H * dv) + h * dv;
+    bf* dvp = a.dv + ((long)b * a.bmul * N + ki) * (a.H * dv) + h * dv;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -688,6 +689,7 @@ static int da_fill(DiffArgs& a, const cenet_diffattn_t* p) {
   a.U = (bf*)p->U; a.lse = p->lse; a.dU = (const bf*)p->dU;
   a.dq = (bf*)p->dq; a.dk = (bf*)p->dk; a.dv = (bf*)p->dv; a.aug = (bf*)p->ws;
   a.B = p->B; a.H = p->H; a.N = p->N; a.hd = p->hd; a.scale = p->scale;
+  a.bmul = p->batch_mul > 0 ? p->batch_mul : 1;
   const uintptr_t m = (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.U | (uintptr_t)a.dU | (uintptr_t)a.dq |
                       (uintptr_t)a.dk | (uintptr_t)a.dv | (uintptr_t)a.aug;
   if (m & 15) return CENET_EINVAL;  // rows are moved in 16-byte chunks
@@ -746,6 +748,7 @@ static int da_fill64(DiffArgs& a, const cenet_diffattn_t* p) {
   a.U = (bf*)p->U; a.lse = p->lse; a.dU = (const bf*)p->dU;
   a.dq = (bf*)p->dq; a.dk = (bf*)p->dk; a.dv = (bf*)p->dv; a.aug = (bf*)p->ws;
   a.B = p->B; a.H = p->H; a.N = p->N; a.hd = p->hd / 2; a.scale = p->scale;  // a head = a "pair" of two hd/2-wide halves
+  a.bmul = p->batch_mul > 0 ? p->batch_mul : 1;
   const uintptr_t m = (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.U | (uintptr_t)a.dU | (uintptr_t)a.dq |
                       (uintptr_t)a.dk | (uintptr_t)a.dv | (uintptr_t)a.aug;
   if (m & 15) return CENET_EINVAL;

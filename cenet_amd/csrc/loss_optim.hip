@@ -302,6 +302,32 @@ __global__ __launch_bounds__(256) void cast_clear4_kernel(float* __restrict__ x,
     st4(x + 4 * i, z);
   }
 }
+// the same with a per-column bias (rows of N columns, N % 4 == 0): y = bf16(x + bias[col]); x = 0 — the tail of a split-K Linear
+// whose partial sums were added atomically into the (zero-at-rest) fp32 accumulator x
+__global__ __launch_bounds__(256) void cast_clear_bias4_kernel(float* __restrict__ x, bf16_t* __restrict__ y,
+                                                              const float* __restrict__ bias, int N4, long nq) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nq; i += (long)gridDim.x * 256) {
+    f4 v = ld4(x + 4 * i);
+    const f4 b = ld4(bias + 4 * (int)(i % N4));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v.v[e] += b.v[e];
+    st4(y + 4 * i, v);
+    f4 z;
+    z.v[0] = z.v[1] = z.v[2] = z.v[3] = 0.f;
+    st4(x + 4 * i, z);
+  }
+}
+extern "C" int cenet_cast_clear_bias_f32_to_bf16(float* x, unsigned short* y, const float* bias, int N, long n,
+                                                 hipStream_t stream) {
+  if (!x || !y || !bias || n <= 0 || N <= 0 || (n % N) != 0) return CENET_EINVAL;
+  if ((N & 3) != 0 || !quad_aligned<float>(x) || !quad_aligned<bf16_t>((const bf16_t*)y) || !quad_aligned<float>(bias))
+    return CENET_EUNSUPPORTED;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  CENET_LAUNCH(cast_clear_bias4_kernel, dim3((unsigned)blocks), dim3(256), stream, x, (bf16_t*)y, bias, N / 4, n / 4);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
 extern "C" int cenet_cast_clear_f32_to_bf16(float* x, unsigned short* y, long n, hipStream_t stream) {
   if (!x || !y || n <= 0) return CENET_EINVAL;
   if ((n & 3) == 0 && quad_aligned<float>(x) && quad_aligned<bf16_t>((const bf16_t*)y)) {

@@ -262,7 +262,7 @@ def flash_bwd(a: AttnT, bf16: bool = False):
 class DiffAttnT(C.Structure):
     """cenet_diffattn_t (include/cenet_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "U", "lse", "dU", "dq", "dk", "dv", "ws")] + \
-               [(n, C.c_int) for n in ("B", "H", "N", "hd")] + [("scale", C.c_float)]
+               [(n, C.c_int) for n in ("B", "H", "N", "hd")] + [("scale", C.c_float), ("batch_mul", C.c_int)]
 
 
 def diffattn_heads_supported(hd: int, N: int) -> bool:
@@ -823,11 +823,15 @@ def cast(x: torch.Tensor, dtype) -> torch.Tensor:
     return y
 
 
-def cast_clear(x: torch.Tensor, y: torch.Tensor):
-    """y (bf16) = x (fp32, contiguous); x = 0 afterwards (see ops._zero_ws)"""
-    _chk(x, y)
+def cast_clear(x: torch.Tensor, y: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """y (bf16) = x (fp32, contiguous) [+ bias over the last axis]; x = 0 afterwards (see ops._ZeroWs)"""
+    _chk(x, y, bias)
     assert x.dtype == torch.float32 and y.dtype == BF16 and x.numel() == y.numel()
-    _lib.check(_lib.lib().cenet_cast_clear_f32_to_bf16(P(x), P(y), L(x.numel()), stream()), "cenet_cast_clear_f32_to_bf16")
+    if bias is None:
+        _lib.check(_lib.lib().cenet_cast_clear_f32_to_bf16(P(x), P(y), L(x.numel()), stream()), "cenet_cast_clear_f32_to_bf16")
+    else:
+        _lib.check(_lib.lib().cenet_cast_clear_bias_f32_to_bf16(P(x), P(y), P(bias), C.c_int(bias.numel()), L(x.numel()), stream()),
+                   "cenet_cast_clear_bias_f32_to_bf16")
 
 
 def cast_into(x: torch.Tensor, y: torch.Tensor):

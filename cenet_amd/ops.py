@@ -72,10 +72,10 @@ class _ZeroWs:
         return e[0].view(shape)
 
     @staticmethod
-    def give_back_as(ws: Tensor, like: Tensor) -> Tensor:
-        """-> a tensor of like's dtype (bf16) holding ws; ws is zero again"""
+    def give_back_as(ws: Tensor, like: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+        """-> a tensor of like's dtype (bf16) holding ws (+ bias over the last axis); ws is zero again"""
         out = torch.empty(ws.shape, device=ws.device, dtype=like.dtype)
-        kern.cast_clear(ws, out)
+        kern.cast_clear(ws, out, bias)
         _ZeroWs.bufs[(ws.device.type, ws.device.index, ws.numel())][1] = False
         return out
 
@@ -445,9 +445,16 @@ class LinearFn(Function):
         Wq = kern.wq(W, x)  # fp32 weight, or its bf16 shadow for bf16 activations
         if split_k and bscale is None and K >= 1024 and _bf(x):  # parity mode keeps a deterministic forward
             splits = kern.pick_splits(M, N, 1, K // 32)
-        if splits > 1:
-            # few output tiles under a long reduction: split K over workgroups; the partial sums are added atomically
-            # onto an fp32 output pre-filled with bias + residual, which is then rounded to the activation type
+        if splits > 1 and resid is None and N % 4 == 0 and (b is None or b.data_ptr() % 16 == 0):
+            # few output tiles under a long reduction (the spatial-reduction convs as GEMMs, K = C s^2): split K over workgroups; the
+            # partial sums are added atomically into a zero-at-rest fp32 accumulator, and one pass adds the bias, rounds to the
+            # activation type and leaves the accumulator zero (no bias pre-fill, no zero fill: 3 launches -> 2)
+            acc = _ZeroWs.take(shape, x)
+            kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(Wq, 1, K, kfast=1), acc, M, N, K, scr=N, scc=1,
+                      splits=splits, atomic=True)
+            y = _ZeroWs.give_back_as(acc, x, bias=b)
+        elif splits > 1:
+            # (general form) ... onto an fp32 output pre-filled with bias + residual, which is then rounded to the activation type
             if resid is not None:
                 y = _acc32(shape, x, resid)
                 if b is not None:
@@ -1503,18 +1510,21 @@ class NonlocalAttnJointFn(Function):
         ctx.dims = (B, Cn, N, tuple(tpg.shape))
         oshape = (B, Cn) + tuple(tpg.shape[2:])
         if ctx.tok64:
-            qt, kt, vt = (torch.empty((B, N, Cn), device=tpg.device, dtype=tpg.dtype) for _ in range(3))
-            for j, dst in enumerate((qt, kt, vt)):
-                kern.transpose(tpg, 3 * Cn * N, dst, Cn * N, B, Cn, N, x_off=j * Cn * N)
+            # token-major copies of theta | phi | g as ONE tensor [B, 3, N, C] (one transpose launch over 3 B planes); the
+            # attention kernels read the thirds in place (batch_mul = 3)
+            T = torch.empty((B, 3, N, Cn), device=tpg.device, dtype=tpg.dtype)
+            kern.transpose(tpg, Cn * N, T, Cn * N, 3 * B, Cn, N)
             U = torch.empty((B, 1, N, Cn), device=tpg.device, dtype=tpg.dtype)
             lse = torch.empty((B, 1, N), device=tpg.device, dtype=torch.float32)
             a = kern.DiffAttnT()
-            a.q, a.k, a.v, a.U, a.lse = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr()
-            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, Cn, Cn ** -0.5
+            e = T.element_size()
+            a.q, a.k, a.v = T.data_ptr(), T.data_ptr() + e * N * Cn, T.data_ptr() + 2 * e * N * Cn
+            a.U, a.lse = U.data_ptr(), lse.data_ptr()
+            a.B, a.H, a.N, a.hd, a.scale, a.batch_mul = B, 1, N, Cn, Cn ** -0.5, 3
             kern.attn64(a, backward=False)
             o = torch.empty(oshape, device=tpg.device, dtype=tpg.dtype)
             kern.transpose(U, N * Cn, o, Cn * N, B, N, Cn)
-            ctx.save_for_backward(qt, kt, vt, U, lse)
+            ctx.save_for_backward(T, U, lse)
             return o
         st, so = (3 * Cn * N, 0, 1, N), (Cn * N, 0, 1, N)
         d = _AttnDesc(B, 1, N, N, Cn, Cn, Cn ** -0.5, 1, st, st, st, so, qoff=0, koff=Cn * N, voff=2 * Cn * N)
@@ -1530,18 +1540,20 @@ class NonlocalAttnJointFn(Function):
         B, Cn, N, shape = ctx.dims
         dj = torch.empty(shape, device=g.device, dtype=g.dtype)
         if ctx.tok64:
-            qt, kt, vt, U, lse = ctx.saved_tensors
+            T, U, lse = ctx.saved_tensors
             gt = torch.empty_like(U)
             kern.transpose(g, Cn * N, gt, N * Cn, B, Cn, N)
-            dq, dk, dv = torch.empty_like(qt), torch.empty_like(kt), torch.empty_like(vt)
+            dT = torch.empty_like(T)  # dq | dk | dv, token-major, [B, 3, N, C]
             ws = torch.empty(kern.attn64_ws_bytes(B, 1, N), device=g.device, dtype=torch.uint8)
             a = kern.DiffAttnT()
-            a.q, a.k, a.v, a.U, a.lse, a.dU = qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), U.data_ptr(), lse.data_ptr(), gt.data_ptr()
-            a.dq, a.dk, a.dv, a.ws = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr()
-            a.B, a.H, a.N, a.hd, a.scale = B, 1, N, Cn, Cn ** -0.5
+            e = T.element_size()
+            a.q, a.k, a.v = T.data_ptr(), T.data_ptr() + e * N * Cn, T.data_ptr() + 2 * e * N * Cn
+            a.U, a.lse, a.dU = U.data_ptr(), lse.data_ptr(), gt.data_ptr()
+            a.dq, a.dk, a.dv = dT.data_ptr(), dT.data_ptr() + e * N * Cn, dT.data_ptr() + 2 * e * N * Cn
+            a.ws = ws.data_ptr()
+            a.B, a.H, a.N, a.hd, a.scale, a.batch_mul = B, 1, N, Cn, Cn ** -0.5, 3
             kern.attn64(a, backward=True)
-            for j, src in enumerate((dq, dk, dv)):
-                kern.transpose(src, N * Cn, dj, 3 * Cn * N, B, N, Cn, y_off=j * Cn * N)
+            kern.transpose(dT, N * Cn, dj, Cn * N, 3 * B, N, Cn)  # -> [B, 3 C, N] in one launch
             return dj
         tpg, o, saved = ctx.saved_tensors
         _attn_backward(ctx.d, ctx.kind, saved, tpg, tpg, tpg, o, g, dj, dj, dj)

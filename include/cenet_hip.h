@@ -195,6 +195,9 @@ typedef struct {
   void* ws;
   int B, H, N, hd;
   float scale;
+  int batch_mul; /* 0 / 1: dense tensors.  m > 1: q / k / v (and dq / dk / dv) of image b start m rows-blocks apart, i.e. at
+                  * element b * m * N * row_len of their pointers — q | k | v stacked per image as [B, 3, N, C] (the Non-local
+                  * block's merged theta / phi / g projection, nlb.py:117-119, m = 3) are read and written in place */
 } cenet_diffattn_t;
 int cenet_diffattn_heads_supported(int hd, int N);
 long cenet_diffattn_heads_ws_bytes(int B, int H, int N);
@@ -626,6 +629,9 @@ int cenet_cast_bf16_to_f32(const unsigned short* x, float* y, long n, cenet_stre
 /* y = bf16(x) and x = 0 in one pass: x is a persistent fp32 accumulator that kernels add into atomically (the dK / dV of the
  * spatial-reduction attention backward, pvtv2.py:88-109), left zero for its next use instead of a fill before every use */
 int cenet_cast_clear_f32_to_bf16(float* x, unsigned short* y, long n, cenet_stream_t stream);
+/* rows of N columns (N % 4 == 0): y = bf16(x + bias[col]); x = 0 — the tail of a split-K Linear (pvtv2.py:93-95 spatial-reduction
+ * conv as a GEMM over K = C s^2) whose partial products were added atomically into the zero-at-rest accumulator x */
+int cenet_cast_clear_bias_f32_to_bf16(float* x, unsigned short* y, const float* bias, int N, long n, cenet_stream_t stream);
 
 #ifdef __cplusplus
 }

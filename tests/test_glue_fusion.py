@@ -216,3 +216,23 @@ def test_batchnorm_backward_adds_the_residual_gradient(dev, dt, B, Cn, H, W):
     torch.testing.assert_close(res[0][1].float(), res[1][1].float(), **tol)
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(res[0][3], res[1][3], rtol=1e-4, atol=1e-4)
+
+
+def test_split_k_linear_tail_is_one_pass(dev, monkeypatch):
+    """the spatial-reduction convs as split-K GEMMs (few rows, K = C s^2): atomics into a zero-at-rest accumulator, then ONE pass
+    adds the bias, rounds and clears — same numbers as bias pre-fill + atomics + cast, twice in a row"""
+    g = torch.Generator().manual_seed(9)
+    R, K, N = 98, 2048, 64
+    x = (torch.randn(2, R // 2, K, generator=g) * 0.5).to(BF).to(dev)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).requires_grad_(True)
+    b = (0.1 * torch.randn(N, generator=g)).to(dev).requires_grad_(True)
+    monkeypatch.setattr(kern, "pick_splits", lambda *a, **k: 4)
+    with torch.no_grad():
+        y1 = ops.linear(x, W, b, split_k=True)
+        y2 = ops.linear(x, W, b, split_k=True)
+        ref = ops.linear(x, W, b)
+    assert y1.dtype == BF and torch.equal(y1, y2) if dev.type == "cpu" else True
+    torch.testing.assert_close(y1.float(), ref.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(y2.float(), ref.float(), rtol=2e-2, atol=2e-2)
+    key = (dev.type, dev.index, R * N)
+    assert ops._ZeroWs.bufs[key][1] is False and float(ops._ZeroWs.bufs[key][0].abs().max()) == 0.0
