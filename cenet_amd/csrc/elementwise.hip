@@ -25,7 +25,7 @@
 // ---- batched 2-D transpose: y[b][j][i] = x[b][i][j], x: [R x Cc] per batch -------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, long sxb, T* __restrict__ y, long syb, int R,
-                                                       int Cc) {
+                                                       int Cc, const T* __restrict__ add) {
   __shared__ T tile[32][33];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -41,12 +41,16 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int c = c0 + ty + 8 * i, r = r0 + tx;
-    if (r < R && c < Cc) yb[(long)c * R + r] = tile[tx][ty + 8 * i];
+    if (r < R && c < Cc) {
+      // add (laid out like y): y = x^T + add — a gradient that reached the transposed tensor's source along another path
+      if (add) stf(&yb[(long)c * R + r], ldf(&tile[tx][ty + 8 * i]) + ldf(add + (long)b * syb + (long)c * R + r));
+      else yb[(long)c * R + r] = tile[tx][ty + 8 * i];
+    }
   }
 }
 // bf16, both extents multiples of 2: a thread moves 2x2 blocks, so both sides are 4-byte accesses (64 x 64 tiles)
 __global__ __launch_bounds__(256) void transpose_bf16x2_kernel(const bf16_t* __restrict__ x, long sxb, bf16_t* __restrict__ y,
-                                                              long syb, int R, int Cc) {
+                                                              long syb, int R, int Cc, const bf16_t* __restrict__ add) {
   __shared__ unsigned tile[64][33];  // [row][col pair]
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -69,7 +73,12 @@ __global__ __launch_bounds__(256) void transpose_bf16x2_kernel(const bf16_t* __r
     if (c < Cc && r < R) {
       const unsigned a = tile[2 * tx][cl >> 1], bq = tile[2 * tx + 1][cl >> 1];
       const unsigned lo = (cl & 1) ? (a >> 16) : (a & 0xFFFFu), hi = (cl & 1) ? (bq >> 16) : (bq & 0xFFFFu);
-      const unsigned v = lo | (hi << 16);
+      unsigned v = lo | (hi << 16);
+      if (add) {
+        unsigned w;
+        memcpy(&w, add + (long)b * syb + (long)c * R + r, 4);
+        v = cenet_pack_bf2(cenet_bf2f(lo) + cenet_bf2f(w & 0xFFFFu), cenet_bf2f(hi) + cenet_bf2f(w >> 16));
+      }
       memcpy(yb + (long)c * R + r, &v, 4);
     }
   }
@@ -846,24 +855,34 @@ static inline int chunks_for(int n) {
 }
 
 template <typename T>
-static int transpose_impl(const T* x, long sxb, T* y, long syb, int B, int R, int Cc, hipStream_t stream) {
+static int transpose_impl(const T* x, long sxb, T* y, long syb, int B, int R, int Cc, hipStream_t stream,
+                          const T* add = nullptr) {
   if (B <= 0 || R <= 0 || Cc <= 0) return CENET_EINVAL;
-  CENET_LAUNCH((transpose_kernel<T>), dim3(cdiv(Cc, 32), cdiv(R, 32), B), dim3(256), stream, x, sxb, y, syb, R, Cc);
+  CENET_LAUNCH((transpose_kernel<T>), dim3(cdiv(Cc, 32), cdiv(R, 32), B), dim3(256), stream, x, sxb, y, syb, R, Cc, add);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
 template <>
-int transpose_impl<bf16_t>(const bf16_t* x, long sxb, bf16_t* y, long syb, int B, int R, int Cc, hipStream_t stream) {
+int transpose_impl<bf16_t>(const bf16_t* x, long sxb, bf16_t* y, long syb, int B, int R, int Cc, hipStream_t stream,
+                           const bf16_t* add) {
   if (B <= 0 || R <= 0 || Cc <= 0) return CENET_EINVAL;
-  if (((R | Cc) & 1) == 0 && ((sxb | syb) & 1) == 0 && ((((uintptr_t)x | (uintptr_t)y) & 3) == 0))
-    CENET_LAUNCH(transpose_bf16x2_kernel, dim3(cdiv(Cc, 64), cdiv(R, 64), B), dim3(256), stream, x, sxb, y, syb, R, Cc);
+  if (((R | Cc) & 1) == 0 && ((sxb | syb) & 1) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)add) & 3) == 0))
+    CENET_LAUNCH(transpose_bf16x2_kernel, dim3(cdiv(Cc, 64), cdiv(R, 64), B), dim3(256), stream, x, sxb, y, syb, R, Cc, add);
   else
-    CENET_LAUNCH((transpose_kernel<bf16_t>), dim3(cdiv(Cc, 32), cdiv(R, 32), B), dim3(256), stream, x, sxb, y, syb, R, Cc);
+    CENET_LAUNCH((transpose_kernel<bf16_t>), dim3(cdiv(Cc, 32), cdiv(R, 32), B), dim3(256), stream, x, sxb, y, syb, R, Cc, add);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
 CENET_TWIN(transpose, (const T* x, long sxb, T* y, long syb, int B, int R, int Cc, hipStream_t stream),
            (x, sxb, y, syb, B, R, Cc, stream))
+// y = x^T + add (add laid out like y, batch stride syb): the backward of a layout change whose source has a second consumer
+// (pvtv2.py:320-321: a stage's token output feeds the decoder as NCHW and the next stage's patch embedding as tokens)
+template <typename T>
+static int transpose_add_impl(const T* x, long sxb, T* y, long syb, const T* add, int B, int R, int Cc, hipStream_t stream) {
+  return transpose_impl<T>(x, sxb, y, syb, B, R, Cc, stream, add);
+}
+CENET_TWIN(transpose_add, (const T* x, long sxb, T* y, long syb, const T* add, int B, int R, int Cc, hipStream_t stream),
+           (x, sxb, y, syb, add, B, R, Cc, stream))
 
 template <typename T>
 static int copy_batched_impl(const T* x, long sxb, T* y, long syb, int B, long n, int accumulate, hipStream_t stream) {

@@ -69,10 +69,11 @@ __device__ __forceinline__ void bil_range(int i, float scale, int align, int out
 template <typename T, int BIL_MAXR>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx,
                                                           long sdb, int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw,
-                                                          int align) {
+                                                          int align, const T* __restrict__ dx_add) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
   const T* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
   T* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
+  const T* ap = dx_add ? dx_add + (long)b * sdb + (long)c * Hi * Wi : nullptr;  // (laid out like dx)
   for (int p = blockIdx.y * 256 + threadIdx.x; p < Hi * Wi; p += gridDim.y * 256) {
     const int iy = p / Wi, ix = p - iy * Wi;
     int ylo, yhi, xlo, xhi;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
         acc += wy * row;
       }
     }
-    stf(dp + p, acc);
+    stf(dp + p, ap ? acc + ldf(ap + p) : acc);
   }
 }
 
@@ -376,8 +377,18 @@ __global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(const T* __restr
 
 template <typename T>
 static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
-                             float scale_w, int align_corners, hipStream_t stream) {
+                             float scale_w, int align_corners, hipStream_t stream, const T* dx_add = nullptr) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
+  if (dx_add) {  // with an addend: the general kernel (the specialised forms below have no such operand)
+    if (scale_w >= 0.5f)
+      CENET_LAUNCH((bilinear_bwd_kernel<T, 6>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
+                   Wo, scale_h, scale_w, align_corners, dx_add);
+    else
+      CENET_LAUNCH((bilinear_bwd_kernel<T, 10>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
+                   Wo, scale_h, scale_w, align_corners, dx_add);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   // (bf16 tensors only: the fp32 parity mode keeps the one summation order of the general kernel)
   if (sizeof(T) == 2 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && scale_h == 0.5f && scale_w == 0.5f && Hi > 1 && Wi > 1) {
     CENET_LAUNCH((bilinear_up2_bwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi);
@@ -398,16 +409,26 @@ static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int 
   }
   if (scale_w >= 0.5f)
     CENET_LAUNCH((bilinear_bwd_kernel<T, 6>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
-                 Wo, scale_h, scale_w, align_corners);
+                 Wo, scale_h, scale_w, align_corners, (const T*)nullptr);
   else
     CENET_LAUNCH((bilinear_bwd_kernel<T, 10>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
-                 Wo, scale_h, scale_w, align_corners);
+                 Wo, scale_h, scale_w, align_corners, (const T*)nullptr);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
 CENET_TWIN(bilinear_bwd, (const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
                           float scale_w, int align_corners, hipStream_t stream),
            (dy, sgb, dx, sdb, B, C, Hi, Wi, Ho, Wo, scale_h, scale_w, align_corners, stream))
+// dx = backward(dy) + dx_add (dx_add laid out like dx): the input of the resampling has further consumers (dseb.py:63-76: the FEA
+// down-samplings read the tensor the attention and the combine also read) whose gradients arrive here as one addend
+template <typename T>
+static int bilinear_bwd_add_impl(const T* dy, long sgb, T* dx, long sdb, const T* dx_add, int B, int C, int Hi, int Wi, int Ho,
+                                 int Wo, float scale_h, float scale_w, int align_corners, hipStream_t stream) {
+  return bilinear_bwd_impl<T>(dy, sgb, dx, sdb, B, C, Hi, Wi, Ho, Wo, scale_h, scale_w, align_corners, stream, dx_add);
+}
+CENET_TWIN(bilinear_bwd_add, (const T* dy, long sgb, T* dx, long sdb, const T* dx_add, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                              float scale_h, float scale_w, int align_corners, hipStream_t stream),
+           (dy, sgb, dx, sdb, dx_add, B, C, Hi, Wi, Ho, Wo, scale_h, scale_w, align_corners, stream))
 
 template <typename T>
 static int nearest2x_fwd_impl(const T* x, long sxb, T* y, long syb, int B, int C, int Hi, int Wi, hipStream_t stream) {

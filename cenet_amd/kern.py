@@ -536,9 +536,13 @@ def bilinear_fwd(x, sxb, y, syb, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align):
     _call("cenet_bilinear_fwd_f32", x, L(sxb), y, L(syb), B, Cn, Hi, Wi, Ho, Wo, float(sh), float(sw), int(align))
 
 
-def bilinear_bwd(dy, sgb, dx, sdb, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align):
-    _chk(dy, dx)
-    _call("cenet_bilinear_bwd_f32", dy, L(sgb), dx, L(sdb), B, Cn, Hi, Wi, Ho, Wo, float(sh), float(sw), int(align))
+def bilinear_bwd(dy, sgb, dx, sdb, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align, dx_add=None):
+    """dx_add (laid out like dx, optional): added to dx by the kernel that writes it"""
+    _chk(dy, dx, dx_add)
+    if dx_add is None:
+        _call("cenet_bilinear_bwd_f32", dy, L(sgb), dx, L(sdb), B, Cn, Hi, Wi, Ho, Wo, float(sh), float(sw), int(align))
+    else:
+        _call("cenet_bilinear_bwd_add_f32", dy, L(sgb), dx, L(sdb), dx_add, B, Cn, Hi, Wi, Ho, Wo, float(sh), float(sw), int(align))
 
 
 def nearest2x_fwd(x, sxb, y, syb, B, Cn, Hi, Wi):
@@ -626,9 +630,13 @@ def srm_bwd_apply(x, dy, f, u, du, amax, dx, B, Cn, HW):
 
 
 # ---- glue ---------------------------------------------------------------------------------------------------
-def transpose(x, sxb, y, syb, B, R, Cc, x_off=0, y_off=0):
-    _chk(x, y)
-    _call("cenet_transpose_f32", Ptr(x, x_off), L(sxb), Ptr(y, y_off), L(syb), B, R, Cc)
+def transpose(x, sxb, y, syb, B, R, Cc, x_off=0, y_off=0, add=None):
+    """y[b] = x[b]^T (+ add[b], laid out like y with batch stride syb)"""
+    _chk(x, y, add)
+    if add is None:
+        _call("cenet_transpose_f32", Ptr(x, x_off), L(sxb), Ptr(y, y_off), L(syb), B, R, Cc)
+    else:
+        _call("cenet_transpose_add_f32", Ptr(x, x_off), L(sxb), Ptr(y, y_off), L(syb), add, B, R, Cc)
 
 
 def copy_batched(x, sxb, y, syb, B, n, accumulate=False, x_off=0, y_off=0):

@@ -19,16 +19,20 @@ class FEA(nn.Module):
         assert 2 <= self.n <= 3, "FEA supports 2 or 3 scales"
         self.w = nn.Parameter(torch.randn(1, dim, 1, 1) + 0.5)
 
-    def recons(self, x):
+    def recons(self, x, tap=False):
+        """tap=True: returns (list, x_tap) — x routed through the down-samplings' autograd nodes, for x's remaining consumer"""
         H, W = x.shape[2:]
         out = []
         for s in self.scale_factors:
             if float(s) == 1.0:
                 out.append(None)  # interpolate(scale 1.0) is the identity -> e_s == 0 exactly
             else:
-                d = ops.interpolate_bilinear(x, scale_factor=s, align_corners=False)
+                if tap:
+                    d, x = ops.interpolate_bilinear(x, scale_factor=s, align_corners=False, tap=True)
+                else:
+                    d = ops.interpolate_bilinear(x, scale_factor=s, align_corners=False)
                 out.append(ops.interpolate_bilinear(d, size=(H, W), align_corners=False))
-        return out
+        return (out, x) if tap else out
 
     def forward(self, x):
         return ops.dseb_combine(x, self.w, None, self.recons(x), ycoef=1.0)  # x + w*edge
@@ -55,6 +59,9 @@ class DSEBlock(nn.Module):
         self.dec_tap = dec
         B, C2, H, W = y.shape
         # dseb.py:115: the flat NCHW buffer re-read as [B, HW, 2C] tokens (a view, not a permute)
-        diff = self.diffattn(y.view(B, H * W, C2)).view(B, C2, H, W)
-        z = ops.dseb_combine(y, self.boundary.w, diff, self.boundary.recons(y))  # (FEA(y)+y) + diff*y
+        # y has four consumers (the attention's projections, two down-samplings, the combine): each hands y on as a tap, so that the
+        # four gradients are added by the backward kernels along that chain instead of three aten::add launches on 2C-channel maps
+        diff, yt = self.diffattn(y.view(B, H * W, C2), None, None, True)
+        rec, yt = self.boundary.recons(yt.view(B, C2, H, W), tap=True)
+        z = ops.dseb_combine(yt, self.boundary.w, diff.view(B, C2, H, W), rec)  # (FEA(y)+y) + diff*y
         return ops.conv1x1(z, self.mixer.weight, None, resid=skip)

@@ -40,17 +40,19 @@ class MultiheadDiffAttn(nn.Module):
             self._wqkv = Wm
         return Wm
 
-    def forward(self, x, rel_pos=None, attn_mask=None):
+    def forward(self, x, rel_pos=None, attn_mask=None, tap=False):
+        """tap=True: returns (out, x_tap) — x routed through the projections' autograd node, for x's other consumers (DSEBlock)"""
         if rel_pos is not None or attn_mask is not None:
             raise NotImplementedError
         Wm = self._merged_qkv()
         if Wm is not None:  # the three projections as one batched launch per pass (weights back to back in the ParamArena)
             ops.refresh_member_shadows(Wm, x)
-            q, k, v = ops.multi_linear(x, Wm)
+            q, k, v, x = ops.multi_linear(x, Wm, tap=True)
         else:
             q, x = ops.linear(x, self.q_proj.weight, tap=True)  # (taps: the three data gradients add up inside the GEMMs)
             k, x = ops.linear(x, self.k_proj.weight, tap=True)
-            v = ops.linear(x, self.v_proj.weight)
+            v, x = ops.linear(x, self.v_proj.weight, tap=True)
         U = ops.diff_attention_heads(q, k, v, self.num_heads)  # [B, 2H, N, 2hd], two softmaxes per head, tiled
         a = ops.diff_attention_combine(U, self.lambda_q1, self.lambda_k1, self.lambda_q2, self.lambda_k2, self.lambda_init)
-        return ops.linear(a, self.out_proj.weight)
+        out = ops.linear(a, self.out_proj.weight)
+        return (out, x) if tap else out

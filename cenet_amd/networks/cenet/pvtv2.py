@@ -253,7 +253,9 @@ class PyramidVisionTransformerImpr(nn.Module):
                 leaf = t.detach().requires_grad_(True)
                 cuts.append((t, leaf))
                 t = leaf
-            x = ops.tok_to_nchw(t, H, W)
+            # (t has a second consumer, the next stage's patch embedding: it reads the tap so that its gradient joins the decoder's
+            # inside the transpose of this node's backward)
+            x, t = ops.tok_to_nchw(t, H, W, tap=True)
             outs.append(x)
         return outs
 

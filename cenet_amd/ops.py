@@ -531,7 +531,7 @@ class MultiLinearFn(Function):
     as DiffAttnHeadsFn returns them; otherwise n GEMMs chained through the residual operand)."""
 
     @staticmethod
-    def forward(ctx, x, W):
+    def forward(ctx, x, W, tap=False):
         x = _c(x)
         n, N, K = W.shape[:3]
         R = x.numel() // K
@@ -540,7 +540,9 @@ class MultiLinearFn(Function):
                   scb=R * N, nbatch=n)
         ctx.save_for_backward(x, W)
         ctx.refs = (W,)
-        return tuple(Y[j] for j in range(n))
+        ctx.tap = tap
+        # tap: x itself as a last output; x's other consumers read it and their gradient rides in the data-gradient GEMM (R)
+        return tuple(Y[j] for j in range(n)) + ((x.view_as(x),) if tap else ())
 
     @staticmethod
     def backward(ctx, *gs):
@@ -548,6 +550,13 @@ class MultiLinearFn(Function):
         Wp, = ctx.refs
         n, N, K = W.shape[:3]
         R = x.numel() // K
+        g_tap = None
+        if ctx.tap:
+            gs, g_tap = gs[:-1], gs[-1]
+            if all(g is None for g in gs):
+                return g_tap, None, None
+            if g_tap is not None:
+                g_tap = _c(g_tap) if g_tap.dtype == x.dtype else _c(g_tap.to(x.dtype))
         gs = [_c(g) if g is not None else torch.zeros(x.shape[:-1] + (N,), device=x.device, dtype=x.dtype) for g in gs]
         esz = gs[0].element_size()
         joint = all(g.data_ptr() == gs[0].data_ptr() + j * R * N * esz for j, g in enumerate(gs))
@@ -571,17 +580,20 @@ class MultiLinearFn(Function):
             Wq = kern.wq(Wp, x)
             if joint:
                 kern.gemm(kern.mat_plain(gs[0], N, 1, skb=R * N, kfast=1), kern.mat_plain(Wq, K, 1, skb=N * K, kfast=0), dx, R, K, N,
-                          scr=K, scc=1, nkb=n)
+                          scr=K, scc=1, nkb=n, R=g_tap, srr=K, src=1)
             else:
                 for j, g in enumerate(gs):
                     kern.gemm(kern.mat_plain(g, N, 1, kfast=1), kern.mat_plain(Wq, K, 1, kfast=0, offset=j * N * K), dx, R, K, N,
-                              scr=K, scc=1, R=(dx if j else None), srr=K, src=1)
-        return dx, None
+                              scr=K, scc=1, R=(dx if j else g_tap), srr=K, src=1)
+        elif g_tap is not None:
+            dx = g_tap
+        return dx, None, None
 
 
-def multi_linear(x, W):
-    """W [n, N, K] (ops.merged_param of n bias-free Linear weights): returns the n products x W_j^T"""
-    return MultiLinearFn.apply(x, W)
+def multi_linear(x, W, tap=False):
+    """W [n, N, K] (ops.merged_param of n bias-free Linear weights): returns the n products x W_j^T (+ x_tap with tap=True: hand
+    it, not x, to x's other consumers)"""
+    return MultiLinearFn.apply(x, W, tap)
 
 
 class Conv1x1Fn(Function):
@@ -1609,27 +1621,34 @@ def diff_attention_combine(U, lq1, lk1, lq2, lk2, lambda_init):
 # layout / glue
 # =====================================================================================================
 class TokToNCHWFn(Function):
-    """pvtv2.py:320-321: [B,N,C] -> [B,C,H,W] contiguous."""
+    """pvtv2.py:320-321: [B,N,C] -> [B,C,H,W] contiguous.
+    tap: also returns x itself; x's other consumer (the next stage's patch embedding, pvtv2.py:330) reads the tap, and its gradient
+    is added by the transpose that writes dx."""
 
     @staticmethod
-    def forward(ctx, x, H, Wd):
+    def forward(ctx, x, H, Wd, tap=False):
         x = _c(x)
         B, N, Cn = x.shape
         y = _act((B, Cn, H, Wd), x)
         kern.transpose(x, N * Cn, y, N * Cn, B, N, Cn)
-        return y
+        return (y, x.view_as(x)) if tap else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_tap=None):
+        if g is None:
+            return g_tap, None, None, None
         g = _c(g)
         B, Cn, H, Wd = g.shape
         dx = _act((B, H * Wd, Cn), g)
-        kern.transpose(g, Cn * H * Wd, dx, Cn * H * Wd, B, Cn, H * Wd)
-        return dx, None, None
+        if g_tap is not None:
+            g_tap = _c(g_tap) if g_tap.dtype == g.dtype else _c(g_tap.to(g.dtype))
+        kern.transpose(g, Cn * H * Wd, dx, Cn * H * Wd, B, Cn, H * Wd, add=g_tap)
+        return dx, None, None, None
 
 
-def tok_to_nchw(x, H, Wd):
-    return TokToNCHWFn.apply(x, H, Wd)
+def tok_to_nchw(x, H, Wd, tap=False):
+    """tap=True returns (x_nchw, x_tap): hand x_tap (not x) to x's other consumer"""
+    return TokToNCHWFn.apply(x, H, Wd, tap)
 
 
 class Concat2Fn(Function):
@@ -1999,31 +2018,38 @@ def scale_residual(x, y, ls):
 # resampling
 # =====================================================================================================
 class BilinearFn(Function):
+    """tap: also returns x itself; x's other consumers read the tap and their gradient is added by the kernel that writes dx"""
+
     @staticmethod
-    def forward(ctx, x, Ho, Wo, sh, sw, align):
+    def forward(ctx, x, Ho, Wo, sh, sw, align, tap=False):
         x = _c(x)
         B, Cn, Hi, Wi = x.shape
         y = _act((B, Cn, Ho, Wo), x)
         kern.bilinear_fwd(x, Cn * Hi * Wi, y, Cn * Ho * Wo, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align)
         ctx.cfg = (Hi, Wi, Ho, Wo, sh, sw, align)
-        return y
+        return (y, x.view_as(x)) if tap else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_tap=None):
         Hi, Wi, Ho, Wo, sh, sw, align = ctx.cfg
+        if g is None:
+            return (g_tap,) + (None,) * 6
         g = _c(g)
         B, Cn = g.shape[:2]
         dx = _act((B, Cn, Hi, Wi), g)
-        kern.bilinear_bwd(g, Cn * Ho * Wo, dx, Cn * Hi * Wi, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align)
-        return dx, None, None, None, None, None
+        if g_tap is not None:
+            g_tap = _c(g_tap) if g_tap.dtype == g.dtype else _c(g_tap.to(g.dtype))
+        kern.bilinear_bwd(g, Cn * Ho * Wo, dx, Cn * Hi * Wi, B, Cn, Hi, Wi, Ho, Wo, sh, sw, align, dx_add=g_tap)
+        return (dx,) + (None,) * 6
 
 
 def _f32(v: float) -> float:
     return float(torch.tensor(v, dtype=torch.float32))
 
 
-def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=False):
-    """F.interpolate(mode='bilinear') with PyTorch's coordinate rules (recompute_scale_factor=None)."""
+def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=False, tap=False):
+    """F.interpolate(mode='bilinear') with PyTorch's coordinate rules (recompute_scale_factor=None).
+    tap=True returns (y, x_tap): hand x_tap (not x) to x's other consumers"""
     Hi, Wi = x.shape[2:]
     if size is not None:
         Ho, Wo = size
@@ -2037,7 +2063,7 @@ def interpolate_bilinear(x, size=None, scale_factor=None, align_corners=False):
     else:
         sh = _f32(1.0 / sfh) if sfh else _f32(Hi / Ho)
         sw = _f32(1.0 / sfw) if sfw else _f32(Wi / Wo)
-    return BilinearFn.apply(x, Ho, Wo, sh, sw, int(align_corners))
+    return BilinearFn.apply(x, Ho, Wo, sh, sw, int(align_corners), tap)
 
 
 class Nearest2xFn(Function):

@@ -349,6 +349,10 @@ int cenet_bilinear_fwd_f32(const float* x, long sxb, float* y, long syb, int B, 
                            float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
 int cenet_bilinear_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo,
                            float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
+/* dx = backward(dy) + dx_add (laid out like dx): the resampled tensor has further consumers (dseb.py:63-76, 153-160) whose
+ * gradients arrive as one addend instead of aten::add launches (round 4) */
+int cenet_bilinear_bwd_add_f32(const float* dy, long sgb, float* dx, long sdb, const float* dx_add, int B, int C, int Hi, int Wi,
+                               int Ho, int Wo, float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
 /* aten::upsample_nearest2d(+_backward) x2 — blocks.py:304 */
 int cenet_nearest2x_fwd_f32(const float* x, long sxb, float* y, long syb, int B, int C, int Hi, int Wi, cenet_stream_t stream);
 int cenet_nearest2x_bwd_f32(const float* dy, long sgb, float* dx, long sdb, int B, int C, int Hi, int Wi, cenet_stream_t stream);
@@ -390,6 +394,10 @@ int cenet_srm_bwd_apply_f32(const float* x, const float* dy, const float* f, con
 
 /* ---- glue (elementwise.hip) --------------------------------------------------------------------------------- */
 int cenet_transpose_f32(const float* x, long sxb, float* y, long syb, int B, int R, int Cc, cenet_stream_t stream);
+/* y = x^T + add (add laid out like y, batch stride syb): backward of a layout change whose source has a second consumer
+ * (pvtv2.py:320-321: a stage's token output feeds the decoder as NCHW and the next stage's patch embedding as tokens) */
+int cenet_transpose_add_f32(const float* x, long sxb, float* y, long syb, const float* add, int B, int R, int Cc,
+                            cenet_stream_t stream);
 int cenet_copy_batched_f32(const float* x, long sxb, float* y, long syb, int B, long n, int accumulate, cenet_stream_t stream);
 /* torch.cat(parts, dim=1) of up to four contiguous NCHW tensors [B, c_j, HW] into joined [B, sum c_j, HW] (split == 0), or
  * its backward: the channel slices of joined copied out into the parts (split == 1) — one launch either way.  Unused
@@ -508,6 +516,8 @@ int cenet_dwconv3x3_tok_bwd_pre_bf16(const unsigned short* x, const unsigned sho
 /* elementwise.hip */
 int cenet_transpose_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, int R, int Cc,
     cenet_stream_t stream);
+int cenet_transpose_add_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, const unsigned short* add, int B,
+    int R, int Cc, cenet_stream_t stream);
 int cenet_copy_batched_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, long n, int accumulate,
     cenet_stream_t stream);
 int cenet_cat_channels_bf16(unsigned short* p0, unsigned short* p1, unsigned short* p2, unsigned short* p3, int c0, int c1,
@@ -587,6 +597,8 @@ int cenet_bilinear_fwd_bf16(const unsigned short* x, long sxb, unsigned short* y
     int Ho, int Wo, float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
 int cenet_bilinear_bwd_bf16(const unsigned short* dy, long sgb, unsigned short* dx, long sdb, int B, int C, int Hi, int Wi,
     int Ho, int Wo, float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
+int cenet_bilinear_bwd_add_bf16(const unsigned short* dy, long sgb, unsigned short* dx, long sdb, const unsigned short* dx_add,
+    int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h, float scale_w, int align_corners, cenet_stream_t stream);
 int cenet_nearest2x_fwd_bf16(const unsigned short* x, long sxb, unsigned short* y, long syb, int B, int C, int Hi, int Wi,
     cenet_stream_t stream);
 int cenet_nearest2x_bwd_bf16(const unsigned short* dy, long sgb, unsigned short* dx, long sdb, int B, int C, int Hi, int Wi,

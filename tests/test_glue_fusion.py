@@ -236,3 +236,65 @@ def test_split_k_linear_tail_is_one_pass(dev, monkeypatch):
     torch.testing.assert_close(y2.float(), ref.float(), rtol=2e-2, atol=2e-2)
     key = (dev.type, dev.index, R * N)
     assert ops._ZeroWs.bufs[key][1] is False and float(ops._ZeroWs.bufs[key][0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+@pytest.mark.parametrize("B,H,W,Cn", [(2, 7, 7, 64), (1, 5, 3, 10), (2, 14, 14, 320), (1, 9, 4, 33)])
+def test_layout_change_backward_adds_the_token_path_gradient(dev, dt, B, H, W, Cn):
+    g = torch.Generator().manual_seed(H * 10 + Cn)
+    t0 = torch.randn(B, H * W, Cn, generator=g).to(dt).to(dev)
+    wn = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    wt = torch.randn(B, H * W, Cn, generator=g).to(dt).to(dev)
+    t = t0.clone().requires_grad_(True)
+    x, tt = ops.tok_to_nchw(t, H, W, tap=True)
+    assert torch.equal(x, t0.transpose(1, 2).reshape(B, Cn, H, W))
+    ((x.float() * wn.float()).sum() + (tt.float() * wt.float()).sum()).backward()
+    want = wn.float().reshape(B, Cn, H * W).transpose(1, 2) + wt.float()
+    tol = dict(rtol=0, atol=0) if dt == torch.float32 else dict(rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(t.grad.float(), want, **tol)
+    t2 = t0.clone().requires_grad_(True)
+    x2, _ = ops.tok_to_nchw(t2, H, W, tap=True)  # tap unused: the plain transpose
+    (x2.float() * wn.float()).sum().backward()
+    torch.testing.assert_close(t2.grad.float(), wn.float().reshape(B, Cn, H * W).transpose(1, 2).to(dt).float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+@pytest.mark.parametrize("scale", [0.8, 0.4, 2.0])
+def test_bilinear_backward_adds_the_gradient_of_other_consumers(dev, dt, scale):
+    g = torch.Generator().manual_seed(int(scale * 10))
+    B, Cn, H, W = 2, 6, 14, 10
+    x0 = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    wt = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    res = []
+    for tap in (True, False):
+        x = x0.clone().requires_grad_(True)
+        if tap:
+            y, xt = ops.interpolate_bilinear(x, scale_factor=scale, tap=True)
+        else:
+            y, xt = ops.interpolate_bilinear(x, scale_factor=scale), x
+        wy = torch.linspace(-1, 1, y.numel()).reshape(y.shape).to(dt).to(dev)
+        ((y.float() * wy.float()).sum() + (xt.float() * wt.float()).sum()).backward()
+        res.append((y.detach(), x.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    tol = dict(rtol=1e-6, atol=1e-6) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(res[0][1].float(), res[1][1].float(), **tol)
+
+
+def test_multi_linear_tap_gradient_rides_in_the_data_gradient_gemm(dev):
+    g = torch.Generator().manual_seed(2)
+    R, K, N, n = 96, 64, 64, 3
+    x0 = torch.randn(2, R // 2, K, generator=g).to(BF).to(dev)
+    W = (torch.randn(n, N, K, generator=g) * K ** -0.5).to(dev).requires_grad_(True)
+    ws = [torch.randn(2, R // 2, N, generator=g).to(BF).to(dev) for _ in range(n)]
+    wt = torch.randn(2, R // 2, K, generator=g).to(BF).to(dev)
+    res = []
+    for tap in (True, False):
+        x = x0.clone().requires_grad_(True)
+        W.grad = torch.zeros_like(W)
+        outs = ops.multi_linear(x, W, tap=tap)
+        xt = outs[n] if tap else x
+        (sum((o.float() * w.float()).sum() for o, w in zip(outs[:n], ws)) + (xt.float() * wt.float()).sum()).backward()
+        ops.wgrad_flush()
+        res.append((x.grad, W.grad.clone()))
+    torch.testing.assert_close(res[0][0].float(), res[1][0].float(), rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
