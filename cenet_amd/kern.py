@@ -413,6 +413,28 @@ def bn_bwd(dy, sgb, x, sxb, dx, sdb, mean, var, eps, gamma, beta, act, slope, B,
               ACT[act], float(slope), B, Cn, HW, ws, dgamma, dbeta)
 
 
+def res_tail_supported(x2, x3) -> bool:
+    return bool(is_bf16(x2) and is_bf16(x3) and x2.dim() == 4 and x2.shape == x3.shape and x2.data_ptr() % 16 == 0
+                and x3.data_ptr() % 16 == 0 and _lib.lib().cenet_res_tail_supported(int(x2.shape[2]), int(x2.shape[3])))
+
+
+def res_tail_fwd(x2, x3, mean2, var2, g2, b2, eps2, mean3, var3, g3, b3, eps3, w, slope, out, B, Cn, H, W):
+    """out = w[c] * MaxPool2x2(LeakyReLU(BN2(x2) + BN3(x3))) from the batch statistics, one launch (csrc/res_tail.hip)"""
+    _chk(x2, x3, mean2, var2, g2, b2, mean3, var3, g3, b3, w, out)
+    _call("cenet_res_tail_fwd_bf16", x2, x3, mean2, var2, g2, b2, float(eps2), mean3, var3, g3, b3, float(eps3), w, float(slope), out,
+          B, Cn, H, W)
+
+
+def res_tail_bwd(g, x2, x3, mean2, var2, g2, b2, eps2, mean3, var3, g3, b3, eps3, w, slope, dx2, dx3, dg2, db2, dg3, db3, dw, B, Cn,
+                 H, W):
+    _chk(g, x2, x3, mean2, var2, g2, b2, mean3, var3, g3, b3, w, dx2, dx3, dg2, db2, dg3, db3, dw)
+    f = _lib.lib().cenet_res_tail_bwd_ws_floats
+    f.restype = C.c_long
+    ws = torch.empty(int(f(Cn)), device=g.device, dtype=torch.float32)
+    _call("cenet_res_tail_bwd_bf16", g, x2, x3, mean2, var2, g2, b2, float(eps2), mean3, var3, g3, b3, float(eps3), w, float(slope),
+          dx2, dx3, dg2, db2, dg3, db3, dw, ws, B, Cn, H, W)
+
+
 # ---- depthwise conv ------------------------------------------------------------------------------------
 def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0, x_off=0, y_off=0):
     """x_off / y_off (elements): read / write a channel slice of a wider tensor in place (batch strides sxb / syb)"""

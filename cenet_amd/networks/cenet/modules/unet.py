@@ -40,16 +40,25 @@ class UnetResBlock(nn.Module):
             self.norm3 = nn.BatchNorm2d(out_channels)
         self.apply(_init)
 
-    def forward(self, inp):
+    def forward(self, inp, pool_scale=None):
+        """pool_scale (OutHead.w, out.py:43,70): return pool_scale * MaxPool2d(2,2)(block(inp)) instead of block(inp) — on bf16 maps
+        in training mode the two BatchNorms, the residual add, the LeakyReLU and the pool are ONE kernel (ops.res_tail_pool)"""
         p = self.k // 2
         out = ops.conv2d_nchw(inp, self.conv1.conv.weight, None, stride=1, pad=p)
         out = bn_call(self.norm1, out, "lrelu", self.slope)
         out = ops.conv2d_nchw(out, self.conv2.conv.weight, None, stride=1, pad=p)
+        if pool_scale is not None and self.downsample:
+            res = ops.conv1x1(inp, self.conv3.conv.weight)
+            if ops.res_tail_pool_supported(out, res, self.norm2, self.norm3, pool_scale):
+                return ops.res_tail_pool(out, self.norm2, res, self.norm3, pool_scale, self.slope)
+            y = ops.add_act(bn_call(self.norm2, out), bn_call(self.norm3, res), "lrelu", self.slope)
+            return ops.maxpool2_scale(y, pool_scale)
         out = bn_call(self.norm2, out)
         res = inp
         if self.downsample:
             res = bn_call(self.norm3, ops.conv1x1(inp, self.conv3.conv.weight))
-        return ops.add_act(out, res, "lrelu", self.slope)
+        y = ops.add_act(out, res, "lrelu", self.slope)
+        return ops.maxpool2_scale(y, pool_scale) if pool_scale is not None else y
 
 
 class UnetOutBlock(nn.Module):

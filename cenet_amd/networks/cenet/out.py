@@ -30,7 +30,7 @@ class OutHead(nn.Module):
             nn.MaxPool2d(kernel_size=2, stride=2))
 
     def forward(self, dec, x):
-        rb = ops.maxpool2_scale(self.rb[0](x), self.w)  # w * MaxPool2(ResBlock5x5(x))
+        rb = self.rb[0](x, self.w)  # w * MaxPool2(ResBlock5x5(x)): block tail and pool fused (UnetResBlock.forward)
         d = self.up(dec)
         z = ops.concat2(d, rb)
         y = self.out[1](self.out[0](z))

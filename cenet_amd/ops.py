@@ -2140,6 +2140,56 @@ def maxpool2_scale(x, w):
     return MaxPool2ScaleFn.apply(x, w)
 
 
+class ResTailPoolFn(Function):
+    """w * MaxPool2d(2,2)(LeakyReLU(BN2(x2) + BN3(x3))) — the tail of the head's image branch (out.py:60,70 over unet.py:201-214)
+    on bf16 maps in training mode: batch statistics by the BatchNorm statistics kernels, then ONE pass (csrc/res_tail.hip); the
+    backward recomputes the activation from x2 / x3 in its two passes."""
+
+    @staticmethod
+    def forward(ctx, x2, x3, w, slope, g2, b2, rm2, rv2, nbt2, eps2, mom2, g3, b3, rm3, rv3, nbt3, eps3, mom3):
+        x2, x3 = _c(x2), _c(x3)
+        B, Cn, H, Wd = x2.shape
+        HW = H * Wd
+        st = []
+        for x, rm, rv, nbt, mom in ((x2, rm2, rv2, nbt2, mom2), (x3, rm3, rv3, nbt3, mom3)):
+            mean, var = _empty((Cn,), x), _empty((Cn,), x)
+            ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
+            kern.bn_stats(x, Cn * HW, B, Cn, HW, ws, mean, var, rm, rv, mom, nbt)
+            st += [mean, var]
+        wv = _c(w.reshape(-1))
+        out = _act((B, Cn, H // 2, Wd // 2), x2)
+        kern.res_tail_fwd(x2, x3, st[0], st[1], g2, b2, eps2, st[2], st[3], g3, b3, eps3, wv, slope, out, B, Cn, H, Wd)
+        ctx.save_for_backward(x2, x3, wv, g2, b2, g3, b3, *st)
+        ctx.refs = (w, g2, b2, g3, b3)
+        ctx.cfg = (slope, eps2, eps3)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, x3, wv, g2, b2, g3, b3, m2, v2, m3, v3 = ctx.saved_tensors
+        wp, g2p, b2p, g3p, b3p = ctx.refs
+        slope, eps2, eps3 = ctx.cfg
+        g = _c(g)
+        B, Cn, H, Wd = x2.shape
+        dx2, dx3 = torch.empty_like(x2), torch.empty_like(x3)
+        dw = grad_buf(wp)
+        kern.res_tail_bwd(g, x2, x3, m2, v2, g2, b2, eps2, m3, v3, g3, b3, eps3, wv, slope, dx2, dx3, grad_buf(g2p), grad_buf(b2p),
+                          grad_buf(g3p), grad_buf(b3p), dw.view(-1) if dw is not None else None, B, Cn, H, Wd)
+        return (dx2, dx3) + (None,) * 16
+
+
+def res_tail_pool(x2, bn2, x3, bn3, w, slope):
+    """bn2 / bn3: nn.BatchNorm2d modules in training mode (their running statistics are updated)"""
+    return ResTailPoolFn.apply(x2, x3, w, slope, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked,
+                               bn2.eps, bn2.momentum if bn2.momentum is not None else 0.1, bn3.weight, bn3.bias, bn3.running_mean,
+                               bn3.running_var, bn3.num_batches_tracked, bn3.eps, bn3.momentum if bn3.momentum is not None else 0.1)
+
+
+def res_tail_pool_supported(x2, x3, bn2, bn3, w) -> bool:
+    return bool(bn2.training and bn3.training and x2.is_cuda == x3.is_cuda and kern.res_tail_supported(x2, x3)
+                and w.numel() == x2.shape[1] and os.environ.get("CENET_RES_TAIL_FUSED", "1") != "0")
+
+
 # =====================================================================================================
 # CCU and SRM gates (cfam.py:251-264, 93-101)
 # =====================================================================================================

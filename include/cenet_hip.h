@@ -332,6 +332,24 @@ int cenet_pvt_mlp_bwd_bf16(const unsigned short* g, const float* bscale, const u
                            const float* up_scale, unsigned short* dxs, float* dwd_acc, float* dbd_acc, float* dln_g_acc,
                            float* dln_b_acc, float* db2_acc, float* ws, int B, int H, int W, int C, int HD, cenet_stream_t stream);
 
+/* ---- tail of the output head's image branch, fused (res_tail.hip, round 4) — out.py:60,70 over unet.py:201-214 on bf16 maps -------
+ * out = w[c] * MaxPool2d(2,2)(LeakyReLU(BN2(x2) + BN3(x3))) with x2 = conv2's output, x3 = the 1x1 shortcut conv's output
+ * ([B, C, H, W], H even, W % 8 == 0) and the BatchNorms' batch statistics given (cenet_bn_stats_*): replaces bn_apply x 2 + add +
+ * LeakyReLU + max_pool2d + mul forward (one launch; the pre-pool activation is never stored) and max_pool2d_backward +
+ * leaky_relu_backward + native_batch_norm_backward x 2 backward (two launches; the activation is recomputed from x2, x3).
+ * dgamma / dbeta of both norms and dw (gradient of w) are ADDED into (any may be NULL); ws: cenet_res_tail_bwd_ws_floats(C). */
+int cenet_res_tail_supported(int H, int W);
+int cenet_res_tail_fwd_bf16(const unsigned short* x2, const unsigned short* x3, const float* mean2, const float* var2,
+                            const float* gamma2, const float* beta2, float eps2, const float* mean3, const float* var3,
+                            const float* gamma3, const float* beta3, float eps3, const float* w, float slope, unsigned short* out,
+                            int B, int C, int H, int W, cenet_stream_t stream);
+long cenet_res_tail_bwd_ws_floats(int C);
+int cenet_res_tail_bwd_bf16(const unsigned short* g, const unsigned short* x2, const unsigned short* x3, const float* mean2,
+                            const float* var2, const float* gamma2, const float* beta2, float eps2, const float* mean3,
+                            const float* var3, const float* gamma3, const float* beta3, float eps3, const float* w, float slope,
+                            unsigned short* dx2, unsigned short* dx3, float* dgamma2_acc, float* dbeta2_acc, float* dgamma3_acc,
+                            float* dbeta3_acc, float* dw_acc, float* ws, int B, int C, int H, int W, cenet_stream_t stream);
+
 /* n <= 4 bias-free, activation-free depthwise 3x3 convs (flip = 1: their data gradients) / weight gradients of bf16 NCHW channel slices
  * in ONE launch — the three dilated SepConvBN branches of a CFAM block (cfam.py:208-212, blocks.py:142-150).  Branch i: x[i] (batch
  * stride sxb[i]) -> y[i] (syb[i]), C[i] channels, dilation dil[i], all on H x W maps of B images.  CENET_EUNSUPPORTED unless every

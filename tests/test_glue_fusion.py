@@ -298,3 +298,89 @@ def test_multi_linear_tap_gradient_rides_in_the_data_gradient_gemm(dev):
         res.append((x.grad, W.grad.clone()))
     torch.testing.assert_close(res[0][0].float(), res[1][0].float(), rtol=2e-2, atol=3e-2)
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,Cn,H,W", [(2, 8, 8, 16), (3, 4, 6, 24), (1, 32, 16, 8)])
+def test_head_image_branch_tail_fused_equals_the_chain(dev, monkeypatch, B, Cn, H, W):
+    """w * MaxPool(LeakyReLU(BN2(conv2) + BN3(conv3))) as one forward kernel and two backward kernels (csrc/res_tail.hip) against the
+    chain bn x 2 + add_act + maxpool2_scale, through the module that uses it (UnetResBlock with pool_scale)"""
+    import copy
+
+    from cenet_amd.networks.cenet.modules.unet import UnetResBlock
+    torch.manual_seed(5)
+    blk = UnetResBlock(2, 1, Cn, kernel_size=3, stride=1, norm_name="batch").to(dev)
+    with torch.no_grad():
+        for bn in (blk.norm1, blk.norm2, blk.norm3):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    w = (torch.randn(1, Cn, 1, 1) + 0.75).to(dev).requires_grad_(True)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 1, H, W, generator=g).to(BF).to(dev)
+    go = torch.randn(B, Cn, H // 2, W // 2, generator=g).to(BF).to(dev)
+    res = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CENET_RES_TAIL_FUSED", fused)
+        m = copy.deepcopy(blk).train()
+        wc = w.detach().clone().requires_grad_(True)
+        for p_ in list(m.parameters()) + [wc]:
+            p_.grad = torch.zeros_like(p_)
+        out = m(x, wc)
+        out.backward(go)
+        ops.wgrad_flush()
+        res.append((out.detach().float(), wc.grad.clone(), [p_.grad.clone() for p_ in m.parameters()],
+                    [b_.clone() for b_ in m.buffers()]))
+    f, u = res
+    # the fused form rounds once where the chain rounds three times (two normalised maps and their sum): bf16-ulp differences,
+    # and a window whose two largest activations tie after the chain's rounding may pick another element
+    d = (f[0] - u[0]).abs()
+    assert d.max().item() <= 0.06 * max(u[0].abs().max().item(), 1e-3) and d.mean().item() <= 4e-3 * u[0].abs().mean().item()
+    cos = lambda a, b: float((a.flatten().double() @ b.flatten().double()) / (a.double().norm() * b.double().norm() + 1e-30))
+    assert cos(f[1], u[1]) > 0.999
+    for a, b_ in zip(f[2], u[2]):
+        if b_.abs().max() > 1e-6:
+            assert cos(a, b_) > 0.99, (a.shape, cos(a, b_))
+    for a, b_ in zip(f[3], u[3]):  # running statistics and counters: the same statistics kernels
+        torch.testing.assert_close(a.float(), b_.float(), rtol=1e-5, atol=1e-6)
+
+
+def test_res_tail_kernels_against_fp64_autograd(dev):
+    import torch.nn.functional as F
+    B, Cn, H, W = 2, 6, 8, 16
+    g = torch.Generator().manual_seed(3)
+    x2 = torch.randn(B, Cn, H, W, generator=g).to(BF)
+    x3 = (0.7 * torch.randn(B, Cn, H, W, generator=g) + 0.2).to(BF)
+    go = torch.randn(B, Cn, H // 2, W // 2, generator=g).to(BF)
+    par = [(1 + 0.3 * torch.randn(Cn, generator=g)), 0.2 * torch.randn(Cn, generator=g), (1 + 0.3 * torch.randn(Cn, generator=g)),
+           0.2 * torch.randn(Cn, generator=g), torch.randn(Cn, generator=g) + 0.75]
+    # fp64 reference
+    r = [t.double().requires_grad_(True) for t in (x2, x3)] + [p.double().requires_grad_(True) for p in par]
+    y = F.leaky_relu(F.batch_norm(r[0], None, None, r[2], r[3], True, 0.1, 1e-5) + F.batch_norm(r[1], None, None, r[4], r[5], True, 0.1, 1e-5), 0.01)
+    out_ref = F.max_pool2d(y, 2, 2) * r[6].view(1, -1, 1, 1)
+    out_ref.backward(go.double())
+    # kernels
+    d = dev
+    bn = []
+    for _ in range(2):
+        m = torch.nn.BatchNorm2d(Cn).to(d).train()
+        bn.append(m)
+    with torch.no_grad():
+        bn[0].weight.copy_(par[0]); bn[0].bias.copy_(par[1]); bn[1].weight.copy_(par[2]); bn[1].bias.copy_(par[3])
+    w = par[4].to(d).view(1, Cn, 1, 1).requires_grad_(True)
+    a2, a3 = x2.to(d).requires_grad_(True), x3.to(d).requires_grad_(True)
+    for p_ in [w] + list(bn[0].parameters()) + list(bn[1].parameters()):
+        p_.grad = torch.zeros_like(p_)
+    out = ops.res_tail_pool(a2, bn[0], a3, bn[1], w, 0.01)
+    out.backward(go.to(d))
+    tol = dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out.float().cpu(), out_ref.float(), **tol)
+    torch.testing.assert_close(a2.grad.float().cpu(), r[0].grad.float(), **tol)
+    torch.testing.assert_close(a3.grad.float().cpu(), r[1].grad.float(), **tol)
+    for got, want in ((bn[0].weight.grad, r[2].grad), (bn[0].bias.grad, r[3].grad), (bn[1].weight.grad, r[4].grad),
+                      (bn[1].bias.grad, r[5].grad), (w.grad.view(-1), r[6].grad)):
+        torch.testing.assert_close(got.float().cpu(), want.float(), rtol=2e-2, atol=3e-2)
+    # running statistics as torch's (momentum 0.1, unbiased running variance)
+    rm = 0.1 * x2.double().mean((0, 2, 3))
+    rv = 0.9 + 0.1 * x2.double().var((0, 2, 3), unbiased=True)
+    torch.testing.assert_close(bn[0].running_mean.double().cpu(), rm, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn[0].running_var.double().cpu(), rv, rtol=1e-4, atol=1e-5)
+    assert int(bn[0].num_batches_tracked) == 1
