@@ -435,6 +435,23 @@ def res_tail_bwd(g, x2, x3, mean2, var2, g2, b2, eps2, mean3, var3, g3, b3, eps3
           dx2, dx3, dg2, db2, dg3, db3, dw, ws, B, Cn, H, W)
 
 
+def res_tail_img_fwd(x2, img, mean2, var2, g2, b2, eps2, imean, ivar, w3, g3, b3, eps3, rm3, rv3, nbt3, mom3, w, slope, out, B, Cn, H, W):
+    """res_tail_fwd with the shortcut x3 = w3[c] * img not materialised (one-channel input); updates BatchNorm3's running statistics"""
+    _chk(x2, img, mean2, var2, g2, b2, imean, ivar, w3, g3, b3, rm3, rv3, w, out)
+    _call("cenet_res_tail_img_fwd_bf16", x2, img, mean2, var2, g2, b2, float(eps2), imean, ivar, w3, g3, b3, float(eps3), rm3, rv3, nbt3,
+          float(mom3), w, float(slope), out, B, Cn, H, W)
+
+
+def res_tail_img_bwd(g, x2, img, mean2, var2, g2, b2, eps2, imean, ivar, w3, g3, b3, eps3, w, slope, dx2, dg2, db2, dg3, db3, dw3, dw,
+                     B, Cn, H, W):
+    _chk(g, x2, img, mean2, var2, g2, b2, imean, ivar, w3, g3, b3, w, dx2, dg2, db2, dg3, db3, dw3, dw)
+    f = _lib.lib().cenet_res_tail_bwd_ws_floats
+    f.restype = C.c_long
+    ws = torch.empty(int(f(Cn)), device=g.device, dtype=torch.float32)
+    _call("cenet_res_tail_img_bwd_bf16", g, x2, img, mean2, var2, g2, b2, float(eps2), imean, ivar, w3, g3, b3, float(eps3), w,
+          float(slope), dx2, dg2, db2, dg3, db3, dw3, dw, ws, B, Cn, H, W)
+
+
 # ---- depthwise conv ------------------------------------------------------------------------------------
 def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0, x_off=0, y_off=0):
     """x_off / y_off (elements): read / write a channel slice of a wider tensor in place (batch strides sxb / syb)"""

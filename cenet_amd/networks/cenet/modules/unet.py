@@ -48,6 +48,9 @@ class UnetResBlock(nn.Module):
         out = bn_call(self.norm1, out, "lrelu", self.slope)
         out = ops.conv2d_nchw(out, self.conv2.conv.weight, None, stride=1, pad=p)
         if pool_scale is not None and self.downsample:
+            if ops.res_tail_img_pool_supported(out, inp, self.conv3.conv.weight, self.norm2, self.norm3, pool_scale):
+                # one-channel input: the shortcut w3[c] * inp is never materialised (ops.ResTailImgPoolFn)
+                return ops.res_tail_img_pool(out, self.norm2, inp, self.conv3.conv.weight, self.norm3, pool_scale, self.slope)
             res = ops.conv1x1(inp, self.conv3.conv.weight)
             if ops.res_tail_pool_supported(out, res, self.norm2, self.norm3, pool_scale):
                 return ops.res_tail_pool(out, self.norm2, res, self.norm3, pool_scale, self.slope)

@@ -2185,6 +2185,68 @@ def res_tail_pool(x2, bn2, x3, bn3, w, slope):
                                bn3.running_var, bn3.num_batches_tracked, bn3.eps, bn3.momentum if bn3.momentum is not None else 0.1)
 
 
+class ResTailImgPoolFn(Function):
+    """ResTailPoolFn for a ONE-CHANNEL network input: the shortcut x3 = conv3(img) = w3[c] * img (unet.py conv3, 1x1) is not
+    materialised — BN3(x3) is an affine map of the image, with coefficients from the image's batch statistics.  No shortcut conv, no
+    statistics pass over it, no dx3, no weight-gradient kernel for it: its weight only reaches the output through eps (BatchNorm is
+    invariant to the scale of its input), and that gradient comes out of the sums the backward computes anyway."""
+    _dummy: dict = {}  # per device: (running mean, running var, counter) the image's statistics call writes nowhere useful
+
+    @staticmethod
+    def forward(ctx, x2, img, w3, w, slope, g2, b2, rm2, rv2, nbt2, eps2, mom2, g3, b3, rm3, rv3, nbt3, eps3, mom3):
+        x2, img = _c(x2), _c(img)
+        B, Cn, H, Wd = x2.shape
+        HW = H * Wd
+        mean2, var2 = _empty((Cn,), x2), _empty((Cn,), x2)
+        kern.bn_stats(x2, Cn * HW, B, Cn, HW, _empty((2 * Cn * 256,), x2), mean2, var2, rm2, rv2, mom2, nbt2)
+        key = (x2.device.type, x2.device.index)
+        dm = ResTailImgPoolFn._dummy.get(key)
+        if dm is None:
+            dm = ResTailImgPoolFn._dummy[key] = (torch.zeros(1, device=x2.device), torch.ones(1, device=x2.device),
+                                                 torch.zeros(1, device=x2.device, dtype=torch.long))
+        imean, ivar = _empty((1,), x2), _empty((1,), x2)
+        kern.bn_stats(img, HW, B, 1, HW, _empty((2 * 256,), x2), imean, ivar, dm[0], dm[1], 0.0, dm[2])
+        wv, w3v = _c(w.reshape(-1)), _c(w3.reshape(-1))
+        out = _act((B, Cn, H // 2, Wd // 2), x2)
+        kern.res_tail_img_fwd(x2, img, mean2, var2, g2, b2, eps2, imean, ivar, w3v, g3, b3, eps3, rm3, rv3, nbt3, mom3, wv, slope, out,
+                              B, Cn, H, Wd)
+        ctx.save_for_backward(x2, img, wv, w3v, g2, b2, g3, b3, mean2, var2, imean, ivar)
+        ctx.refs = (w, w3, g2, b2, g3, b3)
+        ctx.cfg = (slope, eps2, eps3)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, img, wv, w3v, g2, b2, g3, b3, mean2, var2, imean, ivar = ctx.saved_tensors
+        wp, w3p, g2p, b2p, g3p, b3p = ctx.refs
+        slope, eps2, eps3 = ctx.cfg
+        g = _c(g)
+        B, Cn, H, Wd = x2.shape
+        dx2 = torch.empty_like(x2)
+        dw, dw3 = grad_buf(wp), grad_buf(w3p)
+        kern.res_tail_img_bwd(g, x2, img, mean2, var2, g2, b2, eps2, imean, ivar, w3v, g3, b3, eps3, wv, slope, dx2, grad_buf(g2p),
+                              grad_buf(b2p), grad_buf(g3p), grad_buf(b3p), dw3.view(-1) if dw3 is not None else None,
+                              dw.view(-1) if dw is not None else None, B, Cn, H, Wd)
+        return (dx2,) + (None,) * 18
+
+
+def res_tail_img_pool(x2, bn2, img, w3, bn3, w, slope):
+    return ResTailImgPoolFn.apply(x2, img, w3, w, slope, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+                                  bn2.num_batches_tracked, bn2.eps, bn2.momentum if bn2.momentum is not None else 0.1, bn3.weight,
+                                  bn3.bias, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked, bn3.eps,
+                                  bn3.momentum if bn3.momentum is not None else 0.1)
+
+
+def res_tail_img_pool_supported(x2, img, w3, bn2, bn3, w) -> bool:
+    """conv3 is a bias-free 1x1 conv of a one-channel bf16 image that needs no gradient"""
+    return bool(bn2.training and bn3.training and _bf(x2) and _bf(img) and img.dim() == 4 and img.shape[1] == 1
+                and not img.requires_grad and tuple(w3.shape[1:]) == (1, 1, 1) and w3.shape[0] == x2.shape[1]
+                and img.shape[0] == x2.shape[0] and tuple(img.shape[2:]) == tuple(x2.shape[2:]) and w.numel() == x2.shape[1]
+                and x2.data_ptr() % 16 == 0 and img.data_ptr() % 16 == 0
+                and kern._lib.lib().cenet_res_tail_supported(int(x2.shape[2]), int(x2.shape[3]))
+                and os.environ.get("CENET_RES_TAIL_FUSED", "1") not in ("0", "x3"))
+
+
 def res_tail_pool_supported(x2, x3, bn2, bn3, w) -> bool:
     return bool(bn2.training and bn3.training and x2.is_cuda == x3.is_cuda and kern.res_tail_supported(x2, x3)
                 and w.numel() == x2.shape[1] and os.environ.get("CENET_RES_TAIL_FUSED", "1") != "0")

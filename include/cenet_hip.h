@@ -350,6 +350,23 @@ int cenet_res_tail_bwd_bf16(const unsigned short* g, const unsigned short* x2, c
                             unsigned short* dx2, unsigned short* dx3, float* dgamma2_acc, float* dbeta2_acc, float* dgamma3_acc,
                             float* dbeta3_acc, float* dw_acc, float* ws, int B, int C, int H, int W, cenet_stream_t stream);
 
+/* The same with the shortcut branch NOT materialised (one-channel network input: unet.py conv3 is a 1x1 conv 1 -> C, x3 = w3[c] * img):
+ * BN3(x3) is an affine map of the image whose coefficients follow from the image's batch mean / variance (img_mean, img_var: one float
+ * each, cenet_bn_stats_* of the [B, 1, H, W] image).  Replaces, besides the above, the shortcut conv, its BatchNorm statistics pass and
+ * its weight-gradient kernel.  The forward kernel updates BatchNorm3's running statistics / batch counter (rmean3, rvar3, nbt3, momentum
+ * mom3; NULL: not wanted); the backward ADDS dw3 = the shortcut weight's gradient (it reaches the output through eps only). */
+int cenet_res_tail_img_fwd_bf16(const unsigned short* x2, const unsigned short* img, const float* mean2, const float* var2,
+                                const float* gamma2, const float* beta2, float eps2, const float* img_mean, const float* img_var,
+                                const float* w3, const float* gamma3, const float* beta3, float eps3, float* rmean3, float* rvar3,
+                                long* nbt3, float mom3, const float* w, float slope, unsigned short* out, int B, int C, int H, int W,
+                                cenet_stream_t stream);
+int cenet_res_tail_img_bwd_bf16(const unsigned short* g, const unsigned short* x2, const unsigned short* img, const float* mean2,
+                                const float* var2, const float* gamma2, const float* beta2, float eps2, const float* img_mean,
+                                const float* img_var, const float* w3, const float* gamma3, const float* beta3, float eps3,
+                                const float* w, float slope, unsigned short* dx2, float* dgamma2_acc, float* dbeta2_acc,
+                                float* dgamma3_acc, float* dbeta3_acc, float* dw3_acc, float* dw_acc, float* ws, int B, int C, int H,
+                                int W, cenet_stream_t stream);
+
 /* n <= 4 bias-free, activation-free depthwise 3x3 convs (flip = 1: their data gradients) / weight gradients of bf16 NCHW channel slices
  * in ONE launch — the three dilated SepConvBN branches of a CFAM block (cfam.py:208-212, blocks.py:142-150).  Branch i: x[i] (batch
  * stride sxb[i]) -> y[i] (syb[i]), C[i] channels, dilation dil[i], all on H x W maps of B images.  CENET_EUNSUPPORTED unless every

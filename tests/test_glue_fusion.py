@@ -318,7 +318,7 @@ def test_head_image_branch_tail_fused_equals_the_chain(dev, monkeypatch, B, Cn, 
     x = torch.randn(B, 1, H, W, generator=g).to(BF).to(dev)
     go = torch.randn(B, Cn, H // 2, W // 2, generator=g).to(BF).to(dev)
     res = []
-    for fused in ("1", "0"):
+    for fused in ("1", "x3", "0"):  # 1: shortcut not materialised (one-channel input); x3: the two-tensor form; 0: the chain
         monkeypatch.setenv("CENET_RES_TAIL_FUSED", fused)
         m = copy.deepcopy(blk).train()
         wc = w.detach().clone().requires_grad_(True)
@@ -329,7 +329,11 @@ def test_head_image_branch_tail_fused_equals_the_chain(dev, monkeypatch, B, Cn, 
         ops.wgrad_flush()
         res.append((out.detach().float(), wc.grad.clone(), [p_.grad.clone() for p_ in m.parameters()],
                     [b_.clone() for b_ in m.buffers()]))
-    f, u = res
+    for f in res[:2]:
+        _compare_tail(f, res[2])
+
+
+def _compare_tail(f, u):
     # the fused form rounds once where the chain rounds three times (two normalised maps and their sum): bf16-ulp differences,
     # and a window whose two largest activations tie after the chain's rounding may pick another element
     d = (f[0] - u[0]).abs()
@@ -384,3 +388,49 @@ def test_res_tail_kernels_against_fp64_autograd(dev):
     torch.testing.assert_close(bn[0].running_mean.double().cpu(), rm, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(bn[0].running_var.double().cpu(), rv, rtol=1e-4, atol=1e-5)
     assert int(bn[0].num_batches_tracked) == 1
+
+
+def test_res_tail_image_form_against_fp64_autograd(dev):
+    """shortcut = 1x1 conv of the one-channel image, never materialised: output, dx2 and every parameter gradient — including the
+    shortcut weight's, which reaches the output through eps only — against fp64 autograd of the unfused expression"""
+    import torch.nn.functional as F
+    B, Cn, H, W = 2, 6, 8, 16
+    g = torch.Generator().manual_seed(8)
+    x2 = torch.randn(B, Cn, H, W, generator=g).to(BF)
+    img = (0.5 * torch.randn(B, 1, H, W, generator=g) + 0.1).to(BF)
+    go = torch.randn(B, Cn, H // 2, W // 2, generator=g).to(BF)
+    w3 = torch.tensor([0.8, -0.6, 0.05, 1.3, -0.02, 0.4])
+    par = [(1 + 0.3 * torch.randn(Cn, generator=g)), 0.2 * torch.randn(Cn, generator=g), (1 + 0.3 * torch.randn(Cn, generator=g)),
+           0.2 * torch.randn(Cn, generator=g), torch.randn(Cn, generator=g) + 0.75]
+    eps3 = 1e-3  # (large enough for the eps-only gradient of w3 to be measurable against fp64)
+    r = [x2.double().requires_grad_(True), w3.double().requires_grad_(True)] + [p.double().requires_grad_(True) for p in par]
+    x3 = img.double() * r[1].view(1, -1, 1, 1)
+    y = F.leaky_relu(F.batch_norm(r[0], None, None, r[2], r[3], True, 0.1, 1e-5) + F.batch_norm(x3, None, None, r[4], r[5], True, 0.1, eps3), 0.01)
+    out_ref = F.max_pool2d(y, 2, 2) * r[6].view(1, -1, 1, 1)
+    out_ref.backward(go.double())
+    d = dev
+    bn = [torch.nn.BatchNorm2d(Cn).to(d).train(), torch.nn.BatchNorm2d(Cn, eps=eps3).to(d).train()]
+    with torch.no_grad():
+        bn[0].weight.copy_(par[0]); bn[0].bias.copy_(par[1]); bn[1].weight.copy_(par[2]); bn[1].bias.copy_(par[3])
+    w = par[4].to(d).view(1, Cn, 1, 1).requires_grad_(True)
+    w3d = w3.to(d).view(Cn, 1, 1, 1).requires_grad_(True)
+    a2 = x2.to(d).requires_grad_(True)
+    for p_ in [w, w3d] + list(bn[0].parameters()) + list(bn[1].parameters()):
+        p_.grad = torch.zeros_like(p_)
+    assert ops.res_tail_img_pool_supported(a2, img.to(d), w3d, bn[0], bn[1], w)
+    out = ops.res_tail_img_pool(a2, bn[0], img.to(d), w3d, bn[1], w, 0.01)
+    out.backward(go.to(d))
+    tol = dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out.float().cpu(), out_ref.float(), **tol)
+    torch.testing.assert_close(a2.grad.float().cpu(), r[0].grad.float(), **tol)
+    for got, want in ((bn[0].weight.grad, r[2].grad), (bn[0].bias.grad, r[3].grad), (bn[1].weight.grad, r[4].grad),
+                      (bn[1].bias.grad, r[5].grad), (w.grad.view(-1), r[6].grad)):
+        torch.testing.assert_close(got.float().cpu(), want.float(), rtol=2e-2, atol=3e-2)
+    # the shortcut weight's gradient: small (eps / var) but exact in form — compare with relative tolerance on its own scale
+    gw3, ref3 = w3d.grad.view(-1).double().cpu(), r[1].grad
+    assert float((gw3 - ref3).abs().max()) <= 0.05 * float(ref3.abs().max()) + 1e-7, (gw3, ref3)
+    # BatchNorm3's running statistics: those of w3 * img
+    x3f = img.double() * w3.double().view(1, -1, 1, 1)
+    torch.testing.assert_close(bn[1].running_mean.double().cpu(), 0.1 * x3f.mean((0, 2, 3)), rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(bn[1].running_var.double().cpu(), 0.9 + 0.1 * x3f.var((0, 2, 3), unbiased=True), rtol=1e-3, atol=1e-5)
+    assert int(bn[1].num_batches_tracked) == 1 and int(bn[0].num_batches_tracked) == 1
