@@ -152,8 +152,11 @@ __global__ __launch_bounds__(256) void res_tail_bwd_partial_kernel(ResTailArgs a
     for (int j = 0; j < 4; ++j) {
       sw += gv[j] * mv[j];
       const float d = gv[j] * wc * (mv[j] > 0.f ? 1.f : a.slope);
-      const int col = 2 * j + (am[j] & 1);
-      const float v2 = (am[j] & 2) ? l2[col] : u2[col], v3 = (am[j] & 2) ? l3[col] : u3[col];
+      // the window's maximal element (static indices: the loaded rows stay in registers)
+      float v2 = u2[2 * j], v3 = u3[2 * j];
+      if (am[j] == 1) v2 = u2[2 * j + 1], v3 = u3[2 * j + 1];
+      if (am[j] == 2) v2 = l2[2 * j], v3 = l3[2 * j];
+      if (am[j] == 3) v2 = l2[2 * j + 1], v3 = l3[2 * j + 1];
       sd += d;
       s2 += d * ((v2 - k.m2) * k.r2);
       s3 += d * ((v3 - k.m3) * k.r3);
