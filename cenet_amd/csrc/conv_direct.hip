@@ -225,6 +225,7 @@ struct ConvWgradArgs {
   const bf16_t* dy;  // [B, COUT, H, W]
   float* ws;         // [gridDim.x][COUT*CIN*KS*KS] partial sums, register order
   int B, H, W, tiles_x, tiles_y, ntiles;
+  int vec;           // 16-byte staging: W % 8 == 0 and 16-byte aligned tensors (else pixel pairs, 4 bytes at a time)
 };
 
 __device__ __forceinline__ unsigned funnel16(unsigned lo, unsigned hi) { return (lo >> 16) | (hi << 16); }
@@ -255,7 +256,70 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
   const int xcd = blockIdx.x % G, nloc = ((int)gridDim.x + G - 1 - xcd) / G;
   const int per = (a.ntiles + G - 1) / G;
   const int t_end = (xcd + 1) * per < a.ntiles ? (xcd + 1) * per : a.ntiles;
-  for (int tile = xcd * per + (int)blockIdx.x / G; tile < t_end; tile += nloc) {
+  // ---- staging, 16-byte form (a.vec): a halo row of X is the 48 pixels x0 - 8 .. x0 + 39 = six aligned 16-byte chunks that map
+  // one to one onto the 24 dwords of its LDS row (8 px pad | 32 px | 8 px pad), a dY row is four chunks.  A thread's chunks are the
+  // same for every tile (chunk number = tid + 256 q): their LDS offsets and image-relative offsets are computed once.  The chunks of
+  // tile t + 1 are fetched into registers BEFORE tile t is multiplied and written to LDS after it — the kernel was parked on its
+  // loads and barriers 62 - 66 % of the time (SQ_WAIT_ANY) with 4-byte loads issued and waited for between the tiles.
+  constexpr int NXC = CIN * HH * 6, NGC = COUT * TH_ * 4;
+  constexpr int QX = (NXC + 255) / 256, QG = (NGC + 255) / 256;
+  int xl[QX], xg[QX], xm[QX];  // LDS dword offset (-1: none), offset in the image batch relative to the tile origin, (hy | chunk << 8)
+  int gl[QG], gg[QG], gm[QG];
+  if (a.vec) {
+#pragma unroll
+    for (int q = 0; q < QX; ++q) {
+      const int u = tid + 256 * q;
+      const int c = u % 6, r2 = u / 6, hy = r2 % HH, ci = r2 / HH;
+      xl[q] = u < NXC ? ci * XPL + hy * XROW + 4 * c : -1;
+      xg[q] = ci * HWp + hy * a.W + 8 * c - 8;
+      xm[q] = hy | (c << 8);
+    }
+#pragma unroll
+    for (int q = 0; q < QG; ++q) {
+      const int u = tid + 256 * q;
+      const int c = u & 3, r2 = u >> 2, yy = r2 % TH_, co = r2 / TH_;
+      gl[q] = u < NGC ? co * GPL + yy * 16 + 4 * c : -1;
+      gg[q] = co * HWp + yy * a.W + 8 * c;
+      gm[q] = yy | (c << 8);
+    }
+  }
+  uint4 xv[QX], gv[QG];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
+    const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+    const int y0 = ty * TH_, x0 = tx * 32;
+    const bf16_t* xb = a.x + (long)b * CIN * HWp + (long)(y0 - P) * a.W + x0;
+    const bf16_t* gb = a.dy + (long)b * COUT * HWp + (long)y0 * a.W + x0;
+#pragma unroll
+    for (int q = 0; q < QX; ++q) {
+      const int iy = y0 - P + (xm[q] & 255), ix = x0 - 8 + 8 * (xm[q] >> 8);
+      xv[q] = uint4{0u, 0u, 0u, 0u};
+      if (xl[q] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) memcpy(&xv[q], xb + xg[q], 16);
+    }
+#pragma unroll
+    for (int q = 0; q < QG; ++q) {
+      const int iy = y0 + (gm[q] & 255), ix = x0 + 8 * (gm[q] >> 8);
+      gv[q] = uint4{0u, 0u, 0u, 0u};
+      if (gl[q] >= 0 && iy < a.H && ix < a.W) memcpy(&gv[q], gb + gg[q], 16);
+    }
+  };
+  auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < QX; ++q)
+      if (xl[q] >= 0) memcpy(&Xs[xl[q]], &xv[q], 16);
+#pragma unroll
+    for (int q = 0; q < QG; ++q)
+      if (gl[q] >= 0) memcpy(&Gs[gl[q]], &gv[q], 16);
+  };
+  const int tile0 = xcd * per + (int)blockIdx.x / G;
+  if (a.vec && tile0 < t_end) {
+    fetch(tile0);
+    stage();
+  }
+  for (int tile = tile0; tile < t_end; tile += nloc) {
+    if (a.vec) {
+      if (tile + nloc < t_end) fetch(tile + nloc);  // in flight while this tile is multiplied
+    } else {
     const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
     const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
     const int y0 = ty * TH_, x0 = tx * 32;
@@ -324,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
         }
       }
     }
+    }
     __syncthreads();
     // ---- one k-step (32 pixels) per tile row
     for (int row = 0; row < TH_; ++row) {
@@ -350,6 +415,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
           }
         }
       }
+    }
+    if (a.vec && tile + nloc < t_end) {
+      __syncthreads();  // this tile's fragments are consumed
+      stage();
     }
   }
   // ---- partial sums, register order: ws[block][((wave*NPW + j)*KK + t)*256 + lane*4 + r]
@@ -395,11 +464,20 @@ extern "C" int cenet_conv_wgrad_direct_bf16(const bf16_t* x, const bf16_t* dy, f
   if (!cenet_conv_wgrad_direct_supported(Cin, Cout, k, 1, k / 2)) return CENET_EUNSUPPORTED;
   ConvWgradArgs a;
   a.x = x; a.dy = dy; a.ws = ws; a.B = B; a.H = H; a.W = W;
+  {
+    static const bool no_vec = getenv("CENET_WGRAD_NO_VEC") != nullptr;  // measurement aid
+    a.vec = !no_vec && (W & 7) == 0 && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0) && H < 256 &&
+            (long)(Cin > Cout ? Cin : Cout) * H * W < (1L << 30);  // (row index in 8 bits, image-relative offsets in an int)
+  }
   const int th = (k == 5) ? 8 : 4;
   a.tiles_x = cdiv(W, 32);
   a.tiles_y = cdiv(H, th);
   a.ntiles = B * a.tiles_x * a.tiles_y;
-  const int grid = a.ntiles < CENET_WGRAD_SLABS ? a.ntiles : CENET_WGRAD_SLABS;
+  int grid = a.ntiles < CENET_WGRAD_SLABS ? a.ntiles : CENET_WGRAD_SLABS;
+  if (const char* e = getenv("CENET_WGRAD_GRID")) {  // test aid: few workgroups, so that each one walks several tiles
+    const int gset = atoi(e);
+    if (gset >= 1 && gset < grid) grid = gset;
+  }
   if (k == 5) CENET_LAUNCH((conv_wgrad_direct_kernel<32, 32, 5, 8>), dim3(grid), dim3(256), stream, a);
   else if (Cout == 64) CENET_LAUNCH((conv_wgrad_direct_kernel<64, 64, 3, 4>), dim3(grid), dim3(256), stream, a);
   else CENET_LAUNCH((conv_wgrad_direct_kernel<64, 32, 3, 4>), dim3(grid), dim3(256), stream, a);

@@ -118,8 +118,9 @@ def test_whole_model_bf16_mode_stays_close_to_fp32_goldens():
     assert abs(O.mean_class_dice(le, lab.cpu(), cfg.num_classes) - float(z["dice_eval"])) < 1e-3
 
 
-@pytest.mark.parametrize("Cin,Cout,k,H,W", [(32, 32, 5, 16, 40), (64, 64, 3, 12, 36), (64, 32, 3, 9, 33), (32, 32, 5, 11, 70)])
-def test_direct_conv_bf16_fwd_and_dgrad(dev, bf16_mode, Cin, Cout, k, H, W):
+@pytest.mark.parametrize("Cin,Cout,k,H,W", [(32, 32, 5, 16, 40), (64, 64, 3, 12, 36), (64, 32, 3, 9, 33), (32, 32, 5, 11, 70),
+                                            (64, 64, 3, 12, 48), (64, 32, 3, 9, 72), (32, 32, 5, 19, 104)])
+def test_direct_conv_bf16_fwd_and_dgrad(dev, bf16_mode, monkeypatch, Cin, Cout, k, H, W):
     """conv_direct.hip (LDS-halo direct convolution of the output head) vs fp32 torch conv, forward and data-gradient;
     ragged tiles (H, W not multiples of the 8x32 tile, odd W) included; the weight gradient of the three forward shapes
     is the direct kernel as well (LDS tiles + funnel-shifted tap windows)."""
@@ -131,6 +132,8 @@ def test_direct_conv_bf16_fwd_and_dgrad(dev, bf16_mode, Cin, Cout, k, H, W):
     go = torch.randn(B, Cout, H, W, generator=g).to(dev).to(BF)
     bf16_mode()
     assert kern.conv_direct_supported(Cin, Cout, k, 1, k // 2)
+    if W % 8 == 0 and H > 12:  # (weight gradient, 16-byte staging: three workgroups, so that each walks several tiles and the
+        monkeypatch.setenv("CENET_WGRAD_GRID", "3")  # next tile's register prefetch / late LDS write is exercised)
     y = ops.conv2d_nchw(x, w, None, stride=1, pad=k // 2)
     y.backward(go)
     xr = f32(x)

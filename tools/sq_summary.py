@@ -10,7 +10,7 @@ rows = collections.defaultdict(lambda: collections.defaultdict(float))
 meta = {}
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"].replace("void ", "").split("(")[0]
-    if not n.startswith(("dattn_", "sra_", "flashc_")):
+    if not n.startswith(("dattn_", "sra_", "flashc_", "conv_wgrad", "conv_direct")):
         continue
     key = (n, int(r["Grid_Size"]))
     rows[key][r["Counter_Name"]] += float(r["Counter_Value"])
