@@ -318,18 +318,26 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const T* __restri
 // x0.5 down-sampling: output o reads (2o: .5, 2o+1: .5), so dx[i] = .25 g[i/2][j/2]
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_down2_bwd_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx, long sdb,
-                                                                int C, int Ho, int Wo) {
+                                                                int C, int Ho, int Wo, const T* __restrict__ dx_add) {
   const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
   const T* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
   T* dp = dx + (long)b * sdb + (long)c * 4 * Ho * Wo;
+  const T* ap = dx_add ? dx_add + (long)b * sdb + (long)c * 4 * Ho * Wo : nullptr;  // (laid out like dx)
   for (int p = blockIdx.y * 256 + threadIdx.x; p < Ho * Wo; p += gridDim.y * 256) {
     const int oy = p / Wo, ox = p - oy * Wo;
     const float v = 0.25f * ldf(gp + p);
-    T* o = dp + (long)(2 * oy) * (2 * Wo) + 2 * ox;
-    stf(o, v);
-    stf(o + 1, v);
-    stf(o + 2 * Wo, v);
-    stf(o + 2 * Wo + 1, v);
+    const long off = (long)(2 * oy) * (2 * Wo) + 2 * ox;
+    T* o = dp + off;
+    float q[4] = {v, v, v, v};
+    if (ap) {
+      float t[4];
+      ldv<2>(t, ap + off);
+      ldv<2>(t + 2, ap + off + 2 * Wo);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[e] += t[e];
+    }
+    stv<2>(o, q);
+    stv<2>(o + 2 * Wo, q + 2);
   }
 }
 
@@ -379,7 +387,14 @@ template <typename T>
 static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
                              float scale_w, int align_corners, hipStream_t stream, const T* dx_add = nullptr) {
   if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CENET_EINVAL;
-  if (dx_add) {  // with an addend: the general kernel (the specialised forms below have no such operand)
+  if (dx_add && sizeof(T) == 2 && !align_corners && Hi == 2 * Ho && Wi == 2 * Wo && scale_h == 2.0f && scale_w == 2.0f &&
+      ((((uintptr_t)dx | (uintptr_t)dx_add) & 3) == 0) && (sdb & 1) == 0) {
+    CENET_LAUNCH((bilinear_down2_bwd_kernel<T>), dim3(B * C, chunks_for(Ho * Wo)), dim3(256), stream, dy, sgb, dx, sdb, C, Ho, Wo,
+                 dx_add);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
+  if (dx_add) {  // with an addend: the general kernel (the other specialised forms have no such operand)
     if (scale_w >= 0.5f)
       CENET_LAUNCH((bilinear_bwd_kernel<T, 6>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho,
                    Wo, scale_h, scale_w, align_corners, dx_add);
@@ -403,7 +418,8 @@ static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int 
     return CENET_OK;
   }
   if (sizeof(T) == 2 && !align_corners && Hi == 2 * Ho && Wi == 2 * Wo && scale_h == 2.0f && scale_w == 2.0f) {
-    CENET_LAUNCH((bilinear_down2_bwd_kernel<T>), dim3(B * C, chunks_for(Ho * Wo)), dim3(256), stream, dy, sgb, dx, sdb, C, Ho, Wo);
+    CENET_LAUNCH((bilinear_down2_bwd_kernel<T>), dim3(B * C, chunks_for(Ho * Wo)), dim3(256), stream, dy, sgb, dx, sdb, C, Ho, Wo,
+                 (const T*)nullptr);
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }

@@ -9,6 +9,7 @@
 // 1/C of the activation) are always fp32.  Plane kernels take a vector width V (4 when HW % 4 == 0 and the planes are
 // quad-aligned, else 1); HWv = HW / V.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cenet_hip.h"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -365,8 +366,9 @@ __global__ __launch_bounds__(256) void srm_conv_fwd_kernel(const float* __restri
 }
 
 // du[b,ch,p] from df[b,p]; weight grads (3 + 27): per-thread partial sums over the workgroup's pixel chunks, ONE set of 30
-// block sums and 30 float atomics per workgroup.  (All 30 gradients live in one cache line and same-line atomics serialise at
-// ~12 ns each: with a workgroup per 256 pixels the 56x56 level issued 12 480 of them = 150 us; the grid is now (<= 2, B).)
+// sums and 30 float atomics per workgroup.  (All 30 gradients live in one cache line and same-line atomics serialise at
+// ~12 ns each: with a workgroup per 256 pixels the 56x56 level issued 12 480 of them = 150 us; the grid is now (1, B) — one
+// workgroup per image walks its pixels — 960 atomics: round 4, 38 -> ~10 us per call at 56x56.)
 __global__ __launch_bounds__(256) void srm_conv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ df,
                                                           const float* __restrict__ pwc, const float* __restrict__ dwc,
                                                           float* __restrict__ du, float* __restrict__ dpwc,
@@ -401,15 +403,22 @@ __global__ __launch_bounds__(256) void srm_conv_bwd_kernel(const float* __restri
       wsum[ch][9] += g * ub[ch * HW + p];
     }
   }
+  // the 30 sums: wave shuffles, then ONE pass through LDS (30 block_sum calls were 60 barriers per workgroup)
+  __shared__ float part[4][30];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    const float sp = block_sum(wsum[ch][9], red);
-    if (threadIdx.x == 0) atomicAdd(&dpwc[ch], sp);
+  for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float sw = block_sum(wsum[ch][t], red);
-      if (threadIdx.x == 0) atomicAdd(&ddwc[ch * 9 + t], sw);
+    for (int t = 0; t < 10; ++t) {
+      const float v = wave_sum(wsum[ch][t]);
+      if (lane == 0) part[wave][ch * 10 + t] = v;
     }
+  __syncthreads();
+  if (threadIdx.x < 30) {
+    const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    const int ch = threadIdx.x / 10, t = threadIdx.x - ch * 10;
+    if (t == 9) atomicAdd(&dpwc[ch], v);
+    else atomicAdd(&ddwc[ch * 9 + t], v);
   }
 }
 
@@ -742,8 +751,9 @@ extern "C" int cenet_srm_conv_fwd_f32(const float* u, const float* pwc, const fl
 extern "C" int cenet_srm_conv_bwd_acc_f32(const float* u, const float* df, const float* pwc, const float* dwc, float* du,
                                           float* dpwc_acc, float* ddwc_acc, int B, int H, int W, hipStream_t stream) {
   if (B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
-  CENET_LAUNCH(srm_conv_bwd_kernel, dim3(H * W > 2048 ? 4 : (H * W > 512 ? 2 : 1), B), dim3(256), stream, u, df, pwc, dwc, du, dpwc_acc, ddwc_acc, H,
-               W);
+  static const int gx = getenv("CENET_SRM_BWD_GX") ? atoi(getenv("CENET_SRM_BWD_GX")) : 0;  // measurement aid
+  CENET_LAUNCH(srm_conv_bwd_kernel, dim3(gx > 0 ? gx : (H * W > 8192 ? 2 : 1), B), dim3(256), stream, u, df, pwc, dwc, du, dpwc_acc,
+               ddwc_acc, H, W);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
