@@ -1137,6 +1137,89 @@ __global__ __launch_bounds__(256) void bn_bwd_1k_kernel(const bf16_t* __restrict
   }
 }
 
+// ---- BatchNorm1d on a [B, C] fp32 matrix, B <= 64 (the CCU gate, cfam.py:251-264: one value per image and channel) ------------------
+// The plane kernels treat this as C planes of B strided single elements: a 32-iteration serial loop per workgroup in the partial
+// passes and B * C workgroups of one busy thread in the apply passes — 5 launches and ~55 us per CCU for a 64 KB tensor.  Here a
+// THREAD owns a channel, its B values live in registers (coalesced over the channels of a row), and a pass is one launch.
+#define BN1D_MAXB 64
+__global__ __launch_bounds__(256) void bn1d_train_fwd_kernel(const float* __restrict__ z, float* __restrict__ zn,
+                                                            float* __restrict__ mean, float* __restrict__ var, float* rmean,
+                                                            float* rvar, float momentum, long* nbt, float eps,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int B,
+                                                            int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  float v[BN1D_MAXB];
+  float s = 0.f;
+#pragma unroll
+  for (int b = 0; b < BN1D_MAXB; ++b) {
+    v[b] = b < B ? z[(long)b * C + c] : 0.f;
+    s += v[b];
+  }
+  const float mu = s / B;
+  float q = 0.f;
+#pragma unroll
+  for (int b = 0; b < BN1D_MAXB; ++b)
+    if (b < B) q += (v[b] - mu) * (v[b] - mu);
+  const float va = q / B;
+  mean[c] = mu;
+  var[c] = va;
+  if (rmean) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * va * ((float)B / (float)(B - 1));
+  }
+  const float a = gamma[c] * rsqrtf(va + eps), sh = beta[c] - a * mu;
+#pragma unroll
+  for (int b = 0; b < BN1D_MAXB; ++b)
+    if (b < B) zn[(long)b * C + c] = a * v[b] + sh;
+}
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dz,
+                                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                      const float* __restrict__ gamma, float* dgamma, float* dbeta, int B, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c];
+  float g[BN1D_MAXB], xh[BN1D_MAXB];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int b = 0; b < BN1D_MAXB; ++b) {
+    g[b] = b < B ? dy[(long)b * C + c] : 0.f;
+    xh[b] = b < B ? (z[(long)b * C + c] - mu) * rs : 0.f;
+    s1 += g[b];
+    s2 += g[b] * xh[b];
+  }
+  const float m1 = s1 / B, m2 = s2 / B;
+#pragma unroll
+  for (int b = 0; b < BN1D_MAXB; ++b)
+    if (b < B) dz[(long)b * C + c] = gm * rs * (g[b] - m1 - xh[b] * m2);
+  if (dgamma) dgamma[c] += s2;  // (this thread is the channel's only writer)
+  if (dbeta) dbeta[c] += s1;
+}
+extern "C" int cenet_bn1d_supported(int B) { return B >= 2 && B <= BN1D_MAXB; }
+/* train-mode BatchNorm1d of z [B, C] (fp32, 2 <= B <= 64): zn = gamma (z - mean) / sqrt(var + eps) + beta, batch mean / biased
+ * variance written, running statistics (unbiased variance) and the batch counter updated (NULL: not wanted) — one launch */
+extern "C" int cenet_bn1d_train_fwd_f32(const float* z, float* zn, float* mean, float* var, float* running_mean, float* running_var,
+                                        float momentum, long* num_batches_tracked, float eps, const float* gamma, const float* beta,
+                                        int B, int C, hipStream_t stream) {
+  if (!z || !zn || !mean || !var || !gamma || !beta || C <= 0 || (running_mean != nullptr) != (running_var != nullptr))
+    return CENET_EINVAL;
+  if (!cenet_bn1d_supported(B)) return CENET_EUNSUPPORTED;
+  CENET_LAUNCH(bn1d_train_fwd_kernel, dim3(cdiv(C, 256)), dim3(256), stream, z, zn, mean, var, running_mean, running_var, momentum,
+               num_batches_tracked, eps, gamma, beta, B, C);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+/* its backward: dz written; dgamma / dbeta ADDED into (NULL: not wanted) — one launch */
+extern "C" int cenet_bn1d_bwd_acc_f32(const float* dy, const float* z, float* dz, const float* mean, const float* var, float eps,
+                                      const float* gamma, float* dgamma_acc, float* dbeta_acc, int B, int C, hipStream_t stream) {
+  if (!dy || !z || !dz || !mean || !var || !gamma || C <= 0) return CENET_EINVAL;
+  if (!cenet_bn1d_supported(B)) return CENET_EUNSUPPORTED;
+  CENET_LAUNCH(bn1d_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), stream, dy, z, dz, mean, var, eps, gamma, dgamma_acc, dbeta_acc, B, C);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
 // the flat forms apply: bf16 tensors (the fp32 parity mode keeps its summation order), small planes, no batch gaps
 template <typename T>
 static inline bool bn_flat_ok(int C, int HW, long s0, long s1, long s2) {

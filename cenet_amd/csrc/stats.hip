@@ -367,8 +367,8 @@ __global__ __launch_bounds__(256) void srm_conv_fwd_kernel(const float* __restri
 
 // du[b,ch,p] from df[b,p]; weight grads (3 + 27): per-thread partial sums over the workgroup's pixel chunks, ONE set of 30
 // sums and 30 float atomics per workgroup.  (All 30 gradients live in one cache line and same-line atomics serialise at
-// ~12 ns each: with a workgroup per 256 pixels the 56x56 level issued 12 480 of them = 150 us; the grid is now (1, B) — one
-// workgroup per image walks its pixels — 960 atomics: round 4, 38 -> ~10 us per call at 56x56.)
+// ~12 ns each: with a workgroup per 256 pixels the 56x56 level issued 12 480 of them = 150 us.  Round 4: the 30 sums meet in ONE
+// pass through LDS instead of 30 block_sum calls = 60 barriers, and the grid is (min(8, pixels / 256), B): 38 -> 19 us per call.)
 __global__ __launch_bounds__(256) void srm_conv_bwd_kernel(const float* __restrict__ u, const float* __restrict__ df,
                                                           const float* __restrict__ pwc, const float* __restrict__ dwc,
                                                           float* __restrict__ du, float* __restrict__ dpwc,
@@ -752,8 +752,10 @@ extern "C" int cenet_srm_conv_bwd_acc_f32(const float* u, const float* df, const
                                           float* dpwc_acc, float* ddwc_acc, int B, int H, int W, hipStream_t stream) {
   if (B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
   static const int gx = getenv("CENET_SRM_BWD_GX") ? atoi(getenv("CENET_SRM_BWD_GX")) : 0;  // measurement aid
-  CENET_LAUNCH(srm_conv_bwd_kernel, dim3(gx > 0 ? gx : (H * W > 8192 ? 2 : 1), B), dim3(256), stream, u, df, pwc, dwc, du, dpwc_acc,
-               ddwc_acc, H, W);
+  // measured at the four decoder levels of the ACDC preset, average us per call: gx = 1: 52, 2: 32, 4: 23, 8: 19, 12: 21, 16: 21, 32: 29
+  int want = cdiv(H * W, 256);
+  if (want > 8) want = 8;
+  CENET_LAUNCH(srm_conv_bwd_kernel, dim3(gx > 0 ? gx : want, B), dim3(256), stream, u, df, pwc, dwc, du, dpwc_acc, ddwc_acc, H, W);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -389,6 +389,26 @@ def bn_stats(x, sb, B, Cn, HW, ws, mean, var, rmean, rvar, momentum, nbt):
     _call("cenet_bn_stats_f32", x, L(sb), B, Cn, HW, ws, mean, var, rmean, rvar, float(momentum), nbt)
 
 
+def bn1d_supported(B: int) -> bool:
+    return bool(_lib.lib().cenet_bn1d_supported(int(B)))
+
+
+def bn1d_train_fwd(z, zn, mean, var, rmean, rvar, momentum, nbt, eps, gamma, beta, B, Cn):
+    """train-mode BatchNorm1d of a [B, C] fp32 matrix (2 <= B <= 64) in one launch: zn, mean / var, running statistics, counter"""
+    _chk(z, zn, mean, var, rmean, rvar, gamma, beta)
+    assert z.dtype == torch.float32 and zn.dtype == torch.float32
+    _lib.check(_lib.lib().cenet_bn1d_train_fwd_f32(P(z), P(zn), P(mean), P(var), P(rmean), P(rvar), C.c_float(momentum), P(nbt),
+                                                   C.c_float(eps), P(gamma), P(beta), int(B), int(Cn), stream()),
+               "cenet_bn1d_train_fwd_f32")
+
+
+def bn1d_bwd(dy, z, dz, mean, var, eps, gamma, dgamma, dbeta, B, Cn):
+    _chk(dy, z, dz, mean, var, gamma, dgamma, dbeta)
+    assert dy.dtype == torch.float32 and z.dtype == torch.float32
+    _lib.check(_lib.lib().cenet_bn1d_bwd_acc_f32(P(dy), P(z), P(dz), P(mean), P(var), C.c_float(eps), P(gamma), P(dgamma), P(dbeta),
+                                                 int(B), int(Cn), stream()), "cenet_bn1d_bwd_acc_f32")
+
+
 def bn_train_fwd(x, sxb, y, syb, ws, mean, var, rmean, rvar, momentum, nbt, eps, gamma, beta, act, slope, B, Cn, HW):
     """train-mode BatchNorm forward: statistics + normalisation (+ activation), mean / var / running statistics written"""
     _chk(x, y, ws, mean, var, rmean, rvar, gamma, beta)

@@ -2289,13 +2289,18 @@ class CCUFn(Function):
         mean = var = None
         if use_bn:
             zn = torch.empty_like(z)
-            if training:
+            if training and kern.bn1d_supported(B):
+                # [B, C] fp32 with one value per image and channel: statistics + running update + normalisation in ONE launch
                 mean, var = _empty((Cn,), x), _empty((Cn,), x)
-                ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
-                kern.bn_stats(z, Cn, B, Cn, 1, ws, mean, var, bn_rm, bn_rv, 0.1, bn_nbt)
+                kern.bn1d_train_fwd(z, zn, mean, var, bn_rm, bn_rv, 0.1, bn_nbt, 1e-5, bn_w, bn_b, B, Cn)
             else:
-                mean, var = bn_rm, bn_rv
-            kern.bn_apply(z, Cn, zn, Cn, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, Cn, 1)
+                if training:
+                    mean, var = _empty((Cn,), x), _empty((Cn,), x)
+                    ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
+                    kern.bn_stats(z, Cn, B, Cn, 1, ws, mean, var, bn_rm, bn_rv, 0.1, bn_nbt)
+                else:
+                    mean, var = bn_rm, bn_rv
+                kern.bn_apply(z, Cn, zn, Cn, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, Cn, 1)
         else:
             zn = z
         y = torch.empty_like(x)
@@ -2322,11 +2327,14 @@ class CCUFn(Function):
             if not training:
                 raise RuntimeError("CCU backward needs training-mode BatchNorm")
             dz = torch.empty_like(dzn)
-            ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
             dg, db = grad_buf(ctx.refs[2]), grad_buf(ctx.refs[3])
-            if dg is None:
-                dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
-            kern.bn_bwd(dzn, Cn, z, Cn, dz, Cn, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, Cn, 1, ws, dg, db)
+            if kern.bn1d_supported(B):
+                kern.bn1d_bwd(dzn, z, dz, mean, var, 1e-5, bn_w, dg, db, B, Cn)  # (one launch; NULL gradients: frozen affine)
+            else:
+                ws = _empty((2 * Cn * 256,), x)  # CENET_BN_WS_FLOATS(C)
+                if dg is None:
+                    dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
+                kern.bn_bwd(dzn, Cn, z, Cn, dz, Cn, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, Cn, 1, ws, dg, db)
         else:
             dz = dzn
         d1, d2 = grad_buf(ctx.refs[0]), grad_buf(ctx.refs[1])

@@ -278,6 +278,16 @@ int cenet_bn_bwd_add_acc_f32(const float* dy, long sgb, const float* x, long sxb
                              int act, float slope, int B, int C, int HW, float* ws, float* dgamma_acc, float* dbeta_acc,
                              cenet_stream_t stream);
 
+/* BatchNorm1d on a [B, C] fp32 matrix with 2 <= B <= 64 (the CCU gate, cfam.py:251-264: one value per image and channel), training
+ * mode, forward and backward in ONE launch each (a thread owns a channel; round 4).  Forward: zn, batch mean / biased variance, running
+ * statistics (unbiased variance) and the batch counter (NULL: not wanted); backward: dz written, dgamma / dbeta ADDED into. */
+int cenet_bn1d_supported(int B);
+int cenet_bn1d_train_fwd_f32(const float* z, float* zn, float* mean, float* var, float* running_mean, float* running_var,
+                             float momentum, long* num_batches_tracked, float eps, const float* gamma, const float* beta, int B,
+                             int C, cenet_stream_t stream);
+int cenet_bn1d_bwd_acc_f32(const float* dy, const float* z, float* dz, const float* mean, const float* var, float eps,
+                           const float* gamma, float* dgamma_acc, float* dbeta_acc, int B, int C, cenet_stream_t stream);
+
 /* ---- depthwise 3x3 conv (dwconv.hip) — aten::convolution(groups=C)(+_backward) ------------------------------ */
 /* pvtv2.py:359-370 (token layout), cfam.py:132-140, blocks.py:142-150,305 (NCHW). y = conv(x)+bias; a = act(y) if a. */
 int cenet_dwconv3x3_nchw_f32(const float* x, long sxb, const float* w, const float* bias, float* y, long syb, float* a,

@@ -434,3 +434,32 @@ def test_res_tail_image_form_against_fp64_autograd(dev):
     torch.testing.assert_close(bn[1].running_mean.double().cpu(), 0.1 * x3f.mean((0, 2, 3)), rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(bn[1].running_var.double().cpu(), 0.9 + 0.1 * x3f.var((0, 2, 3), unbiased=True), rtol=1e-3, atol=1e-5)
     assert int(bn[1].num_batches_tracked) == 1 and int(bn[0].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("B,Cn", [(2, 5), (32, 64), (7, 300), (64, 33)])
+def test_batchnorm1d_one_launch_each_way(dev, B, Cn):
+    """the CCU gate's BatchNorm1d on a [B, C] fp32 matrix (cfam.py:251-264): one kernel per pass, against torch"""
+    g = torch.Generator().manual_seed(B + Cn)
+    z = torch.randn(B, Cn, generator=g) * 2 + 0.5
+    go = torch.randn(B, Cn, generator=g)
+    ref = torch.nn.BatchNorm1d(Cn).train()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5, generator=g)
+        ref.bias.uniform_(-0.5, 0.5, generator=g)
+    zr = z.clone().requires_grad_(True)
+    ref(zr).backward(go)
+    gam, bet = ref.weight.detach().clone().to(dev), ref.bias.detach().clone().to(dev)
+    rm, rv, nbt = torch.zeros(Cn).to(dev), torch.ones(Cn).to(dev), torch.zeros(1, dtype=torch.long).to(dev)
+    zd, zn, mean, var = z.to(dev), torch.empty(B, Cn).to(dev), torch.empty(Cn).to(dev), torch.empty(Cn).to(dev)
+    assert kern.bn1d_supported(B)
+    kern.bn1d_train_fwd(zd, zn, mean, var, rm, rv, 0.1, nbt, 1e-5, gam, bet, B, Cn)
+    torch.testing.assert_close(zn.cpu(), ref(z).detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rm.cpu(), ref.running_mean / 1.0 * 0 + 0.1 * z.mean(0), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv.cpu(), 0.9 + 0.1 * z.var(0, unbiased=True), rtol=1e-5, atol=1e-6)
+    assert int(nbt) == 1
+    dz, dg, db = torch.empty(B, Cn).to(dev), torch.full((Cn,), 2.0).to(dev), torch.full((Cn,), -1.0).to(dev)
+    kern.bn1d_bwd(go.to(dev), zd, dz, mean, var, 1e-5, gam, dg, db, B, Cn)
+    torch.testing.assert_close(dz.cpu(), zr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dg.cpu() - 2.0, ref.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu() + 1.0, ref.bias.grad, rtol=1e-4, atol=1e-4)
+    assert not kern.bn1d_supported(1) and not kern.bn1d_supported(65)
