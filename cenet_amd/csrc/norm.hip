@@ -1139,62 +1139,88 @@ __global__ __launch_bounds__(256) void bn_bwd_1k_kernel(const bf16_t* __restrict
 
 // ---- BatchNorm1d on a [B, C] fp32 matrix, B <= 64 (the CCU gate, cfam.py:251-264: one value per image and channel) ------------------
 // The plane kernels treat this as C planes of B strided single elements: a 32-iteration serial loop per workgroup in the partial
-// passes and B * C workgroups of one busy thread in the apply passes — 5 launches and ~55 us per CCU for a 64 KB tensor.  Here a
-// THREAD owns a channel, its B values live in registers (coalesced over the channels of a row), and a pass is one launch.
+// passes and B * C workgroups of one busy thread in the apply passes — 5 launches and ~55 us per CCU for a 64 KB tensor.  Here the
+// B values of a channel live in the registers of four threads (coalesced over the channels of a row), and a pass is one launch.
 #define BN1D_MAXB 64
+// workgroup = 64 channels x 4 row groups (thread (cx, gy) owns rows gy, gy + 4, ... of channel c: <= 16 values in registers, the loads
+// of a wave are 256-byte row segments); the four groups meet in LDS
 __global__ __launch_bounds__(256) void bn1d_train_fwd_kernel(const float* __restrict__ z, float* __restrict__ zn,
                                                             float* __restrict__ mean, float* __restrict__ var, float* rmean,
                                                             float* rvar, float momentum, long* nbt, float eps,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int B,
                                                             int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0 && nbt) nbt[0] += 1;
-  if (c >= C) return;
-  float v[BN1D_MAXB];
+  __shared__ float red[2][4][64];
+  const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+  const bool ok = c < C;
+  float v[BN1D_MAXB / 4];
   float s = 0.f;
 #pragma unroll
-  for (int b = 0; b < BN1D_MAXB; ++b) {
-    v[b] = b < B ? z[(long)b * C + c] : 0.f;
-    s += v[b];
+  for (int i = 0; i < BN1D_MAXB / 4; ++i) {
+    const int b = gy + 4 * i;
+    v[i] = (ok && b < B) ? z[(long)b * C + c] : 0.f;
+    s += v[i];
   }
-  const float mu = s / B;
+  red[0][gy][cx] = s;
+  __syncthreads();
+  const float mu = (red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx]) / B;
   float q = 0.f;
 #pragma unroll
-  for (int b = 0; b < BN1D_MAXB; ++b)
-    if (b < B) q += (v[b] - mu) * (v[b] - mu);
-  const float va = q / B;
-  mean[c] = mu;
-  var[c] = va;
-  if (rmean) {
-    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-    rvar[c] = (1.f - momentum) * rvar[c] + momentum * va * ((float)B / (float)(B - 1));
+  for (int i = 0; i < BN1D_MAXB / 4; ++i)
+    if (gy + 4 * i < B) q += (v[i] - mu) * (v[i] - mu);
+  red[1][gy][cx] = q;
+  __syncthreads();
+  const float va = (red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx]) / B;
+  if (!ok) return;
+  if (gy == 0) {
+    mean[c] = mu;
+    var[c] = va;
+    if (rmean) {
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * va * ((float)B / (float)(B - 1));
+    }
   }
   const float a = gamma[c] * rsqrtf(va + eps), sh = beta[c] - a * mu;
 #pragma unroll
-  for (int b = 0; b < BN1D_MAXB; ++b)
-    if (b < B) zn[(long)b * C + c] = a * v[b] + sh;
+  for (int i = 0; i < BN1D_MAXB / 4; ++i) {
+    const int b = gy + 4 * i;
+    if (b < B) zn[(long)b * C + c] = a * v[i] + sh;
+  }
 }
 __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dz,
                                                       const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                                       const float* __restrict__ gamma, float* dgamma, float* dbeta, int B, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c];
-  float g[BN1D_MAXB], xh[BN1D_MAXB];
+  __shared__ float red[2][4][64];
+  const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
+  const bool ok = c < C;
+  const float rs = ok ? rsqrtf(var[c] + eps) : 0.f, mu = ok ? mean[c] : 0.f, gm = ok ? gamma[c] : 0.f;
+  float g[BN1D_MAXB / 4], xh[BN1D_MAXB / 4];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int b = 0; b < BN1D_MAXB; ++b) {
-    g[b] = b < B ? dy[(long)b * C + c] : 0.f;
-    xh[b] = b < B ? (z[(long)b * C + c] - mu) * rs : 0.f;
-    s1 += g[b];
-    s2 += g[b] * xh[b];
+  for (int i = 0; i < BN1D_MAXB / 4; ++i) {
+    const int b = gy + 4 * i;
+    const bool in = ok && b < B;
+    g[i] = in ? dy[(long)b * C + c] : 0.f;
+    xh[i] = in ? (z[(long)b * C + c] - mu) * rs : 0.f;
+    s1 += g[i];
+    s2 += g[i] * xh[i];
   }
+  red[0][gy][cx] = s1;
+  red[1][gy][cx] = s2;
+  __syncthreads();
+  s1 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+  s2 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+  if (!ok) return;
   const float m1 = s1 / B, m2 = s2 / B;
 #pragma unroll
-  for (int b = 0; b < BN1D_MAXB; ++b)
-    if (b < B) dz[(long)b * C + c] = gm * rs * (g[b] - m1 - xh[b] * m2);
-  if (dgamma) dgamma[c] += s2;  // (this thread is the channel's only writer)
-  if (dbeta) dbeta[c] += s1;
+  for (int i = 0; i < BN1D_MAXB / 4; ++i) {
+    const int b = gy + 4 * i;
+    if (b < B) dz[(long)b * C + c] = gm * rs * (g[i] - m1 - xh[i] * m2);
+  }
+  if (gy == 0) {  // (this thread is the channel's only writer)
+    if (dgamma) dgamma[c] += s2;
+    if (dbeta) dbeta[c] += s1;
+  }
 }
 extern "C" int cenet_bn1d_supported(int B) { return B >= 2 && B <= BN1D_MAXB; }
 /* train-mode BatchNorm1d of z [B, C] (fp32, 2 <= B <= 64): zn = gamma (z - mean) / sqrt(var + eps) + beta, batch mean / biased
@@ -1205,7 +1231,7 @@ extern "C" int cenet_bn1d_train_fwd_f32(const float* z, float* zn, float* mean, 
   if (!z || !zn || !mean || !var || !gamma || !beta || C <= 0 || (running_mean != nullptr) != (running_var != nullptr))
     return CENET_EINVAL;
   if (!cenet_bn1d_supported(B)) return CENET_EUNSUPPORTED;
-  CENET_LAUNCH(bn1d_train_fwd_kernel, dim3(cdiv(C, 256)), dim3(256), stream, z, zn, mean, var, running_mean, running_var, momentum,
+  CENET_LAUNCH(bn1d_train_fwd_kernel, dim3(cdiv(C, 64)), dim3(256), stream, z, zn, mean, var, running_mean, running_var, momentum,
                num_batches_tracked, eps, gamma, beta, B, C);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
@@ -1215,7 +1241,7 @@ extern "C" int cenet_bn1d_bwd_acc_f32(const float* dy, const float* z, float* dz
                                       const float* gamma, float* dgamma_acc, float* dbeta_acc, int B, int C, hipStream_t stream) {
   if (!dy || !z || !dz || !mean || !var || !gamma || C <= 0) return CENET_EINVAL;
   if (!cenet_bn1d_supported(B)) return CENET_EUNSUPPORTED;
-  CENET_LAUNCH(bn1d_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), stream, dy, z, dz, mean, var, eps, gamma, dgamma_acc, dbeta_acc, B, C);
+  CENET_LAUNCH(bn1d_bwd_kernel, dim3(cdiv(C, 64)), dim3(256), stream, dy, z, dz, mean, var, eps, gamma, dgamma_acc, dbeta_acc, B, C);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
