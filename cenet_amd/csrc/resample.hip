@@ -8,6 +8,7 @@
 // Templates over the activation storage type T (float / bf16_t) and, for the large maps, over OPT = outputs per thread
 // (2 adjacent x positions for bf16 when the output width is even, so that a lane stores 4 bytes).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cenet_hip.h"
 
 __device__ __forceinline__ void bil_coord(int dst, float scale, int align, int in, int& i0, int& i1, float& l1) {
@@ -383,6 +384,65 @@ __global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(const T* __restr
   for (int i = threadIdx.x; i < Hi * Wi; i += 256) stf(dp + i, bins[i]);
 }
 
+// Up-sampling by two with align_corners (nn.UpsamplingBilinear2d(scale_factor=2): the head's UpConv, blocks.py:210, 56 -> 112),
+// backward, bf16: the gather form walks ~5 x 7 candidate outputs per input pixel through predicated 2-byte loads (113 us for a 51 MB
+// gradient).  Here a thread owns FOUR consecutive input pixels of a row: input i is touched by outputs 2i - 2 .. 2i + 3 only (source
+// coordinate o (Hi - 1) / (Ho - 1), slightly below o / 2), so the thread needs output rows 2 iy - 2 .. 2 iy + 3 and the 16 columns
+// 2 ix - 4 .. 2 ix + 11, four 8-byte loads per row; the weights are PyTorch's (bil_coord), zero where an output does not touch.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_up2ac_bwd_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx, long sdb,
+                                                                int C, int Hi, int Wi, float sh, float sw) {
+  const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
+  const int Ho = 2 * Hi, Wo = 2 * Wi, Wq = Wi / 4;
+  const T* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
+  T* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
+  for (int p = blockIdx.y * 256 + threadIdx.x; p < Hi * Wq; p += gridDim.y * 256) {
+    const int iy = p / Wq, ix = 4 * (p - iy * Wq);
+    const int c0 = 2 * ix - 4;  // first column of the 16-column window (a multiple of 4: 8-byte aligned rows)
+    // column weights: wx[e][k] = weight of output column c0 + k for input ix + e
+    float wx[4][16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int ox = c0 + k;
+      int x0 = -9, x1 = -9;
+      float lx = 0.f;
+      if (ox >= 0 && ox < Wo) bil_coord(ox, sw, 1, Wi, x0, x1, lx);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wx[e][k] = (x0 == ix + e ? 1.f - lx : 0.f) + (x1 == ix + e ? lx : 0.f);
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int oy = 2 * iy - 2 + r;
+      if (oy < 0 || oy >= Ho) continue;
+      int y0, y1;
+      float ly;
+      bil_coord(oy, sh, 1, Hi, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      float g[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ox = c0 + 4 * q;
+        if (ox >= 0 && ox + 3 < Wo) {
+          ldv<4>(g + 4 * q, gp + (long)oy * Wo + ox);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) g[4 * q + t] = 0.f;  // (Wo % 4 == 0 and ox % 4 == 0: a quad is inside or outside as a whole)
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float row = 0.f;
+#pragma unroll
+        for (int k = 2 * e + 2; k < 2 * e + 8; ++k) row += wx[e][k] * g[k];  // outputs 2 (ix + e) - 2 .. + 3
+        acc[e] += wy * row;
+      }
+    }
+    stv<4>(dp + (long)iy * Wi + ix, acc);
+  }
+}
+
 template <typename T>
 static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int C, int Hi, int Wi, int Ho, int Wo, float scale_h,
                              float scale_w, int align_corners, hipStream_t stream, const T* dx_add = nullptr) {
@@ -414,6 +474,13 @@ static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int 
     const int maxrows = (int)(2.f / scale_h) + 4;  // bil_range spans (i-1 .. i+1) / scale plus a slack index each side
     CENET_LAUNCH((bilinear_bwd_rows_kernel<T>), dim3(B * C), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho, Wo, scale_h,
                  scale_w, align_corners, maxrows);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
+  if (sizeof(T) == 2 && align_corners && Ho == 2 * Hi && Wo == 2 * Wi && (Wi & 3) == 0 && Hi >= 4 && Wi >= 4 &&
+      ((((uintptr_t)dy | (uintptr_t)dx) & 7) == 0) && ((sgb | sdb) & 3) == 0 && !getenv("CENET_BIL_NO_UP2AC")) {
+    CENET_LAUNCH((bilinear_up2ac_bwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi / 4)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi,
+                 scale_h, scale_w);
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }

@@ -463,3 +463,21 @@ def test_batchnorm1d_one_launch_each_way(dev, B, Cn):
     torch.testing.assert_close(dg.cpu() - 2.0, ref.weight.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(db.cpu() + 1.0, ref.bias.grad, rtol=1e-4, atol=1e-4)
     assert not kern.bn1d_supported(1) and not kern.bn1d_supported(65)
+
+
+@pytest.mark.parametrize("Hi,Wi", [(8, 12), (56, 56), (6, 8), (9, 4)])
+def test_bilinear_x2_align_corners_backward_quad_kernel(dev, Hi, Wi):
+    """nn.UpsamplingBilinear2d(scale_factor=2) on bf16 maps (the head's UpConv): the backward kernel that owns four input pixels per
+    thread (bilinear_up2ac_bwd_kernel) against fp32 torch on the same bf16 gradient"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(Hi * 7 + Wi)
+    x = torch.randn(2, 3, Hi, Wi, generator=g).to(BF)
+    xr = x.float().clone().requires_grad_(True)
+    ref = F.interpolate(xr, scale_factor=2.0, mode="bilinear", align_corners=True)
+    dy = torch.randn(ref.shape, generator=g).to(BF)
+    ref.backward(dy.float())
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.interpolate_bilinear(xd, scale_factor=2.0, align_corners=True)
+    y.backward(dy.to(dev))
+    torch.testing.assert_close(y.float().cpu(), ref.detach(), rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, rtol=1e-2, atol=2e-2)
