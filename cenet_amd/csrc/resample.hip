@@ -384,6 +384,50 @@ __global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(const T* __restr
   for (int i = threadIdx.x; i < Hi * Wi; i += 256) stf(dp + i, bins[i]);
 }
 
+// The same problem class when the whole plane pair is small (Hi, Wi <= 8, Ho, Wo <= 64: the 7 x 7 -> 49 x 49 pooled branch): bilinear
+// resampling is separable, dx = Wy^T dy Wx with Wy [Ho][Hi], Wx [Wo][Wi] (two non-zeros per row), so the backward of a plane is two
+// small dense products through LDS — 49 x 49 x 7 + 49 x 7 x 7 multiply-adds and 2 x 49 coordinate evaluations per PLANE instead of
+// ~16 coordinate evaluations per (pixel, candidate row) item: 19 -> ~5 us per call.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_sep_kernel(const T* __restrict__ dy, long sgb, T* __restrict__ dx, long sdb,
+                                                              int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw, int align) {
+  __shared__ float G[64 * 64], Tm[64 * 8], wxs[64 * 8], wys[64 * 8];
+  const int bc = blockIdx.x, b = bc / C, c = bc - b * C;
+  const T* gp = dy + (long)b * sgb + (long)c * Ho * Wo;
+  T* dp = dx + (long)b * sdb + (long)c * Hi * Wi;
+  for (int i = threadIdx.x; i < Ho * Wo; i += 256) G[i] = ldf(gp + i);
+  for (int i = threadIdx.x; i < 64 * 8; i += 256) wxs[i] = wys[i] = 0.f;
+  __syncthreads();
+  if (threadIdx.x < Wo) {
+    int x0, x1;
+    float lx;
+    bil_coord(threadIdx.x, sw, align, Wi, x0, x1, lx);
+    wxs[threadIdx.x * 8 + x0] += 1.f - lx;  // (x0 == x1 at the border: both weights land on the same input)
+    wxs[threadIdx.x * 8 + x1] += lx;
+  } else if (threadIdx.x >= 64 && threadIdx.x - 64 < Ho) {
+    const int oy = threadIdx.x - 64;
+    int y0, y1;
+    float ly;
+    bil_coord(oy, sh, align, Hi, y0, y1, ly);
+    wys[oy * 8 + y0] += 1.f - ly;
+    wys[oy * 8 + y1] += ly;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Ho * Wi; i += 256) {  // Tm[oy][ix] = sum_ox dy[oy][ox] Wx[ox][ix]
+    const int oy = i / Wi, ix = i - oy * Wi;
+    float t = 0.f;
+    for (int ox = 0; ox < Wo; ++ox) t += G[oy * Wo + ox] * wxs[ox * 8 + ix];
+    Tm[oy * 8 + ix] = t;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Hi * Wi; i += 256) {  // dx[iy][ix] = sum_oy Wy[oy][iy] Tm[oy][ix]
+    const int iy = i / Wi, ix = i - iy * Wi;
+    float t = 0.f;
+    for (int oy = 0; oy < Ho; ++oy) t += wys[oy * 8 + iy] * Tm[oy * 8 + ix];
+    stf(dp + i, t);
+  }
+}
+
 // Up-sampling by two with align_corners (nn.UpsamplingBilinear2d(scale_factor=2): the head's UpConv, blocks.py:210, 56 -> 112),
 // backward, bf16: the gather form walks ~5 x 7 candidate outputs per input pixel through predicated 2-byte loads (113 us for a 51 MB
 // gradient).  Here a thread owns FOUR consecutive input pixels of a row: input i is touched by outputs 2i - 2 .. 2i + 3 only (source
@@ -467,6 +511,12 @@ static int bilinear_bwd_impl(const T* dy, long sgb, T* dx, long sdb, int B, int 
   // (bf16 tensors only: the fp32 parity mode keeps the one summation order of the general kernel)
   if (sizeof(T) == 2 && !align_corners && Ho == 2 * Hi && Wo == 2 * Wi && scale_h == 0.5f && scale_w == 0.5f && Hi > 1 && Wi > 1) {
     CENET_LAUNCH((bilinear_up2_bwd_kernel<T>), dim3(B * C, chunks_for(Hi * Wi)), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
+  if (sizeof(T) == 2 && Hi <= 8 && Wi <= 8 && Ho <= 64 && Wo <= 64 && scale_h > 1e-6f && scale_w > 1e-6f && !getenv("CENET_BIL_NO_SEP")) {
+    CENET_LAUNCH((bilinear_bwd_sep_kernel<T>), dim3(B * C), dim3(256), stream, dy, sgb, dx, sdb, C, Hi, Wi, Ho, Wo, scale_h, scale_w,
+                 align_corners);
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }

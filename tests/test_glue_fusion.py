@@ -481,3 +481,20 @@ def test_bilinear_x2_align_corners_backward_quad_kernel(dev, Hi, Wi):
     y.backward(dy.to(dev))
     torch.testing.assert_close(y.float().cpu(), ref.detach(), rtol=1e-2, atol=2e-2)
     torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("Hi,Wi,kw", [(7, 7, dict(scale_factor=7.0, align_corners=True)), (7, 7, dict(size=(49, 56))), (8, 5, dict(size=(64, 33), align_corners=True)),
+                                      (3, 4, dict(scale_factor=2.0))])
+def test_bilinear_backward_of_small_planes_as_two_products(dev, Hi, Wi, kw):
+    """bf16 planes with Hi, Wi <= 8 and Ho, Wo <= 64 (the pooled branch's 7 x 7 -> 49 x 49): dx = Wy^T dy Wx through LDS"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(Hi * 9 + Wi)
+    x = torch.randn(2, 5, Hi, Wi, generator=g).to(BF)
+    xr = x.float().clone().requires_grad_(True)
+    ref = F.interpolate(xr, mode="bilinear", **kw)
+    dy = torch.randn(ref.shape, generator=g).to(BF)
+    ref.backward(dy.float())
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.interpolate_bilinear(xd, size=kw.get("size"), scale_factor=kw.get("scale_factor"), align_corners=kw.get("align_corners", False))
+    y.backward(dy.to(dev))
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, rtol=1e-2, atol=4e-2)
