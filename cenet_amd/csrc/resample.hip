@@ -189,10 +189,23 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const T* __re
   for (int p = blockIdx.y * 256 + threadIdx.x; p < Hi * Wi; p += gridDim.y * 256) {
     const int iy = p / Wi, ix = p - iy * Wi;
     float s = 0.f;
-    for (int oy = 0; oy < Ho; ++oy) {
+    // pooling DOWN (Hi >= Ho): the windows that hold row iy are among the bin floor(iy Ho / Hi) and its two neighbours (windows
+    // overlap by at most one row) — 3 x 3 candidates instead of all Ho x Wo bins with four integer divisions each
+    int oy_lo = 0, oy_hi = Ho, ox_lo = 0, ox_hi = Wo;
+    if (Hi >= Ho) {
+      const int o = (int)(((long)iy * Ho) / Hi);
+      oy_lo = o > 0 ? o - 1 : 0;
+      oy_hi = o + 2 < Ho ? o + 2 : Ho;
+    }
+    if (Wi >= Wo) {
+      const int o = (int)(((long)ix * Wo) / Wi);
+      ox_lo = o > 0 ? o - 1 : 0;
+      ox_hi = o + 2 < Wo ? o + 2 : Wo;
+    }
+    for (int oy = oy_lo; oy < oy_hi; ++oy) {
       const int ys = ap_start(oy, Hi, Ho), ye = ap_end(oy, Hi, Ho);
       if (iy < ys || iy >= ye) continue;
-      for (int ox = 0; ox < Wo; ++ox) {
+      for (int ox = ox_lo; ox < ox_hi; ++ox) {
         const int xs = ap_start(ox, Wi, Wo), xe = ap_end(ox, Wi, Wo);
         if (ix < xs || ix >= xe) continue;
         s += ldf(gp + oy * Wo + ox) / (float)((ye - ys) * (xe - xs));

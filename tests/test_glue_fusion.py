@@ -498,3 +498,23 @@ def test_bilinear_backward_of_small_planes_as_two_products(dev, Hi, Wi, kw):
     y = ops.interpolate_bilinear(xd, size=kw.get("size"), scale_factor=kw.get("scale_factor"), align_corners=kw.get("align_corners", False))
     y.backward(dy.to(dev))
     torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, rtol=1e-2, atol=4e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, BF])
+@pytest.mark.parametrize("H,W,oh,ow", [(56, 56, 7, 7), (14, 14, 7, 7), (7, 7, 7, 7), (10, 13, 3, 5), (5, 6, 7, 7), (28, 30, 7, 4)])
+def test_adaptive_avgpool_backward_candidate_bins(dev, dt, H, W, oh, ow):
+    """pooling down: a pixel belongs to at most two windows per axis (the kernel looks at three candidates instead of all bins);
+    pooling up keeps the full walk"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(H + W + oh)
+    x = torch.randn(2, 3, H, W, generator=g).to(dt)
+    xr = x.float().clone().requires_grad_(True)
+    ref = F.adaptive_avg_pool2d(xr, (oh, ow))
+    dy = torch.randn(ref.shape, generator=g).to(dt)
+    ref.backward(dy.float())
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.adaptive_avgpool(xd, oh, ow)
+    y.backward(dy.to(dev))
+    tol = dict(rtol=1e-5, atol=1e-6) if dt == torch.float32 else dict(rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(y.float().cpu(), ref.detach(), **tol)
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, **tol)
