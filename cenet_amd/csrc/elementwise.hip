@@ -11,6 +11,7 @@
 // fp32 either way, parameters / statistics / parameter gradients are always fp32 — and the pointwise ones over a vector
 // width V (8 / 4 / 1 elements per thread and access, picked on the host from the length and the pointer alignment).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/cenet_hip.h"
 
 #define EW_GRID(total) dim3((unsigned)((((total) + 255) / 256) > 8192 ? 8192 : (((total) + 255) / 256)))
@@ -1145,11 +1146,15 @@ template <typename T>
 static int col_sum_acc_impl(const T* a, float* out_acc, long R, int C, hipStream_t stream) {
   if (R <= 0 || C <= 0) return CENET_EINVAL;
   if ((C & 3) == 0 && quad_aligned<T>(a)) {
-    // ~2048 workgroups, each at least 64 rows deep
+    // ~2048 workgroups, each at least 64 rows deep — but every workgroup ends with one float atomic per column, and atomics onto the
+    // same cache line serialise: with few columns (C <= 128: 2 - 4 lines) 1 568 workgroups spent most of a 40 us launch queueing on
+    // them (12.8 MB of data = 3 us); ~256 workgroups there
     const int quads = C / 4;
     const int tpr = quads >= 64 ? 64 : (quads >= 32 ? 32 : 16);
     const int ctiles = cdiv(quads, tpr);
-    long rpb = (R * ctiles + 2047) / 2048;
+    static const int wg_small = getenv("CENET_COLSUM_WGS") ? atoi(getenv("CENET_COLSUM_WGS")) : 256;  // measurement aid
+    const long target = C <= 128 ? wg_small : 2048;
+    long rpb = (R * ctiles + target - 1) / target;
     if (rpb < 64) rpb = 64;
     rpb = (rpb + 15) & ~15L;
     dim3 grid(ctiles, (unsigned)((R + rpb - 1) / rpb));
