@@ -463,19 +463,28 @@ extern "C" int cenet_layernorm_bwd_add_part_bf16(const bf16_t* dy, const bf16_t*
   return cenet_layernorm_bwd_add_part_scaled_bf16(dy, x, gamma, mean, rstd, dx_add, dx, part, nullptr, 1, nullptr, rows, C, stream);
 }
 
-/* n <= 48 per launch (more: several launches): dg / db += column sums of the partial buffers */
+/* n <= 48 per launch (more: several launches): dg / db += column sums of the partial buffers.
+ * The fold adds with plain read-modify-writes, one workgroup row per item, so two items of ONE launch must not share a
+ * destination (a LayerNorm run twice before one backward pass, a shared norm module): an item whose dg / db is already in the
+ * launch being assembled closes that launch and opens the next — launches of one stream run in order, nothing is lost. */
 extern "C" int cenet_ln_fold_group(const void* const* part, float* const* dg, float* const* db, const int* nrows, const int* C,
                                    int n, hipStream_t stream) {
   if (n < 0 || (n > 0 && (!part || !dg || !db || !nrows || !C))) return CENET_EINVAL;
-  for (int i0 = 0; i0 < n; i0 += LN_FOLD_MAX) {
+  for (int i = 0; i < n; ++i)
+    if (!part[i] || !dg[i] || !db[i] || nrows[i] <= 0 || C[i] <= 0) return CENET_EINVAL;
+  int i = 0;
+  while (i < n) {
     LnFoldArgs a;
-    const int m = n - i0 < LN_FOLD_MAX ? n - i0 : LN_FOLD_MAX;
-    int cmax = 0;
-    for (int i = 0; i < m; ++i) {
-      if (!part[i0 + i] || !dg[i0 + i] || !db[i0 + i] || nrows[i0 + i] <= 0 || C[i0 + i] <= 0) return CENET_EINVAL;
-      a.d[i].part = (const float*)part[i0 + i]; a.d[i].dg = dg[i0 + i]; a.d[i].db = db[i0 + i];
-      a.d[i].nrows = nrows[i0 + i]; a.d[i].C = C[i0 + i];
-      if (C[i0 + i] > cmax) cmax = C[i0 + i];
+    int m = 0, cmax = 0;
+    for (; i < n && m < LN_FOLD_MAX; ++i) {
+      bool dup = false;
+      for (int j = 0; j < m && !dup; ++j)
+        dup = a.d[j].dg == dg[i] || a.d[j].db == db[i] || a.d[j].dg == db[i] || a.d[j].db == dg[i];
+      if (dup) break;
+      a.d[m].part = (const float*)part[i]; a.d[m].dg = dg[i]; a.d[m].db = db[i];
+      a.d[m].nrows = nrows[i]; a.d[m].C = C[i];
+      if (C[i] > cmax) cmax = C[i];
+      ++m;
     }
     CENET_LAUNCH(ln_fold_group_kernel, dim3(cdiv(2 * cmax, 32), m), dim3(1024), stream, a);
     CENET_CHECK_LAUNCH();

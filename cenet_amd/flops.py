@@ -72,7 +72,7 @@ def count(net, shape, by_op: bool = False):
     """fvcore-rule FLOPs of one eval forward of `net` on an input of `shape` ([B, C, H, W]); by_op: the per-operator Counter"""
     rec = _Recorder()
     old = (_lib._LIB, _lib._HOSTSIM)
-    was_training = net.training
+    orig, was_training = net, net.training
     dev = next(net.parameters()).device
     _lib._LIB, _lib._HOSTSIM = rec, True  # (host tensors pass the device check; nothing is launched)
     try:
@@ -95,8 +95,7 @@ def count(net, shape, by_op: bool = False):
                 h.remove()
     finally:
         _lib._LIB, _lib._HOSTSIM = old
-        if was_training:
-            net.train()
+        orig.train(was_training)  # (the CALLER's module: `net` may be the host copy by now)
     return rec.flops if by_op else sum(rec.flops.values())
 
 

@@ -473,6 +473,27 @@ def res_tail_img_bwd(g, x2, img, mean2, var2, g2, b2, eps2, imean, ivar, w3, g3,
 
 
 # ---- depthwise conv ------------------------------------------------------------------------------------
+# ---- channel-local fused chains (csrc/chanloc.hip) --------------------------------------------------------------------------
+_NO_CHANLOC = __import__("os").environ.get("CENET_NO_CHANLOC") is not None  # measurement aid: the unfused launch chains
+
+
+def eucb_supported(x) -> bool:
+    B, _, H, W = x.shape
+    return (not _NO_CHANLOC) and bool(_lib.lib().cenet_eucb_supported(int(B), int(H), int(W), esz(x)))
+
+
+def eucb_fwd(x, w, gamma, beta, eps, slope, y, mean, var, rmean, rvar, momentum, nbt, B, Cn, H, W):
+    _chk(x, w, gamma, beta, y, mean, var, rmean, rvar)
+    _call("cenet_eucb_fwd_f32", x, L(Cn * H * W), w, gamma, beta, float(eps), float(slope), y, L(4 * Cn * H * W), mean, var, rmean,
+          rvar, float(momentum), nbt, B, Cn, H, W)
+
+
+def eucb_bwd(g, x, w, gamma, beta, eps, slope, mean, var, dx, dw, dgamma, dbeta, B, Cn, H, W):
+    _chk(g, x, w, gamma, beta, mean, var, dx, dw, dgamma, dbeta)
+    _call("cenet_eucb_bwd_acc_f32", g, L(4 * Cn * H * W), x, L(Cn * H * W), w, gamma, beta, float(eps), float(slope), mean, var, dx,
+          L(Cn * H * W), dw, dgamma, dbeta, B, Cn, H, W)
+
+
 def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0, x_off=0, y_off=0):
     """x_off / y_off (elements): read / write a channel slice of a wider tensor in place (batch strides sxb / syb)"""
     _chk(x, w, bias, y, a)

@@ -73,9 +73,15 @@ class EUCB(nn.Module):
         self.apply(_init_conv)
 
     def forward(self, x):
-        x = ops.nearest2x(x)
-        x = ops.dwconv_nchw(x, self.up_dwc[1].weight, None, dil=1)
-        x = bn_call(self.up_dwc[2], x, "lrelu", 0.2)
+        bn = self.up_dwc[2]
+        if ops.eucb_front_supported(x, bn.training):
+            # one launch per pass for everything in front of the 1x1 conv (csrc/chanloc.hip: workgroup = channel over the batch)
+            x = ops.eucb_front(x, self.up_dwc[1].weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                               bn.num_batches_tracked, bn.eps, 0.2, bn.momentum if bn.momentum is not None else 0.1)
+        else:
+            x = ops.nearest2x(x)
+            x = ops.dwconv_nchw(x, self.up_dwc[1].weight, None, dil=1)
+            x = bn_call(bn, x, "lrelu", 0.2)
         return ops.conv1x1(x, self.pwc[0].weight, self.pwc[0].bias)
 
 

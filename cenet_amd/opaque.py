@@ -53,50 +53,68 @@ def _net(handle: int):
     return net
 
 
+_MAX_LIVE = 8  # forwards of one network whose backward has not run yet (more: the oldest graph is dropped)
+_next_token = [1]
+
+
 @torch.library.custom_op("cenet_amd::forward", mutates_args=())
-def forward_op(x: torch.Tensor, anchor: torch.Tensor, handle: int, num_classes: int, bf16: bool, grad: bool) -> torch.Tensor:
+def forward_op(x: torch.Tensor, anchor: torch.Tensor, handle: int, num_classes: int, bf16: bool,
+               grad: bool) -> tuple[torch.Tensor, torch.Tensor]:
+    """-> (logits, token).  The token (a host int64 scalar) names the autograd graph this call built; cenet_amd::backward looks
+    its graph up BY that token, so forwards and backwards pair correctly in any order (two forwards then the later one's
+    backward first; a forward whose backward never runs)."""
     net = _net(handle)
+    token = 0
     if grad:
         # An operator's backend implementation runs BELOW the autograd dispatch keys (they are excluded in thread-local state):
         # plain aten views / reshapes between the network's autograd.Functions would silently stop carrying requires_grad and
         # cut whole branches out of the network's own graph.  Re-include them for the duration of the forward.
         with _autograd_keys_included(), torch.enable_grad():
             out = net._forward(x)
-        net.__dict__.setdefault("_cenet_live", []).append(out)  # the network's own autograd graph, consumed by cenet_amd::backward
+        live = net.__dict__.setdefault("_cenet_live", {})  # token -> the network's own autograd graph (its output)
+        token = _next_token[0]
+        _next_token[0] += 1
+        live[token] = out
+        while len(live) > _MAX_LIVE:  # graphs nobody differentiated (skipped step, train-mode forward used for metrics only)
+            live.pop(next(iter(live)))
     else:
         with torch.no_grad():
             out = net._forward(x)
-    return out.detach()
+    return out.detach(), torch.tensor([token], dtype=torch.int64)
 
 
 @forward_op.register_fake
 def _(x, anchor, handle, num_classes, bf16, grad):
-    return x.new_empty((x.shape[0], num_classes, x.shape[2], x.shape[3]), dtype=torch.bfloat16 if bf16 else torch.float32)
+    return (x.new_empty((x.shape[0], num_classes, x.shape[2], x.shape[3]), dtype=torch.bfloat16 if bf16 else torch.float32),
+            torch.empty((1,), dtype=torch.int64, device="cpu"))
 
 
 @torch.library.custom_op("cenet_amd::backward", mutates_args=())
-def backward_op(g: torch.Tensor, handle: int) -> torch.Tensor:
+def backward_op(g: torch.Tensor, token: torch.Tensor, handle: int) -> torch.Tensor:
     net = _net(handle)
-    live = net.__dict__.get("_cenet_live")
-    if not live:
-        raise RuntimeError("cenet_amd::backward without a matching cenet_amd::forward(grad=True)")
-    out = live.pop(0)
+    live = net.__dict__.get("_cenet_live") or {}
+    out = live.pop(int(token.item()), None)  # (host tensor: no device sync)
+    if out is None:
+        raise RuntimeError("cenet_amd::backward: the graph of this forward is gone (its backward already ran, the forward ran "
+                           f"without gradients, or more than {_MAX_LIVE} forwards of the network were left undifferentiated)")
     out.backward(g.to(out.dtype).contiguous())
     return torch.zeros(1, device=g.device, dtype=torch.float32)
 
 
 @backward_op.register_fake
-def _(g, handle):
+def _(g, token, handle):
     return g.new_zeros((1,), dtype=torch.float32)
 
 
 def _setup_context(ctx, inputs, output):
     ctx.handle = inputs[2]
     ctx.anchor_shape = inputs[1].shape
+    ctx.save_for_backward(output[1])
 
 
-def _backward(ctx, g):
-    z = torch.ops.cenet_amd.backward(g, ctx.handle)
+def _backward(ctx, g, g_token=None):
+    (token,) = ctx.saved_tensors
+    z = torch.ops.cenet_amd.backward(g, token, ctx.handle)
     return None, z.sum().to(g.dtype).expand(ctx.anchor_shape) * 0.0, None, None, None, None
 
 
@@ -107,4 +125,4 @@ def forward(net, x: torch.Tensor, bf16: bool) -> torch.Tensor:
     """what CENet.forward returns under a tracer: one opaque node"""
     anchor = net.out.w
     grad = bool(net.training and torch.is_grad_enabled())
-    return torch.ops.cenet_amd.forward(x, anchor, net._cenet_handle, net.out.out[1].conv.conv.out_channels, bf16, grad)
+    return torch.ops.cenet_amd.forward(x, anchor, net._cenet_handle, net.out.out[1].conv.conv.out_channels, bf16, grad)[0]

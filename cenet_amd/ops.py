@@ -51,23 +51,30 @@ def _zeros(shape, ref: Tensor) -> Tensor:
 
 
 class _ZeroWs:
-    """Persistent fp32 accumulators that are ZERO at rest, one per (device, element count): a kernel adds into one atomically and
-    kern.cast_clear rounds it to the gradient's type and zeroes it again in the same pass — instead of a zero-fill launch in
-    front of every use (the dK / dV accumulator of the spatial-reduction attention backward: 7 fills per step).  `dirty` covers a
-    pass that raised between the two launches: the next taker fills it again."""
-    bufs: dict = {}
+    """Persistent fp32 accumulators that are ZERO at rest, keyed by (device, element count): a kernel adds into one atomically
+    and kern.cast_clear rounds it to the gradient's type and zeroes it again in the same pass — instead of a zero-fill launch in
+    front of every use (the dK / dV accumulator of the spatial-reduction attention backward: 7 fills per step).
+    A buffer that is taken stays IN USE until give_back_as: a second taker of the same size gets a buffer of its own (up to
+    `MAX_LIVE` per size; beyond that the oldest is taken to be the leftover of a pass that raised between the two launches and is
+    filled again).  Single-stream contract: take -> kernel -> give_back_as run on ONE stream (the buffers carry no events)."""
+    bufs: dict = {}  # key -> [[tensor, in_use], ...]
+    MAX_LIVE = 4
 
     @staticmethod
     def take(shape, ref: Tensor) -> Tensor:
         n = 1
         for v in shape:
             n *= int(v)
-        key = (ref.device.type, ref.device.index, n)
-        e = _ZeroWs.bufs.get(key)
+        es = _ZeroWs.bufs.setdefault((ref.device.type, ref.device.index, n), [])
+        e = next((e for e in es if not e[1]), None)
         if e is None:
-            e = _ZeroWs.bufs[key] = [kern.zero_(torch.empty(n, device=ref.device, dtype=torch.float32)), False]
-        elif e[1]:
-            kern.zero_(e[0])
+            if len(es) < _ZeroWs.MAX_LIVE:
+                e = [kern.zero_(torch.empty(n, device=ref.device, dtype=torch.float32)), False]
+                es.append(e)
+            else:  # every buffer of this size is marked in use: leftovers of passes that raised
+                e = es.pop(0)
+                es.append(e)
+                kern.zero_(e[0])
         e[1] = True
         return e[0].view(shape)
 
@@ -76,7 +83,9 @@ class _ZeroWs:
         """-> a tensor of like's dtype (bf16) holding ws (+ bias over the last axis); ws is zero again"""
         out = torch.empty(ws.shape, device=ws.device, dtype=like.dtype)
         kern.cast_clear(ws, out, bias)
-        _ZeroWs.bufs[(ws.device.type, ws.device.index, ws.numel())][1] = False
+        for e in _ZeroWs.bufs.get((ws.device.type, ws.device.index, ws.numel()), ()):
+            if e[0].data_ptr() == ws.data_ptr():
+                e[1] = False
         return out
 
 
@@ -296,7 +305,7 @@ def wgrad_hold(on: bool):
 
 def wgrad_pending() -> int:
     """recorded, not yet launched weight-gradient problems over all devices"""
-    return sum(len(st.items) + len(st.keep) + len(st.ln_items) for st in _WG.values())
+    return sum(len(st.items) + len(st.ln_items) for st in _WG.values())  # (st.keep holds the operands of st.items: not counted again)
 
 
 def _wgrad_deferrable(M: int, N: int, *ts, K: int = 1, nkb: int = 1) -> bool:
@@ -2087,6 +2096,48 @@ class Nearest2xFn(Function):
 
 def nearest2x(x):
     return Nearest2xFn.apply(x)
+
+
+class EucbFrontFn(Function):
+    """blocks.py:297-321 up to the 1x1 conv — LeakyReLU(BatchNorm(DW3x3(nearest_x2(x)))) — as ONE launch per pass
+    (csrc/chanloc.hip: workgroup = channel over the whole batch; the up-sampled tensor and the conv output never exist in HBM,
+    the backward recomputes them from x)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, eps, slope, momentum):
+        x = _c(x)
+        B, Cn, H, Wd = x.shape
+        y = _act((B, Cn, 2 * H, 2 * Wd), x)
+        mean, var = _empty((Cn,), x), _empty((Cn,), x)
+        kern.eucb_fwd(x, w, gamma, beta, eps, slope, y, mean, var, rmean, rvar, momentum, nbt, B, Cn, H, Wd)
+        ctx.save_for_backward(x, w, gamma, beta, mean, var)
+        ctx.refs = (w, gamma, beta)
+        ctx.cfg = (eps, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, gamma, beta, mean, var = ctx.saved_tensors
+        wp, gp, bp = ctx.refs
+        eps, slope = ctx.cfg
+        g = _c(g)
+        B, Cn, H, Wd = x.shape
+        dx = torch.empty_like(x)
+        dw, dg, db = grad_buf(wp), grad_buf(gp), grad_buf(bp)
+        if dw is None:
+            dw = _zeros(w.shape, x)
+        if dg is None:
+            dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
+        kern.eucb_bwd(g, x, w, gamma, beta, eps, slope, mean, var, dx, dw, dg, db, B, Cn, H, Wd)
+        return (dx,) + (None,) * 9
+
+
+def eucb_front_supported(x, training: bool) -> bool:
+    return bool(training) and x.dim() == 4 and kern.eucb_supported(x)
+
+
+def eucb_front(x, w, gamma, beta, rmean, rvar, nbt, eps, slope, momentum):
+    return EucbFrontFn.apply(x, w, gamma, beta, rmean, rvar, nbt, eps, slope, momentum)
 
 
 class AdaptiveAvgPoolFn(Function):

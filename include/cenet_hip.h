@@ -690,6 +690,31 @@ int cenet_cast_clear_f32_to_bf16(float* x, unsigned short* y, long n, cenet_stre
  * conv as a GEMM over K = C s^2) whose partial products were added atomically into the zero-at-rest accumulator x */
 int cenet_cast_clear_bias_f32_to_bf16(float* x, unsigned short* y, const float* bias, int N, long n, cenet_stream_t stream);
 
+/* ---- channel-local fused chains (chanloc.hip, round 5) --------------------------------------------------------------------
+ * One workgroup owns one channel over the whole batch: BatchNorm's batch statistics are workgroup reductions, nothing is
+ * stored between the steps of the chain, no float atomics (results independent of scheduling).
+ * EUCB front, blocks.py:297-321 up to the 1x1 conv: y = LeakyReLU(BatchNorm_train(DW3x3(nearest_x2(x)))); x [B, C, H, W] (batch
+ * stride sxb), y [B, C, 2H, 2W] (batch stride syb), w [C][9] (no bias).  Forward writes the batch mean / biased variance of the
+ * conv output and updates the running statistics (unbiased variance; NULL: not wanted) and the batch counter.  Backward takes
+ * the gradient g of y and writes dx; dw / dgamma / dbeta are ADDED into.  cenet_eucb_supported: the channel's source planes
+ * (B*H*W elements of esize bytes) plus one group of gradient planes fit a workgroup's LDS. */
+int cenet_eucb_supported(int B, int H, int W, int esize);
+int cenet_eucb_fwd_f32(const float* x, long sxb, const float* w, const float* gamma, const float* beta, float eps, float slope,
+                       float* y, long syb, float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                       long* num_batches_tracked, int B, int C, int H, int W, cenet_stream_t stream);
+int cenet_eucb_bwd_acc_f32(const float* g, long sgb, const float* x, long sxb, const float* w, const float* gamma,
+                           const float* beta, float eps, float slope, const float* mean, const float* var, float* dx, long sdb,
+                           float* dw_acc, float* dgamma_acc, float* dbeta_acc, int B, int C, int H, int W,
+                           cenet_stream_t stream);
+int cenet_eucb_fwd_bf16(const unsigned short* x, long sxb, const float* w, const float* gamma, const float* beta, float eps,
+                        float slope, unsigned short* y, long syb, float* mean, float* var, float* running_mean,
+                        float* running_var, float momentum, long* num_batches_tracked, int B, int C, int H, int W,
+                        cenet_stream_t stream);
+int cenet_eucb_bwd_acc_bf16(const unsigned short* g, long sgb, const unsigned short* x, long sxb, const float* w,
+                            const float* gamma, const float* beta, float eps, float slope, const float* mean, const float* var,
+                            unsigned short* dx, long sdb, float* dw_acc, float* dgamma_acc, float* dbeta_acc, int B, int C,
+                            int H, int W, cenet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,6 +242,47 @@ def test_torch_compile_fullgraph_on_the_host_checker():
         _lib._LIB, _lib._HOSTSIM = None, False
 
 
+def test_opaque_backward_finds_its_own_forward():
+    """ADVICE r4: `cenet_amd::backward` looks its graph up by the token its forward returned, not by arrival order: a train-mode
+    forward whose backward never runs (metrics only), then two forwards whose backwards run in REVERSE order — each gradient
+    equals the eager gradient of ITS batch (host checker, aot_eager)."""
+    from backend import use_sim
+    import test_segmented as TS
+    from test_parallel_gloo import _cenet_shard
+    from cenet_amd import _lib
+    use_sim()
+    try:
+        net = TS._net(seed=7)
+        crit = TS._crit()
+        xa, la = _cenet_shard(0)
+        xb, lb = _cenet_shard(1)
+        refs = []
+        for x, lab in ((xa, la), (xb, lb)):
+            ref = copy.deepcopy(net)
+            refs.append(_one_step(ref, ref, x, lab, crit)[2])
+        cnet = torch.compile(net, mode="default", fullgraph=True, backend="aot_eager")
+        cnet(xa)  # a forward nobody differentiates
+        for p_ in net.parameters():
+            p_.grad = None
+        # (train-mode BatchNorm normalises with batch statistics: the running buffers that forward moved do not enter gradients)
+        loss_a = crit(cnet(xa), la)
+        loss_b = crit(cnet(xb), lb)
+        loss_b.backward()
+        gb = {n: p_.grad.detach().clone() for n, p_ in net.named_parameters()}
+        for p_ in net.parameters():
+            p_.grad = None
+        loss_a.backward()
+        ga = {n: p_.grad.detach().clone() for n, p_ in net.named_parameters()}
+        for want, got, tag in ((refs[0], ga, "a"), (refs[1], gb, "b")):
+            for n in want:
+                assert torch.allclose(want[n], got[n], rtol=1e-5, atol=1e-7), (tag, n)
+        with pytest.raises(RuntimeError, match="graph of this forward is gone"):
+            from cenet_amd import opaque  # noqa: F401
+            torch.ops.cenet_amd.backward(torch.zeros(1), torch.tensor([10 ** 9]), net._cenet_handle)
+    finally:
+        _lib._LIB, _lib._HOSTSIM = None, False
+
+
 def test_flop_count_of_the_opaque_operator_is_the_references():
     """utils/utils.py:171-181 prints `FlopCountAnalysis(net, x).total() / 1e9` = 12.76 G for the ACDC preset (SURVEY.md section 6,
     the paper's figure).  fvcore is absent here; cenet_amd.flops prices the operator by fvcore's rules on a dry run (no kernel

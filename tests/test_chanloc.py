@@ -1,0 +1,93 @@
+"""Channel-local fused chains (csrc/chanloc.hip, round 5) against the launch chains they replace.
+
+The fused kernels keep intermediates in fp32 where the unfused chain stores them in the tensors' type, so in bf16 storage the two
+differ by bf16 rounding of the intermediates (bounded here in relative L2); in fp32 storage they agree to fp32 round-off.  The
+reference-made goldens of the modules (tests/test_modules_parity.py: eucb, cfa_module_*, mca_*) run through the fused path too.
+`sim` = the same kernel source on the host SIMT checker (CPU); `hip` = the gfx950 library (marker gpu)."""
+import pytest
+import torch
+
+from backend import dev  # noqa: F401
+from cenet_amd import kern, ops
+
+BF = torch.bfloat16
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def _eucb_chain(x, w, gamma, beta, rm, rv, nbt, fused):
+    if fused:
+        assert ops.eucb_front_supported(x, True)
+        return ops.eucb_front(x, w, gamma, beta, rm, rv, nbt, 1e-5, 0.2, 0.1)
+    y = ops.nearest2x(x)
+    y = ops.dwconv_nchw(y, w, None, dil=1)
+    return ops.batchnorm(y, gamma, beta, rm, rv, nbt, True, 1e-5, "lrelu", 0.2, 0.1)
+
+
+# (B, C, H, W): the three EUCB levels at reduced batch / channels, odd planes, and a plane set that needs the grouped backward
+@pytest.mark.parametrize("shape", [(4, 6, 7, 7), (3, 5, 14, 14), (2, 3, 28, 28), (2, 4, 5, 6), (32, 2, 7, 7), (6, 2, 40, 40)])
+@pytest.mark.parametrize("dt", [torch.float32, BF], ids=["f32", "bf16"])
+def test_eucb_front_equals_the_launch_chain(dev, shape, dt):
+    B, Cn, H, W = shape
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x0 = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    cot = torch.randn(B, Cn, 2 * H, 2 * W, generator=g).to(dt).to(dev)
+    res = []
+    for fused in (False, True):
+        x = x0.clone().requires_grad_(True)
+        gg = torch.Generator().manual_seed(7)
+        w = (0.3 * torch.randn(Cn, 1, 3, 3, generator=gg)).to(dev).requires_grad_(True)
+        gamma = (1 + 0.2 * torch.randn(Cn, generator=gg)).to(dev).requires_grad_(True)
+        beta = (0.2 * torch.randn(Cn, generator=gg)).to(dev).requires_grad_(True)
+        rm, rv = torch.zeros(Cn).to(dev), torch.ones(Cn).to(dev)
+        nbt = torch.zeros((), dtype=torch.long).to(dev)
+        for p in (w, gamma, beta):
+            p.grad = torch.zeros_like(p)
+        y = _eucb_chain(x, w, gamma, beta, rm, rv, nbt, fused)
+        y.backward(cot)
+        ops.wgrad_join() if dev.type != "cpu" else None
+        res.append((y.detach(), x.grad, w.grad, gamma.grad, beta.grad, rm, rv, nbt))
+    tol = 2e-2 if dt == BF else 2e-5
+    names = ("y", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var")
+    for k, name in enumerate(names):
+        assert _rel(res[1][k], res[0][k]) < tol, (name, _rel(res[1][k], res[0][k]))
+    assert int(res[1][7]) == int(res[0][7]) == 1
+
+
+def test_eucb_front_is_deterministic(dev):
+    """no float atomics: two evaluations are bit-identical (outputs and every gradient)"""
+    B, Cn, H, W = 5, 4, 14, 14
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(B, Cn, H, W, generator=g).to(BF).to(dev)
+    cot = torch.randn(B, Cn, 2 * H, 2 * W, generator=g).to(BF).to(dev)
+    outs = []
+    for _ in range(2):
+        x = x0.clone().requires_grad_(True)
+        w = (0.3 * torch.ones(Cn, 1, 3, 3)).to(dev).requires_grad_(True)
+        gamma, beta = torch.ones(Cn).to(dev).requires_grad_(True), torch.zeros(Cn).to(dev).requires_grad_(True)
+        for p in (w, gamma, beta):
+            p.grad = torch.zeros_like(p)
+        y = ops.eucb_front(x, w, gamma, beta, None, None, None, 1e-5, 0.2, 0.1)
+        y.backward(cot)
+        outs.append((y.detach(), x.grad, w.grad, gamma.grad, beta.grad))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_eucb_module_takes_the_fused_path_in_training_only(dev, monkeypatch):
+    from cenet_amd.networks.cenet.modules.blocks import EUCB
+    m = EUCB(8, 4, activation="leakyrelu").to(dev)
+    calls = []
+    orig = kern.eucb_fwd
+    monkeypatch.setattr(kern, "eucb_fwd", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    x = torch.randn(2, 8, 7, 7).to(dev)
+    m.train()
+    m(x)
+    assert len(calls) == 1
+    m.eval()
+    with torch.no_grad():
+        m(x)
+    assert len(calls) == 1

@@ -34,6 +34,27 @@ def test_ln_backward_second_output_is_the_scale_pass(dev, B, N, Cn):
     assert torch.equal(dxs, want)
 
 
+def test_ln_fold_group_with_a_shared_destination(dev):
+    """the same LayerNorm parameters twice in one flush (the model run twice before one backward pass, a shared norm
+    module): the fold adds with plain read-modify-writes, so duplicates must land in separate launches — both contributions
+    arrive.  Items 0 and 2 share dgamma / dbeta, 1 has its own; 60 more items force a second launch by count as well."""
+    g = torch.Generator().manual_seed(5)
+    Cn = 64
+    dg = [torch.zeros(Cn).to(dev) for _ in range(2)]
+    db = [torch.zeros(Cn).to(dev) for _ in range(2)]
+    parts = [torch.randn(r, 2 * Cn, generator=g).to(dev) for r in (7, 40, 13)]
+    items = [(parts[0], dg[0], db[0]), (parts[1], dg[1], db[1]), (parts[2], dg[0], db[0])]
+    many = [torch.randn(3, 2 * Cn, generator=g).to(dev) for _ in range(60)]
+    items += [(p, dg[1], db[1]) for p in many]
+    kern.ln_fold_group(items)
+    s0 = parts[0].sum(0) + parts[2].sum(0)
+    s1 = parts[1].sum(0) + sum(p.sum(0) for p in many)
+    torch.testing.assert_close(dg[0], s0[:Cn], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(db[0], s0[Cn:], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dg[1], s1[:Cn], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db[1], s1[Cn:], rtol=1e-4, atol=1e-4)
+
+
 def _chain(dev_, masks, seed=0):
     """two PVT-style half blocks on tokens: x1 = x + s1 * Linear(LN(x)); x2 = x1 + s2 * Linear(LN(x1)); out = LN(x2)"""
     g = torch.Generator().manual_seed(seed)
@@ -142,10 +163,21 @@ def test_sra_backward_accumulator_is_zero_at_rest(dev, monkeypatch):
     b = run()
     assert len(takes) == 2
     key = (dev.type, dev.index, kv.numel())
-    assert ops._ZeroWs.bufs[key][1] is False and float(ops._ZeroWs.bufs[key][0].abs().max()) == 0.0
-    # an interrupted use (dirty accumulator) is filled again by the next taker
-    ops._ZeroWs.take(kv.shape, kv).fill_(3.0)
+    assert all(e[1] is False and float(e[0].abs().max()) == 0.0 for e in ops._ZeroWs.bufs[key])
+    # an interrupted use (a taker that never gave its accumulator back) does not reach the next taker: it gets a buffer of its
+    # own, two live takers of one size never alias, and once MAX_LIVE leftovers pile up the oldest is filled again and reused
+    leaked = ops._ZeroWs.take(kv.shape, kv).fill_(3.0)
+    other = ops._ZeroWs.take(kv.shape, kv)
+    assert other.data_ptr() != leaked.data_ptr() and float(other.abs().max()) == 0.0
     c = run()
+    for _ in range(ops._ZeroWs.MAX_LIVE + 1):
+        t = ops._ZeroWs.take(kv.shape, kv)
+        assert float(t.abs().max()) == 0.0
+        t.fill_(5.0)
+    assert len(ops._ZeroWs.bufs[key]) == ops._ZeroWs.MAX_LIVE
+    c2 = run()
+    assert torch.equal(c2[0], c[0])
+    ops._ZeroWs.bufs.pop(key)
     # the filled form
     monkeypatch.setattr(ops._ZeroWs, "take", staticmethod(lambda shape, ref: ops._zeros(shape, ref)))
     monkeypatch.setattr(ops._ZeroWs, "give_back_as", staticmethod(lambda ws, like: kern.cast(ws, like.dtype)))
@@ -235,7 +267,7 @@ def test_split_k_linear_tail_is_one_pass(dev, monkeypatch):
     torch.testing.assert_close(y1.float(), ref.float(), rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(y2.float(), ref.float(), rtol=2e-2, atol=2e-2)
     key = (dev.type, dev.index, R * N)
-    assert ops._ZeroWs.bufs[key][1] is False and float(ops._ZeroWs.bufs[key][0].abs().max()) == 0.0
+    assert all(e[1] is False and float(e[0].abs().max()) == 0.0 for e in ops._ZeroWs.bufs[key])
 
 
 @pytest.mark.parametrize("dt", [torch.float32, BF])
