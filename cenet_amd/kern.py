@@ -494,6 +494,24 @@ def eucb_bwd(g, x, w, gamma, beta, eps, slope, mean, var, dx, dw, dgamma, dbeta,
           L(Cn * H * W), dw, dgamma, dbeta, B, Cn, H, W)
 
 
+def chanloc_supported(B: int, HW: int) -> bool:
+    return (not _NO_CHANLOC) and bool(_lib.lib().cenet_chanloc_supported(int(B), int(HW)))
+
+
+def cfam_mid_fwd(p_raw, m, x0, x1, y2, gp, bp, epsp, meanp, varp, rmp, rvp, momp, nbtp, w, ls, g2, b2, eps2, mean2, var2, rm2, rv2,
+                 mom2, nbt2, B, Cn, HW):
+    _chk(p_raw, m, x0, x1, y2, gp, bp, meanp, varp, w, ls, g2, b2, mean2, var2)
+    _call("cenet_cfam_mid_fwd_f32", p_raw, m, x0, x1, y2, gp, bp, float(epsp), meanp, varp, rmp, rvp, float(momp), nbtp, w, ls, g2,
+          b2, float(eps2), mean2, var2, rm2, rv2, float(mom2), nbt2, B, Cn, HW)
+
+
+def cfam_mid_bwd(g_y2, g_x1, p_raw, m, x1, d_p, d_m, d_x0, gp, bp, epsp, meanp, varp, w, ls, g2, eps2, mean2, var2, dgp, dbp, dw, dls,
+                 dg2, db2, B, Cn, HW):
+    _chk(g_y2, g_x1, p_raw, m, x1, d_p, d_m, d_x0)
+    _call("cenet_cfam_mid_bwd_acc_f32", g_y2, g_x1, p_raw, m, x1, d_p, d_m, d_x0, gp, bp, float(epsp), meanp, varp, w, ls, g2,
+          float(eps2), mean2, var2, dgp, dbp, dw, dls, dg2, db2, B, Cn, HW)
+
+
 def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0, x_off=0, y_off=0):
     """x_off / y_off (elements): read / write a channel slice of a wider tensor in place (batch strides sxb / syb)"""
     _chk(x, w, bias, y, a)

@@ -38,13 +38,17 @@ class Nonlocal(nn.Module):
             self._wtpg = m
         return m if m[0] is not None else None
 
-    def forward(self, x):
+    def forward(self, x, raw=False):
+        """raw=True: stop in front of the BatchNorm -> (conv_out output, x as the residual mix wants it): the caller fuses the
+        normalisation and the mix with what follows (CFAModule, ops.cfam_mid)"""
         m = self._merged_tpg()
         if m is not None:
             ops.refresh_member_shadows(m[0], x)
             tpg, x = ops.conv1x1(x, m[0], m[1], tap=True)  # (tap: the residual mix below reads x)
             y = ops.nonlocal_attention_joint(tpg)
             p = ops.conv1x1(y, self.conv_out.weight, self.conv_out.bias)
+            if raw:
+                return p, x
             p = bn_call(self.bn, p)
             return ops.mix(x, p, self.w)
         # x has four consumers (theta, phi, g, the residual mix): each 1x1 conv hands x on as a tap, so the four gradients meet
@@ -54,5 +58,7 @@ class Nonlocal(nn.Module):
         g, x = ops.conv1x1(x, self.conv_g.weight, self.conv_g.bias, tap=True)
         y = ops.nonlocal_attention(theta, phi, g)  # flash-style: the N x N map is never materialised
         p = ops.conv1x1(y, self.conv_out.weight, self.conv_out.bias)
+        if raw:
+            return p, x
         p = bn_call(self.bn, p)
         return ops.mix(x, p, self.w)

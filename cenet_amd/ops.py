@@ -2140,6 +2140,64 @@ def eucb_front(x, w, gamma, beta, rmean, rvar, nbt, eps, slope, momentum):
     return EucbFrontFn.apply(x, w, gamma, beta, rmean, rvar, nbt, eps, slope, momentum)
 
 
+def _gb(p, ref):
+    """gradient buffer of parameter p, or a scratch of its shape when p is frozen"""
+    g = grad_buf(p)
+    return g if g is not None else _zeros(p.shape, ref)
+
+
+def _mom(bn) -> float:
+    return bn.momentum if bn.momentum is not None else 0.1
+
+
+class CfamMidFn(Function):
+    """cfam.py:368-372 around nlb.py:141-148 — BatchNorm of the Non-local block's output conv, the residual mix (1 - w) m + w p,
+    the layer-scale residual x0 + ls1 * (...) and norm2 — as ONE launch per pass (csrc/chanloc.hip, workgroup = channel over the
+    batch).  -> (x1, y2)"""
+
+    @staticmethod
+    def forward(ctx, p_raw, m, x0, w, ls, bnp, bn2):
+        p_raw, m, x0 = _c(p_raw), _c(m), _c(x0)
+        B, Cn = x0.shape[:2]
+        HW = x0.numel() // (B * Cn)
+        x1, y2 = torch.empty_like(x0), torch.empty_like(x0)
+        meanp, varp, mean2, var2 = (_empty((Cn,), x0) for _ in range(4))
+        kern.cfam_mid_fwd(p_raw, m, x0, x1, y2, bnp.weight, bnp.bias, bnp.eps, meanp, varp, bnp.running_mean, bnp.running_var,
+                          _mom(bnp), bnp.num_batches_tracked, w, ls, bn2.weight, bn2.bias, bn2.eps, mean2, var2, bn2.running_mean,
+                          bn2.running_var, _mom(bn2), bn2.num_batches_tracked, B, Cn, HW)
+        ctx.save_for_backward(p_raw, m, x1, w, ls, bnp.weight, bnp.bias, bn2.weight, meanp, varp, mean2, var2)
+        ctx.refs = (w, ls, bnp.weight, bnp.bias, bn2.weight, bn2.bias)
+        ctx.cfg = (bnp.eps, bn2.eps)
+        return x1, y2
+
+    @staticmethod
+    def backward(ctx, g_x1, g_y2):
+        p_raw, m, x1, w, ls, gp, bp, g2, meanp, varp, mean2, var2 = ctx.saved_tensors
+        wp, lsp, gpp, bpp, g2p, b2p = ctx.refs
+        epsp, eps2 = ctx.cfg
+        if g_y2 is None:
+            raise RuntimeError("cfam_mid: the normalised output carried no gradient")
+        g_y2 = _c(g_y2)
+        if g_x1 is not None:
+            g_x1 = _c(g_x1) if g_x1.dtype == g_y2.dtype else _c(g_x1.to(g_y2.dtype))
+        B, Cn = x1.shape[:2]
+        HW = x1.numel() // (B * Cn)
+        d_p, d_m, d_x0 = torch.empty_like(x1), torch.empty_like(x1), torch.empty_like(x1)
+        kern.cfam_mid_bwd(g_y2, g_x1, p_raw, m, x1, d_p, d_m, d_x0, gp, bp, epsp, meanp, varp, w, ls, g2, eps2, mean2, var2,
+                          _gb(gpp, x1), _gb(bpp, x1), _gb(wp, x1), _gb(lsp, x1), _gb(g2p, x1), _gb(b2p, x1), B, Cn, HW)
+        return d_p, d_m, d_x0, None, None, None, None
+
+
+def cfam_mid_supported(x, bnp, bn2) -> bool:
+    return (bnp.training and bn2.training and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)
+            and kern.chanloc_supported(x.shape[0], x.shape[2] * x.shape[3]))
+
+
+def cfam_mid(p_raw, m, x0, w, ls, bnp, bn2):
+    """bnp / bn2: the nn.BatchNorm2d containers (parameters, buffers, eps, momentum)"""
+    return CfamMidFn.apply(p_raw, m, x0, w, ls, bnp, bn2)
+
+
 class AdaptiveAvgPoolFn(Function):
     @staticmethod
     def forward(ctx, x, Ho, Wo):

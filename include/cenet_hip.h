@@ -715,6 +715,37 @@ int cenet_eucb_bwd_acc_bf16(const unsigned short* g, long sgb, const unsigned sh
                             unsigned short* dx, long sdb, float* dw_acc, float* dgamma_acc, float* dbeta_acc, int B, int C,
                             int H, int W, cenet_stream_t stream);
 
+/* CFAM "mid" chain, cfam.py:368-372 around nlb.py:141-148 (p_raw = the Non-local block's output conv, m = that block's input, x0 =
+ * the CFAM block's input; all [B, C, HW] contiguous):  p = BatchNorm_nl(p_raw); z = (1 - w) m + w p; x1 = x0 + ls[c] z;
+ * y2 = BatchNorm_2(x1).  One launch each way (workgroup = channel over the batch; cenet_chanloc_supported(B, HW) says whether a
+ * channel is small enough).  Forward writes x1, y2, both batch means / biased variances, updates both running statistics and
+ * counters (NULL: not wanted).  Backward: g_y2 and (optional) g_x1 in; d_p_raw, d_m, d_x0 out; the six parameter gradients are
+ * ADDED into (dw, a scalar, with one float atomic per channel). */
+int cenet_chanloc_supported(int B, int HW);
+int cenet_cfam_mid_fwd_f32(const float* p_raw, const float* m, const float* x0, float* x1, float* y2, const float* gamma_p,
+                           const float* beta_p, float eps_p, float* mean_p, float* var_p, float* rmean_p, float* rvar_p,
+                           float mom_p, long* nbt_p, const float* w, const float* ls, const float* gamma_2, const float* beta_2,
+                           float eps_2, float* mean_2, float* var_2, float* rmean_2, float* rvar_2, float mom_2, long* nbt_2,
+                           int B, int C, int HW, cenet_stream_t stream);
+int cenet_cfam_mid_bwd_acc_f32(const float* g_y2, const float* g_x1, const float* p_raw, const float* m, const float* x1,
+                               float* d_p_raw, float* d_m, float* d_x0, const float* gamma_p, const float* beta_p, float eps_p,
+                               const float* mean_p, const float* var_p, const float* w, const float* ls, const float* gamma_2,
+                               float eps_2, const float* mean_2, const float* var_2, float* dgamma_p_acc, float* dbeta_p_acc,
+                               float* dw_acc, float* dls_acc, float* dgamma_2_acc, float* dbeta_2_acc, int B, int C, int HW,
+                               cenet_stream_t stream);
+int cenet_cfam_mid_fwd_bf16(const unsigned short* p_raw, const unsigned short* m, const unsigned short* x0, unsigned short* x1,
+                            unsigned short* y2, const float* gamma_p, const float* beta_p, float eps_p, float* mean_p,
+                            float* var_p, float* rmean_p, float* rvar_p, float mom_p, long* nbt_p, const float* w, const float* ls,
+                            const float* gamma_2, const float* beta_2, float eps_2, float* mean_2, float* var_2, float* rmean_2,
+                            float* rvar_2, float mom_2, long* nbt_2, int B, int C, int HW, cenet_stream_t stream);
+int cenet_cfam_mid_bwd_acc_bf16(const unsigned short* g_y2, const unsigned short* g_x1, const unsigned short* p_raw,
+                                const unsigned short* m, const unsigned short* x1, unsigned short* d_p_raw, unsigned short* d_m,
+                                unsigned short* d_x0, const float* gamma_p, const float* beta_p, float eps_p, const float* mean_p,
+                                const float* var_p, const float* w, const float* ls, const float* gamma_2, float eps_2,
+                                const float* mean_2, const float* var_2, float* dgamma_p_acc, float* dbeta_p_acc, float* dw_acc,
+                                float* dls_acc, float* dgamma_2_acc, float* dbeta_2_acc, int B, int C, int HW,
+                                cenet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,3 +91,64 @@ def test_eucb_module_takes_the_fused_path_in_training_only(dev, monkeypatch):
     with torch.no_grad():
         m(x)
     assert len(calls) == 1
+
+
+def _run_cfam(dev, dt, dims, hw, B, fused, monkeypatch, rates=(1, 2, 3)):
+    """one training forward + backward of a CFAModule; returns outputs, input gradient, every parameter gradient and buffer"""
+    from cenet_amd.networks.cenet.modules.cfam import CFAModule
+    monkeypatch.setattr(kern, "_NO_CHANLOC", not fused)
+    torch.manual_seed(5)
+    m = CFAModule(dims, mca_rates=list(rates), init_value=0.5).to(dev)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if p_.dim() == 1 or "layer_scale" in n_:
+                p_.add_(0.1 * torch.randn(p_.shape, generator=g).to(dev))
+    m.train()
+    x = torch.randn(B, dims, hw, hw, generator=g).to(dt).to(dev).requires_grad_(True)
+    cot = torch.randn(B, dims, hw, hw, generator=g).to(dt).to(dev)
+    old = kern.set_compute_bf16(dt == BF)
+    try:
+        for p_ in m.parameters():
+            p_.grad = torch.zeros_like(p_)
+        y = m(x)
+        y.backward(cot)
+        ops.wgrad_flush()
+    finally:
+        kern.set_compute_bf16(old)
+    out = {"y": y.detach(), "dx": x.grad}
+    out.update({"g." + n_: p_.grad for n_, p_ in m.named_parameters()})
+    out.update({"b." + n_: b_.clone() for n_, b_ in m.named_buffers()})
+    return out
+
+
+@pytest.mark.parametrize("dims,hw,B", [(32, 7, 3), (32, 14, 2), (48, 28, 2)])
+@pytest.mark.parametrize("dt", [torch.float32, BF], ids=["f32", "bf16"])
+def test_cfam_block_fused_chains_equal_the_launch_chains(dev, dt, dims, hw, B, monkeypatch):
+    """the whole CFAM block with every channel-local chain on against the same block on the unfused launch chains"""
+    calls = []
+    for name in ("cfam_mid_fwd", "cfam_mid_bwd"):
+        orig = getattr(kern, name)
+        monkeypatch.setattr(kern, name, lambda *a, _o=orig, _n=name, **k: (calls.append(_n), _o(*a, **k))[1])
+    ref = _run_cfam(dev, dt, dims, hw, B, False, monkeypatch)
+    assert not calls
+    got = _run_cfam(dev, dt, dims, hw, B, True, monkeypatch)
+    assert "cfam_mid_fwd" in calls and "cfam_mid_bwd" in calls
+    # bf16 storage: both forms carry rounding noise of their own (the gradients pass ~40 bf16-stored tensors), so the fused form
+    # is held to the fp32 evaluation of the launch chains and may be at most 2x (+ a floor of 2 % of the norm) as far from it as the unfused form
+    ref32 = _run_cfam(dev, torch.float32, dims, hw, B, False, monkeypatch) if dt == BF else None
+    for k in ref:
+        if k.endswith(("conv_phi.bias", "conv_out.bias", "conv_g.bias")):
+            continue  # mathematically zero (a key bias under a softmax, a bias in front of a BatchNorm): round-off noise only
+        if ref[k].dtype in (torch.int64, torch.int32):
+            assert torch.equal(ref[k], got[k]), k
+            continue
+        if dt == BF:
+            r32 = ref32[k].float()
+            nrm = r32.norm().item()
+            floor = 5e-3 * r32.numel() ** 0.5 + 2e-2 * nrm
+            e_f, e_u = (got[k].float() - r32).norm().item(), (ref[k].float() - r32).norm().item()
+            assert e_f <= 2.0 * e_u + floor, (k, e_f, e_u, nrm)
+        else:
+            d = (got[k] - ref[k]).norm().item()
+            assert d < 1e-4 * ref[k].norm().item() + 5e-5 * ref[k].numel() ** 0.5, (k, d, ref[k].norm().item())
