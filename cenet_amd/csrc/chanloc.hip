@@ -43,6 +43,54 @@ __device__ __forceinline__ void block_sum_n(float (&v)[N], float* red) {
   }
 }
 
+// Strided walks without a division per element: thread t visits e = t, t + NT, ... of a [B][HW] (or [B][H][W]) index space and
+// keeps (b, p) / (b, i, j) up to date with adds and carries (an integer division by a run-time value is ~40 instructions: more
+// than the arithmetic of any element here).
+struct Walk2 {
+  int b, p, dB, dP, HW;
+  __device__ __forceinline__ Walk2(int e0, int stride, int HW_) : HW(HW_) {
+    b = e0 / HW_;
+    p = e0 - b * HW_;
+    dB = stride / HW_;
+    dP = stride - dB * HW_;
+  }
+  __device__ __forceinline__ void next() {
+    p += dP;
+    b += dB;
+    if (p >= HW) {
+      p -= HW;
+      ++b;
+    }
+  }
+};
+struct Walk3 {
+  int b, i, j, dB, dI, dJ, H, W;
+  __device__ __forceinline__ Walk3(int e0, int stride, int H_, int W_) : H(H_), W(W_) {
+    const int HW = H_ * W_;
+    b = e0 / HW;
+    int p = e0 - b * HW;
+    i = p / W_;
+    j = p - i * W_;
+    dB = stride / HW;
+    p = stride - dB * HW;
+    dI = p / W_;
+    dJ = p - dI * W_;
+  }
+  __device__ __forceinline__ void next() {
+    j += dJ;
+    i += dI;
+    b += dB;
+    if (j >= W) {
+      j -= W;
+      ++i;
+    }
+    if (i >= H) {
+      i -= H;
+      ++b;
+    }
+  }
+};
+
 struct EucbArgs {
   const void* x;   // [B, C, H, W] (batch stride sxb)
   long sxb;
@@ -89,12 +137,13 @@ __device__ __forceinline__ void eucb_combine(const float (&w)[9], float (&q)[2][
 // channel planes of the batch -> LDS [B][H + 2][W + 2] with a zero border
 template <typename T>
 __device__ __forceinline__ void eucb_stage(const T* x, long sxb, T* xs, int B, int H, int W, int NT) {
-  const int PW = W + 2, PP = (H + 2) * PW, tot = B * PP;
-  for (int e = threadIdx.x; e < tot; e += NT) {
-    const int b = e / PP, r = e - b * PP, yy = r / PW - 1, xx = r - (yy + 1) * PW - 1;
+  const int PW = W + 2, tot = B * (H + 2) * PW;
+  Walk3 k(threadIdx.x, NT, H + 2, PW);
+  for (int e = threadIdx.x; e < tot; e += NT, k.next()) {
+    const int yy = k.i - 1, xx = k.j - 1;
     T v;
     memset(&v, 0, sizeof(T));
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[(long)b * sxb + yy * W + xx];
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[(long)k.b * sxb + yy * W + xx];
     xs[e] = v;
   }
 }
@@ -138,9 +187,9 @@ __global__ __launch_bounds__(NT) void eucb_fwd_kernel(EucbArgs a) {
   eucb_quad(S, q, u);
   const float K = u[0][0];
   float s[2] = {0.f, 0.f};
-  for (int e = threadIdx.x; e < items; e += NT) {
-    const int b = e / HW, p = e - b * HW, i = p / W, j = p - i * W;
-    eucb_load_nb(xs, b, i, j, H, W, S);
+  Walk3 wk(threadIdx.x, NT, H, W);
+  for (int e = threadIdx.x; e < items; e += NT, wk.next()) {
+    eucb_load_nb(xs, wk.b, wk.i, wk.j, H, W, S);
     eucb_quad(S, q, u);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -168,11 +217,11 @@ __global__ __launch_bounds__(NT) void eucb_fwd_kernel(EucbArgs a) {
   // pass 2: normalise + LeakyReLU + store (two pixels = one 4-byte / 8-byte store per output row)
   const int OW = 2 * W;
   T* y = (T*)a.y + (long)c * 4 * HW;
-  for (int e = threadIdx.x; e < items; e += NT) {
-    const int b = e / HW, p = e - b * HW, i = p / W, j = p - i * W;
-    eucb_load_nb(xs, b, i, j, H, W, S);
+  wk = Walk3(threadIdx.x, NT, H, W);
+  for (int e = threadIdx.x; e < items; e += NT, wk.next()) {
+    eucb_load_nb(xs, wk.b, wk.i, wk.j, H, W, S);
     eucb_quad(S, q, u);
-    T* yp = y + (long)b * a.syb + (long)(2 * i) * OW + 2 * j;
+    T* yp = y + (long)wk.b * a.syb + (long)(2 * wk.i) * OW + 2 * wk.j;
 #pragma unroll
     for (int py = 0; py < 2; ++py) {
       float v0 = u[py][0] * sc + sh, v1 = u[py][1] * sc + sh;
@@ -235,9 +284,9 @@ __global__ __launch_bounds__(NT) void eucb_bwd_kernel(EucbArgs a, int G) {
   // pass 1: sum g, sum g * xhat
   float s[2] = {0.f, 0.f};
   float gy[2][2], xh[2][2];
-  for (int e = threadIdx.x; e < items; e += NT) {
-    const int b = e / HW, p = e - b * HW, i = p / W, j = p - i * W;
-    quad_g(b, i, j, gy, xh);
+  Walk3 wk(threadIdx.x, NT, H, W);
+  for (int e = threadIdx.x; e < items; e += NT, wk.next()) {
+    quad_g(wk.b, wk.i, wk.j, gy, xh);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       s[0] += gy[k >> 1][k & 1];
@@ -272,8 +321,9 @@ __global__ __launch_bounds__(NT) void eucb_bwd_kernel(EucbArgs a, int G) {
   for (int b0 = 0; b0 < a.B; b0 += G) {
     const int nb = a.B - b0 < G ? a.B - b0 : G;
     // (a) conv-output gradients of images b0 .. b0 + nb into LDS
-    for (int e = threadIdx.x; e < nb * HW; e += NT) {
-      const int bl = e / HW, p = e - bl * HW, i = p / W, j = p - i * W;
+    wk = Walk3(threadIdx.x, NT, H, W);
+    for (int e = threadIdx.x; e < nb * HW; e += NT, wk.next()) {
+      const int bl = wk.b, i = wk.i, j = wk.j;
       quad_g(b0 + bl, i, j, gy, xh);
       float* dp = du + (long)bl * DP + (2 * i + 1) * DW_ + 2 * j + 1;
 #pragma unroll
@@ -290,8 +340,9 @@ __global__ __launch_bounds__(NT) void eucb_bwd_kernel(EucbArgs a, int G) {
     }
     __syncthreads();
     // (b) data gradient of the group's source pixels: the 4x4 window of padded rows 2i .. 2i + 3
-    for (int e = threadIdx.x; e < nb * HW; e += NT) {
-      const int bl = e / HW, p = e - bl * HW, i = p / W, j = p - i * W;
+    wk = Walk3(threadIdx.x, NT, H, W);
+    for (int e = threadIdx.x; e < nb * HW; e += NT, wk.next()) {
+      const int bl = wk.b, i = wk.i, j = wk.j, p = i * W + j;
       const float* dp = du + (long)bl * DP + (2 * i) * DW_ + 2 * j;
       float t = 0.f;
 #pragma unroll
@@ -345,9 +396,8 @@ struct MidArgs {
 };
 
 template <typename T, int V>
-__device__ __forceinline__ long mid_off(int e, int c, int C, int HWv) {  // element-group e of channel c -> offset in elements
-  const int b = e / HWv, p = e - b * HWv;
-  return ((long)b * C + c) * HWv * V + (long)p * V;
+__device__ __forceinline__ long mid_off(const Walk2& k, int c, int C, int HWv) {  // element group (b, p) of channel c -> elements
+  return ((long)k.b * C + c) * HWv * V + (long)k.p * V;
 }
 __device__ __forceinline__ void bn_publish(float* mean, float* var, float* rm, float* rv, float mom, long* nbt, int c, float mu,
                                            float v, float n) {
@@ -374,9 +424,9 @@ __global__ __launch_bounds__(NT) void cfam_mid_fwd_kernel(MidArgs a) {
   // pass 1: statistics of p_raw (shifted by the channel's first value)
   const float K = ldf(pr + (long)c * a.HW);
   float s[2] = {0.f, 0.f};
-  for (int e = threadIdx.x; e < items; e += NT) {
+  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
     float v[V];
-    ldv<V>(v, pr + mid_off<T, V>(e, c, C, HWv));
+    ldv<V>(v, pr + mid_off<T, V>(wk, c, C, HWv));
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const float d = v[k] - K;
@@ -395,8 +445,8 @@ __global__ __launch_bounds__(NT) void cfam_mid_fwd_kernel(MidArgs a) {
   const long o0 = (long)c * a.HW;
   const float K2 = round_to<T>(ldf(x0 + o0) + ls * ((1.f - wv) * ldf(mm + o0) + wv * (ap * ldf(pr + o0) + cp)));
   s[0] = s[1] = 0.f;
-  for (int e = threadIdx.x; e < items; e += NT) {
-    const long o = mid_off<T, V>(e, c, C, HWv);
+  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
+    const long o = mid_off<T, V>(wk, c, C, HWv);
     float vp[V], vm[V], vx[V];
     ldv<V>(vp, pr + o);
     ldv<V>(vm, mm + o);
@@ -418,8 +468,8 @@ __global__ __launch_bounds__(NT) void cfam_mid_fwd_kernel(MidArgs a) {
   if (threadIdx.x == 0) bn_publish(a.mean2, a.var2, a.rm2, a.rv2, a.mom2, a.nbt2, c, mu2, var2, n);
   const float a2 = a.g2[c] * rsqrtf(var2 + a.eps2), c2 = a.b2[c] - mu2 * a2;
   // pass 3: y2
-  for (int e = threadIdx.x; e < items; e += NT) {
-    const long o = mid_off<T, V>(e, c, C, HWv);
+  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
+    const long o = mid_off<T, V>(wk, c, C, HWv);
     float v[V];
     ldv<V>(v, x1 + o);
 #pragma unroll
@@ -439,8 +489,8 @@ __global__ __launch_bounds__(NT) void cfam_mid_bwd_kernel(MidArgs a) {
   const float mup = a.meanp[c], rsp = rsqrtf(a.varp[c] + a.epsp), ap = a.gp[c] * rsp, cp = a.bp[c] - mup * ap;
   // pass 1: BatchNorm_2 sums
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int e = threadIdx.x; e < items; e += NT) {
-    const long o = mid_off<T, V>(e, c, C, HWv);
+  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
+    const long o = mid_off<T, V>(wk, c, C, HWv);
     float g[V], v[V];
     ldv<V>(g, gy + o);
     ldv<V>(v, x1 + o);
@@ -455,8 +505,8 @@ __global__ __launch_bounds__(NT) void cfam_mid_bwd_kernel(MidArgs a) {
   const float dg2 = s[1], db2 = s[0];
   // pass 2: d x1 (= d x0, stored) and the sums of everything upstream of it
   s[0] = s[1] = s[2] = s[3] = 0.f;  // dls, dw, sum d p, sum d p * xhat_p
-  for (int e = threadIdx.x; e < items; e += NT) {
-    const long o = mid_off<T, V>(e, c, C, HWv);
+  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
+    const long o = mid_off<T, V>(wk, c, C, HWv);
     float g[V], v[V], t[V], vp[V], vm[V];
     ldv<V>(g, gy + o);
     ldv<V>(v, x1 + o);
@@ -488,8 +538,8 @@ __global__ __launch_bounds__(NT) void cfam_mid_bwd_kernel(MidArgs a) {
     atomicAdd(a.dw, s[1]);
   }
   // pass 3: d p_raw, d m
-  for (int e = threadIdx.x; e < items; e += NT) {
-    const long o = mid_off<T, V>(e, c, C, HWv);
+  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
+    const long o = mid_off<T, V>(wk, c, C, HWv);
     float d[V], vp[V], om[V];
     ldv<V>(d, dx0 + o);
     ldv<V>(vp, pr + o);
@@ -561,6 +611,255 @@ static int cfam_mid_bwd_acc_impl(const T* g_y2, const T* g_x1, const T* p_raw, c
   a.mean2 = (float*)mean2; a.var2 = (float*)var2; a.dgp = dgp_acc; a.dbp = dbp_acc; a.dw = dw_acc; a.dls = dls_acc;
   a.dg2 = dg2_acc; a.db2 = db2_acc; a.B = B; a.C = C; a.HW = HW;
   return cfam_mid_launch<T>(a, true, stream);
+}
+
+// ---- dilated depthwise branches of MultiOrderDWConv with their BatchNorm (cfam.py:227-241 over blocks.py:169-177) --------------
+//   v[:, j*g + i] = ReLU(BatchNorm_train(DW3x3_{dil_j}(x[:, j*g + i])))   for the NB (<= 3) branches of g channels each,
+//   rest = x[:, NB*g :]                                                   (the pooled branch's slice, copied)
+// Forward: the conv output goes to v (rounded to the tensor type, as the launch chain stores it), its statistics are taken from
+// those stored values, and after a barrier the workgroup normalises its own channel in place.  Backward recomputes the conv
+// output from x (no saved copy), writes the conv-output gradient to an fp32 scratch plane set it alone reads back, and adds
+// the OTHER gradients of x (g_add: the gate conv's data gradient; g_rest: the pooled branch's) while writing dx: the launch chain
+// ran a depthwise kernel, a BatchNorm (2 launches), and backwards BatchNorm (2), depthwise data and weight gradients and a
+// slice copy.  The channel's planes are staged in LDS when they fit (flat pointer either way).
+struct DwBnArgs {
+  const void* x;     // [B, Ctot, H, W] (batch stride sxb); the branch channels start at channel 0
+  long sxb;
+  void* y;           // forward: v [B, NB*g, H, W] (batch stride syb);  backward: dx [B, Ctot, H, W] (batch stride syb)
+  long syb;
+  void* rest;        // forward: [B, p, H, W] written;  backward: its gradient, read (batch stride srb)
+  long srb;
+  const void* g;     // backward: gradient of v (batch stride sgb)
+  long sgb;
+  const void* gadd;  // backward: other gradient of x [B, Ctot, H, W] (batch stride sab) or null
+  long sab;
+  float* du;         // backward scratch: [NB*g][B][HW] fp32
+  const float* w[3];
+  float* dw[3];
+  int dil[3];
+  int G, NB, P;      // channels per branch, branches, rest channels
+  const float *gamma, *beta;
+  float eps;
+  float *mean, *var, *rmean, *rvar;
+  float momentum;
+  long* nbt;         // NB counters (one per branch) or null
+  float *dgamma, *dbeta;
+  int B, H, W;
+};
+
+template <typename T>
+__device__ __forceinline__ float dw_tap9(const T* pl, int H, int W, int i, int j, int dil, const float (&w)[9], float (&tap)[9]) {
+  float t = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = i + (ky - 1) * dil;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = j + (kx - 1) * dil;
+      const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? ldf(pl + yy * W + xx) : 0.f;
+      tap[ky * 3 + kx] = v;
+      t += w[ky * 3 + kx] * v;
+    }
+  }
+  return t;
+}
+
+// stage the channel's planes [B][HW] into LDS if they fit; returns the base and the image stride to read them with
+template <typename T>
+__device__ __forceinline__ const T* chan_stage(const T* x, long sxb, int B, int HW, unsigned char* smem, int sm_bytes, int NT,
+                                               long& stride) {
+  if ((long)B * HW * (long)sizeof(T) > sm_bytes) {
+    stride = sxb;
+    return x;
+  }
+  T* xs = (T*)smem;
+  int e = threadIdx.x;
+  for (Walk2 k(threadIdx.x, NT, HW); k.b < B; k.next(), e += NT) xs[e] = x[(long)k.b * sxb + k.p];
+  __syncthreads();
+  stride = HW;
+  return xs;
+}
+
+template <typename T, int NT, int SM>
+__global__ __launch_bounds__(NT) void dwbn_fwd_kernel(DwBnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  __shared__ float red[16 * 2];
+  const int c = blockIdx.x, H = a.H, W = a.W, HW = H * W, items = a.B * HW;
+  if (c >= a.NB * a.G) {  // the pooled branch's slice: a copy
+    const int cr = c - a.NB * a.G;
+    const T* x = (const T*)a.x + (long)c * HW;
+    T* r = (T*)a.rest + (long)cr * HW;
+    for (Walk2 k(threadIdx.x, NT, HW); k.b < a.B; k.next()) r[(long)k.b * a.srb + k.p] = x[(long)k.b * a.sxb + k.p];
+    return;
+  }
+  const int j = c / a.G, cl = c - j * a.G, dil = a.dil[j];
+  float w[9], tap[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = a.w[j][cl * 9 + k];
+  long xst;
+  const T* xs = chan_stage((const T*)a.x + (long)c * HW, a.sxb, a.B, HW, smem, SM, NT, xst);
+  T* y = (T*)a.y + (long)c * HW;
+  const float K = round_to<T>(dw_tap9(xs, H, W, H / 2, W / 2, dil, w, tap));
+  float s[2] = {0.f, 0.f};
+  for (Walk3 k(threadIdx.x, NT, H, W); k.b < a.B; k.next()) {
+    const float u = round_to<T>(dw_tap9(xs + k.b * xst, H, W, k.i, k.j, dil, w, tap));
+    stf(y + (long)k.b * a.syb + k.i * W + k.j, u);
+    const float d = u - K;
+    s[0] += d;
+    s[1] += d * d;
+  }
+  block_sum_n<2>(s, red);  // (also orders the stores above before the in-place pass below: same workgroup)
+  const float n = (float)items, m = s[0] / n;
+  float var = s[1] / n - m * m;
+  if (var < 0.f) var = 0.f;
+  const float mu = K + m;
+  if (threadIdx.x == 0) {
+    a.mean[c] = mu;
+    a.var[c] = var;
+    if (a.rmean) {
+      a.rmean[c] = (1.f - a.momentum) * a.rmean[c] + a.momentum * mu;
+      a.rvar[c] = (1.f - a.momentum) * a.rvar[c] + a.momentum * var * (n / (n - 1.f));
+    }
+    if (a.nbt && cl == 0) a.nbt[j] += 1;
+  }
+  const float sc = a.gamma[c] * rsqrtf(var + a.eps), sh = a.beta[c] - mu * sc;
+  for (Walk2 k(threadIdx.x, NT, HW); k.b < a.B; k.next()) {
+    T* q = y + (long)k.b * a.syb + k.p;
+    const float v = ldf(q) * sc + sh;
+    stf(q, v > 0.f ? v : 0.f);
+  }
+}
+
+template <typename T, int NT, int SM>
+__global__ __launch_bounds__(NT) void dwbn_bwd_kernel(DwBnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  __shared__ float red[16 * 9];
+  const int c = blockIdx.x, H = a.H, W = a.W, HW = H * W, items = a.B * HW;
+  T* dx = (T*)a.y + (long)c * HW;
+  const T* ga = a.gadd ? (const T*)a.gadd + (long)c * HW : nullptr;
+  if (c >= a.NB * a.G) {  // pooled-branch channels: dx = g_rest + g_add
+    const T* r = (const T*)a.rest + (long)(c - a.NB * a.G) * HW;
+    for (Walk2 k(threadIdx.x, NT, HW); k.b < a.B; k.next()) {
+      float v = ldf(r + (long)k.b * a.srb + k.p);
+      if (ga) v += ldf(ga + (long)k.b * a.sab + k.p);
+      stf(dx + (long)k.b * a.syb + k.p, v);
+    }
+    return;
+  }
+  const int j = c / a.G, cl = c - j * a.G, dil = a.dil[j];
+  float w[9], tap[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = a.w[j][cl * 9 + k];
+  long xst;
+  const T* xs = chan_stage((const T*)a.x + (long)c * HW, a.sxb, a.B, HW, smem, SM, NT, xst);
+  const T* g = (const T*)a.g + (long)c * HW;
+  const float mu = a.mean[c], rs = rsqrtf(a.var[c] + a.eps), gm = a.gamma[c], bt = a.beta[c];
+  // pass 1: sum g, sum g * xhat (through the ReLU mask); the conv output is recomputed and rounded as the forward stored it
+  float s[2] = {0.f, 0.f};
+  for (Walk3 k(threadIdx.x, NT, H, W); k.b < a.B; k.next()) {
+    const float xh = (round_to<T>(dw_tap9(xs + k.b * xst, H, W, k.i, k.j, dil, w, tap)) - mu) * rs;
+    const float gy = (xh * gm + bt > 0.f) ? ldf(g + (long)k.b * a.sgb + k.i * W + k.j) : 0.f;
+    s[0] += gy;
+    s[1] += gy * xh;
+  }
+  block_sum_n<2>(s, red);
+  const float n = (float)items, m1 = s[0] / n, m2 = s[1] / n, k0 = gm * rs;
+  // pass 2: conv-output gradient -> scratch; weight gradient
+  float acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+  float* du = a.du + (long)c * items;
+  for (Walk3 k(threadIdx.x, NT, H, W); k.b < a.B; k.next()) {
+    const int p = k.i * W + k.j;
+    const float xh = (round_to<T>(dw_tap9(xs + k.b * xst, H, W, k.i, k.j, dil, w, tap)) - mu) * rs;
+    const float gy = (xh * gm + bt > 0.f) ? ldf(g + (long)k.b * a.sgb + p) : 0.f;
+    const float d = k0 * (gy - m1 - xh * m2);
+    du[(long)k.b * HW + p] = d;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] += d * tap[k];
+  }
+  block_sum_n<9>(acc, red);  // (its barriers order the scratch stores before the reads below)
+  if (threadIdx.x < 9) a.dw[j][cl * 9 + threadIdx.x] += acc[threadIdx.x];
+  if (threadIdx.x == 9) a.dgamma[c] += s[1];
+  if (threadIdx.x == 10) a.dbeta[c] += s[0];
+  // pass 3: data gradient (correlation with the flipped taps) + the other gradient of x
+  for (Walk3 k(threadIdx.x, NT, H, W); k.b < a.B; k.next()) {
+    const int b = k.b, i = k.i, jj = k.j, p = i * W + jj;
+    const float* dp = du + (long)b * HW;
+    float t = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = i - (ky - 1) * dil;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = jj - (kx - 1) * dil;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) t += w[ky * 3 + kx] * dp[yy * W + xx];
+      }
+    }
+    if (ga) t += ldf(ga + (long)b * a.sab + p);
+    stf(dx + (long)b * a.syb + p, t);
+  }
+}
+
+constexpr int DWBN_SM = 64 * 1024;
+
+template <typename T>
+static int dwbn_launch(const DwBnArgs& a, bool bwd, hipStream_t stream) {
+  const long per = (long)a.B * a.H * a.W;
+  if (per < 2 || per > CENET_CHANLOC_MAX || a.NB < 1 || a.NB > 3 || a.G < 1 || a.P < 0) return CENET_EUNSUPPORTED;
+  const int grid = a.NB * a.G + a.P;
+  if (per <= 4096) {
+    if (bwd) CENET_LAUNCH((dwbn_bwd_kernel<T, 256, DWBN_SM / 4>), dim3(grid), dim3(256), stream, a);
+    else CENET_LAUNCH((dwbn_fwd_kernel<T, 256, DWBN_SM / 4>), dim3(grid), dim3(256), stream, a);
+  } else {
+    if (bwd) CENET_LAUNCH((dwbn_bwd_kernel<T, 1024, DWBN_SM>), dim3(grid), dim3(1024), stream, a);
+    else CENET_LAUNCH((dwbn_fwd_kernel<T, 1024, DWBN_SM>), dim3(grid), dim3(1024), stream, a);
+  }
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+template <typename T>
+static int dwbn_fwd_impl(const T* x, long sxb, const float* const* w, const int* dil, int nb, int g, int p, T* v, long svb, T* rest,
+                         long srb, const float* gamma, const float* beta, float eps, float* mean, float* var, float* rmean,
+                         float* rvar, float momentum, long* nbt, int B, int H, int W, hipStream_t stream) {
+  if (!x || !w || !dil || !v || !gamma || !beta || !mean || !var || (p > 0 && !rest) || B <= 0 || H <= 0 || W <= 0 || nb < 1 ||
+      nb > 3)
+    return CENET_EINVAL;
+  DwBnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.sxb = sxb; a.y = v; a.syb = svb; a.rest = rest; a.srb = srb;
+  for (int j = 0; j < nb; ++j) {
+    if (!w[j] || dil[j] < 1) return CENET_EINVAL;
+    a.w[j] = w[j];
+    a.dil[j] = dil[j];
+  }
+  a.G = g; a.NB = nb; a.P = p; a.gamma = gamma; a.beta = beta; a.eps = eps; a.mean = mean; a.var = var; a.rmean = rmean;
+  a.rvar = rvar; a.momentum = momentum; a.nbt = nbt; a.B = B; a.H = H; a.W = W;
+  return dwbn_launch<T>(a, false, stream);
+}
+
+template <typename T>
+static int dwbn_bwd_acc_impl(const T* g_v, long sgb, const T* g_rest, long srb, const T* g_add, long sab, const T* x, long sxb,
+                             const float* const* w, const int* dil, int nb, int g, int p, const float* gamma, const float* beta,
+                             float eps, const float* mean, const float* var, T* dx, long sdb, float* du_ws, float* const* dw_acc,
+                             float* dgamma_acc, float* dbeta_acc, int B, int H, int W, hipStream_t stream) {
+  if (!g_v || !x || !w || !dil || !gamma || !beta || !mean || !var || !dx || !du_ws || !dw_acc || !dgamma_acc || !dbeta_acc ||
+      (p > 0 && !g_rest) || B <= 0 || H <= 0 || W <= 0 || nb < 1 || nb > 3)
+    return CENET_EINVAL;
+  DwBnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.sxb = sxb; a.y = dx; a.syb = sdb; a.rest = (void*)g_rest; a.srb = srb; a.g = g_v; a.sgb = sgb; a.gadd = g_add;
+  a.sab = sab; a.du = du_ws;
+  for (int j = 0; j < nb; ++j) {
+    if (!w[j] || !dw_acc[j] || dil[j] < 1) return CENET_EINVAL;
+    a.w[j] = w[j];
+    a.dw[j] = dw_acc[j];
+    a.dil[j] = dil[j];
+  }
+  a.G = g; a.NB = nb; a.P = p; a.gamma = gamma; a.beta = beta; a.eps = eps; a.mean = (float*)mean; a.var = (float*)var;
+  a.dgamma = dgamma_acc; a.dbeta = dbeta_acc; a.B = B; a.H = H; a.W = W;
+  return dwbn_launch<T>(a, true, stream);
 }
 
 constexpr int EUCB_SM_SMALL = 48 * 1024, EUCB_SM_LARGE = 152 * 1024;
@@ -653,3 +952,15 @@ CENET_TWIN(cfam_mid_bwd_acc, (const T* g_y2, const T* g_x1, const T* p_raw, cons
                               float* dgamma_2_acc, float* dbeta_2_acc, int B, int C, int HW, hipStream_t stream),
            (g_y2, g_x1, p_raw, m, x1, d_p_raw, d_m, d_x0, gamma_p, beta_p, eps_p, mean_p, var_p, w, ls, gamma_2, eps_2, mean_2,
             var_2, dgamma_p_acc, dbeta_p_acc, dw_acc, dls_acc, dgamma_2_acc, dbeta_2_acc, B, C, HW, stream))
+
+CENET_TWIN(dwbn_fwd, (const T* x, long sxb, const float* const* w, const int* dil, int nb, int g, int p, T* v, long svb, T* rest,
+                      long srb, const float* gamma, const float* beta, float eps, float* mean, float* var, float* running_mean,
+                      float* running_var, float momentum, long* num_batches_tracked, int B, int H, int W, hipStream_t stream),
+           (x, sxb, w, dil, nb, g, p, v, svb, rest, srb, gamma, beta, eps, mean, var, running_mean, running_var, momentum,
+            num_batches_tracked, B, H, W, stream))
+CENET_TWIN(dwbn_bwd_acc, (const T* g_v, long sgb, const T* g_rest, long srb, const T* g_add, long sab, const T* x, long sxb,
+                          const float* const* w, const int* dil, int nb, int g, int p, const float* gamma, const float* beta,
+                          float eps, const float* mean, const float* var, T* dx, long sdb, float* du_ws, float* const* dw_acc,
+                          float* dgamma_acc, float* dbeta_acc, int B, int H, int W, hipStream_t stream),
+           (g_v, sgb, g_rest, srb, g_add, sab, x, sxb, w, dil, nb, g, p, gamma, beta, eps, mean, var, dx, sdb, du_ws, dw_acc,
+            dgamma_acc, dbeta_acc, B, H, W, stream))

@@ -512,6 +512,22 @@ def cfam_mid_bwd(g_y2, g_x1, p_raw, m, x1, d_p, d_m, d_x0, gp, bp, epsp, meanp, 
           float(eps2), mean2, var2, dgp, dbp, dw, dls, dg2, db2, B, Cn, HW)
 
 
+def dwbn_fwd(x, ws, dils, g, p, v, rest, gamma, beta, eps, mean, var, rmean, rvar, momentum, nbt, B, H, W):
+    """MultiOrderDWConv's dilated depthwise branches + BatchNorm + ReLU and the pooled slice's copy in one launch (chanloc.hip)"""
+    _chk(x, v, rest, gamma, beta, mean, var, rmean, rvar, *ws)
+    nb, Ct = len(ws), len(ws) * g + p
+    _call("cenet_dwbn_fwd_f32", x, L(Ct * H * W), _ptr_arr([w.data_ptr() for w in ws]), (C.c_int * nb)(*[int(d) for d in dils]), nb,
+          g, p, v, L(nb * g * H * W), rest, L(p * H * W), gamma, beta, float(eps), mean, var, rmean, rvar, float(momentum), nbt, B, H, W)
+
+
+def dwbn_bwd(g_v, g_rest, x, ws, dils, g, p, gamma, beta, eps, mean, var, dx, du_ws, dws, dgamma, dbeta, B, H, W):
+    _chk(g_v, g_rest, x, dx, du_ws, dgamma, dbeta, *ws, *dws)
+    nb, Ct = len(ws), len(ws) * g + p
+    _call("cenet_dwbn_bwd_acc_f32", g_v, L(nb * g * H * W), g_rest, L(p * H * W), None, L(0), x, L(Ct * H * W),
+          _ptr_arr([w.data_ptr() for w in ws]), (C.c_int * nb)(*[int(d) for d in dils]), nb, g, p, gamma, beta, float(eps), mean, var,
+          dx, L(Ct * H * W), du_ws, _ptr_arr([w.data_ptr() for w in dws]), dgamma, dbeta, B, H, W)
+
+
 def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0, x_off=0, y_off=0):
     """x_off / y_off (elements): read / write a channel slice of a wider tensor in place (batch strides sxb / syb)"""
     _chk(x, w, bias, y, a)

@@ -94,8 +94,16 @@ class MultiOrderDWConv(nn.Module):
 
     def _branches_merged(self, x, sizes, mg):
         b = list(self.dlps)[:3]
-        u, rest = ops.split_dwconv(x, sizes[:3], [m.rate for m in b], [m.depthwise.weight for m in b], joined=True)
-        for key, bn in (("dbn", b[0].depthwise_bn), ("pbn", b[0].pointwise_bn)):
+        dbn = b[0].depthwise_bn
+        fused = ops.split_dwconv_bn_supported(x, sizes[:3], dbn.training)
+        if fused:
+            # small maps: the three depthwise convs, their BatchNorm + ReLU and the pooled slice's copy in one launch per pass
+            u, rest = ops.split_dwconv_bn(x, sizes[:3], [m.rate for m in b], [m.depthwise.weight for m in b], mg["dbn_w"],
+                                          mg["dbn_b"], mg["dbn_running_mean"], mg["dbn_running_var"],
+                                          mg["dbn_num_batches_tracked"], dbn.eps, dbn.momentum if dbn.momentum is not None else 0.1)
+        else:
+            u, rest = ops.split_dwconv(x, sizes[:3], [m.rate for m in b], [m.depthwise.weight for m in b], joined=True)
+        for key, bn in ((("pbn", b[0].pointwise_bn),) if fused else (("dbn", b[0].depthwise_bn), ("pbn", b[0].pointwise_bn))):
             if key == "pbn":
                 u = ops.grouped_conv1x1(u, mg["pw"])
             u = ops.batchnorm(u, mg[key + "_w"], mg[key + "_b"], mg[key + "_running_mean"], mg[key + "_running_var"],

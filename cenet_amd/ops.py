@@ -1815,6 +1815,55 @@ def split_dwconv(x, sizes, dils, ws, joined=False):
     return SplitDWFn.apply(x, tuple(sizes), tuple(dils), bool(joined), *ws)
 
 
+class SplitDWBnFn(Function):
+    """cfam.py:230-236 over blocks.py:169-177: SplitDWFn(joined) + the branches' (merged) depthwise BatchNorm + ReLU as ONE launch per
+    pass (csrc/chanloc.hip: workgroup = channel over the batch; the pooled slice's copy rides along).  -> (V, rest)"""
+
+    @staticmethod
+    def forward(ctx, x, sizes, dils, gamma, beta, rmean, rvar, nbt, eps, momentum, *ws):
+        x = _c(x)
+        B, Cn, H, Wd = x.shape
+        g, nb = sizes[0], len(ws)
+        p = Cn - g * nb
+        v = _act((B, g * nb, H, Wd), x)
+        rest = _act((B, p, H, Wd), x) if p > 0 else None
+        mean, var = _empty((g * nb,), x), _empty((g * nb,), x)
+        kern.dwbn_fwd(x, ws, dils, g, p, v, rest, gamma, beta, eps, mean, var, rmean, rvar, momentum, nbt, B, H, Wd)
+        ctx.save_for_backward(x, gamma, beta, mean, var, *ws)
+        ctx.refs = (gamma, beta) + tuple(ws)
+        ctx.cfg = (g, p, tuple(dils), eps)
+        return (v, rest) if rest is not None else (v,)
+
+    @staticmethod
+    def backward(ctx, g_v, g_rest=None):
+        x, gamma, beta, mean, var = ctx.saved_tensors[:5]
+        ws = ctx.saved_tensors[5:]
+        g, p, dils, eps = ctx.cfg
+        B, Cn, H, Wd = x.shape
+        if g_v is None:
+            raise RuntimeError("split_dwconv_bn: the branch outputs carried no gradient")
+        g_v = _c(g_v)
+        if p > 0:
+            g_rest = _c(g_rest) if g_rest is not None else kern.zero_(torch.empty((B, p, H, Wd), device=x.device, dtype=x.dtype))
+        dx = torch.empty_like(x)
+        du = _empty((g * len(ws) * B * H * Wd,), x)
+        dws = [_gb(wp, x) for wp in ctx.refs[2:]]
+        kern.dwbn_bwd(g_v, g_rest, x, ws, dils, g, p, gamma, beta, eps, mean, var, dx, du, dws, _gb(ctx.refs[0], x),
+                      _gb(ctx.refs[1], x), B, H, Wd)
+        return (dx,) + (None,) * (9 + len(ws))
+
+
+def split_dwconv_bn_supported(x, sizes, training: bool) -> bool:
+    return (bool(training) and x.dim() == 4 and len(set(sizes)) == 1 and 1 <= len(sizes) <= 3
+            and kern.chanloc_supported(x.shape[0], x.shape[2] * x.shape[3]))
+
+
+def split_dwconv_bn(x, sizes, dils, ws, gamma, beta, rmean, rvar, nbt, eps, momentum):
+    """sizes: the (equal) branch widths; gamma ... nbt: the branches' depthwise BatchNorms joined (ops.merged_param / merged_buffer;
+    nbt holds one counter per branch)"""
+    return SplitDWBnFn.apply(x, tuple(sizes), tuple(dils), gamma, beta, rmean, rvar, nbt, eps, momentum, *ws)
+
+
 class GroupedConv1x1Fn(Function):
     """y[b, j*Co + o] = sum_i W[j, o, i] x[b, j*Ci + i]: G independent bias-free 1x1 convolutions on the channel groups of one
     NCHW tensor in one batched GEMM each way (the pointwise convs of the three dilated SepConvBN branches of cfam.py:208-212,

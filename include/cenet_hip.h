@@ -746,6 +746,32 @@ int cenet_cfam_mid_bwd_acc_bf16(const unsigned short* g_y2, const unsigned short
                                 float* dls_acc, float* dgamma_2_acc, float* dbeta_2_acc, int B, int C, int HW,
                                 cenet_stream_t stream);
 
+/* Dilated depthwise branches of MultiOrderDWConv with their BatchNorm, cfam.py:227-241 over blocks.py:169-177, one launch each
+ * way (workgroup = channel over the batch; cenet_chanloc_supported(B, H*W)):
+ *   v[:, j*g + i] = ReLU(BatchNorm_train(DW3x3 with dilation dil[j] and weights w[j] ([g][9], no bias) of x[:, j*g + i])), j < nb <= 3;
+ *   rest = x[:, nb*g : nb*g + p] (the pooled branch's slice; p may be 0).
+ * x [B, nb*g + p, H, W] (batch stride sxb), v [B, nb*g, H, W] (svb), rest [B, p, H, W] (srb); gamma / beta / mean / var / running
+ * statistics cover the nb*g channels, num_batches_tracked holds nb counters (NULL: not wanted).
+ * Backward: g_v, g_rest and g_add (another gradient of x, [B, nb*g + p, H, W], may be NULL) in; dx = their sum through the chain;
+ * du_ws: nb*g*B*H*W floats of scratch; dw_acc[j] / dgamma / dbeta are ADDED into. */
+int cenet_dwbn_fwd_f32(const float* x, long sxb, const float* const* w, const int* dil, int nb, int g, int p, float* v, long svb,
+                       float* rest, long srb, const float* gamma, const float* beta, float eps, float* mean, float* var,
+                       float* running_mean, float* running_var, float momentum, long* num_batches_tracked, int B, int H, int W,
+                       cenet_stream_t stream);
+int cenet_dwbn_bwd_acc_f32(const float* g_v, long sgb, const float* g_rest, long srb, const float* g_add, long sab, const float* x,
+                           long sxb, const float* const* w, const int* dil, int nb, int g, int p, const float* gamma,
+                           const float* beta, float eps, const float* mean, const float* var, float* dx, long sdb, float* du_ws,
+                           float* const* dw_acc, float* dgamma_acc, float* dbeta_acc, int B, int H, int W, cenet_stream_t stream);
+int cenet_dwbn_fwd_bf16(const unsigned short* x, long sxb, const float* const* w, const int* dil, int nb, int g, int p,
+                        unsigned short* v, long svb, unsigned short* rest, long srb, const float* gamma, const float* beta,
+                        float eps, float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                        long* num_batches_tracked, int B, int H, int W, cenet_stream_t stream);
+int cenet_dwbn_bwd_acc_bf16(const unsigned short* g_v, long sgb, const unsigned short* g_rest, long srb,
+                            const unsigned short* g_add, long sab, const unsigned short* x, long sxb, const float* const* w,
+                            const int* dil, int nb, int g, int p, const float* gamma, const float* beta, float eps,
+                            const float* mean, const float* var, unsigned short* dx, long sdb, float* du_ws, float* const* dw_acc,
+                            float* dgamma_acc, float* dbeta_acc, int B, int H, int W, cenet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,19 +105,20 @@ def _run_cfam(dev, dt, dims, hw, B, fused, monkeypatch, rates=(1, 2, 3)):
             if p_.dim() == 1 or "layer_scale" in n_:
                 p_.add_(0.1 * torch.randn(p_.shape, generator=g).to(dev))
     m.train()
+    from cenet_amd import optim
+    arena = optim.ParamArena(m)  # (parameters of equal role back to back: the merged-branch chains run, as in the benched model)
     x = torch.randn(B, dims, hw, hw, generator=g).to(dt).to(dev).requires_grad_(True)
     cot = torch.randn(B, dims, hw, hw, generator=g).to(dt).to(dev)
     old = kern.set_compute_bf16(dt == BF)
     try:
-        for p_ in m.parameters():
-            p_.grad = torch.zeros_like(p_)
+        arena.zero_grad()
         y = m(x)
         y.backward(cot)
-        ops.wgrad_flush()
+        ops.wgrad_join()
     finally:
         kern.set_compute_bf16(old)
     out = {"y": y.detach(), "dx": x.grad}
-    out.update({"g." + n_: p_.grad for n_, p_ in m.named_parameters()})
+    out.update({"g." + n_: p_.grad.clone() for n_, p_ in m.named_parameters()})
     out.update({"b." + n_: b_.clone() for n_, b_ in m.named_buffers()})
     return out
 
@@ -127,13 +128,14 @@ def _run_cfam(dev, dt, dims, hw, B, fused, monkeypatch, rates=(1, 2, 3)):
 def test_cfam_block_fused_chains_equal_the_launch_chains(dev, dt, dims, hw, B, monkeypatch):
     """the whole CFAM block with every channel-local chain on against the same block on the unfused launch chains"""
     calls = []
-    for name in ("cfam_mid_fwd", "cfam_mid_bwd"):
+    fused_entries = ("cfam_mid_fwd", "cfam_mid_bwd", "dwbn_fwd", "dwbn_bwd")
+    for name in fused_entries:
         orig = getattr(kern, name)
         monkeypatch.setattr(kern, name, lambda *a, _o=orig, _n=name, **k: (calls.append(_n), _o(*a, **k))[1])
     ref = _run_cfam(dev, dt, dims, hw, B, False, monkeypatch)
     assert not calls
     got = _run_cfam(dev, dt, dims, hw, B, True, monkeypatch)
-    assert "cfam_mid_fwd" in calls and "cfam_mid_bwd" in calls
+    assert set(calls) == set(fused_entries), calls
     # bf16 storage: both forms carry rounding noise of their own (the gradients pass ~40 bf16-stored tensors), so the fused form
     # is held to the fp32 evaluation of the launch chains and may be at most 2x (+ a floor of 2 % of the norm) as far from it as the unfused form
     ref32 = _run_cfam(dev, torch.float32, dims, hw, B, False, monkeypatch) if dt == BF else None
