@@ -27,7 +27,7 @@ namespace {
 template <int N>
 __device__ __forceinline__ void block_sum_n(float (&v)[N], float* red) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+  for (int k = 0; k < N; ++k) v[k] = wave_sum_dpp(v[k]);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
   if (l == 0) {
@@ -134,26 +134,36 @@ __device__ __forceinline__ void eucb_combine(const float (&w)[9], float (&q)[2][
     }
 }
 
-// channel planes of the batch -> LDS [B][H + 2][W + 2] with a zero border
+// channel planes of the batch -> LDS [B][H + 2][W + 2] with a zero border, as FP32 whatever the tensor type: 2-byte LDS elements
+// made the tap reads misaligned ds_read_b32 / ds_read_u16 pairs (SQ_WAIT_INST_LDS 39 % of the wave cycles, ~180 cycles per LDS
+// instruction); aligned dwords, consecutive lanes on consecutive banks, read at full rate
 template <typename T>
-__device__ __forceinline__ void eucb_stage(const T* x, long sxb, T* xs, int B, int H, int W, int NT) {
+__device__ __forceinline__ void eucb_stage(const T* x, long sxb, float* xs, int B, int H, int W, int NT) {
   const int PW = W + 2, tot = B * (H + 2) * PW;
   Walk3 k(threadIdx.x, NT, H + 2, PW);
-  for (int e = threadIdx.x; e < tot; e += NT, k.next()) {
-    const int yy = k.i - 1, xx = k.j - 1;
-    T v;
-    memset(&v, 0, sizeof(T));
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x[(long)k.b * sxb + yy * W + xx];
-    xs[e] = v;
+  // eight elements per trip, their loads issued together on clamped addresses (a branch around a load, or a trip per load,
+  // puts one full memory round trip between consecutive loads: measured 3x on this loop)
+  for (int e0 = threadIdx.x; e0 < tot; e0 += 8 * NT) {
+    float v[8];
+    bool in[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int yy = k.i - 1, xx = k.j - 1;
+      in[u] = e0 + u * NT < tot && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      v[u] = ldf(x + (in[u] ? (long)k.b * sxb + yy * W + xx : 0));
+      k.next();
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u * NT < tot) xs[e0 + u * NT] = in[u] ? v[u] : 0.f;
   }
 }
-template <typename T>
-__device__ __forceinline__ void eucb_load_nb(const T* xs, int b, int i, int j, int H, int W, float (&S)[3][3]) {
-  const T* p = xs + ((long)b * (H + 2) + i) * (W + 2) + j;  // padded row i = source row i - 1
+__device__ __forceinline__ void eucb_load_nb(const float* xs, int b, int i, int j, int H, int W, float (&S)[3][3]) {
+  const float* p = xs + ((long)b * (H + 2) + i) * (W + 2) + j;  // padded row i = source row i - 1
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) S[a][c] = ldf(p + a * (W + 2) + c);
+    for (int c = 0; c < 3; ++c) S[a][c] = p[a * (W + 2) + c];
 }
 // the four conv outputs of the quad: u[py][px]
 __device__ __forceinline__ void eucb_quad(const float (&S)[3][3], const float (&q)[2][2][2][2], float (&u)[2][2]) {
@@ -170,7 +180,7 @@ template <typename T, int NT, int SM>
 __global__ __launch_bounds__(NT) void eucb_fwd_kernel(EucbArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
   __shared__ float red[16 * 2];
-  T* xs = (T*)smem;
+  float* xs = (float*)smem;
   const int c = blockIdx.x, H = a.H, W = a.W, HW = H * W, items = a.B * HW;
   eucb_stage((const T*)a.x + (long)c * HW, a.sxb, xs, a.B, H, W, NT);
   float q[2][2][2][2];
@@ -246,8 +256,8 @@ __global__ __launch_bounds__(NT) void eucb_bwd_kernel(EucbArgs a, int G) {
   __shared__ float red[16 * 11];
   const int c = blockIdx.x, H = a.H, W = a.W, HW = H * W, items = a.B * HW, OW = 2 * W, OH = 2 * H;
   const int DW_ = OW + 2, DP = (OH + 2) * DW_;
-  T* xs = (T*)smem;
-  float* du = (float*)(smem + (((long)a.B * (H + 2) * (W + 2) * sizeof(T) + 15) & ~15L));
+  float* xs = (float*)smem;
+  float* du = (float*)(smem + (((long)a.B * (H + 2) * (W + 2) * 4 + 15) & ~15L));
   eucb_stage((const T*)a.x + (long)c * HW, a.sxb, xs, a.B, H, W, NT);
   for (int e = threadIdx.x; e < G * DP; e += NT) du[e] = 0.f;  // (the borders stay zero: only interiors are rewritten)
   float w[9], q[2][2][2][2];
@@ -258,40 +268,63 @@ __global__ __launch_bounds__(NT) void eucb_bwd_kernel(EucbArgs a, int G) {
   __syncthreads();
   const T* g = (const T*)a.g + (long)c * 4 * HW;
   float S[3][3], u[2][2];
-  // gradient of the quad's four conv outputs through LeakyReLU, and their normalised values
-  auto quad_g = [&](int b, int i, int j, float (&gy)[2][2], float (&xh)[2][2]) __attribute__((always_inline)) {
-    eucb_load_nb(xs, b, i, j, H, W, S);
-    eucb_quad(S, q, u);
+  // the two output rows of a quad's gradient as loaded (bf16: one packed pair per row; fp32: two floats per row)
+  struct GRaw {
+    float v[2][2];
+  };
+  auto load_g = [&](int b, int i, int j) __attribute__((always_inline)) -> GRaw {
+    GRaw r;
     const T* gp = g + (long)b * a.sgb + (long)(2 * i) * OW + 2 * j;
 #pragma unroll
     for (int py = 0; py < 2; ++py) {
-      float g0, g1;
       if (sizeof(T) == 2) {
         unsigned pk;
         memcpy(&pk, gp + py * OW, 4);
-        g0 = cenet_bf2f(pk & 0xFFFFu), g1 = cenet_bf2f(pk >> 16);
+        r.v[py][0] = cenet_bf2f(pk & 0xFFFFu), r.v[py][1] = cenet_bf2f(pk >> 16);
       } else {
         float pr[2];
         memcpy(pr, gp + py * OW, 8);
-        g0 = pr[0], g1 = pr[1];
+        r.v[py][0] = pr[0], r.v[py][1] = pr[1];
       }
-      xh[py][0] = (u[py][0] - mu) * rs;
-      xh[py][1] = (u[py][1] - mu) * rs;
-      gy[py][0] = (xh[py][0] * gm + bt > 0.f) ? g0 : g0 * a.slope;
-      gy[py][1] = (xh[py][1] * gm + bt > 0.f) ? g1 : g1 * a.slope;
     }
+    return r;
   };
-  // pass 1: sum g, sum g * xhat
+  // gradient of the quad's four conv outputs through LeakyReLU, and their normalised values
+  auto quad_g = [&](int b, int i, int j, const GRaw& gr, float (&gy)[2][2], float (&xh)[2][2]) __attribute__((always_inline)) {
+    eucb_load_nb(xs, b, i, j, H, W, S);
+    eucb_quad(S, q, u);
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        xh[py][px] = (u[py][px] - mu) * rs;
+        gy[py][px] = (xh[py][px] * gm + bt > 0.f) ? gr.v[py][px] : gr.v[py][px] * a.slope;
+      }
+  };
+  // pass 1: sum g, sum g * xhat.  Four quads per trip, their gradient loads issued together (clamped indices).
   float s[2] = {0.f, 0.f};
   float gy[2][2], xh[2][2];
   Walk3 wk(threadIdx.x, NT, H, W);
-  for (int e = threadIdx.x; e < items; e += NT, wk.next()) {
-    quad_g(wk.b, wk.i, wk.j, gy, xh);
+  for (int e0 = threadIdx.x; e0 < items; e0 += 4 * NT) {
+    int qb[4], qi[4], qj[4];
+    GRaw gr[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      s[0] += gy[k >> 1][k & 1];
-      s[1] += gy[k >> 1][k & 1] * xh[k >> 1][k & 1];
+    for (int t = 0; t < 4; ++t) {
+      const bool v = e0 + t * NT < items;
+      qb[t] = v ? wk.b : 0, qi[t] = v ? wk.i : 0, qj[t] = v ? wk.j : 0;
+      gr[t] = load_g(qb[t], qi[t], qj[t]);
+      wk.next();
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (e0 + t * NT < items) {
+        quad_g(qb[t], qi[t], qj[t], gr[t], gy, xh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s[0] += gy[k >> 1][k & 1];
+          s[1] += gy[k >> 1][k & 1] * xh[k >> 1][k & 1];
+        }
+      }
   }
   block_sum_n<2>(s, red);
   const float n = 4.f * (float)items, m1 = s[0] / n, m2 = s[1] / n, k0 = gm * rs;
@@ -322,20 +355,33 @@ __global__ __launch_bounds__(NT) void eucb_bwd_kernel(EucbArgs a, int G) {
     const int nb = a.B - b0 < G ? a.B - b0 : G;
     // (a) conv-output gradients of images b0 .. b0 + nb into LDS
     wk = Walk3(threadIdx.x, NT, H, W);
-    for (int e = threadIdx.x; e < nb * HW; e += NT, wk.next()) {
-      const int bl = wk.b, i = wk.i, j = wk.j;
-      quad_g(b0 + bl, i, j, gy, xh);
-      float* dp = du + (long)bl * DP + (2 * i + 1) * DW_ + 2 * j + 1;
+    for (int e0 = threadIdx.x; e0 < nb * HW; e0 += 4 * NT) {
+      int qb[4], qi[4], qj[4];
+      GRaw gr[4];
 #pragma unroll
-      for (int py = 0; py < 2; ++py)
+      for (int t = 0; t < 4; ++t) {
+        const bool v = e0 + t * NT < nb * HW;
+        qb[t] = v ? wk.b : 0, qi[t] = v ? wk.i : 0, qj[t] = v ? wk.j : 0;
+        gr[t] = load_g(b0 + qb[t], qi[t], qj[t]);
+        wk.next();
+      }
 #pragma unroll
-        for (int px = 0; px < 2; ++px) {
-          const float d = k0 * (gy[py][px] - m1 - xh[py][px] * m2);
-          dp[py * DW_ + px] = d;
+      for (int t = 0; t < 4; ++t)
+        if (e0 + t * NT < nb * HW) {
+          const int bl = qb[t], i = qi[t], j = qj[t];
+          quad_g(b0 + bl, i, j, gr[t], gy, xh);
+          float* dp = du + (long)bl * DP + (2 * i + 1) * DW_ + 2 * j + 1;
 #pragma unroll
-          for (int a2 = 0; a2 < 2; ++a2)
+          for (int py = 0; py < 2; ++py)
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) A[py][px][a2][c2] += d * S[py + a2][px + c2];
+            for (int px = 0; px < 2; ++px) {
+              const float d = k0 * (gy[py][px] - m1 - xh[py][px] * m2);
+              dp[py * DW_ + px] = d;
+#pragma unroll
+              for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) A[py][px][a2][c2] += d * S[py + a2][px + c2];
+            }
         }
     }
     __syncthreads();
@@ -395,10 +441,6 @@ struct MidArgs {
   int B, C, HW;
 };
 
-template <typename T, int V>
-__device__ __forceinline__ long mid_off(const Walk2& k, int c, int C, int HWv) {  // element group (b, p) of channel c -> elements
-  return ((long)k.b * C + c) * HWv * V + (long)k.p * V;
-}
 __device__ __forceinline__ void bn_publish(float* mean, float* var, float* rm, float* rv, float mom, long* nbt, int c, float mu,
                                            float v, float n) {
   mean[c] = mu;
@@ -414,119 +456,154 @@ __device__ __forceinline__ float round_to(float v) {
   return sizeof(T) == 2 ? cenet_bf2f(cenet_f2bf(v)) : v;
 }
 
-template <typename T, int V, int NT>
-__global__ __launch_bounds__(NT) void cfam_mid_fwd_kernel(MidArgs a) {
-  __shared__ float red[16 * 2];
-  const int c = blockIdx.x, C = a.C, HWv = a.HW / V, items = a.B * HWv;
-  const T *pr = (const T*)a.p_raw, *mm = (const T*)a.m, *x0 = (const T*)a.x0;
-  T *x1 = (T*)a.x1, *y2 = (T*)a.y2;
-  const float n = (float)a.B * (float)a.HW, wv = a.w[0], ls = a.ls[c];
-  // pass 1: statistics of p_raw (shifted by the channel's first value)
-  const float K = ldf(pr + (long)c * a.HW);
-  float s[2] = {0.f, 0.f};
-  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
-    float v[V];
-    ldv<V>(v, pr + mid_off<T, V>(wk, c, C, HWv));
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      const float d = v[k] - K;
-      s[0] += d;
-      s[1] += d * d;
-    }
+// ---- register-resident element ownership ------------------------------------------------------------------------------------
+// A pass over a channel that loads, reduces, loads again ... pays one memory round trip per loop ITERATION when the trip count
+// is a run-time value (the loads of iteration i + 1 sit behind the uses of iteration i): measured 15 - 25 us for 1.5 K elements.
+// Here a thread OWNS up to EPT elements of the channel for the whole kernel: every input is loaded once, all loads of the kernel
+// in flight together, every pass runs on registers, and the outputs are stored at the end.  Ownership is wave-per-image — wave
+// w holds images w, w + nw, ... (slot s), lane l the pixels l, l + 64, ... (row r) — so that per-image reductions are shuffle
+// trees inside one wave and batch reductions one LDS round.  Element k of a thread = (slot k / Rr, row k % Rr), Rr = ceil(HW / 64);
+// slot and row advance with scalar adds under full unrolling.  The host picks EPT >= slots * Rr.
+__device__ __forceinline__ float own_lane0(float v) {  // lane 0's value in every lane
+#ifdef CENET_HOSTSIM_BUILD
+  return __shfl(v, 0);
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+#endif
+}
+struct Own {
+  int lane, wave, nw, Rr, B, HW;
+  __device__ __forceinline__ Own(int B_, int HW_) : B(B_), HW(HW_) {
+    lane = threadIdx.x & 63;
+#ifdef CENET_HOSTSIM_BUILD
+    wave = threadIdx.x >> 6;
+#else
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#endif
+    nw = (int)blockDim.x >> 6;
+    Rr = (HW_ + 63) >> 6;
   }
+};
+// for (k, b, p, ok) over the thread's elements; BODY sees them as locals
+#define OWN_FOR(o, ...)                                                           \
+  {                                                                               \
+    int s__ = 0, r__ = 0;                                                         \
+    _Pragma("unroll") for (int k = 0; k < EPT; ++k) {                             \
+      const int b = (o).wave + s__ * (o).nw, p = r__ * 64 + (o).lane;             \
+      const bool ok = b < (o).B && p < (o).HW;                                    \
+      __VA_ARGS__                                                                 \
+      if (++r__ == (o).Rr) {                                                      \
+        r__ = 0;                                                                  \
+        ++s__;                                                                    \
+      }                                                                           \
+    }                                                                             \
+  }
+
+template <typename T, int EPT>
+__global__ __launch_bounds__(1024) void cfam_mid_fwd_kernel(MidArgs a) {
+  __shared__ float red[16 * 2];
+  const int c = blockIdx.x, C = a.C, HW = a.HW;
+  const Own o(a.B, HW);
+  const long cb = (long)c * HW, sb = (long)C * HW;
+  const T *pr = (const T*)a.p_raw + cb, *mm = (const T*)a.m + cb, *x0 = (const T*)a.x0 + cb;
+  T *x1 = (T*)a.x1 + cb, *y2 = (T*)a.y2 + cb;
+  float P[EPT], M[EPT], X[EPT];
+  // (loads are UNCONDITIONAL on a clamped offset and masked afterwards: a branch per element would put every load in a basic
+  // block of its own, each followed by its wait — straight-line code lets them all issue back to back)
+  OWN_FOR(o, {
+    const long q = ok ? b * sb + p : 0;
+    P[k] = ldf(pr + q);
+    M[k] = ldf(mm + q);
+    X[k] = ldf(x0 + q);
+  })
+  const float KP = ldf(pr), KM = ldf(mm), KX = ldf(x0);  // (shifts of the sums of squares: the channel's first element)
+  const float n = (float)a.B * (float)HW, wv = a.w[0], ls = a.ls[c];
+  // (every per-channel scalar is fetched HERE, with the tensor loads: a load issued after a barrier is a cold miss on the
+  // critical path between two passes)
+  const float gp_ = a.gp[c], bp_ = a.bp[c], g2_ = a.g2[c], b2_ = a.b2[c];
+  float s[2] = {0.f, 0.f};
+  OWN_FOR(o, {
+    const float d = ok ? P[k] - KP : 0.f;
+    s[0] += d;
+    s[1] += d * d;
+  })
   block_sum_n<2>(s, red);
   float mloc = s[0] / n;
   float varp = s[1] / n - mloc * mloc;
   if (varp < 0.f) varp = 0.f;
-  const float mup = K + mloc;
+  const float mup = KP + mloc;
   if (threadIdx.x == 0) bn_publish(a.meanp, a.varp, a.rmp, a.rvp, a.momp, a.nbtp, c, mup, varp, n);
-  const float ap = a.gp[c] * rsqrtf(varp + a.epsp), cp = a.bp[c] - mup * ap;
-  // pass 2: x1 (stored) and its statistics (of the STORED values: the backward pass normalises what it reads)
-  const long o0 = (long)c * a.HW;
-  const float K2 = round_to<T>(ldf(x0 + o0) + ls * ((1.f - wv) * ldf(mm + o0) + wv * (ap * ldf(pr + o0) + cp)));
+  const float ap = gp_ * rsqrtf(varp + a.epsp), cp = bp_ - mup * ap;
+  // x1 and its statistics (of the values as stored: the backward pass normalises what it reads)
+  const float K2 = round_to<T>(KX + ls * ((1.f - wv) * KM + wv * (ap * KP + cp)));
   s[0] = s[1] = 0.f;
-  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
-    const long o = mid_off<T, V>(wk, c, C, HWv);
-    float vp[V], vm[V], vx[V];
-    ldv<V>(vp, pr + o);
-    ldv<V>(vm, mm + o);
-    ldv<V>(vx, x0 + o);
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      vx[k] = round_to<T>(vx[k] + ls * ((1.f - wv) * vm[k] + wv * (ap * vp[k] + cp)));
-      const float d = vx[k] - K2;
-      s[0] += d;
-      s[1] += d * d;
-    }
-    stv<V>(x1 + o, vx);
-  }
-  block_sum_n<2>(s, red);  // (its barriers also order the x1 stores before the reads below: same workgroup, same L1)
+  OWN_FOR(o, {
+    X[k] = round_to<T>(X[k] + ls * ((1.f - wv) * M[k] + wv * (ap * P[k] + cp)));
+    const float d = ok ? X[k] - K2 : 0.f;
+    s[0] += d;
+    s[1] += d * d;
+  })
+  block_sum_n<2>(s, red);
   mloc = s[0] / n;
   float var2 = s[1] / n - mloc * mloc;
   if (var2 < 0.f) var2 = 0.f;
   const float mu2 = K2 + mloc;
   if (threadIdx.x == 0) bn_publish(a.mean2, a.var2, a.rm2, a.rv2, a.mom2, a.nbt2, c, mu2, var2, n);
-  const float a2 = a.g2[c] * rsqrtf(var2 + a.eps2), c2 = a.b2[c] - mu2 * a2;
-  // pass 3: y2
-  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
-    const long o = mid_off<T, V>(wk, c, C, HWv);
-    float v[V];
-    ldv<V>(v, x1 + o);
-#pragma unroll
-    for (int k = 0; k < V; ++k) v[k] = a2 * v[k] + c2;
-    stv<V>(y2 + o, v);
-  }
+  const float a2 = g2_ * rsqrtf(var2 + a.eps2), c2 = b2_ - mu2 * a2;
+  OWN_FOR(o, {
+    if (ok) {
+      stf(x1 + b * sb + p, X[k]);
+      stf(y2 + b * sb + p, a2 * X[k] + c2);
+    }
+  })
 }
 
-template <typename T, int V, int NT>
-__global__ __launch_bounds__(NT) void cfam_mid_bwd_kernel(MidArgs a) {
+template <typename T, int EPT>
+__global__ __launch_bounds__(1024) void cfam_mid_bwd_kernel(MidArgs a) {
   __shared__ float red[16 * 4];
-  const int c = blockIdx.x, C = a.C, HWv = a.HW / V, items = a.B * HWv;
-  const T *pr = (const T*)a.p_raw, *mm = (const T*)a.m, *x1 = (const T*)a.x1, *gy = (const T*)a.g_y2, *gx = (const T*)a.g_x1;
-  T *dp = (T*)a.d_p, *dm = (T*)a.d_m, *dx0 = (T*)a.d_x0;
-  const float n = (float)a.B * (float)a.HW, wv = a.w[0], ls = a.ls[c];
+  const int c = blockIdx.x, C = a.C, HW = a.HW;
+  const Own o(a.B, HW);
+  const long cb = (long)c * HW, sb = (long)C * HW;
+  const T *pr = (const T*)a.p_raw + cb, *mm = (const T*)a.m + cb, *x1 = (const T*)a.x1 + cb, *gy = (const T*)a.g_y2 + cb;
+  const T* gx = a.g_x1 ? (const T*)a.g_x1 + cb : nullptr;
+  T *dp = (T*)a.d_p + cb, *dm = (T*)a.d_m + cb, *dx0 = (T*)a.d_x0 + cb;
+  float G[EPT], X[EPT], P[EPT], M[EPT], D[EPT];
+  const T* gxs = gx ? gx : gy;  // (no tap: any valid address; the value is dropped)
+  OWN_FOR(o, {
+    const long q = ok ? b * sb + p : 0;
+    G[k] = ldf(gy + q);
+    X[k] = ldf(x1 + q);
+    P[k] = ldf(pr + q);
+    M[k] = ldf(mm + q);
+    D[k] = ldf(gxs + q);
+  })
+  OWN_FOR(o, {
+    if (!ok) G[k] = 0.f;
+    if (!ok || !gx) D[k] = 0.f;
+  })
+  const float n = (float)a.B * (float)HW, wv = a.w[0], ls = a.ls[c];
   const float mu2 = a.mean2[c], rs2 = rsqrtf(a.var2[c] + a.eps2), k2 = a.g2[c] * rs2;
   const float mup = a.meanp[c], rsp = rsqrtf(a.varp[c] + a.epsp), ap = a.gp[c] * rsp, cp = a.bp[c] - mup * ap;
-  // pass 1: BatchNorm_2 sums
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
-    const long o = mid_off<T, V>(wk, c, C, HWv);
-    float g[V], v[V];
-    ldv<V>(g, gy + o);
-    ldv<V>(v, x1 + o);
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      s[0] += g[k];
-      s[1] += g[k] * ((v[k] - mu2) * rs2);
-    }
-  }
+  OWN_FOR(o, {
+    X[k] = ok ? (X[k] - mu2) * rs2 : 0.f;  // xhat_2
+    s[0] += G[k];
+    s[1] += G[k] * X[k];
+  })
   block_sum_n<4>(s, red);
   const float m1 = s[0] / n, m2 = s[1] / n;
   const float dg2 = s[1], db2 = s[0];
-  // pass 2: d x1 (= d x0, stored) and the sums of everything upstream of it
   s[0] = s[1] = s[2] = s[3] = 0.f;  // dls, dw, sum d p, sum d p * xhat_p
-  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
-    const long o = mid_off<T, V>(wk, c, C, HWv);
-    float g[V], v[V], t[V], vp[V], vm[V];
-    ldv<V>(g, gy + o);
-    ldv<V>(v, x1 + o);
-    if (gx) ldv<V>(t, gx + o);
-    ldv<V>(vp, pr + o);
-    ldv<V>(vm, mm + o);
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      float d = k2 * (g[k] - m1 - (v[k] - mu2) * rs2 * m2);
-      if (gx) d += t[k];
-      d = round_to<T>(d);  // (the value pass 3 reads back)
-      g[k] = d;
-      const float pn = ap * vp[k] + cp, z = (1.f - wv) * vm[k] + wv * pn, dz = d * ls, dpn = dz * wv;
-      s[0] += d * z;
-      s[1] += dz * (pn - vm[k]);
-      s[2] += dpn;
-      s[3] += dpn * ((vp[k] - mup) * rsp);
-    }
-    stv<V>(dx0 + o, g);
-  }
+  OWN_FOR(o, {
+    const float d = ok ? round_to<T>(k2 * (G[k] - m1 - X[k] * m2) + D[k]) : 0.f;  // d x1 = d x0 (as stored)
+    D[k] = d;
+    const float pn = ap * P[k] + cp, z = (1.f - wv) * M[k] + wv * pn, dz = d * ls, dpn = dz * wv;
+    P[k] = (P[k] - mup) * rsp;  // xhat_p
+    s[0] += d * z;
+    s[1] += dz * (pn - M[k]);
+    s[2] += dpn;
+    s[3] += dpn * P[k];
+  })
   block_sum_n<4>(s, red);
   const float t1 = s[2] / n, t2 = s[3] / n;
   if (threadIdx.x == 0) {
@@ -537,40 +614,47 @@ __global__ __launch_bounds__(NT) void cfam_mid_bwd_kernel(MidArgs a) {
     a.dbp[c] += s[2];
     atomicAdd(a.dw, s[1]);
   }
-  // pass 3: d p_raw, d m
-  for (Walk2 wk(threadIdx.x, NT, HWv); wk.b < a.B; wk.next()) {
-    const long o = mid_off<T, V>(wk, c, C, HWv);
-    float d[V], vp[V], om[V];
-    ldv<V>(d, dx0 + o);
-    ldv<V>(vp, pr + o);
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      const float dz = d[k] * ls, dpn = dz * wv;
-      om[k] = dz * (1.f - wv);
-      vp[k] = ap * (dpn - t1 - (vp[k] - mup) * rsp * t2);
+  OWN_FOR(o, {
+    if (ok) {
+      const long q = b * sb + p;
+      const float dz = D[k] * ls, dpn = dz * wv;
+      stf(dx0 + q, D[k]);
+      stf(dm + q, dz * (1.f - wv));
+      stf(dp + q, ap * (dpn - t1 - P[k] * t2));
     }
-    stv<V>(dm + o, om);
-    stv<V>(dp + o, vp);
+  })
+}
+
+// Threads per workgroup for a channel of B images x HW pixels: the FEWEST waves whose threads still own <= maxE elements each.
+// These kernels are bound by vector-instruction ISSUE, not by bytes: every thread pays the fixed part of the kernel (reductions,
+// scalars, index set-up: several hundred instructions) whatever it owns, so 16 waves holding 2 elements per thread cost four times
+// the issue slots of 4 waves holding 8 (measured at 7x7, 512 channels: 19 -> 11 us).  Returns the elements per thread (0: too large).
+static inline int own_pick(int B, int HW, int maxE, int* nt) {
+  const int Rr = (HW + 63) / 64;
+  for (int nw = 4; nw <= 16; nw *= 2) {
+    const int need = ((B + nw - 1) / nw) * Rr;
+    if (need <= maxE) {
+      *nt = nw * 64;
+      return need;
+    }
   }
+  return 0;
 }
 
 template <typename T>
 static int cfam_mid_launch(const MidArgs& a, bool bwd, hipStream_t stream) {
-  const long per = (long)a.B * a.HW;
-  if (per < 2 || per > CENET_CHANLOC_MAX) return CENET_EUNSUPPORTED;
-  const bool v4 = (a.HW & 3) == 0;
-#define CENET_MID(Vv, NTv)                                                                                   \
-  {                                                                                                          \
-    if (bwd) CENET_LAUNCH((cfam_mid_bwd_kernel<T, Vv, NTv>), dim3(a.C), dim3(NTv), stream, a);               \
-    else CENET_LAUNCH((cfam_mid_fwd_kernel<T, Vv, NTv>), dim3(a.C), dim3(NTv), stream, a);                   \
+  int nt = 0;
+  const int need = own_pick(a.B, a.HW, 16, &nt);
+  if ((long)a.B * a.HW < 2 || need == 0) return CENET_EUNSUPPORTED;
+#define CENET_MID(E)                                                                                     \
+  {                                                                                                      \
+    if (bwd) CENET_LAUNCH((cfam_mid_bwd_kernel<T, E>), dim3(a.C), dim3(nt), stream, a);                  \
+    else CENET_LAUNCH((cfam_mid_fwd_kernel<T, E>), dim3(a.C), dim3(nt), stream, a);                      \
   }
-  if (v4) {
-    if (per / 4 <= 1024) CENET_MID(4, 256)
-    else CENET_MID(4, 1024)
-  } else {
-    if (per <= 2048) CENET_MID(1, 256)
-    else CENET_MID(1, 1024)
-  }
+  if (need <= 2) CENET_MID(2)
+  else if (need <= 4) CENET_MID(4)
+  else if (need <= 8) CENET_MID(8)
+  else CENET_MID(16)
 #undef CENET_MID
   CENET_CHECK_LAUNCH();
   return CENET_OK;
@@ -633,7 +717,6 @@ struct DwBnArgs {
   long sgb;
   const void* gadd;  // backward: other gradient of x [B, Ctot, H, W] (batch stride sab) or null
   long sab;
-  float* du;         // backward scratch: [NB*g][B][HW] fp32
   const float* w[3];
   float* dw[3];
   int dil[3];
@@ -647,8 +730,8 @@ struct DwBnArgs {
   int B, H, W;
 };
 
-template <typename T>
-__device__ __forceinline__ float dw_tap9(const T* pl, int H, int W, int i, int j, int dil, const float (&w)[9], float (&tap)[9]) {
+// 3x3 taps of pixel (i, j) of one LDS plane (zero outside), their weighted sum
+__device__ __forceinline__ float dw_tap9(const float* pl, int H, int W, int i, int j, int dil, const float (&w)[9], float (&tap)[9]) {
   float t = 0.f;
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
@@ -656,60 +739,61 @@ __device__ __forceinline__ float dw_tap9(const T* pl, int H, int W, int i, int j
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int xx = j + (kx - 1) * dil;
-      const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? ldf(pl + yy * W + xx) : 0.f;
-      tap[ky * 3 + kx] = v;
-      t += w[ky * 3 + kx] * v;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const float v = pl[in ? yy * W + xx : 0];
+      tap[ky * 3 + kx] = in ? v : 0.f;
+      t += w[ky * 3 + kx] * tap[ky * 3 + kx];
     }
   }
   return t;
 }
-
-// stage the channel's planes [B][HW] into LDS if they fit; returns the base and the image stride to read them with
-template <typename T>
-__device__ __forceinline__ const T* chan_stage(const T* x, long sxb, int B, int HW, unsigned char* smem, int sm_bytes, int NT,
-                                               long& stride) {
-  if ((long)B * HW * (long)sizeof(T) > sm_bytes) {
-    stride = sxb;
-    return x;
-  }
-  T* xs = (T*)smem;
-  int e = threadIdx.x;
-  for (Walk2 k(threadIdx.x, NT, HW); k.b < B; k.next(), e += NT) xs[e] = x[(long)k.b * sxb + k.p];
-  __syncthreads();
-  stride = HW;
-  return xs;
+// p -> (i, j) = (p / W, p % W) without an integer division (exact for p < 2^22)
+__device__ __forceinline__ void pix_ij(int p, int W, float invW, int& i, int& j) {
+  i = (int)(((float)p + 0.5f) * invW);
+  j = p - i * W;
 }
 
-template <typename T, int NT, int SM>
-__global__ __launch_bounds__(NT) void dwbn_fwd_kernel(DwBnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+constexpr int DWBN_MAXE = 8192;  // elements of a channel over the batch (16 waves x 8 elements x 64 lanes)
+
+template <typename T, int EPT>
+__global__ __launch_bounds__(1024) void dwbn_fwd_kernel(DwBnArgs a) {
+  __shared__ float xs[DWBN_MAXE];  // (fp32 whatever T is: aligned dword reads, see eucb_stage)
   __shared__ float red[16 * 2];
-  const int c = blockIdx.x, H = a.H, W = a.W, HW = H * W, items = a.B * HW;
+  const int c = blockIdx.x, H = a.H, W = a.W, HW = H * W;
+  const Own o(a.B, HW);
   if (c >= a.NB * a.G) {  // the pooled branch's slice: a copy
-    const int cr = c - a.NB * a.G;
     const T* x = (const T*)a.x + (long)c * HW;
-    T* r = (T*)a.rest + (long)cr * HW;
-    for (Walk2 k(threadIdx.x, NT, HW); k.b < a.B; k.next()) r[(long)k.b * a.srb + k.p] = x[(long)k.b * a.sxb + k.p];
+    T* r = (T*)a.rest + (long)(c - a.NB * a.G) * HW;
+    T V[EPT];
+    OWN_FOR(o, { V[k] = x[ok ? (long)b * a.sxb + p : 0]; })
+    OWN_FOR(o, { if (ok) r[(long)b * a.srb + p] = V[k]; })
     return;
   }
   const int j = c / a.G, cl = c - j * a.G, dil = a.dil[j];
+  const T* x = (const T*)a.x + (long)c * HW;
+  {
+    float V[EPT];
+    OWN_FOR(o, { V[k] = ldf(x + (ok ? (long)b * a.sxb + p : 0)); })
+    OWN_FOR(o, { if (ok) xs[b * HW + p] = V[k]; })
+  }
   float w[9], tap[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = a.w[j][cl * 9 + k];
-  long xst;
-  const T* xs = chan_stage((const T*)a.x + (long)c * HW, a.sxb, a.B, HW, smem, SM, NT, xst);
-  T* y = (T*)a.y + (long)c * HW;
+  const float gm = a.gamma[c], bt = a.beta[c], invW = 1.f / (float)W;
+  __syncthreads();
   const float K = round_to<T>(dw_tap9(xs, H, W, H / 2, W / 2, dil, w, tap));
+  float U[EPT];
   float s[2] = {0.f, 0.f};
-  for (Walk3 k(threadIdx.x, NT, H, W); k.b < a.B; k.next()) {
-    const float u = round_to<T>(dw_tap9(xs + k.b * xst, H, W, k.i, k.j, dil, w, tap));
-    stf(y + (long)k.b * a.syb + k.i * W + k.j, u);
-    const float d = u - K;
+  OWN_FOR(o, {
+    int pi, pj;
+    pix_ij(ok ? p : 0, W, invW, pi, pj);
+    U[k] = round_to<T>(dw_tap9(xs + (ok ? b : 0) * HW, H, W, pi, pj, dil, w, tap));  // (rounded as the launch chain stores it)
+    const float d = ok ? U[k] - K : 0.f;
     s[0] += d;
     s[1] += d * d;
-  }
-  block_sum_n<2>(s, red);  // (also orders the stores above before the in-place pass below: same workgroup)
-  const float n = (float)items, m = s[0] / n;
+  })
+  block_sum_n<2>(s, red);
+  const float n = (float)a.B * (float)HW, m = s[0] / n;
   float var = s[1] / n - m * m;
   if (var < 0.f) var = 0.f;
   const float mu = K + m;
@@ -722,99 +806,115 @@ __global__ __launch_bounds__(NT) void dwbn_fwd_kernel(DwBnArgs a) {
     }
     if (a.nbt && cl == 0) a.nbt[j] += 1;
   }
-  const float sc = a.gamma[c] * rsqrtf(var + a.eps), sh = a.beta[c] - mu * sc;
-  for (Walk2 k(threadIdx.x, NT, HW); k.b < a.B; k.next()) {
-    T* q = y + (long)k.b * a.syb + k.p;
-    const float v = ldf(q) * sc + sh;
-    stf(q, v > 0.f ? v : 0.f);
-  }
+  const float sc = gm * rsqrtf(var + a.eps), sh = bt - mu * sc;
+  T* y = (T*)a.y + (long)c * HW;
+  OWN_FOR(o, {
+    const float v = U[k] * sc + sh;
+    if (ok) stf(y + (long)b * a.syb + p, v > 0.f ? v : 0.f);
+  })
 }
 
-template <typename T, int NT, int SM>
-__global__ __launch_bounds__(NT) void dwbn_bwd_kernel(DwBnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+template <typename T, int EPT>
+__global__ __launch_bounds__(1024) void dwbn_bwd_kernel(DwBnArgs a) {
+  __shared__ float xs[DWBN_MAXE];
+  __shared__ float du[DWBN_MAXE];
   __shared__ float red[16 * 9];
-  const int c = blockIdx.x, H = a.H, W = a.W, HW = H * W, items = a.B * HW;
+  const int c = blockIdx.x, H = a.H, W = a.W, HW = H * W;
+  const Own o(a.B, HW);
   T* dx = (T*)a.y + (long)c * HW;
-  const T* ga = a.gadd ? (const T*)a.gadd + (long)c * HW : nullptr;
-  if (c >= a.NB * a.G) {  // pooled-branch channels: dx = g_rest + g_add
+  if (c >= a.NB * a.G) {  // pooled-branch channels: dx = g_rest (+ g_add)
     const T* r = (const T*)a.rest + (long)(c - a.NB * a.G) * HW;
-    for (Walk2 k(threadIdx.x, NT, HW); k.b < a.B; k.next()) {
-      float v = ldf(r + (long)k.b * a.srb + k.p);
-      if (ga) v += ldf(ga + (long)k.b * a.sab + k.p);
-      stf(dx + (long)k.b * a.syb + k.p, v);
-    }
+    const T* ga = a.gadd ? (const T*)a.gadd + (long)c * HW : nullptr;
+    float V[EPT];
+    OWN_FOR(o, {
+      V[k] = ldf(r + (ok ? (long)b * a.srb + p : 0));
+      if (ga) V[k] += ldf(ga + (ok ? (long)b * a.sab + p : 0));
+    })
+    OWN_FOR(o, { if (ok) stf(dx + (long)b * a.syb + p, V[k]); })
     return;
   }
   const int j = c / a.G, cl = c - j * a.G, dil = a.dil[j];
+  const T* x = (const T*)a.x + (long)c * HW;
+  const T* g = (const T*)a.g + (long)c * HW;
+  const T* ga = a.gadd ? (const T*)a.gadd + (long)c * HW : nullptr;
+  float X[EPT], GY[EPT], GA[EPT];
+  OWN_FOR(o, {
+    X[k] = ldf(x + (ok ? (long)b * a.sxb + p : 0));
+    GY[k] = ldf(g + (ok ? (long)b * a.sgb + p : 0));
+    GA[k] = ga ? ldf(ga + (ok ? (long)b * a.sab + p : 0)) : 0.f;
+  })
+  OWN_FOR(o, { if (ok) xs[b * HW + p] = X[k]; })
   float w[9], tap[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = a.w[j][cl * 9 + k];
-  long xst;
-  const T* xs = chan_stage((const T*)a.x + (long)c * HW, a.sxb, a.B, HW, smem, SM, NT, xst);
-  const T* g = (const T*)a.g + (long)c * HW;
-  const float mu = a.mean[c], rs = rsqrtf(a.var[c] + a.eps), gm = a.gamma[c], bt = a.beta[c];
-  // pass 1: sum g, sum g * xhat (through the ReLU mask); the conv output is recomputed and rounded as the forward stored it
+  const float mu = a.mean[c], rs = rsqrtf(a.var[c] + a.eps), gm = a.gamma[c], bt = a.beta[c], invW = 1.f / (float)W;
+  __syncthreads();
+  // pass 1: xhat of the recomputed conv output (rounded as the forward stored it), gradient through the ReLU mask, sums
+  float XH[EPT];
   float s[2] = {0.f, 0.f};
-  for (Walk3 k(threadIdx.x, NT, H, W); k.b < a.B; k.next()) {
-    const float xh = (round_to<T>(dw_tap9(xs + k.b * xst, H, W, k.i, k.j, dil, w, tap)) - mu) * rs;
-    const float gy = (xh * gm + bt > 0.f) ? ldf(g + (long)k.b * a.sgb + k.i * W + k.j) : 0.f;
-    s[0] += gy;
-    s[1] += gy * xh;
-  }
+  OWN_FOR(o, {
+    int pi, pj;
+    pix_ij(ok ? p : 0, W, invW, pi, pj);
+    XH[k] = (round_to<T>(dw_tap9(xs + (ok ? b : 0) * HW, H, W, pi, pj, dil, w, tap)) - mu) * rs;
+    GY[k] = (ok && XH[k] * gm + bt > 0.f) ? GY[k] : 0.f;
+    s[0] += GY[k];
+    s[1] += GY[k] * XH[k];
+  })
   block_sum_n<2>(s, red);
-  const float n = (float)items, m1 = s[0] / n, m2 = s[1] / n, k0 = gm * rs;
-  // pass 2: conv-output gradient -> scratch; weight gradient
+  const float n = (float)a.B * (float)HW, m1 = s[0] / n, m2 = s[1] / n, k0 = gm * rs;
+  // pass 2: conv-output gradient -> LDS
+  OWN_FOR(o, { if (ok) du[b * HW + p] = k0 * (GY[k] - m1 - XH[k] * m2); })
+  __syncthreads();
+  // pass 3: one sweep over the 3x3 neighbourhood of the conv-output gradient gives BOTH remaining gradients:
+  //   d x(p)  = sum_t w[t] du(p - delta_t)                       (correlation with the flipped taps)
+  //   d w[t]  = sum_p du(p) x(p + delta_t) = sum_q x(q) du(q - delta_t)   (the same du(p - delta_t), times the centre value x(p))
   float acc[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-  float* du = a.du + (long)c * items;
-  for (Walk3 k(threadIdx.x, NT, H, W); k.b < a.B; k.next()) {
-    const int p = k.i * W + k.j;
-    const float xh = (round_to<T>(dw_tap9(xs + k.b * xst, H, W, k.i, k.j, dil, w, tap)) - mu) * rs;
-    const float gy = (xh * gm + bt > 0.f) ? ldf(g + (long)k.b * a.sgb + p) : 0.f;
-    const float d = k0 * (gy - m1 - xh * m2);
-    du[(long)k.b * HW + p] = d;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] += d * tap[k];
-  }
-  block_sum_n<9>(acc, red);  // (its barriers order the scratch stores before the reads below)
+  OWN_FOR(o, {
+    int pi, pj;
+    pix_ij(ok ? p : 0, W, invW, pi, pj);
+    const float* dp = du + (ok ? b : 0) * HW;
+    const float xc = ok ? X[k] : 0.f;
+    float t = GA[k];
+_Pragma("unroll")
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = pi - (ky - 1) * dil;
+_Pragma("unroll")
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = pj - (kx - 1) * dil;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        float v = dp[in ? yy * W + xx : 0];
+        v = in ? v : 0.f;
+        t += w[ky * 3 + kx] * v;
+        acc[ky * 3 + kx] += xc * v;
+      }
+    }
+    if (ok) stf(dx + (long)b * a.syb + p, t);
+  })
+  block_sum_n<9>(acc, red);
   if (threadIdx.x < 9) a.dw[j][cl * 9 + threadIdx.x] += acc[threadIdx.x];
   if (threadIdx.x == 9) a.dgamma[c] += s[1];
   if (threadIdx.x == 10) a.dbeta[c] += s[0];
-  // pass 3: data gradient (correlation with the flipped taps) + the other gradient of x
-  for (Walk3 k(threadIdx.x, NT, H, W); k.b < a.B; k.next()) {
-    const int b = k.b, i = k.i, jj = k.j, p = i * W + jj;
-    const float* dp = du + (long)b * HW;
-    float t = 0.f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yy = i - (ky - 1) * dil;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int xx = jj - (kx - 1) * dil;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) t += w[ky * 3 + kx] * dp[yy * W + xx];
-      }
-    }
-    if (ga) t += ldf(ga + (long)b * a.sab + p);
-    stf(dx + (long)b * a.syb + p, t);
-  }
 }
-
-constexpr int DWBN_SM = 64 * 1024;
 
 template <typename T>
 static int dwbn_launch(const DwBnArgs& a, bool bwd, hipStream_t stream) {
-  const long per = (long)a.B * a.H * a.W;
-  if (per < 2 || per > CENET_CHANLOC_MAX || a.NB < 1 || a.NB > 3 || a.G < 1 || a.P < 0) return CENET_EUNSUPPORTED;
+  const int HW = a.H * a.W;
+  int nt = 0;
+  const int need = own_pick(a.B, HW, 8, &nt);
+  if ((long)a.B * HW < 2 || (long)a.B * HW > DWBN_MAXE || need == 0 || a.NB < 1 || a.NB > 3 || a.G < 1 || a.P < 0)
+    return CENET_EUNSUPPORTED;
   const int grid = a.NB * a.G + a.P;
-  if (per <= 4096) {
-    if (bwd) CENET_LAUNCH((dwbn_bwd_kernel<T, 256, DWBN_SM / 4>), dim3(grid), dim3(256), stream, a);
-    else CENET_LAUNCH((dwbn_fwd_kernel<T, 256, DWBN_SM / 4>), dim3(grid), dim3(256), stream, a);
-  } else {
-    if (bwd) CENET_LAUNCH((dwbn_bwd_kernel<T, 1024, DWBN_SM>), dim3(grid), dim3(1024), stream, a);
-    else CENET_LAUNCH((dwbn_fwd_kernel<T, 1024, DWBN_SM>), dim3(grid), dim3(1024), stream, a);
+#define CENET_DWBN(E)                                                                                \
+  {                                                                                                  \
+    if (bwd) CENET_LAUNCH((dwbn_bwd_kernel<T, E>), dim3(grid), dim3(nt), stream, a);                 \
+    else CENET_LAUNCH((dwbn_fwd_kernel<T, E>), dim3(grid), dim3(nt), stream, a);                     \
   }
+  if (need <= 2) CENET_DWBN(2)
+  else if (need <= 4) CENET_DWBN(4)
+  else CENET_DWBN(8)
+#undef CENET_DWBN
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -842,15 +942,15 @@ static int dwbn_fwd_impl(const T* x, long sxb, const float* const* w, const int*
 template <typename T>
 static int dwbn_bwd_acc_impl(const T* g_v, long sgb, const T* g_rest, long srb, const T* g_add, long sab, const T* x, long sxb,
                              const float* const* w, const int* dil, int nb, int g, int p, const float* gamma, const float* beta,
-                             float eps, const float* mean, const float* var, T* dx, long sdb, float* du_ws, float* const* dw_acc,
+                             float eps, const float* mean, const float* var, T* dx, long sdb, float* const* dw_acc,
                              float* dgamma_acc, float* dbeta_acc, int B, int H, int W, hipStream_t stream) {
-  if (!g_v || !x || !w || !dil || !gamma || !beta || !mean || !var || !dx || !du_ws || !dw_acc || !dgamma_acc || !dbeta_acc ||
+  if (!g_v || !x || !w || !dil || !gamma || !beta || !mean || !var || !dx || !dw_acc || !dgamma_acc || !dbeta_acc ||
       (p > 0 && !g_rest) || B <= 0 || H <= 0 || W <= 0 || nb < 1 || nb > 3)
     return CENET_EINVAL;
   DwBnArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.sxb = sxb; a.y = dx; a.syb = sdb; a.rest = (void*)g_rest; a.srb = srb; a.g = g_v; a.sgb = sgb; a.gadd = g_add;
-  a.sab = sab; a.du = du_ws;
+  a.sab = sab;
   for (int j = 0; j < nb; ++j) {
     if (!w[j] || !dw_acc[j] || dil[j] < 1) return CENET_EINVAL;
     a.w[j] = w[j];
@@ -862,12 +962,374 @@ static int dwbn_bwd_acc_impl(const T* g_v, long sgb, const T* g_rest, long srb, 
   return dwbn_launch<T>(a, true, stream);
 }
 
+// ---- CFAM front: norm1 + CCU (cfam.py:366 over cfam.py:251-264) -------------------------------------------------------------------
+//   y1 = BatchNorm_1(x0)                                     (stored: the MCA shortcut and the CCU's input)
+//   u_b = [max, mean, std_biased] of y1[b] over the plane;  z_b = fc2 . relu(fc1 u_b);  zn = BatchNorm1d_train(z) over the batch
+//   (skipped for a batch of one);  xs = y1 * sigmoid(zn_b)
+// Workgroup = channel; per-image statistics are taken by one WAVE per image (shuffle trees, no atomics, fixed order).  Forward
+// 5 - 6 launches -> 1; backward (gate reduce, BatchNorm1d backward, CCU apply, BatchNorm backward: 5 launches) -> 1.
+#define CCU_MAXB 256
+struct FrontArgs {
+  const void* x0;            // [B, C, HW]
+  void *y1, *xs;             // forward outputs
+  const void *g_xs, *g_y1, *g_tap;  // backward inputs (g_y1 / g_tap may be null)
+  void* dx0;                 // backward output
+  const float *g1, *b1;      // norm1
+  float eps1;
+  float *mean1, *var1, *rm1, *rv1;
+  float mom1;
+  long* nbt1;
+  const float *fc1, *fc2;    // [C][3][3], [C][3]
+  const float *gd, *bd;      // BatchNorm1d (null: no BatchNorm1d — batch of one)
+  float epsd;
+  float *meand, *vard, *rmd, *rvd;
+  float momd;
+  long* nbtd;
+  float* u;                  // [B, C, 3]
+  int* amax;                 // [B, C]
+  float *z, *zn;             // [B, C]
+  float *dg1, *db1, *dfc1, *dfc2, *dgd, *dbd;  // backward: ADDED into
+  int B, C, HW;
+};
+
+template <typename T, int EPT>
+__global__ __launch_bounds__(1024) void cfam_front_fwd_kernel(FrontArgs a) {
+  __shared__ float red[16 * 2];
+  __shared__ float zs[CCU_MAXB];
+  const int c = blockIdx.x, C = a.C, HW = a.HW, B = a.B;
+  const Own o(B, HW);
+  const long cb = (long)c * HW, sb = (long)C * HW;
+  const T* x = (const T*)a.x0 + cb;
+  T *y1 = (T*)a.y1 + cb, *xs = (T*)a.xs + cb;
+  float X[EPT];
+  OWN_FOR(o, { X[k] = ldf(x + (ok ? b * sb + p : 0)); })
+  const float K = ldf(x);
+  const float g1 = a.g1[c], b1 = a.b1[c];
+  float w1[9], w2[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w1[k] = a.fc1[c * 9 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) w2[k] = a.fc2[c * 3 + k];
+  const float gd = a.gd ? a.gd[c] : 1.f, bd = a.gd ? a.bd[c] : 0.f;
+  float s[2] = {0.f, 0.f};
+  OWN_FOR(o, {
+    const float d = ok ? X[k] - K : 0.f;
+    s[0] += d;
+    s[1] += d * d;
+  })
+  block_sum_n<2>(s, red);
+  const float n = (float)B * (float)HW, m = s[0] / n;
+  float var = s[1] / n - m * m;
+  if (var < 0.f) var = 0.f;
+  const float mu = K + m;
+  if (threadIdx.x == 0) bn_publish(a.mean1, a.var1, a.rm1, a.rv1, a.mom1, a.nbt1, c, mu, var, n);
+  const float a1 = g1 * rsqrtf(var + a.eps1), c1 = b1 - mu * a1;
+  // y1 (as stored) and the per-image statistics of the stored values: an image's pixels all sit in ONE wave (rows r of a slot)
+  float q1 = 0.f, q2 = 0.f, mx = -3.4e38f, Kb = 0.f;
+  int mi = 0;
+  OWN_FOR(o, {
+    X[k] = round_to<T>(a1 * X[k] + c1);
+    if (r__ == 0) {
+      q1 = q2 = 0.f;
+      mx = -3.4e38f;
+      mi = 0;
+      Kb = own_lane0(X[k]);  // (pixel 0 of the image: lane 0, row 0)
+    }
+    if (ok) {
+      const float d = X[k] - Kb;
+      q1 += d;
+      q2 += d * d;
+      if (X[k] > mx) {
+        mx = X[k];
+        mi = p;
+      }
+    }
+    if (r__ == o.Rr - 1 && b < B) {  // (wave-uniform: b does not depend on the lane)
+      q1 = wave_sum_dpp(q1);
+      q2 = wave_sum_dpp(q2);
+      const float wmx = wave_max_dpp(mx);
+      mi = wave_min_i_dpp(mx == wmx ? mi : 0x7fffffff);  // (ties: the smallest pixel index, as aten::max)
+      mx = wmx;
+      if (o.lane == 0) {
+        const float mb = q1 / HW;
+        float vb = q2 / HW - mb * mb;
+        if (vb < 0.f) vb = 0.f;
+        const float mean = Kb + mb, sd = sqrtf(vb);
+        const long bc = (long)b * C + c;
+        a.u[bc * 3 + 0] = mx;
+        a.u[bc * 3 + 1] = mean;
+        a.u[bc * 3 + 2] = sd;
+        a.amax[bc] = mi;
+        float zz = 0.f;
+_Pragma("unroll")
+        for (int j = 0; j < 3; ++j) {
+          const float hdn = w1[j * 3 + 0] * mx + w1[j * 3 + 1] * mean + w1[j * 3 + 2] * sd;
+          if (hdn > 0.f) zz += w2[j] * hdn;
+        }
+        a.z[bc] = zz;
+        zs[b] = zz;
+      }
+    }
+  })
+  __syncthreads();
+  // BatchNorm1d over the batch (one value per image): every thread computes the same few sums
+  float ad = 1.f, cd = 0.f;
+  if (a.gd) {
+    float t1 = 0.f;
+    for (int b = 0; b < B; ++b) t1 += zs[b];
+    const float mz = t1 / B;
+    float t2 = 0.f;
+    for (int b = 0; b < B; ++b) t2 += (zs[b] - mz) * (zs[b] - mz);
+    const float vz = t2 / B;
+    if (threadIdx.x == 0) bn_publish(a.meand, a.vard, a.rmd, a.rvd, a.momd, a.nbtd, c, mz, vz, (float)B);
+    ad = gd * rsqrtf(vz + a.epsd);
+    cd = bd - mz * ad;
+  }
+  float gate = 0.f;
+  OWN_FOR(o, {
+    if (r__ == 0) {
+      const float zn = ad * zs[b < B ? b : 0] + cd;
+      gate = sigmoid_f(zn);
+      if (o.lane == 0 && b < B) a.zn[(long)b * C + c] = zn;
+    }
+    if (ok) {
+      stf(y1 + b * sb + p, X[k]);
+      stf(xs + b * sb + p, X[k] * gate);
+    }
+  })
+}
+
+template <typename T, int EPT>
+__global__ __launch_bounds__(1024) void cfam_front_bwd_kernel(FrontArgs a) {
+  __shared__ float red[16 * 2];
+  __shared__ float dzn_s[CCU_MAXB], gate_s[CCU_MAXB], dmean_s[CCU_MAXB], dstd_s[CCU_MAXB], dmax_s[CCU_MAXB], mean_s[CCU_MAXB];
+  __shared__ int am_s[CCU_MAXB];
+  const int c = blockIdx.x, C = a.C, HW = a.HW, B = a.B;
+  const Own o(B, HW);
+  const long cb = (long)c * HW, sb = (long)C * HW;
+  const T* x = (const T*)a.x0 + cb;
+  const T* gx = (const T*)a.g_xs + cb;
+  const T* gy = a.g_y1 ? (const T*)a.g_y1 + cb : gx;   // (absent: any valid address, the value is dropped)
+  const T* gt = a.g_tap ? (const T*)a.g_tap + cb : gx;
+  T* dx = (T*)a.dx0 + cb;
+  float X[EPT], GX[EPT], GY[EPT], GT[EPT];
+  OWN_FOR(o, {
+    const long q = ok ? b * sb + p : 0;
+    X[k] = ldf(x + q);
+    GX[k] = ldf(gx + q);
+    GY[k] = ldf(gy + q);
+    GT[k] = ldf(gt + q);
+  })
+  const float mu = a.mean1[c], rs = rsqrtf(a.var1[c] + a.eps1), a1 = a.g1[c] * rs, c1 = a.b1[c] - mu * a1;
+  float w1[9], w2[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w1[k] = a.fc1[c * 9 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) w2[k] = a.fc2[c * 3 + k];
+  float kd = 1.f, mz = 0.f, rsd = 1.f;
+  if (a.gd) {
+    mz = a.meand[c];
+    rsd = rsqrtf(a.vard[c] + a.epsd);
+    kd = a.gd[c] * rsd;
+  }
+  // the wave-0 lanes own images for the tiny per-image algebra: their saved statistics now, with everything else
+  float zb[(CCU_MAXB + 63) / 64], ub[(CCU_MAXB + 63) / 64][3];
+  int ab[(CCU_MAXB + 63) / 64];
+  if (o.wave == 0) {
+#pragma unroll
+    for (int i = 0; i < (CCU_MAXB + 63) / 64; ++i) {
+      const int b = i * 64 + o.lane;
+      const long bc = (long)(b < B ? b : 0) * C + c;
+      zb[i] = a.z[bc];
+      ub[i][0] = a.u[bc * 3];
+      ub[i][1] = a.u[bc * 3 + 1];
+      ub[i][2] = a.u[bc * 3 + 2];
+      ab[i] = a.amax[bc];
+    }
+  }
+  float ZN[EPT];  // zn of the element's image (one value per slot, kept per element for simplicity of the unrolled loops)
+  OWN_FOR(o, { ZN[k] = a.zn[(long)(b < B ? b : 0) * C + c]; })
+  // d gate_b = sum_p g_xs * y1 (the image's pixels sit in one wave) -> d zn_b
+  float q = 0.f;
+  OWN_FOR(o, {
+    if (!ok) GX[k] = 0.f;
+    if (!ok || !a.g_y1) GY[k] = 0.f;
+    if (!ok || !a.g_tap) GT[k] = 0.f;
+    if (r__ == 0) q = 0.f;
+    q += GX[k] * round_to<T>(a1 * X[k] + c1);  // (y1 as the forward stored it)
+    if (r__ == o.Rr - 1 && b < B) {
+      q = wave_sum_dpp(q);
+      if (o.lane == 0) {
+        const float sg = sigmoid_f(ZN[k]);
+        gate_s[b] = sg;
+        dzn_s[b] = q * sg * (1.f - sg);
+      }
+    }
+  })
+  __syncthreads();
+  // BatchNorm1d backward over the batch, then the gate MLP backward per image (lane = image in wave 0)
+  if (o.wave == 0) {
+    float md1 = 0.f, md2 = 0.f;
+    if (a.gd) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < (CCU_MAXB + 63) / 64; ++i) {
+        const int b = i * 64 + o.lane;
+        if (b < B) {
+          t1 += dzn_s[b];
+          t2 += dzn_s[b] * ((zb[i] - mz) * rsd);
+        }
+      }
+      t1 = wave_sum_dpp(t1);
+      t2 = wave_sum_dpp(t2);
+      md1 = t1 / B;
+      md2 = t2 / B;
+      if (o.lane == 0) {
+        a.dgd[c] += t2;
+        a.dbd[c] += t1;
+      }
+    }
+    float f1[9], f2[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f1[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f2[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (CCU_MAXB + 63) / 64; ++i) {
+      const int b = i * 64 + o.lane;
+      if (b < B) {
+        const float gz = a.gd ? kd * (dzn_s[b] - md1 - (zb[i] - mz) * rsd * md2) : dzn_s[b];
+        const float mxv = ub[i][0], mean = ub[i][1], sd = ub[i][2];
+        float du[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float hdn = w1[j * 3] * mxv + w1[j * 3 + 1] * mean + w1[j * 3 + 2] * sd;
+          if (hdn > 0.f) {
+            f2[j] += gz * hdn;
+            const float gh = gz * w2[j];
+            f1[j * 3 + 0] += gh * mxv;
+            f1[j * 3 + 1] += gh * mean;
+            f1[j * 3 + 2] += gh * sd;
+            du[0] += gh * w1[j * 3];
+            du[1] += gh * w1[j * 3 + 1];
+            du[2] += gh * w1[j * 3 + 2];
+          }
+        }
+        dmax_s[b] = du[0];
+        dmean_s[b] = du[1] / HW;
+        dstd_s[b] = sd > 0.f ? du[2] / (HW * sd) : 0.f;  // (aten::std_backward masks the 0/0 of a constant plane to 0)
+        mean_s[b] = mean;
+        am_s[b] = ab[i];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f1[k] = wave_sum_dpp(f1[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f2[k] = wave_sum_dpp(f2[k]);
+    if (o.lane < 9) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v = o.lane == k ? f1[k] : v;
+      a.dfc1[c * 9 + o.lane] += v;
+    } else if (o.lane < 12) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v = o.lane - 9 == k ? f2[k] : v;
+      a.dfc2[c * 3 + o.lane - 9] += v;
+    }
+  }
+  __syncthreads();
+  // d y1 per element (in GX), xhat_1 (in X), BatchNorm_1 sums
+  float s[2] = {0.f, 0.f};
+  float cg = 0.f, cm = 0.f, cs = 0.f, cmean = 0.f, cmax = 0.f;
+  int cam = -1;
+  OWN_FOR(o, {
+    if (r__ == 0) {
+      const int bb = b < B ? b : 0;
+      cg = gate_s[bb], cm = dmean_s[bb], cs = dstd_s[bb], cmean = mean_s[bb], cmax = dmax_s[bb], cam = am_s[bb];
+    }
+    float d = GX[k] * cg + cm + cs * (round_to<T>(a1 * X[k] + c1) - cmean) + GY[k];
+    if (p == cam) d += cmax;
+    if (!ok) d = 0.f;
+    GX[k] = d;
+    X[k] = ok ? (X[k] - mu) * rs : 0.f;  // xhat_1
+    s[0] += d;
+    s[1] += d * X[k];
+  })
+  block_sum_n<2>(s, red);
+  const float n = (float)B * (float)HW, m1 = s[0] / n, m2 = s[1] / n;
+  if (threadIdx.x == 0) {
+    a.dg1[c] += s[1];
+    a.db1[c] += s[0];
+  }
+  OWN_FOR(o, {
+    if (ok) stf(dx + b * sb + p, a1 * (GX[k] - m1 - X[k] * m2) + GT[k]);
+  })
+}
+
+template <typename T>
+static int cfam_front_launch(const FrontArgs& a, bool bwd, hipStream_t stream) {
+  int nt = 0;
+  const int need = own_pick(a.B, a.HW, 16, &nt);
+  if ((long)a.B * a.HW < 2 || need == 0 || a.B > CCU_MAXB) return CENET_EUNSUPPORTED;
+#define CENET_FRONT(E)                                                                                   \
+  {                                                                                                      \
+    if (bwd) CENET_LAUNCH((cfam_front_bwd_kernel<T, E>), dim3(a.C), dim3(nt), stream, a);                \
+    else CENET_LAUNCH((cfam_front_fwd_kernel<T, E>), dim3(a.C), dim3(nt), stream, a);                    \
+  }
+  if (need <= 2) CENET_FRONT(2)
+  else if (need <= 4) CENET_FRONT(4)
+  else if (need <= 8) CENET_FRONT(8)
+  else CENET_FRONT(16)
+#undef CENET_FRONT
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
+template <typename T>
+static int cfam_front_fwd_impl(const T* x0, T* y1, T* xs, const float* gamma1, const float* beta1, float eps1, float* mean1,
+                               float* var1, float* rmean1, float* rvar1, float mom1, long* nbt1, const float* fc1, const float* fc2,
+                               const float* gamma_d, const float* beta_d, float eps_d, float* mean_d, float* var_d, float* rmean_d,
+                               float* rvar_d, float mom_d, long* nbt_d, float* u, int* amax, float* z, float* zn, int B, int C,
+                               int HW, hipStream_t stream) {
+  if (!x0 || !y1 || !xs || !gamma1 || !beta1 || !mean1 || !var1 || !fc1 || !fc2 || !u || !amax || !z || !zn || B <= 0 || C <= 0 ||
+      HW <= 0 || (gamma_d && (!beta_d || !mean_d || !var_d)))
+    return CENET_EINVAL;
+  FrontArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x0 = x0; a.y1 = y1; a.xs = xs; a.g1 = gamma1; a.b1 = beta1; a.eps1 = eps1; a.mean1 = mean1; a.var1 = var1; a.rm1 = rmean1;
+  a.rv1 = rvar1; a.mom1 = mom1; a.nbt1 = nbt1; a.fc1 = fc1; a.fc2 = fc2; a.gd = gamma_d; a.bd = beta_d; a.epsd = eps_d;
+  a.meand = mean_d; a.vard = var_d; a.rmd = rmean_d; a.rvd = rvar_d; a.momd = mom_d; a.nbtd = nbt_d; a.u = u; a.amax = amax;
+  a.z = z; a.zn = zn; a.B = B; a.C = C; a.HW = HW;
+  return cfam_front_launch<T>(a, false, stream);
+}
+template <typename T>
+static int cfam_front_bwd_acc_impl(const T* g_xs, const T* g_y1, const T* g_tap, const T* x0, T* dx0, const float* gamma1,
+                                   const float* beta1, float eps1, const float* mean1, const float* var1, const float* fc1,
+                                   const float* fc2, const float* gamma_d, float eps_d, const float* mean_d, const float* var_d,
+                                   const float* u, const int* amax, const float* z, const float* zn, float* dgamma1_acc,
+                                   float* dbeta1_acc, float* dfc1_acc, float* dfc2_acc, float* dgamma_d_acc, float* dbeta_d_acc,
+                                   int B, int C, int HW, hipStream_t stream) {
+  if (!g_xs || !x0 || !dx0 || !gamma1 || !beta1 || !mean1 || !var1 || !fc1 || !fc2 || !u || !amax || !z || !zn || !dgamma1_acc ||
+      !dbeta1_acc || !dfc1_acc || !dfc2_acc || B <= 0 || C <= 0 || HW <= 0 ||
+      (gamma_d && (!mean_d || !var_d || !dgamma_d_acc || !dbeta_d_acc)))
+    return CENET_EINVAL;
+  FrontArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g_xs = g_xs; a.g_y1 = g_y1; a.g_tap = g_tap; a.x0 = x0; a.dx0 = dx0; a.g1 = gamma1; a.b1 = beta1; a.eps1 = eps1;
+  a.mean1 = (float*)mean1; a.var1 = (float*)var1; a.fc1 = fc1; a.fc2 = fc2; a.gd = gamma_d; a.epsd = eps_d;
+  a.meand = (float*)mean_d; a.vard = (float*)var_d; a.u = (float*)u; a.amax = (int*)amax; a.z = (float*)z; a.zn = (float*)zn;
+  a.dg1 = dgamma1_acc; a.db1 = dbeta1_acc; a.dfc1 = dfc1_acc; a.dfc2 = dfc2_acc; a.dgd = dgamma_d_acc; a.dbd = dbeta_d_acc;
+  a.B = B; a.C = C; a.HW = HW;
+  return cfam_front_launch<T>(a, true, stream);
+}
+
 constexpr int EUCB_SM_SMALL = 48 * 1024, EUCB_SM_LARGE = 152 * 1024;
 
 // images per group of the backward's LDS gradient planes (0: does not fit)
 template <typename T>
 static inline int eucb_bwd_group(int B, int H, int W, int sm) {
-  const long xs = (((long)B * (H + 2) * (W + 2) * sizeof(T)) + 15) & ~15L;
+  const long xs = (((long)B * (H + 2) * (W + 2) * 4) + 15) & ~15L;  // (LDS planes are fp32 for every tensor type)
   const long plane = 4L * (2 * H + 2) * (2 * W + 2);
   long G = (sm - xs) / plane;
   if (G > B) G = B;
@@ -879,7 +1341,7 @@ static int eucb_fwd_impl(const T* x, long sxb, const float* w, const float* gamm
                          T* y, long syb, float* mean, float* var, float* rmean, float* rvar, float momentum, long* nbt, int B,
                          int C, int H, int W, hipStream_t stream) {
   if (!x || !w || !gamma || !beta || !y || !mean || !var || B <= 0 || C <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
-  const long need = (long)B * (H + 2) * (W + 2) * sizeof(T);
+  const long need = (long)B * (H + 2) * (W + 2) * 4;
   if (need > EUCB_SM_LARGE || (syb & 1) || (((uintptr_t)y) & 7)) return CENET_EUNSUPPORTED;
   EucbArgs a;
   a.x = x; a.sxb = sxb; a.y = y; a.syb = syb; a.g = nullptr; a.sgb = 0; a.w = w; a.gamma = gamma; a.beta = beta; a.eps = eps;
@@ -920,7 +1382,7 @@ static int eucb_bwd_acc_impl(const T* g, long sgb, const T* x, long sxb, const f
 /* does the fused EUCB front (forward AND backward) take this shape?  esize = 2 (bf16) / 4 (fp32) */
 extern "C" int cenet_eucb_supported(int B, int H, int W, int esize) {
   if (B <= 0 || H <= 0 || W <= 0 || (esize != 2 && esize != 4)) return 0;
-  const long need = (long)B * (H + 2) * (W + 2) * esize;
+  const long need = (long)B * (H + 2) * (W + 2) * 4;
   if (need > EUCB_SM_LARGE) return 0;
   return (esize == 2 ? eucb_bwd_group<bf16_t>(B, H, W, EUCB_SM_LARGE) : eucb_bwd_group<float>(B, H, W, EUCB_SM_LARGE)) >= 1;
 }
@@ -936,7 +1398,10 @@ CENET_TWIN(eucb_bwd_acc, (const T* g, long sgb, const T* x, long sxb, const floa
            (g, sgb, x, sxb, w, gamma, beta, eps, slope, mean, var, dx, sdb, dw_acc, dgamma_acc, dbeta_acc, B, C, H, W, stream))
 
 /* a channel over the batch (B * HW elements) is small enough for the channel-local chains */
-extern "C" int cenet_chanloc_supported(int B, int HW) { return (long)B * HW >= 2 && (long)B * HW <= CENET_CHANLOC_MAX; }
+extern "C" int cenet_chanloc_supported(int B, int HW) {
+  int nt = 0;
+  return B > 0 && HW > 0 && (long)B * HW >= 2 && (long)B * HW <= 8192 && own_pick(B, HW, 8, &nt) > 0;
+}
 
 CENET_TWIN(cfam_mid_fwd, (const T* p_raw, const T* m, const T* x0, T* x1, T* y2, const float* gamma_p, const float* beta_p,
                           float eps_p, float* mean_p, float* var_p, float* rmean_p, float* rvar_p, float mom_p, long* nbt_p,
@@ -960,7 +1425,23 @@ CENET_TWIN(dwbn_fwd, (const T* x, long sxb, const float* const* w, const int* di
             num_batches_tracked, B, H, W, stream))
 CENET_TWIN(dwbn_bwd_acc, (const T* g_v, long sgb, const T* g_rest, long srb, const T* g_add, long sab, const T* x, long sxb,
                           const float* const* w, const int* dil, int nb, int g, int p, const float* gamma, const float* beta,
-                          float eps, const float* mean, const float* var, T* dx, long sdb, float* du_ws, float* const* dw_acc,
+                          float eps, const float* mean, const float* var, T* dx, long sdb, float* const* dw_acc,
                           float* dgamma_acc, float* dbeta_acc, int B, int H, int W, hipStream_t stream),
-           (g_v, sgb, g_rest, srb, g_add, sab, x, sxb, w, dil, nb, g, p, gamma, beta, eps, mean, var, dx, sdb, du_ws, dw_acc,
+           (g_v, sgb, g_rest, srb, g_add, sab, x, sxb, w, dil, nb, g, p, gamma, beta, eps, mean, var, dx, sdb, dw_acc,
             dgamma_acc, dbeta_acc, B, H, W, stream))
+
+CENET_TWIN(cfam_front_fwd, (const T* x0, T* y1, T* xs, const float* gamma1, const float* beta1, float eps1, float* mean1,
+                            float* var1, float* rmean1, float* rvar1, float mom1, long* nbt1, const float* fc1, const float* fc2,
+                            const float* gamma_d, const float* beta_d, float eps_d, float* mean_d, float* var_d, float* rmean_d,
+                            float* rvar_d, float mom_d, long* nbt_d, float* u, int* amax, float* z, float* zn, int B, int C, int HW,
+                            hipStream_t stream),
+           (x0, y1, xs, gamma1, beta1, eps1, mean1, var1, rmean1, rvar1, mom1, nbt1, fc1, fc2, gamma_d, beta_d, eps_d, mean_d,
+            var_d, rmean_d, rvar_d, mom_d, nbt_d, u, amax, z, zn, B, C, HW, stream))
+CENET_TWIN(cfam_front_bwd_acc, (const T* g_xs, const T* g_y1, const T* g_tap, const T* x0, T* dx0, const float* gamma1,
+                                const float* beta1, float eps1, const float* mean1, const float* var1, const float* fc1,
+                                const float* fc2, const float* gamma_d, float eps_d, const float* mean_d, const float* var_d,
+                                const float* u, const int* amax, const float* z, const float* zn, float* dgamma1_acc,
+                                float* dbeta1_acc, float* dfc1_acc, float* dfc2_acc, float* dgamma_d_acc, float* dbeta_d_acc, int B,
+                                int C, int HW, hipStream_t stream),
+           (g_xs, g_y1, g_tap, x0, dx0, gamma1, beta1, eps1, mean1, var1, fc1, fc2, gamma_d, eps_d, mean_d, var_d, u, amax, z, zn,
+            dgamma1_acc, dbeta1_acc, dfc1_acc, dfc2_acc, dgamma_d_acc, dbeta_d_acc, B, C, HW, stream))

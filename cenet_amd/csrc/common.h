@@ -238,6 +238,64 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- wave reductions on the DPP path (round 5) -------------------------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute_b32: an LDS-crossbar round trip (~60 - 100 cycles) per step, six dependent steps per wave
+// reduction.  Data-parallel-primitive moves (quad_perm / row_shr / row_bcast modifiers on an ordinary VALU instruction) cost an
+// issue slot each: a full 64-lane reduction is six VALU instructions, result in lane 63, broadcast with one v_readlane.  Lanes
+// whose source lies outside the row (or is masked) keep `old` = the reduction's identity.  EVERY lane of the wave must be active.
+#ifdef CENET_HOSTSIM_BUILD
+__device__ __forceinline__ float wave_sum_dpp(float v) { return wave_sum(v); }
+__device__ __forceinline__ float wave_max_dpp(float v) { return wave_max(v); }
+__device__ __forceinline__ int wave_min_i_dpp(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(v, o);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+#else
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                                               ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_f<0xb1, 0xf>(0.f, v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_f<0x4e, 0xf>(0.f, v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_f<0x114, 0xf>(0.f, v);  // row_shr 4
+  v += dpp_f<0x118, 0xf>(0.f, v);  // row_shr 8   -> lanes 12 .. 15 of a row hold the row's sum
+  v += dpp_f<0x142, 0xa>(0.f, v);  // row_bcast 15 into rows 1 and 3
+  v += dpp_f<0x143, 0xc>(0.f, v);  // row_bcast 31 into rows 2 and 3 -> lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  const float I = -3.4028235e38f;
+  v = fmaxf(v, dpp_f<0xb1, 0xf>(I, v));
+  v = fmaxf(v, dpp_f<0x4e, 0xf>(I, v));
+  v = fmaxf(v, dpp_f<0x114, 0xf>(I, v));
+  v = fmaxf(v, dpp_f<0x118, 0xf>(I, v));
+  v = fmaxf(v, dpp_f<0x142, 0xa>(I, v));
+  v = fmaxf(v, dpp_f<0x143, 0xc>(I, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_min_i_dpp(int v) {
+  const int I = 0x7fffffff;
+  int t;
+  t = dpp_i<0xb1, 0xf>(I, v); v = t < v ? t : v;
+  t = dpp_i<0x4e, 0xf>(I, v); v = t < v ? t : v;
+  t = dpp_i<0x114, 0xf>(I, v); v = t < v ? t : v;
+  t = dpp_i<0x118, 0xf>(I, v); v = t < v ? t : v;
+  t = dpp_i<0x142, 0xa>(I, v); v = t < v ? t : v;
+  t = dpp_i<0x143, 0xc>(I, v); v = t < v ? t : v;
+  return __builtin_amdgcn_readlane(v, 63);
+}
+#endif
+
 // Block-wide sum over blockDim.x threads (multiple of 64, <= 1024). `red` is >= 16 floats of LDS.
 // Every thread must call; result broadcast to all threads.
 __device__ __forceinline__ float block_sum(float v, float* red) {

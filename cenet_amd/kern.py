@@ -520,12 +520,26 @@ def dwbn_fwd(x, ws, dils, g, p, v, rest, gamma, beta, eps, mean, var, rmean, rva
           g, p, v, L(nb * g * H * W), rest, L(p * H * W), gamma, beta, float(eps), mean, var, rmean, rvar, float(momentum), nbt, B, H, W)
 
 
-def dwbn_bwd(g_v, g_rest, x, ws, dils, g, p, gamma, beta, eps, mean, var, dx, du_ws, dws, dgamma, dbeta, B, H, W):
-    _chk(g_v, g_rest, x, dx, du_ws, dgamma, dbeta, *ws, *dws)
+def dwbn_bwd(g_v, g_rest, x, ws, dils, g, p, gamma, beta, eps, mean, var, dx, dws, dgamma, dbeta, B, H, W):
+    _chk(g_v, g_rest, x, dx, dgamma, dbeta, *ws, *dws)
     nb, Ct = len(ws), len(ws) * g + p
     _call("cenet_dwbn_bwd_acc_f32", g_v, L(nb * g * H * W), g_rest, L(p * H * W), None, L(0), x, L(Ct * H * W),
           _ptr_arr([w.data_ptr() for w in ws]), (C.c_int * nb)(*[int(d) for d in dils]), nb, g, p, gamma, beta, float(eps), mean, var,
-          dx, L(Ct * H * W), du_ws, _ptr_arr([w.data_ptr() for w in dws]), dgamma, dbeta, B, H, W)
+          dx, L(Ct * H * W), _ptr_arr([w.data_ptr() for w in dws]), dgamma, dbeta, B, H, W)
+
+
+def cfam_front_fwd(x0, y1, xs, g1, b1, eps1, mean1, var1, rm1, rv1, mom1, nbt1, fc1, fc2, gd, bd, epsd, meand, vard, rmd, rvd, momd,
+                   nbtd, u, amax, z, zn, B, Cn, HW):
+    _chk(x0, y1, xs, g1, b1, mean1, var1, fc1, fc2, u, amax, z, zn)
+    _call("cenet_cfam_front_fwd_f32", x0, y1, xs, g1, b1, float(eps1), mean1, var1, rm1, rv1, float(mom1), nbt1, fc1, fc2, gd, bd,
+          float(epsd), meand, vard, rmd, rvd, float(momd), nbtd, u, amax, z, zn, B, Cn, HW)
+
+
+def cfam_front_bwd(g_xs, g_y1, g_tap, x0, dx0, g1, b1, eps1, mean1, var1, fc1, fc2, gd, epsd, meand, vard, u, amax, z, zn, dg1, db1,
+                   dfc1, dfc2, dgd, dbd, B, Cn, HW):
+    _chk(g_xs, g_y1, g_tap, x0, dx0)
+    _call("cenet_cfam_front_bwd_acc_f32", g_xs, g_y1, g_tap, x0, dx0, g1, b1, float(eps1), mean1, var1, fc1, fc2, gd, float(epsd),
+          meand, vard, u, amax, z, zn, dg1, db1, dfc1, dfc2, dgd, dbd, B, Cn, HW)
 
 
 def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0, x_off=0, y_off=0):

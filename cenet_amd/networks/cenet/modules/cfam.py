@@ -169,9 +169,13 @@ class MCA(nn.Module):
         self.denoising_module = Nonlocal(embed_dims)
         self.ccu = CCU(embed_dims)
 
-    def forward(self, x, raw=False):
-        """raw=True: (output conv of the Non-local block before its BatchNorm, the block's input) — see Nonlocal.forward"""
-        x, shortcut = self.ccu(x, True)  # (shortcut = x itself, through the CCU's autograd node: its gradient joins in that kernel)
+    def forward(self, x, raw=False, gated=None):
+        """raw=True: (output conv of the Non-local block before its BatchNorm, the block's input) — see Nonlocal.forward
+        gated: the CCU output when the caller computed it together with x (CFAModule, ops.cfam_front); x is then the shortcut"""
+        if gated is not None:
+            x, shortcut = gated, x
+        else:
+            x, shortcut = self.ccu(x, True)  # (shortcut = x itself, through the CCU's autograd node: its gradient joins there)
         g, x = ops.conv1x1(x, self.gate.weight, self.gate.bias, tap=True)  # value's gradient joins inside gate's dgrad GEMM
         v = self.value(x)
         x = ops.conv1x1(ops.silu_mul(g, v), self.proj_2.weight, self.proj_2.bias, resid=shortcut)
@@ -197,15 +201,19 @@ class CFAModule(nn.Module):
     def forward(self, x):
         # (taps: the residual connection reads x through the BatchNorm's autograd node, whose backward kernel then writes the sum
         # of both gradients of x — no aten::add behind it)
-        y, x = bn_call(self.norm1, x, tap=True)
+        gated = None
+        if ops.cfam_front_supported(x, self.norm1, self.mca.ccu):
+            y, gated, x = ops.cfam_front(x, self.norm1, self.mca.ccu)  # norm1 + the CCU gate in one launch per pass
+        else:
+            y, x = bn_call(self.norm1, x, tap=True)
         nl = self.mca.denoising_module
         if ops.cfam_mid_supported(x, nl.bn, self.norm2):
             # small maps: BatchNorm of the Non-local output conv + residual mix + layer-scale residual + norm2 in one launch per
             # pass (csrc/chanloc.hip: workgroup = channel over the batch)
-            p_raw, m = self.mca(y, raw=True)
+            p_raw, m = self.mca(y, raw=True, gated=gated)
             x, y = ops.cfam_mid(p_raw, m, x, nl.w, self.layer_scale_1, nl.bn, self.norm2)
         else:
-            x = ops.scale_residual(x, self.mca(y), self.layer_scale_1)
+            x = ops.scale_residual(x, self.mca(y, gated=gated), self.layer_scale_1)
             y, x = bn_call(self.norm2, x, tap=True)
         x = ops.scale_residual(x, self.mlp(y), self.layer_scale_2)
         return x

@@ -1846,16 +1846,15 @@ class SplitDWBnFn(Function):
         if p > 0:
             g_rest = _c(g_rest) if g_rest is not None else kern.zero_(torch.empty((B, p, H, Wd), device=x.device, dtype=x.dtype))
         dx = torch.empty_like(x)
-        du = _empty((g * len(ws) * B * H * Wd,), x)
         dws = [_gb(wp, x) for wp in ctx.refs[2:]]
-        kern.dwbn_bwd(g_v, g_rest, x, ws, dils, g, p, gamma, beta, eps, mean, var, dx, du, dws, _gb(ctx.refs[0], x),
+        kern.dwbn_bwd(g_v, g_rest, x, ws, dils, g, p, gamma, beta, eps, mean, var, dx, dws, _gb(ctx.refs[0], x),
                       _gb(ctx.refs[1], x), B, H, Wd)
         return (dx,) + (None,) * (9 + len(ws))
 
 
 def split_dwconv_bn_supported(x, sizes, training: bool) -> bool:
     return (bool(training) and x.dim() == 4 and len(set(sizes)) == 1 and 1 <= len(sizes) <= 3
-            and kern.chanloc_supported(x.shape[0], x.shape[2] * x.shape[3]))
+            and x.shape[0] * x.shape[2] * x.shape[3] <= 8192 and kern.chanloc_supported(x.shape[0], x.shape[2] * x.shape[3]))
 
 
 def split_dwconv_bn(x, sizes, dils, ws, gamma, beta, rmean, rvar, nbt, eps, momentum):
@@ -2245,6 +2244,62 @@ def cfam_mid_supported(x, bnp, bn2) -> bool:
 def cfam_mid(p_raw, m, x0, w, ls, bnp, bn2):
     """bnp / bn2: the nn.BatchNorm2d containers (parameters, buffers, eps, momentum)"""
     return CfamMidFn.apply(p_raw, m, x0, w, ls, bnp, bn2)
+
+
+class CfamFrontFn(Function):
+    """cfam.py:366 over cfam.py:251-264: norm1 and the CCU gate as ONE launch per pass (csrc/chanloc.hip).
+    -> (y1 = BatchNorm_1(x0): the MCA shortcut, xs = CCU(y1), x0 itself as a tap for the residual around the block)"""
+
+    @staticmethod
+    def forward(ctx, x0, bn1, ccu):
+        x0 = _c(x0)
+        B, Cn, H, Wd = x0.shape
+        HW = H * Wd
+        y1, xs = torch.empty_like(x0), torch.empty_like(x0)
+        mean1, var1 = _empty((Cn,), x0), _empty((Cn,), x0)
+        u, z, zn = _empty((B, Cn, 3), x0), _empty((B, Cn), x0), _empty((B, Cn), x0)
+        amax = _empty((B, Cn), x0, torch.int32)
+        bd = ccu.bn
+        use_bn = B > 1 and not _Batch1.on
+        meand, vard = (_empty((Cn,), x0), _empty((Cn,), x0)) if use_bn else (None, None)
+        kern.cfam_front_fwd(x0, y1, xs, bn1.weight, bn1.bias, bn1.eps, mean1, var1, bn1.running_mean, bn1.running_var, _mom(bn1),
+                            bn1.num_batches_tracked, ccu.fc1.weight, ccu.fc2.weight, bd.weight if use_bn else None,
+                            bd.bias if use_bn else None, 1e-5, meand, vard, bd.running_mean if use_bn else None,
+                            bd.running_var if use_bn else None, 0.1, bd.num_batches_tracked if use_bn else None, u, amax, z, zn,
+                            B, Cn, HW)
+        ctx.save_for_backward(x0, bn1.weight, bn1.bias, mean1, var1, ccu.fc1.weight, ccu.fc2.weight, bd.weight, meand, vard, u,
+                              amax, z, zn)
+        ctx.refs = (bn1.weight, bn1.bias, ccu.fc1.weight, ccu.fc2.weight, bd.weight, bd.bias)
+        ctx.cfg = (bn1.eps, use_bn)
+        return y1, xs, x0.view_as(x0)
+
+    @staticmethod
+    def backward(ctx, g_y1, g_xs, g_tap):
+        x0, g1, b1, mean1, var1, fc1, fc2, gd, meand, vard, u, amax, z, zn = ctx.saved_tensors
+        eps1, use_bn = ctx.cfg
+        if g_xs is None:
+            raise RuntimeError("cfam_front: the gated output carried no gradient")
+        g_xs = _c(g_xs)
+        fix = lambda t: None if t is None else (_c(t) if t.dtype == g_xs.dtype else _c(t.to(g_xs.dtype)))  # noqa: E731
+        g_y1, g_tap = fix(g_y1), fix(g_tap)
+        B, Cn = x0.shape[:2]
+        HW = x0.numel() // (B * Cn)
+        dx0 = torch.empty_like(x0)
+        r = ctx.refs
+        kern.cfam_front_bwd(g_xs, g_y1, g_tap, x0, dx0, g1, b1, eps1, mean1, var1, fc1, fc2, gd if use_bn else None, 1e-5, meand,
+                            vard, u, amax, z, zn, _gb(r[0], x0), _gb(r[1], x0), _gb(r[2], x0), _gb(r[3], x0),
+                            _gb(r[4], x0) if use_bn else None, _gb(r[5], x0) if use_bn else None, B, Cn, HW)
+        return dx0, None, None
+
+
+def cfam_front_supported(x, bn1, ccu) -> bool:
+    return (bn1.training and ccu.bn.training and x.dim() == 4 and x.shape[0] <= 256
+            and kern.chanloc_supported(x.shape[0], x.shape[2] * x.shape[3]))
+
+
+def cfam_front(x0, bn1, ccu):
+    """bn1: the block's norm1 (nn.BatchNorm2d), ccu: its CCU module (fc1, fc2, bn) -> (y1, xs, x0_tap)"""
+    return CfamFrontFn.apply(x0, bn1, ccu)
 
 
 class AdaptiveAvgPoolFn(Function):

@@ -753,14 +753,14 @@ int cenet_cfam_mid_bwd_acc_bf16(const unsigned short* g_y2, const unsigned short
  * x [B, nb*g + p, H, W] (batch stride sxb), v [B, nb*g, H, W] (svb), rest [B, p, H, W] (srb); gamma / beta / mean / var / running
  * statistics cover the nb*g channels, num_batches_tracked holds nb counters (NULL: not wanted).
  * Backward: g_v, g_rest and g_add (another gradient of x, [B, nb*g + p, H, W], may be NULL) in; dx = their sum through the chain;
- * du_ws: nb*g*B*H*W floats of scratch; dw_acc[j] / dgamma / dbeta are ADDED into. */
+ * dw_acc[j] / dgamma / dbeta are ADDED into (B*H*W <= 8192: the channel's planes and gradient planes sit in LDS). */
 int cenet_dwbn_fwd_f32(const float* x, long sxb, const float* const* w, const int* dil, int nb, int g, int p, float* v, long svb,
                        float* rest, long srb, const float* gamma, const float* beta, float eps, float* mean, float* var,
                        float* running_mean, float* running_var, float momentum, long* num_batches_tracked, int B, int H, int W,
                        cenet_stream_t stream);
 int cenet_dwbn_bwd_acc_f32(const float* g_v, long sgb, const float* g_rest, long srb, const float* g_add, long sab, const float* x,
                            long sxb, const float* const* w, const int* dil, int nb, int g, int p, const float* gamma,
-                           const float* beta, float eps, const float* mean, const float* var, float* dx, long sdb, float* du_ws,
+                           const float* beta, float eps, const float* mean, const float* var, float* dx, long sdb,
                            float* const* dw_acc, float* dgamma_acc, float* dbeta_acc, int B, int H, int W, cenet_stream_t stream);
 int cenet_dwbn_fwd_bf16(const unsigned short* x, long sxb, const float* const* w, const int* dil, int nb, int g, int p,
                         unsigned short* v, long svb, unsigned short* rest, long srb, const float* gamma, const float* beta,
@@ -769,8 +769,38 @@ int cenet_dwbn_fwd_bf16(const unsigned short* x, long sxb, const float* const* w
 int cenet_dwbn_bwd_acc_bf16(const unsigned short* g_v, long sgb, const unsigned short* g_rest, long srb,
                             const unsigned short* g_add, long sab, const unsigned short* x, long sxb, const float* const* w,
                             const int* dil, int nb, int g, int p, const float* gamma, const float* beta, float eps,
-                            const float* mean, const float* var, unsigned short* dx, long sdb, float* du_ws, float* const* dw_acc,
+                            const float* mean, const float* var, unsigned short* dx, long sdb, float* const* dw_acc,
                             float* dgamma_acc, float* dbeta_acc, int B, int H, int W, cenet_stream_t stream);
+
+/* CFAM front, cfam.py:366 over cfam.py:251-264, one launch each way (workgroup = channel over the batch, one wave per image for the
+ * per-image statistics; cenet_chanloc_supported(B, HW), B <= 256):  y1 = BatchNorm_1(x0);  u[b, c] = [max, mean, biased std] of
+ * y1[b, c];  z = fc2 . relu(fc1 u) (fc1 [C][3][3], fc2 [C][3]);  zn = BatchNorm1d_train(z) over the batch (gamma_d == NULL: zn = z,
+ * the reference's batch-of-one rule);  xs = y1 * sigmoid(zn).  All tensors [B, C, HW] contiguous; u [B, C, 3], amax / z / zn
+ * [B, C] are saved for the backward pass.  Backward: g_xs (gradient of xs), g_y1 (of y1: the MCA shortcut; may be NULL), g_tap (of
+ * x0 itself: the residual around the block; may be NULL) in, dx0 out; parameter gradients ADDED into. */
+int cenet_cfam_front_fwd_f32(const float* x0, float* y1, float* xs, const float* gamma1, const float* beta1, float eps1,
+                             float* mean1, float* var1, float* rmean1, float* rvar1, float mom1, long* nbt1, const float* fc1,
+                             const float* fc2, const float* gamma_d, const float* beta_d, float eps_d, float* mean_d, float* var_d,
+                             float* rmean_d, float* rvar_d, float mom_d, long* nbt_d, float* u, int* amax, float* z, float* zn,
+                             int B, int C, int HW, cenet_stream_t stream);
+int cenet_cfam_front_bwd_acc_f32(const float* g_xs, const float* g_y1, const float* g_tap, const float* x0, float* dx0,
+                                 const float* gamma1, const float* beta1, float eps1, const float* mean1, const float* var1,
+                                 const float* fc1, const float* fc2, const float* gamma_d, float eps_d, const float* mean_d,
+                                 const float* var_d, const float* u, const int* amax, const float* z, const float* zn,
+                                 float* dgamma1_acc, float* dbeta1_acc, float* dfc1_acc, float* dfc2_acc, float* dgamma_d_acc,
+                                 float* dbeta_d_acc, int B, int C, int HW, cenet_stream_t stream);
+int cenet_cfam_front_fwd_bf16(const unsigned short* x0, unsigned short* y1, unsigned short* xs, const float* gamma1,
+                              const float* beta1, float eps1, float* mean1, float* var1, float* rmean1, float* rvar1, float mom1,
+                              long* nbt1, const float* fc1, const float* fc2, const float* gamma_d, const float* beta_d,
+                              float eps_d, float* mean_d, float* var_d, float* rmean_d, float* rvar_d, float mom_d, long* nbt_d,
+                              float* u, int* amax, float* z, float* zn, int B, int C, int HW, cenet_stream_t stream);
+int cenet_cfam_front_bwd_acc_bf16(const unsigned short* g_xs, const unsigned short* g_y1, const unsigned short* g_tap,
+                                  const unsigned short* x0, unsigned short* dx0, const float* gamma1, const float* beta1,
+                                  float eps1, const float* mean1, const float* var1, const float* fc1, const float* fc2,
+                                  const float* gamma_d, float eps_d, const float* mean_d, const float* var_d, const float* u,
+                                  const int* amax, const float* z, const float* zn, float* dgamma1_acc, float* dbeta1_acc,
+                                  float* dfc1_acc, float* dfc2_acc, float* dgamma_d_acc, float* dbeta_d_acc, int B, int C, int HW,
+                                  cenet_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -123,12 +123,12 @@ def _run_cfam(dev, dt, dims, hw, B, fused, monkeypatch, rates=(1, 2, 3)):
     return out
 
 
-@pytest.mark.parametrize("dims,hw,B", [(32, 7, 3), (32, 14, 2), (48, 28, 2)])
+@pytest.mark.parametrize("dims,hw,B", [(32, 7, 3), (32, 14, 2), (48, 16, 5)])
 @pytest.mark.parametrize("dt", [torch.float32, BF], ids=["f32", "bf16"])
 def test_cfam_block_fused_chains_equal_the_launch_chains(dev, dt, dims, hw, B, monkeypatch):
     """the whole CFAM block with every channel-local chain on against the same block on the unfused launch chains"""
     calls = []
-    fused_entries = ("cfam_mid_fwd", "cfam_mid_bwd", "dwbn_fwd", "dwbn_bwd")
+    fused_entries = ("cfam_mid_fwd", "cfam_mid_bwd", "dwbn_fwd", "dwbn_bwd", "cfam_front_fwd", "cfam_front_bwd")
     for name in fused_entries:
         orig = getattr(kern, name)
         monkeypatch.setattr(kern, name, lambda *a, _o=orig, _n=name, **k: (calls.append(_n), _o(*a, **k))[1])
