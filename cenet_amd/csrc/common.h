@@ -227,12 +227,13 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // activation ids shared by several kernels
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_GELU = 3, ACT_SILU = 4, ACT_SIGMOID = 5 };
 
-__device__ __forceinline__ float wave_sum(float v) {
+// the shuffle-tree forms (the host checker's, and the reference the DPP forms below are tested against)
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
+__device__ __forceinline__ float wave_max_shfl(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
@@ -244,8 +245,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // issue slot each: a full 64-lane reduction is six VALU instructions, result in lane 63, broadcast with one v_readlane.  Lanes
 // whose source lies outside the row (or is masked) keep `old` = the reduction's identity.  EVERY lane of the wave must be active.
 #ifdef CENET_HOSTSIM_BUILD
-__device__ __forceinline__ float wave_sum_dpp(float v) { return wave_sum(v); }
-__device__ __forceinline__ float wave_max_dpp(float v) { return wave_max(v); }
+__device__ __forceinline__ float wave_sum_dpp(float v) { return wave_sum_shfl(v); }
+__device__ __forceinline__ float wave_max_dpp(float v) { return wave_max_shfl(v); }
 __device__ __forceinline__ int wave_min_i_dpp(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -295,6 +296,10 @@ __device__ __forceinline__ int wave_min_i_dpp(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 #endif
+
+// wave_sum / wave_max of every kernel: the DPP forms (every call site runs with all 64 lanes of the wave active)
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
 
 // Block-wide sum over blockDim.x threads (multiple of 64, <= 1024). `red` is >= 16 floats of LDS.
 // Every thread must call; result broadcast to all threads.

@@ -119,7 +119,9 @@ def test_fp32_protocol_matches_the_fused_path_and_the_oracle():
         fused.append(loss.item())
     ref = _oracle_trajectory(sd, x, lab)
     for i, (a, b, c) in enumerate(zip(got, fused, ref)):
-        assert abs(a - b) < 2e-5, (got, fused)
+        # (round 5: with a ParamArena the small decoder levels run the channel-local fused chains, without one the launch chains —
+        # the same arithmetic in a different summation order, which the updates amplify like any other fp32 round-off)
+        assert abs(a - b) < (2e-5 if i == 0 else 1e-4), (got, fused)
         # first iteration: the north-star bound on the loss; later iterations compare two fp32 TRAINING trajectories, whose
         # rounding differences the updates amplify (random-filled weights, batch 2: 8e-5 after one update at lr 0.05)
         assert abs(a - c) < (2e-4 if i == 0 else 5e-4), (got, ref)
