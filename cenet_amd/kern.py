@@ -542,6 +542,21 @@ def cfam_front_bwd(g_xs, g_y1, g_tap, x0, dx0, g1, b1, eps1, mean1, var1, fc1, f
           meand, vard, u, amax, z, zn, dg1, db1, dfc1, dfc2, dgd, dbd, B, Cn, HW)
 
 
+def dwact_supported(x) -> bool:
+    B, _, H, W = x.shape
+    return B * H * W <= 8192 and chanloc_supported(B, H * W)
+
+
+def dwact_fwd(x, w, bias, y, act, slope, dil, B, Cn, H, W):
+    _chk(x, w, bias, y)
+    _call("cenet_dwact_fwd_f32", x, w, bias, y, ACT[act], float(slope), dil, B, Cn, H, W)
+
+
+def dwact_bwd(g, x, w, bias, dx, dw, db, act, slope, dil, B, Cn, H, W):
+    _chk(g, x, w, bias, dx, dw, db)
+    _call("cenet_dwact_bwd_acc_f32", g, x, w, bias, dx, dw, db, ACT[act], float(slope), dil, B, Cn, H, W)
+
+
 def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0, x_off=0, y_off=0):
     """x_off / y_off (elements): read / write a channel slice of a wider tensor in place (batch strides sxb / syb)"""
     _chk(x, w, bias, y, a)

@@ -1189,11 +1189,40 @@ class DWConvNCHWFn(Function):
         return dx, None, None, None, None
 
 
+class DWActFn(Function):
+    """cfam.py:150-151: act(DW3x3(x) + bias) as ONE launch per pass at the small decoder levels (csrc/chanloc.hip: workgroup =
+    channel over the batch); the pre-activation is recomputed in the backward pass instead of stored."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dil, act):
+        x = _c(x)
+        B, Cn, H, Wd = x.shape
+        y = torch.empty_like(x)
+        kern.dwact_fwd(x, w, b, y, act, 0.0, dil, B, Cn, H, Wd)
+        ctx.save_for_backward(x, w, b)
+        ctx.refs = (w, b)
+        ctx.cfg = (dil, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, b = ctx.saved_tensors
+        wp, bp = ctx.refs
+        dil, act = ctx.cfg
+        g = _c(g)
+        B, Cn, H, Wd = x.shape
+        dx = torch.empty_like(x)
+        kern.dwact_bwd(g, x, w, b, dx, _gb(wp, x), grad_buf(bp), act, 0.0, dil, B, Cn, H, Wd)
+        return dx, None, None, None, None
+
+
 def dwconv_tok(x, w, b, H, Wd, act="none"):
     return DWConvTokFn.apply(x, w, b, H, Wd, act)
 
 
 def dwconv_nchw(x, w, b=None, dil=1, act="none"):
+    if act != "none" and x.dim() == 4 and torch.is_grad_enabled() and kern.dwact_supported(x):
+        return DWActFn.apply(x, w, b, dil, act)
     return DWConvNCHWFn.apply(x, w, b, dil, act)
 
 

@@ -802,6 +802,20 @@ int cenet_cfam_front_bwd_acc_bf16(const unsigned short* g_xs, const unsigned sho
                                   float* dfc1_acc, float* dfc2_acc, float* dgamma_d_acc, float* dbeta_d_acc, int B, int C, int HW,
                                   cenet_stream_t stream);
 
+/* Depthwise 3x3 (+bias) + activation with NO BatchNorm, cfam.py:150-151 (the CFAM Mlp's conv + GELU), one launch each way
+ * (workgroup = channel over the batch, B*H*W <= 8192 and cenet_chanloc_supported(B, H*W)): y = act(DW3x3_dil(x) + bias); x, y
+ * [B, C, H, W] contiguous, w [C][9], bias [C] or NULL.  The pre-activation is not stored; backward recomputes it from x and
+ * writes dx; dw / dbias (may be NULL) are ADDED into. */
+int cenet_dwact_fwd_f32(const float* x, const float* w, const float* bias, float* y, int act, float slope, int dil, int B, int C,
+                        int H, int W, cenet_stream_t stream);
+int cenet_dwact_bwd_acc_f32(const float* g, const float* x, const float* w, const float* bias, float* dx, float* dw_acc,
+                            float* dbias_acc, int act, float slope, int dil, int B, int C, int H, int W, cenet_stream_t stream);
+int cenet_dwact_fwd_bf16(const unsigned short* x, const float* w, const float* bias, unsigned short* y, int act, float slope,
+                         int dil, int B, int C, int H, int W, cenet_stream_t stream);
+int cenet_dwact_bwd_acc_bf16(const unsigned short* g, const unsigned short* x, const float* w, const float* bias,
+                             unsigned short* dx, float* dw_acc, float* dbias_acc, int act, float slope, int dil, int B, int C,
+                             int H, int W, cenet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,7 +128,8 @@ def _run_cfam(dev, dt, dims, hw, B, fused, monkeypatch, rates=(1, 2, 3)):
 def test_cfam_block_fused_chains_equal_the_launch_chains(dev, dt, dims, hw, B, monkeypatch):
     """the whole CFAM block with every channel-local chain on against the same block on the unfused launch chains"""
     calls = []
-    fused_entries = ("cfam_mid_fwd", "cfam_mid_bwd", "dwbn_fwd", "dwbn_bwd", "cfam_front_fwd", "cfam_front_bwd")
+    fused_entries = ("cfam_mid_fwd", "cfam_mid_bwd", "dwbn_fwd", "dwbn_bwd", "cfam_front_fwd", "cfam_front_bwd", "dwact_fwd",
+                     "dwact_bwd")
     for name in fused_entries:
         orig = getattr(kern, name)
         monkeypatch.setattr(kern, name, lambda *a, _o=orig, _n=name, **k: (calls.append(_n), _o(*a, **k))[1])
@@ -154,3 +155,29 @@ def test_cfam_block_fused_chains_equal_the_launch_chains(dev, dt, dims, hw, B, m
         else:
             d = (got[k] - ref[k]).norm().item()
             assert d < 1e-4 * ref[k].norm().item() + 5e-5 * ref[k].numel() ** 0.5, (k, d, ref[k].norm().item())
+
+
+@pytest.mark.parametrize("shape,dil", [((3, 8, 7, 7), 1), ((2, 5, 14, 14), 1), ((5, 3, 9, 6), 2), ((32, 2, 7, 7), 1)])
+@pytest.mark.parametrize("dt", [torch.float32, BF], ids=["f32", "bf16"])
+def test_dw_gelu_fused_equals_the_launch_chain(dev, shape, dil, dt, monkeypatch):
+    """cfam.py:150-151 conv + bias + GELU: one launch per pass against conv / activation-backward / data- and weight-gradient"""
+    B, Cn, H, W = shape
+    g = torch.Generator().manual_seed(H * 10 + B)
+    x0 = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    cot = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(kern, "_NO_CHANLOC", not fused)
+        x = x0.clone().requires_grad_(True)
+        gg = torch.Generator().manual_seed(7)
+        w = (0.3 * torch.randn(Cn, 1, 3, 3, generator=gg)).to(dev).requires_grad_(True)
+        b = (0.2 * torch.randn(Cn, generator=gg)).to(dev).requires_grad_(True)
+        w.grad, b.grad = torch.zeros_like(w), torch.zeros_like(b)
+        y = ops.dwconv_nchw(x, w, b, dil=dil, act="gelu")
+        assert isinstance(y.grad_fn, torch.autograd.function.BackwardCFunction) and (type(y.grad_fn).__name__.startswith("DWAct") == fused)
+        y.backward(cot)
+        ops.wgrad_join()
+        res.append((y.detach(), x.grad, w.grad, b.grad))
+    tol = 2e-2 if dt == BF else 2e-5
+    for k, name in enumerate(("y", "dx", "dw", "db")):
+        assert _rel(res[1][k], res[0][k]) < tol, (name, _rel(res[1][k], res[0][k]))
