@@ -28,7 +28,7 @@ import torch.nn as nn  # noqa: E402
 
 sys.path.insert(0, ROOT)
 from oracle import cenet_oracle as O  # noqa: E402
-from oracle.golden_cases import CASES, MODEL_CONFIGS  # noqa: E402
+from oracle.golden_cases import CASES, MODEL_CONFIGS, NONFINITE_CASE  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -96,6 +96,33 @@ def gen_module_cases(only_case=None):
             rec["after." + k] = b.detach().numpy()
         np.savez_compressed(os.path.join(OUT, f"mod_{c['name']}.npz"), **rec)
         print(f"[golden] {c['name']}: out {tuple(out.shape)}  {sum(v.nbytes for v in rec.values()) / 1024:.0f} KiB raw")
+
+
+def gen_nonfinite_case():
+    """multihead_diffattn.py:106 (nan_to_num of the scores): eval forward of the reference on inputs whose scores overflow"""
+    c = NONFINITE_CASE
+    modname, clsname, kw = c["ref"]
+    cls = getattr(importlib.import_module(modname), clsname)
+    torch.manual_seed(c["seed"])
+    m = cls(**kw)
+    O.fill_state_dict_(m.state_dict(), seed=c["seed"] + 1)
+    with torch.no_grad():
+        m.q_proj.weight.mul_(c["wscale"])
+        m.k_proj.weight.mul_(c["wscale"])
+    g = torch.Generator().manual_seed(c["seed"] + 2)
+    x = torch.randn(c["inputs"][0], generator=g)
+    m.eval()
+    with torch.no_grad():
+        q = torch.nn.functional.linear(x, m.q_proj.weight)
+        k = torch.nn.functional.linear(x, m.k_proj.weight)
+        assert not torch.isfinite(q @ k.transpose(-1, -2)).all(), "the case is meant to overflow the scores"
+        out = m(x)
+    assert torch.isfinite(out).all(), "the reference's forward is finite on this input"
+    rec = {"sd." + k_: v.detach().clone().numpy() for k_, v in m.state_dict().items()}
+    rec["in0"] = x.numpy()
+    rec["out_eval"] = out.numpy()
+    np.savez_compressed(os.path.join(OUT, f"mod_{c['name']}.npz"), **rec)
+    print(f"[golden] {c['name']}: finite output, max |out| {out.abs().max().item():.3g}")
 
 
 def gen_loss_cases(core):
@@ -194,13 +221,15 @@ def gen_model_cases(core):
 def main():
     os.makedirs(OUT, exist_ok=True)
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="all", choices=["all", "modules", "loss", "models"])
+    ap.add_argument("--only", default="all", choices=["all", "modules", "loss", "models", "nonfinite"])
     ap.add_argument("--case", action="append", help="module cases to (re)generate (default: all)")
     a = ap.parse_args()
     torch.set_num_threads(8)
     core = load_reference_losses()
     if a.only in ("all", "modules"):
         gen_module_cases(a.case)
+    if a.only in ("all", "nonfinite"):
+        gen_nonfinite_case()
     if a.only in ("all", "loss"):
         gen_loss_cases(core)
     if a.only in ("all", "models"):

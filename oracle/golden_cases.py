@@ -118,7 +118,23 @@ CASES = [
           [(2, 32, 14, 14)], lambda sd, ins, tr: O.mca(sd, P, ins[0], (1, 2, 3), tr)),
     _case("mca_7", ("networks.cenet.modules.cfam", "MCA", dict(embed_dims=16, rates=[1, 2, 2])),
           [(3, 16, 7, 7)], lambda sd, ins, tr: O.mca(sd, P, ins[0], (1, 2, 2), tr)),
+    # ---- appended in round 5: SURVEY G1's two remaining MultiheadDiffAttn head dimensions (16: the 56x56 level of the ACDC
+    # preset and 14x14 of Synapse; 80: ACDC 14x14 — until now pinned only through the whole-model goldens) ----
+    _case("diffattn_hd16", ("networks.cenet.modules.multihead_diffattn", "MultiheadDiffAttn",
+                            dict(embed_dim=64, depth=2, num_heads=2)),
+          [(2, 49, 64)], lambda sd, ins, tr: O.multihead_diff_attn(sd, P, ins[0], 2, 2)),
+    _case("diffattn_hd80", ("networks.cenet.modules.multihead_diffattn", "MultiheadDiffAttn",
+                            dict(embed_dim=160, depth=4, num_heads=1)),
+          [(1, 36, 160)], lambda sd, ins, tr: O.multihead_diff_attn(sd, P, ins[0], 1, 4)),
 ]
+
+# multihead_diffattn.py:106 applies torch.nan_to_num to the scores.  A case whose q.k products overflow fp32 (q_proj / k_proj
+# weights scaled by `wscale`, inputs and values ordinary): the reference's forward stays finite and non-trivial; eval output only
+# (its gradients are meaningless).  Generated by gen_golden.gen_nonfinite_case.
+NONFINITE_CASE = dict(name="diffattn_nonfinite", ref=("networks.cenet.modules.multihead_diffattn", "MultiheadDiffAttn",
+                                                      dict(embed_dim=32, depth=2, num_heads=2)),
+                      inputs=[(1, 12, 32)], wscale=1e19, seed=4242,
+                      oracle=lambda sd, ins, tr: O.multihead_diff_attn(sd, P, ins[0], 2, 2))
 
 CASE_BY_NAME = {c["name"]: c for c in CASES}
 

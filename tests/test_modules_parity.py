@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from backend import dev  # noqa: F401
-from oracle.golden_cases import CASES
+from oracle.golden_cases import CASES, NONFINITE_CASE
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -80,3 +80,29 @@ def test_module_parity(dev, case):
             close(g, z[k], rtol=2e-3, atol=loose, what=k)
         if k.startswith("after."):
             close(bufs[k[6:]].float(), z[k].astype(np.float32), rtol=1e-4, atol=1e-5, what=k)
+
+
+def test_nonfinite_scores_propagate(dev):
+    """multihead_diffattn.py:106 (torch.nan_to_num of the scores) is NOT reproduced by the product: the attention kernels never
+    materialise the score matrix, and a q.k product that overflows fp32 is outside the supported input domain (INTEGRATION.md,
+    "Non-finite attention scores").  What the product guarantees instead is that it does not hide it: on the reference-made case
+    whose scores are +-inf / NaN (tests/golden/mod_diffattn_nonfinite.npz, where the reference itself returns finite values) the
+    product's output is non-finite — in both storage modes — so the loss and every check downstream see it."""
+    from cenet_amd import kern
+    z = np.load(os.path.join(GOLDEN, f"mod_{NONFINITE_CASE['name']}.npz"))
+    m = build_product(NONFINITE_CASE, dev)
+    sd = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    x = torch.from_numpy(z["in0"]).to(dev)
+    assert np.isfinite(z["out_eval"]).all()
+    with torch.no_grad():
+        out = m(x)
+    assert not torch.isfinite(out.float()).all()
+    old = kern.set_compute_bf16(True)
+    try:
+        with torch.no_grad():
+            out_b = m(x.to(torch.bfloat16))
+    finally:
+        kern.set_compute_bf16(old)
+    assert not torch.isfinite(out_b.float()).all()

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import cenet_oracle as O
-from oracle.golden_cases import CASES, MODEL_CONFIGS, config_from_kwargs
+from oracle.golden_cases import CASES, MODEL_CONFIGS, NONFINITE_CASE, config_from_kwargs
 from oracle.gen_golden_keys import PROBE_BUFFERS, PROBE_KEYS
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -46,6 +46,25 @@ def test_module_golden(case):
             np.testing.assert_allclose(g.numpy(), ref, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
         if k.startswith("after."):
             np.testing.assert_allclose(sd_t["m." + k[6:]].detach().numpy(), z[k], rtol=1e-4, atol=1e-6)
+
+
+def test_nonfinite_scores_golden():
+    """multihead_diffattn.py:106: the reference passes the scores through torch.nan_to_num, so a forward whose q.k products
+    overflow fp32 stays finite.  The oracle restates that line; pinned on a case generated from the reference with q_proj / k_proj
+    scaled until the scores are +-inf / NaN (oracle/gen_golden.py gen_nonfinite_case).  Without the nan_to_num the same forward is
+    NaN — asserted too, so the case really exercises the line."""
+    z, sd, ins = load_case(NONFINITE_CASE["name"])
+    q = torch.nn.functional.linear(ins[0], sd["m.q_proj.weight"])
+    k = torch.nn.functional.linear(ins[0], sd["m.k_proj.weight"])
+    assert not torch.isfinite(q @ k.transpose(-1, -2)).all()
+    with torch.no_grad():
+        out = NONFINITE_CASE["oracle"]({k_: v.clone() for k_, v in sd.items()}, ins, False)
+    assert torch.isfinite(out).all()
+    np.testing.assert_allclose(out.numpy(), z["out_eval"], **TOL)
+    import unittest.mock as mock
+    with mock.patch.object(torch, "nan_to_num", lambda t, *a, **kw: t), torch.no_grad():
+        raw = NONFINITE_CASE["oracle"]({k_: v.clone() for k_, v in sd.items()}, ins, False)
+    assert not torch.isfinite(raw).all()
 
 
 def test_loss_golden():
