@@ -1466,6 +1466,265 @@ static int cfam_front_bwd_acc_impl(const T* g_xs, const T* g_y1, const T* g_tap,
   return cfam_front_launch<T>(a, true, stream);
 }
 
+// ---- pooled branch of MultiOrderDWConv (cfam.py:212-218,231-232) ------------------------------------------------------------------
+//   pooled = AdaptiveAvgPool_7x7(x)   t = Conv1x1_{p x p}(pooled)   z = LeakyReLU_{0.01}(BatchNorm_train(t))
+//   y = bilinear(bilinear(z, x7, align_corners) -> 49 x 49, size (H, W), align_corners = False)
+// On [B, p, 7, 7] values (p = C / 16 = 4 ... 32) the launch chain — pool, conv, BatchNorm (2), two resamplings — ran six launches
+// of pure fill / drain latency each way at EVERY decoder level.  Here: two launches each way.
+//   mix   workgroup = image:   pool the image's p planes, mix the channels                      -> pooled, t  [B, p, 49] fp32
+//   up    workgroup = channel: batch statistics of t[:, c], normalise, LeakyReLU, and BOTH resamplings as one separable linear map
+//         y[b] = RH z[b] RW^T with RH = R_{49 -> H} R_{7 -> 49} ([H, 7], built on the host with the kernels' own coordinate rule)
+// and mirrored backwards (up: RH^T g RW, LeakyReLU', BatchNorm backward, the conv weight gradient's row c; mix: W^T, un-pool).
+#define POOLB 7
+#define POOLK 49
+struct PoolArgs {
+  const void* x;      // mix fwd: [B, p, H, W] slice (batch stride sxb) ; up bwd: gradient of y (batch stride sxb)
+  long sxb;
+  void* y;            // up fwd: y slice (batch stride syb) ; mix bwd: dx [B, p, H, W] (batch stride syb)
+  long syb;
+  float *pooled, *t;  // [B, p, 49]
+  float* dt;          // [B, p, 49]
+  const float* wc;    // [p, p]
+  float* dwc;         // ADDED into
+  const float *gamma, *beta, *RH, *RW;  // RH [H, 7], RW [W, 7]
+  float eps, slope;
+  float *mean, *var, *rmean, *rvar;
+  float momentum;
+  long* nbt;
+  float *dgamma, *dbeta;
+  int B, P, H, W;
+};
+__device__ __forceinline__ int pool_lo(int o, int in) { return (o * in) / POOLB; }
+__device__ __forceinline__ int pool_hi(int o, int in) { return ((o + 1) * in + POOLB - 1) / POOLB; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_mix_fwd_kernel(PoolArgs a) {
+  __shared__ float pl[32 * POOLK];
+  const int b = blockIdx.x, P = a.P, H = a.H, W = a.W;
+  const T* x = (const T*)a.x + (long)b * a.sxb;
+  for (int e = threadIdx.x; e < P * POOLK; e += 256) {
+    const int ci = e / POOLK, k = e - ci * POOLK, oy = k / POOLB, ox = k - oy * POOLB;
+    const int ys = pool_lo(oy, H), ye = pool_hi(oy, H), xs = pool_lo(ox, W), xe = pool_hi(ox, W);
+    const T* xp = x + (long)ci * H * W;
+    float sm = 0.f;
+    for (int iy = ys; iy < ye; ++iy)
+      for (int ix = xs; ix < xe; ++ix) sm += ldf(xp + iy * W + ix);
+    sm /= (float)((ye - ys) * (xe - xs));
+    pl[e] = sm;
+    a.pooled[(long)b * P * POOLK + e] = sm;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < P * POOLK; e += 256) {
+    const int co = e / POOLK, k = e - co * POOLK;
+    float sm = 0.f;
+    for (int ci = 0; ci < P; ++ci) sm += a.wc[co * P + ci] * pl[ci * POOLK + k];
+    a.t[(long)b * P * POOLK + e] = sm;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_mix_bwd_kernel(PoolArgs a) {
+  __shared__ float dpl[32 * POOLK];
+  const int b = blockIdx.x, P = a.P, H = a.H, W = a.W, HW = H * W;
+  for (int e = threadIdx.x; e < P * POOLK; e += 256) {
+    const int ci = e / POOLK, k = e - ci * POOLK, oy = k / POOLB, ox = k - oy * POOLB;
+    float sm = 0.f;
+    for (int co = 0; co < P; ++co) sm += a.wc[co * P + ci] * a.dt[((long)b * P + co) * POOLK + k];
+    dpl[e] = sm / (float)((pool_hi(oy, H) - pool_lo(oy, H)) * (pool_hi(ox, W) - pool_lo(ox, W)));
+  }
+  __syncthreads();
+  T* dx = (T*)a.y + (long)b * a.syb;
+  for (int e = threadIdx.x; e < P * HW; e += 256) {
+    const int ci = e / HW, q = e - ci * HW, iy = q / W, ix = q - iy * W;
+    // the bins that hold row iy: floor(iy 7 / H) and (windows overlap by at most one row) its neighbours
+    const int oy0 = (iy * POOLB) / H, ox0 = (ix * POOLB) / W;
+    float sm = 0.f;
+    for (int oy = oy0 > 0 ? oy0 - 1 : 0; oy <= oy0 + 1 && oy < POOLB; ++oy) {
+      if (iy < pool_lo(oy, H) || iy >= pool_hi(oy, H)) continue;
+      for (int ox = ox0 > 0 ? ox0 - 1 : 0; ox <= ox0 + 1 && ox < POOLB; ++ox)
+        if (ix >= pool_lo(ox, W) && ix < pool_hi(ox, W)) sm += dpl[ci * POOLK + oy * POOLB + ox];
+    }
+    stf(dx + e, sm);
+  }
+}
+
+// up, forward: workgroup = (channel c, image b).  The batch statistics of t[:, c] (B * 49 values) are recomputed by each of the
+// channel's B workgroups — cheaper than a launch of their own — and image 0's workgroup publishes them.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_up_fwd_kernel(PoolArgs a) {
+  __shared__ float red[16 * 2];
+  __shared__ float z[POOLK];
+  __shared__ float tmp[POOLB * 64];
+  const int c = blockIdx.x, b = blockIdx.y, B = a.B, P = a.P, H = a.H, W = a.W, n = B * POOLK;
+  float s[2] = {0.f, 0.f};
+  const float K = a.t[(long)c * POOLK];
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int bb = e / POOLK, k = e - bb * POOLK;
+    const float v = a.t[((long)bb * P + c) * POOLK + k] - K;
+    s[0] += v;
+    s[1] += v * v;
+  }
+  block_sum_n<2>(s, red);
+  const float m = s[0] / n;
+  float var = s[1] / n - m * m;
+  if (var < 0.f) var = 0.f;
+  const float mu = K + m;
+  if (threadIdx.x == 0 && b == 0) {
+    a.mean[c] = mu;
+    a.var[c] = var;
+    if (a.rmean) {
+      a.rmean[c] = (1.f - a.momentum) * a.rmean[c] + a.momentum * mu;
+      a.rvar[c] = (1.f - a.momentum) * a.rvar[c] + a.momentum * var * ((float)n / ((float)n - 1.f));
+    }
+    if (a.nbt && c == 0) a.nbt[0] += 1;
+  }
+  const float sc = a.gamma[c] * rsqrtf(var + a.eps), sh = a.beta[c] - mu * sc;
+  if (threadIdx.x < POOLK) {
+    const float v = a.t[((long)b * P + c) * POOLK + threadIdx.x] * sc + sh;
+    z[threadIdx.x] = v > 0.f ? v : v * a.slope;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < POOLB * W; e += 256) {  // tmp[i][x] = sum_j z[i][j] RW[x][j]
+    const int i = e / W, xx = e - i * W;
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < POOLB; ++j) sm += z[i * POOLB + j] * a.RW[xx * POOLB + j];
+    tmp[i * 64 + xx] = sm;
+  }
+  __syncthreads();
+  T* y = (T*)a.y + (long)b * a.syb + (long)c * H * W;
+  for (int e = threadIdx.x; e < H * W; e += 256) {      // y[y][x] = sum_i RH[y][i] tmp[i][x]
+    const int yy = e / W, xx = e - yy * W;
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < POOLB; ++i) sm += a.RH[yy * POOLB + i] * tmp[i * 64 + xx];
+    stf(y + e, sm);
+  }
+}
+
+// up, backward, per (channel, image): dzr[b, c] = RH^T g[b, c] RW   (the gradient plane goes through LDS: every element is read 7 times)
+template <typename T>
+__global__ __launch_bounds__(256) void pool_up_bwd_resample_kernel(PoolArgs a) {
+  __shared__ float gl[64 * 64];
+  __shared__ float tmp[POOLB * 64];
+  const int c = blockIdx.x, b = blockIdx.y, P = a.P, H = a.H, W = a.W;
+  const T* g = (const T*)a.x + (long)b * a.sxb + (long)c * H * W;
+  for (int e0 = threadIdx.x; e0 < H * W; e0 += 4 * 256) {  // four loads in flight per thread
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ldf(g + (e0 + u * 256 < H * W ? e0 + u * 256 : 0));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (e0 + u * 256 < H * W) gl[e0 + u * 256] = v[u];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < POOLB * W; e += 256) {  // tmp[i][x] = sum_y RH[y][i] g[y][x]
+    const int i = e / W, xx = e - i * W;
+    float sm = 0.f;
+    for (int yy = 0; yy < H; ++yy) sm += a.RH[yy * POOLB + i] * gl[yy * W + xx];
+    tmp[i * 64 + xx] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x < POOLK) {                            // dzr[i][j] = sum_x tmp[i][x] RW[x][j]
+    const int i = threadIdx.x / POOLB, j = threadIdx.x - i * POOLB;
+    float sm = 0.f;
+    for (int xx = 0; xx < W; ++xx) sm += tmp[i * 64 + xx] * a.RW[xx * POOLB + j];
+    a.dt[((long)b * P + c) * POOLK + threadIdx.x] = sm;
+  }
+}
+
+// up, backward, per channel: LeakyReLU', BatchNorm backward over the batch (in place in dt), row c of the conv weight gradient
+__global__ __launch_bounds__(1024) void pool_up_bwd_bn_kernel(PoolArgs a) {
+  __shared__ float red[16 * 2];
+  __shared__ float z[64 * POOLK];  // B <= 64
+  const int c = blockIdx.x, B = a.B, P = a.P, n = B * POOLK;
+  const float mu = a.mean[c], rs = rsqrtf(a.var[c] + a.eps), gm = a.gamma[c], bt = a.beta[c];
+  float s[2] = {0.f, 0.f};
+  for (int e = threadIdx.x; e < n; e += 1024) {
+    const int b = e / POOLK, k = e - b * POOLK;
+    const long q = ((long)b * P + c) * POOLK + k;
+    const float xh = (a.t[q] - mu) * rs, d = a.dt[q];
+    const float gy = (xh * gm + bt > 0.f) ? d : d * a.slope;
+    z[e] = gy;
+    s[0] += gy;
+    s[1] += gy * xh;
+  }
+  block_sum_n<2>(s, red);
+  const float m1 = s[0] / n, m2 = s[1] / n, k0 = gm * rs;
+  if (threadIdx.x == 0) {
+    a.dgamma[c] += s[1];
+    a.dbeta[c] += s[0];
+  }
+  for (int e = threadIdx.x; e < n; e += 1024) {
+    const int b = e / POOLK, k = e - b * POOLK;
+    const long q = ((long)b * P + c) * POOLK + k;
+    const float d = k0 * (z[e] - m1 - (a.t[q] - mu) * rs * m2);
+    z[e] = d;
+    a.dt[q] = d;
+  }
+  __syncthreads();
+  // dW[c][ci] = sum_{b, k} dt[b, c, k] pooled[b, ci, k]   (one wave per input channel in turn)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int ci = wave; ci < P; ci += 16) {
+    float sm = 0.f;
+    for (int e0 = lane; e0 < n; e0 += 8 * 64) {  // eight loads in flight per lane (clamped indices, masked products)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 64 * u < n ? e0 + 64 * u : 0, b = e / POOLK, k = e - b * POOLK;
+        v[u] = a.pooled[((long)b * P + ci) * POOLK + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + 64 * u < n) sm += z[e0 + 64 * u] * v[u];
+    }
+    sm = wave_sum(sm);
+    if (lane == 0) a.dwc[c * P + ci] += sm;
+  }
+}
+
+static inline bool pool_ok(int B, int P, int H, int W) {
+  return B >= 1 && B <= 64 && P >= 1 && P <= 32 && H >= 1 && W >= 1 && W <= 64 && H <= 64 && (long)B * POOLK >= 2;
+}
+
+template <typename T>
+static int pool_branch_fwd_impl(const T* x, long sxb, const float* wc, const float* gamma, const float* beta, float eps,
+                                float slope, const float* RH, const float* RW, T* y, long syb, float* pooled, float* t, float* mean,
+                                float* var, float* rmean, float* rvar, float momentum, long* nbt, int B, int P, int H, int W,
+                                hipStream_t stream) {
+  if (!x || !wc || !gamma || !beta || !RH || !RW || !y || !pooled || !t || !mean || !var) return CENET_EINVAL;
+  if (!pool_ok(B, P, H, W)) return CENET_EUNSUPPORTED;
+  PoolArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.sxb = sxb; a.y = y; a.syb = syb; a.pooled = pooled; a.t = t; a.wc = wc; a.gamma = gamma; a.beta = beta; a.RH = RH;
+  a.RW = RW; a.eps = eps; a.slope = slope; a.mean = mean; a.var = var; a.rmean = rmean; a.rvar = rvar; a.momentum = momentum;
+  a.nbt = nbt; a.B = B; a.P = P; a.H = H; a.W = W;
+  CENET_LAUNCH((pool_mix_fwd_kernel<T>), dim3(B), dim3(256), stream, a);
+  CENET_LAUNCH((pool_up_fwd_kernel<T>), dim3(P, B), dim3(256), stream, a);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+template <typename T>
+static int pool_branch_bwd_acc_impl(const T* g, long sgb, const float* wc, const float* gamma, const float* beta, float eps,
+                                    float slope, const float* RH, const float* RW, const float* pooled, const float* t,
+                                    const float* mean, const float* var, float* dt_ws, T* dx, long sdb, float* dwc_acc,
+                                    float* dgamma_acc, float* dbeta_acc, int B, int P, int H, int W, hipStream_t stream) {
+  if (!g || !wc || !gamma || !beta || !RH || !RW || !pooled || !t || !mean || !var || !dt_ws || !dx || !dwc_acc || !dgamma_acc ||
+      !dbeta_acc)
+    return CENET_EINVAL;
+  if (!pool_ok(B, P, H, W)) return CENET_EUNSUPPORTED;
+  PoolArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = g; a.sxb = sgb; a.y = dx; a.syb = sdb; a.pooled = (float*)pooled; a.t = (float*)t; a.dt = dt_ws; a.wc = wc; a.dwc = dwc_acc;
+  a.gamma = gamma; a.beta = beta; a.RH = RH; a.RW = RW; a.eps = eps; a.slope = slope; a.mean = (float*)mean; a.var = (float*)var;
+  a.dgamma = dgamma_acc; a.dbeta = dbeta_acc; a.B = B; a.P = P; a.H = H; a.W = W;
+  CENET_LAUNCH((pool_up_bwd_resample_kernel<T>), dim3(P, B), dim3(256), stream, a);
+  CENET_LAUNCH(pool_up_bwd_bn_kernel, dim3(P), dim3(1024), stream, a);
+  CENET_LAUNCH((pool_mix_bwd_kernel<T>), dim3(B), dim3(256), stream, a);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
 constexpr int EUCB_SM_SMALL = 48 * 1024, EUCB_SM_LARGE = 152 * 1024;
 
 // images per group of the backward's LDS gradient planes (0: does not fit)
@@ -1593,3 +1852,16 @@ CENET_TWIN(dwact_fwd, (const T* x, const float* w, const float* bias, T* y, int 
 CENET_TWIN(dwact_bwd_acc, (const T* g, const T* x, const float* w, const float* bias, T* dx, float* dw_acc, float* dbias_acc,
                            int act, float slope, int dil, int B, int C, int H, int W, hipStream_t stream),
            (g, x, w, bias, dx, dw_acc, dbias_acc, act, slope, dil, B, C, H, W, stream))
+
+CENET_TWIN(pool_branch_fwd, (const T* x, long sxb, const float* wc, const float* gamma, const float* beta, float eps, float slope,
+                             const float* RH, const float* RW, T* y, long syb, float* pooled, float* t, float* mean, float* var,
+                             float* running_mean, float* running_var, float momentum, long* num_batches_tracked, int B, int P,
+                             int H, int W, hipStream_t stream),
+           (x, sxb, wc, gamma, beta, eps, slope, RH, RW, y, syb, pooled, t, mean, var, running_mean, running_var, momentum,
+            num_batches_tracked, B, P, H, W, stream))
+CENET_TWIN(pool_branch_bwd_acc, (const T* g, long sgb, const float* wc, const float* gamma, const float* beta, float eps,
+                                 float slope, const float* RH, const float* RW, const float* pooled, const float* t,
+                                 const float* mean, const float* var, float* dt_ws, T* dx, long sdb, float* dwc_acc,
+                                 float* dgamma_acc, float* dbeta_acc, int B, int P, int H, int W, hipStream_t stream),
+           (g, sgb, wc, gamma, beta, eps, slope, RH, RW, pooled, t, mean, var, dt_ws, dx, sdb, dwc_acc, dgamma_acc, dbeta_acc, B,
+            P, H, W, stream))

@@ -557,6 +557,22 @@ def dwact_bwd(g, x, w, bias, dx, dw, db, act, slope, dil, B, Cn, H, W):
     _call("cenet_dwact_bwd_acc_f32", g, x, w, bias, dx, dw, db, ACT[act], float(slope), dil, B, Cn, H, W)
 
 
+def pool_branch_supported(B, P, H, W) -> bool:
+    return (not _NO_CHANLOC) and 1 <= B <= 64 and 1 <= P <= 32 and 1 <= H <= 64 and 1 <= W <= 64 and B * 49 >= 2
+
+
+def pool_branch_fwd(x, sxb, wc, gamma, beta, eps, slope, RH, RW, y, syb, pooled, t, mean, var, rmean, rvar, momentum, nbt, B, P, H, W):
+    _chk(x, wc, gamma, beta, RH, RW, y, pooled, t, mean, var, rmean, rvar)
+    _call("cenet_pool_branch_fwd_f32", x, L(sxb), wc, gamma, beta, float(eps), float(slope), RH, RW, y, L(syb), pooled, t, mean, var,
+          rmean, rvar, float(momentum), nbt, B, P, H, W)
+
+
+def pool_branch_bwd(g, sgb, wc, gamma, beta, eps, slope, RH, RW, pooled, t, mean, var, dt_ws, dx, sdb, dwc, dgamma, dbeta, B, P, H, W):
+    _chk(g, wc, gamma, beta, RH, RW, pooled, t, mean, var, dt_ws, dx, dwc, dgamma, dbeta)
+    _call("cenet_pool_branch_bwd_acc_f32", g, L(sgb), wc, gamma, beta, float(eps), float(slope), RH, RW, pooled, t, mean, var, dt_ws,
+          dx, L(sdb), dwc, dgamma, dbeta, B, P, H, W)
+
+
 def dw_nchw(x, sxb, w, bias, y, syb, a, sab, B, Cn, H, W, dil, flip, act="none", slope=0.0, x_off=0, y_off=0):
     """x_off / y_off (elements): read / write a channel slice of a wider tensor in place (batch strides sxb / syb)"""
     _chk(x, w, bias, y, a)

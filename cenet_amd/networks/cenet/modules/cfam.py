@@ -127,12 +127,15 @@ class MultiOrderDWConv(nn.Module):
             ys = [b[j].after_depthwise(us[j]) for j in range(3)]
             rest = us[3]
         pool = self.dlps[3]
-        y = ops.adaptive_avgpool(rest, 7, 7)
-        y = ops.conv1x1(y, pool[1].weight)
-        y = bn_call(pool[2], y, "lrelu", 0.01)
-        y = ops.interpolate_bilinear(y, scale_factor=7, align_corners=True)
-        if y.shape[2] != H or y.shape[3] != W:
-            y = ops.interpolate_bilinear(y, size=(H, W), align_corners=False)
+        if ops.pool_branch_supported(rest, pool[2]):
+            y = ops.pool_branch(rest, pool[1].weight, pool[2])  # the whole pooled branch: two launches per pass
+        else:
+            y = ops.adaptive_avgpool(rest, 7, 7)
+            y = ops.conv1x1(y, pool[1].weight)
+            y = bn_call(pool[2], y, "lrelu", 0.01)
+            y = ops.interpolate_bilinear(y, scale_factor=7, align_corners=True)
+            if y.shape[2] != H or y.shape[3] != W:
+                y = ops.interpolate_bilinear(y, size=(H, W), align_corners=False)
         ys.append(y)
         x = ops.concat(ys)
         return ops.conv1x1(x, self.PW_conv.weight, self.PW_conv.bias)

@@ -2331,6 +2331,80 @@ def cfam_front(x0, bn1, ccu):
     return CfamFrontFn.apply(x0, bn1, ccu)
 
 
+_POOL_R: dict = {}
+
+
+def _bil_matrix(n_in: int, n_out: int, scale: float, align: bool) -> Tensor:
+    """[n_out, n_in] fp32 matrix of one bilinear resampling along an axis, by the kernels' coordinate rule (resample.hip
+    bil_coord: align: src = scale * dst; else src = max(scale * (dst + 0.5) - 0.5, 0); fp32 arithmetic)"""
+    R = torch.zeros(n_out, n_in, dtype=torch.float32)
+    sc = torch.tensor(scale, dtype=torch.float32)
+    for d in range(n_out):
+        dst = torch.tensor(float(d), dtype=torch.float32)
+        src = sc * dst if align else torch.clamp(sc * (dst + 0.5) - 0.5, min=0.0)
+        i0 = min(int(src.item()), n_in - 1)
+        i1 = i0 + (1 if i0 < n_in - 1 else 0)
+        l1 = min(float((src - i0).item()), 1.0)
+        R[d, i0] += 1.0 - l1
+        R[d, i1] += l1
+    return R
+
+
+def _pool_matrices(H: int, Wd: int, device):
+    """(RH [H, 7], RW [W, 7]): cfam.py:217 (UpsamplingBilinear2d x7, align_corners=True) followed by cfam.py:232 (interpolate to
+    (H, W), align_corners=False, skipped when 49 == H) composed into one linear map per axis"""
+    key = (H, Wd, str(device))
+    m = _POOL_R.get(key)
+    if m is None:
+        def one(n):
+            r1 = _bil_matrix(7, 49, _f32(6.0 / 48.0), True).double()
+            r = r1 if n == 49 else _bil_matrix(49, n, _f32(49.0 / n), False).double() @ r1
+            return r.float().contiguous().to(device)
+        m = _POOL_R[key] = (one(H), one(Wd))
+    return m
+
+
+class PoolBranchFn(Function):
+    """cfam.py:212-218,231-232: AdaptiveAvgPool(7) -> 1x1 conv -> BatchNorm -> LeakyReLU(0.01) -> x7 bilinear (align) -> bilinear to
+    (H, W): two launches per pass (csrc/chanloc.hip pool_mix_* / pool_up_*) instead of six."""
+
+    @staticmethod
+    def forward(ctx, x, wc, bn, H, Wd):
+        x = _c(x)
+        B, P = x.shape[:2]
+        RH, RW = _pool_matrices(H, Wd, x.device)
+        y = torch.empty_like(x)
+        pooled, t = _empty((B, P, 49), x), _empty((B, P, 49), x)
+        mean, var = _empty((P,), x), _empty((P,), x)
+        kern.pool_branch_fwd(x, P * H * Wd, wc, bn.weight, bn.bias, bn.eps, 0.01, RH, RW, y, P * H * Wd, pooled, t, mean, var,
+                             bn.running_mean, bn.running_var, _mom(bn), bn.num_batches_tracked, B, P, H, Wd)
+        ctx.save_for_backward(wc, bn.weight, bn.bias, RH, RW, pooled, t, mean, var)
+        ctx.refs = (wc, bn.weight, bn.bias)
+        ctx.cfg = (bn.eps, B, P, H, Wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        wc, gamma, beta, RH, RW, pooled, t, mean, var = ctx.saved_tensors
+        eps, B, P, H, Wd = ctx.cfg
+        g = _c(g)
+        dx = torch.empty_like(g)
+        dt = _empty((B, P, 49), g)
+        r = ctx.refs
+        kern.pool_branch_bwd(g, P * H * Wd, wc, gamma, beta, eps, 0.01, RH, RW, pooled, t, mean, var, dt, dx, P * H * Wd,
+                             _gb(r[0], g), _gb(r[1], g), _gb(r[2], g), B, P, H, Wd)
+        return dx, None, None, None, None
+
+
+def pool_branch_supported(x, bn) -> bool:
+    return bool(bn.training) and x.dim() == 4 and kern.pool_branch_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3])
+
+
+def pool_branch(x, wc, bn):
+    """x [B, p, H, W] (the pooled branch's channel slice), wc [p, p, 1, 1], bn: its nn.BatchNorm2d"""
+    return PoolBranchFn.apply(x, wc, bn, x.shape[2], x.shape[3])
+
+
 class AdaptiveAvgPoolFn(Function):
     @staticmethod
     def forward(ctx, x, Ho, Wo):

@@ -816,6 +816,31 @@ int cenet_dwact_bwd_acc_bf16(const unsigned short* g, const unsigned short* x, c
                              unsigned short* dx, float* dw_acc, float* dbias_acc, int act, float slope, int dil, int B, int C,
                              int H, int W, cenet_stream_t stream);
 
+/* Pooled branch of MultiOrderDWConv, cfam.py:212-218,231-232, two launches each way at every decoder level:
+ *   y = bilinear_{(H, W), align_corners = False}(bilinear_{x7, align_corners = True}(LeakyReLU(BatchNorm_train(Conv1x1_{PxP}(AdaptiveAvgPool_7x7(x))))))
+ * x [B, P, H, W] (batch stride sxb: a channel slice of a wider tensor), y likewise (syb); P <= 32, B <= 64, H, W <= 64.
+ * RH [H, 7] / RW [W, 7]: the two resamplings composed into one linear map per axis (R_{49 -> H} R_{7 -> 49}; host-built with
+ * the coordinate rule of cenet_bilinear_fwd).  pooled, t [B, P, 49] fp32 are written for the backward pass, which takes g (the
+ * gradient of y, batch stride sgb) and a [B, P, 49] fp32 workspace, writes dx [B, P, H, W] (batch stride sdb) and ADDS the
+ * conv-weight [P, P] and BatchNorm gradients. */
+int cenet_pool_branch_fwd_f32(const float* x, long sxb, const float* wc, const float* gamma, const float* beta, float eps,
+                              float slope, const float* RH, const float* RW, float* y, long syb, float* pooled, float* t,
+                              float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                              long* num_batches_tracked, int B, int P, int H, int W, cenet_stream_t stream);
+int cenet_pool_branch_bwd_acc_f32(const float* g, long sgb, const float* wc, const float* gamma, const float* beta, float eps,
+                                  float slope, const float* RH, const float* RW, const float* pooled, const float* t,
+                                  const float* mean, const float* var, float* dt_ws, float* dx, long sdb, float* dwc_acc,
+                                  float* dgamma_acc, float* dbeta_acc, int B, int P, int H, int W, cenet_stream_t stream);
+int cenet_pool_branch_fwd_bf16(const unsigned short* x, long sxb, const float* wc, const float* gamma, const float* beta,
+                               float eps, float slope, const float* RH, const float* RW, unsigned short* y, long syb,
+                               float* pooled, float* t, float* mean, float* var, float* running_mean, float* running_var,
+                               float momentum, long* num_batches_tracked, int B, int P, int H, int W, cenet_stream_t stream);
+int cenet_pool_branch_bwd_acc_bf16(const unsigned short* g, long sgb, const float* wc, const float* gamma, const float* beta,
+                                   float eps, float slope, const float* RH, const float* RW, const float* pooled, const float* t,
+                                   const float* mean, const float* var, float* dt_ws, unsigned short* dx, long sdb,
+                                   float* dwc_acc, float* dgamma_acc, float* dbeta_acc, int B, int P, int H, int W,
+                                   cenet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,7 +129,7 @@ def test_cfam_block_fused_chains_equal_the_launch_chains(dev, dt, dims, hw, B, m
     """the whole CFAM block with every channel-local chain on against the same block on the unfused launch chains"""
     calls = []
     fused_entries = ("cfam_mid_fwd", "cfam_mid_bwd", "dwbn_fwd", "dwbn_bwd", "cfam_front_fwd", "cfam_front_bwd", "dwact_fwd",
-                     "dwact_bwd")
+                     "dwact_bwd", "pool_branch_fwd", "pool_branch_bwd")
     for name in fused_entries:
         orig = getattr(kern, name)
         monkeypatch.setattr(kern, name, lambda *a, _o=orig, _n=name, **k: (calls.append(_n), _o(*a, **k))[1])
