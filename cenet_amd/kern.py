@@ -23,6 +23,8 @@ def _chk(*ts):
     for t in ts:
         if t is None:
             continue
+        if isinstance(t, Ptr):
+            t = t.t
         if t.dtype not in (torch.float32, torch.bfloat16, torch.int32, torch.int64, torch.uint8):
             raise TypeError(f"cenet_amd kernels take fp32 / bf16 tensors (int32 / int64 / uint8 for indices and masks); "
                             f"got {t.dtype}")

@@ -106,6 +106,12 @@ class MultiOrderDWConv(nn.Module):
         for key, bn in ((("pbn", b[0].pointwise_bn),) if fused else (("dbn", b[0].depthwise_bn), ("pbn", b[0].pointwise_bn))):
             if key == "pbn":
                 u = ops.grouped_conv1x1(u, mg["pw"])
+                pool = self.dlps[3]
+                if bn.training and rest is not None and ops.pool_branch_supported(rest, pool[2]):
+                    # the pointwise BatchNorm + ReLU and the pooled branch write their channel slices of ONE tensor: no concat
+                    return ops.join_bn_pool(u, rest, mg["pbn_w"], mg["pbn_b"], mg["pbn_running_mean"], mg["pbn_running_var"],
+                                            mg["pbn_num_batches_tracked"], bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                            pool[1].weight, pool[2]), None
             u = ops.batchnorm(u, mg[key + "_w"], mg[key + "_b"], mg[key + "_running_mean"], mg[key + "_running_var"],
                               mg[key + "_num_batches_tracked"], bn.training, bn.eps, "relu", 0.0,
                               bn.momentum if bn.momentum is not None else 0.1)
@@ -121,6 +127,8 @@ class MultiOrderDWConv(nn.Module):
         if mg is not None:
             ops.refresh_member_shadows(mg["pw"], x)
             u, rest = self._branches_merged(x, sizes, mg)
+            if rest is None:  # (the branches and the pooled branch already share one tensor)
+                return ops.conv1x1(u, self.PW_conv.weight, self.PW_conv.bias)
             ys = [u]
         else:
             us = ops.split_dwconv(x, sizes[:3], [m.rate for m in b], [m.depthwise.weight for m in b])

@@ -2396,6 +2396,56 @@ class PoolBranchFn(Function):
         return dx, None, None, None, None
 
 
+class JoinBnPoolFn(Function):
+    """Tail of MultiOrderDWConv's branches without the concat (cfam.py:233-240): the (merged) pointwise BatchNorm + ReLU of the three
+    dilated branches writes channels [0, 3g) of ONE [B, C, H, W] tensor, the pooled branch (PoolBranchFn's kernels) channels
+    [3g, C); backwards both read their slice of the joint gradient in place (batch strides) — no cat / split launches."""
+
+    @staticmethod
+    def forward(ctx, v_raw, rest, gamma, beta, rmean, rvar, nbt, eps, momentum, wc, pbn):
+        v_raw, rest = _c(v_raw), _c(rest)
+        B, G3, H, Wd = v_raw.shape
+        P = rest.shape[1]
+        Cn, HW = G3 + P, H * Wd
+        joint = _act((B, Cn, H, Wd), v_raw)
+        mean, var = _empty((G3,), v_raw), _empty((G3,), v_raw)
+        ws = _empty((2 * G3 * 256,), v_raw)  # CENET_BN_WS_FLOATS(C)
+        kern.bn_train_fwd(v_raw, G3 * HW, joint, Cn * HW, ws, mean, var, rmean, rvar, momentum, nbt, eps, gamma, beta, "relu", 0.0, B,
+                          G3, HW)
+        RH, RW = _pool_matrices(H, Wd, v_raw.device)
+        pooled, t = _empty((B, P, 49), v_raw), _empty((B, P, 49), v_raw)
+        pmean, pvar = _empty((P,), v_raw), _empty((P,), v_raw)
+        kern.pool_branch_fwd(rest, P * HW, wc, pbn.weight, pbn.bias, pbn.eps, 0.01, RH, RW, kern.Ptr(joint, G3 * HW), Cn * HW, pooled,
+                             t, pmean, pvar, pbn.running_mean, pbn.running_var, _mom(pbn), pbn.num_batches_tracked, B, P, H, Wd)
+        ctx.save_for_backward(v_raw, gamma, beta, mean, var, wc, pbn.weight, pbn.bias, RH, RW, pooled, t, pmean, pvar)
+        ctx.refs = (gamma, beta, wc, pbn.weight, pbn.bias)
+        ctx.cfg = (eps, pbn.eps, P)
+        return joint
+
+    @staticmethod
+    def backward(ctx, g):
+        v_raw, gamma, beta, mean, var, wc, pg, pb, RH, RW, pooled, t, pmean, pvar = ctx.saved_tensors
+        eps, peps, P = ctx.cfg
+        g = _c(g)
+        B, G3, H, Wd = v_raw.shape
+        Cn, HW = G3 + P, H * Wd
+        r = ctx.refs
+        dv = torch.empty_like(v_raw)
+        ws = _empty((2 * G3 * 256,), v_raw)
+        kern.bn_bwd(g, Cn * HW, v_raw, G3 * HW, dv, G3 * HW, mean, var, eps, gamma, beta, "relu", 0.0, B, G3, HW, ws, _gb(r[0], g),
+                    _gb(r[1], g))
+        drest = torch.empty((B, P, H, Wd), device=g.device, dtype=g.dtype)
+        dt = _empty((B, P, 49), g)
+        kern.pool_branch_bwd(kern.Ptr(g, G3 * HW), Cn * HW, wc, pg, pb, peps, 0.01, RH, RW, pooled, t, pmean, pvar, dt, drest, P * HW,
+                             _gb(r[2], g), _gb(r[3], g), _gb(r[4], g), B, P, H, Wd)
+        return (dv, drest) + (None,) * 9
+
+
+def join_bn_pool(v_raw, rest, gamma, beta, rmean, rvar, nbt, eps, momentum, wc, pbn):
+    """-> [B, 3g + p, H, W]: ReLU(BatchNorm(v_raw)) | pooled_branch(rest)"""
+    return JoinBnPoolFn.apply(v_raw, rest, gamma, beta, rmean, rvar, nbt, eps, momentum, wc, pbn)
+
+
 def pool_branch_supported(x, bn) -> bool:
     return bool(bn.training) and x.dim() == 4 and kern.pool_branch_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3])
 
