@@ -21,7 +21,7 @@
 // some headroom; beyond that the launch chains with partial sums over many workgroups win)
 #define CENET_CHANLOC_MAX 32768
 
-namespace {
+// (no anonymous namespace: the kernels keep plain names, as the profiler tools of tools/ key on them)
 
 // sum over the workgroup of N values at once (one barrier pair for all of them); result in every thread.  red: >= 16 * N floats
 template <int N>
@@ -1778,7 +1778,6 @@ static int eucb_bwd_acc_impl(const T* g, long sgb, const T* x, long sxb, const f
   return CENET_OK;
 }
 
-}  // namespace
 
 /* does the fused EUCB front (forward AND backward) take this shape?  esize = 2 (bf16) / 4 (fp32) */
 extern "C" int cenet_eucb_supported(int B, int H, int W, int esize) {

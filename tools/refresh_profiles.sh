@@ -24,6 +24,7 @@ cp $(ls $O/stats_c/*/*kernel_stats.csv | head -1) $O/${TAG}_c_kernel_stats_noroo
 cd $R
 python3 tools/prof_summary.py $O/stats_c 25 > $O/prof_summary_c.txt 2>&1
 rm -rf $O/stats_b $O/stats_c $O/pmc_fetch/*/*kernel_trace.csv $O/pmc_write/*/*kernel_trace.csv   # (traces: tens of MB)
+cp $O/${TAG}_c_kernel_stats_noroofline.csv profiles/   # (bench.py's roofline.rocprof_avg_launch_ms reads the latest round's summary)
 # the bench lines
 python3 bench.py > $O/${TAG}_bench_50steps.json 2> $O/bench.err
 python3 bench.py --config synapse --no-f32 --no-cpu-baseline > $O/${TAG}_bench_synapse.json 2>> $O/bench.err
