@@ -1522,29 +1522,31 @@ __global__ __launch_bounds__(256) void pool_mix_fwd_kernel(PoolArgs a) {
   }
 }
 
+// mix, backward: workgroup = (image b, input channel ci) — the un-pooling writes H * W values per plane and is what takes the time at
+// the large levels (one workgroup per IMAGE left 32 workgroups walking 12 K outputs each)
 template <typename T>
 __global__ __launch_bounds__(256) void pool_mix_bwd_kernel(PoolArgs a) {
-  __shared__ float dpl[32 * POOLK];
-  const int b = blockIdx.x, P = a.P, H = a.H, W = a.W, HW = H * W;
-  for (int e = threadIdx.x; e < P * POOLK; e += 256) {
-    const int ci = e / POOLK, k = e - ci * POOLK, oy = k / POOLB, ox = k - oy * POOLB;
+  __shared__ float dpl[POOLK];
+  const int b = blockIdx.x, ci = blockIdx.y, P = a.P, H = a.H, W = a.W, HW = H * W;
+  if (threadIdx.x < POOLK) {
+    const int k = threadIdx.x, oy = k / POOLB, ox = k - oy * POOLB;
     float sm = 0.f;
     for (int co = 0; co < P; ++co) sm += a.wc[co * P + ci] * a.dt[((long)b * P + co) * POOLK + k];
-    dpl[e] = sm / (float)((pool_hi(oy, H) - pool_lo(oy, H)) * (pool_hi(ox, W) - pool_lo(ox, W)));
+    dpl[k] = sm / (float)((pool_hi(oy, H) - pool_lo(oy, H)) * (pool_hi(ox, W) - pool_lo(ox, W)));
   }
   __syncthreads();
-  T* dx = (T*)a.y + (long)b * a.syb;
-  for (int e = threadIdx.x; e < P * HW; e += 256) {
-    const int ci = e / HW, q = e - ci * HW, iy = q / W, ix = q - iy * W;
+  T* dx = (T*)a.y + (long)b * a.syb + (long)ci * HW;
+  for (int q = threadIdx.x; q < HW; q += 256) {
+    const int iy = q / W, ix = q - iy * W;
     // the bins that hold row iy: floor(iy 7 / H) and (windows overlap by at most one row) its neighbours
     const int oy0 = (iy * POOLB) / H, ox0 = (ix * POOLB) / W;
     float sm = 0.f;
     for (int oy = oy0 > 0 ? oy0 - 1 : 0; oy <= oy0 + 1 && oy < POOLB; ++oy) {
       if (iy < pool_lo(oy, H) || iy >= pool_hi(oy, H)) continue;
       for (int ox = ox0 > 0 ? ox0 - 1 : 0; ox <= ox0 + 1 && ox < POOLB; ++ox)
-        if (ix >= pool_lo(ox, W) && ix < pool_hi(ox, W)) sm += dpl[ci * POOLK + oy * POOLB + ox];
+        if (ix >= pool_lo(ox, W) && ix < pool_hi(ox, W)) sm += dpl[oy * POOLB + ox];
     }
-    stf(dx + e, sm);
+    stf(dx + q, sm);
   }
 }
 
@@ -1720,7 +1722,7 @@ static int pool_branch_bwd_acc_impl(const T* g, long sgb, const float* wc, const
   a.dgamma = dgamma_acc; a.dbeta = dbeta_acc; a.B = B; a.P = P; a.H = H; a.W = W;
   CENET_LAUNCH((pool_up_bwd_resample_kernel<T>), dim3(P, B), dim3(256), stream, a);
   CENET_LAUNCH(pool_up_bwd_bn_kernel, dim3(P), dim3(1024), stream, a);
-  CENET_LAUNCH((pool_mix_bwd_kernel<T>), dim3(B), dim3(256), stream, a);
+  CENET_LAUNCH((pool_mix_bwd_kernel<T>), dim3(B, P), dim3(256), stream, a);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }
@@ -1866,3 +1868,27 @@ CENET_TWIN(pool_branch_bwd_acc, (const T* g, long sgb, const float* wc, const fl
                                  float* dgamma_acc, float* dbeta_acc, int B, int P, int H, int W, hipStream_t stream),
            (g, sgb, wc, gamma, beta, eps, slope, RH, RW, pooled, t, mean, var, dt_ws, dx, sdb, dwc_acc, dgamma_acc, dbeta_acc, B,
             P, H, W, stream))
+
+// ---- self-test of the DPP wave reductions of common.h (tests/test_kern_misc.py): wave w of the launch reduces x[64 w .. 64 w + 64);
+// sums / maxs / mins hold 2 nwaves entries ----
+__global__ __launch_bounds__(256) void wave_reduce_selftest_kernel(const float* __restrict__ x, float* __restrict__ sums,
+                                                                  float* __restrict__ maxs, int* __restrict__ mins, int nwaves) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= nwaves) return;  // (wave-uniform)
+  const float v = x[(long)w * 64 + lane];
+  const float s = wave_sum_dpp(v), m = wave_max_dpp(v);
+  const int mi = wave_min_i_dpp((int)(v * 1024.f) + lane);
+  // every lane must hold the result (the reductions broadcast): lane 0 writes row w, lane 37 row nwaves + w
+  if (lane == 0 || lane == 37) {
+    const int o = lane ? nwaves + w : w;
+    sums[o] = s;
+    maxs[o] = m;
+    mins[o] = mi;
+  }
+}
+extern "C" int cenet_selftest_wave_reduce(const float* x, float* sums, float* maxs, int* mins, int nwaves, hipStream_t stream) {
+  if (!x || !sums || !maxs || !mins || nwaves <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(wave_reduce_selftest_kernel, dim3(cdiv(nwaves, 4)), dim3(256), stream, x, sums, maxs, mins, nwaves);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}

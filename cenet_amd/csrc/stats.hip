@@ -824,3 +824,280 @@ static int srm_bwd_apply_impl(const T* x, const T* dy, const float* f, const flo
 }
 CENET_TWIN(srm_bwd_apply, (const T* x, const T* dy, const float* f, const float* u, const float* du, const int* amax, T* dx,
                            int B, int C, int HW, hipStream_t stream), (x, dy, f, u, du, amax, dx, B, C, HW, stream))
+
+
+// =====================================================================================================================
+// SRM tail without its BatchNorm / activation launches (round 5).  cfam.py:93-101 after the channel statistics:
+//   f = pwc(u) + dwc(u);  fa = GELU(f);  fb = BatchNorm_train(fa) (ONE channel over B*H*W);  y = x * sigmoid(fb)
+// ran as conv, act, bn_stats, bn_apply, gate (5 launches on a [B, 1, H, W] map at every decoder level) and 6 backwards.
+//   srm_conv_gelu_fwd   conv + GELU, and per workgroup (count, mean, M2) of its fa values        -> f, fa, part [G][3]
+//   gate_pix_bn_fwd     folds the G partial triples (Chan's merge: exact in any order), normalises and gates in one pass;
+//                       image-0-channel-0's workgroups publish mean / var / running statistics, the first channel of every
+//                       image writes fb (the backward kernels read it)
+//   srm_bn_bwd_part     per workgroup sum(dfb), sum(dfb * xhat)                                    -> part2 [G][2]
+//   srm_conv_bn_bwd     folds part2, rebuilds df = BatchNormBackward(dfb) * GELU'(f) for its image in LDS, then the conv backward
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void srm_conv_gelu_fwd_kernel(const float* __restrict__ u, const float* __restrict__ pwc,
+                                                               const float* __restrict__ dwc, float* __restrict__ f,
+                                                               float* __restrict__ fa, float* __restrict__ part, int H, int W) {
+  __shared__ float red[16];
+  const int b = blockIdx.y, HW = H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = p < HW;
+  float a = 0.f;
+  if (ok) {
+    const int py = p / W, px = p - py * W;
+    const float* ub = u + (long)b * 3 * HW;
+    float acc = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      acc += pwc[ch] * ub[ch * HW + p];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = py + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = px + kx - 1;
+          if (ix < 0 || ix >= W) continue;
+          acc += dwc[ch * 9 + ky * 3 + kx] * ub[ch * HW + iy * W + ix];
+        }
+      }
+    }
+    a = gelu_f(acc);
+    f[(long)b * HW + p] = acc;
+    fa[(long)b * HW + p] = a;
+  }
+  const int n = HW - blockIdx.x * 256 < 256 ? HW - blockIdx.x * 256 : 256;
+  const float m = block_sum(ok ? a : 0.f, red) / n;
+  const float m2 = block_sum(ok ? (a - m) * (a - m) : 0.f, red);
+  if (threadIdx.x == 0) {
+    float* q = part + 3 * ((long)b * gridDim.x + blockIdx.x);
+    q[0] = (float)n;
+    q[1] = m;
+    q[2] = m2;
+  }
+}
+
+// total (mean, biased variance) of G (count, mean, M2) triples.  Every WAVE folds for itself (same order in every wave, so every
+// wave of the launch holds the same bits): no LDS, no barrier in front of the kernel's real work.
+__device__ __forceinline__ void srm_fold(const float* __restrict__ part, int G, float& mean, float& var, float& cnt) {
+  const int lane = threadIdx.x & 63;
+  float n = 0.f, nm = 0.f;
+  for (int i = lane; i < G; i += 64) {
+    n += part[3 * i];
+    nm += part[3 * i] * part[3 * i + 1];
+  }
+  n = wave_sum(n);
+  nm = wave_sum(nm);
+  mean = nm / n;
+  float m2 = 0.f;
+  for (int i = lane; i < G; i += 64) {
+    const float d = part[3 * i + 1] - mean;
+    m2 += part[3 * i + 2] + part[3 * i] * d * d;
+  }
+  var = wave_sum(m2) / n;
+  cnt = n;
+}
+
+// y = x * sigmoid(a fa + c), a / c from the folded statistics.  grid (ceil(B*HWv / 256), channel slices): a thread owns V
+// consecutive pixels of one image — the normalisation and the sigmoid are evaluated ONCE per pixel, not once per channel — and
+// walks its channel slice with 4 independent loads in flight.  Slice 0 also stores fb (the backward kernels read it).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gate_pix_bn_fwd_kernel(const T* __restrict__ x, const float* __restrict__ fa,
+                                                             const float* __restrict__ part, int G, float* __restrict__ fb,
+                                                             T* __restrict__ y, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float* mean_out,
+                                                             float* var_out, float* rmean, float* rvar, float momentum, long* nbt,
+                                                             int B, int C, int HWv) {
+  float mean, var, cnt;
+  srm_fold(part, G, mean, var, cnt);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    mean_out[0] = mean;
+    var_out[0] = var;
+    if (rmean) {
+      rmean[0] = (1.f - momentum) * rmean[0] + momentum * mean;
+      rvar[0] = (1.f - momentum) * rvar[0] + momentum * var * (cnt / (cnt - 1.f));
+    }
+    if (nbt) nbt[0] += 1;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * HWv) return;
+  const float a = gamma[0] * rsqrtf(var + eps), c = beta[0] - mean * a;
+  const int b = i / HWv, pv = i - b * HWv;
+  float sg[V];
+  ldv<V>(sg, fa + (long)i * V);
+#pragma unroll
+  for (int e = 0; e < V; ++e) sg[e] = a * sg[e] + c;
+  if (blockIdx.y == 0) stv<V>(fb + (long)i * V, sg);
+#pragma unroll
+  for (int e = 0; e < V; ++e) sg[e] = sigmoid_f(sg[e]);
+  const int per = (C + (int)gridDim.y - 1) / (int)gridDim.y, c0 = blockIdx.y * per, c1 = c0 + per < C ? c0 + per : C;
+  const long HW = (long)HWv * V;
+  const T* xp = x + ((long)b * C + c0) * HW + (long)pv * V;
+  T* yp = y + ((long)b * C + c0) * HW + (long)pv * V;
+  int ch = c0;
+  for (; ch + 4 <= c1; ch += 4, xp += 4 * HW, yp += 4 * HW) {
+    float xv[4][V];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ldv<V>(xv[k], xp + k * HW);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) xv[k][e] *= sg[e];
+      stv<V>(yp + k * HW, xv[k]);
+    }
+  }
+  for (; ch < c1; ++ch, xp += HW, yp += HW) {
+    float xv[V];
+    ldv<V>(xv, xp);
+#pragma unroll
+    for (int e = 0; e < V; ++e) xv[e] *= sg[e];
+    stv<V>(yp, xv);
+  }
+}
+
+__global__ __launch_bounds__(256) void srm_bn_bwd_part_kernel(const float* __restrict__ dfb, const float* __restrict__ fa,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             float eps, float* __restrict__ part2, int HW) {
+  __shared__ float red[16];
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  float g = 0.f, gx = 0.f;
+  if (p < HW) {
+    g = dfb[(long)b * HW + p];
+    gx = g * (fa[(long)b * HW + p] - mean[0]) * rsqrtf(var[0] + eps);
+  }
+  g = block_sum(g, red);
+  gx = block_sum(gx, red);
+  if (threadIdx.x == 0) {
+    float* q = part2 + 2 * ((long)b * gridDim.x + blockIdx.x);
+    q[0] = g;
+    q[1] = gx;
+  }
+}
+
+#define SRM_MAXHW 4096
+// grid (gx, B): as srm_conv_bwd_kernel, with df built in LDS from dfb / fa / f and the folded BatchNorm sums
+__global__ __launch_bounds__(256) void srm_conv_bn_bwd_kernel(const float* __restrict__ u, const float* __restrict__ dfb,
+                                                             const float* __restrict__ fa, const float* __restrict__ f,
+                                                             const float* __restrict__ part2, int G2, float ntot,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             float eps, const float* __restrict__ gamma,
+                                                             const float* __restrict__ pwc, const float* __restrict__ dwc,
+                                                             float* __restrict__ du, float* __restrict__ dpwc,
+                                                             float* __restrict__ ddwc, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int H, int W) {
+  __shared__ float red[16];
+  __shared__ float gl[SRM_MAXHW];
+  const int b = blockIdx.y, HW = H * W;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < G2; i += 256) {
+    s1 += part2[2 * i];
+    s2 += part2[2 * i + 1];
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    dgamma[0] += s2;
+    dbeta[0] += s1;
+  }
+  const float mu = mean[0], rs = rsqrtf(var[0] + eps), k0 = gamma[0] * rs, m1 = s1 / ntot, m2 = s2 / ntot;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const long q = (long)b * HW + p;
+    const float xh = (fa[q] - mu) * rs;
+    gl[p] = k0 * (dfb[q] - m1 - xh * m2) * gelu_grad_f(f[q]);
+  }
+  __syncthreads();
+  const float* ub = u + (long)b * 3 * HW;
+  float wsum[3][10];  // [channel][9 taps, pointwise]
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int t = 0; t < 10; ++t) wsum[ch][t] = 0.f;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const int py = p / W, px = p - py * W;
+    const float g = gl[p];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float acc = pwc[ch] * g;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int t = ky * 3 + kx;
+          const int qy = py - (ky - 1), qx = px - (kx - 1);
+          if (qy >= 0 && qy < H && qx >= 0 && qx < W) acc += dwc[ch * 9 + t] * gl[qy * W + qx];
+          const int iy = py + ky - 1, ix = px + kx - 1;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) wsum[ch][t] += g * ub[ch * HW + iy * W + ix];
+        }
+      du[(long)b * 3 * HW + ch * HW + p] = acc;
+      wsum[ch][9] += g * ub[ch * HW + p];
+    }
+  }
+  __shared__ float part[4][30];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      const float v = wave_sum(wsum[ch][t]);
+      if (lane == 0) part[wave][ch * 10 + t] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 30) {
+    const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    const int ch = threadIdx.x / 10, t = threadIdx.x - ch * 10;
+    if (t == 9) atomicAdd(&dpwc[ch], v);
+    else atomicAdd(&ddwc[ch * 9 + t], v);
+  }
+}
+
+extern "C" int cenet_srm_fused_supported(int B, int H, int W) { return B > 0 && H > 0 && W > 0 && (long)H * W <= SRM_MAXHW; }
+/* partial triples written by cenet_srm_conv_gelu_fwd_f32: B * ceil(H*W / 256) */
+extern "C" int cenet_srm_parts(int B, int H, int W) { return B * cdiv(H * W, 256); }
+extern "C" int cenet_srm_conv_gelu_fwd_f32(const float* u, const float* pwc, const float* dwc, float* f, float* fa, float* part,
+                                           int B, int H, int W, hipStream_t stream) {
+  if (!u || !pwc || !dwc || !f || !fa || !part || B <= 0 || H <= 0 || W <= 0) return CENET_EINVAL;
+  CENET_LAUNCH(srm_conv_gelu_fwd_kernel, dim3(cdiv(H * W, 256), B), dim3(256), stream, u, pwc, dwc, f, fa, part, H, W);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+template <typename T>
+static int gate_pix_bn_fwd_impl(const T* x, const float* fa, const float* part, int G, float* fb, T* y, const float* gamma,
+                                const float* beta, float eps, float* mean, float* var, float* rmean, float* rvar, float momentum,
+                                long* nbt, int B, int C, int HW, hipStream_t stream) {
+  if (!x || !fa || !part || !fb || !y || !gamma || !beta || !mean || !var || G <= 0 || B <= 0 || C <= 0 || HW <= 0) return CENET_EINVAL;
+  const int V = (plane_vw<T>(HW, x, y) == 4 && (((uintptr_t)fa | (uintptr_t)fb) & 15) == 0) ? 4 : 1;
+  const int px = cdiv(B * (HW / V), 256);
+  int cs = 1;
+  while (cs < 64 && (long)px * cs < 1024 && C / (cs * 2) >= 8) cs *= 2;
+  if (V == 4)
+    CENET_LAUNCH((gate_pix_bn_fwd_kernel<T, 4>), dim3(px, cs), dim3(256), stream, x, fa, part, G, fb, y, gamma, beta, eps, mean, var,
+                 rmean, rvar, momentum, nbt, B, C, HW / 4);
+  else
+    CENET_LAUNCH((gate_pix_bn_fwd_kernel<T, 1>), dim3(px, cs), dim3(256), stream, x, fa, part, G, fb, y, gamma, beta, eps, mean, var,
+                 rmean, rvar, momentum, nbt, B, C, HW);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+CENET_TWIN(gate_pix_bn_fwd, (const T* x, const float* fa, const float* part, int G, float* fb, T* y, const float* gamma,
+                             const float* beta, float eps, float* mean, float* var, float* running_mean, float* running_var,
+                             float momentum, long* num_batches_tracked, int B, int C, int HW, hipStream_t stream),
+           (x, fa, part, G, fb, y, gamma, beta, eps, mean, var, running_mean, running_var, momentum, num_batches_tracked, B, C, HW,
+            stream))
+extern "C" int cenet_srm_conv_bn_bwd_acc_f32(const float* u, const float* dfb, const float* fa, const float* f, const float* mean,
+                                             const float* var, float eps, const float* gamma, const float* pwc, const float* dwc,
+                                             float* part2_ws, float* du, float* dpwc_acc, float* ddwc_acc, float* dgamma_acc,
+                                             float* dbeta_acc, int B, int H, int W, hipStream_t stream) {
+  if (!u || !dfb || !fa || !f || !mean || !var || !gamma || !pwc || !dwc || !part2_ws || !du || !dpwc_acc || !ddwc_acc ||
+      !dgamma_acc || !dbeta_acc || B <= 0 || H <= 0 || W <= 0)
+    return CENET_EINVAL;
+  if ((long)H * W > SRM_MAXHW) return CENET_EUNSUPPORTED;
+  const int gx = cdiv(H * W, 256);
+  CENET_LAUNCH(srm_bn_bwd_part_kernel, dim3(gx, B), dim3(256), stream, dfb, fa, mean, var, eps, part2_ws, H * W);
+  int want = gx > 8 ? 8 : gx;
+  CENET_LAUNCH(srm_conv_bn_bwd_kernel, dim3(want, B), dim3(256), stream, u, dfb, fa, f, (const float*)part2_ws, gx * B,
+               (float)((long)B * H * W), mean, var, eps, gamma, pwc, dwc, du, dpwc_acc, ddwc_acc, dgamma_acc, dbeta_acc, H, W);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}

@@ -775,6 +775,34 @@ def srm_conv_bwd(u, df, pwc, dwc, du, dpwc, ddwc, B, H, W):
     _call("cenet_srm_conv_bwd_acc_f32", u, df, pwc, dwc, du, dpwc, ddwc, B, H, W)
 
 
+_NO_SRM_FUSED = __import__("os").environ.get("CENET_NO_SRM_FUSED") is not None  # measurement aid
+
+
+def srm_fused_supported(B, H, W) -> bool:
+    return (not _NO_CHANLOC) and (not _NO_SRM_FUSED) and bool(_lib.lib().cenet_srm_fused_supported(int(B), int(H), int(W)))
+
+
+def srm_parts(B, H, W) -> int:
+    return int(_lib.lib().cenet_srm_parts(int(B), int(H), int(W)))
+
+
+def srm_conv_gelu_fwd(u, pwc, dwc, f, fa, part, B, H, W):
+    _chk(u, pwc, dwc, f, fa, part)
+    _call("cenet_srm_conv_gelu_fwd_f32", u, pwc, dwc, f, fa, part, B, H, W)
+
+
+def gate_pix_bn_fwd(x, fa, part, G, fb, y, gamma, beta, eps, mean, var, rmean, rvar, momentum, nbt, B, Cn, HW):
+    _chk(x, fa, part, fb, y, gamma, beta, mean, var, rmean, rvar)
+    _call("cenet_gate_pix_bn_fwd_f32", x, fa, part, G, fb, y, gamma, beta, float(eps), mean, var, rmean, rvar, float(momentum), nbt, B,
+          Cn, HW)
+
+
+def srm_conv_bn_bwd(u, dfb, fa, f, mean, var, eps, gamma, pwc, dwc, part2, du, dpwc, ddwc, dgamma, dbeta, B, H, W):
+    _chk(u, dfb, fa, f, mean, var, gamma, pwc, dwc, part2, du, dpwc, ddwc, dgamma, dbeta)
+    _call("cenet_srm_conv_bn_bwd_acc_f32", u, dfb, fa, f, mean, var, float(eps), gamma, pwc, dwc, part2, du, dpwc, ddwc, dgamma,
+          dbeta, B, H, W)
+
+
 def gate_pix_fwd(x, f, y, B, Cn, HW):
     _chk(x, f, y)
     _call("cenet_gate_pix_fwd_f32", x, f, y, B, Cn, HW)

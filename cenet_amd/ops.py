@@ -2735,6 +2735,10 @@ def ccu(x, fc1, fc2, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training, tap=False):
 
 
 class SRMFn(Function):
+    """cfam.py:93-101.  Training mode on planes of <= 4096 pixels (round 5): the conv + GELU kernel also leaves per-workgroup
+    (count, mean, M2) triples, the gate kernel folds them and normalises inline, and backwards ONE kernel does BatchNorm backward,
+    GELU' and the conv backward: 3 + 4 launches instead of 6 + 6 (csrc/stats.hip)."""
+
     @staticmethod
     def forward(ctx, x, pwc, dwc, bn_w, bn_b, bn_rm, bn_rv, bn_nbt, training):
         x = _c(x)
@@ -2744,22 +2748,31 @@ class SRMFn(Function):
         amax = _empty((B, HW), x, torch.int32)
         kern.srm_stats_fwd(x, u, amax, B, Cn, HW)
         f = _empty((B, 1, H, Wd), x)
-        kern.srm_conv_fwd(u, pwc, dwc, f, B, H, Wd)
         fa = torch.empty_like(f)
-        kern.act_fwd(f, fa, f.numel(), "gelu")
-        if training:
-            mean, var = _empty((1,), x), _empty((1,), x)
-            ws = _empty((2 * 256,), x)  # CENET_BN_WS_FLOATS(1)
-            kern.bn_stats(fa, HW, B, 1, HW, ws, mean, var, bn_rm, bn_rv, 0.1, bn_nbt)
-        else:
-            mean, var = bn_rm, bn_rv
         fb = torch.empty_like(f)
-        kern.bn_apply(fa, HW, fb, HW, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, 1, HW)
         y = torch.empty_like(x)
-        kern.gate_pix_fwd(x, fb, y, B, Cn, HW)
+        fused = bool(training) and kern.srm_fused_supported(B, H, Wd)
+        if fused:
+            G = kern.srm_parts(B, H, Wd)
+            part = _empty((G, 3), x)
+            mean, var = _empty((1,), x), _empty((1,), x)
+            kern.srm_conv_gelu_fwd(u, pwc, dwc, f, fa, part, B, H, Wd)
+            kern.gate_pix_bn_fwd(x, fa, part, G, fb, y, bn_w, bn_b, 1e-5, mean, var, bn_rm, bn_rv, 0.1, bn_nbt, B, Cn, HW)
+        else:
+            kern.srm_conv_fwd(u, pwc, dwc, f, B, H, Wd)
+            kern.act_fwd(f, fa, f.numel(), "gelu")
+            if training:
+                mean, var = _empty((1,), x), _empty((1,), x)
+                ws = _empty((2 * 256,), x)  # CENET_BN_WS_FLOATS(1)
+                kern.bn_stats(fa, HW, B, 1, HW, ws, mean, var, bn_rm, bn_rv, 0.1, bn_nbt)
+            else:
+                mean, var = bn_rm, bn_rv
+            kern.bn_apply(fa, HW, fb, HW, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, 1, HW)
+            kern.gate_pix_fwd(x, fb, y, B, Cn, HW)
         ctx.save_for_backward(x, pwc, dwc, u, amax, f, fa, fb, mean, var, bn_w, bn_b)
         ctx.refs = (pwc, dwc, bn_w, bn_b)
         ctx.training = training
+        ctx.fused = fused
         return y
 
     @staticmethod
@@ -2772,19 +2785,23 @@ class SRMFn(Function):
         HW = H * Wd
         dfb = torch.empty_like(f)
         kern.gate_pix_bwd_reduce(x, g, fb, dfb, B, Cn, HW)
-        dfa = torch.empty_like(f)
-        ws = _empty((2 * 256,), x)  # CENET_BN_WS_FLOATS(1)
         dg, db = grad_buf(ctx.refs[2]), grad_buf(ctx.refs[3])
         if dg is None:
             dg, db = _zeros((1,), x), _zeros((1,), x)
-        kern.bn_bwd(dfb, HW, fa, HW, dfa, HW, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, 1, HW, ws, dg, db)
-        df = torch.empty_like(f)
-        kern.act_bwd(f, dfa, df, f.numel(), "gelu")
         du = torch.empty_like(u)
         dp, dd = grad_buf(ctx.refs[0]), grad_buf(ctx.refs[1])
         if dp is None:
             dp, dd = _zeros(pwc.shape, x), _zeros(dwc.shape, x)
-        kern.srm_conv_bwd(u, df, pwc, dwc, du, dp, dd, B, H, Wd)
+        if ctx.fused:
+            part2 = _empty((kern.srm_parts(B, H, Wd), 2), x)
+            kern.srm_conv_bn_bwd(u, dfb, fa, f, mean, var, 1e-5, bn_w, pwc, dwc, part2, du, dp, dd, dg, db, B, H, Wd)
+        else:
+            dfa = torch.empty_like(f)
+            ws = _empty((2 * 256,), x)  # CENET_BN_WS_FLOATS(1)
+            kern.bn_bwd(dfb, HW, fa, HW, dfa, HW, mean, var, 1e-5, bn_w, bn_b, "none", 0.0, B, 1, HW, ws, dg, db)
+            df = torch.empty_like(f)
+            kern.act_bwd(f, dfa, df, f.numel(), "gelu")
+            kern.srm_conv_bwd(u, df, pwc, dwc, du, dp, dd, B, H, Wd)
         dx = torch.empty_like(x)
         kern.srm_bwd_apply(x, g, fb, u, du, amax, dx, B, Cn, HW)
         return (dx,) + (None,) * 8

@@ -841,6 +841,33 @@ int cenet_pool_branch_bwd_acc_bf16(const unsigned short* g, long sgb, const floa
                                    float* dwc_acc, float* dgamma_acc, float* dbeta_acc, int B, int P, int H, int W,
                                    cenet_stream_t stream);
 
+/* Self-test of the wave reductions every kernel's block reductions rest on (common.h wave_sum / wave_max / wave_min_i on the
+ * DPP path): wave w reduces x[64 w .. 64 w + 64) -> sums[w], maxs[w], mins[w] = min over lanes of (int)(1024 x) + lane, as lane 0
+ * holds them, and the same three at [nwaves + w] as lane 37 holds them (each array: 2 nwaves entries). */
+int cenet_selftest_wave_reduce(const float* x, float* sums, float* maxs, int* mins, int nwaves, cenet_stream_t stream);
+
+/* SRM tail without separate activation / BatchNorm launches (stats.hip, round 5; cfam.py:93-101 after the channel statistics,
+ * training mode): cenet_srm_conv_gelu_fwd_f32 writes f = pwc(u) + dwc(u), fa = GELU(f) and cenet_srm_parts(B, H, W) (count, mean, M2)
+ * triples; cenet_gate_pix_bn_fwd_* folds them (exact in any order), writes y = x * sigmoid(fb) with fb = BatchNorm(fa) ([B, HW],
+ * also stored), the batch mean / biased variance, and updates the running statistics; cenet_srm_conv_bn_bwd_acc_f32 takes dfb (the
+ * gradient of fb, from cenet_gate_pix_bwd_reduce_*) and does BatchNorm backward, GELU' and the conv backward (du [B, 3, H, W]; the
+ * conv and BatchNorm parameter gradients ADDED into; part2_ws: 2 * cenet_srm_parts floats).  H * W <= 4096. */
+int cenet_srm_fused_supported(int B, int H, int W);
+int cenet_srm_parts(int B, int H, int W);
+int cenet_srm_conv_gelu_fwd_f32(const float* u, const float* pwc, const float* dwc, float* f, float* fa, float* part, int B, int H,
+                                int W, cenet_stream_t stream);
+int cenet_gate_pix_bn_fwd_f32(const float* x, const float* fa, const float* part, int G, float* fb, float* y, const float* gamma,
+                              const float* beta, float eps, float* mean, float* var, float* running_mean, float* running_var,
+                              float momentum, long* num_batches_tracked, int B, int C, int HW, cenet_stream_t stream);
+int cenet_gate_pix_bn_fwd_bf16(const unsigned short* x, const float* fa, const float* part, int G, float* fb, unsigned short* y,
+                               const float* gamma, const float* beta, float eps, float* mean, float* var, float* running_mean,
+                               float* running_var, float momentum, long* num_batches_tracked, int B, int C, int HW,
+                               cenet_stream_t stream);
+int cenet_srm_conv_bn_bwd_acc_f32(const float* u, const float* dfb, const float* fa, const float* f, const float* mean,
+                                  const float* var, float eps, const float* gamma, const float* pwc, const float* dwc,
+                                  float* part2_ws, float* du, float* dpwc_acc, float* ddwc_acc, float* dgamma_acc, float* dbeta_acc,
+                                  int B, int H, int W, cenet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -181,3 +181,38 @@ def test_dw_gelu_fused_equals_the_launch_chain(dev, shape, dil, dt, monkeypatch)
     tol = 2e-2 if dt == BF else 2e-5
     for k, name in enumerate(("y", "dx", "dw", "db")):
         assert _rel(res[1][k], res[0][k]) < tol, (name, _rel(res[1][k], res[0][k]))
+
+
+@pytest.mark.parametrize("shape", [(3, 10, 7, 7), (2, 12, 14, 14), (2, 8, 24, 40), (32, 6, 7, 7)])
+@pytest.mark.parametrize("dt", [torch.float32, BF], ids=["f32", "bf16"])
+def test_srm_fused_tail_equals_the_launch_chain(dev, shape, dt, monkeypatch):
+    """cfam.py:93-101: conv + GELU + BatchNorm(1) + gate with the statistics folded by the gate kernel (3 + 4 launches) against the
+    6 + 6 launches of the chain; running statistics and the batch counter included"""
+    from cenet_amd.networks.cenet.modules.cfam import SRM
+    B, Cn, H, W = shape
+    g = torch.Generator().manual_seed(H + B)
+    x0 = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    cot = torch.randn(B, Cn, H, W, generator=g).to(dt).to(dev)
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(kern, "_NO_CHANLOC", not fused)
+        torch.manual_seed(1)
+        m = SRM().to(dev).train()
+        with torch.no_grad():
+            m.bn.weight.fill_(1.3), m.bn.bias.fill_(-0.2)
+        x = x0.clone().requires_grad_(True)
+        for p_ in m.parameters():
+            p_.grad = torch.zeros_like(p_)
+        calls = []
+        orig = kern.srm_conv_gelu_fwd
+        monkeypatch.setattr(kern, "srm_conv_gelu_fwd", lambda *a, _o=orig, **k: (calls.append(1), _o(*a, **k))[1])
+        y = m(x)
+        assert bool(calls) == fused
+        y.backward(cot)
+        ops.wgrad_join()
+        res.append([y.detach(), x.grad] + [p_.grad for p_ in m.parameters()] + [m.bn.running_mean.clone(), m.bn.running_var.clone()])
+        assert int(m.bn.num_batches_tracked) == 1
+        monkeypatch.setattr(kern, "srm_conv_gelu_fwd", orig)
+    tol = 2e-2 if dt == BF else 1e-4
+    for a, b in zip(res[1], res[0]):
+        assert (a.float() - b.float()).norm().item() <= tol * b.float().norm().item() + 1e-6, (a.shape, _rel(a, b))

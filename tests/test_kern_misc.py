@@ -253,3 +253,31 @@ def test_zero_fill_of_odd_sized_bf16_buffers(dev, n, off):
     out = buf.float().cpu()
     assert torch.all(out[off:off + n] == 0)
     assert torch.all(out[:off] == 3.0) and torch.all(out[off + n:] == 3.0)
+
+
+def test_dpp_wave_reductions(dev):
+    """common.h wave_sum_dpp / wave_max_dpp / wave_min_i_dpp (round 5: the wave reductions of every kernel): against numpy on
+    random, all-negative and single-outlier waves; on the host checker the same entry runs the shuffle forms."""
+    import ctypes as C
+    import numpy as np
+    from cenet_amd import _lib, kern
+    g = torch.Generator().manual_seed(4)
+    nw = 37
+    x = torch.randn(nw, 64, generator=g)
+    x[1] = -x[1].abs() - 1.0          # all negative: a zero-filled (bound_ctrl) DPP source would corrupt the maximum
+    x[2] = 0.0
+    x[2, 63] = 5.0                    # the result lane itself
+    x[3] = 0.0
+    x[3, 0] = -7.0
+    xd = x.to(dev)
+    sums, maxs = torch.empty(2 * nw).to(dev), torch.empty(2 * nw).to(dev)
+    mins = torch.empty(2 * nw, dtype=torch.int32).to(dev)
+    rc = _lib.lib().cenet_selftest_wave_reduce(kern.P(xd), kern.P(sums), kern.P(maxs), kern.P(mins), C.c_int(nw), kern.stream())
+    assert rc == 0
+    if dev.type != "cpu":
+        torch.cuda.synchronize()
+    np.testing.assert_allclose(sums.cpu().numpy(), x.double().sum(1).repeat(2).numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(sums[:nw], sums[nw:])  # (lane 0 and lane 37 hold the same bits)
+    assert torch.equal(maxs.cpu(), x.max(1).values.repeat(2))
+    want = ((x * 1024.0).to(torch.int32) + torch.arange(64, dtype=torch.int32)).min(1).values
+    assert torch.equal(mins.cpu(), want.repeat(2))
