@@ -450,18 +450,24 @@ __global__ __launch_bounds__(256, HDP > 32 ? 1 : (HDP <= 16 ? 3 : 2)) void dattn
       for (int kd = 0; kd < NKD; ++kd) vf[kd] = da_rm(Vimg, G::VPR, r, 16 * kd, hh);
 #pragma unroll
       for (int s = 0; s < NH; ++s) {
-        f32x16 S = da_zero(), dP = da_zero();
+        // the query is the MFMA column: its delta is a lane constant, so the dP chain can start from -delta (dP - delta comes out
+        // of the accumulator: one VALU instruction per score less).  Not at HDP = 16: a zero accumulator is an inline constant of
+        // the first MFMA, a -delta one is 16 live registers more, and that instance sits on its 168-register cap (30 spilled).
+        constexpr bool INITD = HDP > 16;
+        f32x16 S = da_zero(), dP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dP[i] = INITD ? -dl[s] : 0.f;
 #pragma unroll
         for (int sp = (ONE ? 0 : s); sp <= (ONE ? 1 : s); ++sp)
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks) S = DA_MFMA(da_rm(Kimg, G::KP, r, sp * HDP + 16 * ks, hh), qf[sp][ks], S);
 #pragma unroll
-        for (int kd = 0; kd < NKD; ++kd) dP = DA_MFMA(vf[kd], gf[s][kd], dP);  // dP^T[key][query] = V dU^T
+        for (int kd = 0; kd < NKD; ++kd) dP = DA_MFMA(vf[kd], gf[s][kd], dP);  // dP^T[key][query] = V dU^T - delta
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           float p = da_exp2(S[i] * c - lse2[s]);
           if (MASKED && da_row(i, hh) >= klim) p = 0.f;
-          S[i] = p * (dP[i] - dl[s]);
+          S[i] = INITD ? p * dP[i] : p * (dP[i] - dl[s]);
         }
         // dQ^T[d][query] += K^T[d][key] dS^T[key][query]; accumulator rows >= hd (the other head's columns, padding) are
         // never stored

@@ -1179,3 +1179,15 @@ def set_compute_bf16(on: bool) -> bool:
 
 def get_compute_bf16() -> bool:
     return _COMPUTE_BF16
+
+
+def augment_acdc(pool_img, pool_lab, tab, dp, stage_img, stage_lab, stage_stride, max_h, max_w, out_img, out_lab, B, OH, OW):
+    """cenet_augment_acdc (augment.hip): gather + augment one training batch from the device-resident slices"""
+    assert pool_img.dtype == torch.float32 and pool_lab.dtype == torch.uint8 and tab.dtype == torch.int64 and dp.dtype == torch.float64
+    assert stage_img.dtype == torch.float64 and stage_lab.dtype == torch.uint8 and out_img.dtype == torch.float32
+    for t in (pool_img, pool_lab, tab, dp, stage_img, stage_lab, out_img, out_lab):
+        assert t.is_contiguous()
+    rc = _lib.lib().cenet_augment_acdc(P(pool_img), P(pool_lab), P(tab), P(dp), P(stage_img), P(stage_lab), L(stage_stride),
+                                       C.c_int(max_h), C.c_int(max_w), P(out_img), P(out_lab), C.c_int(B), C.c_int(OH), C.c_int(OW),
+                                       stream())
+    _lib.check(rc, "cenet_augment_acdc")

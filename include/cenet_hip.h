@@ -868,6 +868,20 @@ int cenet_srm_conv_bn_bwd_acc_f32(const float* u, const float* dfb, const float*
                                   float* part2_ws, float* du, float* dpwc_acc, float* ddwc_acc, float* dgamma_acc, float* dbeta_acc,
                                   int B, int H, int W, cenet_stream_t stream);
 
+/* The ACDC training-time augmentation on the device (augment.hip, round 5; replaces RandomGenerator.__call__,
+ * src/datasets/dataset_acdc.py:32-48 with random_rot_flip :15-22 and random_rotate :25-29, for a whole batch).  The training
+ * slices live in two device pools (pool_img fp32, pool_lab uint8, same element offsets).  Per sample b:
+ *   tab[8 b ..]  = offset, H, W, mode (0 none / 1 quarter turns + flip / 2 rotation), k, axis, resize flag, 0
+ *   dp[10 b ..]  = rotation matrix m00 m01 m10 m11, offset0, offset1 (scipy.ndimage.rotate's, mode 2 only);
+ *                  pole^(Ha-1), pole^(Wa-1) with pole = sqrt(3) - 2 and (Ha, Wa) the size after stage 1; (Ha-1)/(OH-1), (Wa-1)/(OW-1)
+ * all computed by the host in fp64 (cenet_amd/data.py DeviceAugmenter.draw, which consumes `random` / `np.random` in the
+ * reference's order).  stage_img (fp64) / stage_lab (uint8): B * stage_stride elements of scratch, stage_stride >= max_h * max_w
+ * >= every sample's H * W.  out_img [B, 1, OH, OW] fp32, out_lab [B, OH, OW] fp32 (class indices).  Labels are bit-identical to
+ * the reference's, images to fp64 rounding of the same operation order. */
+int cenet_augment_acdc(const float* pool_img, const unsigned char* pool_lab, const long* tab, const double* dp, double* stage_img,
+                       unsigned char* stage_lab, long stage_stride, int max_h, int max_w, float* out_img, float* out_lab, int B,
+                       int OH, int OW, cenet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
