@@ -4,7 +4,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ... import kern
+from ... import kern, ops
 from .decoders import Decoder
 from .encoder import get_encoder2d
 from .out import OutHead
@@ -56,6 +56,21 @@ class CENet(nn.Module):
             x = kern.cast(x, torch.bfloat16)
         # grayscale input: the 3-channel replication of net.py:55 is a zero-stride channel read in patch_embed1
         x1, x2, x3, x4 = self.backbone(x)
+        # the head's full-resolution residual block reads only x (out.py:69): it runs on a branch stream (ops.branch_stream) beside
+        # the decoder's small-map levels, whose launches leave most of the chip idle, and joins in OutHead.forward; its backward
+        # (weight gradients only) is held until the decoder's backward has reached x4 and then runs beside encoder stages 4 and 3
+        rb = None
+        bs = ops.branch_stream(x)
+        if bs is not None:
+            cur = torch.cuda.current_stream(x.device)
+            bs.wait_stream(cur)
+            gate = ops.BranchGate() if (self.training and x4.requires_grad and ops.branch_gate_enabled()) else None
+            with torch.cuda.stream(bs):
+                rb = self.out.branch(x)
+                if gate is not None:
+                    rb = gate.hold(rb)
+            if gate is not None:
+                x4.register_hook(gate.release)
         sync = getattr(self, "_grad_sync", None)
         if sync is not None and self.training and x4.requires_grad:
             # gradient-arena segments (cenet_amd.optim.cenet_segments) become final when backward reaches these
@@ -63,4 +78,4 @@ class CENet(nn.Module):
             for i, t in enumerate((x4, x3, x2, x1)):
                 t.register_hook(sync.hook(i))
         dec = self.decoder(x4, [x3, x2, x1])
-        return self.out(dec, x)
+        return self.out(dec, x, rb=rb)

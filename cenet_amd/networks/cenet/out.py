@@ -29,8 +29,20 @@ class OutHead(nn.Module):
             UnetResBlock(2, x_in_channels, om, kernel_size=5, stride=1, norm_name='batch', act_name=act, dropout=0),
             nn.MaxPool2d(kernel_size=2, stride=2))
 
-    def forward(self, dec, x):
-        rb = self.rb[0](x, self.w)  # w * MaxPool2(ResBlock5x5(x)): block tail and pool fused (UnetResBlock.forward)
+    def branch(self, x):
+        """w * MaxPool2(ResBlock5x5(x)) (out.py:69): block tail and pool fused (UnetResBlock.forward).  Depends on the input image
+        only — CENet._forward launches it on a branch stream ahead of the encoder and hands the result to forward(rb=...)"""
+        return self.rb[0](x, self.w)
+
+    def forward(self, dec, x, rb=None):
+        if rb is None:
+            rb = self.branch(x)
+        elif rb.is_cuda:
+            cur = torch.cuda.current_stream(rb.device)
+            bs = ops.branch_stream(rb)
+            if bs is not None:
+                cur.wait_stream(bs)
+                rb.record_stream(cur)
         d = self.up(dec)
         z = ops.concat2(d, rb)
         y = self.out[1](self.out[0](z))

@@ -56,16 +56,22 @@ class _ZeroWs:
     front of every use (the dK / dV accumulator of the spatial-reduction attention backward: 7 fills per step).
     A buffer that is taken stays IN USE until give_back_as: a second taker of the same size gets a buffer of its own (up to
     `MAX_LIVE` per size; beyond that the oldest is taken to be the leftover of a pass that raised between the two launches and is
-    filled again).  Single-stream contract: take -> kernel -> give_back_as run on ONE stream (the buffers carry no events)."""
+    filled again).  Single-stream contract: take -> kernel -> give_back_as run on ONE stream (the buffers carry no events) — the
+    key holds the stream, so the branch streams of branch_stream() each own their buffers."""
     bufs: dict = {}  # key -> [[tensor, in_use], ...]
     MAX_LIVE = 4
+
+    @staticmethod
+    def _key(dev, n):
+        sid = torch.cuda.current_stream(dev).stream_id if dev.type == "cuda" else 0
+        return (dev.type, dev.index, n, sid)
 
     @staticmethod
     def take(shape, ref: Tensor) -> Tensor:
         n = 1
         for v in shape:
             n *= int(v)
-        es = _ZeroWs.bufs.setdefault((ref.device.type, ref.device.index, n), [])
+        es = _ZeroWs.bufs.setdefault(_ZeroWs._key(ref.device, n), [])
         e = next((e for e in es if not e[1]), None)
         if e is None:
             if len(es) < _ZeroWs.MAX_LIVE:
@@ -83,7 +89,7 @@ class _ZeroWs:
         """-> a tensor of like's dtype (bf16) holding ws (+ bias over the last axis); ws is zero again"""
         out = torch.empty(ws.shape, device=ws.device, dtype=like.dtype)
         kern.cast_clear(ws, out, bias)
-        for e in _ZeroWs.bufs.get((ws.device.type, ws.device.index, ws.numel()), ()):
+        for e in _ZeroWs.bufs.get(_ZeroWs._key(ws.device, ws.numel()), ()):
             if e[0].data_ptr() == ws.data_ptr():
                 e[1] = False
         return out
@@ -187,6 +193,7 @@ class _WgradState:
         self.held = 0      # their bytes
         self.task = None   # autograd graph task whose end-of-backward callback is queued
         self.ln_items = []  # (partial buffer, dgamma, dbeta) of LayerNorm backward launches: folded by ONE launch at the flush
+        self.rec_streams = []  # the streams the recorded operands were produced on (branch_stream(): more than one)
         # --- the weight-gradient stream
         self.stream = None
         self.events = None
@@ -200,6 +207,20 @@ class _WgradState:
         items, self.items = self.items, []
         ln, self.ln_items = self.ln_items, []
         self.held = 0
+        if self.rec_streams:
+            # operands recorded from a branch stream: the flushing stream is ordered after that stream, and the allocator is told
+            # that the operands are read here as well
+            cur = torch.cuda.current_stream(self.device)
+            other = [r for r in self.rec_streams if r != cur]
+            self.rec_streams = []
+            for r in other:
+                cur.wait_stream(r)
+            if other:
+                for pair in self.keep:
+                    for t in pair:
+                        t.record_stream(cur)
+                for part, _, _ in ln:
+                    part.record_stream(cur)
 
         def go():
             if ln:
@@ -231,6 +252,75 @@ class _WgradState:
 
 
 _WG = {}
+
+# ---- branch streams: independent sub-graphs of the network on a second HIP stream -------------------------------------------
+# The out head's 5x5 residual block reads only the input image (out.py:69): it can run on branch stream 0 beside the decoder, whose
+# small-map kernels leave most of the chip idle; autograd runs each backward node on its forward's stream, so the block's backward
+# (weight gradients only: the image needs no gradient) overlaps the rest of the backward pass the same way (BranchGate chooses
+# where).  Under hipGraph capture the fork / join become graph edges.
+# OFF by default — measured, round 5, same box, ACDC step under hipGraph replay: 18.72 / 18.78 ms without, 19.00 / 19.00 ms with
+# the branch beside the decoder (backward held to x4 or not), 19.01 ms with it beside encoder stage 1.  The replayed graph then
+# spreads its nodes over two hardware queues (486 / 372 kernels in the trace) and pays a cross-queue dependency at every hand-over;
+# that costs more than the ~0.9 ms of residual-block work hidden.  set_branch_streams(True) / CENET_BRANCH_STREAMS=1 turn it on.
+_BRANCH: dict = {}
+_BRANCH_ON = [os.environ.get("CENET_BRANCH_STREAMS") is not None]
+
+
+def set_branch_streams(on: bool) -> bool:
+    old, _BRANCH_ON[0] = _BRANCH_ON[0], bool(on)
+    return old
+
+
+def branch_stream(ref: Tensor, i: int = 0):
+    """branch stream i of ref's device, or None where there are no streams (CPU tensors, the host checker) or it is disabled"""
+    if not _BRANCH_ON[0] or not ref.is_cuda or kern._lib.is_hostsim():
+        return None
+    key = (ref.device.index, i)
+    st = _BRANCH.get(key)
+    if st is None:
+        st = _BRANCH[key] = torch.cuda.Stream(ref.device)
+    return st
+
+
+def branch_gate_enabled() -> bool:
+    return os.environ.get("CENET_BRANCH_GATE", "1") != "0"
+
+
+class _HoldFn(Function):
+    @staticmethod
+    def forward(ctx, t, gate):
+        ctx.gate = gate
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        ev = ctx.gate.event
+        if ev is not None and g.is_cuda:
+            torch.cuda.current_stream(g.device).wait_event(ev)  # (this node runs on its forward's stream: the branch stream)
+        return g, None
+
+
+class BranchGate:
+    """Holds the BACKWARD of a branch-stream sub-graph until some other point of the backward pass has been reached:
+    `y = gate.hold(y)` at the end of the branch (on the branch stream), `t.register_hook(gate.release)` on the tensor whose
+    gradient marks that point.  Without the release the hold does nothing."""
+
+    def __init__(self):
+        self.event = None
+
+    def hold(self, t: Tensor) -> Tensor:
+        return _HoldFn.apply(t, self)
+
+    def release(self, grad):
+        if grad.is_cuda:
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(grad.device))
+        return None
+
+
+def branch_streams(device) -> list:
+    """the branch streams created so far on `device` (GradReducer orders the collective after them)"""
+    return [s for (d, _), s in _BRANCH.items() if d == device.index]
 
 
 def _wg(device) -> _WgradState:
@@ -351,6 +441,10 @@ def _wgrad_defer(A: Tensor, a_off: int, lda: int, skbA: int, B: Tensor, b_off: i
 def _defer_begin(st) -> int:
     """before a record: the current autograd graph task; drops the records of a pass that never reached its end"""
     tid = _graph_task_id() if _graph_task_id is not None else 0
+    if st.device.type == "cuda" and _BRANCH:
+        cur = torch.cuda.current_stream(st.device)
+        if cur not in st.rec_streams:
+            st.rec_streams.append(cur)
     if not _WgradCfg.hold and (st.items or st.ln_items) and st.task is not None and tid != st.task:
         # records of a backward pass that never reached its end (it raised: the engine runs no callbacks then).  Their
         # gradients are void; adding them into a later pass's would be wrong, and they must not block that pass's own callback.

@@ -63,6 +63,8 @@ class GradReducer:
             wg = ops.wgrad_stream()
             if wg is not None:
                 self.side.wait_stream(wg)
+            for bs in ops.branch_streams(buf.device):  # gradients produced on a branch stream (the head's residual block)
+                self.side.wait_stream(bs)
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 if self.bf16_buckets:

@@ -83,3 +83,32 @@ def test_replay_trains_like_eager(mode):
     finally:
         kern.set_compute_bf16(old_bf)
         ops.set_wgrad_overlap(old_ov)
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph", "segmented"])
+def test_branch_streams_train_alike(mode):
+    """ops.set_branch_streams(True): the head's residual block on a second stream beside the decoder, its backward held to x4
+    (ops.BranchGate) — off by default (measured slower under replay, ops.py) but kept correct: same trajectory as the one-stream
+    step in eager launches, under one captured graph, and under the segmented captures of the N > 1 path."""
+    dev = torch.device("cuda:0")
+    old_bf = kern.set_compute_bf16(True)
+    try:
+        base = _setup(dev)
+        for m in base.modules():
+            if hasattr(m, "drop_prob"):
+                m.drop_prob = 0.0
+        ref, rep = base, copy.deepcopy(base)
+        le, pe = _train(ref, dev, mode, 4)
+        old = ops.set_branch_streams(True)
+        try:
+            lg, pg = _train(rep, dev, mode, 4)
+        finally:
+            ops.set_branch_streams(old)
+        assert ops.branch_streams(dev)  # (the branch really ran on its own stream)
+        for a, b in zip(le, lg):
+            assert abs(a - b) <= 2e-2 * max(1.0, abs(a)), (le, lg)
+        cos = torch.nn.functional.cosine_similarity((pe - pe.mean()).flatten(), (pg - pg.mean()).flatten(), dim=0).item()
+        rel = ((pe - pg).norm() / pe.norm()).item()
+        assert cos > 0.9999 and rel < 2e-3, (cos, rel)
+    finally:
+        kern.set_compute_bf16(old_bf)

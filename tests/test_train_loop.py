@@ -66,3 +66,40 @@ def test_replayed_loop_equals_the_eager_loop_on_changing_batches(bf16):
     assert cos > 0.99999
     # the replayed loop really replayed: one captured graph, eight iterations counted by the optimizer
     assert hg["optimizer"]._steps == 8 and he["optimizer"]._steps == 8
+
+
+@pytest.mark.gpu
+def test_loop_fed_by_the_device_loader_equals_the_host_pipeline():
+    """train_acdc over DeviceTrainLoader (slices resident in HBM, augmentation on the device) against the same loop over the
+    host pipeline (DataLoader(shuffle=True) of RandomGenerator samples, main_acdc.py:136-140) from the same seeds of torch,
+    `random` and `np.random`: same batches in the same order, so the same losses."""
+    import random
+
+    from cenet_amd import data as D, train
+    dev = use_hip()
+    rng = np.random.default_rng(3)
+    shapes = [(216, 256), (154, 224), (224, 224), (256, 208)] * 2
+    samples = [(rng.random(s).astype(np.float32), rng.integers(0, 4, s).astype(np.uint8)) for s in shapes]
+
+    class Host(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(samples)
+
+        def __getitem__(self, i):
+            return D.RandomGenerator([224, 224])({"image": samples[i][0].copy(), "label": samples[i][1].copy()})
+
+    ref_net = _net(dev)
+    losses = []
+    for device_side in (False, True):
+        torch.manual_seed(31)
+        random.seed(4)
+        np.random.seed(4)
+        if device_side:
+            loader = D.DeviceTrainLoader(D.DeviceSlices(samples, dev), (224, 224), batch_size=4, shuffle=True)
+        else:
+            loader = torch.utils.data.DataLoader(Host(), batch_size=4, shuffle=True)
+        h = train.train_acdc(copy.deepcopy(ref_net), loader, max_epochs=2, base_lr=0.01, device=dev, graph=True, log_every=1,
+                             log=lambda s: None)
+        losses.append(np.array([v for _, v in h["loss"]]))
+    assert len(losses[0]) == len(losses[1]) == 4
+    assert np.abs(losses[0] - losses[1]).max() < 2e-4, losses
