@@ -230,15 +230,18 @@ struct ConvWgradArgs {
 
 __device__ __forceinline__ unsigned funnel16(unsigned lo, unsigned hi) { return (lo >> 16) | (hi << 16); }
 
-template <int CIN, int COUT, int KS, int TH_>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs a) {
+// NW waves per workgroup: 4 (two workgroups per CU) or 8 (one: the 64 x 64 instance — 16 pairs x 9 taps = 144 accumulator registers
+// per lane at 4 waves, 356 bytes of scratch per lane under the 256-register cap; at 8 waves a lane holds 72)
+template <int CIN, int COUT, int KS, int TH_, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wgrad_direct_kernel(ConvWgradArgs a) {
+  constexpr int NT = 64 * NW;
   constexpr int P = KS / 2, HH = TH_ + KS - 1, KK = KS * KS;
   constexpr int XROW = 24;                                   // dwords per halo row: 8 px pad + 32 px + 8 px pad
   constexpr int XPL = HH * XROW + (12 - (HH * XROW) % 8) % 8;  // ci plane stride in dwords, == 4 (mod 8): conflict-free b128
   constexpr int GPL = TH_ * 16 + (12 - (TH_ * 16) % 8) % 8;    // co plane stride of dY
   static_assert(XPL % 8 == 4 && GPL % 8 == 4, "plane strides must be 4 mod 8 dwords");
-  constexpr int NCI = CIN / 16, NCO = COUT / 16, PAIRS = NCI * NCO, NPW = PAIRS / 4;
-  static_assert(PAIRS % 4 == 0 && (NPW <= NCI) && (NCI % NPW == 0), "a wave's pairs share one output-channel tile");
+  constexpr int NCI = CIN / 16, NCO = COUT / 16, PAIRS = NCI * NCO, NPW = PAIRS / NW;
+  static_assert(PAIRS % NW == 0 && (NPW <= NCI) && (NCI % NPW == 0), "a wave's pairs share one output-channel tile");
   __shared__ __attribute__((aligned(16))) unsigned Xs[CIN * XPL];
   __shared__ __attribute__((aligned(16))) unsigned Gs[COUT * GPL];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
@@ -261,28 +264,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
   // same for every tile (chunk number = tid + 256 q): their LDS offsets and image-relative offsets are computed once.  The chunks of
   // tile t + 1 are fetched into registers BEFORE tile t is multiplied and written to LDS after it — the kernel was parked on its
   // loads and barriers 62 - 66 % of the time (SQ_WAIT_ANY) with 4-byte loads issued and waited for between the tiles.
+  // A thread's chunks are the same for every tile (chunk number = tid + NT q); their coordinates are recomputed from that number
+  // at every use (divisions by constants) rather than held in registers: the arrays cost 39 registers of the 256.
   constexpr int NXC = CIN * HH * 6, NGC = COUT * TH_ * 4;
-  constexpr int QX = (NXC + 255) / 256, QG = (NGC + 255) / 256;
-  int xl[QX], xg[QX], xm[QX];  // LDS dword offset (-1: none), offset in the image batch relative to the tile origin, (hy | chunk << 8)
-  int gl[QG], gg[QG], gm[QG];
-  if (a.vec) {
-#pragma unroll
-    for (int q = 0; q < QX; ++q) {
-      const int u = tid + 256 * q;
-      const int c = u % 6, r2 = u / 6, hy = r2 % HH, ci = r2 / HH;
-      xl[q] = u < NXC ? ci * XPL + hy * XROW + 4 * c : -1;
-      xg[q] = ci * HWp + hy * a.W + 8 * c - 8;
-      xm[q] = hy | (c << 8);
-    }
-#pragma unroll
-    for (int q = 0; q < QG; ++q) {
-      const int u = tid + 256 * q;
-      const int c = u & 3, r2 = u >> 2, yy = r2 % TH_, co = r2 / TH_;
-      gl[q] = u < NGC ? co * GPL + yy * 16 + 4 * c : -1;
-      gg[q] = co * HWp + yy * a.W + 8 * c;
-      gm[q] = yy | (c << 8);
-    }
-  }
+  constexpr int QX = (NXC + NT - 1) / NT, QG = (NGC + NT - 1) / NT;
   uint4 xv[QX], gv[QG];
   auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int b = tile / (a.tiles_x * a.tiles_y), tt = tile - b * (a.tiles_x * a.tiles_y);
@@ -292,24 +277,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
     const bf16_t* gb = a.dy + (long)b * COUT * HWp + (long)y0 * a.W + x0;
 #pragma unroll
     for (int q = 0; q < QX; ++q) {
-      const int iy = y0 - P + (xm[q] & 255), ix = x0 - 8 + 8 * (xm[q] >> 8);
+      const int u = tid + NT * q;
+      const int c = u % 6, r2 = u / 6, hy = r2 % HH, ci = r2 / HH;
+      const int iy = y0 - P + hy, ix = x0 - 8 + 8 * c;
       xv[q] = uint4{0u, 0u, 0u, 0u};
-      if (xl[q] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) memcpy(&xv[q], xb + xg[q], 16);
+      if (u < NXC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) memcpy(&xv[q], xb + (ci * HWp + hy * a.W + 8 * c - 8), 16);
     }
 #pragma unroll
     for (int q = 0; q < QG; ++q) {
-      const int iy = y0 + (gm[q] & 255), ix = x0 + 8 * (gm[q] >> 8);
+      const int u = tid + NT * q;
+      const int c = u & 3, r2 = u >> 2, yy = r2 % TH_, co = r2 / TH_;
+      const int iy = y0 + yy, ix = x0 + 8 * c;
       gv[q] = uint4{0u, 0u, 0u, 0u};
-      if (gl[q] >= 0 && iy < a.H && ix < a.W) memcpy(&gv[q], gb + gg[q], 16);
+      if (u < NGC && iy < a.H && ix < a.W) memcpy(&gv[q], gb + (co * HWp + yy * a.W + 8 * c), 16);
     }
   };
   auto stage = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < QX; ++q)
-      if (xl[q] >= 0) memcpy(&Xs[xl[q]], &xv[q], 16);
+    for (int q = 0; q < QX; ++q) {
+      const int u = tid + NT * q;
+      const int c = u % 6, r2 = u / 6, hy = r2 % HH, ci = r2 / HH;
+      if (u < NXC) memcpy(&Xs[ci * XPL + hy * XROW + 4 * c], &xv[q], 16);
+    }
 #pragma unroll
-    for (int q = 0; q < QG; ++q)
-      if (gl[q] >= 0) memcpy(&Gs[gl[q]], &gv[q], 16);
+    for (int q = 0; q < QG; ++q) {
+      const int u = tid + NT * q;
+      const int c = u & 3, r2 = u >> 2, yy = r2 % TH_, co = r2 / TH_;
+      if (u < NGC) memcpy(&Gs[co * GPL + yy * 16 + 4 * c], &gv[q], 16);
+    }
   };
   const int tile0 = xcd * per + (int)blockIdx.x / G;
   if (a.vec && tile0 < t_end) {
@@ -328,11 +323,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
     __syncthreads();  // the previous tile's fragments are consumed
     // ---- X halo: dwords 3..20 of every (ci, halo row) = pixels x0-2 .. x0+33 ; 8 pairs in flight per thread
     constexpr int NXU = CIN * HH * 18;
-    for (int u0 = tid; u0 < NXU; u0 += 256 * 8) {
+    for (int u0 = tid; u0 < NXU; u0 += NT * 8) {
       unsigned v[8];  // packed pixel pairs, raw bf16
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int u = u0 + 256 * q;
+        const int u = u0 + NT * q;
         v[q] = 0u;
         if (u < NXU) {
           const int d = u % 18, r2 = u / 18, hy = r2 % HH, ci = r2 / HH;
@@ -350,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int u = u0 + 256 * q;
+        const int u = u0 + NT * q;
         if (u < NXU) {
           const int d = u % 18, r2 = u / 18, hy = r2 % HH, ci = r2 / HH;
           Xs[ci * XPL + hy * XROW + 3 + d] = v[q];
@@ -359,11 +354,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
     }
     // ---- dY tile
     constexpr int NGU = COUT * TH_ * 16;
-    for (int u0 = tid; u0 < NGU; u0 += 256 * 8) {
+    for (int u0 = tid; u0 < NGU; u0 += NT * 8) {
       unsigned v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int u = u0 + 256 * q;
+        const int u = u0 + NT * q;
         v[q] = 0u;
         if (u < NGU) {
           const int d = u & 15, r2 = u >> 4, yy = r2 % TH_, co = r2 / TH_;
@@ -381,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_direct_kernel(ConvWgradArgs
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int u = u0 + 256 * q;
+        const int u = u0 + NT * q;
         if (u < NGU) {
           const int d = u & 15, r2 = u >> 4, yy = r2 % TH_, co = r2 / TH_;
           Gs[co * GPL + yy * 16 + d] = v[q];
@@ -485,9 +480,11 @@ extern "C" int cenet_conv_wgrad_direct_bf16(const bf16_t* x, const bf16_t* dy, f
     const int gset = atoi(e);
     if (gset >= 1 && gset < grid) grid = gset;
   }
-  if (k == 5) CENET_LAUNCH((conv_wgrad_direct_kernel<32, 32, 5, 8>), dim3(grid), dim3(256), stream, a);
-  else if (Cout == 64) CENET_LAUNCH((conv_wgrad_direct_kernel<64, 64, 3, 4>), dim3(grid), dim3(256), stream, a);
-  else CENET_LAUNCH((conv_wgrad_direct_kernel<64, 32, 3, 4>), dim3(grid), dim3(256), stream, a);
+  const bool wide = k == 3 && Cout == 64;  // eight waves, one workgroup per CU
+  if (wide && grid > CENET_WGRAD_SLABS / 2) grid = CENET_WGRAD_SLABS / 2;
+  if (k == 5) CENET_LAUNCH((conv_wgrad_direct_kernel<32, 32, 5, 8, 4>), dim3(grid), dim3(256), stream, a);
+  else if (wide) CENET_LAUNCH((conv_wgrad_direct_kernel<64, 64, 3, 4, 8>), dim3(grid), dim3(512), stream, a);
+  else CENET_LAUNCH((conv_wgrad_direct_kernel<64, 32, 3, 4, 4>), dim3(grid), dim3(256), stream, a);
   const int psize = Cin * Cout * k * k;
   CENET_LAUNCH(conv_wgrad_reduce_kernel, dim3(psize / 256, 8), dim3(256), stream, (const float*)ws, dw_acc, grid, psize, Cin,
                k * k);
