@@ -1241,8 +1241,10 @@ _Pragma("unroll")
   })
 }
 
-template <typename T, int EPT>
-__global__ __launch_bounds__(1024) void cfam_front_bwd_kernel(FrontArgs a) {
+// MAXT: the launch's thread count is at most this (512: eight waves, 256 registers per lane — the 16-element instance at the
+// 1024-thread cap of 128 spilled 296 bytes per lane)
+template <typename T, int EPT, int MAXT>
+__global__ __launch_bounds__(MAXT) void cfam_front_bwd_kernel(FrontArgs a) {
   __shared__ float red[16 * 2];
   __shared__ float dzn_s[CCU_MAXB], gate_s[CCU_MAXB], dmean_s[CCU_MAXB], dstd_s[CCU_MAXB], dmax_s[CCU_MAXB], mean_s[CCU_MAXB];
   __shared__ int am_s[CCU_MAXB];
@@ -1416,7 +1418,8 @@ static int cfam_front_launch(const FrontArgs& a, bool bwd, hipStream_t stream) {
   if ((long)a.B * a.HW < 2 || need == 0 || a.B > CCU_MAXB) return CENET_EUNSUPPORTED;
 #define CENET_FRONT(E)                                                                                   \
   {                                                                                                      \
-    if (bwd) CENET_LAUNCH((cfam_front_bwd_kernel<T, E>), dim3(a.C), dim3(nt), stream, a);                \
+    if (bwd && nt <= 512) CENET_LAUNCH((cfam_front_bwd_kernel<T, E, 512>), dim3(a.C), dim3(nt), stream, a); \
+    else if (bwd) CENET_LAUNCH((cfam_front_bwd_kernel<T, E, 1024>), dim3(a.C), dim3(nt), stream, a);     \
     else CENET_LAUNCH((cfam_front_fwd_kernel<T, E>), dim3(a.C), dim3(nt), stream, a);                    \
   }
   if (need <= 2) CENET_FRONT(2)
