@@ -266,7 +266,27 @@ __global__ __launch_bounds__(256) void gemm_group_fold_kernel(GroupArgs ga, cons
   for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float rs = 0.f;
   const bool do_rs = bx == 0 && P.asum && i == 0 && tid < BM;
-  for (int s = 0; s < splits; ++s) {
+  // four slices' loads in flight, added in slice order (a run-time trip count with a dependent add per iteration put one memory
+  // round trip between consecutive slices)
+  int s = 0;
+  for (; s + 4 <= splits; s += 4) {
+    f32x4 v[4][NJ];
+    float r4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* slot = base + (long)(s + k) * TILE_FLOATS;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) memcpy(&v[k][j], slot + ((i * NJ + j) * 256 + tid) * 4, 16);
+      if (do_rs) r4[k] = slot[BM * BN + tid];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[j] += v[k][j];
+      rs += r4[k];
+    }
+  }
+  for (; s < splits; ++s) {
     const float* slot = base + (long)s * TILE_FLOATS;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {

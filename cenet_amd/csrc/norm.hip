@@ -408,8 +408,17 @@ __global__ __launch_bounds__(1024) void ln_fold_group_kernel(LnFoldArgs a) {
   const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
   if (blockIdx.x * 32 >= C2) return;
   float s = 0.f;
-  if (col < C2)
-    for (int r = rl; r < d.nrows; r += 32) s += d.part[(long)r * C2 + col];
+  if (col < C2) {
+    // eight independent loads in flight per thread (one dependent add per ~1 us round trip otherwise: 56 us for 47 MB)
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = rl;
+    for (; r + 7 * 32 < d.nrows; r += 8 * 32) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a8[k] += d.part[(long)(r + 32 * k) * C2 + col];
+    }
+    for (; r < d.nrows; r += 32) a8[0] += d.part[(long)r * C2 + col];
+    s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  }
   red[rl][threadIdx.x & 31] = s;
   __syncthreads();
   if (rl == 0 && col < C2) {

@@ -162,7 +162,7 @@ def test_sra_backward_accumulator_is_zero_at_rest(dev, monkeypatch):
     a = run()
     b = run()
     assert len(takes) == 2
-    key = (dev.type, dev.index, kv.numel())
+    key = ops._ZeroWs._key(dev, kv.numel())
     assert all(e[1] is False and float(e[0].abs().max()) == 0.0 for e in ops._ZeroWs.bufs[key])
     # an interrupted use (a taker that never gave its accumulator back) does not reach the next taker: it gets a buffer of its
     # own, two live takers of one size never alias, and once MAX_LIVE leftovers pile up the oldest is filled again and reused
@@ -266,7 +266,7 @@ def test_split_k_linear_tail_is_one_pass(dev, monkeypatch):
     assert y1.dtype == BF and torch.equal(y1, y2) if dev.type == "cpu" else True
     torch.testing.assert_close(y1.float(), ref.float(), rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(y2.float(), ref.float(), rtol=2e-2, atol=2e-2)
-    key = (dev.type, dev.index, R * N)
+    key = ops._ZeroWs._key(dev, R * N)
     assert all(e[1] is False and float(e[0].abs().max()) == 0.0 for e in ops._ZeroWs.bufs[key])
 
 
