@@ -32,18 +32,22 @@ struct ConvDirectArgs {
   int B, H, W, dgrad, tiles_x, tiles_y, ntiles;
 };
 
-template <int CIN, int COUT, int KS>
-__global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv_direct_bf16_kernel(ConvDirectArgs a) {
+// NW waves per workgroup: 4, or 8 for the 64 -> 64 instance — its LDS image (117 KB) allows one workgroup per CU, and at four waves
+// (365 registers: 64 accumulators, 88 for the prefetched halo) that was ONE wave per SIMD with nothing to cover an LDS read; eight
+// waves own one tile row each (32 accumulators, half the halo slots: under 256 registers, two waves per SIMD)
+template <int CIN, int COUT, int KS, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 || (CIN == 64 && COUT == 64)) ? 1 : 2) void conv_direct_bf16_kernel(ConvDirectArgs a) {
+  constexpr int NT = 64 * NW, RPW = TH / NW, NI = 2 * RPW;  // tile rows per wave, (row, x-segment) pairs per wave
   constexpr int CQ = CIN / 8, HH = TH + KS - 1, HW_ = TW + KS - 1, KK = KS * KS, PADK = KS / 2;
   constexpr int UNITS = CQ * HH * HW_;           // 16-byte halo slots
-  constexpr int UPT = (UNITS + 255) / 256;       // slots per thread
+  constexpr int UPT = (UNITS + NT - 1) / NT;     // slots per thread
   constexpr int MT = COUT / 16;                  // output-channel tiles
   __shared__ __attribute__((aligned(16))) bf Ws[KK * CQ * COUT * 8];
   __shared__ __attribute__((aligned(16))) bf Xs[UNITS * 8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
 
   // ---- weights -> LDS once per workgroup: Ws[((tap*CQ + ci/8)*COUT + co)*8 + ci%8]
-  for (int e = tid; e < KK * CIN * COUT; e += 256) {
+  for (int e = tid; e < KK * CIN * COUT; e += NT) {
     const int t = e % KK, rest = e / KK;
     int co, ci;
     float v;
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
   long uoff[UPT];
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
-    const int s = tid + 256 * u;
+    const int s = tid + NT * u;
     const int cq = s / (HH * HW_), rem = s - cq * (HH * HW_);
     uhy[u] = (s < UNITS) ? rem / HW_ - PADK : -(1 << 20);  // out-of-range slots fail every row test
     uhx[u] = rem % HW_ - PADK;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
   auto store_halo = [&]() {
 #pragma unroll
     for (int u = 0; u < UPT; ++u) {
-      const int s = tid + 256 * u;
+      const int s = tid + NT * u;
       if (s < UNITS) {
         unsigned pk[4];
 #pragma unroll
@@ -116,12 +120,12 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
     const int nxt = tile + nloc;
     if (nxt < t_end) load_halo(nxt);  // next halo flies under this tile's MFMAs
 
-    f32x4 acc[MT][4];
+    f32x4 acc[MT][NI];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // wave w owns tile rows 2w, 2w+1 ; ni -> (row = 2w + ni/2, xseg = 16*(ni&1))
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // wave w owns tile rows RPW w .. RPW w + RPW - 1 ; ni -> (row = RPW w + ni/2, xseg = 16*(ni&1))
     // fully unrolled: every LDS address below is one per-lane base plus a compile-time offset (the rolled loop spent ~35
     // VALU instructions per tap on divisions and address arithmetic — the kernel was VALU-bound, not MFMA- or HBM-bound)
 #pragma unroll
@@ -134,8 +138,8 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) memcpy(&wf[mi], &Ws[((t * CQ + kb * 4 + fq) * COUT + mi * 16 + fr) * 8], 16);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int row = 2 * wave + (ni >> 1), xs = 16 * (ni & 1);
+        for (int ni = 0; ni < NI; ++ni) {
+          const int row = RPW * wave + (ni >> 1), xs = 16 * (ni & 1);
           bf16x8 xf;
           memcpy(&xf, &Xs[(((kb * 4 + fq) * HH + row + ky) * HW_ + xs + fr + kx) * 8], 16);
 #pragma unroll
@@ -148,8 +152,8 @@ __global__ __launch_bounds__(256, ((CIN == 64 && COUT == 64) ? 1 : 2)) void conv
     const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
     bf16_t* yb = a.y + (long)b * COUT * HWp;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int oy = ty * TH + 2 * wave + (ni >> 1), ox = tx * TW + 16 * (ni & 1) + 4 * fq;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int oy = ty * TH + RPW * wave + (ni >> 1), ox = tx * TW + 16 * (ni & 1) + 4 * fq;
       if (oy < a.H && ox < a.W) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
@@ -194,13 +198,13 @@ extern "C" int cenet_conv_direct_bf16(const bf16_t* x, const float* w, bf16_t* y
   const int slots = two ? 512 : 256;
   int grid = a.ntiles < slots ? a.ntiles : slots;
   if (k == 5 && Cin == 32 && Cout == 32) {
-    CENET_LAUNCH((conv_direct_bf16_kernel<32, 32, 5>), dim3(grid), dim3(256), stream, a);
+    CENET_LAUNCH((conv_direct_bf16_kernel<32, 32, 5, 4>), dim3(grid), dim3(256), stream, a);
   } else if (k == 3 && Cin == 64 && Cout == 64) {
-    CENET_LAUNCH((conv_direct_bf16_kernel<64, 64, 3>), dim3(grid), dim3(256), stream, a);
+    CENET_LAUNCH((conv_direct_bf16_kernel<64, 64, 3, 8>), dim3(grid), dim3(512), stream, a);
   } else if (k == 3 && Cin == 64 && Cout == 32) {
-    CENET_LAUNCH((conv_direct_bf16_kernel<64, 32, 3>), dim3(grid), dim3(256), stream, a);
+    CENET_LAUNCH((conv_direct_bf16_kernel<64, 32, 3, 4>), dim3(grid), dim3(256), stream, a);
   } else {
-    CENET_LAUNCH((conv_direct_bf16_kernel<32, 64, 3>), dim3(grid), dim3(256), stream, a);
+    CENET_LAUNCH((conv_direct_bf16_kernel<32, 64, 3, 4>), dim3(grid), dim3(256), stream, a);
   }
   CENET_CHECK_LAUNCH();
   return CENET_OK;
