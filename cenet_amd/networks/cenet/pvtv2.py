@@ -156,7 +156,13 @@ class OverlapPatchEmbed(nn.Module):
             t = ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps)
             return t, Ho, Wo
         expand = self.in_chans if (x.shape[1] == 1 and self.in_chans > 1) else 0  # net.py:55 without materialising cat
-        t = ops.conv2d_nchw(x, self.proj.weight, self.proj.bias, stride=s, pad=p, out_layout="tok", expand_channels=expand)
+        if expand and x.dtype == torch.bfloat16:
+            # throughput mode: a conv over `expand` identical copies of one channel is the conv of that channel with the
+            # channel-summed weight — a third of the reduction length (K = 49 instead of 147 for the 7x7 stem); the weight
+            # gradient comes back through the sum's autograd node.  (fp32 parity mode keeps the reference's operation order.)
+            t = ops.conv2d_nchw(x, self.proj.weight.sum(1, keepdim=True), self.proj.bias, stride=s, pad=p, out_layout="tok")
+        else:
+            t = ops.conv2d_nchw(x, self.proj.weight, self.proj.bias, stride=s, pad=p, out_layout="tok", expand_channels=expand)
         t = ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps)
         return t, Ho, Wo
 

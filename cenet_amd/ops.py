@@ -902,9 +902,16 @@ class Conv2dFn(Function):
                           dx, Kd, Ho * Wo, Cout, scr=0, scc=0, scb=sb, nbatch=B, atomic=overlap,
                           col2im=dict(KH=k, KW=k, Pw=Wo, Hs=H, Ws=Wd, stride=stride, pad=pad, sci=sc, sy=sy, sx=sx))
                 dx = kern.cast(dx, x.dtype)
-        dW, db = grad_buf(Wp), grad_buf(bp)
+        # a DERIVED weight (not a leaf: the channel-summed stem weight of OverlapPatchEmbed) has no gradient buffer of its own:
+        # its gradient is computed into a fresh fp32 tensor on this stream and handed to autograd
+        derived = Wp is not None and not Wp.is_leaf
+        if derived:
+            dW = _zeros(Wp.shape, g) if ctx.needs_input_grad[1] else None
+        else:
+            dW = grad_buf(Wp)
+        db = grad_buf(bp)
         if dW is not None or db is not None:
-            with _wgrad_side(g, x):
+            with (contextlib.nullcontext() if derived else _wgrad_side(g, x)):
                 if dW is not None and getattr(ctx, "c1", False) and _bf(g):
                     kern.conv_c1_wgrad(x, g, dW, B, Cout, H, Wd, k)
                 elif (dW is not None and getattr(ctx, "direct", False) and _bf(g)
@@ -921,7 +928,7 @@ class Conv2dFn(Function):
                         kern.chan_dot(g, Cout * Ho * Wo, None, 0, db, B, Cout, Ho * Wo)
                     else:
                         kern.col_sum(g, db, B * Ho * Wo, Cout)
-        return dx, None, None, None
+        return dx, (dW if derived else None), None, None
 
 
 def conv2d_nchw(x, W, b=None, stride=1, pad=0, out_layout="nchw", expand_channels: int = 0):
