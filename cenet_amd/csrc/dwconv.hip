@@ -472,6 +472,87 @@ __device__ __forceinline__ void dwp_stage(const DwPlaneArgs& a, float* tile, int
   __syncthreads();
 }
 
+// Fast form of the two bodies below for W % 4 == 0 and at most 1024 quads per workgroup (28x28: five planes, 56x56: one): a
+// thread OWNS its <= 4 quads — their loads are issued together on clamped addresses, every index is computed once with float
+// reciprocals (the general bodies spend ~6 integer divisions per quad and iteration: ~240 instructions around 36 multiply-adds,
+// behind loops whose trip count is a run-time value), a quad never straddles a row, and with dilation 1 the 18 distinct tap values
+// of a quad are read once (the address arithmetic is compile-time, so the 36 reads of the general form fold).
+struct DwpOwn {
+  int toff[4], pl[4];   // tile offset of the quad's first element (tap (1, 1)); plane
+  long go[4];           // element offset of the quad inside its image batch: c * HW + 4 q
+  int b[4];
+  bool ok[4];
+};
+__device__ __forceinline__ bool dwp_fast_ok(const DwPlaneArgs& a, int np) {
+  return (a.W & 3) == 0 && np * ((a.H * a.W) >> 2) <= 1024;
+}
+template <bool D1>
+__device__ __forceinline__ void dwp_own(const DwPlaneArgs& a, int p0, int np, int PS, int PWd, DwpOwn& o) {
+  const int HW = a.H * a.W, nq = HW >> 2, d = D1 ? 1 : a.dil, Q = np * nq;
+  const float invW = 1.f / (float)a.W, invnq = 1.f / (float)nq, invC = 1.f / (float)a.C;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    o.ok[k] = i < Q;
+    const int ii = o.ok[k] ? i : 0;
+    const int pl = np == 1 ? 0 : (int)(((float)ii + 0.5f) * invnq), q = ii - pl * nq;
+    const int bc = p0 + pl, b = (int)(((float)bc + 0.5f) * invC), c = bc - b * a.C;
+    const int py = (int)(((float)(4 * q) + 0.5f) * invW), px = 4 * q - py * a.W;
+    o.pl[k] = pl;
+    o.b[k] = b;
+    o.go[k] = (long)c * HW + 4 * q;
+    o.toff[k] = pl * PS + (py + d) * PWd + px + d;
+  }
+}
+// zero-fills the tile, then stages src planes (batch stride sb) into it
+__device__ __forceinline__ void dwp_stage_own(const DwpOwn& o, const bf16_t* src, long sb, float* tile, int nfl) {
+  for (int i = threadIdx.x; i < nfl; i += 256) tile[i] = 0.f;
+  float v[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ld4v(v[k], src + (long)o.b[k] * sb + o.go[k]);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (o.ok[k]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[o.toff[k] + e] = v[k][e];
+    }
+  __syncthreads();
+}
+
+template <int ACT, bool D1>
+__device__ __forceinline__ void dwp_fwd_fast(const DwPlaneArgs& a, int p0, int np, float* tile, float (*wts)[10]) {
+  const int d = D1 ? 1 : a.dil;
+  const int PWd = a.W + 2 * d, PS = (a.H + 2 * d) * PWd;
+  DwpOwn o;
+  dwp_own<D1>(a, p0, np, PS, PWd, o);
+  dwp_stage_own(o, a.x, a.sxb, tile, np * PS);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!o.ok[k]) continue;
+    const float* w = wts[o.pl[k]];
+    const float* t0 = tile + o.toff[k] - d * PWd - d;
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = w[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float wv = w[ky * 3 + kx];
+        const float* tp = t0 + ky * d * PWd + kx * d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += wv * tp[e];
+      }
+    if (a.y) st4v(a.y + (long)o.b[k] * a.syb + o.go[k], acc);
+    if (a.a) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = dw_act<ACT>(acc[e], a.act, a.slope);
+      st4v(a.a + (long)o.b[k] * a.sab + o.go[k], acc);
+    }
+  }
+}
+
 template <int ACT>
 __device__ __forceinline__ void dwp_fwd_body(const DwPlaneArgs& a, int bx) {
   __shared__ float tile[DWP_MAX];
@@ -483,6 +564,11 @@ __device__ __forceinline__ void dwp_fwd_body(const DwPlaneArgs& a, int bx) {
   for (int i = threadIdx.x; i < np * 10; i += 256) {
     const int pl = i / 10, t = i - pl * 10, c = (p0 + pl) % a.C;
     wts[pl][t] = t < 9 ? a.w[c * 9 + (a.flip ? 8 - t : t)] : (a.bias ? a.bias[c] : 0.f);
+  }
+  if (dwp_fast_ok(a, np)) {  // (workgroup-uniform)
+    if (d == 1) dwp_fwd_fast<ACT, true>(a, p0, np, tile, wts);
+    else dwp_fwd_fast<ACT, false>(a, p0, np, tile, wts);
+    return;
   }
   dwp_stage<0>(a, tile, p0, np, PS, PWd);
   for (int i = threadIdx.x; i < np * nq; i += 256) {
@@ -528,6 +614,47 @@ __device__ __forceinline__ void dwp_wgrad_body(const DwPlaneArgs& a, int bx) {
   const int PWd = a.W + 2 * d, PS = (a.H + 2 * d) * PWd;
   const int p0 = bx * a.ppw;
   const int np = p0 + a.ppw <= a.BC ? a.ppw : a.BC - p0;
+  if (np == 1 && dwp_fast_ok(a, 1)) {  // (workgroup-uniform) one plane per workgroup: the ten sums are workgroup reductions
+    DwpOwn o;
+    if (d == 1) dwp_own<true>(a, p0, 1, PS, PWd, o);
+    else dwp_own<false>(a, p0, 1, PS, PWd, o);
+    float g[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ld4v(g[k], a.dy + (long)o.b[k] * a.sgb + o.go[k]);
+    dwp_stage_own(o, a.x, a.sxb, tile, PS);
+    float acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!o.ok[k]) continue;
+      const float* t0 = tile + o.toff[k] - d * PWd - d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[9] += g[k][e];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float* tp = t0 + ky * d * PWd + kx * d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[ky * 3 + kx] += g[k][e] * tp[e];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      const float sm = wave_sum(acc[t]);
+      if (lane == 0) sums[wave][t] = sm;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+      const float sm = sums[0][threadIdx.x] + sums[1][threadIdx.x] + sums[2][threadIdx.x] + sums[3][threadIdx.x];
+      const int c = p0 % a.C;
+      if (threadIdx.x < 9) atomicAdd(&a.dw[c * 9 + threadIdx.x], sm);
+      else if (a.db) atomicAdd(&a.db[c], sm);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < np * 10; i += 256) sums[i / 10][i % 10] = 0.f;
   dwp_stage<2>(a, tile, p0, np, PS, PWd);
   // work items = (plane, chunk of 64 quads), dealt to the four waves in turn: the plane is wave-uniform, so the ten partial sums

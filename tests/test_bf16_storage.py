@@ -203,7 +203,9 @@ def test_dwconv_tok(dev, B, C, H, W, act):
 # bf16 with H*W % 4 == 0 takes the plane-in-LDS kernels (several planes per workgroup; 14x14: quads straddle rows; dilation 5;
 # 7x7 keeps the scalar kernels); the 2 x 70 x 8 x 8 case makes a workgroup's planes span two images
 @pytest.mark.parametrize("B,C,H,W,dil,act", [(2, 3, 8, 8, 1, "gelu"), (1, 2, 12, 12, 2, "none"), (2, 3, 7, 7, 3, "none"),
-                                             (2, 5, 14, 14, 1, "gelu"), (1, 3, 20, 28, 5, "none"), (2, 70, 8, 8, 2, "none")])
+                                             (2, 5, 14, 14, 1, "gelu"), (1, 3, 20, 28, 5, "none"), (2, 70, 8, 8, 2, "none"),
+                                             # one plane per workgroup (owned quads; the weight gradient's workgroup reduction)
+                                             (1, 2, 48, 48, 1, "gelu"), (2, 2, 56, 56, 2, "none"), (1, 3, 56, 56, 1, "none")])
 def test_dwconv_nchw(dev, B, C, H, W, dil, act):
     g = G(C + H + dil)
     x = torch.randn(B, C, H, W, generator=g)
