@@ -386,6 +386,76 @@ __global__ __launch_bounds__(256) void ln_bwd_v8_kernel(const bf16_t* __restrict
   }
 }
 
+// ---- LayerNorm of a split-K accumulator (round 5): the spatial-reduction conv of pvtv2.py:93-95 runs as a split-K GEMM into a
+// zero-at-rest fp32 accumulator (ops._ZeroWs); instead of cast_clear_bias (-> bf16 rows) followed by the LayerNorm launch, ONE
+// kernel reads the accumulator, adds the conv bias, stores the rounded rows xpre (the LayerNorm backward reads them), normalises
+// THE ROUNDED VALUES (the same numbers the two-launch form normalises), stores y, mean, rstd and leaves the accumulator zero.
+// One wave per row; C <= 512, C % 4 == 0.
+__global__ __launch_bounds__(256) void ln_fwd_acc_kernel(float* __restrict__ acc, const float* __restrict__ bias,
+                                                        bf16_t* __restrict__ xpre, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        float* __restrict__ mean, float* __restrict__ rstd, int rows, int C,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // (wave-uniform)
+  float* ar = acc + (long)row * C;
+  float v[2][4];
+  const int nq = C >> 2;  // quads per row (<= 128: two per lane)
+  float s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int q = lane + 64 * k;
+    const bool ok = q < nq;
+    const int qq = ok ? q : 0;
+    const f4 a = ld4(ar + 4 * qq);
+    const f4 b = bias ? ld4(bias + 4 * qq) : f4{{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[k][e] = ok ? cenet_bf2f(cenet_f2bf(a.v[e] + b.v[e])) : 0.f;
+      s1 += v[k][e];
+    }
+    if (ok) {
+      st4(ar + 4 * q, f4{{0.f, 0.f, 0.f, 0.f}});
+      st4v(xpre + (long)row * C + 4 * q, v[k]);
+    }
+  }
+  const float mu = wave_sum(s1) / (float)C;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (lane + 64 * k < nq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s2 += (v[k][e] - mu) * (v[k][e] - mu);
+    }
+  const float rs = rsqrtf(wave_sum(s2) / (float)C + eps);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int q = lane + 64 * k;
+    if (q < nq) {
+      const f4 g = ld4(gamma + 4 * q), bt = ld4(beta + 4 * q);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu) * rs * g.v[e] + bt.v[e];
+      st4v(y + (long)row * C + 4 * q, o);
+    }
+  }
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+extern "C" int cenet_layernorm_fwd_acc_bf16(float* acc, const float* bias, bf16_t* xpre, const float* gamma, const float* beta,
+                                            bf16_t* y, float* mean, float* rstd, int rows, int C, float eps, hipStream_t stream) {
+  if (!acc || !xpre || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0) return CENET_EINVAL;
+  if ((C & 3) != 0 || C > 512 ||
+      ((((uintptr_t)acc | (uintptr_t)bias | (uintptr_t)gamma | (uintptr_t)beta) & 15) != 0) ||
+      ((((uintptr_t)xpre | (uintptr_t)y) & 7) != 0))
+    return CENET_EUNSUPPORTED;
+  CENET_LAUNCH(ln_fwd_acc_kernel, dim3(cdiv(rows, 4)), dim3(256), stream, acc, bias, xpre, gamma, beta, y, mean, rstd, rows, C, eps);
+  CENET_CHECK_LAUNCH();
+  return CENET_OK;
+}
+
 // ---- deferred fold of LayerNorm affine-gradient partials (round 4) ----------------------------------------------------------
 // With float atomics every LayerNorm backward ended in 2 C same-address adds per workgroup, which capped the grid at ~256
 // workgroups x 6 - 8 dependent steps (14 - 18 us per call on 4 - 13 MB of data).  Writing one partial ROW per workgroup instead

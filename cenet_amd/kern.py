@@ -1191,3 +1191,12 @@ def augment_acdc(pool_img, pool_lab, tab, dp, stage_img, stage_lab, stage_stride
                                        C.c_int(max_h), C.c_int(max_w), P(out_img), P(out_lab), C.c_int(B), C.c_int(OH), C.c_int(OW),
                                        stream())
     _lib.check(rc, "cenet_augment_acdc")
+
+
+def layernorm_fwd_acc(acc, bias, xpre, gamma, beta, y, mean, rstd, rows, Cn, eps):
+    """cenet_layernorm_fwd_acc_bf16: LayerNorm straight from a split-K fp32 accumulator (+ bias); acc is zero afterwards"""
+    _chk(acc, bias, xpre, gamma, beta, y, mean, rstd)
+    assert acc.dtype == torch.float32 and xpre.dtype == BF16 and y.dtype == BF16
+    rc = _lib.lib().cenet_layernorm_fwd_acc_bf16(P(acc), P(bias), P(xpre), P(gamma), P(beta), P(y), P(mean), P(rstd), C.c_int(rows),
+                                                 C.c_int(Cn), C.c_float(eps), stream())
+    _lib.check(rc, "cenet_layernorm_fwd_acc_bf16")

@@ -89,8 +89,7 @@ class Attention(nn.Module):
     def forward(self, x, H, W, resid=None, bscale=None):
         q, x = ops.linear(x, self.q.weight, self.q.bias, tap=True)  # the kv branch's gradient joins q's inside the dgrad GEMM
         if self.sr_ratio > 1:
-            x_ = ops.conv2d_tok(x, H, W, self.sr.weight, self.sr.bias, stride=self.sr_ratio, pad=0, out_layout="tok")
-            x_ = ops.layernorm(x_, self.norm.weight, self.norm.bias, self.norm.eps)
+            x_ = ops.sr_conv_ln(x, H, W, self.sr.weight, self.sr.bias, self.sr_ratio, self.norm.weight, self.norm.bias, self.norm.eps)
         else:
             x_ = x
         kv = ops.linear(x_, self.kv.weight, self.kv.bias)

@@ -85,6 +85,13 @@ class _ZeroWs:
         return e[0].view(shape)
 
     @staticmethod
+    def release(ws: Tensor):
+        """ws is zero again (a kernel of the caller cleared it)"""
+        for e in _ZeroWs.bufs.get(_ZeroWs._key(ws.device, ws.numel()), ()):
+            if e[0].data_ptr() == ws.data_ptr():
+                e[1] = False
+
+    @staticmethod
     def give_back_as(ws: Tensor, like: Tensor, bias: Optional[Tensor] = None) -> Tensor:
         """-> a tensor of like's dtype (bf16) holding ws (+ bias over the last axis); ws is zero again"""
         out = torch.empty(ws.shape, device=ws.device, dtype=like.dtype)
@@ -1036,6 +1043,77 @@ class LayerNormFn(Function):
             dg, db = _zeros((Cn,), x), _zeros((Cn,), x)
         _ln_bwd(g, x, gamma, mean, rstd, dx, dg, db, rows, Cn, up_scale=ctx.up_scale)
         return dx, None, None, None, None
+
+
+class LinearLNFn(Function):
+    """LayerNorm(x W^T + b) for a LONG reduction under few output rows — the spatial-reduction conv (as a Linear layer over patch
+    rows, conv2d_tok) and its norm, pvtv2.py:93-95,99-100 — bf16 mode: split-K GEMM into a zero-at-rest fp32 accumulator, then ONE
+    kernel (cenet_layernorm_fwd_acc_bf16) adds the bias, rounds, normalises and clears the accumulator, where LinearFn +
+    LayerNormFn launch cast_clear_bias and layernorm_fwd.  Backward = LayerNormFn's followed by LinearFn's."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, eps):
+        x = _c(x)
+        K, N = x.shape[-1], W.shape[0]
+        R = x.numel() // K
+        shape = x.shape[:-1] + (N,)
+        acc = _ZeroWs.take(shape, x)
+        kern.gemm(kern.mat_plain(x, K, 1, kfast=1), kern.mat_plain(kern.wq(W, x), 1, K, kfast=1), acc, R, N, K, scr=N, scc=1,
+                  splits=kern.pick_splits(R, N, 1, K // 32), atomic=True)
+        xpre, y = _act(shape, x), _act(shape, x)
+        mean, rstd = _empty((R,), x), _empty((R,), x)
+        kern.layernorm_fwd_acc(acc, b, xpre, gamma, beta, y, mean, rstd, R, N, eps)
+        _ZeroWs.release(acc)
+        ctx.save_for_backward(x, W, xpre, gamma, mean, rstd)
+        ctx.refs = (W, b, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, xpre, gamma, mean, rstd = ctx.saved_tensors
+        Wp, bp, gp, btp = ctx.refs
+        g = _c(g)
+        K, N = x.shape[-1], W.shape[0]
+        R = x.numel() // K
+        d = torch.empty_like(xpre)
+        dg, dbt = grad_buf(gp), grad_buf(btp)
+        if dg is None:
+            dg, dbt = _zeros((N,), xpre), _zeros((N,), xpre)
+        _ln_bwd(g, xpre, gamma, mean, rstd, d, dg, dbt, R, N)
+        dW, db = grad_buf(Wp), grad_buf(bp)
+        if dW is not None and _wgrad_deferrable(N, K, d, x, K=R):
+            _wgrad_defer(d, 0, N, 0, x, 0, K, 0, dW, 0, db, N, K, R, 1, 0)
+        elif dW is not None or db is not None:
+            with _wgrad_side(d, x):
+                if dW is not None:
+                    kern.gemm(kern.mat_plain(d, 1, N, kfast=0), kern.mat_plain(x, K, 1, kfast=0), dW, N, K, R, scr=K, scc=1,
+                              splits=kern.pick_splits(N, K, 1, (R + 31) // 32), atomic=True, asum=db)
+                else:
+                    kern.col_sum(d, db, R, N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            kern.gemm(kern.mat_plain(d, N, 1, kfast=1), kern.mat_plain(kern.wq(Wp, x), K, 1, kfast=0), dx, R, K, N, scr=K, scc=1)
+        return dx, None, None, None, None, None
+
+
+def linear_ln_supported(x, W, b) -> bool:
+    K, N = x.shape[-1], W.shape[0]
+    R = x.numel() // K
+    return bool(_bf(x) and K >= 1024 and N % 4 == 0 and N <= 512 and (b is None or b.data_ptr() % 16 == 0)
+                and kern.pick_splits(R, N, 1, K // 32) > 1)
+
+
+def sr_conv_ln(x, H, Wd, W, b, stride, gamma, beta, eps):
+    """LayerNorm(Conv2d(k = stride, no padding)(tokens as a map)) -> tokens (pvtv2.py:93-95,99-100)"""
+    x = _c(x)
+    B, N, C = x.shape
+    k = W.shape[2]
+    if (k == stride and W.shape[3] == k and k in (2, 4, 8) and H % k == 0 and Wd % k == 0 and N == H * Wd and W.is_contiguous()):
+        xp = PatchTokFn.apply(x, H, Wd, k)
+        if linear_ln_supported(xp, W, b):
+            return LinearLNFn.apply(xp, W, b, gamma, beta, eps)
+    return layernorm(conv2d_tok(x, H, Wd, W, b, stride=stride, pad=0, out_layout="tok"), gamma, beta, eps)
 
 
 def layernorm(x, gamma, beta, eps):

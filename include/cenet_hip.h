@@ -882,6 +882,12 @@ int cenet_augment_acdc(const float* pool_img, const unsigned char* pool_lab, con
                        unsigned char* stage_lab, long stage_stride, int max_h, int max_w, float* out_img, float* out_lab, int B,
                        int OH, int OW, cenet_stream_t stream);
 
+/* LayerNorm of a split-K accumulator (norm.hip, round 5; pvtv2.py:93-95,99-100: sr conv -> norm): acc [rows, C] fp32 holds the
+ * conv's products (zero-at-rest accumulator of a split-K GEMM); xpre = bf16(acc + bias) (the rows the LayerNorm backward reads),
+ * y = LayerNorm(xpre) * gamma + beta, mean / rstd [rows]; acc is left zero.  bias may be NULL.  C % 4 == 0, C <= 512. */
+int cenet_layernorm_fwd_acc_bf16(float* acc, const float* bias, unsigned short* xpre, const float* gamma, const float* beta,
+                                 unsigned short* y, float* mean, float* rstd, int rows, int C, float eps, cenet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -550,3 +550,39 @@ def test_adaptive_avgpool_backward_candidate_bins(dev, dt, H, W, oh, ow):
     tol = dict(rtol=1e-5, atol=1e-6) if dt == torch.float32 else dict(rtol=1e-2, atol=2e-2)
     torch.testing.assert_close(y.float().cpu(), ref.detach(), **tol)
     torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, **tol)
+
+
+@pytest.mark.parametrize("B,C,H,W,s", [(2, 64, 16, 16, 8), (3, 64, 8, 12, 4), (2, 320, 4, 4, 2)])
+def test_sr_conv_and_norm_as_one_tail_kernel(dev, B, C, H, W, s):
+    """ops.sr_conv_ln (pvtv2.py:93-95,99-100, bf16 mode): patch rows -> split-K GEMM into the zero-at-rest accumulator -> ONE kernel
+    that adds the bias, rounds, normalises and clears the accumulator (cenet_layernorm_fwd_acc_bf16) — against the launch chain
+    conv2d_tok + layernorm: same rounded rows, same statistics; gradients of the input, conv and norm parameters."""
+    g = torch.Generator().manual_seed(B + C + s)
+    x0 = torch.randn(B, H * W, C, generator=g).to(BF)
+    W0 = (torch.randn(C, C, s, s, generator=g) * (C * s * s) ** -0.5)
+    b0, ga0, be0 = torch.randn(C, generator=g) * 0.1, 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    cot = torch.randn(B, (H // s) * (W // s), C, generator=g).to(BF).to(dev)
+    res = []
+    for fused in (True, False):
+        x = x0.clone().to(dev).requires_grad_(True)
+        ps = [t.clone().to(dev).requires_grad_(True) for t in (W0, b0, ga0, be0)]
+        for p in ps:
+            p.grad = torch.zeros_like(p)
+        if fused:
+            with torch.no_grad():
+                xp = ops.PatchTokFn.apply(x, H, W, s)
+            if not ops.linear_ln_supported(xp, ps[0], ps[1]):
+                pytest.skip("reduction too short to split here")
+            y = ops.sr_conv_ln(x, H, W, ps[0], ps[1], s, ps[2], ps[3], 1e-5)
+        else:
+            y = ops.layernorm(ops.conv2d_tok(x, H, W, ps[0], ps[1], stride=s, pad=0, out_layout="tok"), ps[2], ps[3], 1e-5)
+        y.backward(cot)
+        ops.wgrad_flush()
+        res.append([y.detach().float().cpu(), x.grad.float().cpu()] + [p.grad.float().cpu() for p in ps])
+    names = ["y", "dx", "dW", "db", "dgamma", "dbeta"]
+    for n, a, b in zip(names, *res):
+        tol = 2e-2 * float(b.abs().max()) + 1e-6  # (split-K atomics order the fp32 sums differently run to run; bf16 rows)
+        assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), tol)
+    # the accumulator is zero at rest and free again
+    for es in ops._ZeroWs.bufs.values():
+        assert all(e[1] is False and float(e[0].abs().max()) == 0.0 for e in es)
