@@ -217,8 +217,9 @@ def test_torch_compile_fullgraph_trains_like_eager():
 
 
 def test_torch_compile_fullgraph_on_the_host_checker():
-    """the tracing protocol itself needs no GPU: the same check at 32x32 on the host SIMT checker (aot_eager backend: the
-    tracer, functionalisation and the joint forward / backward graph are the real ones, only code generation is skipped)"""
+    """the tracing protocol itself needs no GPU: one training step at 32x32 on the host SIMT checker, eager against
+    torch.compile(fullgraph=True) (aot_eager backend: the tracer, functionalisation and the joint forward / backward graph are the
+    real ones, only code generation is skipped)"""
     from backend import use_sim
     import test_segmented as TS
     from test_parallel_gloo import _cenet_shard
@@ -235,11 +236,8 @@ def test_torch_compile_fullgraph_on_the_host_checker():
         assert l0 == l1 and torch.equal(o0, o1) and set(g0) == set(g1)
         for n in g0:
             assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-7), n
-        with torch.no_grad():
-            net.eval(), ref.eval()
-            traced = torch.jit.trace(net, x, check_trace=False, strict=False)
-            assert [n.kind() for n in traced.graph.nodes() if n.kind().startswith("cenet_amd")] == ["cenet_amd::forward"]
-            assert torch.equal(traced(x), ref(x))
+        # (torch.jit.trace of the same module: test_jit_trace_of_the_model_completes, on the GPU — three more forwards of the
+        # full network cost the host checker a minute)
     finally:
         _lib._LIB, _lib._HOSTSIM = None, False
 
