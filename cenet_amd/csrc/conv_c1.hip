@@ -147,6 +147,181 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(ConvC1Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 5x5, 1 -> 32 channels on the matrix cores (round 5).  The VALU stencils above spend 25 multiply-adds per output value: 1.3 G
+// of them per pass at 224x224, B = 32 — 66 us forward, 122 us weight gradient for 103 MB of traffic.  As MFMA products with the
+// 25 taps (padded to 32) as one of the dimensions:
+//   forward  out[px][co] = sum_t X[px + d_t] W[co][t]:   A = 16 pixels x 32 taps (a lane gathers the 8 taps of ITS tap group from
+//            the fp32 LDS halo tile: per-lane constant offsets), B = the weights (two 16-channel fragments, loaded once);
+//            a lane receives 4 consecutive pixels of one channel -> 8-byte stores.
+//   wgrad    dW[co][t] = sum_px dY[co][px] X[px + d_t]:   A = dY rows straight from HBM (8 consecutive pixels = one 16-byte load),
+//            B = 32 pixels x 16 taps (a lane reads 8 consecutive tile floats at ITS tap's offset); four accumulator tiles per wave
+//            over all its pixels, one LDS fold and one set of float atomics per workgroup.
+// ~30 instructions per 16 pixels x 32 channels instead of ~200.  The tile holds the bf16 inputs widened to fp32, so re-packing
+// two of them is a byte permute (exact).
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned c1_pack(float lo, float hi) {  // (both are bf16 values held as fp32: low halves are zero)
+  return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+}
+#define C1M_TR 8
+#define C1M_TC 128
+#define C1M_LW (C1M_TC + 4)
+// stages rows y0 - 2 .. y0 + NR + 1, columns x0 - 2 .. x0 + 129 of image xb into tile[(NR + 4) * C1M_LW] (zero outside the image)
+template <int NR>
+__device__ __forceinline__ void c1m_stage(const bf16_t* xb, int H, int W, int y0, int x0, float* tile) {
+  constexpr int LH = NR + 4;
+  const int c = threadIdx.x & 127, r0 = threadIdx.x >> 7;
+  float v[LH / 2];
+#pragma unroll
+  for (int k = 0; k < LH / 2; ++k) {
+    const int r = r0 + 2 * k, iy = y0 - 2 + r, ix = x0 - 2 + c;
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    v[k] = cenet_bf2f(xb[ok ? (long)iy * W + ix : 0]);
+    if (!ok) v[k] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < LH / 2; ++k) tile[(r0 + 2 * k) * C1M_LW + c] = v[k];
+  if (threadIdx.x < LH * 4) {  // the last four columns
+    const int r = threadIdx.x >> 2, cc = 128 + (threadIdx.x & 3), iy = y0 - 2 + r, ix = x0 - 2 + cc;
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float t = cenet_bf2f(xb[ok ? (long)iy * W + ix : 0]);
+    tile[r * C1M_LW + cc] = ok ? t : 0.f;
+  }
+}
+
+// grid (ceil(W / 128), ceil(H / 8), B); W % 4 == 0
+__global__ __launch_bounds__(256) void conv_c1_fwd_mfma5_kernel(ConvC1Args a) {
+  __shared__ float tile[(C1M_TR + 4) * C1M_LW];
+  const cenet_bid bid = cenet_xcd_block();
+  const int x0 = bid.x * C1M_TC, y0 = bid.y * C1M_TR, b = bid.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+  c1m_stage<C1M_TR>(a.x + (long)b * a.H * a.W, a.H, a.W, y0, x0, tile);
+  // this lane's tap group: t = 8 fq + j -> tile offset (ky, kx); taps 25 .. 31 read offset 0 against a zero weight
+  int toff[8];
+  bf16x8 wf[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int t = 8 * fq + j, ky = t / 5, kx = t - 5 * ky;
+    toff[j] = t < 25 ? ky * C1M_LW + kx : 0;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    unsigned u[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int t0 = 8 * fq + 2 * h, co = 16 * ct + fr;
+      const float w0 = (t0 < 25 && co < a.Cout) ? a.w[co * 25 + t0] : 0.f, w1 = (t0 + 1 < 25 && co < a.Cout) ? a.w[co * 25 + t0 + 1] : 0.f;
+      u[h] = cenet_pack_bf2(w0, w1);
+    }
+    memcpy(&wf[ct], u, 16);
+  }
+  __syncthreads();
+  const long HW = (long)a.H * a.W;
+  bf16_t* yb = a.y + (long)b * a.Cout * HW;
+#pragma unroll 1
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = 2 * wave + rr, oy = y0 + row;
+    if (oy >= a.H) break;  // (wave-uniform)
+#pragma unroll 2
+    for (int g = 0; g < C1M_TC / 16; ++g) {
+      const int xs = 16 * g;
+      if (x0 + xs >= a.W) break;  // (wave-uniform; W % 16 == 0 for the fast path)
+      const float* tp = tile + row * C1M_LW + xs + fr;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tp[toff[j]];
+      unsigned u[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) u[h] = c1_pack(v[2 * h], v[2 * h + 1]);
+      bf16x8 af;
+      memcpy(&af, u, 16);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wf[ct], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const int co = 16 * ct + fr;
+        if (co < a.Cout) {
+          const float o[4] = {d[0], d[1], d[2], d[3]};
+          st4v(yb + (long)co * HW + (long)oy * a.W + x0 + xs + 4 * fq, o);
+        }
+      }
+    }
+  }
+}
+
+// grid (ceil(W / 128), ceil(H / rows_per_wg), B); W % 32 == 0
+__global__ __launch_bounds__(256) void conv_c1_wgrad_mfma5_kernel(ConvC1Args a) {
+  __shared__ float tile[(C1M_TR + 4) * C1M_LW];
+  __shared__ float red[4][4][256];
+  const cenet_bid bid = cenet_xcd_block();
+  const int x0 = bid.x * C1M_TC, b = bid.z;
+  const int ybeg = bid.y * a.rows_per_wg, yend = ybeg + a.rows_per_wg < a.H ? ybeg + a.rows_per_wg : a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+  const long HW = (long)a.H * a.W;
+  const bf16_t* xb = a.x + (long)b * HW;
+  const int xs = 32 * wave;  // this wave's 32-pixel segment of the tile's columns
+  const bool wok = x0 + xs < a.W;
+  // B operand: tap t = 16 tt + fr -> tile offset of (ky, kx); taps >= 25 alias tap 0 (their columns are never written back)
+  int toff[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int t = 16 * tt + fr, ky = t / 5, kx = t - 5 * ky;
+    toff[tt] = t < 25 ? ky * C1M_LW + kx : 0;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) acc[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // A operand: dY[co = 16 ct + fr][row][x0 + xs + 8 fq .. + 7]
+  const bf16_t* gp[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int co = 16 * ct + fr < a.Cout ? 16 * ct + fr : 0;
+    gp[ct] = a.dy + ((long)b * a.Cout + co) * HW + x0 + xs + 8 * fq;
+  }
+  for (int y0 = ybeg; y0 < yend; y0 += C1M_TR) {
+    __syncthreads();
+    c1m_stage<C1M_TR>(xb, a.H, a.W, y0, x0, tile);
+    __syncthreads();
+    if (!wok) continue;  // (wave-uniform)
+    const int nr = yend - y0 < C1M_TR ? yend - y0 : C1M_TR;
+    bf16x8 af[2], nx[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) memcpy(&af[ct], gp[ct] + (long)y0 * a.W, 16);
+    for (int row = 0; row < nr; ++row) {
+      const int rn = row + 1 < nr ? row + 1 : row;  // next row's dY in flight under this row's products
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) memcpy(&nx[ct], gp[ct] + (long)(y0 + rn) * a.W, 16);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const float* tp = tile + row * C1M_LW + xs + 8 * fq + toff[tt];
+        unsigned u[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) u[h] = c1_pack(tp[2 * h], tp[2 * h + 1]);
+        bf16x8 bfv;
+        memcpy(&bfv, u, 16);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ct][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], bfv, acc[ct][tt], 0, 0, 0);
+      }
+      af[0] = nx[0];
+      af[1] = nx[1];
+    }
+  }
+  // fold the four waves, then one atomic per (channel, tap): acc[ct][tt][r] = dW[co = 16 ct + 4 fq + r][t = 16 tt + fr]
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][ct * 2 + tt][lane * 4 + r] = acc[ct][tt][r];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * 256; i += 256) {
+    const int q = i >> 8, e = i & 255, ct = q >> 1, tt = q & 1, ln = e >> 2, r = e & 3;
+    const int co = 16 * ct + 4 * (ln >> 4) + r, t = 16 * tt + (ln & 15);
+    if (co < a.Cout && t < 25) atomicAdd(&a.dw[co * 25 + t], red[0][q][e] + red[1][q][e] + red[2][q][e] + red[3][q][e]);
+  }
+}
+
 extern "C" int cenet_conv_c1_supported(int Cin, int Cout, int k, int stride, int pad) {
   return Cin == 1 && Cout >= 1 && Cout <= 32 && (k == 1 || k == 3 || k == 5) && stride == 1 && pad == k / 2;
 }
@@ -158,6 +333,12 @@ extern "C" int cenet_conv_c1_fwd_bf16(const bf16_t* x, const float* w, bf16_t* y
   ConvC1Args a;
   a.x = x; a.dy = nullptr; a.w = w; a.y = y; a.dw = nullptr; a.B = B; a.Cout = Cout; a.H = H; a.W = W; a.rows_per_wg = 8;
   const dim3 grid(cdiv(W, 128), cdiv(H, 8), B);
+  static const bool no_mfma = getenv("CENET_C1_NO_MFMA") != nullptr;  // measurement aid
+  if (k == 5 && (W & 15) == 0 && !no_mfma && ((uintptr_t)y & 7) == 0) {
+    CENET_LAUNCH(conv_c1_fwd_mfma5_kernel, grid, dim3(256), stream, a);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   if (k == 1) CENET_LAUNCH((conv_c1_fwd_kernel<1>), grid, dim3(256), stream, a);
   else if (k == 3) CENET_LAUNCH((conv_c1_fwd_kernel<3>), grid, dim3(256), stream, a);
   else CENET_LAUNCH((conv_c1_fwd_kernel<5>), grid, dim3(256), stream, a);
@@ -178,6 +359,12 @@ extern "C" int cenet_conv_c1_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float
   while (rows < H && (long)cdiv(W, 128) * cdiv(H, rows) * B > target) rows += 8;
   a.rows_per_wg = rows;
   const dim3 grid(cdiv(W, 128), cdiv(H, rows), B);
+  static const bool no_mfma = getenv("CENET_C1_NO_MFMA") != nullptr;  // measurement aid
+  if (k == 5 && (W & 31) == 0 && !no_mfma && ((uintptr_t)dy & 15) == 0) {
+    CENET_LAUNCH(conv_c1_wgrad_mfma5_kernel, grid, dim3(256), stream, a);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
   if (k == 1) CENET_LAUNCH((conv_c1_wgrad_kernel<1>), grid, dim3(256), stream, a);
   else if (k == 3) CENET_LAUNCH((conv_c1_wgrad_kernel<3>), grid, dim3(256), stream, a);
   else CENET_LAUNCH((conv_c1_wgrad_kernel<5>), grid, dim3(256), stream, a);

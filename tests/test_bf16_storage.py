@@ -132,7 +132,10 @@ def test_conv2d_implicit_gemm(dev, Cin, Cout, k, s, H, expand, layout):
 # the one-channel stencils of conv_c1.hip (bf16 only; fp32 takes the implicit GEMM): k = 5 / 3 / 1, full 128-column tiles with
 # a ragged last one (W = 140), a width that is not a multiple of 4 (scalar stores), several row groups per workgroup.  The
 # input needs no gradient in the network; here x does, which exercises the generic data-gradient path behind the special forward.
-@pytest.mark.parametrize("Cout,k,H,W", [(32, 5, 20, 140), (32, 1, 9, 132), (12, 3, 11, 30), (32, 5, 7, 9)])
+# W % 32 == 0 with k = 5: the matrix-core kernels (taps as the contraction / an output dimension); 160 columns = a full and a
+# quarter tile, 19 rows = ragged row groups, 24 channels = a partly empty second channel fragment
+@pytest.mark.parametrize("Cout,k,H,W", [(32, 5, 20, 140), (32, 1, 9, 132), (12, 3, 11, 30), (32, 5, 7, 9), (32, 5, 19, 160),
+                                        (24, 5, 8, 32), (32, 5, 30, 224)])
 def test_conv_one_channel_input(dev, Cout, k, H, W):
     g = G(Cout + k + W)
     x = torch.randn(2, 1, H, W, generator=g)
