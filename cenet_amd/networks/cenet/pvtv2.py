@@ -158,8 +158,8 @@ class OverlapPatchEmbed(nn.Module):
         if expand and x.dtype == torch.bfloat16:
             # throughput mode: a conv over `expand` identical copies of one channel is the conv of that channel with the
             # channel-summed weight — a third of the reduction length (K = 49 instead of 147 for the 7x7 stem); the weight
-            # gradient comes back through the sum's autograd node.  (fp32 parity mode keeps the reference's operation order.)
-            t = ops.conv2d_nchw(x, self.proj.weight.sum(1, keepdim=True), self.proj.bias, stride=s, pad=p, out_layout="tok")
+            # gradient is added back into all three channel slices by ops.ChanSumWeightFn.  (fp32 parity mode keeps the reference's operation order.)
+            t = ops.conv2d_nchw(x, ops.chan_sum_weight(self.proj.weight), self.proj.bias, stride=s, pad=p, out_layout="tok")
         else:
             t = ops.conv2d_nchw(x, self.proj.weight, self.proj.bias, stride=s, pad=p, out_layout="tok", expand_channels=expand)
         t = ops.layernorm(t, self.norm.weight, self.norm.bias, self.norm.eps)

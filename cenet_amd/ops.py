@@ -938,6 +938,28 @@ class Conv2dFn(Function):
         return dx, (dW if derived else None), None, None
 
 
+class ChanSumWeightFn(Function):
+    """W [Cout, Cin, k, k] -> sum over Cin [Cout, 1, k, k]: the weight of a conv whose Cin input channels are copies of one channel
+    (net.py:55).  Backward ADDS the broadcast gradient into W's gradient buffer, like every weight-gradient kernel of this file (and
+    returns nothing to autograd: no AccumulateGrad node, whose stream bookkeeping does not fit a step captured on a side stream)."""
+
+    @staticmethod
+    def forward(ctx, W):
+        ctx.ref = W
+        return W.sum(1, keepdim=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        dW = grad_buf(ctx.ref)
+        if dW is not None:
+            dW.add_(g)
+        return None
+
+
+def chan_sum_weight(W):
+    return ChanSumWeightFn.apply(W)
+
+
 def conv2d_nchw(x, W, b=None, stride=1, pad=0, out_layout="nchw", expand_channels: int = 0):
     """x [B,C,H,W] contiguous NCHW.  expand_channels=3 reads a 1-channel input as 3 identical channels (net.py:55)."""
     x = _c(x)
