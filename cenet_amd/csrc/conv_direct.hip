@@ -36,7 +36,7 @@ struct ConvDirectArgs {
 // (365 registers: 64 accumulators, 88 for the prefetched halo) that was ONE wave per SIMD with nothing to cover an LDS read; eight
 // waves own one tile row each (32 accumulators, half the halo slots: under 256 registers, two waves per SIMD)
 template <int CIN, int COUT, int KS, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 8 || (CIN == 64 && COUT == 64)) ? 1 : 2) void conv_direct_bf16_kernel(ConvDirectArgs a) {
+__global__ __launch_bounds__(64 * NW, (CIN == 64 && COUT == 64) ? 1 : 2) void conv_direct_bf16_kernel(ConvDirectArgs a) {
   constexpr int NT = 64 * NW, RPW = TH / NW, NI = 2 * RPW;  // tile rows per wave, (row, x-segment) pairs per wave
   constexpr int CQ = CIN / 8, HH = TH + KS - 1, HW_ = TW + KS - 1, KK = KS * KS, PADK = KS / 2;
   constexpr int UNITS = CQ * HH * HW_;           // 16-byte halo slots
@@ -202,7 +202,7 @@ extern "C" int cenet_conv_direct_bf16(const bf16_t* x, const float* w, bf16_t* y
   } else if (k == 3 && Cin == 64 && Cout == 64) {
     CENET_LAUNCH((conv_direct_bf16_kernel<64, 64, 3, 8>), dim3(grid), dim3(512), stream, a);
   } else if (k == 3 && Cin == 64 && Cout == 32) {
-    CENET_LAUNCH((conv_direct_bf16_kernel<64, 32, 3, 4>), dim3(grid), dim3(256), stream, a);
+    CENET_LAUNCH((conv_direct_bf16_kernel<64, 32, 3, 8>), dim3(grid), dim3(512), stream, a);  // (same time as four waves; no scratch)
   } else {
     CENET_LAUNCH((conv_direct_bf16_kernel<32, 64, 3, 4>), dim3(grid), dim3(256), stream, a);
   }
@@ -236,27 +236,36 @@ __device__ __forceinline__ unsigned funnel16(unsigned lo, unsigned hi) { return 
 
 // NW waves per workgroup: 4 (two workgroups per CU) or 8 (one: the 64 x 64 instance — 16 pairs x 9 taps = 144 accumulator registers
 // per lane at 4 waves, 356 bytes of scratch per lane under the 256-register cap; at 8 waves a lane holds 72)
-template <int CIN, int COUT, int KS, int TH_, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wgrad_direct_kernel(ConvWgradArgs a) {
+// KSPLIT = 2 (the 5 x 5 32 -> 32 instance: only four (co, ci) pairs, 25 taps each = 100 accumulator registers, 136 bytes of scratch
+// at four waves): two waves share a pair and take taps 0 .. 12 / 13 .. 24 — 52 registers each, two 8-wave workgroups per CU
+template <int V>
+struct cd_ic {
+  static constexpr int value = V;
+};
+template <int CIN, int COUT, int KS, int TH_, int NW, int KSPLIT = 1>
+__global__ __launch_bounds__(64 * NW, (NW == 4 || KSPLIT == 2) ? 2 : 1) void conv_wgrad_direct_kernel(ConvWgradArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int P = KS / 2, HH = TH_ + KS - 1, KK = KS * KS;
   constexpr int XROW = 24;                                   // dwords per halo row: 8 px pad + 32 px + 8 px pad
   constexpr int XPL = HH * XROW + (12 - (HH * XROW) % 8) % 8;  // ci plane stride in dwords, == 4 (mod 8): conflict-free b128
   constexpr int GPL = TH_ * 16 + (12 - (TH_ * 16) % 8) % 8;    // co plane stride of dY
   static_assert(XPL % 8 == 4 && GPL % 8 == 4, "plane strides must be 4 mod 8 dwords");
-  constexpr int NCI = CIN / 16, NCO = COUT / 16, PAIRS = NCI * NCO, NPW = PAIRS / NW;
-  static_assert(PAIRS % NW == 0 && (NPW <= NCI) && (NCI % NPW == 0), "a wave's pairs share one output-channel tile");
+  constexpr int NCI = CIN / 16, NCO = COUT / 16, PAIRS = NCI * NCO, NPW = PAIRS * KSPLIT / NW;
+  constexpr int TPP = (KS * KS + KSPLIT - 1) / KSPLIT;  // taps per wave
+  static_assert((PAIRS * KSPLIT) % NW == 0 && NPW >= 1 && (NPW <= NCI) && (NCI % NPW == 0) && (KSPLIT == 1 || NPW == 1),
+                "a wave's pairs share one output-channel tile");
   __shared__ __attribute__((aligned(16))) unsigned Xs[CIN * XPL];
   __shared__ __attribute__((aligned(16))) unsigned Gs[COUT * GPL];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
-  const int cog = (wave * NPW) / NCI, cig0 = (wave * NPW) % NCI;  // this wave: co tile cog, ci tiles cig0 .. cig0+NPW-1
+  const int pw = wave / KSPLIT, part = wave % KSPLIT;                 // pair-set index; which share of the taps
+  const int cog = (pw * NPW) / NCI, cig0 = (pw * NPW) % NCI;  // this wave: co tile cog, ci tiles cig0 .. cig0+NPW-1
   const int HWp = a.H * a.W;
   const bool w_even = (a.W & 1) == 0;
-  f32x4 acc[NPW][KK];
+  f32x4 acc[NPW][TPP];  // acc[j][t - part * TPP]
 #pragma unroll
   for (int j = 0; j < NPW; ++j)
 #pragma unroll
-    for (int t = 0; t < KK; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TPP; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // XCD-aware tile walk, as in the forward kernel: each XCD owns a contiguous eighth of the tile list
   const int G = gridDim.x < 8 ? (int)gridDim.x : 8;
@@ -390,31 +399,40 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wgrad_direct_ke
     }
     __syncthreads();
     // ---- one k-step (32 pixels) per tile row
-    for (int row = 0; row < TH_; ++row) {
-      bf16x8 af;
-      memcpy(&af, &Gs[(16 * cog + fr) * GPL + row * 16 + 4 * fq], 16);
+    auto rows = [&](auto pc) __attribute__((always_inline)) {
+      constexpr int PART = decltype(pc)::value, T0 = PART * TPP, T1 = (T0 + TPP < KK) ? T0 + TPP : KK;
+      for (int row = 0; row < TH_; ++row) {
+        bf16x8 af;
+        memcpy(&af, &Gs[(16 * cog + fr) * GPL + row * 16 + 4 * fq], 16);
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) {
+        for (int j = 0; j < NPW; ++j) {
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky) {
-          const unsigned* xr = &Xs[(16 * (cig0 + j) + fr) * XPL + (row + ky) * XROW + 4 + 4 * fq];
-          unsigned w[6];
-          w[0] = xr[-1];
-          memcpy(&w[1], xr, 16);
-          w[5] = xr[4];
+          for (int ky = 0; ky < KS; ++ky) {
+            if (ky * KS + KS <= T0 || ky * KS >= T1) continue;  // (compile-time: no tap of this kernel row is this wave's)
+            const unsigned* xr = &Xs[(16 * (cig0 + j) + fr) * XPL + (row + ky) * XROW + 4 + 4 * fq];
+            unsigned w[6];
+            w[0] = xr[-1];
+            memcpy(&w[1], xr, 16);
+            w[5] = xr[4];
 #pragma unroll
-          for (int kx = 0; kx < KS; ++kx) {
-            const int s = kx - P + 2;  // first window element of this tap, counted from w[0]'s low half
-            unsigned f[4];
+            for (int kx = 0; kx < KS; ++kx) {
+              constexpr int KS_ = KS;
+              const int t = ky * KS_ + kx;
+              if (t < T0 || t >= T1) continue;  // (compile-time)
+              const int s = kx - P + 2;  // first window element of this tap, counted from w[0]'s low half
+              unsigned f[4];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) f[d] = (s & 1) ? funnel16(w[(s - 1) / 2 + d], w[(s + 1) / 2 + d]) : w[s / 2 + d];
-            bf16x8 bfv;
-            memcpy(&bfv, f, 16);
-            acc[j][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfv, acc[j][ky * KS + kx], 0, 0, 0);
+              for (int d = 0; d < 4; ++d) f[d] = (s & 1) ? funnel16(w[(s - 1) / 2 + d], w[(s + 1) / 2 + d]) : w[s / 2 + d];
+              bf16x8 bfv;
+              memcpy(&bfv, f, 16);
+              acc[j][t - T0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfv, acc[j][t - T0], 0, 0, 0);
+            }
           }
         }
       }
-    }
+    };
+    if (KSPLIT == 1 || part == 0) rows(cd_ic<0>());  // (wave-uniform)
+    else rows(cd_ic<KSPLIT - 1>());
     if (a.vec && tile + nloc < t_end) {
       __syncthreads();  // this tile's fragments are consumed
       stage();
@@ -425,9 +443,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_wgrad_direct_ke
 #pragma unroll
   for (int j = 0; j < NPW; ++j)
 #pragma unroll
-    for (int t = 0; t < KK; ++t) {
-      float v[4] = {acc[j][t][0], acc[j][t][1], acc[j][t][2], acc[j][t][3]};
-      memcpy(slab + ((wave * NPW + j) * KK + t) * 256 + lane * 4, v, 16);
+    for (int tt = 0; tt < TPP; ++tt) {
+      const int t = part * TPP + tt;
+      if (t < KK) {
+        float v[4] = {acc[j][tt][0], acc[j][tt][1], acc[j][tt][2], acc[j][tt][3]};
+        memcpy(slab + ((pw * NPW + j) * KK + t) * 256 + lane * 4, v, 16);
+      }
     }
 }
 
@@ -486,7 +507,7 @@ extern "C" int cenet_conv_wgrad_direct_bf16(const bf16_t* x, const bf16_t* dy, f
   }
   const bool wide = k == 3 && Cout == 64;  // eight waves, one workgroup per CU
   if (wide && grid > CENET_WGRAD_SLABS / 2) grid = CENET_WGRAD_SLABS / 2;
-  if (k == 5) CENET_LAUNCH((conv_wgrad_direct_kernel<32, 32, 5, 8, 4>), dim3(grid), dim3(256), stream, a);
+  if (k == 5) CENET_LAUNCH((conv_wgrad_direct_kernel<32, 32, 5, 8, 8, 2>), dim3(grid), dim3(512), stream, a);
   else if (wide) CENET_LAUNCH((conv_wgrad_direct_kernel<64, 64, 3, 4, 8>), dim3(grid), dim3(512), stream, a);
   else CENET_LAUNCH((conv_wgrad_direct_kernel<64, 32, 3, 4, 4>), dim3(grid), dim3(256), stream, a);
   const int psize = Cin * Cout * k * k;
