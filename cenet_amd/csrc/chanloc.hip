@@ -915,6 +915,16 @@ struct DwActArgs {
   int B, C, H, W;
 };
 
+// Planes in LDS carry a zero border of one pixel when the bordered batch fits (dilation 1: B (H + 2)(W + 2) <= DWBN_MAXE — 14x14
+// and 7x7 at B = 32): the nine taps are then unconditional reads at compile-time offsets from one base address, instead of nine
+// bounds tests, selects and address computations per element and pass.
+__device__ __forceinline__ bool dwact_bordered(const DwActArgs& a) {
+  return a.dil == 1 && (long)a.B * (a.H + 2) * (a.W + 2) <= DWBN_MAXE;
+}
+__device__ __forceinline__ void dwact_zero(float* pl, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) pl[i] = 0.f;
+}
+
 template <typename T, int EPT>
 __global__ __launch_bounds__(1024) void dwact_fwd_kernel(DwActArgs a) {
   __shared__ float xs[DWBN_MAXE];
@@ -923,15 +933,42 @@ __global__ __launch_bounds__(1024) void dwact_fwd_kernel(DwActArgs a) {
   const long cb = (long)c * HW, sb = (long)a.C * HW;
   const T* x = (const T*)a.x + cb;
   T* y = (T*)a.y + cb;
+  const bool bord = dwact_bordered(a);  // (workgroup-uniform)
+  const int PW = W + 2, PS = (H + 2) * PW;
+  const float invW = 1.f / (float)W;
+  float w[9], tap[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = a.w[c * 9 + k];
+  const float bias = a.bias ? a.bias[c] : 0.f;
+  if (bord) {
+    float V[EPT];
+    OWN_FOR(o, { V[k] = ldf(x + (ok ? b * sb + p : 0)); })
+    dwact_zero(xs, a.B * PS);
+    __syncthreads();
+    int base[EPT];  // element (i, j) of image b: xs[base + (ky) * PW + kx] is its tap (ky, kx)
+    OWN_FOR(o, {
+      int pi, pj;
+      pix_ij(ok ? p : 0, W, invW, pi, pj);
+      base[k] = (ok ? b : 0) * PS + pi * PW + pj;
+      if (ok) xs[base[k] + PW + 1] = V[k];
+    })
+    __syncthreads();
+    OWN_FOR(o, {
+      const float* t0 = xs + base[k];
+      float u = bias;
+_Pragma("unroll")
+      for (int ky = 0; ky < 3; ++ky)
+_Pragma("unroll")
+        for (int kx = 0; kx < 3; ++kx) u += w[ky * 3 + kx] * t0[ky * PW + kx];
+      if (ok) stf(y + b * sb + p, act_fwd(a.act, u, a.slope));
+    })
+    return;
+  }
   {
     float V[EPT];
     OWN_FOR(o, { V[k] = ldf(x + (ok ? b * sb + p : 0)); })
     OWN_FOR(o, { if (ok) xs[b * HW + p] = V[k]; })
   }
-  float w[9], tap[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) w[k] = a.w[c * 9 + k];
-  const float bias = a.bias ? a.bias[c] : 0.f, invW = 1.f / (float)W;
   __syncthreads();
   OWN_FOR(o, {
     int pi, pj;
@@ -952,51 +989,94 @@ __global__ __launch_bounds__(1024) void dwact_bwd_kernel(DwActArgs a) {
   const T* x = (const T*)a.x + cb;
   const T* g = (const T*)a.g + cb;
   T* dx = (T*)a.y + cb;
+  const bool bord = dwact_bordered(a);  // (workgroup-uniform)
+  const int PW = W + 2, PS = (H + 2) * PW;
   float X[EPT], G[EPT];
   OWN_FOR(o, {
     const long q = ok ? b * sb + p : 0;
     X[k] = ldf(x + q);
     G[k] = ldf(g + q);
   })
-  OWN_FOR(o, { if (ok) xs[b * HW + p] = X[k]; })
   float w[9], tap[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) w[k] = a.w[c * 9 + k];
   const float bias = a.bias ? a.bias[c] : 0.f, invW = 1.f / (float)W;
-  __syncthreads();
   float acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-  OWN_FOR(o, {
-    int pi, pj;
-    pix_ij(ok ? p : 0, W, invW, pi, pj);
-    const float u = dw_tap9(xs + (ok ? b : 0) * HW, H, W, pi, pj, a.dil, w, tap) + bias;
-    const float d = ok ? G[k] * act_bwd(a.act, u, a.slope) : 0.f;
-    if (ok) du[b * HW + p] = d;
-    acc[9] += d;
-  })
-  __syncthreads();
-  OWN_FOR(o, {
-    int pi, pj;
-    pix_ij(ok ? p : 0, W, invW, pi, pj);
-    const float* dp = du + (ok ? b : 0) * HW;
-    const float xc = ok ? X[k] : 0.f;
-    float t = 0.f;
+  if (bord) {
+    dwact_zero(xs, a.B * PS);
+    dwact_zero(du, a.B * PS);
+    __syncthreads();
+    int base[EPT];
+    OWN_FOR(o, {
+      int pi, pj;
+      pix_ij(ok ? p : 0, W, invW, pi, pj);
+      base[k] = (ok ? b : 0) * PS + pi * PW + pj;
+      if (ok) xs[base[k] + PW + 1] = X[k];
+    })
+    __syncthreads();
+    OWN_FOR(o, {
+      const float* t0 = xs + base[k];
+      float u = bias;
 _Pragma("unroll")
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yy = pi - (ky - 1) * a.dil;
+      for (int ky = 0; ky < 3; ++ky)
 _Pragma("unroll")
-      for (int kx = 0; kx < 3; ++kx) {
-        const int xx = pj - (kx - 1) * a.dil;
-        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        float v = dp[in ? yy * W + xx : 0];
-        v = in ? v : 0.f;
-        t += w[ky * 3 + kx] * v;
-        acc[ky * 3 + kx] += xc * v;
+        for (int kx = 0; kx < 3; ++kx) u += w[ky * 3 + kx] * t0[ky * PW + kx];
+      const float d = ok ? G[k] * act_bwd(a.act, u, a.slope) : 0.f;
+      if (ok) du[base[k] + PW + 1] = d;
+      acc[9] += d;
+    })
+    __syncthreads();
+    OWN_FOR(o, {
+      // dx(q) = sum_t w[t] du(q - d_t); dW[t] = sum_q x(q) du(q - d_t): tap (ky, kx) reads du at offset (2 - ky, 2 - kx) from base
+      const float* t0 = du + base[k];
+      const float xc = ok ? X[k] : 0.f;
+      float t = 0.f;
+_Pragma("unroll")
+      for (int ky = 0; ky < 3; ++ky)
+_Pragma("unroll")
+        for (int kx = 0; kx < 3; ++kx) {
+          const float v = t0[(2 - ky) * PW + (2 - kx)];
+          t += w[ky * 3 + kx] * v;
+          acc[ky * 3 + kx] += xc * v;
+        }
+      if (ok) stf(dx + b * sb + p, t);
+    })
+  } else {
+    OWN_FOR(o, { if (ok) xs[b * HW + p] = X[k]; })
+    __syncthreads();
+    OWN_FOR(o, {
+      int pi, pj;
+      pix_ij(ok ? p : 0, W, invW, pi, pj);
+      const float u = dw_tap9(xs + (ok ? b : 0) * HW, H, W, pi, pj, a.dil, w, tap) + bias;
+      const float d = ok ? G[k] * act_bwd(a.act, u, a.slope) : 0.f;
+      if (ok) du[b * HW + p] = d;
+      acc[9] += d;
+    })
+    __syncthreads();
+    OWN_FOR(o, {
+      int pi, pj;
+      pix_ij(ok ? p : 0, W, invW, pi, pj);
+      const float* dp = du + (ok ? b : 0) * HW;
+      const float xc = ok ? X[k] : 0.f;
+      float t = 0.f;
+_Pragma("unroll")
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = pi - (ky - 1) * a.dil;
+_Pragma("unroll")
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = pj - (kx - 1) * a.dil;
+          const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          float v = dp[in ? yy * W + xx : 0];
+          v = in ? v : 0.f;
+          t += w[ky * 3 + kx] * v;
+          acc[ky * 3 + kx] += xc * v;
+        }
       }
-    }
-    if (ok) stf(dx + b * sb + p, t);
-  })
+      if (ok) stf(dx + b * sb + p, t);
+    })
+  }
   block_sum_n<10>(acc, red);
   if (threadIdx.x < 9) a.dw[c * 9 + threadIdx.x] += acc[threadIdx.x];
   if (threadIdx.x == 9 && a.db) a.db[c] += acc[9];
