@@ -109,6 +109,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         for (int t = 0; t < n; ++t) {
           Fiber& f = s.fibers[t];
           f.done = false;
+          f.xph = 0;
           f.tid = uint3_sim{(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
           ctx_make(&f.ctx, f.stack, kStack, trampoline);
         }

@@ -60,6 +60,7 @@ struct Fiber {
   Ctx ctx;
   char* stack = nullptr;
   bool done = true;
+  unsigned xph = 0;  // exchanges done so far by this lane (parity picks the xbuf copy)
   uint3_sim tid;
 };
 struct State {
@@ -73,7 +74,10 @@ struct State {
   // wave barriers / exchange
   int warrived[32];
   unsigned wgen[32];
-  alignas(16) unsigned char xbuf[32][64][64];  // per wave, per lane, 64 bytes
+  // per wave, per lane, 64 bytes — TWO copies used alternately (Fiber::xph): a lane that runs ahead into the next exchange writes
+  // the other copy, and cannot reach the one after that before every lane of its wave has passed the barrier in between, i.e.
+  // has finished reading this one.  One wave barrier per exchange / MFMA instead of two (half the fiber switches).
+  alignas(16) unsigned char xbuf2[2][32][64][64];
   std::function<void()> body;
 };
 State& st();
@@ -99,6 +103,11 @@ static inline void __syncthreads() {
 }
 
 static inline int sim_lane() { return hipsim::st().cur & 63; }
+// this lane's exchange buffer set for the exchange it is about to make (and advances its count)
+static inline unsigned char (*sim_xset())[64][64] {
+  auto& s = hipsim::st();
+  return s.xbuf2[s.fibers[s.cur].xph++ & 1];
+}
 static inline int sim_wave() { return hipsim::st().cur >> 6; }
 
 template <typename T>
@@ -106,13 +115,13 @@ static inline T sim_exchange(T v, int src_lane) {
   auto& s = hipsim::st();
   int w = sim_wave(), l = sim_lane();
   static_assert(sizeof(T) <= 64, "exchange payload too large");
-  memcpy(s.xbuf[w][l], &v, sizeof(T));
+  auto xb = sim_xset();
+  memcpy(xb[w][l], &v, sizeof(T));
   hipsim::wave_barrier();
   int nl = s.nthreads - w * 64;
   if (nl > 64) nl = 64;
   T r = v;
-  if (src_lane >= 0 && src_lane < nl) memcpy(&r, s.xbuf[w][src_lane], sizeof(T));
-  hipsim::wave_barrier();
+  if (src_lane >= 0 && src_lane < nl) memcpy(&r, xb[w][src_lane], sizeof(T));
   return r;
 }
 template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
@@ -160,8 +169,9 @@ static inline float sim_bf2f(short h) {
 static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
   auto& s = hipsim::st();
   int w = sim_wave(), l = sim_lane();
+  auto xb = sim_xset();
   float ab[2] = {a, b};
-  memcpy(s.xbuf[w][l], ab, 8);
+  memcpy(xb[w][l], ab, 8);
   hipsim::wave_barrier();
   int col = l & 15;
   for (int r = 0; r < 4; ++r) {
@@ -169,13 +179,12 @@ static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4
     float acc = c[r];
     for (int k = 0; k < 4; ++k) {
       float av, bv;
-      memcpy(&av, s.xbuf[w][k * 16 + row], 4);
-      memcpy(&bv, s.xbuf[w][k * 16 + col] + 4, 4);
+      memcpy(&av, xb[w][k * 16 + row], 4);
+      memcpy(&bv, xb[w][k * 16 + col] + 4, 4);
       acc = fmaf(av, bv, acc);
     }
     c[r] = acc;
   }
-  hipsim::wave_barrier();
   return c;
 }
 
@@ -183,8 +192,9 @@ static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4
 static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c, int, int, int) {
   auto& s = hipsim::st();
   int w = sim_wave(), l = sim_lane();
-  memcpy(s.xbuf[w][l], &a, 16);
-  memcpy(s.xbuf[w][l] + 16, &b, 16);
+  auto xb = sim_xset();
+  memcpy(xb[w][l], &a, 16);
+  memcpy(xb[w][l] + 16, &b, 16);
   hipsim::wave_barrier();
   int col = l & 15;
   for (int r = 0; r < 4; ++r) {
@@ -192,13 +202,12 @@ static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, 
     float acc = c[r];
     for (int k = 0; k < 32; ++k) {
       short av, bv;
-      memcpy(&av, s.xbuf[w][(k >> 3) * 16 + row] + 2 * (k & 7), 2);
-      memcpy(&bv, s.xbuf[w][(k >> 3) * 16 + col] + 16 + 2 * (k & 7), 2);
+      memcpy(&av, xb[w][(k >> 3) * 16 + row] + 2 * (k & 7), 2);
+      memcpy(&bv, xb[w][(k >> 3) * 16 + col] + 16 + 2 * (k & 7), 2);
       acc += sim_bf2f(av) * sim_bf2f(bv);
     }
     c[r] = acc;
   }
-  hipsim::wave_barrier();
   return c;
 }
 
@@ -207,8 +216,9 @@ static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, 
 static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
   auto& s = hipsim::st();
   int w = sim_wave(), l = sim_lane();
-  memcpy(s.xbuf[w][l], &a, 16);
-  memcpy(s.xbuf[w][l] + 16, &b, 16);
+  auto xb = sim_xset();
+  memcpy(xb[w][l], &a, 16);
+  memcpy(xb[w][l] + 16, &b, 16);
   hipsim::wave_barrier();
   const int col = l & 31, h = l >> 5;
   for (int reg = 0; reg < 16; ++reg) {
@@ -216,13 +226,12 @@ static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b,
     float acc = c[reg];
     for (int k = 0; k < 16; ++k) {
       short av, bv;
-      memcpy(&av, s.xbuf[w][(k >> 3) * 32 + row] + 2 * (k & 7), 2);
-      memcpy(&bv, s.xbuf[w][(k >> 3) * 32 + col] + 16 + 2 * (k & 7), 2);
+      memcpy(&av, xb[w][(k >> 3) * 32 + row] + 2 * (k & 7), 2);
+      memcpy(&bv, xb[w][(k >> 3) * 32 + col] + 16 + 2 * (k & 7), 2);
       acc += sim_bf2f(av) * sim_bf2f(bv);
     }
     c[reg] = acc;
   }
-  hipsim::wave_barrier();
   return c;
 }
 
