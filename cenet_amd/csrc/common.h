@@ -224,6 +224,14 @@ int cenet_zero_async(float* p, long n, hipStream_t stream);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// q / n without the ~40-instruction integer division, for 0 <= q < 2^20 (exact there: (q + 0.5) / n is at least 0.5 / n away from
+// an integer, the float product's error is below that); inv = cenet_inv_small(n, bound on q), 0 -> the integer division
+static inline float cenet_inv_small_host(int n, long qmax) { return (n > 0 && qmax < (1L << 20)) ? 1.f / (float)n : 0.f; }
+__device__ __forceinline__ float cenet_inv_small(int n, long qmax) { return (n > 0 && qmax < (1L << 20)) ? 1.f / (float)n : 0.f; }
+__device__ __forceinline__ int cenet_div_small(int q, int n, float inv) {
+  return inv > 0.f ? (int)(((float)q + 0.5f) * inv) : q / n;
+}
+
 // activation ids shared by several kernels
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_GELU = 3, ACT_SILU = 4, ACT_SIGMOID = 5 };
 

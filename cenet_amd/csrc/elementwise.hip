@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256) void chan_dot_v4_kernel(const T* __restrict__ 
                                                          float* __restrict__ out, int B, int HW) {
   __shared__ float red[16];
   const int c = blockIdx.x, nq = HW >> 2, total = B * nq, stride = gridDim.y * 256;
+  const float inv_nq = cenet_inv_small(nq, total);
   float s = 0.f;
   for (int q0 = blockIdx.y * 256 + threadIdx.x; q0 < total; q0 += 2 * stride) {
     float av[2][4], bv[2][4];
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) void chan_dot_v4_kernel(const T* __restrict__ 
         bv[u][e] = 1.f;
       }
       if (q < total) {
-        const int b = q / nq, qi = q - b * nq;
+        const int b = cenet_div_small(q, nq, inv_nq), qi = q - b * nq;
         ld4v(av[u], a + (long)b * sab + (long)c * HW + 4 * qi);
         if (bb) ld4v(bv[u], bb + (long)b * sbb + (long)c * HW + 4 * qi);
       }

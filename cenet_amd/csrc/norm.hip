@@ -866,6 +866,7 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* __restrict_
   const T* xc = x + (long)c * HW;
   const float shift = ldf(xc);
   const int total = B * nq, stride = gridDim.y * 256;
+  const float inv_nq = cenet_inv_small(nq, total);
   float s1 = 0.f, s2 = 0.f;
   for (int q0 = blockIdx.y * 256 + threadIdx.x; q0 < total; q0 += 4 * stride) {
     float v[4][4];
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(256) void bn_partial_v4_kernel(const T* __restrict_
     for (int u = 0; u < 4; ++u) {
       const int q = q0 + u * stride;
       if (q < total) {
-        const int b = q / nq, qi = q - b * nq;
+        const int b = cenet_div_small(q, nq, inv_nq), qi = q - b * nq;
         ld4v(v[u], xc + (long)b * sb + 4 * qi);
       } else {
         v[u][0] = v[u][1] = v[u][2] = v[u][3] = shift;
@@ -933,6 +934,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const T* __restr
   const int c = blockIdx.x, nq = HW >> 2;
   const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
   const int total = B * nq, stride = gridDim.y * 256;
+  const float inv_nq = cenet_inv_small(nq, total);
   float s1 = 0.f, s2 = 0.f;
   for (int q0 = blockIdx.y * 256 + threadIdx.x; q0 < total; q0 += 2 * stride) {
     float xv[2][4], gv[2][4];
@@ -940,7 +942,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const T* __restr
     for (int u = 0; u < 2; ++u) {
       const int q = q0 + u * stride;
       if (q < total) {
-        const int b = q / nq, qi = q - b * nq;
+        const int b = cenet_div_small(q, nq, inv_nq), qi = q - b * nq;
         ld4v(xv[u], x + (long)b * sxb + (long)c * HW + 4 * qi);
         ld4v(gv[u], dy + (long)b * sgb + (long)c * HW + 4 * qi);
       } else {
@@ -1027,8 +1029,9 @@ __global__ __launch_bounds__(256) void bn_apply_flat_kernel(const T* __restrict_
                                                            long nvec, BnFin fin) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
-  const long plane = i / HWv;
-  const int c = (int)(plane % C);
+  // (flat tensors are the small decoder levels: i < 2^20, no 64-bit division — ~150 instructions — in front of four loads)
+  const int plane = nvec < (1L << 20) ? cenet_div_small((int)i, HWv, 1.f / (float)HWv) : (int)(i / HWv);
+  const int c = plane - cenet_div_small(plane, C, plane < (1 << 20) ? 1.f / (float)C : 0.f) * C;
   float mu, vr;
   if (fin.ws) {
     float a1 = 0.f, a2 = 0.f;
@@ -1040,7 +1043,7 @@ __global__ __launch_bounds__(256) void bn_apply_flat_kernel(const T* __restrict_
     vr = a2 / fin.n - m * m;
     if (vr < 0.f) vr = 0.f;
     mu = ldf(x + (long)c * HWv * V) + m;
-    if (plane < C && i == plane * HWv) bn_fin_publish(fin, c, mu, vr);
+    if (plane < C && i == (long)plane * HWv) bn_fin_publish(fin, c, mu, vr);
   } else {
     mu = mean[c], vr = var[c];
   }
@@ -1063,8 +1066,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restr
                                                                const T* __restrict__ dx_add) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nvec) return;
-  const long plane = i / HWv;
-  const int c = (int)(plane % C);
+  // (flat tensors are the small decoder levels: i < 2^20, no 64-bit division — ~150 instructions — in front of four loads)
+  const int plane = nvec < (1L << 20) ? cenet_div_small((int)i, HWv, 1.f / (float)HWv) : (int)(i / HWv);
+  const int c = plane - cenet_div_small(plane, C, plane < (1 << 20) ? 1.f / (float)C : 0.f) * C;
   const float rs = rsqrtf(var[c] + eps), mu = mean[c], gm = gamma[c], bt = beta[c];
   float s1 = 0.f, s2 = 0.f;
   for (int k = 0; k < S; ++k) {
@@ -1086,7 +1090,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const T* __restr
     gv[e] = gm * rs * (g - m1 - xh * m2) + av[e];
   }
   stv<V>(dx + i * V, gv);
-  if (plane < C && i == plane * HWv) {  // first vector of image 0's plane of channel c
+  if (plane < C && i == (long)plane * HWv) {  // first vector of image 0's plane of channel c
     atomicAdd(&dgamma[c], s2);
     atomicAdd(&dbeta[c], s1);
   }
