@@ -229,6 +229,80 @@ __global__ __launch_bounds__(256) void col2im_tok_kernel(const T* __restrict__ g
   }
 }
 
+// ---- the three kernels above with a row per blockIdx.y (round 5): the flat forms decompose a 64-bit element index with six 64-bit
+// divisions per thread (~600 instructions in front of 4 .. 64 two-byte moves); here (image, output row) come from blockIdx.y
+// (workgroup-uniform arithmetic) and (column, channel) from ONE float-reciprocal division of a small index.  Rows <= 65535.
+template <typename T, int S, bool INV>
+__global__ __launch_bounds__(256) void patch_tok_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int C, int Ho, int Wo) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Wo * C) return;
+  const int ox = (int)(((float)i + 0.5f) * (1.f / (float)C)), c = i - ox * C;
+  const int by = blockIdx.y, b = by / Ho, oy = by - b * Ho;
+  const long Wd = (long)Wo * S;
+  const long r = (long)by * Wo + ox;
+  const long tbase = ((((long)b * Ho + oy) * S) * Wd + (long)ox * S) * C + c;
+  const long pbase = (r * C + c) * (S * S);
+#pragma unroll
+  for (int ky = 0; ky < S; ++ky) {
+    T v[S];
+    if (INV) {
+      memcpy(v, src + pbase + ky * S, S * sizeof(T));
+#pragma unroll
+      for (int kx = 0; kx < S; ++kx) dst[tbase + (ky * Wd + kx) * C] = v[kx];
+    } else {
+#pragma unroll
+      for (int kx = 0; kx < S; ++kx) v[kx] = src[tbase + (ky * Wd + kx) * C];
+      memcpy(dst + pbase + ky * S, v, S * sizeof(T));
+    }
+  }
+}
+template <typename T, int K>
+__global__ __launch_bounds__(256) void im2col_tok_rows_kernel(const T* __restrict__ x, T* __restrict__ xp, int C, int H, int W, int Ho,
+                                                             int Wo, int stride, int pad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Wo * C) return;
+  const int ox = (int)(((float)i + 0.5f) * (1.f / (float)C)), c = i - ox * C;
+  const int by = blockIdx.y, b = by / Ho, oy = by - b * Ho;
+  T v[K * K];
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      T e = x[in ? (((long)b * H + iy) * W + ix) * C + c : 0];  // (unconditional load on a clamped address)
+      if (!in) stf(&e, 0.f);
+      v[ky * K + kx] = e;
+    }
+  T* o = xp + (((long)by * Wo + ox) * C + c) * (K * K);
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) o[t] = v[t];
+}
+template <typename T, int K, bool S2>
+__global__ __launch_bounds__(256) void col2im_tok_rows_kernel(const T* __restrict__ gp, T* __restrict__ dx, int C, int H, int W, int Ho,
+                                                             int Wo, int stride, int pad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W * C) return;
+  const int ix = (int)(((float)i + 0.5f) * (1.f / (float)C)), c = i - ix * C;
+  const int by = blockIdx.y, b = by / H, iy = by - b * H;
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int ny = iy + pad - ky;
+    const int oy = S2 ? ny >> 1 : ny / stride;
+    const bool yok = ny >= 0 && (S2 ? (ny & 1) == 0 : ny % stride == 0) && oy < Ho;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int nx = ix + pad - kx;
+      const int ox = S2 ? nx >> 1 : nx / stride;
+      const bool ok = yok && nx >= 0 && (S2 ? (nx & 1) == 0 : nx % stride == 0) && ox < Wo;
+      const float g = ldf(gp + (ok ? ((((long)b * Ho + oy) * Wo + ox) * C + c) * (K * K) + ky * K + kx : 0));
+      acc += ok ? g : 0.f;
+    }
+  }
+  stf(dx + ((long)by * W + ix) * C + c, acc);
+}
+
 // ---- y[b, i] = s[b] * x[b, i] ------------------------------------------------------------------------------------
 template <typename T, int V>
 __global__ __launch_bounds__(256) void scale_batch_kernel(const T* __restrict__ x, const float* __restrict__ s,
@@ -975,8 +1049,15 @@ template <typename T>
 static int patch_tok_impl(const T* src, T* dst, int B, int Ho, int Wo, int C, int S, int inverse, hipStream_t stream) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (S != 2 && S != 4 && S != 8)) return CENET_EINVAL;
   const long total = (long)B * Ho * Wo * C;
-#define PATCH_GO(S_, INV_) \
-  CENET_LAUNCH((patch_tok_kernel<T, S_, INV_>), EW_GRID(total), dim3(256), stream, src, dst, C, Ho, Wo, total)
+  const bool rows = (long)B * Ho <= 65535 && (long)Wo * C < (1L << 20);
+#define PATCH_GO(S_, INV_)                                                                                                \
+  do {                                                                                                                    \
+    if (rows)                                                                                                             \
+      CENET_LAUNCH((patch_tok_rows_kernel<T, S_, INV_>), dim3(cdiv((long)Wo * C, 256), B * Ho), dim3(256), stream, src, dst, C, Ho, \
+                   Wo);                                                                                                   \
+    else                                                                                                                  \
+      CENET_LAUNCH((patch_tok_kernel<T, S_, INV_>), EW_GRID(total), dim3(256), stream, src, dst, C, Ho, Wo, total);        \
+  } while (0)
   if (S == 2) {
     if (inverse) PATCH_GO(2, true); else PATCH_GO(2, false);
   } else if (S == 4) {
@@ -997,9 +1078,16 @@ static int im2col_tok_impl(const T* src, T* dst, int B, int H, int W, int C, int
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K != 3 || stride < 1 || pad < 0) return CENET_EINVAL;
   const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return CENET_EINVAL;
-  if (inverse) {
+  if (inverse && (long)B * H <= 65535 && (long)W * C < (1L << 20)) {
+    const dim3 grid(cdiv((long)W * C, 256), B * H);
+    if (stride == 2) CENET_LAUNCH((col2im_tok_rows_kernel<T, 3, true>), grid, dim3(256), stream, src, dst, C, H, W, Ho, Wo, stride, pad);
+    else CENET_LAUNCH((col2im_tok_rows_kernel<T, 3, false>), grid, dim3(256), stream, src, dst, C, H, W, Ho, Wo, stride, pad);
+  } else if (inverse) {
     const long total = (long)B * H * W * C;
     CENET_LAUNCH((col2im_tok_kernel<T, 3>), EW_GRID(total), dim3(256), stream, src, dst, C, H, W, Ho, Wo, stride, pad, total);
+  } else if ((long)B * Ho <= 65535 && (long)Wo * C < (1L << 20)) {
+    CENET_LAUNCH((im2col_tok_rows_kernel<T, 3>), dim3(cdiv((long)Wo * C, 256), B * Ho), dim3(256), stream, src, dst, C, H, W, Ho, Wo,
+                 stride, pad);
   } else {
     const long total = (long)B * Ho * Wo * C;
     CENET_LAUNCH((im2col_tok_kernel<T, 3>), EW_GRID(total), dim3(256), stream, src, dst, C, H, W, Ho, Wo, stride, pad, total);
