@@ -833,27 +833,31 @@ __global__ __launch_bounds__(256) void diffattn_combine_bwd_kernel(const T* __re
 // vector, LPV = dv / 8 lanes share one, the values stay in registers between the statistics and the write (the scalar forms
 // above read every element twice through 2-byte loads: 62 us for 154 MB at 56x56).
 template <int LPV>
-__device__ __forceinline__ float lpv_sum(float v) {
+__device__ __forceinline__ float lpv_sum(float v) {  // sum over aligned groups of LPV lanes, every lane of the group gets it
+#ifdef CENET_HOSTSIM_BUILD
 #pragma unroll
   for (int o = LPV >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+#else
+  if (LPV >= 2) v += dpp_f<0xb1, 0xf>(0.f, v);  // quad_perm [1, 0, 3, 2]
+  if (LPV >= 4) v += dpp_f<0x4e, 0xf>(0.f, v);  // quad_perm [2, 3, 0, 1]
+#pragma unroll
+  for (int o = 4; o < LPV; o <<= 1) v += __shfl_xor(v, o);
+#endif
   return v;
 }
+// grid (ceil(N * LPV / 256), B * H): (batch, pair) from blockIdx.y, the token from a shift — the flat forms spent four 64-bit
+// divisions per thread (~400 instructions) on eight elements
 template <int LPV>
 __global__ __launch_bounds__(256) void diffattn_combine_fwd_v8_kernel(const bf16_t* __restrict__ U, const float* __restrict__ lam,
-                                                                     bf16_t* __restrict__ out, int H, int N, float eps, float post,
-                                                                     long nvec) {
+                                                                     bf16_t* __restrict__ out, int H, int N, float eps, float post) {
   constexpr int dv = 8 * LPV;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const long vec = t / LPV;
-  const int sl = (int)(t - vec * LPV);
-  const bool ok = vec < nvec;  // (LPV divides 64: the lanes of a vector leave together)
-  const long vv = ok ? vec : 0;
-  const int n = (int)(vv % N);
-  const long bh = vv / N;
-  const int h = (int)(bh % H);
-  const long b = bh / H;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nn = t / LPV, sl = t - nn * LPV;
+  const bool ok = nn < N;  // (LPV divides 64: the lanes of a vector leave together)
+  const int n = ok ? nn : 0;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
   const float lm = lam[0];
-  const bf16_t* u0 = U + (((b * 2 * H) + 2 * h) * N + n) * (long)dv + 8 * sl;
+  const bf16_t* u0 = U + ((((long)b * 2 * H) + 2 * h) * N + n) * (long)dv + 8 * sl;
   float a0[8], a1[8];
   ldv<8>(a0, u0);
   ldv<8>(a1, u0 + (long)N * dv);
@@ -866,56 +870,61 @@ __global__ __launch_bounds__(256) void diffattn_combine_fwd_v8_kernel(const bf16
   const float r = rsqrtf(lpv_sum<LPV>(ss) / dv + eps) * post;
 #pragma unroll
   for (int e = 0; e < 8; ++e) a0[e] *= r;
-  if (ok) stv<8>(out + (b * N + n) * (long)(H * dv) + (long)h * dv + 8 * sl, a0);
+  if (ok) stv<8>(out + ((long)b * N + n) * (long)(H * dv) + (long)h * dv + 8 * sl, a0);
 }
+// grid (ceil(N * LPV / 2048), B * H): eight vectors per thread, two at a time with their loads issued together; ONE dlam atomic per
+// workgroup (they all hit one address and retire at ~12 ns each: 3 200 workgroups were 38 us of atomics behind 16 us of traffic)
 template <int LPV>
 __global__ __launch_bounds__(256) void diffattn_combine_bwd_v8_kernel(const bf16_t* __restrict__ U, const float* __restrict__ lam,
                                                                      const bf16_t* __restrict__ dout, bf16_t* __restrict__ dU,
-                                                                     float* __restrict__ dlam, int H, int N, float eps, float post,
-                                                                     long nvec) {
+                                                                     float* __restrict__ dlam, int H, int N, float eps, float post) {
   constexpr int dv = 8 * LPV;
   __shared__ float part[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
   const float lm = lam[0];
   float dl = 0.f;
-  // grid-stride: one dlam atomic per workgroup and few workgroups (the atomics all hit one address)
-  const long total = nvec * LPV;
-  for (long base = (long)blockIdx.x * 256; base < total; base += (long)gridDim.x * 256) {  // (workgroup-uniform trip count)
-    const bool ok = base + threadIdx.x < total;
-    const long t = ok ? base + threadIdx.x : 0;
-    const long vec = t / LPV;
-    const int sl = (int)(t - vec * LPV);
-    const int n = (int)(vec % N);
-    const long bh = vec / N;
-    const int h = (int)(bh % H);
-    const long b = bh / H;
-    const long off0 = (((b * 2 * H) + 2 * h) * N + n) * (long)dv + 8 * sl;
-    float a[8], u1[8], g[8];
-    ldv<8>(a, U + off0);
-    ldv<8>(u1, U + off0 + (long)N * dv);
-    ldv<8>(g, dout + (b * N + n) * (long)(H * dv) + (long)h * dv + 8 * sl);
-    float ss = 0.f, ga = 0.f;
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    float a[2][8], u1[2][8], g[2][8];
+    long off0[2];
+    bool ok[2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      a[e] -= lm * u1[e];
-      ss += a[e] * a[e];
-      ga += g[e] * a[e];
+    for (int k = 0; k < 2; ++k) {
+      const int t = ((blockIdx.x * 4 + it) * 2 + k) * 256 + threadIdx.x;
+      const int nn = t / LPV, sl = t - nn * LPV;
+      ok[k] = nn < N;
+      const int n = ok[k] ? nn : 0;
+      off0[k] = ((((long)b * 2 * H) + 2 * h) * N + n) * (long)dv + 8 * sl;
+      ldv<8>(a[k], U + off0[k]);
+      ldv<8>(u1[k], U + off0[k] + (long)N * dv);
+      ldv<8>(g[k], dout + ((long)b * N + n) * (long)(H * dv) + (long)h * dv + 8 * sl);
     }
-    ss = lpv_sum<LPV>(ss);
-    ga = lpv_sum<LPV>(ga);
-    const float r = rsqrtf(ss / dv + eps);
-    const float k = r * r * ga / dv;
-    float d0[8], d1[8];
-    if (ok) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float ss = 0.f, ga = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float da = post * r * (g[e] - a[e] * k);
+        a[k][e] -= lm * u1[k][e];
+        ss += a[k][e] * a[k][e];
+        ga += g[k][e] * a[k][e];
+      }
+      ss = lpv_sum<LPV>(ss);
+      ga = lpv_sum<LPV>(ga);
+      const float r = rsqrtf(ss / dv + eps);
+      const float kk = r * r * ga / dv;
+      float d0[8], d1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float da = post * r * (g[k][e] - a[k][e] * kk);
         d0[e] = da;
         d1[e] = -lm * da;
-        dl -= da * u1[e];
+        if (ok[k]) dl -= da * u1[k][e];
       }
-      stv<8>(dU + off0, d0);
-      stv<8>(dU + off0 + (long)N * dv, d1);
+      if (ok[k]) {
+        stv<8>(dU + off0[k], d0);
+        stv<8>(dU + off0[k] + (long)N * dv, d1);
+      }
     }
   }
   dl = wave_sum(dl);
@@ -1340,12 +1349,12 @@ static int diffattn_combine_fwd_impl(const T* U, const float* lam3, T* out, int 
                                      hipStream_t stream) {
   if (B <= 0 || H <= 0 || N <= 0 || dv <= 0) return CENET_EINVAL;
   long nvec = (long)B * H * N;
-  if (sizeof(T) == 2 && (dv == 16 || dv == 32 || dv == 64) && ((((uintptr_t)U | (uintptr_t)out) & 15) == 0)) {
+  if (sizeof(T) == 2 && (dv == 16 || dv == 32 || dv == 64) && ((((uintptr_t)U | (uintptr_t)out) & 15) == 0) && (long)B * H <= 65535) {
     const int lpv = dv / 8;
-    const dim3 grid((unsigned)((nvec * lpv + 255) / 256));
-    if (lpv == 2) CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<2>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post, nvec);
-    else if (lpv == 4) CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<4>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post, nvec);
-    else CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<8>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post, nvec);
+    const dim3 grid(cdiv((long)N * lpv, 256), B * H);
+    if (lpv == 2) CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<2>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post);
+    else if (lpv == 4) CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<4>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post);
+    else CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<8>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post);
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }
@@ -1365,14 +1374,12 @@ static int diffattn_combine_bwd_acc_impl(const T* U, const float* lam3, const T*
   if (B <= 0 || H <= 0 || N <= 0 || dv <= 0) return CENET_EINVAL;
   long nvec = (long)B * H * N;
   if (sizeof(T) == 2 && (dv == 16 || dv == 32 || dv == 64) &&
-      ((((uintptr_t)U | (uintptr_t)dout | (uintptr_t)dU) & 15) == 0)) {
+      ((((uintptr_t)U | (uintptr_t)dout | (uintptr_t)dU) & 15) == 0) && (long)B * H <= 65535) {
     const int lpv = dv / 8;
-    long wgs = (nvec * lpv + 255) / 256;
-    if (wgs > 2048) wgs = 2048;
-    const dim3 grid((unsigned)wgs);
-    if (lpv == 2) CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<2>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post, nvec);
-    else if (lpv == 4) CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<4>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post, nvec);
-    else CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<8>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post, nvec);
+    const dim3 grid(cdiv((long)N * lpv, 2048), B * H);
+    if (lpv == 2) CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<2>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post);
+    else if (lpv == 4) CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<4>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post);
+    else CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<8>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post);
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }
