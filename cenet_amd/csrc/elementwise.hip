@@ -849,15 +849,17 @@ __device__ __forceinline__ float lpv_sum(float v) {  // sum over aligned groups 
 // divisions per thread (~400 instructions) on eight elements
 template <int LPV>
 __global__ __launch_bounds__(256) void diffattn_combine_fwd_v8_kernel(const bf16_t* __restrict__ U, const float* __restrict__ lam,
-                                                                     bf16_t* __restrict__ out, int H, int N, float eps, float post) {
-  constexpr int dv = 8 * LPV;
+                                                                     bf16_t* __restrict__ out, int H, int N, float eps, float post,
+                                                                     int dv) {
+  // (dv == 8 LPV, or LPV == 32 with dv / 8 < 32 active lanes per vector: head dimension 80 -> dv = 160 = 20 lanes)
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int nn = t / LPV, sl = t - nn * LPV;
-  const bool ok = nn < N;  // (LPV divides 64: the lanes of a vector leave together)
-  const int n = ok ? nn : 0;
+  const bool act = 8 * sl < dv;
+  const bool ok = nn < N && act;  // (LPV divides 64: the lanes of a vector leave together)
+  const int n = nn < N ? nn : 0;
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
   const float lm = lam[0];
-  const bf16_t* u0 = U + ((((long)b * 2 * H) + 2 * h) * N + n) * (long)dv + 8 * sl;
+  const bf16_t* u0 = U + ((((long)b * 2 * H) + 2 * h) * N + n) * (long)dv + (act ? 8 * sl : 0);
   float a0[8], a1[8];
   ldv<8>(a0, u0);
   ldv<8>(a1, u0 + (long)N * dv);
@@ -865,7 +867,7 @@ __global__ __launch_bounds__(256) void diffattn_combine_fwd_v8_kernel(const bf16
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     a0[e] -= lm * a1[e];
-    ss += a0[e] * a0[e];
+    ss += act ? a0[e] * a0[e] : 0.f;
   }
   const float r = rsqrtf(lpv_sum<LPV>(ss) / dv + eps) * post;
 #pragma unroll
@@ -877,8 +879,8 @@ __global__ __launch_bounds__(256) void diffattn_combine_fwd_v8_kernel(const bf16
 template <int LPV>
 __global__ __launch_bounds__(256) void diffattn_combine_bwd_v8_kernel(const bf16_t* __restrict__ U, const float* __restrict__ lam,
                                                                      const bf16_t* __restrict__ dout, bf16_t* __restrict__ dU,
-                                                                     float* __restrict__ dlam, int H, int N, float eps, float post) {
-  constexpr int dv = 8 * LPV;
+                                                                     float* __restrict__ dlam, int H, int N, float eps, float post,
+                                                                     int dv) {
   __shared__ float part[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -893,12 +895,13 @@ __global__ __launch_bounds__(256) void diffattn_combine_bwd_v8_kernel(const bf16
     for (int k = 0; k < 2; ++k) {
       const int t = ((blockIdx.x * 4 + it) * 2 + k) * 256 + threadIdx.x;
       const int nn = t / LPV, sl = t - nn * LPV;
-      ok[k] = nn < N;
-      const int n = ok[k] ? nn : 0;
-      off0[k] = ((((long)b * 2 * H) + 2 * h) * N + n) * (long)dv + 8 * sl;
+      const bool act = 8 * sl < dv;
+      ok[k] = nn < N && act;
+      const int n = nn < N ? nn : 0, so = act ? 8 * sl : 0;
+      off0[k] = ((((long)b * 2 * H) + 2 * h) * N + n) * (long)dv + so;
       ldv<8>(a[k], U + off0[k]);
       ldv<8>(u1[k], U + off0[k] + (long)N * dv);
-      ldv<8>(g[k], dout + ((long)b * N + n) * (long)(H * dv) + (long)h * dv + 8 * sl);
+      ldv<8>(g[k], dout + ((long)b * N + n) * (long)(H * dv) + (long)h * dv + so);
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -906,8 +909,8 @@ __global__ __launch_bounds__(256) void diffattn_combine_bwd_v8_kernel(const bf16
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         a[k][e] -= lm * u1[k][e];
-        ss += a[k][e] * a[k][e];
-        ga += g[k][e] * a[k][e];
+        ss += ok[k] ? a[k][e] * a[k][e] : 0.f;
+        ga += ok[k] ? g[k][e] * a[k][e] : 0.f;
       }
       ss = lpv_sum<LPV>(ss);
       ga = lpv_sum<LPV>(ga);
@@ -1349,12 +1352,13 @@ static int diffattn_combine_fwd_impl(const T* U, const float* lam3, T* out, int 
                                      hipStream_t stream) {
   if (B <= 0 || H <= 0 || N <= 0 || dv <= 0) return CENET_EINVAL;
   long nvec = (long)B * H * N;
-  if (sizeof(T) == 2 && (dv == 16 || dv == 32 || dv == 64) && ((((uintptr_t)U | (uintptr_t)out) & 15) == 0) && (long)B * H <= 65535) {
-    const int lpv = dv / 8;
+  if (sizeof(T) == 2 && (dv & 7) == 0 && dv <= 256 && ((((uintptr_t)U | (uintptr_t)out) & 15) == 0) && (long)B * H <= 65535) {
+    const int lpv = (dv == 16 || dv == 32 || dv == 64) ? dv / 8 : 32;
     const dim3 grid(cdiv((long)N * lpv, 256), B * H);
-    if (lpv == 2) CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<2>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post);
-    else if (lpv == 4) CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<4>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post);
-    else CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<8>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post);
+    if (lpv == 2) CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<2>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post, dv);
+    else if (lpv == 4) CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<4>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post, dv);
+    else if (lpv == 32) CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<32>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post, dv);
+    else CENET_LAUNCH((diffattn_combine_fwd_v8_kernel<8>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (bf16_t*)out, H, N, eps, post, dv);
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }
@@ -1373,13 +1377,14 @@ static int diffattn_combine_bwd_acc_impl(const T* U, const float* lam3, const T*
                                          int N, int dv, float eps, float post, hipStream_t stream) {
   if (B <= 0 || H <= 0 || N <= 0 || dv <= 0) return CENET_EINVAL;
   long nvec = (long)B * H * N;
-  if (sizeof(T) == 2 && (dv == 16 || dv == 32 || dv == 64) &&
+  if (sizeof(T) == 2 && (dv & 7) == 0 && dv <= 256 &&
       ((((uintptr_t)U | (uintptr_t)dout | (uintptr_t)dU) & 15) == 0) && (long)B * H <= 65535) {
-    const int lpv = dv / 8;
+    const int lpv = (dv == 16 || dv == 32 || dv == 64) ? dv / 8 : 32;
     const dim3 grid(cdiv((long)N * lpv, 2048), B * H);
-    if (lpv == 2) CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<2>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post);
-    else if (lpv == 4) CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<4>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post);
-    else CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<8>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post);
+    if (lpv == 2) CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<2>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post, dv);
+    else if (lpv == 4) CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<4>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post, dv);
+    else if (lpv == 32) CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<32>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post, dv);
+    else CENET_LAUNCH((diffattn_combine_bwd_v8_kernel<8>), grid, dim3(256), stream, (const bf16_t*)U, lam3, (const bf16_t*)dout, (bf16_t*)dU, dlam_acc, H, N, eps, post, dv);
     CENET_CHECK_LAUNCH();
     return CENET_OK;
   }
