@@ -335,8 +335,12 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // hardware exponential (v_exp_f32 on the device build; libm on the host checker)
 #ifdef CENET_HOSTSIM_BUILD
 __device__ __forceinline__ float fast_exp(float x) { return expf(x); }
+__device__ __forceinline__ float fast_log(float x) { return logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return 1.f / x; }
 #else
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_log(float x) { return __logf(x); }           // v_log_f32 * ln 2
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32 (1 ulp)
 #endif
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }

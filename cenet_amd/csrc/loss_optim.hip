@@ -7,14 +7,20 @@
 #include "../../include/cenet_hip.h"
 
 #define LOSS_MAXK 16
-// the partial sums of a workgroup land in one of LOSS_SLOTS replicas of acc, LOSS_SLOT_STRIDE floats (256 bytes) apart: float
-// atomics onto one cache line serialise (~12 ns each), so thousands of workgroups must not share a line
-#define LOSS_SLOTS 16
-#define LOSS_SLOT_STRIDE 128
+// float atomics onto one cache line serialise (~12 ns each), so thousands of workgroups must not share a line.
+// Round 5: one value PER 64-BYTE LINE — replica s of value v sits at acc[(v * ns + s) * 16], ns = loss_ns(K) replicas.  With the
+// 13 - 65 values of a replica in one line (the layout until then), the ~10 000 adds of a forward launch queued on 16 lines: 26 of the
+// kernel's 32 us.  The finalize kernel folds the replicas into the compact [0 .. 5K+1) layout the backward kernel reads.
+#define LOSS_ACC_FLOATS 16384
+__host__ __device__ static inline int loss_ns(int K) {
+  const int ns = LOSS_ACC_FLOATS / ((4 * K + 1) * 16);
+  return ns > 16 ? 16 : (ns < 1 ? 1 : ns);
+}
 
 // acc layout: [0..K) intersect, [K..2K) z_sum (p^2), [2K..3K) y_sum (t), [3K] ce_sum, [3K+1..4K+1) boundary pixel counts
 // (BoundaryDoULoss, core.py:105-109), and after finalize [4K+1..5K+1) the per-class alpha of core.py:112-119
 // KM: compile-time bound of the class loops (4 / 9 / 16: the predicated 16-way loops cost 4x the work at K = 4)
+#define DICE_IT 8
 template <typename T, int KM>
 __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ labels,
                                                          float* __restrict__ acc, int K, int HW, long npix, int W,
@@ -25,32 +31,51 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const T* __restrict__ 
   for (int i = 0; i < 3 * KM + 1; ++i) part[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < KM; ++i) bnd[i] = 0.f;
-  const int H = HW / W;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
-    const long b = e / HW;
-    const int p = (int)(e - b * HW);
-    const T* lp = logits + b * (long)K * HW + p;
+  // grid (ceil(HW / (256 IT)), B): a thread owns IT pixels of image blockIdx.y, all their loads issued together (the flat grid-stride
+  // form put a 64-bit division and a dependent round trip of loads in front of every pixel: 32 us for 19 MB)
+  constexpr int IT = KM > 9 ? 4 : DICE_IT;  // (16 classes x 8 pixels would not stay in registers)
+  const int H = HW / W, b = blockIdx.y;
+  const T* lb0 = logits + (long)b * K * HW;
+  const float* lab = labels + (long)b * HW;
+#pragma unroll 1
+  for (int k0 = 0; k0 < IT; k0 += 2) {  // two pixels at a time (the fully unrolled eight ran slower than the loop it replaced)
+  float vv[2][KM], tl[2];
+  int pp[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int p = (blockIdx.x * IT + k0 + k) * 256 + threadIdx.x;
+    pp[k] = p < HW ? p : -1;
+    const int q = p < HW ? p : 0;
+#pragma unroll
+    for (int c = 0; c < KM; ++c)
+      if (c < K) vv[k][c] = ldf(lb0 + (long)c * HW + q);
+    tl[k] = lab[q];
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (pp[k] < 0) continue;
+    const int p = pp[k];
     float v[KM];
     float mx = -3.4e38f;
 #pragma unroll
     for (int c = 0; c < KM; ++c)
       if (c < K) {
-        v[c] = ldf(lp + (long)c * HW);
+        v[c] = vv[k][c];
         mx = fmaxf(mx, v[c]);
       }
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < KM; ++c)
       if (c < K) {
-        v[c] = expf(v[c] - mx);
+        v[c] = fast_exp(v[c] - mx);  // (libm's expf / logf / the IEEE division: ~70 instructions per class and pixel)
         s += v[c];
       }
-    const float inv = 1.f / s;
-    const int t = (int)labels[e];
+    const float inv = fast_rcp(s);
+    const int t = (int)tl[k];
     bool edge = false;
     if (boundary) {  // a foreground pixel of class t is a boundary pixel unless its four neighbours (zero padded) share t
       const int py = p / W, px = p - py * W;
-      const float* lb = labels + b * HW;
+      const float* lb = lab;
       edge = !(py > 0 && (int)lb[p - W] == t && py + 1 < H && (int)lb[p + W] == t && px > 0 && (int)lb[p - 1] == t &&
                px + 1 < W && (int)lb[p + 1] == t);
     }
@@ -63,34 +88,37 @@ __global__ __launch_bounds__(256) void dice_ce_fwd_kernel(const T* __restrict__ 
         if (c == t) {
           part[c] += pc;
           part[2 * KM + c] += 1.f;
-          part[3 * KM] -= logf(fmaxf(pc, 1e-37f));
+          part[3 * KM] -= fast_log(fmaxf(pc, 1e-37f));
         }
       }
   }
-  float* slot = acc + (blockIdx.x % LOSS_SLOTS) * LOSS_SLOT_STRIDE;
+  }
+  const int ns = loss_ns(K), rep = (blockIdx.y * gridDim.x + blockIdx.x) % ns;
+  auto put = [&](int v, float x) { atomicAdd(&acc[(v * ns + rep) * 16], x); };
 #pragma unroll  // static indices: part[] must stay in registers
   for (int c = 0; c < KM; ++c)
     if (c < K) {
       float a0 = block_sum(part[c], red), a1 = block_sum(part[KM + c], red), a2 = block_sum(part[2 * KM + c], red);
       const float a3 = boundary ? block_sum(bnd[c], red) : 0.f;
       if (threadIdx.x == 0) {
-        atomicAdd(&slot[c], a0);
-        atomicAdd(&slot[K + c], a1);
-        atomicAdd(&slot[2 * K + c], a2);
-        if (boundary) atomicAdd(&slot[3 * K + 1 + c], a3);
+        put(c, a0);
+        put(K + c, a1);
+        put(2 * K + c, a2);
+        if (boundary) put(3 * K + 1 + c, a3);
       }
     }
   float ce = block_sum(part[3 * KM], red);
-  if (threadIdx.x == 0) atomicAdd(&slot[3 * K], ce);
+  if (threadIdx.x == 0) put(3 * K, ce);
 }
 
 __global__ void dice_ce_finalize_kernel(float* __restrict__ acc, float* __restrict__ loss, int K, float npix,
                                         float w_dice, float w_ce, float w_bd) {
-  if (threadIdx.x < 4 * K + 1) {  // fold the replicas into slot 0 (what the backward kernel reads)
-    float t = 0.f;
-    for (int sidx = 0; sidx < LOSS_SLOTS; ++sidx) t += acc[sidx * LOSS_SLOT_STRIDE + threadIdx.x];
-    acc[threadIdx.x] = t;
-  }
+  float t = 0.f;  // fold the replicas into the compact layout (what the backward kernel reads): all reads, then all writes
+  const int ns = loss_ns(K);
+  if (threadIdx.x < 4 * K + 1)
+    for (int sidx = 0; sidx < ns; ++sidx) t += acc[(threadIdx.x * ns + sidx) * 16];
+  __syncthreads();
+  if (threadIdx.x < 4 * K + 1) acc[threadIdx.x] = t;
   __syncthreads();
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float d = 0.f, bd = 0.f;
@@ -130,28 +158,43 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const T* __restrict__ 
       }
     }
   const float cew = w_ce / (float)npix;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npix; e += (long)gridDim.x * 256) {
-    const long b = e / HW;
-    const int p = (int)(e - b * HW);
-    const T* lp = logits + b * (long)K * HW + p;
-    T* dp = dlogits + b * (long)K * HW + p;
+  constexpr int IT = 4;  // grid (ceil(HW / (256 IT)), B), as the forward kernel
+  const int b = blockIdx.y;
+  const T* lb0 = logits + (long)b * K * HW;
+  T* db0 = dlogits + (long)b * K * HW;
+  const float* lab = labels + (long)b * HW;
+  float vv[IT][KM], tl[IT];
+  int pp[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int p = (blockIdx.x * IT + k) * 256 + threadIdx.x;
+    pp[k] = p < HW ? p : -1;
+    const int q = p < HW ? p : 0;
+#pragma unroll
+    for (int c = 0; c < KM; ++c)
+      if (c < K) vv[k][c] = ldf(lb0 + (long)c * HW + q);
+    tl[k] = lab[q];
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    if (pp[k] < 0) continue;
     float v[KM];
     float mx = -3.4e38f;
 #pragma unroll
     for (int c = 0; c < KM; ++c)
       if (c < K) {
-        v[c] = ldf(lp + (long)c * HW);
+        v[c] = vv[k][c];
         mx = fmaxf(mx, v[c]);
       }
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < KM; ++c)
       if (c < K) {
-        v[c] = expf(v[c] - mx);
+        v[c] = fast_exp(v[c] - mx);  // (libm's expf / logf / the IEEE division: ~70 instructions per class and pixel)
         s += v[c];
       }
-    const float inv = 1.f / s;
-    const int t = (int)labels[e];
+    const float inv = fast_rcp(s);
+    const int t = (int)tl[k];
     float gp[KM];
     float dot = 0.f;
 #pragma unroll
@@ -163,7 +206,7 @@ __global__ __launch_bounds__(256) void dice_ce_bwd_kernel(const T* __restrict__ 
       }
 #pragma unroll
     for (int c = 0; c < KM; ++c)
-      if (c < K) stf(dp + (long)c * HW, go * (v[c] * (gp[c] - dot) + cew * (v[c] - (c == t ? 1.f : 0.f))));
+      if (c < K) stf(db0 + (long)c * HW + pp[k], go * (v[c] * (gp[c] - dot) + cew * (v[c] - (c == t ? 1.f : 0.f))));
   }
 }
 
@@ -210,15 +253,15 @@ template <typename T>
 static int seg_loss_fwd_impl(const T* logits, const float* labels, float* acc, float* loss, int B, int K, int H, int W,
                              float w_dice, float w_ce, float w_bd, hipStream_t stream) {
   if (B <= 0 || K <= 0 || K > LOSS_MAXK || H <= 0 || W <= 0) return CENET_EINVAL;
-  if (cenet_zero_async(acc, (long)LOSS_SLOTS * LOSS_SLOT_STRIDE, stream) != CENET_OK) return CENET_EINVAL;
+  if (cenet_zero_async(acc, (long)LOSS_ACC_FLOATS, stream) != CENET_OK) return CENET_EINVAL;
   const int HW = H * W;
   const long npix = (long)B * HW;
-  long blocks = (npix + 2047) / 2048;
-  if (blocks > 1024) blocks = 1024;
+  if (B > 65535) return CENET_EUNSUPPORTED;
+  const dim3 blocks(cdiv(HW, 256 * (K > 9 ? 4 : DICE_IT)), B);
   const int bnd = (int)(w_bd != 0.f);
-  if (K <= 4) CENET_LAUNCH((dice_ce_fwd_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W, bnd);
-  else if (K <= 9) CENET_LAUNCH((dice_ce_fwd_kernel<T, 9>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W, bnd);
-  else CENET_LAUNCH((dice_ce_fwd_kernel<T, LOSS_MAXK>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, K, HW, npix, W, bnd);
+  if (K <= 4) CENET_LAUNCH((dice_ce_fwd_kernel<T, 4>), blocks, dim3(256), stream, logits, labels, acc, K, HW, npix, W, bnd);
+  else if (K <= 9) CENET_LAUNCH((dice_ce_fwd_kernel<T, 9>), blocks, dim3(256), stream, logits, labels, acc, K, HW, npix, W, bnd);
+  else CENET_LAUNCH((dice_ce_fwd_kernel<T, LOSS_MAXK>), blocks, dim3(256), stream, logits, labels, acc, K, HW, npix, W, bnd);
   CENET_LAUNCH(dice_ce_finalize_kernel, dim3(1), dim3(128), stream, acc, loss, K, (float)npix, w_dice, w_ce, w_bd);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
@@ -233,11 +276,11 @@ static int seg_loss_bwd_impl(const T* logits, const float* labels, const float* 
   if (B <= 0 || K <= 0 || K > LOSS_MAXK || H <= 0 || W <= 0) return CENET_EINVAL;
   const int HW = H * W;
   const long npix = (long)B * HW;
-  long blocks = (npix + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  if (K <= 4) CENET_LAUNCH((dice_ce_bwd_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix, w_dice, w_ce, w_bd);
-  else if (K <= 9) CENET_LAUNCH((dice_ce_bwd_kernel<T, 9>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix, w_dice, w_ce, w_bd);
-  else CENET_LAUNCH((dice_ce_bwd_kernel<T, LOSS_MAXK>), dim3((unsigned)blocks), dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix, w_dice, w_ce, w_bd);
+  if (B > 65535) return CENET_EUNSUPPORTED;
+  const dim3 blocks(cdiv(HW, 256 * 4), B);
+  if (K <= 4) CENET_LAUNCH((dice_ce_bwd_kernel<T, 4>), blocks, dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix, w_dice, w_ce, w_bd);
+  else if (K <= 9) CENET_LAUNCH((dice_ce_bwd_kernel<T, 9>), blocks, dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix, w_dice, w_ce, w_bd);
+  else CENET_LAUNCH((dice_ce_bwd_kernel<T, LOSS_MAXK>), blocks, dim3(256), stream, logits, labels, acc, gout, dlogits, K, HW, npix, w_dice, w_ce, w_bd);
   CENET_CHECK_LAUNCH();
   return CENET_OK;
 }

@@ -3068,7 +3068,7 @@ class DiceCELossFn(Function):
         logits, labels = _c(logits), _c(labels)
         B, K = logits.shape[:2]
         H, W = (logits.shape[2], logits.shape[3]) if logits.dim() == 4 else (1, logits.numel() // (B * K))
-        acc = _empty((2048,), logits)  # CENET_LOSS_ACC_FLOATS (include/cenet_hip.h): replicated partial sums
+        acc = _empty((16384,), logits)  # CENET_LOSS_ACC_FLOATS (include/cenet_hip.h): replicated partial sums, one value per line
         loss = _empty((1,), logits)
         kern.seg_loss_fwd(logits, labels, acc, loss, B, K, H, W, w_dice, w_ce, w_bd)
         ctx.save_for_backward(logits, labels, acc)

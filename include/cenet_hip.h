@@ -502,7 +502,7 @@ int cenet_diffattn_combine_bwd_acc_f32(const float* U, const float* lam3, const 
 /* ---- loss + optimiser (loss_optim.hip) ---------------------------------------------------------------------- */
 /* utils/core.py:44-80,161-188: loss = w_dice*Dice(softmax(logits), onehot(labels)) + w_ce*CE.
  * acc: CENET_LOSS_ACC_FLOATS floats of workspace (replicated partial sums); its first 3K+1 floats are what bwd reads. */
-#define CENET_LOSS_ACC_FLOATS 2048
+#define CENET_LOSS_ACC_FLOATS 16384
 int cenet_dice_ce_fwd_f32(const float* logits, const float* labels, float* acc, float* loss, int B, int K, int HW, float w_dice,
                           float w_ce, cenet_stream_t stream);
 int cenet_dice_ce_bwd_f32(const float* logits, const float* labels, const float* acc, const float* gout, float* dlogits, int B,
