@@ -915,6 +915,30 @@ struct DwActArgs {
   int B, C, H, W;
 };
 
+// GELU / GELU' of the bf16 (throughput) instances: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp) with the
+// hardware exponential and reciprocal, as the tiled depthwise kernels of dwconv.hip use; the fp32 (parity) instances keep libm's erff.
+template <typename T>
+__device__ __forceinline__ float dwact_f(int act, float u, float slope) {
+  if (sizeof(T) == 2 && act == ACT_GELU) {
+    const float ax = fabsf(u) * 0.70710678118654752f;
+    const float t = fast_rcp(1.f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    return 0.5f * u * (1.f + copysignf(1.f - poly * fast_exp(-0.5f * u * u), u));
+  }
+  return act_fwd(act, u, slope);
+}
+template <typename T>
+__device__ __forceinline__ float dwact_g(int act, float u, float slope) {
+  if (sizeof(T) == 2 && act == ACT_GELU) {  // Phi(u) + u phi(u): one exponential serves both terms
+    const float ax = fabsf(u) * 0.70710678118654752f;
+    const float t = fast_rcp(1.f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = fast_exp(-0.5f * u * u);
+    return 0.5f * (1.f + copysignf(1.f - poly * e, u)) + u * 0.3989422804014327f * e;
+  }
+  return act_bwd(act, u, slope);
+}
+
 // Planes in LDS carry a zero border of one pixel when the bordered batch fits (dilation 1: B (H + 2)(W + 2) <= DWBN_MAXE — 14x14
 // and 7x7 at B = 32): the nine taps are then unconditional reads at compile-time offsets from one base address, instead of nine
 // bounds tests, selects and address computations per element and pass.
@@ -960,7 +984,7 @@ _Pragma("unroll")
       for (int ky = 0; ky < 3; ++ky)
 _Pragma("unroll")
         for (int kx = 0; kx < 3; ++kx) u += w[ky * 3 + kx] * t0[ky * PW + kx];
-      if (ok) stf(y + b * sb + p, act_fwd(a.act, u, a.slope));
+      if (ok) stf(y + b * sb + p, dwact_f<T>(a.act, u, a.slope));
     })
     return;
   }
@@ -974,7 +998,7 @@ _Pragma("unroll")
     int pi, pj;
     pix_ij(ok ? p : 0, W, invW, pi, pj);
     const float u = dw_tap9(xs + (ok ? b : 0) * HW, H, W, pi, pj, a.dil, w, tap) + bias;
-    if (ok) stf(y + b * sb + p, act_fwd(a.act, u, a.slope));
+    if (ok) stf(y + b * sb + p, dwact_f<T>(a.act, u, a.slope));
   })
 }
 
@@ -1023,7 +1047,7 @@ _Pragma("unroll")
       for (int ky = 0; ky < 3; ++ky)
 _Pragma("unroll")
         for (int kx = 0; kx < 3; ++kx) u += w[ky * 3 + kx] * t0[ky * PW + kx];
-      const float d = ok ? G[k] * act_bwd(a.act, u, a.slope) : 0.f;
+      const float d = ok ? G[k] * dwact_g<T>(a.act, u, a.slope) : 0.f;
       if (ok) du[base[k] + PW + 1] = d;
       acc[9] += d;
     })
@@ -1050,7 +1074,7 @@ _Pragma("unroll")
       int pi, pj;
       pix_ij(ok ? p : 0, W, invW, pi, pj);
       const float u = dw_tap9(xs + (ok ? b : 0) * HW, H, W, pi, pj, a.dil, w, tap) + bias;
-      const float d = ok ? G[k] * act_bwd(a.act, u, a.slope) : 0.f;
+      const float d = ok ? G[k] * dwact_g<T>(a.act, u, a.slope) : 0.f;
       if (ok) du[b * HW + p] = d;
       acc[9] += d;
     })
