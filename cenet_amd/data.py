@@ -303,13 +303,18 @@ class DeviceTrainLoader:
     the reference's batches; every batch is {'image', 'label', 'case_name'} with the tensors already on the device."""
 
     def __init__(self, slices: DeviceSlices, output_size: Sequence[int], batch_size: int, shuffle: bool = True,
-                 drop_last: bool = False, generator: Optional[torch.Generator] = None):
+                 drop_last: bool = False, generator: Optional[torch.Generator] = None, sampler=None):
+        """sampler: an index sampler over range(len(slices)) instead of the shuffle — one process per GPU passes
+        `DistributedSampler(range(len(slices)), num_replicas=world, rank=rank)` (and calls its set_epoch), exactly as with a DataLoader;
+        every rank keeps the whole set resident (0.35 GB) and augments its own shard."""
         from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
         self.slices, self.aug = slices, DeviceAugmenter(slices, output_size)
         self.generator = generator
         src = range(len(slices))
-        self.batch_sampler = BatchSampler(RandomSampler(src, generator=generator) if shuffle else SequentialSampler(src),
-                                          batch_size, drop_last)
+        if sampler is None:
+            sampler = RandomSampler(src, generator=generator) if shuffle else SequentialSampler(src)
+        self.sampler = sampler
+        self.batch_sampler = BatchSampler(sampler, batch_size, drop_last)
 
     def __len__(self):
         return len(self.batch_sampler)

@@ -127,6 +127,25 @@ def test_loader_order_is_the_dataloaders(dev):
         np.testing.assert_allclose(g["image"].cpu().numpy(), r["image"].numpy(), rtol=0, atol=1e-6)
 
 
+def test_loader_with_a_distributed_sampler_shards_the_set(dev):
+    """one process per GPU: DistributedSampler over the resident set, as make_train_loader(sampler=...) does for the host pipeline —
+    two ranks see disjoint halves that cover the set, in the sampler's order"""
+    from torch.utils.data.distributed import DistributedSampler
+    samples = _slices([(32, 32)] * 10, 2)
+    sl = D.DeviceSlices(samples, dev, names=[f"s{i}" for i in range(10)])
+    seen = []
+    for rank in range(2):
+        smp = DistributedSampler(range(len(sl)), num_replicas=2, rank=rank, shuffle=True, seed=5)
+        smp.set_epoch(3)
+        loader = D.DeviceTrainLoader(sl, (32, 32), batch_size=2, sampler=smp)
+        random.seed(rank)
+        np.random.seed(rank)
+        names = [n for b in loader for n in b["case_name"]]
+        assert names == [f"s{i}" for i in smp] and len(names) == 5
+        seen += names
+    assert sorted(seen) == sorted(f"s{i}" for i in range(10))
+
+
 @pytest.mark.gpu
 def test_throughput_floor():
     """one host process feeds >= 2 000 augmented 224 x 224 samples/s (the reference's host pipeline: ~30/s)"""
