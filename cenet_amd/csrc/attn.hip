@@ -33,7 +33,14 @@ struct AttnArgs {
   int q_dfast, k_dfast, v_dfast, o_dfast;  // 1: d is the contiguous dim (token layout); 0: token index contiguous (NCHW)
   int dv_atomic;
   float scale;
+  int finite_scores;  // forward: q pre-scaled, scores through nan_to_num (multihead_diffattn.py:95,106)
 };
+
+// torch.nan_to_num on one fp32 score: NaN -> 0, +-inf -> +-FLT_MAX
+__device__ __forceinline__ float score_nan_to_num(float x) {
+  if (x != x) return 0.f;
+  return fminf(fmaxf(x, -3.402823466e+38f), 3.402823466e+38f);
+}
 
 // stage a [64 x cols] tile (zero padded to colsp columns) into LDS dst[r*pitch + c]
 __device__ __forceinline__ void stage_tile(float* dst, int pitch, const float* src, long s_row, long s_col, int row0,
@@ -141,6 +148,15 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
   const float* kb = a.k + (long)b * a.ksb + (long)h * a.ksh;
   const float* vb = a.v + (long)b * a.vsb + (long)hv * a.vsh;
   stage_tile(Qs, PQ, qb, a.qsi, a.qsd, i0, a.Nq, a.D, DQ, a.q_dfast);
+  // finite_scores: the reference scales q first (`q *= self.scaling`, multihead_diffattn.py:95), then multiplies — which products
+  // overflow depends on it; each thread rescales exactly the elements it staged (same index map as stage_tile)
+  const bool fin = a.finite_scores != 0;
+  const float lo = fin ? -3.402823466e+38f : NEG_BIG;  // below every nan_to_num'd score
+  if (fin)
+    for (int idx = threadIdx.x; idx < 64 * DQ; idx += 256) {
+      const int r = a.q_dfast ? idx / DQ : idx & 63, c = a.q_dfast ? idx - (idx / DQ) * DQ : idx >> 6;
+      Qs[r * PQ + c] *= a.scale;
+    }
 
   f32x4 o[NV];
 #pragma unroll
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
   float m[4], l[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    m[r] = NEG_BIG;
+    m[r] = lo;
     l[r] = 0.f;
   }
   const int fr = lane & 15, fq = lane >> 4;
@@ -174,10 +190,10 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(AttnArgs a) {
     float alpha[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float mx = NEG_BIG;
+      float mx = lo;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        float v = (j0 + 16 * t + fr < a.Nk) ? s[t][r] * a.scale : NEG_BIG;
+        float v = (j0 + 16 * t + fr < a.Nk) ? (fin ? score_nan_to_num(s[t][r]) : s[t][r] * a.scale) : lo;
         s[t][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -424,6 +440,7 @@ static void fill_args(AttnArgs& a, const cenet_attn_t* p) {
   a.q_dfast = (p->qsd == 1); a.k_dfast = (p->ksd == 1); a.v_dfast = (p->vsd == 1); a.o_dfast = (p->osd == 1);
   a.dv_atomic = (a.v_head_div > 1);
   a.scale = p->scale;
+  a.finite_scores = p->finite_scores;
 }
 
 static int pick_variant(int D, int Dv) {

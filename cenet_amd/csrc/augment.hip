@@ -158,6 +158,13 @@ __global__ __launch_bounds__(256) void aug_zoom_kernel(const long* __restrict__ 
       continue;
     }
     const double cy = (double)oy * zy, cx = (double)ox * zx;
+    // scipy map_coordinate(mode='constant'): a coordinate outside [0, len - 1] — by one ulp is enough, and (OH - 1)·((Ha - 1)/(OH - 1))
+    // does round above Ha - 1 for some sizes (Ha = 58, 63, 232, 248 ... at OH = 224) — gives cval = 0, image and label alike
+    if (cy > (double)(Ha - 1) || cx > (double)(Wa - 1)) {
+      oi[p] = 0.f;
+      ol[p] = 0.f;
+      continue;
+    }
     const int fy = (int)floor(cy), fx = (int)floor(cx);
     double wy[4], wx[4];
     aug_w3(cy - (double)fy, wy);

@@ -1022,7 +1022,12 @@ static int dw_tile_launch(DwTileArgs a, int B, hipStream_t stream) {
     else                                                                                                         \
       CENET_LAUNCH((dw3x3_tok_tile_kernel<TH_, TW_, MODE, -1>), grid, dim3(256), stream, a);                     \
   }
-  if (a.W % 14 == 0) DW_TILE_GO(8, 14)
+  static const char* t14 = getenv("CENET_DW_T14");
+  const int v14 = t14 ? atoi(t14) : 0;
+  if (a.W == 14 && a.H == 14 && v14 == 1) DW_TILE_GO(7, 14)
+  else if (a.W == 14 && a.H == 14 && v14 == 2) DW_TILE_GO(14, 14)
+  else if (a.W == 7 && a.H == 7 && v14 >= 1) DW_TILE_GO(7, 7)
+  else if (a.W % 14 == 0) DW_TILE_GO(8, 14)
   else if (a.W <= 8 && a.H <= 8) DW_TILE_GO(8, 8)
   else DW_TILE_GO(8, 16)
 #undef DW_TILE_GO

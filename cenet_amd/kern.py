@@ -239,7 +239,7 @@ class AttnT(C.Structure):
                [(n, C.c_long) for n in ("qsb", "qsh", "qsi", "qsd", "ksb", "ksh", "ksi", "ksd", "vsb", "vsh", "vsi", "vsd",
                                         "osb", "osh", "osi", "osd")] + \
                [(n, C.c_int) for n in ("B", "H", "Nq", "Nk", "D", "Dv", "v_head_div")] + [("scale", C.c_float)] + \
-               [("dkv_zeroed", C.c_int), ("dkv_f32", C.c_int)]
+               [("dkv_zeroed", C.c_int), ("dkv_f32", C.c_int), ("finite_scores", C.c_int)]
 
 
 def flash_supported(D: int, Dv: int) -> bool:

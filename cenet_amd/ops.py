@@ -1455,6 +1455,7 @@ class _AttnDesc:
         self.B, self.H, self.Nq, self.Nk, self.D, self.Dv, self.scale, self.vdiv = B, H, Nq, Nk, D, Dv, scale, vdiv
         self.qs, self.ks, self.vs, self.os = qs, ks, vs, os_  # each (sb, sh, si, sd)
         self.qoff, self.koff, self.voff = qoff, koff, voff   # element offsets into q/k/v storage
+        self.finite = False  # fp32 flash forward: q scaled first + torch.nan_to_num of the scores (multihead_diffattn.py:95,106)
 
     def fill(self, a: "kern.AttnT", q, k, v, o, lse):
         e = kern.esz(q)
@@ -1466,6 +1467,7 @@ class _AttnDesc:
         a.osb, a.osh, a.osi, a.osd = self.os
         a.B, a.H, a.Nq, a.Nk, a.D, a.Dv, a.v_head_div = self.B, self.H, self.Nq, self.Nk, self.D, self.Dv, self.vdiv
         a.scale = self.scale
+        a.finite_scores = int(self.finite)
 
 
 def _attn_forward(d: _AttnDesc, q, k, v, o):
@@ -1683,6 +1685,7 @@ class DiffAttnHeadsFn(Function):
         if kern.flashb_supported(hd, dv) if _bf(q) else kern.flash_supported(hd, dv):
             d = _AttnDesc(B, 2 * H, N, N, hd, dv, hd ** -0.5, 2, (N * E, hd, E, 1), (N * E, hd, E, 1), (N * E, dv, E, 1),
                           (2 * H * N * dv, N * dv, dv, 1))
+            d.finite = not _bf(q)  # parity mode reproduces multihead_diffattn.py:106; the bf16 kernels propagate non-finite scores
             kind, saved = _attn_forward(d, q, k, v, U)
             ctx.descs = [d]
             saved_list = [saved]

@@ -173,6 +173,10 @@ typedef struct {
   int dkv_zeroed; /* backward only: caller guarantees dk / dv are zero-filled, so the library may slice the query range
                      over workgroups and accumulate dK / dV atomically (few keys under many queries) */
   int dkv_f32;    /* bf16 entry points only: dk / dv are fp32 accumulators */
+  int finite_scores; /* cenet_flash_attn_fwd_f32 only (multihead_diffattn.py:95-106): q is scaled BEFORE the product (`q *= self.scaling`)
+                        and the scores pass through torch.nan_to_num (NaN -> 0, +-inf -> +-FLT_MAX) before the softmax, so a q.k
+                        product that overflows fp32 gives the reference's finite output.  The bf16 entry points and the backward
+                        ignore it (overflowing scores are outside the supported domain there: INTEGRATION.md) */
 } cenet_attn_t;
 /* Replaces q@k^T -> softmax -> @v (pvtv2.py:101-105; nlb.py:117-138; multihead_diffattn.py:96-116) and backward.
  * Supported head dims: D<=64 with Dv<=128 (cenet_flash_attn_supported). */

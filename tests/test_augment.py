@@ -92,6 +92,24 @@ def test_preset_size_224(dev):
         np.testing.assert_allclose(di.numpy(), hi.numpy(), rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(58, 63), (232, 256), (248, 256)])
+def test_sizes_whose_last_zoom_coordinate_rounds_outside(dev, shape):
+    """scipy's zoom (mode='constant') maps a coordinate above len - 1 to cval: (OH - 1) * ((Ha - 1) / (OH - 1)) rounds above Ha - 1 for
+    Ha in {58, 63, 232, 248, ...} at OH = 224, so the reference's LAST output row / column is zero there, image and label alike
+    (dataset_acdc.py:42-45).  The device path must do the same — not mirror the taps."""
+    if dev.type == "cpu" and shape[0] > 100:
+        pytest.skip("the host checker runs the fp64 prefilter lane by lane: the small case covers the rule")
+    samples = _slices([shape], 9)
+    zeroed = 0
+    for seed in (2, 5, 11):
+        hi, hl = _host(samples, [0], (224, 224), seed)
+        di, dl, _ = _device(samples, [0], (224, 224), seed, dev)
+        assert torch.equal(dl.long(), hl)
+        np.testing.assert_allclose(di.numpy(), hi.numpy(), rtol=0, atol=1e-6)
+        zeroed += int((hi[0, 0, -1] == 0).all()) + int((hi[0, 0, :, -1] == 0).all())
+    assert zeroed > 0  # the case really is exercised: a whole last row or column of the reference's output is cval
+
+
 def test_loader_order_is_the_dataloaders(dev):
     """same torch seed -> the index batches of DataLoader(shuffle=True) (main_acdc.py:140), epoch after epoch; and the same
     `random` / `np.random` seeds -> the host pipeline's samples"""

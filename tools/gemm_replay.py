@@ -83,17 +83,45 @@ def timeit(rec, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3  # us
 
 
+def yardstick(key, reps=20):
+    """the same logical product through torch.matmul (hipBLASLt / rocBLAS) on fresh operands of the same orientation: a YARDSTICK
+    for how far the hand-written kernels are from a tuned library on this shape — never a product path"""
+    M, N, K, nb, nkb = key[:5]
+    if nkb != 1 or key[5] != "pl" or key[7] in ("at", "c2i"):
+        return float("nan")
+    akf, bkf = key[6][1] == "1", key[6][3] == "1"
+    bs = (nb,) if nb > 1 else ()
+    a = torch.randn(*bs, M, K, device=dev, dtype=torch.bfloat16) if akf else torch.randn(*bs, K, M, device=dev, dtype=torch.bfloat16).transpose(-1, -2)
+    b = torch.randn(*bs, N, K, device=dev, dtype=torch.bfloat16).transpose(-1, -2) if bkf else torch.randn(*bs, K, N, device=dev, dtype=torch.bfloat16)
+    out = torch.empty(*bs, M, N, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        torch.matmul(a, b, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        torch.matmul(a, b, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+YARD = os.environ.get("GEMM_YARDSTICK") == "1"
 rows = []
 for key, rec in first.items():
     us = timeit(rec)
+    rec[-1]["_yard"] = yardstick(key) if YARD else float("nan")
     M, N, K, nb, nkb = key[:5]
     flops = 2.0 * M * N * K * nb * nkb
     byt = nb * (2.0 * (M * K * nkb + K * N * nkb) + M * N * (8 if key[7] == "at" else 2))
     ideal = max(byt / 6e12, flops / 2.5e15) * 1e6
-    rows.append((us * count[key], us, count[key], ideal, flops, byt, key))
+    rows.append((us * count[key], us, count[key], ideal, flops, byt, key, rec[-1]["_yard"]))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"{len(log)} gemm launches, {len(rows)} distinct; isolated total {tot / 1e3:.2f} ms per step; ideal {sum(r[2] * r[3] for r in rows) / 1e3:.2f} ms")
-print(f"{'tot us':>8s} {'n':>3s} {'us':>7s} {'ideal':>6s} {'TF':>6s} {'GB/s':>6s}  key")
-for t, us, n, ideal, fl, byt, key in rows[:top_n]:
-    print(f"{t:8.0f} {n:3d} {us:7.1f} {ideal:6.1f} {fl / us / 1e6:6.1f} {byt / us / 1e3:6.0f}  {key}")
+if YARD:
+    both = [r for r in rows if r[7] == r[7]]
+    print(f"yardstick (torch.matmul) over the {len(both)} comparable shapes: ours {sum(r[1] * r[2] for r in both) / 1e3:.2f} ms, library {sum(r[7] * r[2] for r in both) / 1e3:.2f} ms")
+print(f"{'tot us':>8s} {'n':>3s} {'us':>7s} {'lib us':>7s} {'ideal':>6s} {'TF':>6s} {'GB/s':>6s}  key")
+for t, us, n, ideal, fl, byt, key, yd in rows[:top_n]:
+    print(f"{t:8.0f} {n:3d} {us:7.1f} {yd:7.1f} {ideal:6.1f} {fl / us / 1e6:6.1f} {byt / us / 1e3:6.0f}  {key}")
