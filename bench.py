@@ -284,10 +284,12 @@ def roofline_block(body, steps=2):
         return kv[1][0] * (0.5 if "+" in kv[0] else 1.0)
     peak = peak_tflops()
     traffic_rec = {}
+    traffic_tag = None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):  # the latest round's PMC passes
         try:
             traffic_rec = json.load(open(f))
+            traffic_tag = os.path.basename(f).split("_")[0]
             break
         except (OSError, ValueError):
             continue
@@ -306,6 +308,11 @@ def roofline_block(body, steps=2):
             break
         except (OSError, ValueError, KeyError):
             continue
+    # the committed summary describes THIS build only if it was taken on the same kernel sources: tools/refresh_profiles.sh writes
+    # the PMC record (with the source hash in its _meta) and the kernel statistics in one run under one round tag.  A summary of
+    # another build is reported beside the live numbers but never replaces them (`frac` must not go stale).
+    prof_tag = next(iter(prof_avg.values()))[1].split("_")[0] if prof_avg else None
+    prof_current = bool(prof_avg) and prof_tag == traffic_tag and meta.get("kernel_src_sha16") == source_sha16()
 
     def entry(name, ms, n, fl, by):
         n //= steps
@@ -332,8 +339,14 @@ def roofline_block(body, steps=2):
                 pa = (fl if out["bound"] == "mfma" else by) / max(n, 1) / (pms * 1e-3) / (1e12 if out["bound"] == "mfma" else 1e9)
                 out["frac_live"] = out["frac"]
                 out["achieved_live"] = out["achieved"]
-                out["achieved"] = round(pa, 2 if out["bound"] == "mfma" else 1)
-                out["frac"] = round(pa / out["peak"], 4)
+                out["frac_rocprof"] = round(pa / out["peak"], 4)
+                out["achieved_rocprof"] = round(pa, 2 if out["bound"] == "mfma" else 1)
+                out["rocprof_is_this_build"] = prof_current
+                if prof_current:  # `frac` follows from profiles/ only when profiles/ describes the kernels that just ran
+                    out["achieved"], out["frac"] = out["achieved_rocprof"], out["frac_rocprof"]
+                    out["frac_source"] = "rocprofv3 average duration (profiles/, same kernel sources)"
+                else:
+                    out["frac_source"] = "live HIP events (the committed profile is of other kernel sources)"
         if name in tr.valu:
             # the pair / flash attention kernels are bound by vector-instruction ISSUE, not by the matrix pipe (DESIGN.md section 8,
             # profiles/r04_attn_sq_counters.txt): graded against that roof too — issue cycles of the softmax algebra alone over
@@ -500,6 +513,48 @@ def cpu_baseline(steps):
             "sample": f"{steps} train steps of ACDC 224x224 4-class batch=4 fp32 (oracle/cenet_oracle.py), {dt:.2f} s/step"}
 
 
+class _Watchdog:
+    """N > 1: a collective that never completes (a rank died, a link hung) blocks every other rank inside the GPU queue, and the
+    driver would wait for its own time limit.  A daemon thread watches a heartbeat the main thread touches at every phase of the run
+    (set-up, each candidate launch form, warm-up, the timed loop's final synchronise, the instrumented passes); when the heartbeat
+    is older than the limit (CENET_WATCHDOG_S, default 600 s; 0 disables) the process prints what it was doing and EXITS NON-ZERO
+    with os._exit — never by re-executing itself (a process that has touched the GPU must not exec)."""
+
+    def __init__(self):
+        self.t = time.monotonic()
+        self.what = "start"
+        self.limit = 0.0
+        self.thread = None
+        self.done = False
+
+    def beat(self, what):
+        self.t = time.monotonic()
+        self.what = what
+
+    def start(self, limit_s, rank):
+        import threading
+        if limit_s <= 0 or self.thread is not None:
+            return
+        self.limit = limit_s
+        self.beat("process group up")
+
+        def run():
+            while not self.done:
+                time.sleep(min(5.0, self.limit / 4))
+                if not self.done and time.monotonic() - self.t > self.limit:
+                    print(f"[bench] watchdog: rank {rank} made no progress for {self.limit:.0f} s in phase '{self.what}' "
+                          "(hung collective?) - exiting with status 3", file=sys.stderr, flush=True)
+                    os._exit(3)
+        self.thread = threading.Thread(target=run, name="bench-watchdog", daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        self.done = True
+
+
+WATCHDOG = _Watchdog()
+
+
 def _time_steps(fn, n):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -550,7 +605,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group(os.environ.get("CENET_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        import datetime
+        wd_s = float(os.environ.get("CENET_WATCHDOG_S", "600"))
+        dist.init_process_group(os.environ.get("CENET_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=max(60.0, 2.0 * wd_s)))
+        WATCHDOG.start(wd_s, rank)
     dist_record = dist_identity(dev, world) if use_dist else None
 
     from cenet_amd import kern, losses, optim, parallel
@@ -568,13 +627,15 @@ def main():
     crit = losses.Criterion(cfg["classes"], argparse.Namespace(loss_type="dice,ce", loss_weights="0.5,0.5"))
     x, lab = synthetic(B, dev, seed=1234 + rank, cfg=cfg)
 
+    comm = [True]  # (False: rank 0's instrumented passes at N > 1 — the other ranks are not in the step, so no collective)
+
     def body(sync_hyper=True, after_backward=None):
         opt.zero_grad()
         loss = crit(net(x), lab)
         loss.backward()
         if after_backward is not None:  # (instrumented passes only)
             after_backward()
-        if reducer is not None:
+        if reducer is not None and comm[0]:
             reducer.finish()
         opt.step(sync_hyper=sync_hyper)
         return loss
@@ -654,12 +715,14 @@ def main():
         times = {}
         parallel.attach(net, reducer)
         if a.graph != "on":
+            WATCHDOG.beat("timing the eager launch form")
             for _ in range(2):
                 body()
             dist.barrier()
             times["eager"] = _time_steps(body, 4)
         parallel.attach(net, None)
         for name, cand in cands.items():
+            WATCHDOG.beat(f"timing the {name} launch form")
             for _ in range(2):
                 cand()
             dist.barrier()
@@ -688,11 +751,13 @@ def main():
         sched.step()
         return loss
 
+    WATCHDOG.beat("warm-up")
     for _ in range(a.warmup):
         step()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    WATCHDOG.beat("timed loop")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
@@ -700,6 +765,7 @@ def main():
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    WATCHDOG.beat("timed loop done")
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -723,9 +789,19 @@ def main():
             out["config"]["launch_choice"] = launch_note
         if dist_record is not None:
             out["config"]["rccl"] = dict(dist_record, launch_forms_ms={k: round(v * 1e3, 3) for k, v in dist_times.items()})
-        if world == 1 and not a.no_roofline:
+        if not a.no_roofline:
+            # N > 1: rank 0's instrumented passes run AFTER the timed loop with the collectives switched off (the other ranks wait at
+            # the final barrier; the dominant kernel and the stage times do not depend on the all-reduce), so that every line of a
+            # scaling record carries its roofline
+            WATCHDOG.beat("instrumented passes (roofline)")
+            if use_dist:
+                parallel.attach(net, None)
+                comm[0] = False
             out["roofline"] = roofline_block(body)
+            if use_dist:
+                out["roofline"]["note"] = "rank 0, after the timed loop, collectives off (per-GPU kernel times do not depend on N)"
             out["roofline_stages"] = stage_block(net, body, B, cfg["size"])
+            WATCHDOG.beat("instrumented passes done")
             # the whole step against both roofs (fwd + bwd = 3 x the forward contractions; stage-boundary tensors
             # three times, parameters read twice and their gradient written once, the optimizer's three streams)
             sf = (cfg["size"] / 224.0) ** 2
@@ -751,8 +827,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.cpu_steps)
         line = json.dumps(out)
     if use_dist:
+        WATCHDOG.beat("final barrier")
         dist.barrier()
         dist.destroy_process_group()
+    WATCHDOG.stop()
     if rank == 0:
         # the JSON line is the LAST thing on stdout: flush what native libraries (the RCCL version banner) still hold in C stdio
         try:

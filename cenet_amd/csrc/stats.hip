@@ -1052,7 +1052,11 @@ __global__ __launch_bounds__(256) void srm_conv_bn_bwd_kernel(const float* __res
   }
 }
 
-extern "C" int cenet_srm_fused_supported(int B, int H, int W) { return B > 0 && H > 0 && W > 0 && (long)H * W <= SRM_MAXHW; }
+// (B H W > 1: the running variance is updated with the unbiased factor n / (n - 1); a single value has no variance estimate and
+// PyTorch itself refuses to train a BatchNorm on one value per channel)
+extern "C" int cenet_srm_fused_supported(int B, int H, int W) {
+  return B > 0 && H > 0 && W > 0 && (long)H * W <= SRM_MAXHW && (long)B * H * W > 1;
+}
 /* partial triples written by cenet_srm_conv_gelu_fwd_f32: B * ceil(H*W / 256) */
 extern "C" int cenet_srm_parts(int B, int H, int W) { return B * cdiv(H * W, 256); }
 extern "C" int cenet_srm_conv_gelu_fwd_f32(const float* u, const float* pwc, const float* dwc, float* f, float* fa, float* part,

@@ -12,7 +12,7 @@ def bn_call(bn: nn.BatchNorm2d, x, act="none", slope=0.0, tap=False):
     """Train/eval BatchNorm (+fused activation) through the HIP kernels using the container's tensors.
     tap=True: returns (y, x_tap) — x itself routed through the BatchNorm's autograd node, for the residual connection around it"""
     return ops.batchnorm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training,
-                         bn.eps, act, slope, bn.momentum if bn.momentum is not None else 0.1, tap)
+                         bn.eps, act, slope, ops.bn_momentum(bn), tap)
 
 
 def _init_conv(m, scheme="normal"):
@@ -77,7 +77,7 @@ class EUCB(nn.Module):
         if ops.eucb_front_supported(x, bn.training):
             # one launch per pass for everything in front of the 1x1 conv (csrc/chanloc.hip: workgroup = channel over the batch)
             x = ops.eucb_front(x, self.up_dwc[1].weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                               bn.num_batches_tracked, bn.eps, 0.2, bn.momentum if bn.momentum is not None else 0.1)
+                               bn.num_batches_tracked, bn.eps, 0.2, ops.bn_momentum(bn))
         else:
             x = ops.nearest2x(x)
             x = ops.dwconv_nchw(x, self.up_dwc[1].weight, None, dil=1)

@@ -100,7 +100,7 @@ class MultiOrderDWConv(nn.Module):
             # small maps: the three depthwise convs, their BatchNorm + ReLU and the pooled slice's copy in one launch per pass
             u, rest = ops.split_dwconv_bn(x, sizes[:3], [m.rate for m in b], [m.depthwise.weight for m in b], mg["dbn_w"],
                                           mg["dbn_b"], mg["dbn_running_mean"], mg["dbn_running_var"],
-                                          mg["dbn_num_batches_tracked"], dbn.eps, dbn.momentum if dbn.momentum is not None else 0.1)
+                                          mg["dbn_num_batches_tracked"], dbn.eps, ops.bn_momentum(dbn))
         else:
             u, rest = ops.split_dwconv(x, sizes[:3], [m.rate for m in b], [m.depthwise.weight for m in b], joined=True)
         for key, bn in ((("pbn", b[0].pointwise_bn),) if fused else (("dbn", b[0].depthwise_bn), ("pbn", b[0].pointwise_bn))):
@@ -110,11 +110,11 @@ class MultiOrderDWConv(nn.Module):
                 if bn.training and rest is not None and ops.pool_branch_supported(rest, pool[2]):
                     # the pointwise BatchNorm + ReLU and the pooled branch write their channel slices of ONE tensor: no concat
                     return ops.join_bn_pool(u, rest, mg["pbn_w"], mg["pbn_b"], mg["pbn_running_mean"], mg["pbn_running_var"],
-                                            mg["pbn_num_batches_tracked"], bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                            mg["pbn_num_batches_tracked"], bn.eps, ops.bn_momentum(bn),
                                             pool[1].weight, pool[2]), None
             u = ops.batchnorm(u, mg[key + "_w"], mg[key + "_b"], mg[key + "_running_mean"], mg[key + "_running_var"],
                               mg[key + "_num_batches_tracked"], bn.training, bn.eps, "relu", 0.0,
-                              bn.momentum if bn.momentum is not None else 0.1)
+                              ops.bn_momentum(bn))
         return u, rest
 
     def forward(self, x):

@@ -56,14 +56,18 @@ class _ZeroWs:
     front of every use (the dK / dV accumulator of the spatial-reduction attention backward: 7 fills per step).
     A buffer that is taken stays IN USE until give_back_as: a second taker of the same size gets a buffer of its own (up to
     `MAX_LIVE` per size; beyond that the oldest is taken to be the leftover of a pass that raised between the two launches and is
-    filled again).  Single-stream contract: take -> kernel -> give_back_as run on ONE stream (the buffers carry no events) — the
-    key holds the stream, so the branch streams of branch_stream() each own their buffers."""
+    filled again).  Single-stream contract: take -> kernel -> give_back_as run on ONE stream (the buffers carry no events); with
+    branch streams enabled the key holds the stream, so the branch streams of branch_stream() each own their buffers."""
     bufs: dict = {}  # key -> [[tensor, in_use], ...]
     MAX_LIVE = 4
 
     @staticmethod
     def _key(dev, n):
-        sid = torch.cuda.current_stream(dev).stream_id if dev.type == "cuda" else 0
+        # the stream is part of the key only while branch streams are on (two streams really do run take -> kernel -> give_back
+        # concurrently then).  Otherwise ONE set per device: GraphedStep warms up on a side stream and torch.cuda.graph captures on
+        # another, and a per-stream key made the capture allocate fresh buffers inside the graph's pool with their zero-fill
+        # captured as a node that re-ran on every replay — the launches this class exists to avoid (ADVICE r5)
+        sid = torch.cuda.current_stream(dev).stream_id if (dev.type == "cuda" and _BRANCH_ON[0]) else 0
         return (dev.type, dev.index, n, sid)
 
     @staticmethod
@@ -207,6 +211,10 @@ class _WgradState:
         self.next_event = 0
         self.pending = False
         self.side_keep = []  # tensors the side stream still reads (see _wgrad_side): released in wgrad_join()
+        # --- gradients that their producer already scaled (_prescaled_put / _prescaled_take): {data_ptr: (g, bscale, bscale * g)}.
+        # Per device like everything else here: two devices' autograd threads (nn.DataParallel replicas, two models) never touch
+        # the same dictionary
+        self.prescaled = {}
 
     def flush(self):
         if not self.items and not self.ln_items:
@@ -503,8 +511,7 @@ def _wgrad_flush_cb(st, tid):
     if st.task == tid:
         st.task = None
     st.flush()
-    for k in [k for k in _PRESCALED if k[0] == st.device.index]:  # (records nobody asked for)
-        del _PRESCALED[k]
+    st.prescaled.clear()  # (records nobody asked for)
 
 
 # ---- gradients that their producer already scaled ---------------------------------------------------------------------------
@@ -514,17 +521,17 @@ def _wgrad_flush_cb(st, tid):
 # leaves it here; LinearFn.backward picks it up instead of launching scale_batch.  Keyed by the storage of g; the entry holds g
 # itself, so its memory cannot be handed to another tensor while the entry exists, and a pointer match means the same tensor.
 # Nothing found (fp32 mode, autograd summed two gradients into a new tensor, a hook replaced it): the scale pass runs as before.
-_PRESCALED: dict = {}
-
-
+# The records live in the per-device state (_WgradState.prescaled): one dictionary per device, touched only by that device's
+# autograd thread, emptied by the end-of-backward callback of the pass that filled it.
 def _prescaled_put(g: Tensor, bscale: Tensor, gs: Tensor):
-    if len(_PRESCALED) > 64:  # (records nobody asked for: a backward pass that raised)
-        _PRESCALED.clear()
-    _PRESCALED[(g.device.index, g.data_ptr())] = (g, bscale, gs)
+    d = _wg(g.device).prescaled
+    if len(d) > 64:  # (records nobody asked for: a backward pass that raised before its end-of-backward callback)
+        d.clear()
+    d[g.data_ptr()] = (g, bscale, gs)
 
 
 def _prescaled_take(g: Tensor, bscale: Tensor) -> Optional[Tensor]:
-    e = _PRESCALED.pop((g.device.index, g.data_ptr()), None)
+    e = _wg(g.device).prescaled.pop(g.data_ptr(), None)
     if e is None or e[0].shape != g.shape or e[0].dtype != g.dtype or e[0].stride() != g.stride():
         return None
     if e[1].data_ptr() != bscale.data_ptr() or e[1].numel() != bscale.numel():
@@ -2445,8 +2452,17 @@ def _gb(p, ref):
     return g if g is not None else _zeros(p.shape, ref)
 
 
-def _mom(bn) -> float:
-    return bn.momentum if bn.momentum is not None else 0.1
+def bn_momentum(bn) -> float:
+    """the running-statistics factor of a BatchNorm container.  momentum=None means a CUMULATIVE moving average in PyTorch (factor
+    1 / num_batches_tracked); no kernel here implements that and the reference never builds such a layer (every BatchNorm of
+    src/networks/cenet keeps the default 0.1) — refuse loudly rather than train with a silently different factor"""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm(momentum=None) (cumulative moving average) is not supported by the HIP kernels; "
+                                  "the reference network uses momentum=0.1 everywhere")
+    return float(bn.momentum)
+
+
+_mom = bn_momentum
 
 
 class CfamMidFn(Function):
@@ -2515,19 +2531,19 @@ class CfamFrontFn(Function):
         meand, vard = (_empty((Cn,), x0), _empty((Cn,), x0)) if use_bn else (None, None)
         kern.cfam_front_fwd(x0, y1, xs, bn1.weight, bn1.bias, bn1.eps, mean1, var1, bn1.running_mean, bn1.running_var, _mom(bn1),
                             bn1.num_batches_tracked, ccu.fc1.weight, ccu.fc2.weight, bd.weight if use_bn else None,
-                            bd.bias if use_bn else None, 1e-5, meand, vard, bd.running_mean if use_bn else None,
-                            bd.running_var if use_bn else None, 0.1, bd.num_batches_tracked if use_bn else None, u, amax, z, zn,
+                            bd.bias if use_bn else None, bd.eps, meand, vard, bd.running_mean if use_bn else None,
+                            bd.running_var if use_bn else None, _mom(bd), bd.num_batches_tracked if use_bn else None, u, amax, z, zn,
                             B, Cn, HW)
         ctx.save_for_backward(x0, bn1.weight, bn1.bias, mean1, var1, ccu.fc1.weight, ccu.fc2.weight, bd.weight, meand, vard, u,
                               amax, z, zn)
         ctx.refs = (bn1.weight, bn1.bias, ccu.fc1.weight, ccu.fc2.weight, bd.weight, bd.bias)
-        ctx.cfg = (bn1.eps, use_bn)
+        ctx.cfg = (bn1.eps, use_bn, bd.eps)
         return y1, xs, x0.view_as(x0)
 
     @staticmethod
     def backward(ctx, g_y1, g_xs, g_tap):
         x0, g1, b1, mean1, var1, fc1, fc2, gd, meand, vard, u, amax, z, zn = ctx.saved_tensors
-        eps1, use_bn = ctx.cfg
+        eps1, use_bn, epsd = ctx.cfg
         if g_xs is None:
             raise RuntimeError("cfam_front: the gated output carried no gradient")
         g_xs = _c(g_xs)
@@ -2537,7 +2553,7 @@ class CfamFrontFn(Function):
         HW = x0.numel() // (B * Cn)
         dx0 = torch.empty_like(x0)
         r = ctx.refs
-        kern.cfam_front_bwd(g_xs, g_y1, g_tap, x0, dx0, g1, b1, eps1, mean1, var1, fc1, fc2, gd if use_bn else None, 1e-5, meand,
+        kern.cfam_front_bwd(g_xs, g_y1, g_tap, x0, dx0, g1, b1, eps1, mean1, var1, fc1, fc2, gd if use_bn else None, epsd, meand,
                             vard, u, amax, z, zn, _gb(r[0], x0), _gb(r[1], x0), _gb(r[2], x0), _gb(r[3], x0),
                             _gb(r[4], x0) if use_bn else None, _gb(r[5], x0) if use_bn else None, B, Cn, HW)
         return dx0, None, None
@@ -2769,8 +2785,8 @@ class ResTailPoolFn(Function):
 def res_tail_pool(x2, bn2, x3, bn3, w, slope):
     """bn2 / bn3: nn.BatchNorm2d modules in training mode (their running statistics are updated)"""
     return ResTailPoolFn.apply(x2, x3, w, slope, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked,
-                               bn2.eps, bn2.momentum if bn2.momentum is not None else 0.1, bn3.weight, bn3.bias, bn3.running_mean,
-                               bn3.running_var, bn3.num_batches_tracked, bn3.eps, bn3.momentum if bn3.momentum is not None else 0.1)
+                               bn2.eps, bn_momentum(bn2), bn3.weight, bn3.bias, bn3.running_mean,
+                               bn3.running_var, bn3.num_batches_tracked, bn3.eps, bn_momentum(bn3))
 
 
 class ResTailImgPoolFn(Function):
@@ -2820,9 +2836,9 @@ class ResTailImgPoolFn(Function):
 
 def res_tail_img_pool(x2, bn2, img, w3, bn3, w, slope):
     return ResTailImgPoolFn.apply(x2, img, w3, w, slope, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
-                                  bn2.num_batches_tracked, bn2.eps, bn2.momentum if bn2.momentum is not None else 0.1, bn3.weight,
+                                  bn2.num_batches_tracked, bn2.eps, bn_momentum(bn2), bn3.weight,
                                   bn3.bias, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked, bn3.eps,
-                                  bn3.momentum if bn3.momentum is not None else 0.1)
+                                  bn_momentum(bn3))
 
 
 def res_tail_img_pool_supported(x2, img, w3, bn2, bn3, w) -> bool:

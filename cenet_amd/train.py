@@ -11,7 +11,12 @@ What differs from the reference loop and why:
   * the loss is read back once per `log_every` iterations instead of every iteration (main_acdc.py:264-265: a device sync per
     step); the running epoch loss is accumulated on the device;
   * the learning rate for the NEXT step is uploaded by FusedSGD.prepare() before each replay (no host value is baked into the
-    capture).
+    capture);
+  * the epoch log line prints the reference's quantity — the sum of the batch losses over the number of training images
+    (main_acdc.py:264-267) — but accumulated on the device and read back once per epoch;
+  * NOT here: the reference's `best.pth` / last-epoch checkpoint saves and its test inference after training
+    (main_acdc.py:272-289) — cenet_amd.checkpoint.save_weights / save_training_state and cenet_amd.evaluate are the pieces a caller
+    combines for that (tests/test_checkpoint.py, tests/test_evaluate.py); the loop returns the arena and the optimizer for it.
 `train_acdc(..., graph=False)` is the same loop with eager launches: tests/test_train_loop.py holds the two against each other
 on changing batches."""
 from __future__ import annotations
@@ -86,16 +91,17 @@ def train_acdc(net, tr_loader, *, num_classes: int = 4, max_epochs: int = 1, bas
             hist["lr"].append(sched.get_last_lr()[0])
             sched.step()
             it += 1
-            run += loss.detach().float() * x.shape[0]
+            run += loss.detach().float()  # main_acdc.py:264: the plain batch loss ...
             n_img += x.shape[0]
             if it % log_every == 0:
                 hist["loss"].append((it, loss.item()))
                 log(f"iteration {it} : loss : {hist['loss'][-1][1]:f} lr_: {hist['lr'][-1]:f}")
-        hist["epoch_loss"].append(run.item() / max(n_img, 1))
+        hist["epoch_loss"].append(run.item() / max(n_img, 1))  # ... over len(db_train) (main_acdc.py:266), as the reference logs it
         if val_batches is not None:
             hist["val_dice"].append(evaluate.validate(net, val_batches()))
             net.train()
-        log(f"epoch:{epoch:03d}/{max_epochs}, loss:{hist['epoch_loss'][-1]:0.5f}, lr:{hist['lr'][-1]:0.6f}"
+        lr_last = hist["lr"][-1] if hist["lr"] else base_lr  # (an empty loader takes no step)
+        log(f"epoch:{epoch:03d}/{max_epochs}, loss:{hist['epoch_loss'][-1]:0.5f}, lr:{lr_last:0.6f}"
             + (f", vl_DCS:{hist['val_dice'][-1] * 100:0.3f}" if hist["val_dice"] else ""))
     hist["arena"], hist["optimizer"] = arena, opt
     return hist

@@ -94,7 +94,9 @@ def test_bench_with_two_ranks_on_one_gpu(extra):
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 16
     assert d["value"] > 0 and abs(d["value"] - 16 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
     assert d["config"]["final_loss"] == d["config"]["final_loss"]
-    assert "roofline" not in d  # the instrumented passes are a single-GPU extra
+    # every line of a scaling record carries its roofline: rank 0's instrumented passes run after the timed loop, collectives off
+    assert d["roofline"]["bound"] in ("mfma", "hbm") and d["roofline"]["frac"] > 0 and "rank 0" in d["roofline"]["note"]
+    assert len(d["roofline_stages"]) == 22
     r = d["config"]["rccl"]
     # both ranks were pinned to cuda:0 on purpose: the record must SAY that the two ranks share one device, over gloo
     assert r["backend"] == "gloo" and r["world_size"] == 2 and r["distinct_devices"] == 1 and r["hosts"] == 1

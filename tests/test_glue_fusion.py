@@ -92,7 +92,7 @@ def test_block_chain_gradients_do_not_depend_on_where_the_scale_is_applied(dev, 
     assert n_off == 2 and n_on == (0 if ops._WgradCfg.grouping else 2)
     for a, b in zip(on, off):
         assert torch.equal(a, b)
-    assert not ops._PRESCALED
+    assert not any(st.prescaled for st in ops._WG.values())
 
 
 def _attn_then_fused_mlp(dev_, s1, s2, seed=3):
@@ -137,7 +137,7 @@ def test_fused_mlp_backward_hands_the_attention_half_its_scaled_gradient(dev, mo
             assert torch.equal(a, b), i
         else:
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * max(b.abs().max().item(), 1.0)), i
-    assert not ops._PRESCALED
+    assert not any(st.prescaled for st in ops._WG.values())
 
 
 def test_sra_backward_accumulator_is_zero_at_rest(dev, monkeypatch):
