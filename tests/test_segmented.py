@@ -4,7 +4,7 @@ all-reduce can start between two graphs and overlap the rest of the backward pas
 
 * GPU, single process: the five pieces leave the gradient of one whole backward pass, and after piece k the arena slice of
   segment k is FINAL (fp32 and bf16 storage);
-* two gloo ranks on CPU (host SIMT checker): a SegmentedStep as eager pieces — callback order, finality of every segment after
+* two and four gloo ranks on CPU (host SIMT checker): a SegmentedStep as eager pieces — callback order, finality of every segment after
   its piece, identical parameters on both ranks, update == SGD step on the mean of the per-shard ORACLE gradients;
 * GPU: the five-graph replay trains like eager launches (test_graph_replay.py, mode "segmented")."""
 import argparse
@@ -18,6 +18,20 @@ import torch.multiprocessing as mp
 
 from backend import dev, use_sim  # noqa: F401
 from test_parallel_gloo import _cenet_shard, _free_port
+
+
+# shard seeds per rank.  Ranks 0 / 1 keep test_parallel_gloo's shards; ranks 2 / 3 take seeds whose point is WELL CONDITIONED for the
+# random-filled batch-2 model: the fp32 product and the fp32 oracle agree to < 1 % (relative L2 of the whole gradient) on 500 / 502 /
+# 504 ... 508 / 510 / 511 but differ by 7 % on seed 503 and 11 % on 509 (gradient norm 262 / 48 against 3 ... 30: the chaotic
+# golden-point behaviour DESIGN.md section 4 describes) — a known-answer test must not sit on such a point
+_SHARD_SEEDS = (500, 501, 506, 508)
+
+
+def _shard(rank):
+    if rank < 2:
+        return _cenet_shard(rank)
+    g = torch.Generator().manual_seed(_SHARD_SEEDS[rank])
+    return torch.randn(2, 1, 32, 32, generator=g), torch.randint(0, 4, (2, 32, 32), generator=g).float()
 
 
 def _net(seed=7):
@@ -46,7 +60,8 @@ def _oracle_grads(seed, shard):
     params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
     x, lab = shard
     O.criterion(O.cenet_forward(sd, x, cfg, training=True), lab, 4).backward()
-    return {k: v.grad for k, v in params.items()}, {k: v.detach() for k, v in params.items()}
+    bufs = {k: v.detach().clone() for k, v in sd.items() if "running_" in k}  # (the training forward updated them in place)
+    return {k: v.grad for k, v in params.items()}, {k: v.detach() for k, v in params.items()}, bufs
 
 
 @pytest.mark.gpu
@@ -102,7 +117,7 @@ def _worker(rank, world, port, q):
         red.broadcast_state(net)
         opt = optim.FusedSGD(arena, lr=LR, momentum=0.9, weight_decay=WD, grad_scale=red.grad_scale)
         crit = _crit()
-        x, lab = _cenet_shard(rank)
+        x, lab = _shard(rank)
         started, snaps, final = [], {}, {}
 
         def on_segment(i):
@@ -120,21 +135,28 @@ def _worker(rank, world, port, q):
         loss = step().item()
         from cenet_amd import ops
         assert not ops.wgrad_pending()
-        q.put((rank, loss, arena.params.clone().numpy(), started, {n: arena.index[n] for n in arena.index}, final))
+        bn = {k: v.detach().clone().numpy() for k, v in net.state_dict().items() if k in BN_PROBES}
+        q.put((rank, loss, arena.params.clone().numpy(), started, {n: arena.index[n] for n in arena.index}, final, bn,
+               float(red.grad_scale)))
     finally:
         dist.destroy_process_group()
 
 
 LR, WD = 0.05, 1e-4
+# per-rank BatchNorm statistics (no SyncBN, the reference's DataParallel replicas keep their own): one BatchNorm of
+# every part of the network, compared with the oracle's buffers after a training forward on THAT rank's shard
+BN_PROBES = ("decoder.dec4.norm1.running_mean", "decoder.dec1.norm2.running_var", "decoder.dec2.mca.ccu.bn.running_mean",
+             "decoder.up2.up_dwc.2.running_var", "out.rb.0.norm1.running_mean", "out.out.0.norm2.running_var")
 
 
 @pytest.mark.slow
-def test_two_ranks_segmented_step_takes_the_mean_gradient_step():
-    """2 gloo ranks on the host checker, one SegmentedStep run as eager pieces: the segment callback fires once per arena segment
-    in arena order; after piece k the LOCAL gradient slice of segment k never changes again (it is final when its all-reduce
-    would start); both ranks end with IDENTICAL parameters, and the update equals the first SGD step on the mean of the
-    per-shard ORACLE gradients: p - lr * (mean g + wd * p)."""
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_segmented_step_takes_the_mean_gradient_step(world):
+    """2 and 4 gloo ranks on the host checker, one SegmentedStep run as eager pieces: the segment callback fires once per arena
+    segment in arena order; after piece k the LOCAL gradient slice of segment k never changes again (it is final when its
+    all-reduce would start); every rank ends with IDENTICAL parameters, the gradient scale is 1 / world, the update equals the first
+    SGD step on the mean of the per-shard ORACLE gradients: p - lr * (mean g + wd * p), and each rank's BatchNorm buffers are the
+    oracle's on ITS shard (per-replica statistics)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -145,16 +167,25 @@ def test_two_ranks_segmented_step_takes_the_mean_gradient_step():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    torch.testing.assert_close(torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2]), rtol=0, atol=0)  # lock-step
-    assert res[0][3] == [0, 1, 2, 3, 4] and res[1][3] == [0, 1, 2, 3, 4]
-    assert all(res[0][5].values()) and all(res[1][5].values()), f"a segment changed after its piece: {res[0][5]} {res[1][5]}"
-    g0, p0 = _oracle_grads(7, _cenet_shard(0))
-    g1, _ = _oracle_grads(7, _cenet_shard(1))
+    for r in range(1, world):
+        torch.testing.assert_close(torch.from_numpy(res[0][2]), torch.from_numpy(res[r][2]), rtol=0, atol=0)  # lock-step
+    for r in range(world):
+        assert res[r][3] == [0, 1, 2, 3, 4]
+        assert all(res[r][5].values()), f"rank {r}: a segment changed after its piece: {res[r][5]}"
+        assert abs(res[r][7] - 1.0 / world) < 1e-12
+    orc = [_oracle_grads(7, _shard(r)) for r in range(world)]
+    p0 = orc[0][1]
+    for r in range(world):  # per-rank BatchNorm buffers: the oracle's after a training forward on rank r's shard
+        assert set(res[r][6]) == set(BN_PROBES)
+        for k in BN_PROBES:
+            torch.testing.assert_close(torch.from_numpy(res[r][6][k]), orc[r][2][k], rtol=2e-3, atol=2e-4, msg=f"rank {r} {k}")  # (batch 2 per rank: two-sample statistics)
+    if world > 1:  # (and they DIFFER between ranks: nothing synchronised them)
+        assert not torch.allclose(torch.from_numpy(res[0][6][BN_PROBES[0]]), torch.from_numpy(res[1][6][BN_PROBES[0]]))
     got, index = torch.from_numpy(res[0][2]), res[0][4]
     num = den = 0.0
     for name, (off, n) in index.items():
         p = p0[name].reshape(-1)
-        want = -LR * ((g0[name] + g1[name]).reshape(-1) / world + WD * p)
+        want = -LR * (sum(o[0][name] for o in orc).reshape(-1) / world + WD * p)
         upd = got[off:off + n] - p
         num += float(((upd - want) ** 2).sum())
         den += float((want ** 2).sum())
