@@ -999,6 +999,167 @@ __global__ __launch_bounds__(256, 3) void dw3x3_tok_tile_kernel(DwTileArgs a) {
   }
 }
 
+// ---- bf16 token layout, WHOLE small planes (14 x 14 / 7 x 7: PVTv2 stages 3 / 4, pvtv2.py:364-370 at C = 1280 / 2048) -------------
+// The tile kernel above spends ~60 vector instructions per output element (nine 16-byte tap reads per pixel, every tap converted
+// nine times, a one-pixel-per-pass loop) and at these sizes runs ONE round of workgroups, so nothing hides its set-up: 22 / 31 /
+// 14 us for 8 M elements (forward / activation backward / data gradient) where 56 x 56 x 512 costs 1.6 ps per element.  Here a
+// workgroup owns the plane of one image for a slab of 64 channels — (HW + 2)^2 zero-bordered pixels x 128 B in LDS by LDS-DMA,
+// no halo exchange, no ragged tiles — and a thread owns a channel PAIR of one image row: it slides a three-row window along the
+// row (3 ds_read_b32 + 6 conversions per column for 2 x 9 FMAs per output pixel), keeps the row's outputs in registers and
+// stores 4 bytes per pixel (a half wave writes the 128 contiguous bytes of a pixel's slab).  MODE as above; MODE 2 makes a second
+// sweep over the window for the weight gradient (acc[ky][kx] += gu[x - kx] * h[ky][x]) and folds rows in LDS.
+template <int HW, int MODE, int ACT>
+__global__ __launch_bounds__(HW == 14 ? 448 : 256, HW == 14 ? 4 : 3) void dw3x3_tok_plane_kernel(DwTileArgs a) {
+  constexpr int PW = HW + 2, NPIX = PW * PW, NI = (NPIX + 7) / 8, NT = HW == 14 ? 448 : 256, NW = NT / 64;
+  constexpr bool FLIP = MODE == 1;
+  constexpr int RED = MODE == 2 ? NW * 32 * 20 * 4 : 0;
+  constexpr int LDSB = NI * 1024 > RED ? NI * 1024 : RED;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDSB];
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef CENET_HOSTSIM_BUILD
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int c0 = blockIdx.x * 64;
+  const long img = (long)blockIdx.y * HW * HW * a.C;
+  const int cp = tid & 31, row = tid >> 5;
+  const bool rok = row < HW;
+  const int ch = c0 + 2 * cp;
+  // plane -> LDS: one DMA instruction = 8 pixels x 128 B; border pixels (and the tail past the plane) read the zero block
+  for (int i = wave; i < NI; i += NW) {
+    const int pix = 8 * i + (lane >> 3);
+    const int py = pix / PW, px = pix - py * PW;
+    const bool ok = pix < NPIX && py >= 1 && py <= HW && px >= 1 && px <= HW;
+    const void* src = ok ? (const void*)(a.x + img + ((long)(py - 1) * HW + px - 1) * a.C + c0 + (lane & 7) * 8) : (const void*)ring_zero16;
+    ring_glds16(src, lds + i * 1024, lane);
+  }
+  float wt[2][9], bv[2] = {0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[e][t] = a.w[(long)(ch + e) * 9 + t];
+  if (MODE != 1 && a.bias) bv[0] = a.bias[ch], bv[1] = a.bias[ch + 1];
+  unsigned gq[HW];
+  if (MODE == 2 && rok) {
+#pragma unroll
+    for (int i = 0; i < HW; ++i) gq[i] = *(const unsigned*)(a.g + img + ((long)row * HW + i) * a.C + ch);
+  }
+  ring_wait_vm<0>();
+  __syncthreads();
+  float u[HW][2];
+  float acc[MODE == 2 ? 2 : 1][10];
+  if (MODE == 2) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int t = 0; t < 10; ++t) acc[e][t] = 0.f;
+  }
+  if (rok) {
+    const unsigned char* rp = lds + (row * PW) * 128 + cp * 4;  // window rows row .. row + 2 of the bordered plane
+#pragma unroll
+    for (int i = 0; i < HW; ++i) u[i][0] = bv[0], u[i][1] = bv[1];
+#pragma unroll
+    for (int kxx = 0; kxx < PW; ++kxx) {
+      float h0[3], h1[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const unsigned v = *(const unsigned*)(rp + (ky * PW + kxx) * 128);
+        h0[ky] = __uint_as_float(v << 16);
+        h1[ky] = __uint_as_float(v & 0xFFFF0000u);
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int i = kxx - kx;
+        if (i >= 0 && i < HW) {
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int t = FLIP ? (2 - ky) * 3 + 2 - kx : ky * 3 + kx;
+            u[i][0] += wt[0][t] * h0[ky];
+            u[i][1] += wt[1][t] * h1[ky];
+          }
+        }
+      }
+    }
+    const long oo = img + (long)row * HW * a.C + ch;
+    if (MODE != 2) {
+      if (a.out) {
+#pragma unroll
+        for (int i = 0; i < HW; ++i) *(unsigned*)(a.out + oo + (long)i * a.C) = cenet_pack_bf2(u[i][0], u[i][1]);
+      }
+      if (MODE == 0 && a.out2) {
+#pragma unroll
+        for (int i = 0; i < HW; ++i)
+          *(unsigned*)(a.out2 + oo + (long)i * a.C) =
+              cenet_pack_bf2(dw_act<ACT>(u[i][0], a.act, a.slope), dw_act<ACT>(u[i][1], a.act, a.slope));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < HW; ++i) {
+        u[i][0] = __uint_as_float(gq[i] << 16) * dw_act_grad<ACT>(u[i][0], a.act, a.slope);  // u becomes gu
+        u[i][1] = __uint_as_float(gq[i] & 0xFFFF0000u) * dw_act_grad<ACT>(u[i][1], a.act, a.slope);
+        *(unsigned*)(a.out + oo + (long)i * a.C) = cenet_pack_bf2(u[i][0], u[i][1]);
+        acc[0][9] += u[i][0];
+        acc[1][9] += u[i][1];
+      }
+      // (the window is read from LDS AGAIN: without this fence the compiler keeps all 3 x PW x 2 values of the first sweep in
+      // registers — 218 of them at HW = 14, one workgroup per CU)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int kxx = 0; kxx < PW; ++kxx) {
+        float h0[3], h1[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned v = *(const unsigned*)(rp + (ky * PW + kxx) * 128);
+          h0[ky] = __uint_as_float(v << 16);
+          h1[ky] = __uint_as_float(v & 0xFFFF0000u);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int i = kxx - kx;
+          if (i >= 0 && i < HW) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+              acc[0][ky * 3 + kx] += u[i][0] * h0[ky];
+              acc[1][ky * 3 + kx] += u[i][1] * h1[ky];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 2) {
+    // the two rows of a wave meet by one exchange with lane ^ 32, the waves in LDS (the plane is dead), then one atomic per
+    // (channel, tap) and workgroup — 32 images add to an address
+    float* red = (float*)lds;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int t = 0; t < 10; ++t) {
+        const float v = acc[e][t] + __shfl_xor(acc[e][t], 32);
+        if (lane < 32) red[(wave * 32 + lane) * 20 + e * 10 + t] = v;
+      }
+    __syncthreads();
+    for (int i = tid; i < 32 * 20; i += NT) {
+      float sm = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < NW; ++w_) sm += red[w_ * 640 + i];
+      const int c_ = c0 + 2 * (i / 20) + (i % 20) / 10, t = i % 10;
+      if (t < 9) atomicAdd(&a.dw[c_ * 9 + t], sm);
+      else if (a.db) atomicAdd(&a.db[c_], sm);
+    }
+  }
+}
+
+template <int HW, int MODE>
+static void dw_plane_go(const DwTileArgs& a, int B, hipStream_t stream) {
+  const dim3 grid(a.C / 64, B), block(HW == 14 ? 448 : 256);
+  if (MODE == 1 || a.act == ACT_NONE) CENET_LAUNCH((dw3x3_tok_plane_kernel<HW, MODE, ACT_NONE>), grid, block, stream, a);
+  else if (a.act == ACT_GELU) CENET_LAUNCH((dw3x3_tok_plane_kernel<HW, MODE, ACT_GELU>), grid, block, stream, a);
+  else CENET_LAUNCH((dw3x3_tok_plane_kernel<HW, MODE, -1>), grid, block, stream, a);
+}
+
 template <int MODE>
 static int dw_tile_launch(DwTileArgs a, int B, hipStream_t stream) {
   const int slabs = cdiv(a.C, 128);
@@ -1022,12 +1183,14 @@ static int dw_tile_launch(DwTileArgs a, int B, hipStream_t stream) {
     else                                                                                                         \
       CENET_LAUNCH((dw3x3_tok_tile_kernel<TH_, TW_, MODE, -1>), grid, dim3(256), stream, a);                     \
   }
-  static const char* t14 = getenv("CENET_DW_T14");
-  const int v14 = t14 ? atoi(t14) : 0;
-  if (a.W == 14 && a.H == 14 && v14 == 1) DW_TILE_GO(7, 14)
-  else if (a.W == 14 && a.H == 14 && v14 == 2) DW_TILE_GO(14, 14)
-  else if (a.W == 7 && a.H == 7 && v14 >= 1) DW_TILE_GO(7, 7)
-  else if (a.W % 14 == 0) DW_TILE_GO(8, 14)
+  static const bool plane_off = getenv("CENET_DW_NO_PLANE") != nullptr;  // measurement aid
+  if (!plane_off && a.H == a.W && (a.H == 14 || a.H == 7) && (a.C & 63) == 0 && B <= 65535) {
+    if (a.H == 14) dw_plane_go<14, MODE>(a, B, stream);
+    else dw_plane_go<7, MODE>(a, B, stream);
+    CENET_CHECK_LAUNCH();
+    return CENET_OK;
+  }
+  if (a.W % 14 == 0) DW_TILE_GO(8, 14)
   else if (a.W <= 8 && a.H <= 8) DW_TILE_GO(8, 8)
   else DW_TILE_GO(8, 16)
 #undef DW_TILE_GO

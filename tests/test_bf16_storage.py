@@ -195,7 +195,11 @@ def test_batchnorm(dev, B, C, H, W, act):
 # tiles, two channel slabs with a partial one (C = 136), several tiles per workgroup in the fused backward (28x28)
 @pytest.mark.parametrize("B,C,H,W,act", [(2, 8, 6, 6, "gelu"), (1, 6, 30, 9, "none"), (1, 5, 5, 5, "gelu"),
                                          (2, 16, 7, 7, "gelu"), (1, 136, 14, 14, "gelu"), (1, 8, 11, 19, "gelu"),
-                                         (1, 8, 28, 28, "gelu"), (1, 8, 9, 14, "none")])
+                                         (1, 8, 28, 28, "gelu"), (1, 8, 9, 14, "none"),
+                                         # C % 64 == 0 at 14 x 14 / 7 x 7 (PVT stages 3 / 4): whole-plane kernels, thread = channel
+                                         # pair x image row (dw3x3_tok_plane_kernel: forward, activation backward + weight
+                                         # gradient, data gradient); two slabs, two images
+                                         (2, 128, 14, 14, "gelu"), (2, 64, 7, 7, "gelu"), (1, 192, 14, 14, "none")])
 def test_dwconv_tok(dev, B, C, H, W, act):
     g = G(C + H)
     x = torch.randn(B, H * W, C, generator=g)
