@@ -32,6 +32,16 @@ class CENet(nn.Module):
         opaque.register(self)
 
     def forward(self, x):
+        if getattr(self, "_is_replica", False):
+            # torch.nn.parallel.replicate marks the per-device copies a multi-device nn.DataParallel makes.  Their "parameters" are
+            # Broadcast outputs, not leaves: the kernels here add parameter gradients IN PLACE into param.grad, which would never reach
+            # the wrapped module's parameters — training would silently lose every gradient.  Refuse instead (INTEGRATION.md,
+            # "nn.DataParallel"): one device works through the wrap; N GPUs = one process per GPU + parallel.GradReducer.
+            raise RuntimeError("cenet_amd.CENet was replicated by a multi-device nn.DataParallel (main_acdc.py:178-179). In-process "
+                               "replication is not supported: parameter gradients are accumulated in place and would not flow back "
+                               "through Broadcast. Use nn.DataParallel(net, device_ids=[one device]) (works unchanged) or launch one "
+                               "process per GPU with cenet_amd.parallel.GradReducer (python -m torch.distributed.run ... ; see "
+                               "INTEGRATION.md, 'Data-parallel').")
         if torch.jit.is_tracing() or torch.compiler.is_compiling():
             # Tracing callers — utils/utils.py:171-185 (print_param_flops -> fvcore FlopCountAnalysis = torch.jit.trace, called at
             # main_acdc.py:128) and main_acdc.py:188-191 (torch.compile(net, mode='default', fullgraph=True)) — see the forward as ONE

@@ -133,6 +133,20 @@ def test_fp32_protocol_matches_the_fused_path_and_the_oracle():
         assert (pa[k] - pb[k]).abs().max().item() < 1e-5 + 1e-3 * pb[k].abs().max().item(), k
 
 
+def test_multi_device_dataparallel_replica_is_refused():
+    """main_acdc.py:178-179 with several devices: nn.DataParallel replicates the module per device (torch.nn.parallel.replicate marks
+    every copy `_is_replica`); the copies' parameters are Broadcast outputs, and the in-place gradient accumulation of the HIP path would
+    never reach the wrapped module.  CENet.forward refuses such a replica with a message that names the two supported forms — it does
+    not run on one device silently, and it does not train with lost gradients."""
+    from torch.nn.parallel import replicate  # noqa: F401  (the attribute below is what it sets on every replica)
+    from cenet_amd.networks import CENet
+    net = CENet(**ACDC_ARGS)
+    rep = copy.copy(net)
+    rep._is_replica = True
+    with pytest.raises(RuntimeError, match="multi-device nn.DataParallel.*one process per GPU"):
+        rep(torch.zeros(1, 1, 224, 224))
+
+
 @pytest.mark.gpu
 def test_dataparallel_wrap_and_state_dict_round_trip():
     dev = use_hip()

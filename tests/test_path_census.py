@@ -1,6 +1,6 @@
 """Path census: WHICH kernels a preset's training step takes at its BASELINE batch (bf16 throughput mode, the benched configuration).
 
-The fused fast paths of cenet_amd/ops.py are shape-gated (`pvt_mlp_supported`, `split_dwconv_bn_supported`, the channel-local
+The fused fast paths of cenet_amd/ops/ are shape-gated (`pvt_mlp_supported`, `split_dwconv_bn_supported`, the channel-local
 gates `cfam_front_supported` / `cfam_mid_supported` / `eucb_front_supported` / `pool_branch_supported`, `res_tail_*_supported`,
 `kern.diffattn_heads_supported` ...): a gate that silently stops matching (a refactor, a changed default batch, an alignment
 change) would send a stage back to its launch chain and nothing but the bench would notice.  Here one training step per preset runs
