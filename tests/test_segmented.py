@@ -150,7 +150,7 @@ BN_PROBES = ("decoder.dec4.norm1.running_mean", "decoder.dec1.norm2.running_var"
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("world", [4])  # (world 2 is covered by tests/test_parallel_gloo.py on the same network)
+@pytest.mark.parametrize("world", [2, 4])
 def test_ranks_segmented_step_takes_the_mean_gradient_step(world):
     """2 and 4 gloo ranks on the host checker, one SegmentedStep run as eager pieces: the segment callback fires once per arena
     segment in arena order; after piece k the LOCAL gradient slice of segment k never changes again (it is final when its
