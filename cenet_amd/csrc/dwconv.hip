@@ -1246,6 +1246,107 @@ static int dwconv3x3_tok_impl(const T* x, const float* w, const float* bias, T* 
 CENET_TWIN(dwconv3x3_tok, (const T* x, const float* w, const float* bias, T* y, T* a, int B, int C, int H, int W, int flip,
                            int act, float slope, hipStream_t stream), (x, w, bias, y, a, B, C, H, W, flip, act, slope, stream))
 
+// ---- bf16 NCHW weight gradient, ONE CHANNEL ACROSS IMAGES per workgroup (round 6) ---------------------------------------------------
+// dw3x3_wgrad_nchw_plane_kernel gives every (image, channel) plane its own workgroup: at 28x28x512 / 56x56x256 (the CFAM Mlp of
+// dec2 / dec1) that is 16 384 / 8 192 workgroups whose ~10 us of fixed work — zero-fill + stage + two barriers + ten wave
+// reductions + ten global atomics for 784 x 9 multiply-adds — is the kernel (83 / 51 us for 25 / 51 MB), and 32 images add to every
+// (channel, tap) address.  Here a workgroup owns channel c for a GROUP of images: it walks them in passes of `np` planes (as many
+// as give each thread <= 4 quads), the ten sums stay in registers across the passes, and one reduction + ten atomics end the
+// workgroup: 8x fewer workgroups, 8x fewer atomics, the border of the LDS tile zeroed once.
+template <bool D1>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_nchw_chan_kernel(DwPlaneArgs a, int B, int ipg, int np) {
+  __shared__ float tile[DWP_MAX];
+  __shared__ float red[4][10];
+  const int c = blockIdx.x, b_begin = blockIdx.y * ipg;
+  const int b_end = b_begin + ipg < B ? b_begin + ipg : B;
+  const int HW = a.H * a.W, nq = HW >> 2, d = D1 ? 1 : a.dil;
+  const int PWd = a.W + 2 * d, PS = (a.H + 2 * d) * PWd;
+  const float invW = 1.f / (float)a.W, invnq = 1.f / (float)nq;
+  int toff[4], pl[4];
+  long go[4];
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    ok[k] = i < np * nq;
+    const int ii = ok[k] ? i : 0;
+    pl[k] = np == 1 ? 0 : (int)(((float)ii + 0.5f) * invnq);
+    const int q = ii - pl[k] * nq;
+    const int py = (int)(((float)(4 * q) + 0.5f) * invW), px = 4 * q - py * a.W;  // (W % 4 == 0: a quad never straddles a row)
+    go[k] = (long)c * HW + 4 * q;
+    toff[k] = pl[k] * PS + (py + d) * PWd + px + d;
+  }
+  for (int i = threadIdx.x; i < np * PS; i += 256) tile[i] = 0.f;  // (the borders stay zero: every pass rewrites the interiors)
+  float acc[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+  // the NEXT pass's loads are issued before the current pass is computed (bf16 quads kept packed: 16 registers per pass)
+  uint2 gq[4], xq[4], gn[4], xn[4];
+  auto fetch = [&](int b0, uint2* gd, uint2* xd) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // every load of the pass in flight together, on clamped addresses
+      const int bi = b0 + pl[k];
+      const int bc = bi < b_end ? bi : b_end - 1;
+      gd[k] = *(const uint2*)(a.dy + (long)bc * a.sgb + go[k]);
+      xd[k] = *(const uint2*)(a.x + (long)bc * a.sxb + go[k]);
+    }
+  };
+  fetch(b_begin, gn, xn);
+  for (int b0 = b_begin; b0 < b_end; b0 += np) {
+    float g[4][4];
+    bool val[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gq[k] = gn[k];
+      xq[k] = xn[k];
+      val[k] = ok[k] && b0 + pl[k] < b_end;
+    }
+    __syncthreads();  // the zero fill (first pass) / every thread is done reading the previous pass's planes
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ok[k]) {
+        tile[toff[k] + 0] = val[k] ? __uint_as_float(xq[k].x << 16) : 0.f;
+        tile[toff[k] + 1] = val[k] ? __uint_as_float(xq[k].x & 0xFFFF0000u) : 0.f;
+        tile[toff[k] + 2] = val[k] ? __uint_as_float(xq[k].y << 16) : 0.f;
+        tile[toff[k] + 3] = val[k] ? __uint_as_float(xq[k].y & 0xFFFF0000u) : 0.f;
+      }
+    if (b0 + np < b_end) fetch(b0 + np, gn, xn);  // (workgroup-uniform)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g[k][0] = __uint_as_float(gq[k].x << 16), g[k][1] = __uint_as_float(gq[k].x & 0xFFFF0000u);
+      g[k][2] = __uint_as_float(gq[k].y << 16), g[k][3] = __uint_as_float(gq[k].y & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!val[k]) continue;
+      const float* t0 = tile + toff[k] - d * PWd - d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[9] += g[k][e];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float* tp = t0 + ky * d * PWd + kx * d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[ky * 3 + kx] += g[k][e] * tp[e];
+        }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    const float sm = wave_sum(acc[t]);
+    if (lane == 0) red[wave][t] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    const float sm = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 9) atomicAdd(&a.dw[c * 9 + threadIdx.x], sm);
+    else if (a.db) atomicAdd(&a.db[c], sm);
+  }
+}
+
 template <typename T>
 static int dwconv3x3_wgrad_nchw_acc_impl(const T* x, long sxb, const T* dy, long sgb, float* dw_acc, float* dbias_acc, int B,
                                          int C, int H, int W, int dil, hipStream_t stream) {
@@ -1258,6 +1359,23 @@ static int dwconv3x3_wgrad_nchw_acc_impl(const T* x, long sxb, const T* dy, long
       p.x = (const bf16_t*)x; p.sxb = sxb; p.w = nullptr; p.bias = nullptr; p.y = p.a = nullptr; p.syb = p.sab = 0;
       p.dy = (const bf16_t*)dy; p.sgb = sgb; p.dw = dw_acc; p.db = dbias_acc;
       p.BC = B * C; p.C = C; p.H = H; p.W = W; p.dil = dil; p.flip = 0; p.act = 0; p.ppw = ppw; p.slope = 0.f;
+      // one channel across a group of images per workgroup where a plane is at most 1024 quads of whole rows and the batch is deep
+      // enough to share a workgroup: ~1 000 - 2 000 workgroups
+      static const bool chan_off = getenv("CENET_DW_WGRAD_NO_CHAN") != nullptr;  // measurement aid
+      const int nq = (H * W) >> 2, ps = (H + 2 * dil) * (W + 2 * dil);
+      if (!chan_off && (W & 3) == 0 && nq <= 1024 && B >= 4 && C <= 65535) {
+        int np = 1024 / nq;
+        if (np > DWP_MAX / ps) np = DWP_MAX / ps;
+        if (np > B) np = B;
+        int ng = 2048 / C;  // image groups
+        if (ng < 1) ng = 1;
+        if (ng > cdiv(B, np)) ng = cdiv(B, np);
+        const int ipg = cdiv(cdiv(B, ng), np) * np;  // whole passes per group
+        if (dil == 1) CENET_LAUNCH(dw3x3_wgrad_nchw_chan_kernel<true>, dim3(C, cdiv(B, ipg)), dim3(256), stream, p, B, ipg, np);
+        else CENET_LAUNCH(dw3x3_wgrad_nchw_chan_kernel<false>, dim3(C, cdiv(B, ipg)), dim3(256), stream, p, B, ipg, np);
+        CENET_CHECK_LAUNCH();
+        return CENET_OK;
+      }
       CENET_LAUNCH(dw3x3_wgrad_nchw_plane_kernel, dim3(cdiv(B * C, ppw)), dim3(256), stream, p);
       CENET_CHECK_LAUNCH();
       return CENET_OK;

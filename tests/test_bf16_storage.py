@@ -212,7 +212,12 @@ def test_dwconv_tok(dev, B, C, H, W, act):
 @pytest.mark.parametrize("B,C,H,W,dil,act", [(2, 3, 8, 8, 1, "gelu"), (1, 2, 12, 12, 2, "none"), (2, 3, 7, 7, 3, "none"),
                                              (2, 5, 14, 14, 1, "gelu"), (1, 3, 20, 28, 5, "none"), (2, 70, 8, 8, 2, "none"),
                                              # one plane per workgroup (owned quads; the weight gradient's workgroup reduction)
-                                             (1, 2, 48, 48, 1, "gelu"), (2, 2, 56, 56, 2, "none"), (1, 3, 56, 56, 1, "none")])
+                                             (1, 2, 48, 48, 1, "gelu"), (2, 2, 56, 56, 2, "none"), (1, 3, 56, 56, 1, "none"),
+                                             # batch >= 4 with W % 4 == 0: the weight gradient takes ONE CHANNEL ACROSS IMAGES per
+                                             # workgroup (dw3x3_wgrad_nchw_chan_kernel): one pass of 5 planes; passes of 5 + 4
+                                             # planes (28 x 28); one plane per pass over 4 images (56 x 56); dilation 2
+                                             (5, 6, 8, 8, 1, "gelu"), (9, 3, 28, 28, 1, "none"), (4, 2, 56, 56, 1, "none"),
+                                             (6, 4, 12, 12, 2, "none")])
 def test_dwconv_nchw(dev, B, C, H, W, dil, act):
     g = G(C + H + dil)
     x = torch.randn(B, C, H, W, generator=g)
