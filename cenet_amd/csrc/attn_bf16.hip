@@ -42,12 +42,7 @@ struct AttnArgsB {
   float scale;
 };
 
-#ifdef CENET_HOSTSIM_BUILD
-__device__ __forceinline__ float fast_exp2(float x) { return exp2f(x); }
-#else
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-#endif
-
+// (fast_exp2: common.h)
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
   unsigned u[4] = {cenet_pack_bf2(v[0], v[1]), cenet_pack_bf2(v[2], v[3]), cenet_pack_bf2(v[4], v[5]),
                    cenet_pack_bf2(v[6], v[7])};

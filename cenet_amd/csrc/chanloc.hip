@@ -919,23 +919,12 @@ struct DwActArgs {
 // hardware exponential and reciprocal, as the tiled depthwise kernels of dwconv.hip use; the fp32 (parity) instances keep libm's erff.
 template <typename T>
 __device__ __forceinline__ float dwact_f(int act, float u, float slope) {
-  if (sizeof(T) == 2 && act == ACT_GELU) {
-    const float ax = fabsf(u) * 0.70710678118654752f;
-    const float t = fast_rcp(1.f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    return 0.5f * u * (1.f + copysignf(1.f - poly * fast_exp(-0.5f * u * u), u));
-  }
+  if (sizeof(T) == 2 && act == ACT_GELU) return gelu_as(u);
   return act_fwd(act, u, slope);
 }
 template <typename T>
 __device__ __forceinline__ float dwact_g(int act, float u, float slope) {
-  if (sizeof(T) == 2 && act == ACT_GELU) {  // Phi(u) + u phi(u): one exponential serves both terms
-    const float ax = fabsf(u) * 0.70710678118654752f;
-    const float t = fast_rcp(1.f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = fast_exp(-0.5f * u * u);
-    return 0.5f * (1.f + copysignf(1.f - poly * e, u)) + u * 0.3989422804014327f * e;
-  }
+  if (sizeof(T) == 2 && act == ACT_GELU) return gelu_as_grad(u);  // Phi(u) + u phi(u): one exponential serves both terms
   return act_bwd(act, u, slope);
 }
 

@@ -343,6 +343,38 @@ __device__ __forceinline__ float fast_log(float x) { return __logf(x); }        
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32 (1 ulp)
 #endif
 
+#ifdef CENET_HOSTSIM_BUILD
+__device__ __forceinline__ float fast_exp2(float x) { return exp2f(x); }
+#else
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+#endif
+
+// GELU / GELU' of the bf16 (throughput) kernels, erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp), in the
+// FEWEST vector instructions — the kernels that call them (csrc/pvt_mlp.hip P2, the depthwise tile / plane kernels, the channel-local
+// DW + GELU chains) are bound by vector-instruction issue:
+//   h(u) = 1/2 poly(t) exp(-u^2 / 2), t = 1 / (1 + p |u| / sqrt 2)   (= (1 - erf(|u| / sqrt 2)) / 2 = Phi(-|u|))
+//   GELU(u)  = u Phi(u) = max(u, 0) - |u| h          (u >= 0: u - u h;  u < 0: u h — no sign transfer, no 0.5 u (1 + erf) chain)
+//   GELU'(u) = Phi(u) + u phi(u),  Phi(u) = u >= 0 ? 1 - h : h,  phi(u) = exp(-u^2 / 2) / sqrt(2 pi): ONE exponential serves both
+// 11 full-rate instructions + v_rcp_f32 + v_exp_f32 for GELU (was 15 + 2, and an IEEE division — ten instructions — in dwconv.hip).
+// The fp32 (parity) kernels keep libm's erff (gelu_f / gelu_grad_f below).
+__device__ __forceinline__ float gelu_as_h(float au, float e) {  // au = |u|, e = exp(-u^2 / 2)
+  const float t = fast_rcp(fmaf(au, 0.3275911f * 0.70710678118654752f, 1.f));
+  const float ph = t * (0.5f * 0.254829592f + t * (0.5f * -0.284496736f + t * (0.5f * 1.421413741f +
+                   t * (0.5f * -1.453152027f + t * (0.5f * 1.061405429f)))));
+  return ph * e;
+}
+__device__ __forceinline__ float gelu_as(float u) {
+  const float au = fabsf(u);
+  const float h = gelu_as_h(au, fast_exp2(u * u * (-0.5f * 1.4426950408889634f)));
+  return fmaf(-au, h, fmaxf(u, 0.f));
+}
+__device__ __forceinline__ float gelu_as_grad(float u) {
+  const float au = fabsf(u);
+  const float e = fast_exp2(u * u * (-0.5f * 1.4426950408889634f));
+  const float h = gelu_as_h(au, e);
+  return fmaf(u * 0.3989422804014327f, e, u >= 0.f ? 1.f - h : h);
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));

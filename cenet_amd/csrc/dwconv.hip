@@ -295,33 +295,20 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_tok_v4_kernel(const T* __rest
   }
 }
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): the tile kernels are VALU-bound, and libm's
-// erff + expf cost more than the nine taps.  Only the bf16 kernels use it; the fp32 (parity) kernels keep erff.
-__device__ __forceinline__ float dw_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = 1.f / (1.f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.f - poly * fast_exp(-ax * ax);
-  return copysignf(r, x);
-}
+// GELU / GELU' of the bf16 kernels: common.h's gelu_as / gelu_as_grad (Abramowitz & Stegun 7.1.26 erf, |error| <= 1.5e-7, far below a
+// bf16 ulp, hardware reciprocal and exponential): the tile / plane kernels are VALU-bound, and libm's erff + expf cost more than the
+// nine taps (round 6: the previous form here divided in IEEE arithmetic — ten instructions — and carried the 0.5 u (1 + erf) chain).
+// Only the bf16 kernels use it; the fp32 (parity) kernels keep erff.
 template <int ACT>
 __device__ __forceinline__ float dw_act(float u, int act, float slope) {
   if (ACT == ACT_NONE) return u;
-  if (ACT == ACT_GELU) return 0.5f * u * (1.f + dw_erf(u * 0.70710678118654752f));
+  if (ACT == ACT_GELU) return gelu_as(u);
   return act_fwd(act, u, slope);
 }
 template <int ACT>
 __device__ __forceinline__ float dw_act_grad(float u, int act, float slope) {
   if (ACT == ACT_NONE) return 1.f;
-  if (ACT == ACT_GELU) {
-    // Phi(u) + u phi(u): the exponential inside erf(u / sqrt 2) IS exp(-u^2 / 2) — one v_exp_f32 for both terms
-    const float ax = fabsf(u) * 0.70710678118654752f;
-    const float t = 1.f / (1.f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = fast_exp(-0.5f * u * u);
-    const float erfv = copysignf(1.f - poly * e, u);
-    return 0.5f * (1.f + erfv) + u * 0.3989422804014327f * e;
-  }
+  if (ACT == ACT_GELU) return gelu_as_grad(u);
   return act_bwd(act, u, slope);
 }
 

@@ -56,14 +56,8 @@ __device__ __forceinline__ float pvt_rcp(float x) {
   return __builtin_amdgcn_rcpf(x);
 #endif
 }
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, as in dwconv.hip's tiled kernels)
-__device__ __forceinline__ float pvt_gelu(float u) {
-  const float ax = fabsf(u) * 0.70710678118654752f;
-  const float t = pvt_rcp(1.f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.f - poly * fast_exp(-ax * ax);
-  return 0.5f * u * (1.f + copysignf(r, u));
-}
+// GELU by common.h's gelu_as (Abramowitz & Stegun 7.1.26 erf, |error| <= 1.5e-7, in the fewest vector instructions)
+__device__ __forceinline__ float pvt_gelu(float u) { return gelu_as(u); }
 template <int LPT>
 __device__ __forceinline__ float pvt_subrow_sum(float v) {
 #pragma unroll
@@ -340,14 +334,7 @@ __global__ __launch_bounds__(512, 2) void pvt_mlp_fwd_kernel(PvtMlpArgs a) {
 //   K2  dh = DW3x3^T(gu) -> HBM (operand of the fc1 weight gradient);  dxn += dh . W1_slab over the slabs (registers);
 //       dx = g + LayerNormBackward(dxn)                        workgroup = tile, slabs walked inside
 // ============================================================================================================================
-__device__ __forceinline__ float pvt_gelu_grad(float u) {
-  const float ax = fabsf(u) * 0.70710678118654752f;
-  const float t = pvt_rcp(1.f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = fast_exp(-0.5f * u * u);
-  const float cdf = 0.5f * (1.f + copysignf(1.f - poly * e, u));
-  return cdf + u * 0.3989422804014327f * e;
-}
+__device__ __forceinline__ float pvt_gelu_grad(float u) { return gelu_as_grad(u); }
 
 struct PvtBwdArgs {
   const bf16_t* g;       // [B, N, C]  gradient of the block output y
