@@ -835,13 +835,31 @@ extern "C" int cenet_pvt_mlp_bwd_bf16(const bf16_t* g, const float* bscale, cons
     if (a.tpw < 1) a.tpw = 1;
     if (a.tpw > a.tiles_per_img) a.tpw = a.tiles_per_img;
   }
-  const dim3 g1(HD / 64, cdiv(a.tiles_per_img, a.tpw), B), g2(B * a.tiles_per_img);
+  // K1 and K2 meet only through gu [B, N, HD] (token-indexed) and are tiled INDEPENDENTLY: K2 (workgroup = tile, the LayerNorm
+  // partials in ws are per K2 tile) keeps the forward's tile; K1 (workgroup = slab x run of tiles x image) takes 4-row tiles where
+  // they divide the map — more, shorter runs: 94 -> 75 us at 28 x 28 (the forward kernel with 4-row tiles is SLOWER: 90 -> 116 us,
+  // its depthwise phase then fills half the threads)
+  static const char* k1e = getenv("CENET_PVT_K1_TH");  // measurement aid: 0 = K1 on the forward's tile
+  const int k1th = (k1e ? atoi(k1e) : 4) == 4 && TH == 7 && H % 4 == 0 ? 4 : TH;  // (at 56 x 56 the 8-row tile wins: 97 vs 126 us)
+  PvtBwdArgs a1 = a;
+  a1.tiles_per_img = a.tiles_x * (H / k1th);
+  a1.tpw = a1.tiles_per_img >= 16 ? 4 : 2;
+  {
+    static const char* e = getenv("CENET_PVT_TPW");
+    if (e) a1.tpw = atoi(e);
+    if (a1.tpw < 1) a1.tpw = 1;
+    if (a1.tpw > a1.tiles_per_img) a1.tpw = a1.tiles_per_img;
+  }
+  const dim3 g1(HD / 64, cdiv(a1.tiles_per_img, a1.tpw), B), g2(B * a.tiles_per_img);
   if (g1.y > 65535 || g1.z > 65535) return CENET_EUNSUPPORTED;
   static const char* only_e = getenv("CENET_PVT_ONLY");  // measurement aid: 1 / 2 = launch only that kernel
   const int only = only_e ? atoi(only_e) : 0;
 #define PVT_BWD_GO(C_, TH_)                                                                              \
   if (C == C_ && TH == TH_) {                                                                             \
-    if (only != 2) CENET_LAUNCH((pvt_mlp_bwd1_kernel<C_, TH_, 14>), g1, dim3(512), stream, a);            \
+    if (only != 2) {                                                                                      \
+      if (k1th == 4) CENET_LAUNCH((pvt_mlp_bwd1_kernel<C_, 4, 14>), g1, dim3(512), stream, a1);           \
+      else CENET_LAUNCH((pvt_mlp_bwd1_kernel<C_, TH_, 14>), g1, dim3(512), stream, a1);                   \
+    }                                                                                                     \
     if (only != 1) CENET_LAUNCH((pvt_mlp_bwd2_kernel<C_, TH_, 14>), g2, dim3(512), stream, a);            \
   } else
   PVT_BWD_GO(64, 8)
